@@ -1,0 +1,214 @@
+/*
+ * sedumi_hip.h -- C ABI of libsedumi_hip.so, the MI355X (gfx950) implementation
+ * of SeDuMi's per-iteration normal-equations hot path.
+ *
+ * Two tiers:
+ *
+ *  (1) MEX-equivalent entry points  sdm_<mexname>(...)
+ *      One function per reference MEX gateway on the hot path.  Arguments are
+ *      plain pointers / sizes carrying exactly what the gateway unpacks from
+ *      its mxArray inputs (CSC triples with 0-based int64 indices, doubles);
+ *      outputs are written into caller-allocated host buffers.  These are what
+ *      a mexFunction shim (sedumi_amd/mex/) or any other
+ *      FFI binds; sedumi.m stays unchanged.
+ *
+ *  (2) Resident "plan" API  sdm_plan_*
+ *      The same kernels with problem data, ADA', the factor and work vectors
+ *      kept in HBM across the 4-6 calls of an IPM iteration,
+ *      used by bench.py and by a MATLAB-free driver.
+ *
+ * Conventions: all indices 0-based int64 (sdm_int) unless stated; sparse
+ * matrices are CSC (jc[n+1], ir[nnz], pr[nnz]); every function returns 0 on
+ * success, non-zero on error (sdm_last_error() gives the message).  There is
+ * NO CPU fallback: without a usable HIP device every compute entry fails.
+ *
+ * Reference citations are relative to the SeDuMi 1.3.7 tree (/root/reference).
+ */
+#ifndef SEDUMI_HIP_H
+#define SEDUMI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int64_t sdm_int;
+
+/* ----------------------------------------------------------------- general */
+const char *sdm_last_error(void);
+/* "hip-gfx950" for the product library ("emu" for the tests/hipemu build). */
+const char *sdm_backend(void);
+int sdm_device_count(void);
+int sdm_set_device(int dev);
+
+/* Cholesky pivot parameters: pars.chol of checkpars.m:144-168 as read by the
+ * blkchol gateway (blkchol.c:289-311). */
+typedef struct {
+  double canceltol; /* 1e-12 */
+  double maxu;      /* 5e5 (gateway default 5e2 when pars omitted) */
+  double abstol;    /* 1e-20 */
+} sdm_cholpars;
+
+/* Cone description: what conepars (sdmauxCone.c:48-134) and the getada
+ * gateways read from K after pretransfo (pretransfo.m:531-542). */
+typedef struct {
+  sdm_int lpN;             /* K.l (includes the artificial x0 row)            */
+  sdm_int lorN;            /* length(K.q)                                     */
+  const sdm_int *lorNL;    /* K.q, length lorN                                */
+  sdm_int sdpN;            /* length(K.s)                                     */
+  sdm_int rsdpN;           /* K.rsdpN: first rsdpN PSD blocks real symmetric  */
+  const sdm_int *sdpNL;    /* K.s, length sdpN                                */
+} sdm_cone;
+
+/* ================================================================ tier (1) */
+
+/* --- symbolic (host, integer; bit-exact with the reference) --------------- */
+
+/* perm = ordmmdmex(X)            ordmmdmex.c:75-139 -> ordmmd.c:51 (GENMMD)
+ * X m x m symmetric pattern incl. diagonal.  perm[m] out, 0-based. */
+int sdm_ordmmd(sdm_int m, const sdm_int *Xjc, const sdm_int *Xir, sdm_int *perm);
+
+/* L = symfctmex(X, perm)         symfctmex.c:127-272 -> symfct.c sfinit_/symfct_
+ * Two-call protocol: first call with Ljc=Lir=NULL returns *nsuper and *nnzl;
+ * second call fills perm_out[m] (post-ordered), xsuper[nsuper+1], Ljc[m+1],
+ * Lir[nnzl] (every column carries its full sorted row list, diagonal first). */
+int sdm_symfct(sdm_int m, const sdm_int *Xjc, const sdm_int *Xir, const sdm_int *perm_in,
+               sdm_int *perm_out, sdm_int *nsuper, sdm_int *xsuper, sdm_int *nnzl,
+               sdm_int *Ljc, sdm_int *Lir);
+
+/* tmpsiz = choltmpsiz(L)         choltmpsiz.c:57-101 */
+int sdm_choltmpsiz(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, sdm_int nsuper,
+                   const sdm_int *xsuper, sdm_int *tmpsiz);
+/* split = cholsplit(L, cachsz)   cholsplit.c:59-111 (split[m] out) */
+int sdm_cholsplit(sdm_int m, const sdm_int *Ljc, sdm_int nsuper, const sdm_int *xsuper,
+                  sdm_int cachsz, sdm_int *split);
+
+/* --- ADA' ------------------------------------------------------------------ */
+
+/* ADA = getada1(ADA, A, Ajc2, perm, d, blkstart)        getada1.c:161-261
+ * ADApr[nnz(ADA)] out: values on triu(ADA(perm,perm)) at original positions,
+ * zero elsewhere.  Ajc2[m] = absolute offset (into Air/Apr) one past the last
+ * LP/Lorentz nonzero of each column (= Ablkjc(:,3)); dl[lpN], ddet[lorN];
+ * qblkstart[lorN+1] = 0-based K.qblkstart. */
+int sdm_getada1(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir,
+                sdm_int N, const sdm_int *Ajc, const sdm_int *Air, const double *Apr,
+                const sdm_int *Ajc2, const sdm_int *perm,
+                sdm_int lpN, const double *dl, sdm_int lorN, const double *ddet,
+                const sdm_int *qblkstart, double *ADApr);
+
+/* ADA = getada2(ADA, DAt, Aord, K)                      getada2.c:127-214
+ * ADApr in/out (copy of the input values updated on triu(ADA(qperm,qperm))).
+ * DAt.q is lorN x m CSC. */
+int sdm_getada2(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, double *ADApr,
+                sdm_int lorN, const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr,
+                const sdm_int *qperm);
+
+/* [ADA,absd] = getada3(ADA, A, Ajc1, Aord, udsqr, K)    getada3.c:370-569
+ * ADApr in/out (symmetric on return), absd[m] out.  Ajc1[m] = absolute offset
+ * of the first PSD nonzero of each column; sperm = Aord.sperm (only its
+ * triangular bookkeeping is reproduced -- the result is order independent);
+ * udsqr = concatenated full D_k (Hermitian blocks as [Re;Im]); psd_blkstart
+ * [sdpN+1] = 0-based row offsets of the PSD blocks in At (K.sblkstart-1). */
+int sdm_getada3(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, double *ADApr,
+                sdm_int N, const sdm_int *Ajc, const sdm_int *Air, const double *Apr,
+                const sdm_int *Ajc1, const sdm_int *sperm, const double *udsqr,
+                const sdm_cone *K, const sdm_int *psd_blkstart, double *absd);
+
+/* --- numeric factor / solves ---------------------------------------------- */
+
+/* [L.L,L.d,L.skip,L.add] = blkchol(L, X, pars, absd)    blkchol.c:239-440
+ * In: symbolic L (Ljc,Lir,perm,xsuper), X = ADA (full symmetric CSC), absd[m]
+ * or NULL (then diag(X(perm,perm)) is used, blkchol.c:376-381).
+ * Out: Lpr[nnz(L)], d[m], skip/add as (count, idx[m], val[m]) sorted by index
+ * -- exactly the sparse m x 1 outputs of the gateway. */
+int sdm_blkchol(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm,
+                sdm_int nsuper, const sdm_int *xsuper,
+                const sdm_int *Xjc, const sdm_int *Xir, const double *Xpr,
+                const sdm_cholpars *pars, const double *absd,
+                double *Lpr, double *d,
+                sdm_int *nskip, sdm_int *skip_idx, double *skip_val,
+                sdm_int *nadd, sdm_int *add_idx, double *add_val);
+
+/* y = fwblkslv(L, b)     dense b (m x nrhs, column major)   fwblkslv.c:193-320
+ * y = L.L \ b(L.perm,:) */
+int sdm_fwblkslv(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const double *Lpr,
+                 const sdm_int *perm, sdm_int nsuper, const sdm_int *xsuper,
+                 sdm_int nrhs, const double *b, double *y);
+/* y = bwblkslv(L, b)     y(L.perm,:) = L.L' \ b              bwblkslv.c:182-298 */
+int sdm_bwblkslv(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const double *Lpr,
+                 const sdm_int *perm, sdm_int nsuper, const sdm_int *xsuper,
+                 sdm_int nrhs, const double *b, double *y);
+/* sparse-RHS variants: y = fwblkslv(L,b,ysymb) / bwblkslv(L,b,ysymb)
+ * (fwblkslv.c:305-317 selfwsolve, bwblkslv.c:279-291 selbwsolve).  b is m x n
+ * CSC, the pattern of y (Yjc,Yir) comes from symbfwblk; Ypr[nnz(Y)] out.
+ * use_perm: 1 for the forward variant (b is mapped through invperm), 0 for the
+ * backward variant (no permutation, as the reference). */
+int sdm_fwblkslv_sparse(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const double *Lpr,
+                        const sdm_int *perm, sdm_int nsuper, const sdm_int *xsuper,
+                        sdm_int n, const sdm_int *Bjc, const sdm_int *Bir, const double *Bpr,
+                        const sdm_int *Yjc, const sdm_int *Yir, double *Ypr);
+int sdm_bwblkslv_sparse(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const double *Lpr,
+                        sdm_int nsuper, const sdm_int *xsuper,
+                        sdm_int n, const sdm_int *Bjc, const sdm_int *Bir, const double *Bpr,
+                        const sdm_int *Yjc, const sdm_int *Yir, double *Ypr);
+
+/* ================================================================ tier (2) */
+typedef struct sdm_plan sdm_plan;
+
+/* Create a plan on `device` (HIP ordinal).  stream: a hipStream_t passed as
+ * void* (NULL = the plan creates its own).  All numeric plan calls are
+ * stream-ordered and asynchronous unless they return host data. */
+sdm_plan *sdm_plan_create(int device, void *stream);
+void sdm_plan_destroy(sdm_plan *p);
+int sdm_plan_sync(sdm_plan *p);
+
+/* Symbolic factor + ADA pattern (uploaded once per solve). */
+int sdm_plan_set_chol(sdm_plan *p, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir,
+                      const sdm_int *perm, sdm_int nsuper, const sdm_int *xsuper,
+                      const sdm_int *ADAjc, const sdm_int *ADAir);
+
+/* Problem data for ADA' (uploaded once per solve): At with its LP/Lorentz |
+ * PSD split (Ajc_psd[m] = absolute offset of the first PSD nonzero of each
+ * column), cone, 0-based qblkstart[lorN+1] and psd_blkstart[sdpN+1], and the
+ * (fixed) pattern of DAt.q (lorN x m). */
+int sdm_plan_set_ada(sdm_plan *p, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_int *Air,
+                     const double *Apr, const sdm_int *Ajc_psd, const sdm_cone *K,
+                     const sdm_int *qblkstart, const sdm_int *psd_blkstart,
+                     const sdm_int *Qjc, const sdm_int *Qir);
+
+/* Device buffers owned by the plan (for callers that fill them from torch /
+ * other HIP code without a host round trip).  name is one of
+ * "ada","absd","d","y","rhs","udsqr","dl","ddet","qpr","lpr". */
+void *sdm_plan_devptr(sdm_plan *p, const char *name, sdm_int *nelem);
+/* Host <-> plan buffer copies (synchronous). */
+int sdm_plan_upload(sdm_plan *p, const char *name, const double *src, sdm_int nelem);
+int sdm_plan_download(sdm_plan *p, const char *name, double *dst, sdm_int nelem);
+
+/* ADA' = getada1+getada2+getada3 fused (sedumi.m:450-452) from the resident
+ * scaling buffers dl, ddet, qpr (values of DAt.q), udsqr.  Result in "ada"
+ * (values in ADA pattern order, symmetric) and "absd". */
+int sdm_plan_getada(sdm_plan *p);
+/* blkchol (sedumi.m:458) on the resident "ada"/"absd".  use_absd=0 takes
+ * diag(ADA(perm,perm)) as in blkchol.c:380-381. */
+int sdm_plan_blkchol(sdm_plan *p, const sdm_cholpars *pars, int use_absd);
+/* pivot report of the last factor: counts (host, synchronises) and lists. */
+int sdm_plan_pivots(sdm_plan *p, sdm_int *nskip, sdm_int *skip_idx, double *skip_val,
+                    sdm_int *nadd, sdm_int *add_idx, double *add_val);
+/* Solves on the resident factor: "y" <- op("rhs").
+ *  fw:  y = L \ rhs(perm)         bw:  y(perm) = L' \ rhs
+ *  ldl: y(perm) = L' \ ( (L \ rhs(perm)) ./ d )   (wrapPcg.m:56-59, no dense cols) */
+int sdm_plan_fwsolve(sdm_plan *p);
+int sdm_plan_bwsolve(sdm_plan *p);
+int sdm_plan_ldlsolve(sdm_plan *p);
+
+/* Timing of named kernels with HIP events on the plan's stream (bench.py):
+ * begin/end bracket a region; *_ms returns the elapsed milliseconds. */
+int sdm_plan_timer_begin(sdm_plan *p, int slot);
+int sdm_plan_timer_end(sdm_plan *p, int slot);
+int sdm_plan_timer_ms(sdm_plan *p, int slot, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEDUMI_HIP_H */

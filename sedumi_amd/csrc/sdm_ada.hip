@@ -1,0 +1,392 @@
+// sdm_ada.hip -- forming the normal-equations matrix ADA' on gfx950.
+//
+// Reference (getada1.c:89-152, getada2.c:74-118, getada3.c:253-361 with
+// spscale.c:249-305 sprealdxd): a sequential sweep over constraints in three
+// different "sparsest first" orders; for the PSD part D*A_j*D is evaluated
+// only on an incrementally growing pattern (Aord.dz) and each routine fills
+// one triangle, getada3 finally symmetrising (spmakesym, getada3.c:151-180).
+//
+// Here the same numbers are produced data-parallel:
+//   * LP / Lorentz parts: one workgroup per ADA column, one wavefront per
+//     pattern entry, sparse-sparse dot by binary search (no dense scratch).
+//   * PSD part, stage 1: one workgroup per (constraint j, PSD block k) task
+//     computes z_jk = (D_k sym(A_jk) D_k) restricted to U_k, the union pattern
+//     of block k over all constraints (what Aord.dz enumerates incrementally):
+//     Y = D*X(:,cols) is staged in LDS, targets are evaluated with the same
+//     two-dot formula as spscale.c:283-304.
+//   * PSD part, stage 2: one workgroup per ADA column gathers
+//     ADA(i,j) += a_i[psd]' z_j  for every pattern entry (getada3.c:333-351),
+//     absd fused on the diagonal entry.
+// The triangular bookkeeping of the reference (which triangle each routine
+// writes) is reproduced for the stand-alone MEX-equivalent calls through an
+// inverse-permutation mask; the fused resident path writes the symmetric
+// matrix directly.
+#include "sdm_plan.h"
+#include <algorithm>
+#include <cmath>
+
+namespace sdm {
+
+// ============================================================ host analysis
+void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_int *Air, const double *Apr,
+               const sdm_int *Ajc_psd, sdm_int lpN, sdm_int lorN, const sdm_int *lorNL, sdm_int sdpN,
+               sdm_int rsdpN, const sdm_int *sdpNL, const sdm_int *qblkstart, const sdm_int *psd_blkstart,
+               const sdm_int *Qjc, const sdm_int *Qir, const sdm_int *ADAjc, const sdm_int *ADAir) {
+  AdaPlan &A = P->ada;
+  A.N = N; A.m = m; A.nnzA = Ajc[m]; A.lpN = lpN; A.lorN = lorN; A.sdpN = sdpN; A.rsdpN = rsdpN;
+  if (A.nnzA >= (sdm_int)1 << 31 || N >= (sdm_int)1 << 31) throw std::runtime_error("At too large for 32-bit row indices");
+  (void)lorNL;
+  A.nlq = sdpN > 0 ? psd_blkstart[0] : N;
+  if (lorN > 0 && qblkstart[lorN] != A.nlq && sdpN > 0) throw std::runtime_error("qblkstart / psd_blkstart mismatch");
+  // ---- dsqr source codes (getada1.c:106-118): -1 -> dl[r];  -2-k -> -ddet[k];  k>=0 -> ddet[k]
+  {
+    std::vector<int> code((size_t)A.nlq, -1);
+    for (sdm_int r = lpN; r < lpN + lorN && r < A.nlq; r++) code[r] = (int)(-2 - (r - lpN));
+    for (sdm_int k = 0; k < lorN; k++)
+      for (sdm_int r = qblkstart[k]; r < qblkstart[k + 1] && r < A.nlq; r++) code[r] = (int)k;
+    A.dsqr_code.upload(code);
+  }
+  if (sdpN > rsdpN) throw std::runtime_error("Hermitian PSD blocks are not supported yet");
+  // ---- PSD blocks
+  A.psd_n.assign(sdpNL, sdpNL + sdpN);
+  A.psd_start.assign(psd_blkstart, psd_blkstart + sdpN + (sdpN > 0 ? 1 : 0));
+  A.psd_udoff.assign(sdpN + 1, 0);
+  A.maxn = 0;
+  for (sdm_int k = 0; k < sdpN; k++) {
+    sdm_int n = sdpNL[k];
+    sdm_int len = (k < rsdpN ? 1 : 2) * n * n;
+    if (psd_blkstart[k + 1] - psd_blkstart[k] != len) throw std::runtime_error("PSD block size / blkstart mismatch");
+    A.psd_udoff[k + 1] = A.psd_udoff[k] + len;
+    A.maxn = std::max<int>(A.maxn, (int)n);
+  }
+  A.lenud = A.psd_udoff[sdpN];
+  // ---- per PSD nonzero: block id and position in the union pattern U_k
+  std::vector<int> Ablk((size_t)A.nnzA, -1), Aupos((size_t)A.nnzA, 0);
+  std::vector<std::vector<int>> U(sdpN);
+  for (sdm_int j = 0; j < m && sdpN > 0; j++) {
+    sdm_int k = 0;
+    for (sdm_int t = Ajc_psd[j]; t < Ajc[j + 1]; t++) {
+      sdm_int r = Air[t];
+      if (r < A.nlq) throw std::runtime_error("Ajc_psd points into the LP/Lorentz part");
+      while (k < sdpN && r >= psd_blkstart[k + 1]) k++;
+      if (k >= sdpN) throw std::runtime_error("At row index beyond the PSD blocks");
+      Ablk[t] = (int)k;
+      U[k].push_back((int)(r - psd_blkstart[k]));
+    }
+  }
+  std::vector<int64_t> uoff(sdpN + 1, 0);
+  for (sdm_int k = 0; k < sdpN; k++) {
+    std::sort(U[k].begin(), U[k].end());
+    U[k].erase(std::unique(U[k].begin(), U[k].end()), U[k].end());
+    uoff[k + 1] = uoff[k] + (int64_t)U[k].size();
+  }
+  std::vector<int> upos_all((size_t)uoff[sdpN]);
+  for (sdm_int k = 0; k < sdpN; k++) std::copy(U[k].begin(), U[k].end(), upos_all.begin() + uoff[k]);
+  sdm_int psdnnz = 0;
+  for (sdm_int j = 0; j < m && sdpN > 0; j++)
+    for (sdm_int t = Ajc_psd[j]; t < Ajc[j + 1]; t++) {
+      int k = Ablk[t];
+      int q = (int)(Air[t] - psd_blkstart[k]);
+      Aupos[t] = (int)(std::lower_bound(U[k].begin(), U[k].end(), q) - U[k].begin());
+      psdnnz++;
+    }
+  A.thread_per_row = (m > 0 && psdnnz / (double)m < 16.0);
+  // ---- stage-1 tasks and slots
+  std::vector<int> t_col, t_blk, t_n, t_nslot, t_ulen, t_herm, s_col;
+  std::vector<int64_t> t_slotptr, t_udoff, t_uoff, t_zoff, s_nzptr, c_taskptr(m + 1, 0);
+  int64_t zlen = 0;
+  for (sdm_int j = 0; j < m; j++) {
+    sdm_int t = sdpN > 0 ? Ajc_psd[j] : Ajc[j + 1];
+    while (t < Ajc[j + 1]) {
+      int k = Ablk[t];
+      sdm_int te = t;
+      while (te < Ajc[j + 1] && Ablk[te] == k) te++;
+      const sdm_int n = A.psd_n[k];
+      const bool herm = k >= rsdpN;
+      t_col.push_back((int)j); t_blk.push_back(k); t_n.push_back((int)n); t_herm.push_back(herm ? 1 : 0);
+      t_slotptr.push_back((int64_t)s_col.size());
+      t_udoff.push_back(A.psd_udoff[k]); t_uoff.push_back(uoff[k]); t_ulen.push_back((int)U[k].size());
+      t_zoff.push_back(zlen); zlen += (int64_t)U[k].size();
+      // slots: distinct columns of X_jk (real part first, then imaginary part for Hermitian blocks)
+      int nslot = 0; sdm_int prevcol = -1; int prevpart = -1;
+      for (sdm_int u = t; u < te; u++) {
+        sdm_int q = Air[u] - psd_blkstart[k];
+        int part = q >= n * n ? 1 : 0;
+        sdm_int col = (q - part * n * n) / n;
+        if (col != prevcol || part != prevpart) {
+          s_col.push_back((int)(col + part * n)); s_nzptr.push_back((int64_t)u);
+          nslot++; prevcol = col; prevpart = part;
+        }
+      }
+      t_nslot.push_back(nslot);
+      t = te;
+    }
+    c_taskptr[j + 1] = (int64_t)t_col.size();
+  }
+  s_nzptr.push_back(A.nnzA);   // sentinel (only used through per-task end pointers)
+  A.ntask = (sdm_int)t_col.size(); A.zlen = zlen;
+  // per task: end of its last slot = start of next task's first nonzero; store explicit end pointers in s_nzptr
+  // by giving every slot an (begin) and using the next slot's begin inside a task, and the task end via t_end:
+  std::vector<int64_t> t_end(A.ntask);
+  { sdm_int ti = 0;
+    for (sdm_int j = 0; j < m; j++) {
+      sdm_int t = sdpN > 0 ? Ajc_psd[j] : Ajc[j + 1];
+      while (t < Ajc[j + 1]) { int k = Ablk[t]; sdm_int te = t; while (te < Ajc[j + 1] && Ablk[te] == k) te++; t_end[ti++] = te; t = te; }
+    } }
+  // ---- transposed-entry map of the ADA pattern
+  std::vector<int> adaT((size_t)ADAjc[m], -1);
+  { std::vector<sdm_int> nxt(ADAjc, ADAjc + m);
+    // for entry e=(i,j): find (j,i) by binary search in column i
+    for (sdm_int j = 0; j < m; j++)
+      for (sdm_int e = ADAjc[j]; e < ADAjc[j + 1]; e++) {
+        sdm_int i = ADAir[e];
+        const sdm_int *b = ADAir + ADAjc[i], *en = ADAir + ADAjc[i + 1];
+        const sdm_int *f = std::lower_bound(b, en, j);
+        if (f != en && *f == j) adaT[e] = (int)(f - ADAir);
+      } }
+  // ---- upload
+  { std::vector<int64_t> v(Ajc, Ajc + m + 1); A.d_Ajc.upload(v); }
+  { std::vector<int64_t> v(Ajc_psd, Ajc_psd + m); A.d_Ajc_psd.upload(v); }
+  { std::vector<int> v((size_t)A.nnzA); for (sdm_int t = 0; t < A.nnzA; t++) v[t] = (int)Air[t]; A.d_Air.upload(v); }
+  A.d_Apr.upload(Apr, (size_t)A.nnzA);
+  A.d_Ablk.upload(Ablk); A.d_Aupos.upload(Aupos);
+  A.nnzQ = lorN > 0 ? Qjc[m] : 0;
+  { std::vector<int64_t> v(m + 1, 0); if (lorN > 0) v.assign(Qjc, Qjc + m + 1); A.d_Qjc.upload(v); }
+  { std::vector<int> v((size_t)A.nnzQ); for (sdm_int t = 0; t < A.nnzQ; t++) v[t] = (int)Qir[t]; A.d_Qir.upload(v); }
+  { std::vector<int64_t> v(ADAjc, ADAjc + m + 1); A.d_ADAjc.upload(v); }
+  { std::vector<int> v((size_t)ADAjc[m]); for (sdm_int t = 0; t < ADAjc[m]; t++) v[t] = (int)ADAir[t]; A.d_ADAir.upload(v); }
+  A.d_ADAT.upload(adaT);
+  A.u_pos.upload(upos_all);
+  A.t_col.upload(t_col); A.t_blk.upload(t_blk); A.t_n.upload(t_n); A.t_nslot.upload(t_nslot); A.t_ulen.upload(t_ulen);
+  A.t_herm.upload(t_herm);
+  A.t_slotptr.upload(t_slotptr); A.t_udoff.upload(t_udoff); A.t_uoff.upload(t_uoff); A.t_zoff.upload(t_zoff);
+  A.s_col.upload(s_col); A.s_nzptr.upload(s_nzptr); A.c_taskptr.upload(c_taskptr);
+  A.t_end.upload(t_end);
+  { std::vector<int64_t> v(A.psd_start.begin(), A.psd_start.end()); if (v.empty()) v.push_back(0); A.d_psd_start.upload(v); }
+  A.zbuf.alloc((size_t)std::max<int64_t>(zlen, 1));
+  A.dsqr.alloc((size_t)std::max<sdm_int>(A.nlq, 1));
+  A.dl.alloc((size_t)std::max<sdm_int>(lpN, 1)); A.ddet.alloc((size_t)std::max<sdm_int>(lorN, 1));
+  A.qpr.alloc((size_t)std::max<sdm_int>(A.nnzQ, 1)); A.udsqr.alloc((size_t)std::max<sdm_int>(A.lenud, 1));
+  A.symtmp.alloc((size_t)std::max<sdm_int>(ADAjc[m], 1));
+  // LDS budget for stage 1: Y chunk of CC slots x n rows
+  A.stage1_lds = 96 * 1024;
+  if ((size_t)A.maxn * sizeof(double) > A.stage1_lds) A.stage1_lds = (size_t)A.maxn * sizeof(double);
+  if (A.stage1_lds > 160 * 1024 - 1024) throw std::runtime_error("PSD block too large for the LDS-staged D*A*D kernel (n > 20k)");
+  P->has_ada = true;
+}
+
+// ================================================================= kernels
+__global__ void k_dsqr(double *dsqr, const int *code, const double *dl, const double *ddet, int nlq) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nlq) { int c = code[r]; dsqr[r] = c == -1 ? dl[r] : (c >= 0 ? ddet[c] : -ddet[-2 - c]); }
+}
+__global__ void k_fill(double *x, double v, int64_t n) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; t < n; t += stride) x[t] = v;
+}
+
+// sparse weighted dot of two At columns restricted to [beg,end) ranges; one wavefront per ADA entry.
+//   val(i,j) = sum_r  M(r,i) * w(r) * M(r,j),   w = dsqr (getada1) or 1 (getada2)
+__global__ void __launch_bounds__(256)
+k_ada_spdot(double *ada, const int64_t *ADAjc, const int *ADAir, const int64_t *Mbeg, const int64_t *Mend,
+            const int *Mir, const double *Mpr, const double *wgt, const int *invperm, int accumulate) {
+  const int j = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int64_t jb = Mbeg[j], je = Mend[j];
+  const int ipj = invperm ? invperm[j] : 0;
+  for (int64_t e = ADAjc[j] + wave; e < ADAjc[j + 1]; e += nw) {
+    const int i = ADAir[e];
+    if (invperm && invperm[i] > ipj) continue;       // wave-uniform
+    double acc = 0.0;
+    if (je > jb) {
+      for (int64_t t = Mbeg[i] + lane; t < Mend[i]; t += 64) {
+        const int r = Mir[t];
+        int64_t lo = jb, hi = je;                     // first index with Mir >= r
+        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (Mir[mid] < r) lo = mid + 1; else hi = mid; }
+        if (lo < je && Mir[lo] == r) acc += Mpr[t] * ((wgt ? wgt[r] : 1.0) * Mpr[lo]);
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) { if (accumulate) ada[e] += acc; else ada[e] = acc; }
+  }
+}
+
+// ---- stage 1: z_jk = (D_k sym(X_jk) D_k)[U_k]    (spscale.c:249-305)
+struct Stage1Tab {
+  const int *t_n, *t_nslot, *t_ulen, *t_herm, *s_col, *u_pos, *Air;
+  const int64_t *t_slotptr, *t_udoff, *t_uoff, *t_zoff, *t_end, *s_nzptr;
+  const double *Apr;
+  const int *t_blk;
+  const int64_t *psd_start;
+};
+__global__ void __launch_bounds__(256)
+k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY) {
+  SDM_DYN_SMEM(smem);
+  double *Y = (double *)smem;                       // Y[slot][row], chunk of CC slots
+  const int task = blockIdx.x;
+  const int n = T.t_n[task], nslot = T.t_nslot[task], ulen = T.t_ulen[task];
+  const int64_t slot0 = T.t_slotptr[task], tend = T.t_end[task];
+  const double *D = udsqr + T.t_udoff[task];
+  const int *U = T.u_pos + T.t_uoff[task];
+  double *z = zbuf + T.t_zoff[task];
+  const int64_t rowbase = T.psd_start[T.t_blk[task]];
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
+  int CC = ldsY / n; if (CC < 1) CC = 1; if (CC > nslot) CC = nslot;
+  for (int c0 = 0; c0 < nslot; c0 += CC) {
+    const int cc = min(CC, nslot - c0);
+    // (1) Y[:,t] = sum_{nz in slot} x * D[:, row(nz)]          (realdmulx, spscale.c:73-107)
+    for (int t = wave; t < cc; t += nw) {
+      const int64_t sb = T.s_nzptr[slot0 + c0 + t];
+      const int64_t se = (c0 + t + 1 < nslot) ? T.s_nzptr[slot0 + c0 + t + 1] : tend;
+      const int col = T.s_col[slot0 + c0 + t];
+      for (int i = lane; i < n; i += 64) {
+        double acc = 0.0;
+        for (int64_t u = sb; u < se; u++) {
+          const int rx = (int)(T.Air[u] - rowbase) - col * n;
+          acc += T.Apr[u] * D[(int64_t)rx * n + i];
+        }
+        Y[t * n + i] = acc;
+      }
+    }
+    __syncthreads();
+    // (2) targets: z(r,c) (+)= ( sum_t Y[r,t] D[col_t,c] + Y[c,t] D[col_t,r] ) / 2   (spscale.c:283-304)
+    for (int u = tid; u < ulen; u += bs) {
+      const int q = U[u];
+      const int c = q / n, r = q - c * n;
+      double a1 = 0.0, a2 = 0.0;
+      for (int t = 0; t < cc; t++) {
+        const double *Dc = D + (int64_t)T.s_col[slot0 + c0 + t] * n;
+        a1 += Y[t * n + r] * Dc[c];
+        a2 += Y[t * n + c] * Dc[r];
+      }
+      const double v = (a1 + a2) / 2;
+      if (c0 == 0) z[u] = v; else z[u] += v;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- stage 2: ADA(i,j) += a_i[psd]' z_j ; absd fused (getada3.c:333-351)
+__global__ void __launch_bounds__(256)
+k_psd_stage2(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, const int64_t *Ajc,
+             const int64_t *Ajc_psd, const double *Apr, const int *Ablk, const int *Aupos,
+             const int64_t *c_taskptr, const int *t_blk, const int64_t *t_zoff, const double *zbuf,
+             const int *invperm, int nblk, int thread_per_row) {
+  SDM_DYN_SMEM(smem);
+  long long *zo = (long long *)smem;                // block -> offset of z_jk in zbuf (or -1)
+  const int j = blockIdx.x;
+  const int tid = threadIdx.x, bs = blockDim.x;
+  for (int k = tid; k < nblk; k += bs) zo[k] = -1;
+  __syncthreads();
+  for (int64_t t = c_taskptr[j] + tid; t < c_taskptr[j + 1]; t += bs) zo[t_blk[t]] = t_zoff[t];
+  __syncthreads();
+  const bool jhas = c_taskptr[j + 1] > c_taskptr[j];
+  const int ipj = invperm ? invperm[j] : 0;
+  if (thread_per_row) {
+    for (int64_t e = ADAjc[j] + tid; e < ADAjc[j + 1]; e += bs) {
+      const int i = ADAir[e];
+      if (invperm && invperm[i] > ipj) continue;
+      double acc = 0.0, aabs = 0.0;
+      if (jhas)
+        for (int64_t t = Ajc_psd[i]; t < Ajc[i + 1]; t++) {
+          const long long off = zo[Ablk[t]];
+          if (off >= 0) { const double term = Apr[t] * zbuf[off + Aupos[t]]; acc += term; aabs += fabs(term); }
+        }
+      const double base = ada[e];
+      ada[e] = base + acc;
+      if (i == j) absd[j] = jhas ? base + aabs : 0.0;
+    }
+  } else {
+    const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
+    for (int64_t e = ADAjc[j] + wave; e < ADAjc[j + 1]; e += nw) {
+      const int i = ADAir[e];
+      if (invperm && invperm[i] > ipj) continue;
+      double acc = 0.0, aabs = 0.0;
+      if (jhas)
+        for (int64_t t = Ajc_psd[i] + lane; t < Ajc[i + 1]; t += 64) {
+          const long long off = zo[Ablk[t]];
+          if (off >= 0) { const double term = Apr[t] * zbuf[off + Aupos[t]]; acc += term; aabs += fabs(term); }
+        }
+      for (int off = 32; off > 0; off >>= 1) { acc += __shfl_down(acc, off); aabs += __shfl_down(aabs, off); }
+      if (lane == 0) {
+        const double base = ada[e];
+        ada[e] = base + acc;
+        if (i == j) absd[j] = jhas ? base + aabs : 0.0;
+      }
+    }
+  }
+}
+
+// spmakesym (getada3.c:151-180): out(i,j) = in(i,j) + in(j,i) for i != j
+__global__ void k_symmetrize(double *out, const double *in, const int64_t *ADAjc, const int *ADAir, const int *adaT, int m) {
+  const int j = blockIdx.x;
+  for (int64_t e = ADAjc[j] + threadIdx.x; e < ADAjc[j + 1]; e += blockDim.x) {
+    const int i = ADAir[e];
+    double v = in[e];
+    if (i != j) { const int et = adaT[e]; if (et >= 0) v += in[et]; }
+    out[e] = v;
+  }
+}
+// cpspdiag (getada3.c:119-135): absd = diag(ADA) when there are no PSD blocks
+__global__ void k_diag(double *absd, const double *ada, const int64_t *ADAjc, const int *ADAir, int m) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  double v = 0.0;
+  for (int64_t e = ADAjc[j]; e < ADAjc[j + 1]; e++) if (ADAir[e] == j) { v = ada[e]; break; }
+  absd[j] = v;
+}
+
+// ============================================================ host drivers
+void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
+  AdaPlan &A = P->ada;
+  hipStream_t st = P->stream;
+  if (A.nlq > 0)
+    SDM_LAUNCH(k_dsqr, dim3((unsigned)((A.nlq + 255) / 256)), dim3(256), 0, st, A.dsqr.p, A.dsqr_code.p, A.dl.p, A.ddet.p, (int)A.nlq);
+  SDM_LAUNCH(k_ada_spdot, dim3((unsigned)A.m), dim3(256), 0, st, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p,
+             A.d_Air.p, A.d_Apr.p, A.dsqr.p, d_invperm, accumulate ? 1 : 0);
+}
+void ada_q(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
+  AdaPlan &A = P->ada;
+  if (A.lorN == 0 || A.nnzQ == 0) return;
+  SDM_LAUNCH(k_ada_spdot, dim3((unsigned)A.m), dim3(256), 0, P->stream, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Qjc.p, A.d_Qjc.p + 1,
+             A.d_Qir.p, A.qpr.p, (const double *)nullptr, d_invperm, accumulate ? 1 : 0);
+}
+void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
+  AdaPlan &A = P->ada;
+  hipStream_t st = P->stream;
+  const int m = (int)A.m;
+  if (A.sdpN == 0) {
+    if (sym_input) {
+      SDM_LAUNCH(k_symmetrize, dim3(m), dim3(128), 0, st, A.symtmp.p, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_ADAT.p, m);
+      SDM_HIP_CHECK(hipMemcpyAsync(ada, A.symtmp.p, A.symtmp.n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    SDM_LAUNCH(k_diag, dim3((m + 255) / 256), dim3(256), 0, st, P->absd.p, ada, A.d_ADAjc.p, A.d_ADAir.p, m);
+    return;
+  }
+  if (A.ntask > 0) {
+    Stage1Tab T;
+    T.t_n = A.t_n.p; T.t_nslot = A.t_nslot.p; T.t_ulen = A.t_ulen.p; T.t_herm = A.t_herm.p; T.s_col = A.s_col.p;
+    T.u_pos = A.u_pos.p; T.Air = A.d_Air.p; T.t_slotptr = A.t_slotptr.p; T.t_udoff = A.t_udoff.p; T.t_uoff = A.t_uoff.p;
+    T.t_zoff = A.t_zoff.p; T.t_end = A.t_end.p; T.s_nzptr = A.s_nzptr.p; T.Apr = A.d_Apr.p; T.t_blk = A.t_blk.p;
+    T.psd_start = A.d_psd_start.p;
+#ifndef SDM_EMU
+    SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A.stage1_lds));
+#endif
+    SDM_LAUNCH(k_psd_stage1, dim3((unsigned)A.ntask), dim3(256), A.stage1_lds, st, T, A.udsqr.p, A.zbuf.p,
+               (int)(A.stage1_lds / sizeof(double)));
+  }
+  // the reference first adds the PSD part on one triangle and symmetrises at the very end; summing the
+  // transposed partial sums of getada1/2 first and adding the (symmetric) PSD part afterwards is the same sum.
+  if (sym_input) {
+    SDM_LAUNCH(k_symmetrize, dim3(m), dim3(128), 0, st, A.symtmp.p, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_ADAT.p, m);
+    SDM_HIP_CHECK(hipMemcpyAsync(ada, A.symtmp.p, A.symtmp.n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
+  SDM_LAUNCH(k_psd_stage2, dim3(m), dim3(256), (size_t)A.sdpN * 8, st, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p,
+             A.d_Ajc_psd.p, A.d_Apr.p, A.d_Ablk.p, A.d_Aupos.p, A.c_taskptr.p, A.t_blk.p, A.t_zoff.p, A.zbuf.p, d_invperm,
+             (int)A.sdpN, A.thread_per_row ? 1 : 0);
+  SDM_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace sdm

@@ -1,0 +1,379 @@
+// sdm_capi.hip -- extern "C" entry points of libsedumi_hip.so (include/sedumi_hip.h).
+#include "../../include/sedumi_hip.h"
+#include "sdm_plan.h"
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
+namespace sdm {
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+}  // namespace sdm
+using namespace sdm;
+
+#define SDM_TRY try {
+#define SDM_CATCH                                              \
+  }                                                            \
+  catch (const std::exception &e) { set_error(e.what()); return 1; } \
+  catch (...) { set_error("unknown error"); return 1; }        \
+  return 0;
+
+extern "C" {
+
+const char *sdm_last_error(void) { return g_err.c_str(); }
+#ifdef SDM_EMU
+const char *sdm_backend(void) { return "emu"; }
+#else
+const char *sdm_backend(void) { return "hip-gfx950"; }
+#endif
+int sdm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+int sdm_set_device(int dev) {
+  SDM_TRY
+  SDM_HIP_CHECK(hipSetDevice(dev));
+  SDM_CATCH
+}
+
+// ------------------------------------------------------------------ plan
+sdm_plan *sdm_plan_create(int device, void *stream) {
+  try {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device available (libsedumi_hip has no CPU fallback)"); return nullptr; }
+    SDM_HIP_CHECK(hipSetDevice(device));
+    sdm_plan *p = new sdm_plan();
+    p->device = device;
+    if (stream) { p->stream = (hipStream_t)stream; p->own_stream = false; }
+    else { SDM_HIP_CHECK(hipStreamCreate(&p->stream)); p->own_stream = true; }
+    return p;
+  } catch (const std::exception &e) { set_error(e.what()); return nullptr; }
+}
+void sdm_plan_destroy(sdm_plan *p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  (void)hipStreamSynchronize(p->stream);
+  for (int i = 0; i < 16; i++) { if (p->ev_begin[i]) (void)hipEventDestroy(p->ev_begin[i]); if (p->ev_end[i]) (void)hipEventDestroy(p->ev_end[i]); }
+  if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+}
+int sdm_plan_sync(sdm_plan *p) {
+  SDM_TRY
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  SDM_CATCH
+}
+
+int sdm_plan_set_chol(sdm_plan *p, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm,
+                      sdm_int nsuper, const sdm_int *xsuper, const sdm_int *ADAjc, const sdm_int *ADAir) {
+  SDM_TRY
+  SDM_HIP_CHECK(hipSetDevice(p->device));
+  chol_build(p, m, Ljc, Lir, perm, nsuper, xsuper, ADAjc, ADAir);
+  p->ada_jc.assign(ADAjc, ADAjc + m + 1);
+  p->ada_ir.assign(ADAir, ADAir + ADAjc[m]);
+  SDM_CATCH
+}
+
+int sdm_plan_set_ada(sdm_plan *p, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_int *Air, const double *Apr,
+                     const sdm_int *Ajc_psd, const sdm_cone *K, const sdm_int *qblkstart, const sdm_int *psd_blkstart,
+                     const sdm_int *Qjc, const sdm_int *Qir) {
+  SDM_TRY
+  SDM_HIP_CHECK(hipSetDevice(p->device));
+  if (!p->has_chol) throw std::runtime_error("sdm_plan_set_ada: call sdm_plan_set_chol first (it carries the ADA pattern)");
+  if (m != p->chol.m) throw std::runtime_error("sdm_plan_set_ada: m mismatch");
+  ada_build(p, N, m, Ajc, Air, Apr, Ajc_psd, K->lpN, K->lorN, K->lorNL, K->sdpN, K->rsdpN, K->sdpNL, qblkstart,
+            psd_blkstart, Qjc, Qir, p->ada_jc.data(), p->ada_ir.data());
+  SDM_CATCH
+}
+
+static DevBuf<double> *plan_buf(sdm_plan *p, const char *name) {
+  std::string s(name);
+  if (s == "ada") return &p->ada_val;
+  if (s == "absd") return &p->absd;
+  if (s == "d") return &p->chol.d;
+  if (s == "dsolve") return &p->chol.dsolve;
+  if (s == "y") return &p->y;
+  if (s == "rhs") return &p->rhs;
+  if (s == "lpr") return &p->lpr;
+  if (s == "udsqr") return &p->ada.udsqr;
+  if (s == "dl") return &p->ada.dl;
+  if (s == "ddet") return &p->ada.ddet;
+  if (s == "qpr") return &p->ada.qpr;
+  throw std::runtime_error("unknown plan buffer: " + s);
+}
+void *sdm_plan_devptr(sdm_plan *p, const char *name, sdm_int *nelem) {
+  try {
+    DevBuf<double> *b = plan_buf(p, name);
+    if (nelem) *nelem = (sdm_int)b->n;
+    return b->p;
+  } catch (const std::exception &e) { set_error(e.what()); return nullptr; }
+}
+int sdm_plan_upload(sdm_plan *p, const char *name, const double *src, sdm_int nelem) {
+  SDM_TRY
+  DevBuf<double> *b = plan_buf(p, name);
+  if ((size_t)nelem > b->n) throw std::runtime_error(std::string("upload: too many elements for buffer ") + name);
+  SDM_HIP_CHECK(hipMemcpyAsync(b->p, src, (size_t)nelem * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  SDM_CATCH
+}
+int sdm_plan_download(sdm_plan *p, const char *name, double *dst, sdm_int nelem) {
+  SDM_TRY
+  DevBuf<double> *b = plan_buf(p, name);
+  if (std::string(name) == "lpr") chol_extract(p, p->lpr.p);
+  if ((size_t)nelem > b->n) throw std::runtime_error(std::string("download: too many elements for buffer ") + name);
+  SDM_HIP_CHECK(hipMemcpyAsync(dst, b->p, (size_t)nelem * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  SDM_CATCH
+}
+
+int sdm_plan_getada(sdm_plan *p) {
+  SDM_TRY
+  if (!p->has_ada) throw std::runtime_error("sdm_plan_getada: no ADA data set");
+  ada_lq(p, p->ada_val.p, nullptr, false);
+  ada_q(p, p->ada_val.p, nullptr, true);
+  ada_psd(p, p->ada_val.p, nullptr, false);
+  SDM_CATCH
+}
+int sdm_plan_blkchol(sdm_plan *p, const sdm_cholpars *pars, int use_absd) {
+  SDM_TRY
+  if (!p->has_chol) throw std::runtime_error("sdm_plan_blkchol: no symbolic factor set");
+  sdm_cholpars q = {1e-12, 5e2, 1e-20};           // blkchol.c:292-294 defaults
+  if (pars) q = *pars;
+  if (q.abstol < 0.0) q.abstol = 0.0;              // blkchol.c:303
+  chol_factor(p, q.canceltol, q.maxu, q.abstol, use_absd);
+  SDM_CATCH
+}
+int sdm_plan_pivots(sdm_plan *p, sdm_int *nskip, sdm_int *skip_idx, double *skip_val, sdm_int *nadd,
+                    sdm_int *add_idx, double *add_val) {
+  SDM_TRY
+  const sdm_int m = p->chol.m;
+  std::vector<int> st(m);
+  std::vector<double> val(m);
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  SDM_HIP_CHECK(hipMemcpy(st.data(), p->chol.pivstat.p, m * sizeof(int), hipMemcpyDeviceToHost));
+  SDM_HIP_CHECK(hipMemcpy(val.data(), p->chol.pivval.p, m * sizeof(double), hipMemcpyDeviceToHost));
+  sdm_int ns = 0, na = 0;
+  for (sdm_int j = 0; j < m; j++) {
+    if (st[j] == 1) { if (skip_idx) skip_idx[ns] = j; if (skip_val) skip_val[ns] = val[j]; ns++; }
+    else if (st[j] == 2) { if (add_idx) add_idx[na] = j; if (add_val) add_val[na] = val[j]; na++; }
+  }
+  if (nskip) *nskip = ns;
+  if (nadd) *nadd = na;
+  SDM_CATCH
+}
+int sdm_plan_fwsolve(sdm_plan *p) {
+  SDM_TRY
+  if (!p->factored) throw std::runtime_error("fwsolve: no factor resident");
+  vec_gather(p, p->ywork.p, p->rhs.p, true);
+  solve_fw(p);
+  SDM_HIP_CHECK(hipMemcpyAsync(p->y.p, p->ywork.p, p->chol.m * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  SDM_CATCH
+}
+int sdm_plan_bwsolve(sdm_plan *p) {
+  SDM_TRY
+  if (!p->factored) throw std::runtime_error("bwsolve: no factor resident");
+  SDM_HIP_CHECK(hipMemcpyAsync(p->ywork.p, p->rhs.p, p->chol.m * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  solve_bw(p);
+  vec_gather(p, p->y.p, p->ywork.p, false);
+  SDM_CATCH
+}
+int sdm_plan_ldlsolve(sdm_plan *p) {
+  SDM_TRY
+  if (!p->factored) throw std::runtime_error("ldlsolve: no factor resident");
+  vec_gather(p, p->ywork.p, p->rhs.p, true);
+  solve_fw(p);
+  vec_divd(p, p->ywork.p);
+  solve_bw(p);
+  vec_gather(p, p->y.p, p->ywork.p, false);
+  SDM_CATCH
+}
+int sdm_plan_timer_begin(sdm_plan *p, int slot) {
+  SDM_TRY
+  if (slot < 0 || slot >= 16) throw std::runtime_error("timer slot out of range");
+  if (!p->ev_begin[slot]) { SDM_HIP_CHECK(hipEventCreate(&p->ev_begin[slot])); SDM_HIP_CHECK(hipEventCreate(&p->ev_end[slot])); }
+  SDM_HIP_CHECK(hipEventRecord(p->ev_begin[slot], p->stream));
+  SDM_CATCH
+}
+int sdm_plan_timer_end(sdm_plan *p, int slot) {
+  SDM_TRY
+  if (slot < 0 || slot >= 16 || !p->ev_end[slot]) throw std::runtime_error("timer slot not started");
+  SDM_HIP_CHECK(hipEventRecord(p->ev_end[slot], p->stream));
+  SDM_CATCH
+}
+int sdm_plan_timer_ms(sdm_plan *p, int slot, float *ms) {
+  SDM_TRY
+  if (slot < 0 || slot >= 16 || !p->ev_end[slot]) throw std::runtime_error("timer slot not started");
+  SDM_HIP_CHECK(hipEventSynchronize(p->ev_end[slot]));
+  SDM_HIP_CHECK(hipEventElapsedTime(ms, p->ev_begin[slot], p->ev_end[slot]));
+  SDM_CATCH
+}
+
+// ------------------------------------------------- tier (1): MEX equivalents
+struct PlanGuard {
+  sdm_plan *p;
+  PlanGuard() : p(sdm_plan_create(0, nullptr)) { if (!p) throw std::runtime_error(g_err); }
+  ~PlanGuard() { sdm_plan_destroy(p); }
+};
+static void upload_invperm(DevBuf<int> &buf, const sdm_int *perm, sdm_int m) {
+  std::vector<int> ip(m);
+  for (sdm_int k = 0; k < m; k++) {
+    if (perm[k] < 0 || perm[k] >= m) throw std::runtime_error("permutation entry out of range");
+    ip[perm[k]] = (int)k;
+  }
+  buf.upload(ip);
+}
+// a trivial symbolic factor (diagonal) so that an ADA-only plan can be built
+static void set_trivial_chol(sdm_plan *p, sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir) {
+  std::vector<sdm_int> Ljc(m + 1), Lir(m), perm(m), xs(m + 1);
+  for (sdm_int j = 0; j <= m; j++) { Ljc[j] = j; xs[j] = j; }
+  for (sdm_int j = 0; j < m; j++) { Lir[j] = j; perm[j] = j; }
+  if (sdm_plan_set_chol(p, m, Ljc.data(), Lir.data(), perm.data(), m, xs.data(), ADAjc, ADAir)) throw std::runtime_error(g_err);
+}
+
+int sdm_getada1(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc,
+                const sdm_int *Air, const double *Apr, const sdm_int *Ajc2, const sdm_int *perm, sdm_int lpN,
+                const double *dl, sdm_int lorN, const double *ddet, const sdm_int *qblkstart, double *ADApr) {
+  SDM_TRY
+  PlanGuard G; sdm_plan *p = G.p;
+  set_trivial_chol(p, m, ADAjc, ADAir);
+  // only the LP/Lorentz rows matter here: present At as if it had no PSD part
+  sdm_cone K = {lpN, lorN, nullptr, 0, 0, nullptr};
+  std::vector<sdm_int> Qjc(m + 1, 0);
+  // rows >= qblkstart[lorN] (PSD part) are never touched: Ajc2 is the end of the LP/Lorentz nonzeros
+  sdm_int nlq = lorN > 0 ? qblkstart[lorN] : lpN;
+  (void)N;
+  ada_build(p, nlq, m, Ajc, Air, Apr, Ajc2, K.lpN, K.lorN, nullptr, 0, 0, nullptr, qblkstart, nullptr, Qjc.data(), nullptr,
+            ADAjc, ADAir);
+  if (lpN) SDM_HIP_CHECK(hipMemcpy(p->ada.dl.p, dl, lpN * sizeof(double), hipMemcpyHostToDevice));
+  if (lorN) SDM_HIP_CHECK(hipMemcpy(p->ada.ddet.p, ddet, lorN * sizeof(double), hipMemcpyHostToDevice));
+  DevBuf<int> ip; upload_invperm(ip, perm, m);
+  SDM_HIP_CHECK(hipMemsetAsync(p->ada_val.p, 0, (size_t)ADAjc[m] * sizeof(double), p->stream));   // getada1.c:222-225
+  ada_lq(p, p->ada_val.p, ip.p, false);
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  SDM_HIP_CHECK(hipMemcpy(ADApr, p->ada_val.p, (size_t)ADAjc[m] * sizeof(double), hipMemcpyDeviceToHost));
+  SDM_CATCH
+}
+
+int sdm_getada2(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, double *ADApr, sdm_int lorN,
+                const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, const sdm_int *qperm) {
+  SDM_TRY
+  if (lorN <= 0) return 0;                          // getada2.c:154-155: nothing to do without Lorentz cones
+  PlanGuard G; sdm_plan *p = G.p;
+  set_trivial_chol(p, m, ADAjc, ADAir);
+  std::vector<sdm_int> Ajc(m + 1, 0), qb(lorN + 1, 0);
+  ada_build(p, lorN, m, Ajc.data(), nullptr, nullptr, Ajc.data(), 0, lorN, nullptr, 0, 0, nullptr, qb.data(), nullptr,
+            Qjc, Qir, ADAjc, ADAir);
+  if (Qjc[m]) SDM_HIP_CHECK(hipMemcpy(p->ada.qpr.p, Qpr, Qjc[m] * sizeof(double), hipMemcpyHostToDevice));
+  SDM_HIP_CHECK(hipMemcpy(p->ada_val.p, ADApr, (size_t)ADAjc[m] * sizeof(double), hipMemcpyHostToDevice));
+  DevBuf<int> ip; upload_invperm(ip, qperm, m);
+  ada_q(p, p->ada_val.p, ip.p, true);
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  SDM_HIP_CHECK(hipMemcpy(ADApr, p->ada_val.p, (size_t)ADAjc[m] * sizeof(double), hipMemcpyDeviceToHost));
+  SDM_CATCH
+}
+
+int sdm_getada3(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, double *ADApr, sdm_int N, const sdm_int *Ajc,
+                const sdm_int *Air, const double *Apr, const sdm_int *Ajc1, const sdm_int *sperm, const double *udsqr,
+                const sdm_cone *K, const sdm_int *psd_blkstart, double *absd) {
+  SDM_TRY
+  (void)sperm;   // the sum is independent of the fill order (see sdm_ada.hip header)
+  PlanGuard G; sdm_plan *p = G.p;
+  set_trivial_chol(p, m, ADAjc, ADAir);
+  std::vector<sdm_int> Qjc(m + 1, 0), qb(K->lorN + 1, 0);
+  // the LP/Lorentz rows are not read by getada3: describe them as plain LP rows up to the first PSD row
+  sdm_int nlq = K->sdpN > 0 ? psd_blkstart[0] : N;
+  ada_build(p, N, m, Ajc, Air, Apr, Ajc1, nlq, 0, nullptr, K->sdpN, K->rsdpN, K->sdpNL, qb.data(), psd_blkstart,
+            Qjc.data(), nullptr, ADAjc, ADAir);
+  if (p->ada.lenud) SDM_HIP_CHECK(hipMemcpy(p->ada.udsqr.p, udsqr, p->ada.lenud * sizeof(double), hipMemcpyHostToDevice));
+  SDM_HIP_CHECK(hipMemcpy(p->ada_val.p, ADApr, (size_t)ADAjc[m] * sizeof(double), hipMemcpyHostToDevice));
+  ada_psd(p, p->ada_val.p, nullptr, true);
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  SDM_HIP_CHECK(hipMemcpy(ADApr, p->ada_val.p, (size_t)ADAjc[m] * sizeof(double), hipMemcpyDeviceToHost));
+  SDM_HIP_CHECK(hipMemcpy(absd, p->absd.p, m * sizeof(double), hipMemcpyDeviceToHost));
+  SDM_CATCH
+}
+
+int sdm_blkchol(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm, sdm_int nsuper,
+                const sdm_int *xsuper, const sdm_int *Xjc, const sdm_int *Xir, const double *Xpr,
+                const sdm_cholpars *pars, const double *absd, double *Lpr, double *d, sdm_int *nskip,
+                sdm_int *skip_idx, double *skip_val, sdm_int *nadd, sdm_int *add_idx, double *add_val) {
+  SDM_TRY
+  PlanGuard G; sdm_plan *p = G.p;
+  if (sdm_plan_set_chol(p, m, Ljc, Lir, perm, nsuper, xsuper, Xjc, Xir)) throw std::runtime_error(g_err);
+  SDM_HIP_CHECK(hipMemcpy(p->ada_val.p, Xpr, (size_t)Xjc[m] * sizeof(double), hipMemcpyHostToDevice));
+  if (absd) SDM_HIP_CHECK(hipMemcpy(p->absd.p, absd, m * sizeof(double), hipMemcpyHostToDevice));
+  if (sdm_plan_blkchol(p, pars, absd ? 1 : 0)) throw std::runtime_error(g_err);
+  if (sdm_plan_download(p, "lpr", Lpr, Ljc[m])) throw std::runtime_error(g_err);
+  if (sdm_plan_download(p, "d", d, m)) throw std::runtime_error(g_err);
+  if (sdm_plan_pivots(p, nskip, skip_idx, skip_val, nadd, add_idx, add_val)) throw std::runtime_error(g_err);
+  SDM_CATCH
+}
+
+static void solve_common(bool fw, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const double *Lpr,
+                         const sdm_int *perm, sdm_int nsuper, const sdm_int *xsuper, sdm_int nrhs, const double *b,
+                         double *y) {
+  PlanGuard G; sdm_plan *p = G.p;
+  // the ADA pattern is irrelevant for a solve: use an empty one
+  std::vector<sdm_int> zj(m + 1, 0), idperm;
+  if (!perm) { idperm.resize(m); for (sdm_int i = 0; i < m; i++) idperm[i] = i; perm = idperm.data(); }
+  if (sdm_plan_set_chol(p, m, Ljc, Lir, perm, nsuper, xsuper, zj.data(), nullptr)) throw std::runtime_error(g_err);
+  chol_load_factor(p, Lpr);
+  for (sdm_int c = 0; c < nrhs; c++) {
+    SDM_HIP_CHECK(hipMemcpyAsync(p->rhs.p, b + c * m, m * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    if ((fw ? sdm_plan_fwsolve(p) : sdm_plan_bwsolve(p))) throw std::runtime_error(g_err);
+    SDM_HIP_CHECK(hipMemcpyAsync(y + c * m, p->y.p, m * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  }
+}
+int sdm_fwblkslv(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const double *Lpr, const sdm_int *perm,
+                 sdm_int nsuper, const sdm_int *xsuper, sdm_int nrhs, const double *b, double *y) {
+  SDM_TRY
+  solve_common(true, m, Ljc, Lir, Lpr, perm, nsuper, xsuper, nrhs, b, y);
+  SDM_CATCH
+}
+int sdm_bwblkslv(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const double *Lpr, const sdm_int *perm,
+                 sdm_int nsuper, const sdm_int *xsuper, sdm_int nrhs, const double *b, double *y) {
+  SDM_TRY
+  solve_common(false, m, Ljc, Lir, Lpr, perm, nsuper, xsuper, nrhs, b, y);
+  SDM_CATCH
+}
+
+// sparse right-hand sides: the pattern (Yjc,Yir) from symbfwblk is closed under the solve, so the
+// dense solve restricted to it gives exactly the entries selfwsolve / selbwsolve define.
+static void solve_sparse(bool fw, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const double *Lpr,
+                         const sdm_int *perm, sdm_int nsuper, const sdm_int *xsuper, sdm_int n, const sdm_int *Bjc,
+                         const sdm_int *Bir, const double *Bpr, const sdm_int *Yjc, const sdm_int *Yir, double *Ypr) {
+  PlanGuard G; sdm_plan *p = G.p;
+  std::vector<sdm_int> zj(m + 1, 0), idperm(m);
+  for (sdm_int i = 0; i < m; i++) idperm[i] = i;
+  // forward variant maps b through invperm == dense fwblkslv on a dense copy of b (fwblkslv.c:308-309);
+  // backward variant uses no permutation at all (bwblkslv.c:279-291)
+  if (sdm_plan_set_chol(p, m, Ljc, Lir, fw ? perm : idperm.data(), nsuper, xsuper, zj.data(), nullptr)) throw std::runtime_error(g_err);
+  chol_load_factor(p, Lpr);
+  std::vector<double> col(m), out(m);
+  for (sdm_int c = 0; c < n; c++) {
+    std::fill(col.begin(), col.end(), 0.0);
+    for (sdm_int t = Bjc[c]; t < Bjc[c + 1]; t++) col[Bir[t]] = Bpr[t];
+    SDM_HIP_CHECK(hipMemcpyAsync(p->rhs.p, col.data(), m * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    if ((fw ? sdm_plan_fwsolve(p) : sdm_plan_bwsolve(p))) throw std::runtime_error(g_err);
+    SDM_HIP_CHECK(hipMemcpyAsync(out.data(), p->y.p, m * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    for (sdm_int t = Yjc[c]; t < Yjc[c + 1]; t++) Ypr[t] = out[Yir[t]];
+  }
+}
+int sdm_fwblkslv_sparse(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const double *Lpr, const sdm_int *perm,
+                        sdm_int nsuper, const sdm_int *xsuper, sdm_int n, const sdm_int *Bjc, const sdm_int *Bir,
+                        const double *Bpr, const sdm_int *Yjc, const sdm_int *Yir, double *Ypr) {
+  SDM_TRY
+  solve_sparse(true, m, Ljc, Lir, Lpr, perm, nsuper, xsuper, n, Bjc, Bir, Bpr, Yjc, Yir, Ypr);
+  SDM_CATCH
+}
+int sdm_bwblkslv_sparse(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const double *Lpr, sdm_int nsuper,
+                        const sdm_int *xsuper, sdm_int n, const sdm_int *Bjc, const sdm_int *Bir, const double *Bpr,
+                        const sdm_int *Yjc, const sdm_int *Yir, double *Ypr) {
+  SDM_TRY
+  solve_sparse(false, m, Ljc, Lir, Lpr, nullptr, nsuper, xsuper, n, Bjc, Bir, Bpr, Yjc, Yir, Ypr);
+  SDM_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// sdm_plan.h -- internal structures of the resident plan (not part of the ABI).
+#pragma once
+#include "sdm_rt.h"
+#include <string>
+#include <vector>
+
+namespace sdm {
+
+constexpr int NB = 32;     // factor / solve panel width (columns)
+constexpr int TILE = 64;   // trailing-update tile (MFMA 4 waves x 32x32)
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    SDM_HIP_CHECK(hipMalloc((void **)&p, (count ? count : 1) * sizeof(T)));
+  }
+  void upload(const std::vector<T> &h) {
+    alloc(h.size());
+    if (!h.empty()) SDM_HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+  void upload(const T *h, size_t count) {
+    alloc(count);
+    if (count) SDM_HIP_CHECK(hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice));
+  }
+};
+
+// ---------------------------------------------------------------- chol plan
+// Supernodal elimination tree of the symbolic factor L laid
+// out for a level-scheduled multifrontal LDL': every supernode s owns a dense
+// m_s x m_s column-major "front" in one HBM arena; its first n_s columns end up
+// holding the columns of L (unit diagonal stored as 1.0, blkchol2.c:136).
+struct LevelLaunch {
+  int level, panel;     // panel index p (columns p*NB .. ) of the fronts in level
+  int nactive;          // fronts (prefix of the level list, sorted by n_s desc) with n_s > p*NB
+  int maxrows;          // max over active fronts of rows below the panel's diagonal block
+  int maxtiles;         // max number of TILE x TILE lower tiles in the trailing update
+};
+
+struct CholPlan {
+  sdm_int m = 0, nsuper = 0, nnzL = 0, nnzADA = 0;
+  int nlevels = 0;
+  int64_t fsize = 0, wsize = 0;
+  std::vector<sdm_int> Ljc, perm;
+  std::vector<int> sn_first, sn_ns, sn_ms, sn_parent, sn_level;
+  std::vector<int64_t> sn_foff, sn_xl, sn_woff, sn_roff;
+  std::vector<int> childptr, childlist, levptr, levlist, lev_T;
+  std::vector<LevelLaunch> launches;     // factor panel launches in execution order
+  std::vector<int> lev_first_launch;     // index into launches per level (+ sentinel)
+  // device copies
+  DevBuf<int> d_first, d_ns, d_ms, d_parent, d_childptr, d_childlist, d_levlist, d_lindx, d_relidx, d_perm;
+  DevBuf<int64_t> d_foff, d_xl, d_woff, d_roff, d_asm_dst, d_Ljc;
+  DevBuf<int> d_asm_src;
+  DevBuf<double> fronts, wvec, colbuf, d, dsolve, lb, pivval, ub;
+  DevBuf<int> pivstat;
+};
+
+// ----------------------------------------------------------------- ada plan
+struct AdaPlan {
+  sdm_int N = 0, m = 0, nnzA = 0, lpN = 0, lorN = 0, sdpN = 0, rsdpN = 0;
+  sdm_int nlq = 0;       // number of LP + Lorentz rows (= first PSD row)
+  sdm_int lenud = 0, ntask = 0, zlen = 0, nnzQ = 0;
+  int maxn = 0;
+  bool thread_per_row = false;
+  std::vector<sdm_int> psd_n, psd_start, psd_udoff;
+  DevBuf<int64_t> d_Ajc, d_Ajc_psd, d_Qjc, d_ADAjc;
+  DevBuf<int> d_Air, d_Qir, d_ADAir, d_ADAT;
+  DevBuf<double> d_Apr;
+  DevBuf<int> d_Ablk, d_Aupos;            // per PSD nonzero of At: block id, position in U_k
+  // stage-1 tasks (constraint j, PSD block k)
+  DevBuf<int> t_col, t_blk, t_n, t_nslot, t_ulen, t_herm;
+  DevBuf<int64_t> t_slotptr, t_udoff, t_uoff, t_zoff;
+  DevBuf<int> s_col;                      // per slot: column of X_jk
+  DevBuf<int64_t> s_nzptr;                // per slot (+1): nonzero range in At
+  DevBuf<int> u_pos;                      // concatenated target lists U_k (position r + c*n_k [+ n_k^2 for Im])
+  DevBuf<int64_t> c_taskptr;              // per constraint: its tasks
+  DevBuf<double> zbuf, dsqr, symtmp;
+  DevBuf<int> dsqr_code;
+  DevBuf<int64_t> t_end, d_psd_start;
+  DevBuf<double> dl, ddet, qpr, udsqr;
+  size_t stage1_lds = 0;
+};
+
+}  // namespace sdm
+
+struct sdm_plan {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool has_chol = false, has_ada = false, factored = false;
+  sdm::CholPlan chol;
+  sdm::AdaPlan ada;
+  sdm::DevBuf<double> ada_val, absd, rhs, y, ywork, lpr;
+  std::vector<sdm_int> ada_jc, ada_ir;   // host copy of the ADA pattern
+  hipEvent_t ev_begin[16] = {}, ev_end[16] = {};
+};
+
+namespace sdm {
+void set_error(const std::string &msg);
+// sdm_chol.hip
+void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm,
+                sdm_int nsuper, const sdm_int *xsuper, const sdm_int *ADAjc, const sdm_int *ADAir);
+void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd);
+void chol_extract(sdm_plan *P, double *d_Lpr_out);           // device pointer, nnzL doubles
+void chol_load_factor(sdm_plan *P, const double *h_Lpr);     // host L values -> fronts (for stand-alone solves)
+void solve_fw(sdm_plan *P);   // in place on P->ywork
+void solve_bw(sdm_plan *P);   // in place on P->ywork
+void vec_gather(sdm_plan *P, double *dst, const double *src, bool forward);  // dst[k]=src[perm[k]] / dst[perm[k]]=src[k]
+void vec_divd(sdm_plan *P, double *v);
+// sdm_ada.hip
+void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_int *Air, const double *Apr,
+               const sdm_int *Ajc_psd, sdm_int lpN, sdm_int lorN, const sdm_int *lorNL, sdm_int sdpN,
+               sdm_int rsdpN, const sdm_int *sdpNL, const sdm_int *qblkstart, const sdm_int *psd_blkstart,
+               const sdm_int *Qjc, const sdm_int *Qir, const sdm_int *ADAjc, const sdm_int *ADAir);
+// mode bits: 1 = LP/Lorentz-det part (getada1), 2 = Lorentz rank-1 part (getada2), 4 = PSD part (getada3)
+// tri_perm (device, length m, inverse permutation) != nullptr -> only entries with invperm[i] <= invperm[j]
+// are touched (the reference's triangular bookkeeping); symmetrize -> spmakesym afterwards.
+void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate);
+void ada_q(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate);
+void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input);
+}  // namespace sdm

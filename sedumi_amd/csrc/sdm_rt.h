@@ -1,0 +1,35 @@
+// sdm_rt.h -- device runtime include for the sedumi_amd HIP sources.
+//
+// Product build: hipcc --offload-arch=gfx950 (plain HIP for CDNA4, no other
+// back-ends).  The SDM_EMU branch exists only so tests/hipemu can run the same
+// kernel sources through its CPU fiber emulator inside the GPU-less build
+// container; it is never compiled into libsedumi_hip.so.
+#pragma once
+#ifdef SDM_EMU
+#include "hipemu.h"
+typedef emu_double4 sdm_double4;
+#define SDM_MFMA_F64_16x16x4(a, b, c) emu_mfma_f64_16x16x4((a), (b), (c))
+#define SDM_DYN_SMEM(name) char *name = emu_dyn_smem()
+#else
+#include <hip/hip_runtime.h>
+typedef double sdm_double4 __attribute__((ext_vector_type(4)));
+#define SDM_MFMA_F64_16x16x4(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define SDM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define SDM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+  hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (stream), __VA_ARGS__)
+#endif
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+#define SDM_HIP_CHECK(expr)                                                          \
+  do {                                                                               \
+    hipError_t e_ = (expr);                                                          \
+    if (e_ != hipSuccess)                                                            \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + \
+                               " at " __FILE__ ":" + std::to_string(__LINE__));      \
+  } while (0)
+
+typedef int64_t sdm_int;  // host-side index type of the C ABI

@@ -1,0 +1,234 @@
+"""Host-side mirror of the reference MEX interface for the hot path.
+
+Every function has the name, argument order and argument meaning of the MEX
+gateway it replaces (MATLAB conventions: 1-based indices carried as doubles,
+structs as dicts, sparse matrices as scipy CSC), converts exactly what the
+gateway converts, and calls the C ABI of libsedumi_hip.so (tier 1 of
+include/sedumi_hip.h).  So a parity test reads like the MATLAB call site:
+
+    ADA = getada1(ADA, A, Ablkjc[:, 2], Aord["lqperm"], d, K["qblkstart"])   # sedumi.m:450
+    ADA = getada2(ADA, DAt, Aord, K)                                          # sedumi.m:451
+    ADA, absd = getada3(ADA, A, Ablkjc[:, 2], Aord, udsqr, K)                 # sedumi.m:452
+    LL, Ld, Lskip, Ladd = blkchol(L, ADA, pars_chol, absd)                    # sedumi.m:458
+    y = bwblkslv(L, fwblkslv(L, b) / Ld)                                      # wrapPcg.m:56-59
+
+Errors raise SdmError (the gateways call mexErrMsgTxt).  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import capi
+from .capi import SdmError, check, f64, i64, pf, pi
+
+
+def _csc(X):
+    X = sp.csc_matrix(X)
+    if not X.has_sorted_indices:
+        X = X.copy()
+        X.sort_indices()
+    return X
+
+
+def _field(s, name, what):
+    if name not in s:
+        raise SdmError(f"Missing field {what}.{name}.")
+    return s[name]
+
+
+def _same_pattern(X, pr):
+    return sp.csc_matrix((pr, X.indices.copy(), X.indptr.copy()), shape=X.shape)
+
+
+def _perm0(p, m, what):
+    p = i64(np.asarray(p, dtype=np.float64).ravel()) - 1
+    if p.size != m:
+        raise SdmError(f"Size mismatch {what}.")
+    return p
+
+
+def _Kfields(K):
+    l = int(np.asarray(K.get("l", 0)).ravel()[0]) if np.size(K.get("l", 0)) else 0
+    q = np.asarray(K.get("q", []), dtype=np.float64).ravel()
+    if q.size == 1 and q[0] == 0:
+        q = q[:0]
+    s = np.asarray(K.get("s", []), dtype=np.float64).ravel()
+    if s.size == 1 and s[0] == 0:
+        s = s[:0]
+    rsdpN = int(np.asarray(K["rsdpN"]).ravel()[0]) if "rsdpN" in K else s.size
+    return l, i64(q), i64(s), rsdpN
+
+
+# --------------------------------------------------------------------- ADA'
+def getada1(ADA, A, Ajc2, perm, d, blkstart):
+    """ADA = getada1(ADA, A, Ajc2, perm, d, blkstart)   (getada1.c:161-261)"""
+    ADA, A = _csc(ADA), _csc(A)
+    m = A.shape[1]
+    if ADA.shape != (m, m):
+        raise SdmError("Size mismatch ADA.")
+    Ajc2 = i64(np.asarray(Ajc2, dtype=np.float64))
+    if Ajc2.size != m:
+        raise SdmError("Size mismatch Ajc2.")
+    p0 = _perm0(perm, m, "perm")
+    dl = f64(_field(d, "l", "d"))
+    ddet = f64(_field(d, "det", "d"))
+    qb = i64(np.asarray(blkstart, dtype=np.float64)) - 1      # K.qblkstart, 1-based -> 0-based
+    lorN = qb.size - 1
+    if lorN != ddet.size:
+        raise SdmError("Size d.det mismatch")
+    out = np.zeros(ADA.indptr[-1], dtype=np.float64)
+    jc, ir = i64(ADA.indptr), i64(ADA.indices)
+    Ajc, Air, Apr = i64(A.indptr), i64(A.indices), f64(A.data)
+    check(capi.lib().sdm_getada1(C.c_int64(m), pi(jc), pi(ir), C.c_int64(A.shape[0]), pi(Ajc), pi(Air), pf(Apr),
+                                 pi(Ajc2), pi(p0), C.c_int64(dl.size), pf(dl), C.c_int64(lorN), pf(ddet), pi(qb), pf(out)))
+    return _same_pattern(ADA, out)
+
+
+def getada2(ADA, DAt, Aord, K):
+    """ADA = getada2(ADA, DAt, Aord, K)   (getada2.c:127-214)"""
+    ADA = _csc(ADA)
+    m = ADA.shape[0]
+    out = f64(ADA.data).copy()
+    _, q, _, _ = _Kfields(K)
+    if q.size == 0:
+        return _same_pattern(ADA, out)
+    Q = _csc(_field(DAt, "q", "DAt"))
+    if Q.shape != (q.size, m):
+        raise SdmError("Size mismatch DAt.q.")
+    qperm = _perm0(_field(Aord, "qperm", "Aord"), m, "Aord.qperm")
+    jc, ir = i64(ADA.indptr), i64(ADA.indices)
+    Qjc, Qir, Qpr = i64(Q.indptr), i64(Q.indices), f64(Q.data)
+    check(capi.lib().sdm_getada2(C.c_int64(m), pi(jc), pi(ir), pf(out), C.c_int64(q.size), pi(Qjc), pi(Qir), pf(Qpr),
+                                 pi(qperm)))
+    return _same_pattern(ADA, out)
+
+
+def getada3(ADA, A, Ajc1, Aord, udsqr, K):
+    """[ADA, absd] = getada3(ADA, A, Ajc1, Aord, udsqr, K)   (getada3.c:370-569)"""
+    ADA, A = _csc(ADA), _csc(A)
+    m = A.shape[1]
+    if ADA.shape != (m, m):
+        raise SdmError("Size mismatch ADA.")
+    lpN, q, s, rsdpN = _Kfields(K)
+    Ajc1 = i64(np.asarray(Ajc1, dtype=np.float64))
+    if Ajc1.size != m:
+        raise SdmError("Ajc1 size mismatch")
+    sperm = _perm0(_field(Aord, "sperm", "Aord"), m, "Aord.sperm")
+    blkstart = np.asarray(_field(K, "blkstart", "K"), dtype=np.float64).ravel()
+    if blkstart.size != 2 + q.size + s.size:
+        raise SdmError("Size mismatch K.blkstart.")
+    psd_start = i64(blkstart[q.size + 1:]) - 1
+    ud = f64(udsqr)
+    lenud = int(np.sum(s[:rsdpN] ** 2) + 2 * np.sum(s[rsdpN:] ** 2))
+    if ud.size != lenud:
+        raise SdmError("udsqr size mismatch.")
+    Kc, keep = capi.make_cone(lpN, q, s, rsdpN)
+    out = f64(ADA.data).copy()
+    absd = np.zeros(m, dtype=np.float64)
+    jc, ir = i64(ADA.indptr), i64(ADA.indices)
+    Ajc, Air, Apr = i64(A.indptr), i64(A.indices), f64(A.data)
+    check(capi.lib().sdm_getada3(C.c_int64(m), pi(jc), pi(ir), pf(out), C.c_int64(A.shape[0]), pi(Ajc), pi(Air), pf(Apr),
+                                 pi(Ajc1), pi(sperm), pf(ud), C.byref(Kc), pi(psd_start), pf(absd)))
+    del keep
+    return _same_pattern(ADA, out), absd.reshape(-1, 1)
+
+
+# ------------------------------------------------------------- factor / solve
+def _Lstruct(L, need_values):
+    if not isinstance(L, dict):
+        raise SdmError("Parameter `L' should be a structure.")
+    LL = _field(L, "L", "L")
+    if not sp.issparse(LL):
+        raise SdmError("L.L should be sparse.")
+    LL = _csc(LL)
+    m = LL.shape[0]
+    if LL.shape != (m, m):
+        raise SdmError("Size L.L mismatch.")
+    perm = _perm0(_field(L, "perm", "L"), m, "L.perm")
+    xs = i64(np.asarray(_field(L, "xsuper", "L"), dtype=np.float64)) - 1
+    if xs.size - 1 > m:
+        raise SdmError("Size L.xsuper mismatch.")
+    return m, LL, i64(LL.indptr), i64(LL.indices), (f64(LL.data) if need_values else None), perm, xs
+
+
+def blkchol(L, X, pars=None, absd=None):
+    """[L.L, L.d, L.skip, L.add] = blkchol(L, X, pars, absd)   (blkchol.c:239-440)"""
+    m, LL, Ljc, Lir, _, perm, xs = _Lstruct(L, False)
+    X = _csc(X)
+    if X.shape != (m, m):
+        raise SdmError("P must be square")
+    cp = capi.CholPars(1e-12, 5e2, 1e-20)            # blkchol.c:292-294
+    if pars is not None:
+        if "canceltol" in pars:
+            cp.canceltol = float(np.asarray(pars["canceltol"]).ravel()[0])
+        if "maxu" in pars:
+            cp.maxu = float(np.asarray(pars["maxu"]).ravel()[0])
+        if "abstol" in pars:
+            cp.abstol = max(float(np.asarray(pars["abstol"]).ravel()[0]), 0.0)
+    ab = None
+    if pars is not None and absd is not None:          # absd is only read when pars is given (blkchol.c:312-316)
+        ab = f64(absd)
+        if ab.size != m:
+            raise SdmError("absd size mismatch")
+    Xjc, Xir, Xpr = i64(X.indptr), i64(X.indices), f64(X.data)
+    Lpr = np.zeros(Ljc[-1], dtype=np.float64)
+    d = np.zeros(m, dtype=np.float64)
+    nskip, nadd = C.c_int64(0), C.c_int64(0)
+    sidx, aidx = np.zeros(m, dtype=np.int64), np.zeros(m, dtype=np.int64)
+    sval, aval = np.zeros(m, dtype=np.float64), np.zeros(m, dtype=np.float64)
+    check(capi.lib().sdm_blkchol(C.c_int64(m), pi(Ljc), pi(Lir), pi(perm), C.c_int64(xs.size - 1), pi(xs), pi(Xjc), pi(Xir),
+                                 pf(Xpr), C.byref(cp), pf(ab), pf(Lpr), pf(d), C.byref(nskip), pi(sidx), pf(sval),
+                                 C.byref(nadd), pi(aidx), pf(aval)))
+    ns, na = nskip.value, nadd.value
+    Lout = sp.csc_matrix((Lpr, LL.indices.copy(), LL.indptr.copy()), shape=(m, m))
+    skip = sp.csc_matrix((sval[:ns], sidx[:ns], np.array([0, ns])), shape=(m, 1))
+    add = sp.csc_matrix((aval[:na], aidx[:na], np.array([0, na])), shape=(m, 1))
+    return Lout, d.reshape(-1, 1), skip, add
+
+
+def _solve(fw, L, b, ysymb):
+    m, LL, Ljc, Lir, Lpr, perm, xs = _Lstruct(L, True)
+    lib = capi.lib()
+    if sp.issparse(b):
+        if ysymb is None:
+            raise SdmError("fwblkslv requires more inputs in case of sparse b.")
+        B, Y = _csc(b), _csc(ysymb)
+        if B.shape[0] != m:
+            raise SdmError("Size mismatch b.")
+        if Y.shape != B.shape:
+            raise SdmError("Size mismatch y.")
+        n = B.shape[1]
+        Bjc, Bir, Bpr = i64(B.indptr), i64(B.indices), f64(B.data)
+        Yjc, Yir = i64(Y.indptr), i64(Y.indices)
+        Ypr = np.zeros(max(int(Yjc[-1]), 1), dtype=np.float64)
+        if fw:
+            check(lib.sdm_fwblkslv_sparse(C.c_int64(m), pi(Ljc), pi(Lir), pf(Lpr), pi(perm), C.c_int64(xs.size - 1), pi(xs),
+                                          C.c_int64(n), pi(Bjc), pi(Bir), pf(Bpr), pi(Yjc), pi(Yir), pf(Ypr)))
+        else:
+            check(lib.sdm_bwblkslv_sparse(C.c_int64(m), pi(Ljc), pi(Lir), pf(Lpr), C.c_int64(xs.size - 1), pi(xs),
+                                          C.c_int64(n), pi(Bjc), pi(Bir), pf(Bpr), pi(Yjc), pi(Yir), pf(Ypr)))
+        return sp.csc_matrix((Ypr[:Yjc[-1]], Y.indices.copy(), Y.indptr.copy()), shape=Y.shape)
+    b = np.asarray(b, dtype=np.float64)
+    if b.ndim == 1:
+        b = b.reshape(-1, 1)
+    if b.shape[0] != m:
+        raise SdmError("Size mismatch b.")
+    n = b.shape[1]
+    bf = f64(b)
+    y = np.zeros(m * n, dtype=np.float64)
+    fn = lib.sdm_fwblkslv if fw else lib.sdm_bwblkslv
+    check(fn(C.c_int64(m), pi(Ljc), pi(Lir), pf(Lpr), pi(perm), C.c_int64(xs.size - 1), pi(xs), C.c_int64(n), pf(bf), pf(y)))
+    return y.reshape((m, n), order="F")
+
+
+def fwblkslv(L, b, ysymb=None):
+    """y = fwblkslv(L, b [,ysymb]):  y = L.L \\ b(L.perm,:)   (fwblkslv.c:193-320)"""
+    return _solve(True, L, b, ysymb)
+
+
+def bwblkslv(L, b, ysymb=None):
+    """y = bwblkslv(L, b [,ysymb]):  y(L.perm,:) = L.L' \\ b   (bwblkslv.c:182-298)"""
+    return _solve(False, L, b, ysymb)

@@ -1,0 +1,31 @@
+"""tests/hipemu/build_emu.py -- TEST INFRASTRUCTURE ONLY.
+Compiles the sedumi_amd/csrc kernel sources with g++ against the fiber emulator
+(hipemu.h) into tests/hipemu/libsedumi_hipemu.so for CPU-side logic tests."""
+import glob
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+CSRC = os.path.join(ROOT, "sedumi_amd", "csrc")
+LIB = os.path.join(HERE, "libsedumi_hipemu.so")
+
+
+def build(force=False):
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "hipemu.*")) + \
+        glob.glob(os.path.join(ROOT, "include", "*.h"))
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(f) <= os.path.getmtime(LIB) for f in deps):
+        return LIB
+    objs = []
+    for s in srcs + [os.path.join(HERE, "hipemu.cpp")]:
+        o = os.path.join(HERE, "_obj_" + os.path.basename(s) + ".o")
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-DSDM_EMU", "-x", "c++", "-I", HERE, "-I", CSRC,
+                               "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-variable", "-c", s, "-o", o])
+        objs.append(o)
+    subprocess.check_call(["g++", "-shared", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))

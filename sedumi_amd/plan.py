@@ -1,0 +1,147 @@
+"""Resident plan: problem data, ADA', the factor and the work vectors stay in HBM across the calls of an
+IPM iteration (tier 2 of include/sedumi_hip.h).
+
+    plan = Plan(device=0)
+    plan.set_chol(L, ADA_pattern)                  # once per solve  (sedumi.m:382-387)
+    plan.set_ada(At, Ablkjc, K, DAtq_pattern)      # once per solve  (sedumi.m:356-378)
+    # every iteration (sedumi.m:442-473):
+    plan.upload("dl", d.l); plan.upload("ddet", d.det); plan.upload("qpr", DAt.q values); plan.upload("udsqr", udsqr)
+    plan.getada(); plan.blkchol(pars); plan.upload("rhs", r); plan.ldlsolve(); y = plan.download("y")
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import capi
+from .capi import SdmError, check, f64, i64, pf, pi
+
+
+class Plan:
+    def __init__(self, device=0, stream=None):
+        self._lib = capi.lib()
+        self._p = self._lib.sdm_plan_create(int(device), C.c_void_p(stream) if stream else None)
+        if not self._p:
+            raise SdmError(self._lib.sdm_last_error().decode())
+        self.m = 0
+        self.nnzL = 0
+        self.nnzADA = 0
+
+    def close(self):
+        if self._p:
+            self._lib.sdm_plan_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------ symbolic
+    def set_chol(self, L, ADA):
+        LL = sp.csc_matrix(L["L"])
+        LL.sort_indices()
+        ADA = sp.csc_matrix(ADA)
+        ADA.sort_indices()
+        m = LL.shape[0]
+        Ljc, Lir = i64(LL.indptr), i64(LL.indices)
+        perm = i64(np.asarray(L["perm"], dtype=np.float64)) - 1
+        xs = i64(np.asarray(L["xsuper"], dtype=np.float64)) - 1
+        jc, ir = i64(ADA.indptr), i64(ADA.indices)
+        check(self._lib.sdm_plan_set_chol(C.c_void_p(self._p), C.c_int64(m), pi(Ljc), pi(Lir), pi(perm),
+                                          C.c_int64(xs.size - 1), pi(xs), pi(jc), pi(ir)))
+        self.m, self.nnzL, self.nnzADA = m, int(Ljc[-1]), int(jc[-1])
+        self.L_pattern, self.ADA_pattern = LL, ADA
+
+    def set_ada(self, At, Ablkjc, K, Qpattern=None):
+        At = sp.csc_matrix(At)
+        At.sort_indices()
+        m = At.shape[1]
+        lpN = int(np.asarray(K["l"]).ravel()[0])
+        q = i64(np.asarray(K["q"], dtype=np.float64))
+        s = i64(np.asarray(K["s"], dtype=np.float64))
+        rsdpN = int(np.asarray(K.get("rsdpN", s.size)).ravel()[0])
+        blkstart = np.asarray(K["blkstart"], dtype=np.float64).ravel()
+        qb = i64(blkstart[1:2 + q.size]) - 1
+        psd = i64(blkstart[1 + q.size:]) - 1
+        Ajc, Air, Apr = i64(At.indptr), i64(At.indices), f64(At.data)
+        Ajc_psd = i64(np.asarray(Ablkjc, dtype=np.float64)[:, 2])
+        if Qpattern is None or q.size == 0:
+            Qjc, Qir = np.zeros(m + 1, dtype=np.int64), np.zeros(1, dtype=np.int64)
+            self.nnzQ = 0
+        else:
+            Q = sp.csc_matrix(Qpattern)
+            Q.sort_indices()
+            Qjc, Qir = i64(Q.indptr), i64(Q.indices)
+            self.nnzQ = int(Qjc[-1])
+        Kc, keep = capi.make_cone(lpN, q, s, rsdpN)
+        check(self._lib.sdm_plan_set_ada(C.c_void_p(self._p), C.c_int64(At.shape[0]), C.c_int64(m), pi(Ajc), pi(Air), pf(Apr),
+                                         pi(Ajc_psd), C.byref(Kc), pi(qb), pi(psd), pi(Qjc), pi(Qir)))
+        del keep
+
+    # ------------------------------------------------------------- buffers
+    def upload(self, name, arr):
+        a = f64(arr)
+        check(self._lib.sdm_plan_upload(C.c_void_p(self._p), name.encode(), pf(a), C.c_int64(a.size)))
+
+    def download(self, name, n=None):
+        if n is None:
+            n = {"ada": self.nnzADA, "lpr": self.nnzL}.get(name, self.m)
+        out = np.zeros(int(n), dtype=np.float64)
+        check(self._lib.sdm_plan_download(C.c_void_p(self._p), name.encode(), pf(out), C.c_int64(out.size)))
+        return out
+
+    def devptr(self, name):
+        n = C.c_int64(0)
+        p = self._lib.sdm_plan_devptr(C.c_void_p(self._p), name.encode(), C.byref(n))
+        if not p:
+            raise SdmError(self._lib.sdm_last_error().decode())
+        return p, n.value
+
+    # ------------------------------------------------------------- numeric
+    def getada(self):
+        check(self._lib.sdm_plan_getada(C.c_void_p(self._p)))
+
+    def blkchol(self, pars=None, use_absd=True):
+        cp = capi.CholPars(1e-12, 5e5, 1e-20)          # checkpars.m:144-168
+        if pars:
+            cp.canceltol = float(pars.get("canceltol", cp.canceltol))
+            cp.maxu = float(pars.get("maxu", cp.maxu))
+            cp.abstol = max(float(pars.get("abstol", cp.abstol)), 0.0)
+        check(self._lib.sdm_plan_blkchol(C.c_void_p(self._p), C.byref(cp), 1 if use_absd else 0))
+
+    def pivots(self):
+        m = self.m
+        ns, na = C.c_int64(0), C.c_int64(0)
+        si, ai = np.zeros(m, dtype=np.int64), np.zeros(m, dtype=np.int64)
+        sv, av = np.zeros(m), np.zeros(m)
+        self._lib.sdm_plan_pivots.argtypes = None
+        check(self._lib.sdm_plan_pivots(C.c_void_p(self._p), C.byref(ns), pi(si), pf(sv), C.byref(na), pi(ai), pf(av)))
+        return (si[:ns.value], sv[:ns.value]), (ai[:na.value], av[:na.value])
+
+    def fwsolve(self):
+        check(self._lib.sdm_plan_fwsolve(C.c_void_p(self._p)))
+
+    def bwsolve(self):
+        check(self._lib.sdm_plan_bwsolve(C.c_void_p(self._p)))
+
+    def ldlsolve(self):
+        check(self._lib.sdm_plan_ldlsolve(C.c_void_p(self._p)))
+
+    def sync(self):
+        check(self._lib.sdm_plan_sync(C.c_void_p(self._p)))
+
+    # --------------------------------------------------------------- timing
+    def timer_begin(self, slot):
+        check(self._lib.sdm_plan_timer_begin(C.c_void_p(self._p), slot))
+
+    def timer_end(self, slot):
+        check(self._lib.sdm_plan_timer_end(C.c_void_p(self._p), slot))
+
+    def timer_ms(self, slot):
+        ms = C.c_float(0)
+        check(self._lib.sdm_plan_timer_ms(C.c_void_p(self._p), slot, C.byref(ms)))
+        return float(ms.value)

@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py -- IPM iterations per second of the normal-equations hot path on MI355X.
+
+One "step" = one IPM iteration unit (sedumi.m:450-473) on frozen, HBM-resident inputs:
+    1 x (getada1 + getada2 + getada3)  ->  1 x blkchol  ->  4 x (fwblkslv, ./L.d, bwblkslv)   (single RHS each)
+Workload at N=1: the control07-shaped SDP of BASELINE.json configs[1] (m=666, K.s=[70 35], dense ADA',
+synthetic data of that shape -- the reference's examples do not travel to the GPU box).
+
+N>1 (launched with torch.distributed.run, one rank per GPU): the single dense supernode of this workload
+does not shard, so every rank runs an independent replica of the unit ("replicas
+only") -- weak scaling, no data-path collective; barrier + max-over-ranks timing.
+
+Prints ONE JSON line (rank 0) with the fields the driver expects plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PARS = {"canceltol": 1e-12, "maxu": 5e5, "abstol": 1e-20}          # checkpars.m:144-168
+HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md: HBM3E 8 TB/s
+NSOLVE = 4
+
+
+def build_workload(name, seed):
+    from sedumi_amd import problem
+    if name == "control07":
+        P = problem.control_like(seed=seed)
+    elif name.startswith("maxcut"):
+        P = problem.maxcut(int(name[6:] or 4000))
+    else:
+        raise SystemExit("unknown workload " + name)
+    L, ADA, Q = problem.dense_symbolic(P.m), problem.dense_pattern(P.m), problem.lorentz_pattern(P)
+    d, ud = problem.spd_scaling(P.K, seed=seed + 5)
+    rhs = np.random.default_rng(seed).standard_normal(P.m)
+    return P, L, ADA, Q, d, ud, rhs
+
+
+def cpu_baseline(P, d, ud, rhs, budget_s=12.0):
+    """The compiled reference MEX (oracle/_ref) timed on this host, one thread, on a bounded sample of the
+    same workload: repeated iteration units until ~budget_s of CPU time is spent."""
+    try:
+        from oracle import glue as gl, refmex
+        if not refmex.available():
+            return None
+        G = gl.Glue()
+        ref = G.ref
+        S = G.setup(P.At, P.K)
+        K = P.K
+        dd = {"l": d["l"], "det": d["det"], "q1": np.ones(K["q"].size),
+              "q2": np.zeros(int(K["mainblks"].ravel()[2] - K["mainblks"].ravel()[1]))}
+        DAt = G.getDAtm(S, dd)
+        dstruct = {"l": dd["l"].reshape(-1, 1), "det": dd["det"].reshape(-1, 1)}
+        units, tot = 0, 0.0
+        t_wall = time.perf_counter()
+        while True:
+            t1, ADA1 = ref.timed_call("getada1", 1, (S["ADA"], S["A"], S["Ablkjc"][:, 2], S["Aord"]["lqperm"], dstruct, K["qblkstart"]))
+            t2, ADA2 = ref.timed_call("getada2", 1, (ADA1, DAt, S["Aord"], K))
+            t3, (ADA3, absd) = ref.timed_call("getada3", 2, (ADA2, S["A"], S["Ablkjc"][:, 2], S["Aord"], ud.reshape(-1, 1), K))
+            t4, (LL, Ld, _, _) = ref.timed_call("blkchol", 4, (S["L"], ADA3, dict(PARS), absd))
+            L = dict(S["L"]); L["L"] = LL
+            ts = 0.0
+            for _ in range(NSOLVE):
+                tf, p = ref.timed_call("fwblkslv", 1, (L, rhs.reshape(-1, 1)))
+                tb, _y = ref.timed_call("bwblkslv", 1, (L, p / Ld))
+                ts += tf[0] + tb[0]
+            tot += t1[0] + t2[0] + t3[0] + t4[0] + ts
+            units += 1
+            if tot >= budget_s or time.perf_counter() - t_wall > 3 * budget_s or units >= 400:
+                break
+        return {"value": units / tot, "unit": "IPM iters/s", "cores": 1, "kind": "reference",
+                "sample": f"{units} iteration units of {P.name} through oracle/_ref (unmodified reference C, gcc -O2, "
+                          f"naive BLAS-1), MEX calls only ({tot:.1f} s CPU)"}
+    except Exception as e:  # the baseline must never break the bench line
+        return {"value": None, "unit": "IPM iters/s", "cores": 1, "kind": "reference", "sample": f"failed: {e}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="control07")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    from sedumi_amd.plan import Plan
+    P, L, ADA, Q, d, ud, rhs = build_workload(args.workload, seed=rank)
+    plan = Plan(local_rank)
+    plan.set_chol(L, ADA)
+    plan.set_ada(P.At, P.Ablkjc, P.K, Q)
+    plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud); plan.upload("rhs", rhs)
+
+    def step():
+        plan.getada()
+        plan.blkchol(PARS, True)
+        for _ in range(NSOLVE):
+            plan.ldlsolve()
+
+    def barrier():
+        plan.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    plan.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline leg: the dominant kernel's launches timed with HIP events on the plan's stream
+    # (same steps, events around every launch; the un-instrumented loop above gives `value`).
+    plan.kprof(True)
+    for _ in range(min(args.steps, 50)):
+        step()
+    prof = plan.kprof_summary()
+    plan.kprof(False)
+    nprof = min(args.steps, 50)
+    m, nnzL = plan.m, plan.nnzL
+    solve_bytes = 8.0 * nnzL + 8.0 * m + 16.0 * m       # 8*nnz(L) + 8*len(lindx) + 16*m per solve
+    dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
+    roof = None
+    if dom:
+        calls, ms = prof[dom]
+        avg_s = ms / calls * 1e-3
+        if dom in ("k_fw_level", "k_bw_level"):
+            alg_bytes = solve_bytes
+        elif dom in ("k_psd_stage1", "k_psd_stage2"):
+            alg_bytes = 8.0 * (ud.size + P.At.nnz + plan.nnzADA)          # SURVEY.md 8(d) getada3 lower bound
+        else:
+            alg_bytes = 8.0 * (plan.nnzADA / 2 + 2 * nnzL) / max(1, calls // nprof)   # factor: 8*(nnz(tril ADA)+2 nnz(L)) per unit
+        ach = alg_bytes / avg_s / 1e9
+        roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_per_step": calls / nprof,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "stage_ms_per_step": {k: v[1] / nprof for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                roof["traffic"] = json.load(open(pmc)).get(dom)
+            except Exception:
+                pass
+
+    if rank == 0:
+        base = None
+        if world == 1 and not args.no_cpu_baseline:
+            base = cpu_baseline(P, d, ud, rhs)
+        out = {
+            "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": world * args.steps / elapsed, "unit": "IPM iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{P.name}: control07-shaped SDP (BASELINE.json configs[1]), m={P.m}, nnz(At)={P.At.nnz}, "
+                                   f"dense ADA' {P.m}x{P.m}, nnz(L)={nnzL}; unit = getada1+2+3, blkchol, {NSOLVE}x(fwblkslv,./d,bwblkslv)",
+                       "parallelism": "replicas" if world > 1 else "single GPU"},
+            "roofline": roof, "cpu_baseline": base,
+        }
+        if base and base.get("value"):
+            out["speedup_vs_cpu_reference"] = out["value"] / world / base["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -208,6 +208,13 @@ int sdm_plan_timer_begin(sdm_plan *p, int slot);
 int sdm_plan_timer_end(sdm_plan *p, int slot);
 int sdm_plan_timer_ms(sdm_plan *p, int slot, float *ms);
 
+/* Per-kernel timing: while enabled every kernel launch of the plan is bracketed by HIP events on the
+ * plan's stream.  kprof_get returns the number of launches and the summed duration of one kernel (by its
+ * unqualified name, e.g. "k_bw_level"); kprof_summary writes "name:calls:ms;" for all kernels seen. */
+int sdm_plan_kprof_enable(sdm_plan *p, int on);
+int sdm_plan_kprof_get(sdm_plan *p, const char *kernel, sdm_int *calls, double *total_ms);
+int sdm_plan_kprof_summary(sdm_plan *p, char *buf, sdm_int buflen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -343,14 +343,14 @@ void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
   AdaPlan &A = P->ada;
   hipStream_t st = P->stream;
   if (A.nlq > 0)
-    SDM_LAUNCH(k_dsqr, dim3((unsigned)((A.nlq + 255) / 256)), dim3(256), 0, st, A.dsqr.p, A.dsqr_code.p, A.dl.p, A.ddet.p, (int)A.nlq);
-  SDM_LAUNCH(k_ada_spdot, dim3((unsigned)A.m), dim3(256), 0, st, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p,
+    SDM_KLAUNCH(P, k_dsqr, dim3((unsigned)((A.nlq + 255) / 256)), dim3(256), 0, A.dsqr.p, A.dsqr_code.p, A.dl.p, A.ddet.p, (int)A.nlq);
+  SDM_KLAUNCH(P, k_ada_spdot, dim3((unsigned)A.m), dim3(256), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p,
              A.d_Air.p, A.d_Apr.p, A.dsqr.p, d_invperm, accumulate ? 1 : 0);
 }
 void ada_q(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
   AdaPlan &A = P->ada;
   if (A.lorN == 0 || A.nnzQ == 0) return;
-  SDM_LAUNCH(k_ada_spdot, dim3((unsigned)A.m), dim3(256), 0, P->stream, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Qjc.p, A.d_Qjc.p + 1,
+  SDM_KLAUNCH(P, k_ada_spdot, dim3((unsigned)A.m), dim3(256), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Qjc.p, A.d_Qjc.p + 1,
              A.d_Qir.p, A.qpr.p, (const double *)nullptr, d_invperm, accumulate ? 1 : 0);
 }
 void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
@@ -359,10 +359,10 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
   const int m = (int)A.m;
   if (A.sdpN == 0) {
     if (sym_input) {
-      SDM_LAUNCH(k_symmetrize, dim3(m), dim3(128), 0, st, A.symtmp.p, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_ADAT.p, m);
+      SDM_KLAUNCH(P, k_symmetrize, dim3(m), dim3(128), 0, A.symtmp.p, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_ADAT.p, m);
       SDM_HIP_CHECK(hipMemcpyAsync(ada, A.symtmp.p, A.symtmp.n * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
-    SDM_LAUNCH(k_diag, dim3((m + 255) / 256), dim3(256), 0, st, P->absd.p, ada, A.d_ADAjc.p, A.d_ADAir.p, m);
+    SDM_KLAUNCH(P, k_diag, dim3((m + 255) / 256), dim3(256), 0, P->absd.p, ada, A.d_ADAjc.p, A.d_ADAir.p, m);
     return;
   }
   if (A.ntask > 0) {
@@ -374,16 +374,16 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
 #ifndef SDM_EMU
     SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A.stage1_lds));
 #endif
-    SDM_LAUNCH(k_psd_stage1, dim3((unsigned)A.ntask), dim3(256), A.stage1_lds, st, T, A.udsqr.p, A.zbuf.p,
+    SDM_KLAUNCH(P, k_psd_stage1, dim3((unsigned)A.ntask), dim3(256), A.stage1_lds, T, A.udsqr.p, A.zbuf.p,
                (int)(A.stage1_lds / sizeof(double)));
   }
   // the reference first adds the PSD part on one triangle and symmetrises at the very end; summing the
   // transposed partial sums of getada1/2 first and adding the (symmetric) PSD part afterwards is the same sum.
   if (sym_input) {
-    SDM_LAUNCH(k_symmetrize, dim3(m), dim3(128), 0, st, A.symtmp.p, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_ADAT.p, m);
+    SDM_KLAUNCH(P, k_symmetrize, dim3(m), dim3(128), 0, A.symtmp.p, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_ADAT.p, m);
     SDM_HIP_CHECK(hipMemcpyAsync(ada, A.symtmp.p, A.symtmp.n * sizeof(double), hipMemcpyDeviceToDevice, st));
   }
-  SDM_LAUNCH(k_psd_stage2, dim3(m), dim3(256), (size_t)A.sdpN * 8, st, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p,
+  SDM_KLAUNCH(P, k_psd_stage2, dim3(m), dim3(256), (size_t)A.sdpN * 8, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p,
              A.d_Ajc_psd.p, A.d_Apr.p, A.d_Ablk.p, A.d_Aupos.p, A.c_taskptr.p, A.t_blk.p, A.t_zoff.p, A.zbuf.p, d_invperm,
              (int)A.sdpN, A.thread_per_row ? 1 : 0);
   SDM_HIP_CHECK(hipGetLastError());

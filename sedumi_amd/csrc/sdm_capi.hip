@@ -208,6 +208,42 @@ int sdm_plan_timer_ms(sdm_plan *p, int slot, float *ms) {
   SDM_CATCH
 }
 
+// per-kernel timing (HIP events around every launch of the plan while enabled)
+int sdm_plan_kprof_enable(sdm_plan *p, int on) {
+  SDM_TRY
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  for (auto &r : p->kprof.recs) { p->kprof.pool.push_back(r.a); p->kprof.pool.push_back(r.b); }
+  p->kprof.recs.clear();
+  p->kprof.enabled = on != 0;
+  SDM_CATCH
+}
+int sdm_plan_kprof_get(sdm_plan *p, const char *kernel, sdm_int *calls, double *total_ms) {
+  SDM_TRY
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  sdm_int n = 0; double tot = 0.0;
+  for (auto &r : p->kprof.recs)
+    if (std::string(r.name) == kernel) { float ms = 0; SDM_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b)); tot += ms; n++; }
+  if (calls) *calls = n;
+  if (total_ms) *total_ms = tot;
+  SDM_CATCH
+}
+// writes "name:calls:ms;" records for every kernel seen into buf (truncated to buflen)
+int sdm_plan_kprof_summary(sdm_plan *p, char *buf, sdm_int buflen) {
+  SDM_TRY
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  std::vector<std::string> names; std::vector<sdm_int> cnt; std::vector<double> tot;
+  for (auto &r : p->kprof.recs) {
+    float ms = 0; SDM_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+    size_t i = 0; for (; i < names.size(); i++) if (names[i] == r.name) break;
+    if (i == names.size()) { names.push_back(r.name); cnt.push_back(0); tot.push_back(0.0); }
+    cnt[i]++; tot[i] += ms;
+  }
+  std::string out;
+  for (size_t i = 0; i < names.size(); i++) out += names[i] + ":" + std::to_string(cnt[i]) + ":" + std::to_string(tot[i]) + ";";
+  if (buflen > 0) { size_t n = std::min<size_t>(out.size(), (size_t)buflen - 1); memcpy(buf, out.data(), n); buf[n] = 0; }
+  SDM_CATCH
+}
+
 // ------------------------------------------------- tier (1): MEX equivalents
 struct PlanGuard {
   sdm_plan *p;

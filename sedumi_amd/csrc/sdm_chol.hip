@@ -557,33 +557,33 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
   const int m = (int)C.m;
   
   SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), st));
-  SDM_LAUNCH(k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, st, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
+  SDM_KLAUNCH(P, k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
              C.d_asm_dst.p, (int64_t)C.nnzL);
-  SDM_LAUNCH(k_prep_pivots, dim3(1), dim3(256), 0, st, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
+  SDM_KLAUNCH(P, k_prep_pivots, dim3(1), dim3(256), 0, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
              P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p);
   for (int l = 0; l < C.nlevels; l++) {
     const int *list = C.d_levlist.p + C.levptr[l];
     const int nfr = C.levptr[l + 1] - C.levptr[l];
-    if (l > 0) SDM_LAUNCH(k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, st, C.fronts.p, tab, list);
+    if (l > 0) SDM_KLAUNCH(P, k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, C.fronts.p, tab, list);
     for (int li = C.lev_first_launch[l]; li < C.lev_first_launch[l + 1]; li++) {
       const LevelLaunch &L = C.launches[li];
-      SDM_LAUNCH(k_ldl_diag, dim3(L.nactive), dim3(256), 0, st, C.fronts.p, tab, list, L.panel, C.d.p, C.lb.p, C.ub.p,
+      SDM_KLAUNCH(P, k_ldl_diag, dim3(L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p, C.lb.p, C.ub.p,
                  C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m);
       if (L.maxrows > 0) {
-        SDM_LAUNCH(k_ldl_panel, dim3((L.maxrows + 255) / 256, L.nactive), dim3(256), 0, st, C.fronts.p, tab, list,
+        SDM_KLAUNCH(P, k_ldl_panel, dim3((L.maxrows + 255) / 256, L.nactive), dim3(256), 0, C.fronts.p, tab, list,
                    L.panel, C.d.p);
-        SDM_LAUNCH(k_ldl_update, dim3(L.maxtiles, L.nactive), dim3(256), 0, st, C.fronts.p, tab, list, L.panel, C.d.p);
+        SDM_KLAUNCH(P, k_ldl_update, dim3(L.maxtiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p);
       }
     }
   }
-  SDM_LAUNCH(k_dsolve, dim3((m + 255) / 256), dim3(256), 0, st, C.dsolve.p, C.d.p, m);
+  SDM_KLAUNCH(P, k_dsolve, dim3((m + 255) / 256), dim3(256), 0, C.dsolve.p, C.d.p, m);
   SDM_HIP_CHECK(hipGetLastError());
   P->factored = true;
 }
 
 void chol_extract(sdm_plan *P, double *d_Lpr_out) {
   CholPlan &C = P->chol;
-  SDM_LAUNCH(k_extract, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, P->stream, d_Lpr_out, C.fronts.p, C.d_asm_dst.p,
+  SDM_KLAUNCH(P, k_extract, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, d_Lpr_out, C.fronts.p, C.d_asm_dst.p,
              (int64_t)C.nnzL);
 }
 
@@ -591,7 +591,7 @@ void chol_load_factor(sdm_plan *P, const double *h_Lpr) {
   CholPlan &C = P->chol;
   DevBuf<double> tmp;
   tmp.upload(h_Lpr, (size_t)C.nnzL);
-  SDM_LAUNCH(k_load_factor, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, P->stream, C.fronts.p, tmp.p, C.d_asm_dst.p,
+  SDM_KLAUNCH(P, k_load_factor, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, tmp.p, C.d_asm_dst.p,
              (int64_t)C.nnzL);
   SDM_HIP_CHECK(hipStreamSynchronize(P->stream));
   P->factored = true;
@@ -602,7 +602,7 @@ void solve_fw(sdm_plan *P) {
   FrontTab tab = front_tab(C);
   for (int l = 0; l < C.nlevels; l++) {
     const int nfr = C.levptr[l + 1] - C.levptr[l];
-    SDM_LAUNCH(k_fw_level, dim3(nfr), dim3(512), 0, P->stream, C.fronts.p, tab, C.d_levlist.p + C.levptr[l], C.wvec.p,
+    SDM_KLAUNCH(P, k_fw_level, dim3(nfr), dim3(512), 0, C.fronts.p, tab, C.d_levlist.p + C.levptr[l], C.wvec.p,
                P->ywork.p);
   }
 }
@@ -611,16 +611,16 @@ void solve_bw(sdm_plan *P) {
   FrontTab tab = front_tab(C);
   for (int l = C.nlevels - 1; l >= 0; l--) {
     const int nfr = C.levptr[l + 1] - C.levptr[l];
-    SDM_LAUNCH(k_bw_level, dim3(nfr), dim3(512), 0, P->stream, C.fronts.p, tab, C.d_levlist.p + C.levptr[l], P->ywork.p);
+    SDM_KLAUNCH(P, k_bw_level, dim3(nfr), dim3(512), 0, C.fronts.p, tab, C.d_levlist.p + C.levptr[l], P->ywork.p);
   }
 }
 void vec_gather(sdm_plan *P, double *dst, const double *src, bool forward) {
   const int m = (int)P->chol.m;
-  SDM_LAUNCH(k_gather_perm, dim3((m + 255) / 256), dim3(256), 0, P->stream, dst, src, P->chol.d_perm.p, m, forward ? 1 : 0);
+  SDM_KLAUNCH(P, k_gather_perm, dim3((m + 255) / 256), dim3(256), 0, dst, src, P->chol.d_perm.p, m, forward ? 1 : 0);
 }
 void vec_divd(sdm_plan *P, double *v) {
   const int m = (int)P->chol.m;
-  SDM_LAUNCH(k_divd, dim3((m + 255) / 256), dim3(256), 0, P->stream, v, P->chol.dsolve.p, m);
+  SDM_KLAUNCH(P, k_divd, dim3((m + 255) / 256), dim3(256), 0, v, P->chol.dsolve.p, m);
 }
 
 }  // namespace sdm

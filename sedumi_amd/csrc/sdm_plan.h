@@ -94,8 +94,24 @@ struct AdaPlan {
 
 }  // namespace sdm
 
+namespace sdm {
+// optional per-kernel HIP-event timing (bench.py roofline leg): every launch made through SDM_KLAUNCH is
+// bracketed by two events on the plan's stream while enabled.
+struct KProf {
+  bool enabled = false;
+  struct Rec { const char *name; hipEvent_t a, b; };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; SDM_HIP_CHECK(hipEventCreate(&e)); return e;
+  }
+};
+}  // namespace sdm
+
 struct sdm_plan {
   int device = 0;
+  sdm::KProf kprof;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   bool has_chol = false, has_ada = false, factored = false;
@@ -105,6 +121,19 @@ struct sdm_plan {
   std::vector<sdm_int> ada_jc, ada_ir;   // host copy of the ADA pattern
   hipEvent_t ev_begin[16] = {}, ev_end[16] = {};
 };
+
+#define SDM_KLAUNCH(P, kernel, grid, block, shmem, ...)                                   \
+  do {                                                                                     \
+    if ((P)->kprof.enabled) {                                                              \
+      sdm::KProf::Rec r_; r_.name = #kernel; r_.a = (P)->kprof.get(); r_.b = (P)->kprof.get(); \
+      SDM_HIP_CHECK(hipEventRecord(r_.a, (P)->stream));                                    \
+      SDM_LAUNCH(kernel, grid, block, shmem, (P)->stream, __VA_ARGS__);                    \
+      SDM_HIP_CHECK(hipEventRecord(r_.b, (P)->stream));                                    \
+      (P)->kprof.recs.push_back(r_);                                                       \
+    } else {                                                                               \
+      SDM_LAUNCH(kernel, grid, block, shmem, (P)->stream, __VA_ARGS__);                    \
+    }                                                                                      \
+  } while (0)
 
 namespace sdm {
 void set_error(const std::string &msg);

@@ -232,3 +232,74 @@ def fwblkslv(L, b, ysymb=None):
 def bwblkslv(L, b, ysymb=None):
     """y = bwblkslv(L, b [,ysymb]):  y(L.perm,:) = L.L' \\ b   (bwblkslv.c:182-298)"""
     return _solve(False, L, b, ysymb)
+
+
+# ------------------------------------------------------------------ symbolic
+def ordmmdmex(X):
+    """perm = ordmmdmex(X): multiple-minimum-degree ordering of spones(X)   (ordmmdmex.c:75-139)"""
+    if not sp.issparse(X):
+        raise SdmError("Input matrix must be sparse")
+    X = _csc(X)
+    m = X.shape[0]
+    if X.shape != (m, m):
+        raise SdmError("X should be square.")
+    jc, ir = i64(X.indptr), i64(X.indices)
+    perm = np.zeros(m, dtype=np.int64)
+    check(capi.lib().sdm_ordmmd(C.c_int64(m), pi(jc), pi(ir), pi(perm)))
+    return (perm + 1).astype(np.float64).reshape(-1, 1)
+
+
+def symfctmex(X, perm):
+    """L = symfctmex(X, perm) -> L.{L, perm, xsuper}   (symfctmex.c:127-272)"""
+    X = _csc(X)
+    m = X.shape[0]
+    if X.shape != (m, m):
+        raise SdmError("X must be square")
+    p0 = _perm0(perm, m, "perm")
+    jc, ir = i64(X.indptr), i64(X.indices)
+    nsuper, nnzl = C.c_int64(0), C.c_int64(0)
+    lib = capi.lib()
+    check(lib.sdm_symfct(C.c_int64(m), pi(jc), pi(ir), pi(p0), None, C.byref(nsuper), None, C.byref(nnzl), None, None))
+    pout = np.zeros(m, dtype=np.int64)
+    xs = np.zeros(nsuper.value + 1, dtype=np.int64)
+    Ljc = np.zeros(m + 1, dtype=np.int64)
+    Lir = np.zeros(max(nnzl.value, 1), dtype=np.int64)
+    check(lib.sdm_symfct(C.c_int64(m), pi(jc), pi(ir), pi(p0), pi(pout), C.byref(nsuper), pi(xs), C.byref(nnzl), pi(Ljc), pi(Lir)))
+    LL = sp.csc_matrix((np.ones(nnzl.value), Lir[:nnzl.value], Ljc), shape=(m, m))
+    return {"L": LL, "perm": (pout + 1).astype(np.float64).reshape(-1, 1), "xsuper": (xs + 1).astype(np.float64).reshape(-1, 1)}
+
+
+def choltmpsiz(L):
+    """tmpsiz = choltmpsiz(L)   (choltmpsiz.c:110-173)"""
+    LL = _csc(_field(L, "L", "L"))
+    m = LL.shape[0]
+    xs = i64(np.asarray(_field(L, "xsuper", "L"), dtype=np.float64)) - 1
+    jc, ir = i64(LL.indptr), i64(LL.indices)
+    out = C.c_int64(0)
+    check(capi.lib().sdm_choltmpsiz(C.c_int64(m), pi(jc), pi(ir), C.c_int64(xs.size - 1), pi(xs), C.byref(out)))
+    return np.array([[float(out.value)]])
+
+
+def cholsplit(L, cachsz):
+    """split = cholsplit(L, cachsz)   (cholsplit.c:118-184)"""
+    LL = _csc(_field(L, "L", "L"))
+    m = LL.shape[0]
+    xs = i64(np.asarray(_field(L, "xsuper", "L"), dtype=np.float64)) - 1
+    jc = i64(LL.indptr)
+    split = np.zeros(max(m, 1), dtype=np.int64)
+    check(capi.lib().sdm_cholsplit(C.c_int64(m), pi(jc), C.c_int64(xs.size - 1), pi(xs), C.c_int64(int(np.asarray(cachsz).ravel()[0])), pi(split)))
+    return split[:m].astype(np.float64).reshape(-1, 1)
+
+
+def symbchol(ADA, cachsz=512):
+    """symbchol.m:62-83 on top of the entry points above (MATLAB glue, host only)."""
+    ADA = _csc(ADA)
+    m = ADA.shape[0]
+    if ADA.nnz < m * m:
+        L = symfctmex(ADA, ordmmdmex(ADA))
+    else:
+        L = {"perm": np.arange(1, m + 1, dtype=np.float64).reshape(-1, 1), "L": sp.csc_matrix(np.tril(np.ones((m, m)))),
+             "xsuper": np.array([[1.0], [m + 1.0]])}
+    L["tmpsiz"] = choltmpsiz(L)
+    L["split"] = cholsplit(L, cachsz)
+    return L

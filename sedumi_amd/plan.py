@@ -134,6 +134,20 @@ class Plan:
     def sync(self):
         check(self._lib.sdm_plan_sync(C.c_void_p(self._p)))
 
+    # ------------------------------------------------------ per-kernel timing
+    def kprof(self, on):
+        check(self._lib.sdm_plan_kprof_enable(C.c_void_p(self._p), 1 if on else 0))
+
+    def kprof_summary(self):
+        buf = C.create_string_buffer(8192)
+        check(self._lib.sdm_plan_kprof_summary(C.c_void_p(self._p), buf, C.c_int64(8192)))
+        out = {}
+        for rec in buf.value.decode().split(";"):
+            if rec:
+                name, calls, ms = rec.rsplit(":", 2)
+                out[name] = (int(calls), float(ms))
+        return out
+
     # --------------------------------------------------------------- timing
     def timer_begin(self, slot):
         check(self._lib.sdm_plan_timer_begin(C.c_void_p(self._p), slot))

@@ -1,0 +1,155 @@
+"""Kernel-logic parity on CPU: the HIP kernel sources of sedumi_amd/csrc compiled against the fiber emulator
+(tests/hipemu) and run through the same C ABI / MEX-mirror calls as on the GPU, against the compiled reference.
+These tests exist because the build container has no GPU; the GPU parity tests proper are test_gpu_parity.py."""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from helpers import TOL, check_golden, check_iteration, relerr, spd_pattern, use_emu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _emu():
+    use_emu()
+
+
+def _set_reverse(rev):
+    from sedumi_amd import capi
+    lib = ctypes.CDLL(capi._lib_path)
+    lib._Z15emu_set_reversei(int(rev))
+
+
+@pytest.mark.parametrize("seed,kw", [(0, {}), (1, dict(m=20, lp=0, q=(), s=(6, 3))), (2, dict(m=35, lp=8, q=(4, 3, 5), s=())),
+                                     (3, dict(m=40, block_local=True)), (4, dict(m=16, lp=3, q=(3,), s=(9,), dens=0.9))])
+def test_iteration_unit_small_mixed_cones(glue, seed, kw):
+    from sedumi_amd import problem
+    P = problem.random_sdp(seed=seed, **kw)
+    for rev in (0, 1):                       # both work-item schedules: a missing barrier shows up in one of them
+        _set_reverse(rev)
+        check_iteration(glue, P, seed=seed)
+    _set_reverse(0)
+    check_iteration(glue, P, seed=seed, identity=True)
+
+
+def test_iteration_unit_block_diagonal_multi_supernode(glue):
+    from sedumi_amd import problem
+    P = problem.blockdiag_sdp(nblk=5, n=12, mper=9, nnz=5, seed=3)
+    errs, S, _ = check_iteration(glue, P, seed=1)
+    assert S["L"]["xsuper"].size - 1 > 1
+
+
+def test_golden_arch0():
+    for tag in ("init", "rand"):
+        errs = check_golden("arch0", tag)
+        assert max(errs.values()) < TOL, errs
+
+
+@pytest.mark.parametrize("kind,m", [("rand", 120), ("band", 90), ("arrow", 70), ("blockdiag", 100), ("grid", 100), ("diag", 9)])
+def test_sparse_factor_and_solves(refmex, glue, kind, m):
+    from oracle import glue as gl
+    from sedumi_amd import mex
+    rng = np.random.default_rng(m)
+    X = spd_pattern(kind, m, rng, 0.04)
+    L = mex.symbchol(X)                       # own ordering + symbolic (bit-exact with the reference, test_oracle.py)
+    pars = gl.default_pars_chol()
+    r = refmex.call("blkchol", 4, L, X, pars)
+    o = mex.blkchol(L, X, pars)
+    assert relerr(o[0], r[0]) < TOL and relerr(o[1], r[1]) < TOL
+    L2 = dict(L); L2["L"] = r[0]
+    rhs = rng.standard_normal((X.shape[0], 3))
+    assert relerr(mex.fwblkslv(L2, rhs), refmex.call("fwblkslv", 1, L2, rhs)) < TOL
+    assert relerr(mex.bwblkslv(L2, rhs), refmex.call("bwblkslv", 1, L2, rhs)) < TOL
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_pivot_decisions_skip_and_add(refmex, glue, case):
+    """Never-fail pivot rule (blkchol2.c:114-161): same skipped / diag-added columns as the reference."""
+    from oracle import glue as gl
+    from sedumi_amd import mex
+    rng = np.random.default_rng(50 + case)
+    m = [40, 90, 70, 100, 64, 33][case]
+    if case % 2 == 0:
+        B = rng.standard_normal((m, m // 2))
+        X = B @ B.T
+        X = sp.csc_matrix(X + np.diag(10.0 ** rng.uniform(-14, -2, m)) * np.abs(X).max())
+    else:
+        S = sp.random(m, m, density=0.05, random_state=rng, format="csc"); S = S + S.T
+        sc = 10.0 ** rng.uniform(-7, 3, m)
+        X = sp.diags(sc) @ (S + sp.diags(np.asarray(abs(S).sum(axis=1)).ravel() * rng.choice([1.0, 1.0, 0.5], m) + 1e-3)) @ sp.diags(sc)
+        X = sp.csc_matrix(X); X.sort_indices()
+    L = glue.symbchol(X)
+    for maxu in (5e5, 30.0, 2.0):
+        pars = dict(gl.default_pars_chol()); pars["maxu"] = maxu
+        absd = np.abs(X.diagonal()) * rng.choice([1.0, 1e3, 1e8], m) if case > 2 else None
+        args = (L, X, pars) + ((absd,) if absd is not None else ())
+        r = refmex.call("blkchol", 4, *args)
+        o = mex.blkchol(*args)
+        assert np.array_equal(o[2].indices, r[2].indices) and np.array_equal(o[3].indices, r[3].indices)
+        assert relerr(o[1], r[1]) < 1e-8
+        if r[2].nnz:
+            assert relerr(o[2], r[2]) < 1e-6
+        if r[3].nnz:
+            assert relerr(o[3], r[3]) < 1e-6
+
+
+def test_sparse_rhs_solves(refmex, glue):
+    """fwblkslv / bwblkslv with a sparse right-hand side and the symbfwblk pattern (deninfac.m:67)."""
+    from oracle import glue as gl
+    from sedumi_amd import mex
+    rng = np.random.default_rng(3)
+    X = spd_pattern("rand", 80, rng, 0.05)
+    L = glue.symbchol(X)
+    r = refmex.call("blkchol", 4, L, X, gl.default_pars_chol())
+    L2 = dict(L); L2["L"] = r[0]
+    B = sp.random(80, 4, density=0.05, random_state=rng, format="csc")
+    Ys = refmex.call("symbfwblk", 1, L2, B)
+    yr = refmex.call("fwblkslv", 1, L2, B, Ys)
+    yo = mex.fwblkslv(L2, B, Ys)
+    assert np.array_equal(yo.indices, yr.indices) and relerr(yo, yr) < TOL
+
+
+def test_resident_plan_matches_reference(glue):
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    from helpers import ref_scaling
+    P = problem.random_sdp(m=30, seed=9)
+    S = glue.setup(P.At, P.K)
+    d, ud = ref_scaling(P, 4)
+    it = glue.iteration_ref(S, d, ud)
+    rhs = np.random.default_rng(1).standard_normal(P.m)
+    plan = Plan(0)
+    plan.set_chol(S["L"], S["ADA"])
+    Qpat = sp.csc_matrix(S["DAt"]["q"])
+    plan.set_ada(P.At, P.Ablkjc, P.K, Qpat)
+    Qn = sp.csc_matrix(it["DAt"]["q"])
+    cols = np.repeat(np.arange(P.m), np.diff(Qpat.indptr))
+    plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud); plan.upload("rhs", rhs)
+    if Qpat.nnz:
+        plan.upload("qpr", np.asarray(Qn[Qpat.indices, cols]).ravel())
+    plan.getada(); plan.blkchol(None, True); plan.ldlsolve()
+    assert relerr(plan.download("ada"), it["ADA"].data) < TOL
+    assert relerr(plan.download("absd"), it["absd"].ravel()) < TOL
+    assert relerr(plan.download("d"), it["Ld"].ravel()) < TOL
+    assert relerr(plan.download("lpr"), it["LL"].data) < TOL
+    assert relerr(plan.download("y"), glue.solve_ref(S, it, rhs).ravel()) < TOL
+    (si, sv), (ai, av) = plan.pivots()
+    assert len(si) == it["Lskip"].nnz and len(ai) == it["Ladd"].nnz
+    prof_before = plan.kprof_summary()
+    plan.kprof(True); plan.ldlsolve(); prof = plan.kprof_summary(); plan.kprof(False)
+    assert not prof_before and "k_fw_level" in prof and "k_bw_level" in prof
+    plan.close()
+
+
+def test_bad_inputs_raise_like_mexErrMsgTxt():
+    from sedumi_amd import mex
+    from sedumi_amd.capi import SdmError
+    L = {"L": sp.csc_matrix(np.tril(np.ones((4, 4)))), "perm": np.arange(1, 5.0)}
+    with pytest.raises(SdmError, match="Missing field L.xsuper"):
+        mex.fwblkslv(L, np.ones(4))
+    L["xsuper"] = np.array([1.0, 5.0])
+    with pytest.raises(SdmError, match="Size mismatch b"):
+        mex.fwblkslv(L, np.ones(5))
+    with pytest.raises(SdmError):
+        mex.fwblkslv(L, sp.csc_matrix(np.ones((4, 1))))       # sparse b needs ysymb (fwblkslv.c:243-244)

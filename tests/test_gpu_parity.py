@@ -1,0 +1,197 @@
+"""Parity tests proper: the HIP path on a real MI355X, through the C ABI, against the oracle (compiled reference in
+oracle/_ref -- it travels to the GPU box as a built artefact -- and the committed golden fixtures), plus
+size-independent properties at the BASELINE.json sizes.  Run with `pytest -m gpu`."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from helpers import TOL, check_golden, check_iteration, ref_scaling, relerr, spd_pattern, use_hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _hip():
+    use_hip()
+
+
+def test_native_library_is_the_one_loaded():
+    from sedumi_amd import capi
+    assert capi.backend() == "hip-gfx950"
+    assert capi._lib_path is None and capi.lib()._name.endswith("sedumi_amd/lib/libsedumi_hip.so")
+
+
+@pytest.mark.parametrize("name,tag", [("arch0", "init"), ("arch0", "rand"), ("control07", "init"), ("control07", "rand")])
+def test_golden_reference_examples(name, tag):
+    """examples/arch0.mat and examples/control07.mat (BASELINE.json configs[0..1]) through getada1/2/3, blkchol,
+    fwblkslv, bwblkslv against the outputs of the unmodified reference MEX (tests/golden)."""
+    errs = check_golden(name, tag)
+    assert max(errs.values()) < TOL, errs
+
+
+@pytest.mark.parametrize("seed,kw", [(0, {}), (1, dict(m=20, lp=0, q=(), s=(6, 3))), (2, dict(m=35, lp=8, q=(4, 3, 5), s=())),
+                                     (3, dict(m=40, block_local=True)), (4, dict(m=16, lp=3, q=(3,), s=(9,), dens=0.9)),
+                                     (5, dict(m=120, lp=30, q=(6, 9, 3, 4), s=(12, 20, 7), dens=0.15)),
+                                     (6, dict(m=200, lp=10, q=(5,), s=(33, 10), dens=0.05, block_local=True))])
+def test_iteration_unit_mixed_cones(glue, seed, kw):
+    from sedumi_amd import problem
+    P = problem.random_sdp(seed=seed, **kw)
+    check_iteration(glue, P, seed=seed)
+    check_iteration(glue, P, seed=seed, identity=True)
+
+
+def test_control07_shaped_unit(glue):
+    from sedumi_amd import problem
+    check_iteration(glue, problem.control_like(), seed=5)
+
+
+def test_blockdiag_multi_supernode_unit(glue):
+    from sedumi_amd import problem
+    P = problem.blockdiag_sdp(nblk=12, n=40, mper=30, nnz=8, seed=4)
+    errs, S, _ = check_iteration(glue, P, seed=2)
+    assert S["L"]["xsuper"].size - 1 >= 12
+
+
+def test_maxcut_unit(glue):
+    from sedumi_amd import problem
+    check_iteration(glue, problem.maxcut(600), seed=3)
+
+
+@pytest.mark.parametrize("kind,m,dens", [("rand", 300, 0.01), ("rand", 2000, 0.004), ("band", 500, 0), ("arrow", 400, 0),
+                                         ("blockdiag", 600, 0), ("grid", 900, 0), ("diag", 50, 0), ("rand", 700, 0.3)])
+def test_sparse_factor_and_solves(refmex, kind, m, dens):
+    from oracle import glue as gl
+    from sedumi_amd import mex
+    rng = np.random.default_rng(m)
+    X = spd_pattern(kind, m, rng, dens)
+    L = mex.symbchol(X)
+    pars = gl.default_pars_chol()
+    r = refmex.call("blkchol", 4, L, X, pars)
+    o = mex.blkchol(L, X, pars)
+    assert relerr(o[0], r[0]) < TOL and relerr(o[1], r[1]) < TOL
+    assert o[2].nnz == r[2].nnz and o[3].nnz == r[3].nnz
+    L2 = dict(L); L2["L"] = r[0]
+    rhs = rng.standard_normal((X.shape[0], 3))
+    assert relerr(mex.fwblkslv(L2, rhs), refmex.call("fwblkslv", 1, L2, rhs)) < TOL
+    assert relerr(mex.bwblkslv(L2, rhs), refmex.call("bwblkslv", 1, L2, rhs)) < TOL
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_pivot_decisions_skip_and_add(refmex, glue, case):
+    from oracle import glue as gl
+    from sedumi_amd import mex
+    rng = np.random.default_rng(50 + case)
+    m = [40, 90, 150, 200, 64, 333][case]
+    if case % 2 == 0:
+        B = rng.standard_normal((m, m // 2))
+        X = B @ B.T
+        X = sp.csc_matrix(X + np.diag(10.0 ** rng.uniform(-14, -2, m)) * np.abs(X).max())
+    else:
+        S = sp.random(m, m, density=0.05, random_state=rng, format="csc"); S = S + S.T
+        sc = 10.0 ** rng.uniform(-7, 3, m)
+        X = sp.diags(sc) @ (S + sp.diags(np.asarray(abs(S).sum(axis=1)).ravel() * rng.choice([1.0, 1.0, 0.5], m) + 1e-3)) @ sp.diags(sc)
+        X = sp.csc_matrix(X); X.sort_indices()
+    L = glue.symbchol(X)
+    for maxu in (5e5, 30.0, 2.0):
+        pars = dict(gl.default_pars_chol()); pars["maxu"] = maxu
+        absd = np.abs(X.diagonal()) * rng.choice([1.0, 1e3, 1e8], m) if case > 2 else None
+        args = (L, X, pars) + ((absd,) if absd is not None else ())
+        r = refmex.call("blkchol", 4, *args)
+        o = mex.blkchol(*args)
+        assert np.array_equal(o[2].indices, r[2].indices) and np.array_equal(o[3].indices, r[3].indices)
+        assert relerr(o[1], r[1]) < 1e-8
+
+
+def test_edge_cases_empty_and_tiny(refmex):
+    from oracle import glue as gl
+    from sedumi_amd import mex
+    for m in (1, 2):
+        X = sp.csc_matrix(np.eye(m) * 3.0 + (np.ones((m, m)) - np.eye(m)) * 0.5)
+        L = mex.symbchol(X)
+        r = refmex.call("blkchol", 4, L, X, gl.default_pars_chol())
+        o = mex.blkchol(L, X, gl.default_pars_chol())
+        assert relerr(o[0], r[0]) < TOL and relerr(o[1], r[1]) < TOL
+        L2 = dict(L); L2["L"] = r[0]
+        b = np.arange(1.0, m + 1).reshape(-1, 1)
+        assert relerr(mex.bwblkslv(L2, mex.fwblkslv(L2, b)), refmex.call("bwblkslv", 1, L2, refmex.call("fwblkslv", 1, L2, b))) < TOL
+    # a zero matrix: every pivot is skipped, L = I, d = 0 (blkchol never fails)
+    X = sp.csc_matrix(np.zeros((5, 5))) + sp.eye(5) * 0.0
+    X = sp.csc_matrix((np.zeros(25), np.tile(np.arange(5), 5), np.arange(0, 26, 5)), shape=(5, 5))
+    from sedumi_amd import problem
+    L = problem.dense_symbolic(5)
+    r = refmex.call("blkchol", 4, L, X, gl.default_pars_chol())
+    o = mex.blkchol(L, X, gl.default_pars_chol())
+    assert np.array_equal(o[2].indices, r[2].indices) and relerr(o[0], r[0]) == 0 and np.all(o[1] == 0)
+
+
+def test_resident_plan_and_kernel_timers(glue):
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    P = problem.random_sdp(m=60, lp=12, q=(4, 6), s=(10, 14), seed=9)
+    S = glue.setup(P.At, P.K)
+    d, ud = ref_scaling(P, 4)
+    it = glue.iteration_ref(S, d, ud)
+    rhs = np.random.default_rng(1).standard_normal(P.m)
+    plan = Plan(0)
+    plan.set_chol(S["L"], S["ADA"])
+    Qpat = sp.csc_matrix(S["DAt"]["q"])
+    plan.set_ada(P.At, P.Ablkjc, P.K, Qpat)
+    Qn = sp.csc_matrix(it["DAt"]["q"])
+    cols = np.repeat(np.arange(P.m), np.diff(Qpat.indptr))
+    plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud); plan.upload("rhs", rhs)
+    plan.upload("qpr", np.asarray(Qn[Qpat.indices, cols]).ravel())
+    for _ in range(3):                      # repeated iterations on the same resident plan
+        plan.getada(); plan.blkchol(None, True); plan.ldlsolve()
+    assert relerr(plan.download("ada"), it["ADA"].data) < TOL
+    assert relerr(plan.download("absd"), it["absd"].ravel()) < TOL
+    assert relerr(plan.download("d"), it["Ld"].ravel()) < TOL
+    assert relerr(plan.download("lpr"), it["LL"].data) < TOL
+    assert relerr(plan.download("y"), glue.solve_ref(S, it, rhs).ravel()) < TOL
+    plan.kprof(True); plan.ldlsolve(); prof = plan.kprof_summary(); plan.kprof(False)
+    assert prof["k_fw_level"][1] > 0 and prof["k_bw_level"][1] > 0
+    plan.close()
+
+
+# ---------------------------------------------------------------- full-size, size-independent properties
+def _full_size_properties(P, ada_dense=True):
+    """At BASELINE.json sizes the reference would take too long as a per-entry oracle; check instead
+    (1) symmetry of ADA', (2) ADA' y == rhs after factor + solve (round trip), (3) linearity of the solve,
+    (4) L D L' == ADA'(perm,perm) on a random probe vector, (5) idempotence of re-running the iteration."""
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    m = P.m
+    d, ud = problem.spd_scaling(P.K, seed=11)
+    plan = Plan(0)
+    plan.set_chol(problem.dense_symbolic(m), problem.dense_pattern(m))
+    plan.set_ada(P.At, P.Ablkjc, P.K, problem.lorentz_pattern(P))
+    plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud)
+    rng = np.random.default_rng(0)
+    r1, r2 = rng.standard_normal(m), rng.standard_normal(m)
+    plan.getada(); plan.blkchol(None, True)
+    ADA = plan.download("ada").reshape(m, m, order="F")
+    assert relerr(ADA, ADA.T) < 1e-13
+    ys = []
+    for r in (r1, r2, 2.0 * r1 - 3.0 * r2):
+        plan.upload("rhs", r); plan.ldlsolve(); ys.append(plan.download("y"))
+    assert relerr(ADA @ ys[0], r1) < 1e-9 and relerr(ADA @ ys[1], r2) < 1e-9
+    assert relerr(ys[2], 2.0 * ys[0] - 3.0 * ys[1]) < 1e-10
+    Lp = plan.download("lpr"); dd = plan.download("d")
+    L = np.zeros((m, m)); L[np.tril_indices(m)] = 0
+    Lm = sp.csc_matrix((Lp, plan.L_pattern.indices, plan.L_pattern.indptr), shape=(m, m))
+    v = rng.standard_normal(m)
+    assert relerr(Lm @ (dd * (Lm.T @ v)), ADA @ v) < 1e-11
+    (si, _), (ai, _) = plan.pivots()
+    assert len(si) == 0 and len(ai) == 0
+    plan.getada(); plan.blkchol(None, True)
+    assert np.array_equal(plan.download("ada"), ADA.ravel(order="F")) and np.array_equal(plan.download("d"), dd)
+    plan.close()
+
+
+def test_full_size_control07_shape():
+    from sedumi_amd import problem
+    _full_size_properties(problem.control_like(seed=1))
+
+
+def test_full_size_maxcut_2000():
+    from sedumi_amd import problem
+    _full_size_properties(problem.maxcut(2000))

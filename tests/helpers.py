@@ -71,7 +71,14 @@ def check_iteration(G, P, seed=0, identity=False, tol=TOL, pars=None):
         # pointer (sdmauxCmp.c:48, blksdp.h:121) -- undefined behaviour; sedumi.m never takes this branch
         # (sum(K.s)==0 goes through getada.m, sedumi.m:446-448).  We pin the documented semantics.
         errs["absd"] = relerr(absd.ravel(), it["ADA"].diagonal())
-    LL, Ld, Lskip, Ladd = mex.blkchol(S["L"], it["ADA"], pars, it["absd"])
+    if not K["s"].size:
+        # feed both factorizations the documented absd (see above); with the reference's garbage absd (zeros) the
+        # noise-level pivots of a rank-deficient ADA' would be accepted or skipped by rounding luck
+        absd_in = it["ADA"].diagonal().reshape(-1, 1)
+        it["LL"], it["Ld"], it["Lskip"], it["Ladd"] = G.ref.call("blkchol", 4, S["L"], it["ADA"], pars, absd_in)
+    else:
+        absd_in = it["absd"]
+    LL, Ld, Lskip, Ladd = mex.blkchol(S["L"], it["ADA"], pars, absd_in)
     errs["L"] = relerr(LL, it["LL"])
     errs["d"] = relerr(Ld, it["Ld"])
     assert np.array_equal(Lskip.indices, it["Lskip"].indices), "skip decisions differ"

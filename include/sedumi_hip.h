@@ -82,7 +82,7 @@ int sdm_choltmpsiz(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, sdm_int ns
                    const sdm_int *xsuper, sdm_int *tmpsiz);
 /* split = cholsplit(L, cachsz)   cholsplit.c:59-111 (split[m] out) */
 int sdm_cholsplit(sdm_int m, const sdm_int *Ljc, sdm_int nsuper, const sdm_int *xsuper,
-                  sdm_int cachsz, sdm_int *split);
+                  double cachsz_kb, sdm_int *split);
 
 /* --- ADA' ------------------------------------------------------------------ */
 

@@ -74,6 +74,7 @@ void mxFree(void *p);
 void mexErrMsgTxt(const char *msg);
 void mexWarnMsgTxt(const char *msg);
 int mexPrintf(const char *fmt, ...);
+int mexAtExit(void (*fn)(void));
 
 #ifdef NDEBUG
 #define mxAssert(c, msg) ((void)0)

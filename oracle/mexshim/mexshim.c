@@ -148,6 +148,11 @@ int mexPrintf(const char *fmt, ...) {
   return r;
 }
 
+/* exit handlers are run when the shim library is unloaded */
+static void (*g_atexit[16])(void); static int g_natexit = 0;
+int mexAtExit(void (*fn)(void)) { if (g_natexit < 16) g_atexit[g_natexit++] = fn; return 0; }
+__attribute__((destructor)) static void run_atexit(void) { int i; for (i = 0; i < g_natexit; i++) g_atexit[i](); }
+
 int shim_call(shim_mexfun_t f, int nlhs, mxArray **plhs, int nrhs, const mxArray **prhs) {
   g_errmsg[0] = 0;
   if (setjmp(g_jmp)) { g_jmp_armed = 0; return 1; }

@@ -56,8 +56,8 @@ class RefMexError(RuntimeError):
 class RefMex:
     """Loads the shim and (lazily) the per-MEX shared objects."""
 
-    def __init__(self, ref_dir: str = REF_DIR):
-        self.dir = ref_dir
+    def __init__(self, ref_dir: str = REF_DIR, mex_dir: str | None = None):
+        self.dir = mex_dir or ref_dir          # where <name>.so with a mexFunction are looked up
         path = os.path.join(ref_dir, "libmexshim.so")
         if not os.path.exists(path):
             raise RefMexError(f"{path} missing: run `make -C oracle ref` (needs /root/reference)")

@@ -537,10 +537,10 @@ int sdm_choltmpsiz(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, sdm_int ns
 
 // cache groups of cholsplit.c:59-111 (vestigial in the reference too: blkchol never reads L.split).
 // cachsz in KB as passed by symbchol.m:66,83; cachesiz = floor(0.9 * 128 * cachsz) doubles.
-int sdm_cholsplit(sdm_int m, const sdm_int *Ljc, sdm_int nsuper, const sdm_int *xsuper, sdm_int cachsz,
+int sdm_cholsplit(sdm_int m, const sdm_int *Ljc, sdm_int nsuper, const sdm_int *xsuper, double cachsz,
                   sdm_int *split) {
   try {
-    const Int cache = (Int)std::floor(0.9 * (1024 / sizeof(double)) * (double)cachsz);
+    const Int cache = (Int)std::floor(0.9 * (1024 / sizeof(double)) * cachsz);
     std::fill(split, split + m, 0);
     Int k = 0;
     for (Int s = 0; s < nsuper; s++) {

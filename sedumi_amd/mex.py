@@ -287,7 +287,7 @@ def cholsplit(L, cachsz):
     xs = i64(np.asarray(_field(L, "xsuper", "L"), dtype=np.float64)) - 1
     jc = i64(LL.indptr)
     split = np.zeros(max(m, 1), dtype=np.int64)
-    check(capi.lib().sdm_cholsplit(C.c_int64(m), pi(jc), C.c_int64(xs.size - 1), pi(xs), C.c_int64(int(np.asarray(cachsz).ravel()[0])), pi(split)))
+    check(capi.lib().sdm_cholsplit(C.c_int64(m), pi(jc), C.c_int64(xs.size - 1), pi(xs), C.c_double(float(np.asarray(cachsz).ravel()[0])), pi(split)))
     return split[:m].astype(np.float64).reshape(-1, 1)
 
 

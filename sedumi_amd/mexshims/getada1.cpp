@@ -1,0 +1,25 @@
+// ADA = getada1(ADA,A,Ajc2,perm,d,blkstart)  -- replaces getada1.c:161-261
+#include "mexcommon.h"
+void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
+  if (nrhs < 6) mexErrMsgTxt("getADA requires more input arguments.");
+  const mxArray *ADA = prhs[0], *A = prhs[1];
+  if (!mxIsSparse(A)) mexErrMsgTxt("At should be sparse.");
+  if (!mxIsSparse(ADA)) mexErrMsgTxt("ADA should be sparse.");
+  const sdm_int m = (sdm_int)mxGetN(A);
+  if ((sdm_int)mxGetM(ADA) != m || (sdm_int)mxGetN(ADA) != m) mexErrMsgTxt("Size mismatch ADA.");
+  if ((sdm_int)numel(prhs[2]) != m) mexErrMsgTxt("Size mismatch Ajc2.");
+  if ((sdm_int)numel(prhs[3]) != m) mexErrMsgTxt("Size mismatch perm.");
+  if (!mxIsStruct(prhs[4])) mexErrMsgTxt("Parameter `d' should be a structure.");
+  const mxArray *dl = need_field(prhs[4], "l", "Field d.l missing."), *ddet = need_field(prhs[4], "det", "Field d.det missing.");
+  ivec qb = idx_from_dbl(prhs[5], -1);                              // K.qblkstart
+  const sdm_int lorN = (sdm_int)qb.size() - 1;
+  if ((sdm_int)numel(ddet) != lorN) mexErrMsgTxt("Size d.det mismatch");
+  ivec jc = idx_from_mw(mxGetJc(ADA), m + 1), ir = idx_from_mw(mxGetIr(ADA), mxGetJc(ADA)[m]);
+  ivec Ajc = idx_from_mw(mxGetJc(A), m + 1), Air = idx_from_mw(mxGetIr(A), mxGetJc(A)[m]);
+  ivec Ajc2 = idx_from_dbl(prhs[2], 0), perm = idx_from_dbl(prhs[3], -1);
+  plhs[0] = mxCreateSparse(m, m, jc[m], mxREAL);                     // getada1.c:222-225
+  memcpy(mxGetJc(plhs[0]), mxGetJc(ADA), (m + 1) * sizeof(mwIndex));
+  memcpy(mxGetIr(plhs[0]), mxGetIr(ADA), jc[m] * sizeof(mwIndex));
+  sdm_check(sdm_getada1(m, jc.data(), ir.data(), (sdm_int)mxGetM(A), Ajc.data(), Air.data(), mxGetPr(A), Ajc2.data(), perm.data(),
+                        (sdm_int)numel(dl), mxGetPr(dl), lorN, mxGetPr(ddet), qb.data(), mxGetPr(plhs[0])));
+}

@@ -1,0 +1,27 @@
+// [ADA,absd] = getada3(ADA,A,Ajc1,Aord,udsqr,K)  -- replaces getada3.c:370-569
+#include "mexcommon.h"
+void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
+  if (nrhs < 6) mexErrMsgTxt("getADA requires more input arguments.");
+  const mxArray *ADA = prhs[0], *A = prhs[1];
+  if (!mxIsSparse(A)) mexErrMsgTxt("At should be sparse.");
+  if (!mxIsSparse(ADA)) mexErrMsgTxt("ADA should be sparse.");
+  ConeK ck; read_cone(prhs[5], ck);
+  const sdm_int m = (sdm_int)mxGetN(A);
+  if ((sdm_int)mxGetM(ADA) != m || (sdm_int)mxGetN(ADA) != m) mexErrMsgTxt("Size mismatch ADA.");
+  if ((sdm_int)numel(prhs[2]) != m) mexErrMsgTxt("Ajc1 size mismatch");
+  const mxArray *bs = need_field(prhs[5], "blkstart", "Missing K.blkstart.");
+  if ((sdm_int)numel(bs) != 2 + ck.K.lorN + ck.K.sdpN) mexErrMsgTxt("Size mismatch K.blkstart.");
+  ivec blk = idx_from_dbl(bs, -1);
+  ivec psd(blk.begin() + ck.K.lorN + 1, blk.end());
+  const mxArray *sp = need_field(prhs[3], "sperm", "Missing field Aord.sperm.");
+  if ((sdm_int)numel(sp) != m) mexErrMsgTxt("Aord.sperm size mismatch");
+  ivec jc = idx_from_mw(mxGetJc(ADA), m + 1), ir = idx_from_mw(mxGetIr(ADA), mxGetJc(ADA)[m]);
+  ivec Ajc = idx_from_mw(mxGetJc(A), m + 1), Air = idx_from_mw(mxGetIr(A), mxGetJc(A)[m]);
+  ivec Ajc1 = idx_from_dbl(prhs[2], 0), sperm = idx_from_dbl(sp, -1);
+  mxArray *out0 = mxDuplicateArray(ADA);                            // getada3.c:452
+  mxArray *out1 = mxCreateDoubleMatrix(m, 1, mxREAL);
+  sdm_check(sdm_getada3(m, jc.data(), ir.data(), mxGetPr(out0), (sdm_int)mxGetM(A), Ajc.data(), Air.data(), mxGetPr(A), Ajc1.data(),
+                        sperm.data(), mxGetPr(prhs[4]), &ck.K, psd.data(), mxGetPr(out1)));
+  plhs[0] = out0;
+  if (nlhs > 1) plhs[1] = out1; else mxDestroyArray(out1);           // getada3.c:565-568
+}

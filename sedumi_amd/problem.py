@@ -130,8 +130,21 @@ def random_sdp(m=30, lp=6, q=(3, 4), s=(5, 7, 4), dens=0.3, seed=0, block_local=
     start, ns = _psd_rows(K)
     rows, cols, vals = [], [], []
     nblocks = 1 + nq + len(s)
+    # block_local: keep the number of constraints per block below the block's dimension so that ADA' stays
+    # nonsingular (otherwise the pivots of the dependent constraints are pure rounding noise)
+    caps = [int(0.7 * lp)] + [int(0.7 * qk) for qk in q] + [int(0.7 * n * (n + 1) / 2) for n in ns]
+    picks = []
+    if block_local:
+        left = list(caps)
+        for j in range(m):
+            avail = [b for b in range(nblocks) if left[b] > 0]
+            if not avail:
+                raise ValueError("random_sdp(block_local): m exceeds the capacity of the cone blocks")
+            b = int(avail[rng.integers(0, len(avail))])
+            left[b] -= 1
+            picks.append(b)
     for j in range(m):
-        pick = rng.integers(0, nblocks) if block_local else -1
+        pick = picks[j] if block_local else -1
         if lp and (pick in (-1, 0)):
             for r in range(1, lp + 1):
                 if rng.random() < dens:

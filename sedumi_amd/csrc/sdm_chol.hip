@@ -37,7 +37,9 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   C.sn_first.resize(nsuper); C.sn_ns.resize(nsuper); C.sn_ms.resize(nsuper);
   C.sn_parent.assign(nsuper, -1); C.sn_level.assign(nsuper, 0);
   C.sn_foff.resize(nsuper); C.sn_xl.resize(nsuper); C.sn_woff.resize(nsuper); C.sn_roff.assign(nsuper, 0);
-  int64_t foff = 0, xl = 0;
+  C.sn_toff.resize(nsuper);
+  int64_t foff = 0, xl = 0, toff = 0;
+  C.maxms = 0; C.maxns = 0;
   for (sdm_int s = 0; s < nsuper; s++) {
     sdm_int f = xsuper[s], n = xsuper[s + 1] - f, ms = Ljc[f + 1] - Ljc[f];
     if (n <= 0 || ms < n) throw std::runtime_error("bad supernode partition");
@@ -46,10 +48,11 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
       if (Ljc[j + 1] - Ljc[j] != ms - (j - f)) throw std::runtime_error("L.L columns are not nested within a supernode");
     }
     C.sn_first[s] = (int)f; C.sn_ns[s] = (int)n; C.sn_ms[s] = (int)ms;
-    C.sn_foff[s] = foff; C.sn_xl[s] = xl; C.sn_woff[s] = xl;
-    foff += (int64_t)ms * ms; xl += ms;
+    C.sn_foff[s] = foff; C.sn_xl[s] = xl; C.sn_woff[s] = xl; C.sn_toff[s] = toff;
+    foff += (int64_t)ms * ms; xl += ms; toff += (int64_t)ms * n;
+    C.maxms = std::max(C.maxms, (int)ms); C.maxns = std::max(C.maxns, (int)n);
   }
-  C.fsize = foff; C.wsize = xl;
+  C.fsize = foff; C.wsize = xl; C.tsize = toff;
   // compressed subscripts (row list of the first column of every supernode)
   std::vector<int> lindx((size_t)xl);
   for (sdm_int s = 0; s < nsuper; s++) {
@@ -101,7 +104,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   }
   // permuteP map (blkchol.c:95-120): L slot -> ADA value index / front offset
   std::vector<int> asm_src((size_t)C.nnzL);
-  std::vector<int64_t> asm_dst((size_t)C.nnzL);
+  std::vector<int64_t> asm_dst((size_t)C.nnzL), asm_dstT((size_t)C.nnzL);
   { std::vector<int> rowpos(m, -1);
     for (sdm_int j = 0; j < m; j++) {
       sdm_int jc = perm[j];
@@ -110,6 +113,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
       for (sdm_int t = Ljc[j]; t < Ljc[j + 1]; t++) {
         asm_src[t] = rowpos[perm[Lir[t]]];
         asm_dst[t] = C.sn_foff[s] + (int64_t)c * ms + c + (t - Ljc[j]);
+        asm_dstT[t] = C.sn_toff[s] + (int64_t)(c + (t - Ljc[j])) * C.sn_ns[s] + c;     // L^T panel: (row r) * n_s + c
       }
       for (sdm_int t = ADAjc[jc]; t < ADAjc[jc + 1]; t++) rowpos[ADAir[t]] = -1;
     }
@@ -144,7 +148,8 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   C.d_lindx.upload(lindx); C.d_relidx.upload(relidx);
   { std::vector<int> p32(m); for (sdm_int i = 0; i < m; i++) p32[i] = (int)perm[i]; C.d_perm.upload(p32); }
   C.d_foff.upload(C.sn_foff); C.d_xl.upload(C.sn_xl); C.d_woff.upload(C.sn_woff); C.d_roff.upload(C.sn_roff);
-  C.d_asm_src.upload(asm_src); C.d_asm_dst.upload(asm_dst);
+  C.d_asm_src.upload(asm_src); C.d_asm_dst.upload(asm_dst); C.d_asm_dstT.upload(asm_dstT); C.d_toff.upload(C.sn_toff);
+  C.frontsT.alloc((size_t)C.tsize);
   { std::vector<int64_t> l64(C.Ljc.begin(), C.Ljc.end()); C.d_Ljc.upload(l64); }
   C.fronts.alloc((size_t)C.fsize); C.wvec.alloc((size_t)C.wsize); C.colbuf.alloc((size_t)C.wsize + (size_t)nsuper);
   C.d.alloc(m); C.dsolve.alloc(m); C.lb.alloc(m); C.pivval.alloc(m); C.pivstat.alloc(m); C.ub.alloc(2);
@@ -156,7 +161,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
 // ================================================================= kernels
 struct FrontTab {
   const int *first, *ns, *ms;
-  const int64_t *foff, *xl, *woff, *roff;
+  const int64_t *foff, *xl, *woff, *roff, *toff;
   const int *childptr, *childlist, *lindx, *relidx;
 };
 
@@ -171,10 +176,10 @@ __global__ void k_extract(double *Lpr, const double *F, const int64_t *dst, int6
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; t < nnzL; t += stride) Lpr[t] = F[dst[t]];
 }
-__global__ void k_load_factor(double *F, const double *Lpr, const int64_t *dst, int64_t nnzL) {
+__global__ void k_load_factor(double *F, double *FT, const double *Lpr, const int64_t *dst, const int64_t *dstT, int64_t nnzL) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; t < nnzL; t += stride) F[dst[t]] = Lpr[t];
+  for (; t < nnzL; t += stride) { const double v = Lpr[t]; F[dst[t]] = v; FT[dstT[t]] = v; }
 }
 
 // ---- pivot thresholds (blkchol.c:168-184): one workgroup.
@@ -280,7 +285,7 @@ __device__ double pivot_probe(const double (*S)[NB + 1], int k, int kb, int k0, 
 
 // ---- K1: LDL' of the kb x kb diagonal block of panel p (one workgroup per front)
 __global__ void __launch_bounds__(256)
-k_ldl_diag(double *F, FrontTab tab, const int *list, int panel, double *d, double *lb, const double *ubp,
+k_ldl_diag(double *F, double *FT, FrontTab tab, const int *list, int panel, double *d, double *lb, const double *ubp,
            int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src,
            const int64_t *Ljc, int mtot) {
   __shared__ double S[NB][NB + 1];
@@ -291,9 +296,67 @@ k_ldl_diag(double *F, FrontTab tab, const int *list, int panel, double *d, doubl
   const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
   const int k0 = panel * NB, kb = min(NB, ns - k0);
   double *Fs = F + tab.foff[s];
+  double *Ts = FT + tab.toff[s];
   double *cb = colbuf + tab.woff[s] + s;
   const int tid = threadIdx.x;
   const double ub = ubp[0], maxu = ubp[1];
+  // ---- fast path: one wavefront, lane i owns row i of the block in registers; column k's pivot and the
+  // unscaled column entries travel by v_readlane broadcasts -- no LDS traffic, no barrier in the k-loop.
+  // It gives up (nothing written) as soon as a pivot needs the column probe of the never-fail rule, which
+  // is then handled by the general LDS path below.
+  __shared__ int fast_ok;
+  if (tid < 64) {
+    const int i = tid;
+    double x[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) x[j] = (j <= i && i < kb) ? Fs[(int64_t)(k0 + j) * ms + k0 + i] : 0.0;
+    const double mylb = i < kb ? lb[first + k0 + i] : 0.0;
+    double dval = 0.0, pval = 0.0;
+    int stat = 0;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      if (k < kb && ok) {
+        const double xkk = sdm_bcast_lane(x[k], k);
+        const double lbk = sdm_bcast_lane(mylb, k);
+        if (xkk > lbk) {
+          if (ms - (k0 + k) > 1 && xkk < ub) {
+            ok = false;
+          } else {
+            const double l = x[k] / xkk;               // lanes i > k: l_ik
+#pragma unroll
+            for (int j = k + 1; j < NB; j++) {
+              if (j < kb) {
+                const double xjk = sdm_bcast_lane(x[k], j);     // S[j][k], still unscaled
+                if (i >= j) x[j] -= l * xjk;
+              }
+            }
+            if (i > k) x[k] = l;
+            if (i == k) { dval = xkk; stat = 0; }
+          }
+        } else {
+          if (i > k) x[k] = 0.0;
+          if (i == k) { dval = 0.0; stat = 1; pval = xkk; }
+        }
+      }
+    }
+    if (tid == 0) fast_ok = ok ? 1 : 0;
+    if (ok && i < kb) {
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        if (j <= i) {
+          const double v = (j == i) ? 1.0 : x[j];
+          Fs[(int64_t)(k0 + j) * ms + k0 + i] = v;
+          Ts[(int64_t)(k0 + i) * ns + k0 + j] = v;
+        }
+      }
+      const int gk = first + k0 + i;
+      d[gk] = dval;
+      if (stat) { pivstat[gk] = 1; pivval[gk] = pval; }
+    }
+  }
+  __syncthreads();
+  if (fast_ok) return;
   for (int idx = tid; idx < kb * kb; idx += blockDim.x) {
     int i = idx % kb, j = idx / kb;
     if (i >= j) S[i][j] = Fs[(int64_t)(k0 + j) * ms + k0 + i];
@@ -334,13 +397,17 @@ k_ldl_diag(double *F, FrontTab tab, const int *list, int panel, double *d, doubl
   }
   for (int idx = tid; idx < kb * kb; idx += blockDim.x) {
     int i = idx % kb, j = idx / kb;
-    if (i >= j) Fs[(int64_t)(k0 + j) * ms + k0 + i] = (i == j) ? 1.0 : S[i][j];   // unit diagonal (blkchol2.c:136)
+    if (i >= j) {
+      const double v = (i == j) ? 1.0 : S[i][j];                                  // unit diagonal (blkchol2.c:136)
+      Fs[(int64_t)(k0 + j) * ms + k0 + i] = v;
+      Ts[(int64_t)(k0 + i) * ns + k0 + j] = v;                                    // L^T panel copy for the backward solve
+    }
   }
 }
 
 // ---- K2: rows below the diagonal block: X = A21 * L11^-T, L21 = X * D^-1 (one row per work-item)
 __global__ void __launch_bounds__(256)
-k_ldl_panel(double *F, FrontTab tab, const int *list, int panel, const double *d) {
+k_ldl_panel(double *F, double *FT, FrontTab tab, const int *list, int panel, const double *d) {
   __shared__ double Ls[NB][NB + 1];
   __shared__ double ds[NB];
   const int s = list[blockIdx.y];
@@ -349,6 +416,7 @@ k_ldl_panel(double *F, FrontTab tab, const int *list, int panel, const double *d
   const int r0 = k0 + kb;
   if ((int)(blockIdx.x * blockDim.x) >= ms - r0) return;       // uniform per workgroup
   double *Fs = F + tab.foff[s];
+  double *Ts = FT + tab.toff[s];
   const int tid = threadIdx.x;
   for (int idx = tid; idx < kb * kb; idx += blockDim.x) {
     int i = idx % kb, j = idx / kb;
@@ -368,7 +436,9 @@ k_ldl_panel(double *F, FrontTab tab, const int *list, int panel, const double *d
           if (j < c) v -= x[j] * Ls[c][j];
         const double dc = ds[c];
         x[c] = dc > 0.0 ? v : 0.0;
-        Fs[(int64_t)(k0 + c) * ms + r] = dc > 0.0 ? v / dc : 0.0;
+        const double l = dc > 0.0 ? v / dc : 0.0;
+        Fs[(int64_t)(k0 + c) * ms + r] = l;
+        Ts[(int64_t)r * ns + k0 + c] = l;
       }
     }
   }
@@ -431,21 +501,23 @@ k_ldl_update(double *F, FrontTab tab, const int *list, int panel, const double *
 }
 
 // ================================================================== solves
-// One workgroup per front (fronts of a level are independent).
-// Forward: multifrontal -- the front's local vector w (length m_s) is
-// assembled from the right-hand side and the children's update vectors in a
-// fixed order (deterministic), then per 32-column panel a wave-synchronous
-// unit-lower TRSV on the LDS copy of the diagonal block followed by the panel
-// GEMV on all rows below (fwblkslv.c:77-134 does the same per supernode with
-// daxpy + scatter).
+// One workgroup (512) per front; fronts of an etree level are independent.  The front-local vector lives in
+// LDS.  Per 64-column panel: ONE wavefront does the in-block triangular solve -- lane i owns row i, its 64
+// coefficients sit in registers (prefetched while the previous panel's GEMV runs) and the dependency chain is
+// a v_readlane broadcast + one FMA per column (no LDS, no barrier) -- then all waves apply the panel to the
+// remaining rows with fully coalesced column reads (one row per work-item, 64 independent loads in flight).
+// Forward (fwblkslv.c:77-134): multifrontal, the children's update vectors are summed in a fixed order.
+// Backward (bwblkslv.c:73-125): runs on the L^T panel copy written by the factor kernels, so the update of
+// the earlier unknowns is the same coalesced, reduction-free GEMV as in the forward sweep.
 __global__ void __launch_bounds__(512)
-k_fw_level(const double *F, FrontTab tab, const int *list, double *wvec, double *y) {
-  __shared__ double Ls[NB][NB + 1];
-  __shared__ double wb[NB];
+k_fw_level(const double *F, FrontTab tab, const int *list, double *wvec, double *y, int use_lds) {
+  SDM_DYN_SMEM(smem);
+  __shared__ double wb[SNB];
   const int s = list[blockIdx.x];
   const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
   const double *Fs = F + tab.foff[s];
-  double *w = wvec + tab.woff[s];
+  double *wg = wvec + tab.woff[s];
+  double *w = use_lds ? (double *)smem : wg;
   const int tid = threadIdx.x, bs = blockDim.x;
   for (int i = tid; i < ms; i += bs) w[i] = i < ns ? y[first + i] : 0.0;
   __syncthreads();
@@ -457,70 +529,103 @@ k_fw_level(const double *F, FrontTab tab, const int *list, double *wvec, double 
     for (int i = tid; i < mu; i += bs) w[rel[i]] += wc[i];
     __syncthreads();
   }
-  for (int k0 = 0; k0 < ns; k0 += NB) {
-    const int kb = min(NB, ns - k0);
-    for (int idx = tid; idx < kb * kb; idx += bs) {
-      int i = idx % kb, j = idx / kb;
-      if (i > j) Ls[i][j] = Fs[(int64_t)(k0 + j) * ms + k0 + i];
-    }
-    __syncthreads();
+  double lr[SNB];
+  if (tid < 64) {                                    // row tid of the first diagonal block
+    const int kb = min(SNB, ns);
+#pragma unroll
+    for (int c = 0; c < SNB; c++) lr[c] = (c < tid && tid < kb) ? Fs[(int64_t)c * ms + tid] : 0.0;
+  }
+  for (int k0 = 0; k0 < ns; k0 += SNB) {
+    const int kb = min(SNB, ns - k0);
     if (tid < 64) {
       double wi = tid < kb ? w[k0 + tid] : 0.0;
-      for (int k = 0; k < kb; k++) {
-        const double wk = __shfl(wi, k);
-        if (tid > k && tid < kb) wi -= Ls[tid][k] * wk;
+#pragma unroll
+      for (int k = 0; k < SNB; k++) {
+        if (k < kb) {
+          const double wk = sdm_bcast_lane(wi, k);
+          if (tid > k) wi -= lr[k] * wk;             // lr[k] = 0 for lanes outside the block
+        }
       }
       if (tid < kb) { w[k0 + tid] = wi; wb[tid] = wi; y[first + k0 + tid] = wi; }
+      const int k1 = k0 + SNB;                         // prefetch the next diagonal block's rows
+      if (k1 < ns) {
+        const int kbn = min(SNB, ns - k1);
+#pragma unroll
+        for (int c = 0; c < SNB; c++) lr[c] = (c < tid && tid < kbn) ? Fs[(int64_t)(k1 + c) * ms + k1 + tid] : 0.0;
+      }
     }
     __syncthreads();
     for (int r = k0 + kb + tid; r < ms; r += bs) {
+      const double *col = Fs + (int64_t)k0 * ms + r;
       double acc = 0.0;
-      for (int c = 0; c < kb; c++) acc += Fs[(int64_t)(k0 + c) * ms + r] * wb[c];
+#pragma unroll 8
+      for (int c = 0; c < kb; c++) acc += col[(int64_t)c * ms] * wb[c];
       w[r] -= acc;
     }
     __syncthreads();
   }
+  if (use_lds) for (int i = ns + tid; i < ms; i += bs) wg[i] = w[i];      // update vector for the parent
 }
 
-// Backward: y_s = L11^-T ( y_s - L21' * y[rows below] )  (bwblkslv.c:73-125)
 __global__ void __launch_bounds__(512)
-k_bw_level(const double *F, FrontTab tab, const int *list, double *y) {
-  __shared__ double Ls[NB][NB + 1];
-  __shared__ double sb[NB];
+k_bw_level(const double *FT, FrontTab tab, const int *list, double *y, int use_lds) {
+  SDM_DYN_SMEM(smem);
+  __shared__ double yb[SNB];
   const int s = list[blockIdx.x];
   const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
-  const double *Fs = F + tab.foff[s];
+  const double *T = FT + tab.toff[s];                // T[j*ns + r] = L(j, r): n_s x m_s, column-major
   const int *rows = tab.lindx + tab.xl[s];
+  double *yl = use_lds ? (double *)smem : y + first;
   const int tid = threadIdx.x, bs = blockDim.x;
-  const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
-  const int npan = (ns + NB - 1) / NB;
-  for (int pnl = npan - 1; pnl >= 0; pnl--) {
-    const int k0 = pnl * NB, kb = min(NB, ns - k0);
-    for (int c = wave; c < kb; c += nw) {
-      const double *col = Fs + (int64_t)(k0 + c) * ms;
-      double acc = 0.0;
-      for (int r = k0 + kb + lane; r < ms; r += 64) {
-        const double v = r < ns ? y[first + r] : y[rows[r]];
-        acc += col[r] * v;
-      }
-      for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-      if (lane == 0) sb[c] = acc;
-    }
-    for (int idx = tid; idx < kb * kb; idx += bs) {
-      int i = idx % kb, j = idx / kb;
-      if (i > j) Ls[i][j] = Fs[(int64_t)(k0 + j) * ms + k0 + i];
-    }
+  if (use_lds) {
+    for (int r = tid; r < ns; r += bs) yl[r] = y[first + r];
     __syncthreads();
-    if (tid < 64) {
-      double yi = tid < kb ? y[first + k0 + tid] - sb[tid] : 0.0;
-      for (int k = kb - 1; k >= 0; k--) {
-        const double yk = __shfl(yi, k);
-        if (tid < k) yi -= Ls[k][tid] * yk;
-      }
-      if (tid < kb) y[first + k0 + tid] = yi;
+  }
+  // rows below the supernode belong to ancestors (already solved): y_s -= L21' * y[anc]
+  if (ms > ns) {
+    for (int r = tid; r < ns; r += bs) {
+      double acc = 0.0;
+      for (int j = ns; j < ms; j++) acc += T[(int64_t)j * ns + r] * y[rows[j]];
+      yl[r] -= acc;
     }
     __syncthreads();
   }
+  const int npan = (ns + SNB - 1) / SNB;
+  double lr[SNB];
+  if (tid < 64) {
+    const int k0 = (npan - 1) * SNB, kb = ns - k0;
+#pragma unroll
+    for (int c = 0; c < SNB; c++) lr[c] = (c > tid && c < kb) ? T[(int64_t)(k0 + c) * ns + k0 + tid] : 0.0;
+  }
+  for (int pnl = npan - 1; pnl >= 0; pnl--) {
+    const int k0 = pnl * SNB, kb = min(SNB, ns - k0);
+    if (tid < 64) {
+      double yi = tid < kb ? yl[k0 + tid] : 0.0;
+#pragma unroll
+      for (int k = SNB - 1; k >= 0; k--) {
+        if (k < kb) {
+          const double yk = sdm_bcast_lane(yi, k);
+          if (tid < k) yi -= lr[k] * yk;             // lr[k] = L(k0+k, k0+tid)
+        }
+      }
+      if (tid < kb) { yl[k0 + tid] = yi; yb[tid] = yi; }
+      if (pnl > 0) {
+        const int k1 = k0 - SNB;
+#pragma unroll
+        for (int c = 0; c < SNB; c++) lr[c] = (c > tid) ? T[(int64_t)(k1 + c) * ns + k1 + tid] : 0.0;
+      }
+    }
+    __syncthreads();
+    for (int r = tid; r < k0; r += bs) {
+      const double *col = T + (int64_t)k0 * ns + r;
+      double acc = 0.0;
+#pragma unroll 8
+      for (int c = 0; c < kb; c++) acc += col[(int64_t)c * ns] * yb[c];
+      yl[r] -= acc;
+    }
+    __syncthreads();
+  }
+  if (use_lds) for (int r = tid; r < ns; r += bs) y[first + r] = yl[r];
 }
 
 __global__ void k_gather_perm(double *dst, const double *src, const int *perm, int m, int forward) {
@@ -541,7 +646,7 @@ __global__ void k_dsolve(double *ds, const double *d, int m) {
 static FrontTab front_tab(CholPlan &C) {
   FrontTab t;
   t.first = C.d_first.p; t.ns = C.d_ns.p; t.ms = C.d_ms.p;
-  t.foff = C.d_foff.p; t.xl = C.d_xl.p; t.woff = C.d_woff.p; t.roff = C.d_roff.p;
+  t.foff = C.d_foff.p; t.xl = C.d_xl.p; t.woff = C.d_woff.p; t.roff = C.d_roff.p; t.toff = C.d_toff.p;
   t.childptr = C.d_childptr.p; t.childlist = C.d_childlist.p; t.lindx = C.d_lindx.p; t.relidx = C.d_relidx.p;
   return t;
 }
@@ -567,10 +672,10 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
     if (l > 0) SDM_KLAUNCH(P, k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, C.fronts.p, tab, list);
     for (int li = C.lev_first_launch[l]; li < C.lev_first_launch[l + 1]; li++) {
       const LevelLaunch &L = C.launches[li];
-      SDM_KLAUNCH(P, k_ldl_diag, dim3(L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p, C.lb.p, C.ub.p,
+      SDM_KLAUNCH(P, k_ldl_diag, dim3(L.nactive), dim3(256), 0, C.fronts.p, C.frontsT.p, tab, list, L.panel, C.d.p, C.lb.p, C.ub.p,
                  C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m);
       if (L.maxrows > 0) {
-        SDM_KLAUNCH(P, k_ldl_panel, dim3((L.maxrows + 255) / 256, L.nactive), dim3(256), 0, C.fronts.p, tab, list,
+        SDM_KLAUNCH(P, k_ldl_panel, dim3((L.maxrows + 255) / 256, L.nactive), dim3(256), 0, C.fronts.p, C.frontsT.p, tab, list,
                    L.panel, C.d.p);
         SDM_KLAUNCH(P, k_ldl_update, dim3(L.maxtiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p);
       }
@@ -591,27 +696,41 @@ void chol_load_factor(sdm_plan *P, const double *h_Lpr) {
   CholPlan &C = P->chol;
   DevBuf<double> tmp;
   tmp.upload(h_Lpr, (size_t)C.nnzL);
-  SDM_KLAUNCH(P, k_load_factor, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, tmp.p, C.d_asm_dst.p,
-             (int64_t)C.nnzL);
+  SDM_KLAUNCH(P, k_load_factor, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, C.frontsT.p, tmp.p, C.d_asm_dst.p,
+              C.d_asm_dstT.p, (int64_t)C.nnzL);
   SDM_HIP_CHECK(hipStreamSynchronize(P->stream));
   P->factored = true;
 }
 
+// the front-local vector goes to LDS when the largest front of the plan fits (96 KB), else it stays in HBM
+static void solve_lds(CholPlan &C, bool fw, size_t &bytes, int &use) {
+  const int need = fw ? C.maxms : C.maxns;
+  use = need <= SOLVE_LDS_MAX ? 1 : 0;
+  bytes = use ? (size_t)need * sizeof(double) : 0;
+}
 void solve_fw(sdm_plan *P) {
   CholPlan &C = P->chol;
   FrontTab tab = front_tab(C);
+  size_t fw_lds; int fw_use; solve_lds(C, true, fw_lds, fw_use);
+#ifndef SDM_EMU
+  if (fw_lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_fw_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds));
+#endif
   for (int l = 0; l < C.nlevels; l++) {
     const int nfr = C.levptr[l + 1] - C.levptr[l];
-    SDM_KLAUNCH(P, k_fw_level, dim3(nfr), dim3(512), 0, C.fronts.p, tab, C.d_levlist.p + C.levptr[l], C.wvec.p,
-               P->ywork.p);
+    SDM_KLAUNCH(P, k_fw_level, dim3(nfr), dim3(512), fw_lds, C.fronts.p, tab, C.d_levlist.p + C.levptr[l], C.wvec.p,
+                P->ywork.p, fw_use);
   }
 }
 void solve_bw(sdm_plan *P) {
   CholPlan &C = P->chol;
   FrontTab tab = front_tab(C);
+  size_t bw_lds; int bw_use; solve_lds(C, false, bw_lds, bw_use);
+#ifndef SDM_EMU
+  if (bw_lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_bw_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bw_lds));
+#endif
   for (int l = C.nlevels - 1; l >= 0; l--) {
     const int nfr = C.levptr[l + 1] - C.levptr[l];
-    SDM_KLAUNCH(P, k_bw_level, dim3(nfr), dim3(512), 0, C.fronts.p, tab, C.d_levlist.p + C.levptr[l], P->ywork.p);
+    SDM_KLAUNCH(P, k_bw_level, dim3(nfr), dim3(512), bw_lds, C.frontsT.p, tab, C.d_levlist.p + C.levptr[l], P->ywork.p, bw_use);
   }
 }
 void vec_gather(sdm_plan *P, double *dst, const double *src, bool forward) {

@@ -8,6 +8,8 @@ namespace sdm {
 
 constexpr int NB = 32;     // factor / solve panel width (columns)
 constexpr int TILE = 64;   // trailing-update tile (MFMA 4 waves x 32x32)
+constexpr int SNB = 64;    // solve panel width: one wavefront does the in-block TRSV, one lane per row
+constexpr int SOLVE_LDS_MAX = 12288;  // doubles of the front-local vector kept in LDS (96 KB)
 
 template <class T>
 struct DevBuf {
@@ -51,18 +53,19 @@ struct LevelLaunch {
 struct CholPlan {
   sdm_int m = 0, nsuper = 0, nnzL = 0, nnzADA = 0;
   int nlevels = 0;
-  int64_t fsize = 0, wsize = 0;
+  int64_t fsize = 0, wsize = 0, tsize = 0;
+  int maxms = 0, maxns = 0;
   std::vector<sdm_int> Ljc, perm;
   std::vector<int> sn_first, sn_ns, sn_ms, sn_parent, sn_level;
-  std::vector<int64_t> sn_foff, sn_xl, sn_woff, sn_roff;
+  std::vector<int64_t> sn_foff, sn_xl, sn_woff, sn_roff, sn_toff;
   std::vector<int> childptr, childlist, levptr, levlist, lev_T;
   std::vector<LevelLaunch> launches;     // factor panel launches in execution order
   std::vector<int> lev_first_launch;     // index into launches per level (+ sentinel)
   // device copies
   DevBuf<int> d_first, d_ns, d_ms, d_parent, d_childptr, d_childlist, d_levlist, d_lindx, d_relidx, d_perm;
-  DevBuf<int64_t> d_foff, d_xl, d_woff, d_roff, d_asm_dst, d_Ljc;
+  DevBuf<int64_t> d_foff, d_xl, d_woff, d_roff, d_toff, d_asm_dst, d_asm_dstT, d_Ljc;
   DevBuf<int> d_asm_src;
-  DevBuf<double> fronts, wvec, colbuf, d, dsolve, lb, pivval, ub;
+  DevBuf<double> fronts, frontsT, wvec, colbuf, d, dsolve, lb, pivval, ub;
   DevBuf<int> pivstat;
 };
 

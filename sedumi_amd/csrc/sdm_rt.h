@@ -10,6 +10,8 @@
 typedef emu_double4 sdm_double4;
 #define SDM_MFMA_F64_16x16x4(a, b, c) emu_mfma_f64_16x16x4((a), (b), (c))
 #define SDM_DYN_SMEM(name) char *name = emu_dyn_smem()
+// value of `v` in lane `lane` (lane uniform across the wavefront), delivered to every lane
+inline double sdm_bcast_lane(double v, int lane) { return emu_shfl(v, lane, 0); }
 #else
 #include <hip/hip_runtime.h>
 typedef double sdm_double4 __attribute__((ext_vector_type(4)));
@@ -17,6 +19,14 @@ typedef double sdm_double4 __attribute__((ext_vector_type(4)));
 #define SDM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define SDM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
   hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (stream), __VA_ARGS__)
+// v_readlane_b32 x2: a scalar broadcast, no LDS crossbar round trip (ds_bpermute) on the dependency chain
+__device__ __forceinline__ double sdm_bcast_lane(double v, int lane) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+  return u.d;
+}
 #endif
 
 #include <cstdint>

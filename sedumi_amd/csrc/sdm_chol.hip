@@ -241,6 +241,7 @@ __global__ void k_extend_add(double *F, FrontTab tab, const int *list) {
 __device__ double pivot_probe(const double (*S)[NB + 1], int k, int kb, int k0, int ns, int ms, int first,
                               const double *Fs, const double *d, double *cb, double next_raw_diag,
                               double *red_v, int *red_i) {
+  SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
   const int tid = threadIdx.x, bs = blockDim.x;
   const int len = ms - (k0 + k) - 1;          // entries below the diagonal of this column
   const int nin = kb - k - 1;                 // of which inside the LDS block
@@ -288,6 +289,7 @@ __global__ void __launch_bounds__(256)
 k_ldl_diag(double *F, double *FT, FrontTab tab, const int *list, int panel, double *d, double *lb, const double *ubp,
            int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src,
            const int64_t *Ljc, int mtot) {
+  SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
   __shared__ double S[NB][NB + 1];
   __shared__ double lcol[NB];
   __shared__ double red_v[256];
@@ -327,8 +329,10 @@ k_ldl_diag(double *F, double *FT, FrontTab tab, const int *list, int panel, doub
 #pragma unroll
             for (int j = k + 1; j < NB; j++) {
               if (j < kb) {
-                const double xjk = sdm_bcast_lane(x[k], j);     // S[j][k], still unscaled
-                if (i >= j) x[j] -= l * xjk;
+                // x(i,j) -= (x(j,k)/xkk) * x(i,k): scaled multiplier of column j times the unscaled own entry,
+                // the operand order of cholonBlk (blkchol2.c:141-146) so that noise-level pivots round alike
+                const double ljk = sdm_bcast_lane(l, j);
+                if (i >= j) x[j] -= ljk * x[k];
               }
             }
             if (i > k) x[k] = l;
@@ -408,6 +412,7 @@ k_ldl_diag(double *F, double *FT, FrontTab tab, const int *list, int panel, doub
 // ---- K2: rows below the diagonal block: X = A21 * L11^-T, L21 = X * D^-1 (one row per work-item)
 __global__ void __launch_bounds__(256)
 k_ldl_panel(double *F, double *FT, FrontTab tab, const int *list, int panel, const double *d) {
+  SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
   __shared__ double Ls[NB][NB + 1];
   __shared__ double ds[NB];
   const int s = list[blockIdx.y];

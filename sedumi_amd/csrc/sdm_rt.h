@@ -29,6 +29,14 @@ __device__ __forceinline__ double sdm_bcast_lane(double v, int lane) {
 }
 #endif
 
+// Statement-level switch: keep a*b-c as two roundings (gcc -O2 on x86-64 emits no FMA for the reference's
+// daxpy loops); used where a pivot accept/skip decision depends on noise-level values (blkchol2.c:114-161).
+#ifdef SDM_EMU
+#define SDM_FP_STRICT do {} while (0)
+#else
+#define SDM_FP_STRICT _Pragma("clang fp contract(off)")
+#endif
+
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>

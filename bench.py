@@ -152,7 +152,7 @@ def main():
     if dom:
         calls, ms = prof[dom]
         avg_s = ms / calls * 1e-3
-        if dom in ("k_fw_level", "k_bw_level"):
+        if dom in ("k_fw_level", "k_bw_level", "k_ldl_single"):
             alg_bytes = solve_bytes
         elif dom in ("k_psd_stage1", "k_psd_stage2"):
             alg_bytes = 8.0 * (ud.size + P.At.nnz + plan.nnzADA)          # SURVEY.md 8(d) getada3 lower bound

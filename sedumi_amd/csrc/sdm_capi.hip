@@ -164,6 +164,7 @@ int sdm_plan_pivots(sdm_plan *p, sdm_int *nskip, sdm_int *skip_idx, double *skip
 int sdm_plan_fwsolve(sdm_plan *p) {
   SDM_TRY
   if (!p->factored) throw std::runtime_error("fwsolve: no factor resident");
+  if (solve_single(p, p->rhs.p, p->y.p, 1)) return 0;
   vec_gather(p, p->ywork.p, p->rhs.p, true);
   solve_fw(p);
   SDM_HIP_CHECK(hipMemcpyAsync(p->y.p, p->ywork.p, p->chol.m * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
@@ -172,6 +173,7 @@ int sdm_plan_fwsolve(sdm_plan *p) {
 int sdm_plan_bwsolve(sdm_plan *p) {
   SDM_TRY
   if (!p->factored) throw std::runtime_error("bwsolve: no factor resident");
+  if (solve_single(p, p->rhs.p, p->y.p, 4)) return 0;
   SDM_HIP_CHECK(hipMemcpyAsync(p->ywork.p, p->rhs.p, p->chol.m * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   solve_bw(p);
   vec_gather(p, p->y.p, p->ywork.p, false);
@@ -180,6 +182,7 @@ int sdm_plan_bwsolve(sdm_plan *p) {
 int sdm_plan_ldlsolve(sdm_plan *p) {
   SDM_TRY
   if (!p->factored) throw std::runtime_error("ldlsolve: no factor resident");
+  if (solve_single(p, p->rhs.p, p->y.p, 7)) return 0;
   vec_gather(p, p->ywork.p, p->rhs.p, true);
   solve_fw(p);
   vec_divd(p, p->ywork.p);

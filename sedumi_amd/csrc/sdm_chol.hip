@@ -10,10 +10,11 @@
 // independent fronts of an elimination-tree level are factored by the same
 // launches; children pass their Schur complements to the parent by a
 // deterministic, ownership-partitioned extend-add (no atomics).  Inside a
-// front the elimination is blocked: a 32-column diagonal block is factored in
-// LDS (pivot rule applied column by column), the panel below is solved one
-// row per work-item, and the trailing update  C -= L21*D*L21'  runs on the FP64
-// matrix cores (v_mfma_f64_16x16x4_f64, 64x64 tile per 4-wave workgroup).
+// front the elimination is blocked by 64 columns, two launches per panel: (1) the
+// diagonal block is factored in LDS (pivot rule applied column by column) and the
+// rows below it are solved one row per work-item, (2) the trailing update
+// C -= L21*D*L21'  runs on the FP64 matrix cores (v_mfma_f64_16x16x4_f64, 64x64
+// tile per 4-wave workgroup).
 // The result is the same L, d (unit diagonal stored explicitly, skipped
 // columns returned as unit vectors, blkchol.c:409-414) up to rounding, and the
 // pivot DECISIONS follow blkchol2.c:114-161 including the idamax quirk of
@@ -34,7 +35,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   C.Ljc.assign(Ljc, Ljc + m + 1);
   C.perm.assign(perm, perm + m);
   std::vector<int> snode(m);
-  C.sn_first.resize(nsuper); C.sn_ns.resize(nsuper); C.sn_ms.resize(nsuper);
+  C.sn_first.resize(nsuper); C.sn_ns.resize(nsuper); C.sn_ms.resize(nsuper); C.sn_ld.resize(nsuper);
   C.sn_parent.assign(nsuper, -1); C.sn_level.assign(nsuper, 0);
   C.sn_foff.resize(nsuper); C.sn_xl.resize(nsuper); C.sn_woff.resize(nsuper); C.sn_roff.assign(nsuper, 0);
   C.sn_toff.resize(nsuper);
@@ -49,7 +50,8 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
     }
     C.sn_first[s] = (int)f; C.sn_ns[s] = (int)n; C.sn_ms[s] = (int)ms;
     C.sn_foff[s] = foff; C.sn_xl[s] = xl; C.sn_woff[s] = xl; C.sn_toff[s] = toff;
-    foff += (int64_t)ms * ms; xl += ms; toff += (int64_t)ms * n;
+    C.sn_ld[s] = (int)(ms + (ms & 1));                        // even leading dimension: 16-byte aligned row pairs in every column
+    foff += (int64_t)C.sn_ld[s] * ms; xl += ms; toff += (int64_t)((n + NB - 1) / NB) * NB * NB;
     C.maxms = std::max(C.maxms, (int)ms); C.maxns = std::max(C.maxns, (int)n);
   }
   C.fsize = foff; C.wsize = xl; C.tsize = toff;
@@ -109,11 +111,14 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
     for (sdm_int j = 0; j < m; j++) {
       sdm_int jc = perm[j];
       for (sdm_int t = ADAjc[jc]; t < ADAjc[jc + 1]; t++) rowpos[ADAir[t]] = (int)t;
-      int s = snode[j]; int c = (int)(j - C.sn_first[s]); int64_t ms = C.sn_ms[s];
+      int s = snode[j]; int c = (int)(j - C.sn_first[s]);
       for (sdm_int t = Ljc[j]; t < Ljc[j + 1]; t++) {
         asm_src[t] = rowpos[perm[Lir[t]]];
-        asm_dst[t] = C.sn_foff[s] + (int64_t)c * ms + c + (t - Ljc[j]);
-        asm_dstT[t] = C.sn_toff[s] + (int64_t)(c + (t - Ljc[j])) * C.sn_ns[s] + c;     // L^T panel: (row r) * n_s + c
+        asm_dst[t] = C.sn_foff[s] + (int64_t)c * C.sn_ld[s] + c + (t - Ljc[j]);
+        { // transposed copy of the 64x64 diagonal blocks only: DT[panel][row in block][col in block]
+          const int64_t rr = c + (t - Ljc[j]); const int pnl = c / NB;
+          asm_dstT[t] = (rr < (int64_t)(pnl + 1) * NB && rr < C.sn_ns[s]) ? C.sn_toff[s] + (int64_t)pnl * NB * NB + (rr - (int64_t)pnl * NB) * NB + (c - pnl * NB) : -1;
+        }
       }
       for (sdm_int t = ADAjc[jc]; t < ADAjc[jc + 1]; t++) rowpos[ADAir[t]] = -1;
     }
@@ -143,7 +148,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   }
   C.lev_first_launch[nlev] = (int)C.launches.size();
   // upload
-  C.d_first.upload(C.sn_first); C.d_ns.upload(C.sn_ns); C.d_ms.upload(C.sn_ms); C.d_parent.upload(C.sn_parent);
+  C.d_first.upload(C.sn_first); C.d_ns.upload(C.sn_ns); C.d_ms.upload(C.sn_ms); C.d_ld.upload(C.sn_ld); C.d_parent.upload(C.sn_parent);
   C.d_childptr.upload(C.childptr); C.d_childlist.upload(C.childlist); C.d_levlist.upload(C.levlist);
   C.d_lindx.upload(lindx); C.d_relidx.upload(relidx);
   { std::vector<int> p32(m); for (sdm_int i = 0; i < m; i++) p32[i] = (int)perm[i]; C.d_perm.upload(p32); }
@@ -151,7 +156,14 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   C.d_asm_src.upload(asm_src); C.d_asm_dst.upload(asm_dst); C.d_asm_dstT.upload(asm_dstT); C.d_toff.upload(C.sn_toff);
   C.frontsT.alloc((size_t)C.tsize);
   { std::vector<int64_t> l64(C.Ljc.begin(), C.Ljc.end()); C.d_Ljc.upload(l64); }
-  C.fronts.alloc((size_t)C.fsize); C.wvec.alloc((size_t)C.wsize); C.colbuf.alloc((size_t)C.wsize + (size_t)nsuper);
+  { std::vector<int64_t> cboff(nsuper); int64_t o = 0;      // per front: one probe column per row batch of its first panel
+    for (sdm_int s = 0; s < nsuper; s++) {
+      cboff[s] = o;
+      const int rows = C.sn_ms[s] - std::min(NB, C.sn_ns[s]);
+      o += (int64_t)std::max(1, (rows + TRSM_ROWS - 1) / TRSM_ROWS) * (C.sn_ms[s] + 1);
+    }
+    C.d_cboff.upload(cboff); C.colbuf.alloc((size_t)o); }
+  C.fronts.alloc((size_t)C.fsize); C.wvec.alloc((size_t)C.wsize);
   C.d.alloc(m); C.dsolve.alloc(m); C.lb.alloc(m); C.pivval.alloc(m); C.pivstat.alloc(m); C.ub.alloc(2);
   P->ada_val.alloc((size_t)C.nnzADA); P->absd.alloc(m); P->lpr.alloc((size_t)C.nnzL);
   P->rhs.alloc(m); P->y.alloc(m); P->ywork.alloc(m);
@@ -160,8 +172,8 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
 
 // ================================================================= kernels
 struct FrontTab {
-  const int *first, *ns, *ms;
-  const int64_t *foff, *xl, *woff, *roff, *toff;
+  const int *first, *ns, *ms, *ld;
+  const int64_t *foff, *xl, *woff, *roff, *toff, *cboff;
   const int *childptr, *childlist, *lindx, *relidx;
 };
 
@@ -179,7 +191,7 @@ __global__ void k_extract(double *Lpr, const double *F, const int64_t *dst, int6
 __global__ void k_load_factor(double *F, double *FT, const double *Lpr, const int64_t *dst, const int64_t *dstT, int64_t nnzL) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; t < nnzL; t += stride) { const double v = Lpr[t]; F[dst[t]] = v; FT[dstT[t]] = v; }
+  for (; t < nnzL; t += stride) { const double v = Lpr[t]; F[dst[t]] = v; if (dstT[t] >= 0) FT[dstT[t]] = v; }
 }
 
 // ---- pivot thresholds (blkchol.c:168-184): one workgroup.
@@ -214,11 +226,11 @@ __global__ void k_prep_pivots(int m, const double *ada, const int *asm_src, cons
 __global__ void k_extend_add(double *F, FrontTab tab, const int *list) {
   const int p = list[blockIdx.y];
   const int slice = blockIdx.x, T = gridDim.x;
-  const int msp = tab.ms[p];
+  const int msp = tab.ld[p];
   double *Fp = F + tab.foff[p];
   for (int ci = tab.childptr[p]; ci < tab.childptr[p + 1]; ci++) {
     const int c = tab.childlist[ci];
-    const int nc = tab.ns[c], mc = tab.ms[c], mu = mc - nc;
+    const int nc = tab.ns[c], mu = tab.ms[c] - nc, mc = tab.ld[c];
     const int *rel = tab.relidx + tab.roff[c];
     const double *Fc = F + tab.foff[c];
     for (int j = 0; j < mu; j++) {
@@ -236,11 +248,13 @@ __global__ void k_extend_add(double *F, FrontTab tab, const int *list) {
 // for column k of the current panel, i.e. x[idamax+1-based] (blkchol2.c:66-70,
 // 121-131).  Column storage order = front rows below the diagonal.  All
 // threads of the workgroup call this (uniform).  S = diagonal block in LDS
-// (columns < k already final), rows below the block are obtained by forward
-// substitution against those columns.  cb = scratch of >= ms+1 doubles.
-__device__ double pivot_probe(const double (*S)[NB + 1], int k, int kb, int k0, int ns, int ms, int first,
-                              const double *Fs, const double *d, double *cb, double next_raw_diag,
-                              double *red_v, int *red_i) {
+// (unscaled, updated by the columns < k), Lc[j*NB+i] = l_ij of the finished
+// columns, ds = their pivots, rows below the block are
+// obtained by forward substitution against those columns.  cb = scratch of >= ms+1
+// doubles (every row batch of the front computes and writes the same values).
+__device__ __noinline__ double pivot_probe(const double (*S)[NB + 1], const double *Lc, int k, int kb, int k0, int ns,
+                                           int ms, int ld, const double *Fs, const double *ds, double *cb,
+                                           double next_raw_diag, double *red_v, int *red_i) {
   SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
   const int tid = threadIdx.x, bs = blockDim.x;
   const int len = ms - (k0 + k) - 1;          // entries below the diagonal of this column
@@ -251,15 +265,15 @@ __device__ double pivot_probe(const double (*S)[NB + 1], int k, int kb, int k0, 
     double x[NB];
     double diagacc = 0.0;
     for (int c = 0; c <= k; c++) {
-      double v = Fs[(int64_t)(k0 + c) * ms + r];
-      for (int j = 0; j < c; j++) v -= x[j] * S[c][j];
-      double dc = (c < k) ? d[first + k0 + c] : 1.0;
+      double v = Fs[(int64_t)(k0 + c) * ld + r];
+      for (int j = 0; j < c; j++) v -= x[j] * Lc[j * NB + c];   // l_cj, scaled
+      double dc = (c < k) ? ds[c] : 1.0;
       x[c] = (dc > 0.0) ? v : 0.0;
       if (c < k && dc > 0.0) diagacc += x[c] * (x[c] / dc);
     }
     cb[nin + (r - (k0 + kb))] = x[k];
     if (r == k0 + kb && nin == 0 && k0 + k + 1 < ns)   // next column = first row below the block
-      cb[len] = Fs[(int64_t)r * ms + r] - diagacc;
+      cb[len] = Fs[(int64_t)r * ld + r] - diagacc;
   }
   if (tid == 0) {
     if (k0 + k + 1 >= ns) cb[len] = next_raw_diag;      // next column lives in the next supernode: untouched so far
@@ -284,167 +298,102 @@ __device__ double pivot_probe(const double (*S)[NB + 1], int k, int kb, int k0, 
   return val;
 }
 
-// ---- K1: LDL' of the kb x kb diagonal block of panel p (one workgroup per front)
-__global__ void __launch_bounds__(256)
-k_ldl_diag(double *F, double *FT, FrontTab tab, const int *list, int panel, double *d, double *lb, const double *ubp,
-           int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src,
-           const int64_t *Ljc, int mtot) {
+// ---- K1: one launch per 64-column panel p of the fronts of a level: LDL' of the kb x kb diagonal block and
+// the solve of the rows below it.  grid = (row batches of TRSM_ROWS, fronts).  EVERY workgroup factors the
+// diagonal block itself in LDS (it needs L11 and d for its rows anyway; redundant work on otherwise idle CUs
+// is cheaper than a launch boundary), batch 0 writes it back.  Arithmetic follows cholonBlk operand for
+// operand (blkchol2.c:114-161): column i -= (x_ik / x_kk) * x(:,k), rows below the block
+// x_rc = a_rc - sum_{j<c} x_rj * l_cj in ascending j, l_rc = x_rc / d_c; skipped pivots (d = 0) are not used.
+__global__ void __launch_bounds__(PANEL_THREADS)
+k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, double *d, double *lb, const double *ubp,
+            int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src,
+            const int64_t *Ljc, int mtot) {
   SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
-  __shared__ double S[NB][NB + 1];
-  __shared__ double lcol[NB];
-  __shared__ double red_v[256];
-  __shared__ int red_i[256];
-  const int s = list[blockIdx.x];
-  const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
+  SDM_DYN_SMEM(smem);
+  double (*S)[NB + 1] = (double (*)[NB + 1])smem;                 // diagonal block, S[row][col]
+  double *Xs = (double *)smem + NB * (NB + 1);                    // unscaled x of finished column chunks: Xs[col][row in batch]
+  __shared__ double ds[NB], lbs[NB], pv[NB];
+  __shared__ int stt[NB];
+  __shared__ double red_v[PANEL_THREADS];
+  __shared__ int red_i[PANEL_THREADS];
+  const int s = list[blockIdx.y];
+  const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
   const int k0 = panel * NB, kb = min(NB, ns - k0);
+  const int r0 = k0 + kb, nrows = ms - r0;
+  const int batch = blockIdx.x;
+  if (batch > 0 && batch * TRSM_ROWS >= nrows) return;            // uniform; batch 0 always runs (it owns the block)
   double *Fs = F + tab.foff[s];
-  double *Ts = FT + tab.toff[s];
-  double *cb = colbuf + tab.woff[s] + s;
-  const int tid = threadIdx.x;
+  double *cb = colbuf + tab.cboff[s] + (int64_t)batch * (ms + 1);     // probe scratch of this row batch
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int tx = tid & 63, ty = tid >> 6, ny = bs >> 6;
   const double ub = ubp[0], maxu = ubp[1];
-  // ---- fast path: one wavefront, lane i owns row i of the block in registers; column k's pivot and the
-  // unscaled column entries travel by v_readlane broadcasts -- no LDS traffic, no barrier in the k-loop.
-  // It gives up (nothing written) as soon as a pivot needs the column probe of the never-fail rule, which
-  // is then handled by the general LDS path below.
-  __shared__ int fast_ok;
-  if (tid < 64) {
-    const int i = tid;
-    double x[NB];
-#pragma unroll
-    for (int j = 0; j < NB; j++) x[j] = (j <= i && i < kb) ? Fs[(int64_t)(k0 + j) * ms + k0 + i] : 0.0;
-    const double mylb = i < kb ? lb[first + k0 + i] : 0.0;
-    double dval = 0.0, pval = 0.0;
-    int stat = 0;
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-      if (k < kb && ok) {
-        const double xkk = sdm_bcast_lane(x[k], k);
-        const double lbk = sdm_bcast_lane(mylb, k);
-        if (xkk > lbk) {
-          if (ms - (k0 + k) > 1 && xkk < ub) {
-            ok = false;
-          } else {
-            const double l = x[k] / xkk;               // lanes i > k: l_ik
-#pragma unroll
-            for (int j = k + 1; j < NB; j++) {
-              if (j < kb) {
-                // x(i,j) -= (x(j,k)/xkk) * x(i,k): scaled multiplier of column j times the unscaled own entry,
-                // the operand order of cholonBlk (blkchol2.c:141-146) so that noise-level pivots round alike
-                const double ljk = sdm_bcast_lane(l, j);
-                if (i >= j) x[j] -= ljk * x[k];
-              }
-            }
-            if (i > k) x[k] = l;
-            if (i == k) { dval = xkk; stat = 0; }
-          }
-        } else {
-          if (i > k) x[k] = 0.0;
-          if (i == k) { dval = 0.0; stat = 1; pval = xkk; }
-        }
-      }
-    }
-    if (tid == 0) fast_ok = ok ? 1 : 0;
-    if (ok && i < kb) {
-#pragma unroll
-      for (int j = 0; j < NB; j++) {
-        if (j <= i) {
-          const double v = (j == i) ? 1.0 : x[j];
-          Fs[(int64_t)(k0 + j) * ms + k0 + i] = v;
-          Ts[(int64_t)(k0 + i) * ns + k0 + j] = v;
-        }
-      }
-      const int gk = first + k0 + i;
-      d[gk] = dval;
-      if (stat) { pivstat[gk] = 1; pivval[gk] = pval; }
-    }
-  }
-  __syncthreads();
-  if (fast_ok) return;
-  for (int idx = tid; idx < kb * kb; idx += blockDim.x) {
-    int i = idx % kb, j = idx / kb;
-    if (i >= j) S[i][j] = Fs[(int64_t)(k0 + j) * ms + k0 + i];
-  }
+  double *Lc = Xs;                                                  // Lc[k*NB+i] = l_ik (aliases Xs until the row solve)
+  for (int j = ty; j < NB; j += ny) { S[tx][j] = (tx < kb && j <= tx) ? Fs[(int64_t)(k0 + j) * ld + k0 + tx] : 0.0; Lc[j * NB + tx] = 0.0; }
+  if (tid < NB) { lbs[tid] = tid < kb ? lb[first + k0 + tid] : 0.0; ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
   __syncthreads();
   for (int k = 0; k < kb; k++) {
-    const int gk = first + k0 + k;
     double xkk = S[k][k];
-    const double lbk = lb[gk];
-    const bool accept = xkk > lbk;
-    if (accept) {
-      const int mrem = ms - (k0 + k);
-      if (mrem > 1 && xkk < ub) {
+    if (xkk > lbs[k]) {
+      if (ms - (k0 + k) > 1 && xkk < ub) {                         // rare: stability probe of the never-fail rule
         double nraw = 0.0;
         if (k0 + k + 1 >= ns && first + ns < mtot) { int sidx = asm_src[Ljc[first + ns]]; nraw = sidx < 0 ? 0.0 : ada[sidx]; }
-        const double ubk = pivot_probe(S, k, kb, k0, ns, ms, first, Fs, d, cb, nraw, red_v, red_i) / maxu;
+        const double ubk = pivot_probe(S, Lc, k, kb, k0, ns, ms, ld, Fs, ds, cb, nraw, red_v, red_i) / maxu;
         if (xkk < ubk) {
-          if (tid == 0) { pivstat[gk] = 2; pivval[gk] = ubk - xkk; lb[gk] = ubk - xkk; }
+          if (tid == 0) { stt[k] = 2; pv[k] = ubk - xkk; lbs[k] = ubk - xkk; }
           xkk = ubk;
         }
       }
-      if (tid > k && tid < kb) lcol[tid] = S[tid][k] / xkk;
-      __syncthreads();
-      const int nrem = kb - k - 1;
-      for (int idx = tid; idx < nrem * nrem; idx += blockDim.x) {
-        int r = k + 1 + idx % nrem, i = k + 1 + idx / nrem;
-        if (r >= i) S[r][i] -= lcol[i] * S[r][k];
-      }
-      __syncthreads();
-      if (tid > k && tid < kb) S[tid][k] = lcol[tid];
-      if (tid == 0) d[gk] = xkk;
+      // every work-item forms the multipliers it needs itself (same division, same rounding): one barrier per column
+      const double sik = S[tx][k];
+      if (tid > k && tid < kb) Lc[k * NB + tid] = sik / xkk;
+      if (tid == 0) ds[k] = xkk;
+      for (int i = k + 1 + ty; i < kb; i += ny)
+        if (tx >= i) S[tx][i] -= (S[i][k] / xkk) * sik;
     } else {
-      // skipped pivot: d=0, column becomes the unit vector (blkchol2.c:157-161, blkchol.c:409-414)
-      if (tid > k && tid < kb) S[tid][k] = 0.0;
-      if (tid == 0) { pivstat[gk] = 1; pivval[gk] = xkk; d[gk] = 0.0; }   // S[k][k] is still being read by slower waves
+      // skipped pivot: d = 0, the column becomes the unit vector (blkchol2.c:157-161, blkchol.c:409-414)
+      if (tid == 0) { stt[k] = 1; pv[k] = xkk; ds[k] = 0.0; }
     }
     __syncthreads();
   }
-  for (int idx = tid; idx < kb * kb; idx += blockDim.x) {
-    int i = idx % kb, j = idx / kb;
-    if (i >= j) {
-      const double v = (i == j) ? 1.0 : S[i][j];                                  // unit diagonal (blkchol2.c:136)
-      Fs[(int64_t)(k0 + j) * ms + k0 + i] = v;
-      Ts[(int64_t)(k0 + i) * ns + k0 + j] = v;                                    // L^T panel copy for the backward solve
+  for (int j = ty; j < NB; j += ny) if (tx > j) S[tx][j] = Lc[j * NB + tx];     // scaled columns for the row solve
+  __syncthreads();
+  if (batch == 0) {
+    double *Ds = DT + tab.toff[s] + (int64_t)panel * NB * NB;
+    for (int j = ty; j < kb; j += ny)
+      if (tx < kb && tx >= j) {
+        const double v = (tx == j) ? 1.0 : S[tx][j];                // unit diagonal stored explicitly (blkchol2.c:136)
+        Fs[(int64_t)(k0 + j) * ld + k0 + tx] = v;
+        Ds[tx * NB + j] = v;                                        // transposed copy of the block for the backward solve
+      }
+    if (tid < kb) {
+      const int gk = first + k0 + tid;
+      d[gk] = ds[tid];
+      if (stt[tid]) { pivstat[gk] = stt[tid]; pivval[gk] = pv[tid]; }
+      if (stt[tid] == 2) lb[gk] = lbs[tid];
     }
   }
-}
-
-// ---- K2: rows below the diagonal block: X = A21 * L11^-T, L21 = X * D^-1 (one row per work-item)
-__global__ void __launch_bounds__(256)
-k_ldl_panel(double *F, double *FT, FrontTab tab, const int *list, int panel, const double *d) {
-  SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
-  __shared__ double Ls[NB][NB + 1];
-  __shared__ double ds[NB];
-  const int s = list[blockIdx.y];
-  const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
-  const int k0 = panel * NB, kb = min(NB, ns - k0);
-  const int r0 = k0 + kb;
-  if ((int)(blockIdx.x * blockDim.x) >= ms - r0) return;       // uniform per workgroup
-  double *Fs = F + tab.foff[s];
-  double *Ts = FT + tab.toff[s];
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < kb * kb; idx += blockDim.x) {
-    int i = idx % kb, j = idx / kb;
-    if (i > j) Ls[i][j] = Fs[(int64_t)(k0 + j) * ms + k0 + i];
-  }
-  if (tid < kb) ds[tid] = d[first + k0 + tid];
-  __syncthreads();
-  const int r = r0 + blockIdx.x * blockDim.x + tid;
-  if (r < ms) {
-    double x[NB];
+  // ---- rows below the block: one row per work-item, 16-column chunks; x of earlier chunks parked in LDS
+  const int r = r0 + batch * TRSM_ROWS + tid;
+  if (tid >= TRSM_ROWS || r >= ms) return;
+  for (int c0 = 0; c0 < kb; c0 += CHK) {
+    double acc[CHK], x[CHK];
 #pragma unroll
-    for (int c = 0; c < NB; c++) {
-      if (c < kb) {
-        double v = Fs[(int64_t)(k0 + c) * ms + r];
+    for (int cc = 0; cc < CHK; cc++) acc[cc] = (c0 + cc < kb) ? Fs[(int64_t)(k0 + c0 + cc) * ld + r] : 0.0;
+    for (int j = 0; j < c0; j++) {
+      const double xj = Xs[j * TRSM_ROWS + tid];
 #pragma unroll
-        for (int j = 0; j < NB; j++)
-          if (j < c) v -= x[j] * Ls[c][j];
-        const double dc = ds[c];
-        x[c] = dc > 0.0 ? v : 0.0;
-        const double l = dc > 0.0 ? v / dc : 0.0;
-        Fs[(int64_t)(k0 + c) * ms + r] = l;
-        Ts[(int64_t)r * ns + k0 + c] = l;
-      }
+      for (int cc = 0; cc < CHK; cc++) acc[cc] -= xj * S[c0 + cc][j];
+    }
+#pragma unroll
+    for (int cc = 0; cc < CHK; cc++) {
+      double v = acc[cc];
+#pragma unroll
+      for (int jj = 0; jj < CHK; jj++)
+        if (jj < cc) v -= x[jj] * S[c0 + cc][c0 + jj];
+      const double dc = ds[c0 + cc];
+      x[cc] = dc > 0.0 ? v : 0.0;
+      if (c0 + cc < kb) Fs[(int64_t)(k0 + c0 + cc) * ld + r] = dc > 0.0 ? v / dc : 0.0;
+      if (c0 + CHK < NB) Xs[(c0 + cc) * TRSM_ROWS + tid] = x[cc];
     }
   }
 }
@@ -459,7 +408,7 @@ k_ldl_update(double *F, FrontTab tab, const int *list, int panel, const double *
   __shared__ double As[NB][TILE];   // As[k][i] = L21[I-tile row i][k]
   __shared__ double Bs[NB][TILE];   // Bs[k][j] = L21[J-tile row j][k] * d_k
   const int s = list[blockIdx.y];
-  const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
+  const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
   const int k0 = panel * NB, kb = min(NB, ns - k0);
   const int r0 = k0 + kb, nrem = ms - r0;
   const int nt = (nrem + TILE - 1) / TILE;
@@ -476,8 +425,8 @@ k_ldl_update(double *F, FrontTab tab, const int *list, int panel, const double *
     const int ri = r0 + I * TILE + i, rj = r0 + J * TILE + i;
     double a = 0.0, b = 0.0;
     if (k < kb) {
-      if (ri < ms) a = Fs[(int64_t)(k0 + k) * ms + ri];
-      if (rj < ms) b = Fs[(int64_t)(k0 + k) * ms + rj] * d[first + k0 + k];
+      if (ri < ms) a = Fs[(int64_t)(k0 + k) * ld + ri];
+      if (rj < ms) b = Fs[(int64_t)(k0 + k) * ld + rj] * d[first + k0 + k];
     }
     As[k][i] = a; Bs[k][i] = b;
   }
@@ -501,32 +450,146 @@ k_ldl_update(double *F, FrontTab tab, const int *list, int panel, const double *
         const int jj = lk + 4 * r;                 // result row  -> J dimension (front column)
         const int gi = r0 + I * TILE + wi * 32 + a * 16 + ll;
         const int gj = r0 + J * TILE + wj * 32 + b * 16 + jj;
-        if (gi < ms && gj < ms && gi >= gj) Fs[(int64_t)gj * ms + gi] -= acc[a][b][r];
+        if (gi < ms && gj < ms && gi >= gj) Fs[(int64_t)gj * ld + gi] -= acc[a][b][r];
       }
 }
 
 // ================================================================== solves
-// One workgroup (512) per front; fronts of an etree level are independent.  The front-local vector lives in
-// LDS.  Per 64-column panel: ONE wavefront does the in-block triangular solve -- lane i owns row i, its 64
-// coefficients sit in registers (prefetched while the previous panel's GEMV runs) and the dependency chain is
-// a v_readlane broadcast + one FMA per column (no LDS, no barrier) -- then all waves apply the panel to the
-// remaining rows with fully coalesced column reads (one row per work-item, 64 independent loads in flight).
-// Forward (fwblkslv.c:77-134): multifrontal, the children's update vectors are summed in a fixed order.
-// Backward (bwblkslv.c:73-125): runs on the L^T panel copy written by the factor kernels, so the update of
-// the earlier unknowns is the same coalesced, reduction-free GEMV as in the forward sweep.
-__global__ void __launch_bounds__(512)
+// One workgroup per front; fronts of an etree level are independent.  The front-local vector w lives in LDS
+// (HBM scratch for fronts beyond SOLVE_LDS_MAX rows).  Per 64-column panel ONE wavefront does the in-block
+// triangular solve -- lane i owns row i, its 64 coefficients sit in registers (prefetched while the previous
+// panel streams) and the dependency chain is a v_readlane broadcast + one FMA per column (no LDS, no barrier)
+// -- while all waves stream the panel below the block exactly once with coalesced reads:
+//   forward  (fwblkslv.c:77-134): one row per work-item, 16 independent loads in flight per lane;
+//   backward (bwblkslv.c:73-125): one column per wavefront at a time (contiguous reads), wave reduction.
+// The transposed in-block solve of the backward sweep reads the 64x64 diagonal blocks from the compact
+// transposed copy DT written by the factor (coalesced for lane = column).
+// Stage the strictly lower triangle of a kb x kb diagonal block into LDS (Sd[c*64 + i] = L(k0+i, k0+c) for
+// c < i < kb, 0 elsewhere) -- all work-items, coalesced along the rows.  The in-block triangular solve then
+// reads its coefficient of step k with one conflict-free ds_read (address independent of the dependency chain).
+__device__ __forceinline__ void stage_block(double *Sd, const double *blk, int ld, int kb) {
+  for (int idx = threadIdx.x; idx < SNB * SNB; idx += blockDim.x) {
+    const int i = idx & 63, c = idx >> 6;
+    Sd[idx] = (c < i && i < kb) ? blk[(int64_t)c * ld + i] : 0.0;
+  }
+}
+// the same from the transposed copy DT (Dp[c*64 + i] = L(k0+c, k0+i)): Sd[c*64 + i] = L(k0+c, k0+i) for i < c < kb
+__device__ __forceinline__ void stage_blockT(double *Sd, const double *Dp, int kb) {
+  for (int idx = threadIdx.x; idx < SNB * SNB; idx += blockDim.x) {
+    const int i = idx & 63, c = idx >> 6;
+    Sd[idx] = (c > i && c < kb) ? Dp[idx] : 0.0;
+  }
+}
+
+constexpr int GB = 16;   // 16-byte loads in flight per lane in the forward panel sweep
+__device__ __forceinline__ void front_fw(const double *Fs, int ns, int ms, int ld, double *w, double *wb, double *Sd) {
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int ld2 = ld >> 1;
+  stage_block(Sd, Fs, ld, min(SNB, ns));
+  __syncthreads();
+  for (int k0 = 0; k0 < ns; k0 += SNB) {
+    const int kb = min(SNB, ns - k0);
+    if (tid < 64) {
+      double wi = tid < kb ? w[k0 + tid] : 0.0;
+#pragma unroll
+      for (int k = 0; k < SNB; k++) wi -= Sd[k * SNB + tid] * sdm_bcast_lane(wi, k);   // coefficient 0 for lanes <= k, k >= kb
+      if (tid < kb) { w[k0 + tid] = wi; wb[tid] = wi; }
+    }
+    __syncthreads();
+    { const int k1 = k0 + SNB;                           // next diagonal block -> LDS while the panel streams
+      if (k1 < ns) stage_block(Sd, Fs + (int64_t)k1 * ld + k1, ld, min(SNB, ns - k1)); }
+    // rows below the block, two per work-item (16-byte loads; ld and the first row are even)
+    const int rb = k0 + kb, ra = rb + (rb & 1);
+    const int npair = ms > ra ? (ms - ra) >> 1 : 0;
+    for (int t = tid; t < npair; t += bs) {
+      const int r = ra + 2 * t;
+      const sdm_double2 *col = (const sdm_double2 *)(Fs + (int64_t)k0 * ld + r);
+      double a0 = 0.0, a1 = 0.0;
+      if (kb == SNB) {
+#pragma unroll 1
+        for (int c0 = 0; c0 < SNB; c0 += GB) {
+          sdm_double2 v[GB];
+#pragma unroll
+          for (int c = 0; c < GB; c++) v[c] = col[(int64_t)(c0 + c) * ld2];
+#pragma unroll
+          for (int c = 0; c < GB; c++) { a0 += v[c].x * wb[c0 + c]; a1 += v[c].y * wb[c0 + c]; }
+        }
+      } else {
+        for (int c = 0; c < kb; c++) { const sdm_double2 v = col[(int64_t)c * ld2]; a0 += v.x * wb[c]; a1 += v.y * wb[c]; }
+      }
+      w[r] -= a0; w[r + 1] -= a1;
+    }
+    {  // the (at most two) unpaired rows: rb when odd, the last row when the pair range leaves one over
+      int r = -1;
+      if (tid == bs - 1 && (rb & 1) && rb < ms) r = rb;
+      if (tid == bs - 2 && ms > ra && ((ms - ra) & 1)) r = ms - 1;
+      if (r >= 0) {
+        const double *col = Fs + (int64_t)k0 * ld + r;
+        double acc = 0.0;
+        for (int c = 0; c < kb; c++) acc += col[(int64_t)c * ld] * wb[c];
+        w[r] -= acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void front_bw(const double *Fs, const double *Ds, int ns, int ms, int ld, double *w, double *dots, double *Sd) {
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
+  const int npan = (ns + SNB - 1) / SNB;
+  for (int pnl = npan - 1; pnl >= 0; pnl--) {
+    stage_blockT(Sd, Ds + (int64_t)pnl * SNB * SNB, ns - pnl * SNB);     // ns - k0 >= kb: entries beyond kb are masked by c < kb
+    const int k0 = pnl * SNB, kb = min(SNB, ns - k0);
+    const int rb = k0 + kb, ra = rb + (rb & 1);
+    // dots[c] = sum_{r >= rb} L(r, k0+c) * w[r]: one column per wavefront at a time, 16-byte loads along the column
+    if (rb < ms) {
+      const int npair = ms > ra ? (ms - ra) >> 1 : 0;
+      for (int c = wave; c < kb; c += nw) {
+        const double *colp = Fs + (int64_t)(k0 + c) * ld;
+        const sdm_double2 *col2 = (const sdm_double2 *)(colp + ra);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int t = lane;
+        for (; t + 192 < npair; t += 256) {
+          const sdm_double2 v0 = col2[t], v1 = col2[t + 64], v2 = col2[t + 128], v3 = col2[t + 192];
+          const double *wp = w + ra + 2 * t;
+          a0 += v0.x * wp[0] + v0.y * wp[1];     a1 += v1.x * wp[128] + v1.y * wp[129];
+          a2 += v2.x * wp[256] + v2.y * wp[257]; a3 += v3.x * wp[384] + v3.y * wp[385];
+        }
+        for (; t < npair; t += 64) { const sdm_double2 v = col2[t]; a0 += v.x * w[ra + 2 * t] + v.y * w[ra + 2 * t + 1]; }
+        if (lane == 0) {
+          if (rb & 1) a1 += colp[rb] * w[rb];
+          if (ms > ra && ((ms - ra) & 1)) a2 += colp[ms - 1] * w[ms - 1];
+        }
+        double acc = (a0 + a1) + (a2 + a3);
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if (lane == 0) dots[c] = acc;
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      double yi = tid < kb ? w[k0 + tid] - (rb < ms ? dots[tid] : 0.0) : 0.0;
+#pragma unroll
+      for (int k = SNB - 1; k >= 0; k--) yi -= Sd[k * SNB + tid] * sdm_bcast_lane(yi, k);   // L(k0+k, k0+tid), 0 unless k > tid
+      if (tid < kb) w[k0 + tid] = yi;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(SOLVE_THREADS)
 k_fw_level(const double *F, FrontTab tab, const int *list, double *wvec, double *y, int use_lds) {
   SDM_DYN_SMEM(smem);
   __shared__ double wb[SNB];
+  __shared__ double Sd[SNB * SNB];
   const int s = list[blockIdx.x];
   const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
-  const double *Fs = F + tab.foff[s];
   double *wg = wvec + tab.woff[s];
   double *w = use_lds ? (double *)smem : wg;
   const int tid = threadIdx.x, bs = blockDim.x;
   for (int i = tid; i < ms; i += bs) w[i] = i < ns ? y[first + i] : 0.0;
   __syncthreads();
-  for (int ci = tab.childptr[s]; ci < tab.childptr[s + 1]; ci++) {
+  for (int ci = tab.childptr[s]; ci < tab.childptr[s + 1]; ci++) {   // children's update vectors, fixed order
     const int c = tab.childlist[ci];
     const int nc = tab.ns[c], mu = tab.ms[c] - nc;
     const int *rel = tab.relidx + tab.roff[c];
@@ -534,103 +597,47 @@ k_fw_level(const double *F, FrontTab tab, const int *list, double *wvec, double 
     for (int i = tid; i < mu; i += bs) w[rel[i]] += wc[i];
     __syncthreads();
   }
-  double lr[SNB];
-  if (tid < 64) {                                    // row tid of the first diagonal block
-    const int kb = min(SNB, ns);
-#pragma unroll
-    for (int c = 0; c < SNB; c++) lr[c] = (c < tid && tid < kb) ? Fs[(int64_t)c * ms + tid] : 0.0;
-  }
-  for (int k0 = 0; k0 < ns; k0 += SNB) {
-    const int kb = min(SNB, ns - k0);
-    if (tid < 64) {
-      double wi = tid < kb ? w[k0 + tid] : 0.0;
-#pragma unroll
-      for (int k = 0; k < SNB; k++) {
-        if (k < kb) {
-          const double wk = sdm_bcast_lane(wi, k);
-          if (tid > k) wi -= lr[k] * wk;             // lr[k] = 0 for lanes outside the block
-        }
-      }
-      if (tid < kb) { w[k0 + tid] = wi; wb[tid] = wi; y[first + k0 + tid] = wi; }
-      const int k1 = k0 + SNB;                         // prefetch the next diagonal block's rows
-      if (k1 < ns) {
-        const int kbn = min(SNB, ns - k1);
-#pragma unroll
-        for (int c = 0; c < SNB; c++) lr[c] = (c < tid && tid < kbn) ? Fs[(int64_t)(k1 + c) * ms + k1 + tid] : 0.0;
-      }
-    }
-    __syncthreads();
-    for (int r = k0 + kb + tid; r < ms; r += bs) {
-      const double *col = Fs + (int64_t)k0 * ms + r;
-      double acc = 0.0;
-#pragma unroll 8
-      for (int c = 0; c < kb; c++) acc += col[(int64_t)c * ms] * wb[c];
-      w[r] -= acc;
-    }
-    __syncthreads();
-  }
+  front_fw(F + tab.foff[s], ns, ms, tab.ld[s], w, wb, Sd);
+  for (int i = tid; i < ns; i += bs) y[first + i] = w[i];
   if (use_lds) for (int i = ns + tid; i < ms; i += bs) wg[i] = w[i];      // update vector for the parent
 }
 
-__global__ void __launch_bounds__(512)
-k_bw_level(const double *FT, FrontTab tab, const int *list, double *y, int use_lds) {
+__global__ void __launch_bounds__(SOLVE_THREADS)
+k_bw_level(const double *F, const double *DT, FrontTab tab, const int *list, double *wvec, double *y, int use_lds) {
   SDM_DYN_SMEM(smem);
-  __shared__ double yb[SNB];
+  __shared__ double dots[SNB];
+  __shared__ double Sd[SNB * SNB];
   const int s = list[blockIdx.x];
   const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
-  const double *T = FT + tab.toff[s];                // T[j*ns + r] = L(j, r): n_s x m_s, column-major
   const int *rows = tab.lindx + tab.xl[s];
-  double *yl = use_lds ? (double *)smem : y + first;
+  double *w = use_lds ? (double *)smem : wvec + tab.woff[s];
   const int tid = threadIdx.x, bs = blockDim.x;
-  if (use_lds) {
-    for (int r = tid; r < ns; r += bs) yl[r] = y[first + r];
-    __syncthreads();
-  }
-  // rows below the supernode belong to ancestors (already solved): y_s -= L21' * y[anc]
-  if (ms > ns) {
-    for (int r = tid; r < ns; r += bs) {
-      double acc = 0.0;
-      for (int j = ns; j < ms; j++) acc += T[(int64_t)j * ns + r] * y[rows[j]];
-      yl[r] -= acc;
-    }
-    __syncthreads();
-  }
-  const int npan = (ns + SNB - 1) / SNB;
-  double lr[SNB];
-  if (tid < 64) {
-    const int k0 = (npan - 1) * SNB, kb = ns - k0;
-#pragma unroll
-    for (int c = 0; c < SNB; c++) lr[c] = (c > tid && c < kb) ? T[(int64_t)(k0 + c) * ns + k0 + tid] : 0.0;
-  }
-  for (int pnl = npan - 1; pnl >= 0; pnl--) {
-    const int k0 = pnl * SNB, kb = min(SNB, ns - k0);
-    if (tid < 64) {
-      double yi = tid < kb ? yl[k0 + tid] : 0.0;
-#pragma unroll
-      for (int k = SNB - 1; k >= 0; k--) {
-        if (k < kb) {
-          const double yk = sdm_bcast_lane(yi, k);
-          if (tid < k) yi -= lr[k] * yk;             // lr[k] = L(k0+k, k0+tid)
-        }
-      }
-      if (tid < kb) { yl[k0 + tid] = yi; yb[tid] = yi; }
-      if (pnl > 0) {
-        const int k1 = k0 - SNB;
-#pragma unroll
-        for (int c = 0; c < SNB; c++) lr[c] = (c > tid) ? T[(int64_t)(k1 + c) * ns + k1 + tid] : 0.0;
-      }
-    }
-    __syncthreads();
-    for (int r = tid; r < k0; r += bs) {
-      const double *col = T + (int64_t)k0 * ns + r;
-      double acc = 0.0;
-#pragma unroll 8
-      for (int c = 0; c < kb; c++) acc += col[(int64_t)c * ns] * yb[c];
-      yl[r] -= acc;
-    }
-    __syncthreads();
-  }
-  if (use_lds) for (int r = tid; r < ns; r += bs) y[first + r] = yl[r];
+  // rows below the supernode belong to ancestors, already final (bwblkslv.c:104-105 gathers them once)
+  for (int i = tid; i < ms; i += bs) w[i] = i < ns ? y[first + i] : y[rows[i]];
+  __syncthreads();
+  front_bw(F + tab.foff[s], DT + tab.toff[s], ns, ms, tab.ld[s], w, dots, Sd);
+  for (int i = tid; i < ns; i += bs) y[first + i] = w[i];
+}
+
+// The whole  y(perm) = L' \ ((L \ rhs(perm)) ./ d)  of wrapPcg.m:56-59 in ONE launch when the factor is a single
+// front (the dense shortcut of symbchol.m:75-77 -- every shipped example): gather, forward sweep, diagonal
+// scaling, backward sweep and scatter without leaving the CU.
+__global__ void __launch_bounds__(SOLVE_THREADS)
+k_ldl_single(const double *F, const double *DT, int m, const int *perm, const double *dsolve, const double *rhs,
+             double *yout, double *wglob, int use_lds, int mode) {
+  SDM_DYN_SMEM(smem);
+  __shared__ double wb[SNB];
+  __shared__ double Sd[SNB * SNB];
+  double *w = use_lds ? (double *)smem : wglob;
+  const int tid = threadIdx.x, bs = blockDim.x;
+  // mode bits: 1 forward sweep, 2 divide by d, 4 backward sweep; rhs is permuted on the way in iff forward,
+  // the result on the way out iff backward (fwblkslv.c:298-303, bwblkslv.c:272-278)
+  for (int i = tid; i < m; i += bs) w[i] = (mode & 1) ? rhs[perm[i]] : rhs[i];
+  __syncthreads();
+  if (mode & 1) front_fw(F, m, m, m + (m & 1), w, wb, Sd);
+  if (mode & 2) { for (int i = tid; i < m; i += bs) w[i] /= dsolve[i]; __syncthreads(); }
+  if (mode & 4) front_bw(F, DT, m, m, m + (m & 1), w, wb, Sd);
+  for (int i = tid; i < m; i += bs) { if (mode & 4) yout[perm[i]] = w[i]; else yout[i] = w[i]; }
 }
 
 __global__ void k_gather_perm(double *dst, const double *src, const int *perm, int m, int forward) {
@@ -650,8 +657,8 @@ __global__ void k_dsolve(double *ds, const double *d, int m) {
 // ============================================================ host drivers
 static FrontTab front_tab(CholPlan &C) {
   FrontTab t;
-  t.first = C.d_first.p; t.ns = C.d_ns.p; t.ms = C.d_ms.p;
-  t.foff = C.d_foff.p; t.xl = C.d_xl.p; t.woff = C.d_woff.p; t.roff = C.d_roff.p; t.toff = C.d_toff.p;
+  t.first = C.d_first.p; t.ns = C.d_ns.p; t.ms = C.d_ms.p; t.ld = C.d_ld.p;
+  t.foff = C.d_foff.p; t.xl = C.d_xl.p; t.woff = C.d_woff.p; t.roff = C.d_roff.p; t.toff = C.d_toff.p; t.cboff = C.d_cboff.p;
   t.childptr = C.d_childptr.p; t.childlist = C.d_childlist.p; t.lindx = C.d_lindx.p; t.relidx = C.d_relidx.p;
   return t;
 }
@@ -666,6 +673,9 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
   FrontTab tab = front_tab(C);
   const int m = (int)C.m;
   
+#ifndef SDM_EMU
+  SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS));
+#endif
   SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), st));
   SDM_KLAUNCH(P, k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
              C.d_asm_dst.p, (int64_t)C.nnzL);
@@ -677,13 +687,12 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
     if (l > 0) SDM_KLAUNCH(P, k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, C.fronts.p, tab, list);
     for (int li = C.lev_first_launch[l]; li < C.lev_first_launch[l + 1]; li++) {
       const LevelLaunch &L = C.launches[li];
-      SDM_KLAUNCH(P, k_ldl_diag, dim3(L.nactive), dim3(256), 0, C.fronts.p, C.frontsT.p, tab, list, L.panel, C.d.p, C.lb.p, C.ub.p,
-                 C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m);
-      if (L.maxrows > 0) {
-        SDM_KLAUNCH(P, k_ldl_panel, dim3((L.maxrows + 255) / 256, L.nactive), dim3(256), 0, C.fronts.p, C.frontsT.p, tab, list,
-                   L.panel, C.d.p);
+      const int nbatch = std::max(1, (L.maxrows + TRSM_ROWS - 1) / TRSM_ROWS);
+      SDM_KLAUNCH(P, k_ldl_panel, dim3(nbatch, L.nactive), dim3(PANEL_THREADS), PANEL_LDS, C.fronts.p, C.frontsT.p, tab, list,
+                  L.panel, C.d.p, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p,
+                  C.d_Ljc.p, m);
+      if (L.maxrows > 0)
         SDM_KLAUNCH(P, k_ldl_update, dim3(L.maxtiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p);
-      }
     }
   }
   SDM_KLAUNCH(P, k_dsolve, dim3((m + 255) / 256), dim3(256), 0, C.dsolve.p, C.d.p, m);
@@ -708,35 +717,52 @@ void chol_load_factor(sdm_plan *P, const double *h_Lpr) {
 }
 
 // the front-local vector goes to LDS when the largest front of the plan fits (96 KB), else it stays in HBM
-static void solve_lds(CholPlan &C, bool fw, size_t &bytes, int &use) {
-  const int need = fw ? C.maxms : C.maxns;
-  use = need <= SOLVE_LDS_MAX ? 1 : 0;
-  bytes = use ? (size_t)need * sizeof(double) : 0;
+static void solve_cfg(CholPlan &C, size_t &bytes, int &use) {
+  use = C.maxms <= SOLVE_LDS_MAX ? 1 : 0;
+  bytes = use ? (size_t)C.maxms * sizeof(double) : 0;
+}
+static int level_threads(const CholPlan &C, int l) {
+  int mx = 0;
+  for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) mx = std::max(mx, C.sn_ms[C.levlist[i]]);
+  return std::min(SOLVE_THREADS, std::max(64, (mx + 63) / 64 * 64));
 }
 void solve_fw(sdm_plan *P) {
   CholPlan &C = P->chol;
   FrontTab tab = front_tab(C);
-  size_t fw_lds; int fw_use; solve_lds(C, true, fw_lds, fw_use);
+  size_t lds; int use; solve_cfg(C, lds, use);
 #ifndef SDM_EMU
-  if (fw_lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_fw_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds));
+  if (lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_fw_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
   for (int l = 0; l < C.nlevels; l++) {
     const int nfr = C.levptr[l + 1] - C.levptr[l];
-    SDM_KLAUNCH(P, k_fw_level, dim3(nfr), dim3(512), fw_lds, C.fronts.p, tab, C.d_levlist.p + C.levptr[l], C.wvec.p,
-                P->ywork.p, fw_use);
+    SDM_KLAUNCH(P, k_fw_level, dim3(nfr), dim3(level_threads(C, l)), lds, C.fronts.p, tab, C.d_levlist.p + C.levptr[l], C.wvec.p,
+                P->ywork.p, use);
   }
 }
 void solve_bw(sdm_plan *P) {
   CholPlan &C = P->chol;
   FrontTab tab = front_tab(C);
-  size_t bw_lds; int bw_use; solve_lds(C, false, bw_lds, bw_use);
+  size_t lds; int use; solve_cfg(C, lds, use);
 #ifndef SDM_EMU
-  if (bw_lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_bw_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bw_lds));
+  if (lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_bw_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
   for (int l = C.nlevels - 1; l >= 0; l--) {
     const int nfr = C.levptr[l + 1] - C.levptr[l];
-    SDM_KLAUNCH(P, k_bw_level, dim3(nfr), dim3(512), bw_lds, C.frontsT.p, tab, C.d_levlist.p + C.levptr[l], P->ywork.p, bw_use);
+    SDM_KLAUNCH(P, k_bw_level, dim3(nfr), dim3(level_threads(C, l)), lds, C.fronts.p, C.frontsT.p, tab, C.d_levlist.p + C.levptr[l],
+                C.wvec.p, P->ywork.p, use);
   }
+}
+// single-front factor: the complete solve (mode bits 1 fw | 2 ./d | 4 bw) in one launch, rhs -> yout
+bool solve_single(sdm_plan *P, const double *rhs, double *yout, int mode) {
+  CholPlan &C = P->chol;
+  if (C.nsuper != 1) return false;
+  size_t lds; int use; solve_cfg(C, lds, use);
+#ifndef SDM_EMU
+  if (lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
+  SDM_KLAUNCH(P, k_ldl_single, dim3(1), dim3(level_threads(C, 0)), lds, C.fronts.p, C.frontsT.p, (int)C.m, C.d_perm.p, C.dsolve.p,
+              rhs, yout, C.wvec.p, use, mode);
+  return true;
 }
 void vec_gather(sdm_plan *P, double *dst, const double *src, bool forward) {
   const int m = (int)P->chol.m;

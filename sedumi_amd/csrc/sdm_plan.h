@@ -6,10 +6,16 @@
 
 namespace sdm {
 
-constexpr int NB = 32;     // factor / solve panel width (columns)
+constexpr int NB = 64;     // factor panel width (columns)
 constexpr int TILE = 64;   // trailing-update tile (MFMA 4 waves x 32x32)
 constexpr int SNB = 64;    // solve panel width: one wavefront does the in-block TRSV, one lane per row
 constexpr int SOLVE_LDS_MAX = 12288;  // doubles of the front-local vector kept in LDS (96 KB)
+constexpr int SOLVE_THREADS = 512;    // workgroup of the per-front solve kernels (8 waves stream the panel; 256 VGPRs each)
+constexpr int PANEL_THREADS = 1024;   // workgroup of the factor's panel kernel (LDL' of the diagonal block)
+constexpr int TRSM_ROWS = 256;        // rows below the diagonal block solved per workgroup (one row per work-item)
+constexpr int CHK = 16;               // column chunk of the row solve held in registers
+constexpr size_t PANEL_LDS = (size_t)(NB * (NB + 1) + (NB - CHK) * TRSM_ROWS) * sizeof(double);
+static_assert(NB == SNB, "the transposed diagonal blocks written by the factor are read by the solves");
 
 template <class T>
 struct DevBuf {
@@ -56,14 +62,14 @@ struct CholPlan {
   int64_t fsize = 0, wsize = 0, tsize = 0;
   int maxms = 0, maxns = 0;
   std::vector<sdm_int> Ljc, perm;
-  std::vector<int> sn_first, sn_ns, sn_ms, sn_parent, sn_level;
+  std::vector<int> sn_first, sn_ns, sn_ms, sn_ld, sn_parent, sn_level;
   std::vector<int64_t> sn_foff, sn_xl, sn_woff, sn_roff, sn_toff;
   std::vector<int> childptr, childlist, levptr, levlist, lev_T;
   std::vector<LevelLaunch> launches;     // factor panel launches in execution order
   std::vector<int> lev_first_launch;     // index into launches per level (+ sentinel)
   // device copies
-  DevBuf<int> d_first, d_ns, d_ms, d_parent, d_childptr, d_childlist, d_levlist, d_lindx, d_relidx, d_perm;
-  DevBuf<int64_t> d_foff, d_xl, d_woff, d_roff, d_toff, d_asm_dst, d_asm_dstT, d_Ljc;
+  DevBuf<int> d_first, d_ns, d_ms, d_ld, d_parent, d_childptr, d_childlist, d_levlist, d_lindx, d_relidx, d_perm;
+  DevBuf<int64_t> d_foff, d_xl, d_woff, d_roff, d_toff, d_cboff, d_asm_dst, d_asm_dstT, d_Ljc;
   DevBuf<int> d_asm_src;
   DevBuf<double> fronts, frontsT, wvec, colbuf, d, dsolve, lb, pivval, ub;
   DevBuf<int> pivstat;
@@ -148,6 +154,7 @@ void chol_extract(sdm_plan *P, double *d_Lpr_out);           // device pointer, 
 void chol_load_factor(sdm_plan *P, const double *h_Lpr);     // host L values -> fronts (for stand-alone solves)
 void solve_fw(sdm_plan *P);   // in place on P->ywork
 void solve_bw(sdm_plan *P);   // in place on P->ywork
+bool solve_single(sdm_plan *P, const double *rhs, double *yout, int mode);  // single-front plans: whole solve in one launch
 void vec_gather(sdm_plan *P, double *dst, const double *src, bool forward);  // dst[k]=src[perm[k]] / dst[perm[k]]=src[k]
 void vec_divd(sdm_plan *P, double *v);
 // sdm_ada.hip

@@ -8,6 +8,7 @@
 #ifdef SDM_EMU
 #include "hipemu.h"
 typedef emu_double4 sdm_double4;
+struct sdm_double2 { double x, y; };
 #define SDM_MFMA_F64_16x16x4(a, b, c) emu_mfma_f64_16x16x4((a), (b), (c))
 #define SDM_DYN_SMEM(name) char *name = emu_dyn_smem()
 // value of `v` in lane `lane` (lane uniform across the wavefront), delivered to every lane
@@ -15,6 +16,7 @@ inline double sdm_bcast_lane(double v, int lane) { return emu_shfl(v, lane, 0); 
 #else
 #include <hip/hip_runtime.h>
 typedef double sdm_double4 __attribute__((ext_vector_type(4)));
+typedef double2 sdm_double2;
 #define SDM_MFMA_F64_16x16x4(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 #define SDM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define SDM_LAUNCH(kernel, grid, block, shmem, stream, ...) \

@@ -32,6 +32,7 @@ using std::max;
 #define __device__
 #define __host__
 #define __forceinline__ inline
+#define __noinline__
 #define __launch_bounds__(...)
 #define __restrict__
 

@@ -148,7 +148,7 @@ def test_resident_plan_and_kernel_timers(glue):
     assert relerr(plan.download("lpr"), it["LL"].data) < TOL
     assert relerr(plan.download("y"), glue.solve_ref(S, it, rhs).ravel()) < TOL
     plan.kprof(True); plan.ldlsolve(); prof = plan.kprof_summary(); plan.kprof(False)
-    assert prof["k_fw_level"][1] > 0 and prof["k_bw_level"][1] > 0
+    assert sum(v[1] for k, v in prof.items() if k in ("k_ldl_single", "k_fw_level", "k_bw_level")) > 0
     plan.close()
 
 

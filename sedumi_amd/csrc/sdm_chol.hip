@@ -481,43 +481,98 @@ __device__ __forceinline__ void stage_blockT(double *Sd, const double *Dp, int k
   }
 }
 
-constexpr int GB = 16;   // 16-byte loads in flight per lane in the forward panel sweep
+constexpr int TCH = 32;  // in-block solve: coefficients fetched from LDS per batch (one LDS round trip per TCH steps of the chain)
+
+// ---- panel streaming helpers.  The panel below a diagonal block is read exactly once, with 16-byte loads (ld
+// and the first row `ra` of the pair range are even), 16 loads per lane in flight.
+// Forward: a row pair is shared by the 4 lanes {l, l+16, l+32, l+48} of a wavefront (g = lane >> 4), each owning
+// 16 of the 64 columns, so that the 16 lanes of one g read 256 contiguous bytes of one column (lanes that are
+// neighbours in a quad must not straddle columns: the L1 coalescer then handles one line per lane, measured 4x
+// slower); the 4 partial sums meet in a fixed-order reduction across g (deterministic).
+__device__ __forceinline__ void fw_issue(sdm_double2 (&v)[16], const double *Fs, int ld, int k0, int ra, int npair, int t, int g) {
+  const sdm_double2 *col = (const sdm_double2 *)(Fs + (int64_t)(k0 + 16 * g) * ld + ra + 2 * min(t, npair - 1));
+  const int ld2 = ld >> 1;
+#pragma unroll
+  for (int c = 0; c < 16; c++) v[c] = col[(int64_t)c * ld2];
+}
+__device__ __forceinline__ void fw_consume(const sdm_double2 (&v)[16], const double *wb, double *w, int ra, int npair, int t, int g) {
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int c = 0; c < 16; c++) { a0 += v[c].x * wb[16 * g + c]; a1 += v[c].y * wb[16 * g + c]; }
+  a0 += __shfl_xor(a0, 16); a1 += __shfl_xor(a1, 16);
+  a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 32);
+  if (g == 0 && t < npair) { w[ra + 2 * t] -= a0; w[ra + 2 * t + 1] -= a1; }
+}
+// Backward: a wavefront sweeps 4 columns at a time, lanes along the row pairs, 4 pair-chunks of 64 per round.
+__device__ __forceinline__ void bw_issue(sdm_double2 (&v)[16], const double *Fs, int ld, int k0, int kb, int cb0, int ra, int npair, int t0) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int tc = min(t0 + 64 * i, npair - 1);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      v[4 * i + q] = ((const sdm_double2 *)(Fs + (int64_t)(k0 + min(cb0 + q, kb - 1)) * ld + ra))[tc];
+  }
+}
+__device__ __forceinline__ void bw_consume(const sdm_double2 (&v)[16], double (&acc)[4], const double *w, int ra, int npair, int t0) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int t = t0 + 64 * i;
+    if (t < npair) {
+      const double w0 = w[ra + 2 * t], w1 = w[ra + 2 * t + 1];
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[q] += v[4 * i + q].x * w0 + v[4 * i + q].y * w1;
+    }
+  }
+}
+
 __device__ __forceinline__ void front_fw(const double *Fs, int ns, int ms, int ld, double *w, double *wb, double *Sd) {
   const int tid = threadIdx.x, bs = blockDim.x;
-  const int ld2 = ld >> 1;
+  const int g = (tid >> 4) & 3, t0 = (tid >> 6) * 16 + (tid & 15), tstep = bs >> 2;
+  SDM_PHASE_BEGIN();
   stage_block(Sd, Fs, ld, min(SNB, ns));
   __syncthreads();
+  SDM_PHASE(0);
   for (int k0 = 0; k0 < ns; k0 += SNB) {
     const int kb = min(SNB, ns - k0);
     if (tid < 64) {
       double wi = tid < kb ? w[k0 + tid] : 0.0;
+      // coefficients of TCH steps are pulled into registers at once (one LDS round trip per TCH steps of the
+      // dependency chain instead of one per step); 0 for lanes <= k and for k >= kb
 #pragma unroll
-      for (int k = 0; k < SNB; k++) wi -= Sd[k * SNB + tid] * sdm_bcast_lane(wi, k);   // coefficient 0 for lanes <= k, k >= kb
+      for (int h = 0; h < SNB; h += TCH) {
+        double lr[TCH];
+#pragma unroll
+        for (int k = 0; k < TCH; k++) lr[k] = Sd[(h + k) * SNB + tid];
+#pragma unroll
+        for (int k = 0; k < TCH; k++) SDM_PIN(lr[k]);
+#pragma unroll
+        for (int k = 0; k < TCH; k++) wi -= lr[k] * sdm_bcast_lane(wi, h + k);
+      }
       if (tid < kb) { w[k0 + tid] = wi; wb[tid] = wi; }
     }
+    SDM_PHASE(1);
     __syncthreads();
-    { const int k1 = k0 + SNB;                           // next diagonal block -> LDS while the panel streams
-      if (k1 < ns) stage_block(Sd, Fs + (int64_t)k1 * ld + k1, ld, min(SNB, ns - k1)); }
-    // rows below the block, two per work-item (16-byte loads; ld and the first row are even)
+    SDM_PHASE(2);
+    const int k1 = k0 + SNB;
+    if (k1 < ns) stage_block(Sd, Fs + (int64_t)k1 * ld + k1, ld, min(SNB, ns - k1));   // next diagonal block -> LDS
+    SDM_PHASE(3);
     const int rb = k0 + kb, ra = rb + (rb & 1);
     const int npair = ms > ra ? (ms - ra) >> 1 : 0;
-    for (int t = tid; t < npair; t += bs) {
-      const int r = ra + 2 * t;
-      const sdm_double2 *col = (const sdm_double2 *)(Fs + (int64_t)k0 * ld + r);
-      double a0 = 0.0, a1 = 0.0;
-      if (kb == SNB) {
-#pragma unroll 1
-        for (int c0 = 0; c0 < SNB; c0 += GB) {
-          sdm_double2 v[GB];
-#pragma unroll
-          for (int c = 0; c < GB; c++) v[c] = col[(int64_t)(c0 + c) * ld2];
-#pragma unroll
-          for (int c = 0; c < GB; c++) { a0 += v[c].x * wb[c0 + c]; a1 += v[c].y * wb[c0 + c]; }
-        }
-      } else {
-        for (int c = 0; c < kb; c++) { const sdm_double2 v = col[(int64_t)c * ld2]; a0 += v.x * wb[c]; a1 += v.y * wb[c]; }
+    if (kb == SNB) {
+      const int lim = (npair + 15) & ~15;                // whole quads / waves stay converged for the shuffles
+      for (int t = t0; t < lim; t += tstep) {
+        sdm_double2 v[16];
+        fw_issue(v, Fs, ld, k0, ra, npair, t, g);
+        fw_consume(v, wb, w, ra, npair, t, g);
       }
-      w[r] -= a0; w[r + 1] -= a1;
+    } else {
+      for (int t = tid; t < npair; t += bs) {
+        const int r = ra + 2 * t;
+        const sdm_double2 *col = (const sdm_double2 *)(Fs + (int64_t)k0 * ld + r);
+        double a0 = 0.0, a1 = 0.0;
+        for (int c = 0; c < kb; c++) { const sdm_double2 x = col[(int64_t)c * (ld >> 1)]; a0 += x.x * wb[c]; a1 += x.y * wb[c]; }
+        w[r] -= a0; w[r + 1] -= a1;
+      }
     }
     {  // the (at most two) unpaired rows: rb when odd, the last row when the pair range leaves one over
       int r = -1;
@@ -530,7 +585,9 @@ __device__ __forceinline__ void front_fw(const double *Fs, int ns, int ms, int l
         w[r] -= acc;
       }
     }
+    SDM_PHASE(4);
     __syncthreads();
+    SDM_PHASE(5);
   }
 }
 
@@ -538,42 +595,64 @@ __device__ __forceinline__ void front_bw(const double *Fs, const double *Ds, int
   const int tid = threadIdx.x, bs = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
   const int npan = (ns + SNB - 1) / SNB;
+  SDM_PHASE_BEGIN();
   for (int pnl = npan - 1; pnl >= 0; pnl--) {
-    stage_blockT(Sd, Ds + (int64_t)pnl * SNB * SNB, ns - pnl * SNB);     // ns - k0 >= kb: entries beyond kb are masked by c < kb
     const int k0 = pnl * SNB, kb = min(SNB, ns - k0);
     const int rb = k0 + kb, ra = rb + (rb & 1);
-    // dots[c] = sum_{r >= rb} L(r, k0+c) * w[r]: one column per wavefront at a time, 16-byte loads along the column
+    const int npair = ms > ra ? (ms - ra) >> 1 : 0;
+    stage_blockT(Sd, Ds + (int64_t)pnl * SNB * SNB, kb);
+    // dots[c] = sum_{r >= rb} L(r, k0+c) * w[r]
     if (rb < ms) {
-      const int npair = ms > ra ? (ms - ra) >> 1 : 0;
-      for (int c = wave; c < kb; c += nw) {
-        const double *colp = Fs + (int64_t)(k0 + c) * ld;
-        const sdm_double2 *col2 = (const sdm_double2 *)(colp + ra);
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int t = lane;
-        for (; t + 192 < npair; t += 256) {
-          const sdm_double2 v0 = col2[t], v1 = col2[t + 64], v2 = col2[t + 128], v3 = col2[t + 192];
-          const double *wp = w + ra + 2 * t;
-          a0 += v0.x * wp[0] + v0.y * wp[1];     a1 += v1.x * wp[128] + v1.y * wp[129];
-          a2 += v2.x * wp[256] + v2.y * wp[257]; a3 += v3.x * wp[384] + v3.y * wp[385];
+      for (int cb0 = wave * 4; cb0 < kb; cb0 += nw * 4) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int tb = lane; tb < npair; tb += 256) {
+          sdm_double2 v[16];
+          bw_issue(v, Fs, ld, k0, kb, cb0, ra, npair, tb);
+          bw_consume(v, acc, w, ra, npair, tb);
         }
-        for (; t < npair; t += 64) { const sdm_double2 v = col2[t]; a0 += v.x * w[ra + 2 * t] + v.y * w[ra + 2 * t + 1]; }
         if (lane == 0) {
-          if (rb & 1) a1 += colp[rb] * w[rb];
-          if (ms > ra && ((ms - ra) & 1)) a2 += colp[ms - 1] * w[ms - 1];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const double *colp = Fs + (int64_t)(k0 + min(cb0 + q, kb - 1)) * ld;
+            if (rb & 1) acc[q] += colp[rb] * w[rb];
+            if (ms > ra && ((ms - ra) & 1)) acc[q] += colp[ms - 1] * w[ms - 1];
+          }
         }
-        double acc = (a0 + a1) + (a2 + a3);
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-        if (lane == 0) dots[c] = acc;
+        // wave reduction of the 4 column sums with 7 shuffles instead of 24: fold the columns into the lane index
+        // first (upper half wave keeps columns 2,3, then odd 16-lane groups keep the odd column), then 4 plain steps
+        {
+          const bool hi = lane >= 32;
+          const double s0 = hi ? acc[0] : acc[2], s1 = hi ? acc[1] : acc[3];      // what the partner half keeps
+          double k0v = (hi ? acc[2] : acc[0]) + __shfl_xor(s0, 32);
+          double k1v = (hi ? acc[3] : acc[1]) + __shfl_xor(s1, 32);
+          const bool od = (lane >> 4) & 1;
+          double a = (od ? k1v : k0v) + __shfl_xor(od ? k0v : k1v, 16);
+          a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+          const int q = (hi ? 2 : 0) + (od ? 1 : 0);                               // column held by this 16-lane group
+          if ((lane & 15) == 0 && cb0 + q < kb) dots[cb0 + q] = a;
+        }
       }
     }
+    SDM_PHASE(8);
     __syncthreads();
+    SDM_PHASE(9);
     if (tid < 64) {
       double yi = tid < kb ? w[k0 + tid] - (rb < ms ? dots[tid] : 0.0) : 0.0;
 #pragma unroll
-      for (int k = SNB - 1; k >= 0; k--) yi -= Sd[k * SNB + tid] * sdm_bcast_lane(yi, k);   // L(k0+k, k0+tid), 0 unless k > tid
+      for (int h = SNB - TCH; h >= 0; h -= TCH) {       // L(k0+k, k0+tid), 0 unless k > tid
+        double lr[TCH];
+#pragma unroll
+        for (int k = 0; k < TCH; k++) lr[k] = Sd[(h + k) * SNB + tid];
+#pragma unroll
+        for (int k = 0; k < TCH; k++) SDM_PIN(lr[k]);
+#pragma unroll
+        for (int k = TCH - 1; k >= 0; k--) yi -= lr[k] * sdm_bcast_lane(yi, h + k);
+      }
       if (tid < kb) w[k0 + tid] = yi;
     }
+    SDM_PHASE(10);
     __syncthreads();
+    SDM_PHASE(11);
   }
 }
 

@@ -10,7 +10,7 @@ constexpr int NB = 64;     // factor panel width (columns)
 constexpr int TILE = 64;   // trailing-update tile (MFMA 4 waves x 32x32)
 constexpr int SNB = 64;    // solve panel width: one wavefront does the in-block TRSV, one lane per row
 constexpr int SOLVE_LDS_MAX = 12288;  // doubles of the front-local vector kept in LDS (96 KB)
-constexpr int SOLVE_THREADS = 512;    // workgroup of the per-front solve kernels (8 waves stream the panel; 256 VGPRs each)
+constexpr int SOLVE_THREADS = 1024;   // workgroup of the per-front solve kernels (16 waves stream the panel)
 constexpr int PANEL_THREADS = 1024;   // workgroup of the factor's panel kernel (LDL' of the diagonal block)
 constexpr int TRSM_ROWS = 256;        // rows below the diagonal block solved per workgroup (one row per work-item)
 constexpr int CHK = 16;               // column chunk of the row solve held in registers

@@ -35,8 +35,22 @@ __device__ __forceinline__ double sdm_bcast_lane(double v, int lane) {
 // daxpy loops); used where a pivot accept/skip decision depends on noise-level values (blkchol2.c:114-161).
 #ifdef SDM_EMU
 #define SDM_FP_STRICT do {} while (0)
+#define SDM_PIN(x) do {} while (0)
 #else
 #define SDM_FP_STRICT _Pragma("clang fp contract(off)")
+// keep a value materialised in a VGPR at this point (stops the scheduler from sinking its load next to the use)
+#define SDM_PIN(x) asm volatile("" : "+v"(x))
+#endif
+
+// Optional in-kernel phase clocks (tools/ubench builds only, -DSDM_PHASES): work-item 0 accumulates wall_clock64
+// ticks (100 MHz) between marks into sdm_phase_acc[].  Compiled out of the product library.
+#if defined(SDM_PHASES) && !defined(SDM_EMU)
+__device__ long long sdm_phase_acc[32];
+#define SDM_PHASE_BEGIN() long long ph_t_ = wall_clock64()
+#define SDM_PHASE(n) do { const long long t_ = wall_clock64(); if (threadIdx.x == 0) sdm_phase_acc[n] += t_ - ph_t_; ph_t_ = t_; } while (0)
+#else
+#define SDM_PHASE_BEGIN() do {} while (0)
+#define SDM_PHASE(n) do {} while (0)
 #endif
 
 #include <cstdint>

@@ -156,14 +156,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   C.d_asm_src.upload(asm_src); C.d_asm_dst.upload(asm_dst); C.d_asm_dstT.upload(asm_dstT); C.d_toff.upload(C.sn_toff);
   C.frontsT.alloc((size_t)C.tsize);
   { std::vector<int64_t> l64(C.Ljc.begin(), C.Ljc.end()); C.d_Ljc.upload(l64); }
-  { std::vector<int64_t> cboff(nsuper); int64_t o = 0;      // per front: one probe column per row batch of its first panel
-    for (sdm_int s = 0; s < nsuper; s++) {
-      cboff[s] = o;
-      const int rows = C.sn_ms[s] - std::min(NB, C.sn_ns[s]);
-      o += (int64_t)std::max(1, (rows + TRSM_ROWS - 1) / TRSM_ROWS) * (C.sn_ms[s] + 1);
-    }
-    C.d_cboff.upload(cboff); C.colbuf.alloc((size_t)o); }
-  C.fronts.alloc((size_t)C.fsize); C.wvec.alloc((size_t)C.wsize);
+  C.fronts.alloc((size_t)C.fsize); C.wvec.alloc((size_t)C.wsize); C.colbuf.alloc((size_t)C.wsize + (size_t)nsuper);
   C.d.alloc(m); C.dsolve.alloc(m); C.lb.alloc(m); C.pivval.alloc(m); C.pivstat.alloc(m); C.ub.alloc(2);
   P->ada_val.alloc((size_t)C.nnzADA); P->absd.alloc(m); P->lpr.alloc((size_t)C.nnzL);
   P->rhs.alloc(m); P->y.alloc(m); P->ywork.alloc(m);
@@ -173,7 +166,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
 // ================================================================= kernels
 struct FrontTab {
   const int *first, *ns, *ms, *ld;
-  const int64_t *foff, *xl, *woff, *roff, *toff, *cboff;
+  const int64_t *foff, *xl, *woff, *roff, *toff;
   const int *childptr, *childlist, *lindx, *relidx;
 };
 
@@ -251,7 +244,7 @@ __global__ void k_extend_add(double *F, FrontTab tab, const int *list) {
 // (unscaled, updated by the columns < k), Lc[j*NB+i] = l_ij of the finished
 // columns, ds = their pivots, rows below the block are
 // obtained by forward substitution against those columns.  cb = scratch of >= ms+1
-// doubles (every row batch of the front computes and writes the same values).
+// doubles.
 __device__ __noinline__ double pivot_probe(const double (*S)[NB + 1], const double *Lc, int k, int kb, int k0, int ns,
                                            int ms, int ld, const double *Fs, const double *ds, double *cb,
                                            double next_raw_diag, double *red_v, int *red_i) {
@@ -298,81 +291,92 @@ __device__ __noinline__ double pivot_probe(const double (*S)[NB + 1], const doub
   return val;
 }
 
-// ---- K1: one launch per 64-column panel p of the fronts of a level: LDL' of the kb x kb diagonal block and
-// the solve of the rows below it.  grid = (row batches of TRSM_ROWS, fronts).  EVERY workgroup factors the
-// diagonal block itself in LDS (it needs L11 and d for its rows anyway; redundant work on otherwise idle CUs
-// is cheaper than a launch boundary), batch 0 writes it back.  Arithmetic follows cholonBlk operand for
-// operand (blkchol2.c:114-161): column i -= (x_ik / x_kk) * x(:,k), rows below the block
-// x_rc = a_rc - sum_{j<c} x_rj * l_cj in ascending j, l_rc = x_rc / d_c; skipped pivots (d = 0) are not used.
-__global__ void __launch_bounds__(PANEL_THREADS)
-k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, double *d, double *lb, const double *ubp,
-            int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src,
-            const int64_t *Ljc, int mtot) {
-  SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
-  SDM_DYN_SMEM(smem);
-  double (*S)[NB + 1] = (double (*)[NB + 1])smem;                 // diagonal block, S[row][col]
-  double *Xs = (double *)smem + NB * (NB + 1);                    // unscaled x of finished column chunks: Xs[col][row in batch]
-  __shared__ double ds[NB], lbs[NB], pv[NB];
-  __shared__ int stt[NB];
-  __shared__ double red_v[PANEL_THREADS];
-  __shared__ int red_i[PANEL_THREADS];
-  const int s = list[blockIdx.y];
-  const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
-  const int k0 = panel * NB, kb = min(NB, ns - k0);
-  const int r0 = k0 + kb, nrows = ms - r0;
-  const int batch = blockIdx.x;
-  if (batch > 0 && batch * TRSM_ROWS >= nrows) return;            // uniform; batch 0 always runs (it owns the block)
-  double *Fs = F + tab.foff[s];
-  double *cb = colbuf + tab.cboff[s] + (int64_t)batch * (ms + 1);     // probe scratch of this row batch
-  const int tid = threadIdx.x, bs = blockDim.x;
-  const int tx = tid & 63, ty = tid >> 6, ny = bs >> 6;
-  const double ub = ubp[0], maxu = ubp[1];
-  double *Lc = Xs;                                                  // Lc[k*NB+i] = l_ik (aliases Xs until the row solve)
-  for (int j = ty; j < NB; j += ny) { S[tx][j] = (tx < kb && j <= tx) ? Fs[(int64_t)(k0 + j) * ld + k0 + tx] : 0.0; Lc[j * NB + tx] = 0.0; }
-  if (tid < NB) { lbs[tid] = tid < kb ? lb[first + k0 + tid] : 0.0; ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
-  __syncthreads();
-  for (int k = 0; k < kb; k++) {
-    double xkk = S[k][k];
-    if (xkk > lbs[k]) {
-      if (ms - (k0 + k) > 1 && xkk < ub) {                         // rare: stability probe of the never-fail rule
-        double nraw = 0.0;
-        if (k0 + k + 1 >= ns && first + ns < mtot) { int sidx = asm_src[Ljc[first + ns]]; nraw = sidx < 0 ? 0.0 : ada[sidx]; }
-        const double ubk = pivot_probe(S, Lc, k, kb, k0, ns, ms, ld, Fs, ds, cb, nraw, red_v, red_i) / maxu;
-        if (xkk < ubk) {
-          if (tid == 0) { stt[k] = 2; pv[k] = ubk - xkk; lbs[k] = ubk - xkk; }
-          xkk = ubk;
+// ---- K1 (k_ldl_panel): one workgroup per front of a level, 64-column panel p: LDL' of the kb x kb diagonal
+// block; when the rows below the block fit one workgroup (<= TRSM_ROWS) they are solved here as well and the
+// block is written back in place.  Otherwise the factored block goes to the transposed copy DT only and
+// K1b (k_ldl_rows, grid = row batches x fronts) solves the rows and copies the block in place -- nobody may
+// overwrite the panel while the never-fail rule's column probe of K1 can still read its raw values.
+//
+// Diagonal block (bit-faithful to cholonBlk, blkchol2.c:114-161: column i -= (x_ik / x_kk) * x(:,k), one multiply
+// and one subtract per entry, columns in order): the 64 columns are swept 16 at a time.  Every wavefront holds
+// the 16 current columns of all 64 rows in registers (lane = row) and runs the sweep itself -- pivots and
+// multipliers travel by v_readlane, there is no LDS traffic and no barrier inside a sweep -- then the trailing
+// columns of the block are shared out among the wavefronts (x_rj -= l_jk * x_rk, k ascending: the same
+// operations in the same order as the column-by-column reference) and one barrier closes the 16 columns.
+// A pivot that needs the never-fail rule's column probe (x_kk < ub) abandons this path; the block is reloaded
+// and factored by the general all-work-items loop, which can call pivot_probe.
+//
+// Rows below the block: fronts with few rows use the faithful substitution (one row per work-item,
+// x_rc = a_rc - sum_{j<c} x_rj * l_cj in ascending j, l_rc = x_rc / d_c).  Fronts with >= MFMA_MIN_ROWS rows below
+// the block solve 16 rows per wavefront by blocked substitution: per 16-column block the GEMM part
+// T_b = A_b - sum_{b'<b} X_b' L_bb'^T runs on the FP64 matrix cores, the 16x16 triangle is solved by substitution
+// (no inverse is formed: the never-fail pivot rule allows multipliers up to maxu = 5e5); results agree with the
+// plain substitution to rounding.
+__device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int k0, int kb, int R0, const double (*S)[NB + 1],
+                                                const double *ds, double *Tw, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  for (int c4 = 0; c4 < NB / 4; c4++) {                       // 16 rows x 64 columns -> LDS tile Tw[col*17 + row]
+    const int c = 4 * c4 + lk;
+    Tw[c * 17 + li] = (c < kb) ? Fs[(int64_t)(k0 + c) * ld + min(R0 + li, ms - 1)] : 0.0;
+  }
+  SDM_WAVE_SYNC();
+  for (int b = 0; b < NB / 16; b++) {
+    const int cb = 16 * b;
+    if (cb >= kb) break;
+    if (b > 0) {
+      // T = A_b - sum_{b'<b} X_b' L_bb'^T on the matrix cores (D layout: lane holds rows lk+4r of column li)
+      sdm_double4 acc;
+      for (int r = 0; r < 4; r++) acc[r] = Tw[(cb + li) * 17 + lk + 4 * r];
+      for (int bp = 0; bp < b; bp++)
+        for (int q = 0; q < 4; q++) {
+          const double a = Tw[(16 * bp + 4 * q + lk) * 17 + li];          // X_bp[row li][k]
+          const double bv = S[cb + li][16 * bp + 4 * q + lk];             // L11[cb + j][k]
+          acc = SDM_MFMA_F64_16x16x4(-a, bv, acc);
         }
-      }
-      // every work-item forms the multipliers it needs itself (same division, same rounding): one barrier per column
-      const double sik = S[tx][k];
-      if (tid > k && tid < kb) Lc[k * NB + tid] = sik / xkk;
-      if (tid == 0) ds[k] = xkk;
-      for (int i = k + 1 + ty; i < kb; i += ny)
-        if (tx >= i) S[tx][i] -= (S[i][k] / xkk) * sik;
-    } else {
-      // skipped pivot: d = 0, the column becomes the unit vector (blkchol2.c:157-161, blkchol.c:409-414)
-      if (tid == 0) { stt[k] = 1; pv[k] = xkk; ds[k] = 0.0; }
+      for (int r = 0; r < 4; r++) Tw[(cb + li) * 17 + lk + 4 * r] = acc[r];
+      SDM_WAVE_SYNC();
     }
-    __syncthreads();
+    // the 16x16 triangle by substitution, lane li = row (the 4 lane groups lk compute the same row redundantly):
+    // x_c = t_c - sum_{j<c} x_j l_cj  -- no inverse of the block is formed (multipliers may be as large as maxu)
+    double x[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) x[c] = Tw[(cb + c) * 17 + li];
+#pragma unroll
+    for (int c = 1; c < 16; c++) {
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+        if (j < c) x[c] -= x[j] * S[cb + c][cb + j];
+      if (ds[cb + c] <= 0.0) x[c] = 0.0;                                  // skipped pivot: column not used (blkchol2.c:157-161)
+    }
+    if (ds[cb] <= 0.0) x[0] = 0.0;
+    SDM_WAVE_SYNC();
+#pragma unroll
+    for (int c = 0; c < 16; c++) Tw[(cb + c) * 17 + li] = x[c];
+    SDM_WAVE_SYNC();
   }
-  for (int j = ty; j < NB; j += ny) if (tx > j) S[tx][j] = Lc[j * NB + tx];     // scaled columns for the row solve
-  __syncthreads();
-  if (batch == 0) {
-    double *Ds = DT + tab.toff[s] + (int64_t)panel * NB * NB;
-    for (int j = ty; j < kb; j += ny)
-      if (tx < kb && tx >= j) {
-        const double v = (tx == j) ? 1.0 : S[tx][j];                // unit diagonal stored explicitly (blkchol2.c:136)
-        Fs[(int64_t)(k0 + j) * ld + k0 + tx] = v;
-        Ds[tx * NB + j] = v;                                        // transposed copy of the block for the backward solve
-      }
-    if (tid < kb) {
-      const int gk = first + k0 + tid;
-      d[gk] = ds[tid];
-      if (stt[tid]) { pivstat[gk] = stt[tid]; pivval[gk] = pv[tid]; }
-      if (stt[tid] == 2) lb[gk] = lbs[tid];
+  for (int c4 = 0; c4 < NB / 4; c4++) {
+    const int c = 4 * c4 + lk, row = R0 + li;
+    if (c < kb && row < ms) {
+      const double dc = ds[c], xv = Tw[c * 17 + li];
+      Fs[(int64_t)(k0 + c) * ld + row] = dc > 0.0 ? xv / dc : 0.0;
     }
   }
-  // ---- rows below the block: one row per work-item, 16-column chunks; x of earlier chunks parked in LDS
+}
+
+// rows [R, ...) of one batch below the diagonal block of panel p: S = scaled L11 (unit lower), ds = pivots (LDS)
+__device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, int k0, int kb, int batch,
+                                           const double (*S)[NB + 1], const double *ds, double *RB) {
+  SDM_FP_STRICT;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int r0 = k0 + kb;
+  if (ms - min(NB, ns) >= MFMA_MIN_ROWS) {                         // per front, the same path for all its panels
+    // 16 rows per wavefront, blocked substitution with the GEMM part on the matrix cores
+    const int R0 = r0 + batch * TRSM_ROWS + 16 * ty;
+    if (R0 < ms) panel_rows_mfma(Fs, ld, ms, k0, kb, R0, S, ds, RB + ty * (NB * 17), tx);
+    return;
+  }
+  // few rows: faithful substitution, one row per work-item, 16-column chunks; x of earlier chunks parked in LDS
+  double *Xs = RB;
   const int r = r0 + batch * TRSM_ROWS + tid;
   if (tid >= TRSM_ROWS || r >= ms) return;
   for (int c0 = 0; c0 < kb; c0 += CHK) {
@@ -396,6 +400,153 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
       if (c0 + CHK < NB) Xs[(c0 + cc) * TRSM_ROWS + tid] = x[cc];
     }
   }
+}
+
+__global__ void __launch_bounds__(PANEL_THREADS)
+k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, double *d, double *lb, const double *ubp,
+            int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src,
+            const int64_t *Ljc, int mtot) {
+  SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
+  SDM_DYN_SMEM(smem);
+  double (*S)[NB + 1] = (double (*)[NB + 1])smem;                 // diagonal block, S[row][col]
+  double *RB = (double *)smem + NB * (NB + 1);                    // Lc during the LDL', then Xs / the wave tiles of the row solve
+  double *Lc = RB;                                                // Lc[k*NB+i] = l_ik
+  __shared__ double ds[NB], lbs[NB], pv[NB];
+  __shared__ int stt[NB];
+  __shared__ double red_v[PANEL_THREADS];
+  __shared__ int red_i[PANEL_THREADS];
+  const int s = list[blockIdx.x];
+  const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
+  const int k0 = panel * NB, kb = min(NB, ns - k0);
+  const int r0 = k0 + kb, nrows = ms - r0;
+  double *Fs = F + tab.foff[s];
+  double *cb = colbuf + tab.woff[s] + s;                          // probe scratch: ms + 1 doubles per front
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int tx = tid & 63, ty = tid >> 6, ny = bs >> 6;
+  const double ub = ubp[0], maxu = ubp[1];
+  for (int j = ty; j < NB; j += ny) { S[tx][j] = (tx < kb && j <= tx) ? Fs[(int64_t)(k0 + j) * ld + k0 + tx] : 0.0; Lc[j * NB + tx] = 0.0; }
+  if (tid < NB) { lbs[tid] = tid < kb ? lb[first + k0 + tid] : 0.0; ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
+  SDM_PHASE_BEGIN();
+  __syncthreads();
+  SDM_PHASE(16);
+  // ---- LDL' of the block, register sweeps of 16 columns (see the header)
+  bool ok = true;
+  for (int c0 = 0; c0 < kb && ok; c0 += 16) {
+    double x[16], lsc[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; cc++) { x[cc] = S[tx][c0 + cc]; lsc[cc] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int gc = c0 + k;
+      if (ok && gc < kb) {                                           // uniform
+        const double xkk = sdm_bcast_lane(x[k], gc);
+        if (xkk > lbs[gc]) {
+          if (ms - (k0 + gc) > 1 && xkk < ub) {
+            ok = false;                                              // needs the column probe: general path below
+          } else {
+            const double l = x[k] / xkk;                             // rows above the pivot hold 0
+#pragma unroll
+            for (int j = k + 1; j < 16; j++) x[j] -= sdm_bcast_lane(l, c0 + j) * x[k];
+            lsc[k] = l;
+            if (tid == 0) ds[gc] = xkk;
+          }
+        } else if (tid == 0) { stt[gc] = 1; pv[gc] = xkk; ds[gc] = 0.0; }       // skipped pivot: d = 0, unit column
+      }
+    }
+    SDM_PHASE(17);
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) Lc[(c0 + k) * NB + tx] = (tx > c0 + k) ? lsc[k] : 0.0;   // every wave writes the same values
+      SDM_WAVE_SYNC();
+      for (int j = c0 + 16 + ty; j < kb; j += ny)
+        if (tx >= j) {
+          double v = S[tx][j];
+#pragma unroll
+          for (int k = 0; k < 16; k++) v -= Lc[(c0 + k) * NB + j] * x[k];
+          S[tx][j] = v;
+        }
+    }
+    SDM_PHASE(18);
+    __syncthreads();
+    SDM_PHASE(19);
+  }
+  if (!ok) {
+    // ---- general path: one column per step by all work-items, pivot_probe available
+    for (int j = ty; j < NB; j += ny) { S[tx][j] = (tx < kb && j <= tx) ? Fs[(int64_t)(k0 + j) * ld + k0 + tx] : 0.0; Lc[j * NB + tx] = 0.0; }
+    if (tid < NB) { ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
+    __syncthreads();
+    for (int k = 0; k < kb; k++) {
+      double xkk = S[k][k];
+      if (xkk > lbs[k]) {
+        if (ms - (k0 + k) > 1 && xkk < ub) {                         // rare: stability probe of the never-fail rule
+          double nraw = 0.0;
+          if (k0 + k + 1 >= ns && first + ns < mtot) { int sidx = asm_src[Ljc[first + ns]]; nraw = sidx < 0 ? 0.0 : ada[sidx]; }
+          const double ubk = pivot_probe(S, Lc, k, kb, k0, ns, ms, ld, Fs, ds, cb, nraw, red_v, red_i) / maxu;
+          if (xkk < ubk) {
+            if (tid == 0) { stt[k] = 2; pv[k] = ubk - xkk; lbs[k] = ubk - xkk; }
+            xkk = ubk;
+          }
+        }
+        // every work-item forms the multipliers it needs itself (same division, same rounding): one barrier per column
+        const double sik = S[tx][k];
+        if (tid > k && tid < kb) Lc[k * NB + tid] = sik / xkk;
+        if (tid == 0) ds[k] = xkk;
+        for (int i = k + 1 + ty; i < kb; i += ny)
+          if (tx >= i) S[tx][i] -= (S[i][k] / xkk) * sik;
+      } else {
+        // skipped pivot: d = 0, the column becomes the unit vector (blkchol2.c:157-161, blkchol.c:409-414)
+        if (tid == 0) { stt[k] = 1; pv[k] = xkk; ds[k] = 0.0; }
+      }
+      __syncthreads();
+    }
+  }
+  SDM_PHASE(20);
+  for (int j = ty; j < NB; j += ny) if (tx > j) S[tx][j] = Lc[j * NB + tx];     // scaled columns for the row solve
+  __syncthreads();
+  SDM_PHASE(21);
+  {
+    double *Ds = DT + tab.toff[s] + (int64_t)panel * NB * NB;
+    const bool inplace = nrows <= TRSM_ROWS;
+    for (int j = ty; j < kb; j += ny)
+      if (tx < kb && tx >= j) {
+        const double v = (tx == j) ? 1.0 : S[tx][j];                // unit diagonal stored explicitly (blkchol2.c:136)
+        if (inplace) Fs[(int64_t)(k0 + j) * ld + k0 + tx] = v;
+        Ds[tx * NB + j] = v;                                        // transposed copy of the block (backward solve)
+      }
+    if (tid < kb) {
+      const int gk = first + k0 + tid;
+      d[gk] = ds[tid];
+      if (stt[tid]) { pivstat[gk] = stt[tid]; pivval[gk] = pv[tid]; }   // pivval = amount added (what blkchol2.c:127 keeps in lb[k])
+    }
+  }
+  SDM_PHASE(22);
+  if (nrows > 0 && nrows <= TRSM_ROWS) panel_rows(Fs, ld, ns, ms, k0, kb, 0, S, ds, RB);
+  SDM_PHASE(23);
+}
+
+// ---- K1b: rows below the diagonal block for fronts with more than TRSM_ROWS of them.  grid = (row batches,
+// fronts of the level); L11 and d come from K1 (DT / d), batch 0 copies the factored block in place.
+__global__ void __launch_bounds__(PANEL_THREADS)
+k_ldl_rows(double *F, const double *DT, FrontTab tab, const int *list, int panel, const double *d) {
+  SDM_DYN_SMEM(smem);
+  double (*S)[NB + 1] = (double (*)[NB + 1])smem;
+  double *RB = (double *)smem + NB * (NB + 1);
+  __shared__ double ds[NB];
+  const int s = list[blockIdx.y];
+  const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
+  const int k0 = panel * NB, kb = min(NB, ns - k0);
+  const int nrows = ms - (k0 + kb), batch = blockIdx.x;
+  if (nrows <= TRSM_ROWS || batch * TRSM_ROWS >= nrows) return;    // uniform (small fronts were finished by K1)
+  double *Fs = F + tab.foff[s];
+  const double *Ds = DT + tab.toff[s] + (int64_t)panel * NB * NB;    // Ds[i*NB + j] = L(k0+i, k0+j)
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = blockDim.x >> 6;
+  for (int i = ty; i < NB; i += ny) S[i][tx] = (i < kb && tx < i) ? Ds[i * NB + tx] : 0.0;
+  if (tid < NB) ds[tid] = tid < kb ? d[first + k0 + tid] : 0.0;
+  if (batch == 0)
+    for (int i = ty; i < kb; i += ny)
+      if (tx <= i) Fs[(int64_t)(k0 + tx) * ld + k0 + i] = Ds[i * NB + tx];
+  __syncthreads();
+  panel_rows(Fs, ld, ns, ms, k0, kb, batch, S, ds, RB);
 }
 
 // ---- K3: trailing update C -= L21 * D * L21' on the FP64 matrix cores.
@@ -737,7 +888,7 @@ __global__ void k_dsolve(double *ds, const double *d, int m) {
 static FrontTab front_tab(CholPlan &C) {
   FrontTab t;
   t.first = C.d_first.p; t.ns = C.d_ns.p; t.ms = C.d_ms.p; t.ld = C.d_ld.p;
-  t.foff = C.d_foff.p; t.xl = C.d_xl.p; t.woff = C.d_woff.p; t.roff = C.d_roff.p; t.toff = C.d_toff.p; t.cboff = C.d_cboff.p;
+  t.foff = C.d_foff.p; t.xl = C.d_xl.p; t.woff = C.d_woff.p; t.roff = C.d_roff.p; t.toff = C.d_toff.p;
   t.childptr = C.d_childptr.p; t.childlist = C.d_childlist.p; t.lindx = C.d_lindx.p; t.relidx = C.d_relidx.p;
   return t;
 }
@@ -754,6 +905,7 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
   
 #ifndef SDM_EMU
   SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS));
+  SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS));
 #endif
   SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), st));
   SDM_KLAUNCH(P, k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
@@ -766,10 +918,12 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
     if (l > 0) SDM_KLAUNCH(P, k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, C.fronts.p, tab, list);
     for (int li = C.lev_first_launch[l]; li < C.lev_first_launch[l + 1]; li++) {
       const LevelLaunch &L = C.launches[li];
-      const int nbatch = std::max(1, (L.maxrows + TRSM_ROWS - 1) / TRSM_ROWS);
-      SDM_KLAUNCH(P, k_ldl_panel, dim3(nbatch, L.nactive), dim3(PANEL_THREADS), PANEL_LDS, C.fronts.p, C.frontsT.p, tab, list,
+      SDM_KLAUNCH(P, k_ldl_panel, dim3(L.nactive), dim3(PANEL_THREADS), PANEL_LDS, C.fronts.p, C.frontsT.p, tab, list,
                   L.panel, C.d.p, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p,
                   C.d_Ljc.p, m);
+      if (L.maxrows > TRSM_ROWS)
+        SDM_KLAUNCH(P, k_ldl_rows, dim3((L.maxrows + TRSM_ROWS - 1) / TRSM_ROWS, L.nactive), dim3(PANEL_THREADS), PANEL_LDS,
+                    C.fronts.p, C.frontsT.p, tab, list, L.panel, C.d.p);
       if (L.maxrows > 0)
         SDM_KLAUNCH(P, k_ldl_update, dim3(L.maxtiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p);
     }

@@ -11,10 +11,13 @@ constexpr int TILE = 64;   // trailing-update tile (MFMA 4 waves x 32x32)
 constexpr int SNB = 64;    // solve panel width: one wavefront does the in-block TRSV, one lane per row
 constexpr int SOLVE_LDS_MAX = 12288;  // doubles of the front-local vector kept in LDS (96 KB)
 constexpr int SOLVE_THREADS = 1024;   // workgroup of the per-front solve kernels (16 waves stream the panel)
-constexpr int PANEL_THREADS = 1024;   // workgroup of the factor's panel kernel (LDL' of the diagonal block)
-constexpr int TRSM_ROWS = 256;        // rows below the diagonal block solved per workgroup (one row per work-item)
-constexpr int CHK = 16;               // column chunk of the row solve held in registers
-constexpr size_t PANEL_LDS = (size_t)(NB * (NB + 1) + (NB - CHK) * TRSM_ROWS) * sizeof(double);
+constexpr int PANEL_THREADS = 512;    // workgroup of the factor's panel kernel (8 wavefronts)
+constexpr int TRSM_ROWS = 128;        // rows below the diagonal block solved per workgroup (16 per wavefront on the matrix cores)
+constexpr int MFMA_MIN_ROWS = 256;    // fronts with fewer rows below their first panel use the bit-faithful row substitution
+constexpr int CHK = 16;               // column chunk of the row substitution held in registers
+constexpr int PANEL_RB = (PANEL_THREADS / 64) * NB * 17;   // doubles: max(Lc 64x64, Xs 48 x TRSM_ROWS, 8 wave tiles 64x17)
+constexpr size_t PANEL_LDS = (size_t)(NB * (NB + 1) + PANEL_RB) * sizeof(double);
+static_assert(PANEL_RB >= NB * NB && PANEL_RB >= (NB - CHK) * TRSM_ROWS && TRSM_ROWS == 16 * (PANEL_THREADS / 64), "panel LDS layout");
 static_assert(NB == SNB, "the transposed diagonal blocks written by the factor are read by the solves");
 
 template <class T>
@@ -69,7 +72,7 @@ struct CholPlan {
   std::vector<int> lev_first_launch;     // index into launches per level (+ sentinel)
   // device copies
   DevBuf<int> d_first, d_ns, d_ms, d_ld, d_parent, d_childptr, d_childlist, d_levlist, d_lindx, d_relidx, d_perm;
-  DevBuf<int64_t> d_foff, d_xl, d_woff, d_roff, d_toff, d_cboff, d_asm_dst, d_asm_dstT, d_Ljc;
+  DevBuf<int64_t> d_foff, d_xl, d_woff, d_roff, d_toff, d_asm_dst, d_asm_dstT, d_Ljc;
   DevBuf<int> d_asm_src;
   DevBuf<double> fronts, frontsT, wvec, colbuf, d, dsolve, lb, pivval, ub;
   DevBuf<int> pivstat;

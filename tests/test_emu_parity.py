@@ -63,6 +63,28 @@ def test_sparse_factor_and_solves(refmex, glue, kind, m):
     assert relerr(mex.bwblkslv(L2, rhs), refmex.call("bwblkslv", 1, L2, rhs)) < TOL
 
 
+@pytest.mark.parametrize("m", [130, 200, 330])
+def test_dense_front_with_several_row_batches(refmex, m):
+    """One dense supernode whose rows below the first 64-column panel span several workgroups of the panel
+    kernel (matrix-core row solve, deferred in-place copy of the diagonal block).  The emulator runs the
+    workgroups of a launch one after the other, which turns any in-place update another workgroup still has
+    to read into a deterministic failure."""
+    from oracle import glue as gl
+    from sedumi_amd import mex, problem
+    rng = np.random.default_rng(m)
+    B = rng.standard_normal((m, m))
+    X = sp.csc_matrix(B @ B.T + m * np.eye(m))
+    L = problem.dense_symbolic(m)
+    pars = gl.default_pars_chol()
+    r = refmex.call("blkchol", 4, L, X, pars)
+    o = mex.blkchol(L, X, pars)
+    assert relerr(o[0], r[0]) < TOL and relerr(o[1], r[1]) < TOL and o[2].nnz == 0 and o[3].nnz == 0
+    L2 = dict(L); L2["L"] = r[0]
+    rhs = rng.standard_normal((m, 2))
+    assert relerr(mex.fwblkslv(L2, rhs), refmex.call("fwblkslv", 1, L2, rhs)) < TOL
+    assert relerr(mex.bwblkslv(L2, rhs), refmex.call("bwblkslv", 1, L2, rhs)) < TOL
+
+
 @pytest.mark.parametrize("case", range(6))
 def test_pivot_decisions_skip_and_add(refmex, glue, case):
     """Never-fail pivot rule (blkchol2.c:114-161): same skipped / diag-added columns as the reference."""

@@ -133,6 +133,59 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
       sdm_int t = sdpN > 0 ? Ajc_psd[j] : Ajc[j + 1];
       while (t < Ajc[j + 1]) { int k = Ablk[t]; sdm_int te = t; while (te < Ajc[j + 1] && Ablk[te] == k) te++; t_end[ti++] = te; t = te; }
     } }
+  // ---- stage-2 fast path (dense-ish ADA patterns): the PSD nonzeros of At re-packed for one-row-per-lane sweeps.
+  // Rows (constraints) are sorted by their number of PSD nonzeros and cut into groups of 64; a group stores its
+  // nonzeros interleaved (entry t of all 64 rows contiguous) and padded to the longest row of the group, so that
+  // every load of the sweep is one coalesced 512-byte line and no cross-lane reduction is needed.
+  {
+    A.ell_ok = false;
+    int64_t zmax = 0;
+    for (sdm_int j = 0; j < m; j++) {
+      int64_t zl = 0;
+      for (int64_t t = c_taskptr[j]; t < c_taskptr[j + 1]; t++) zl += t_ulen[t];
+      zmax = std::max(zmax, zl);
+    }
+    A.zmax = zmax;
+    const double dens = m > 0 ? (double)ADAjc[m] / ((double)m * (double)m) : 0.0;
+    const size_t lds = (size_t)(zmax + 1) * sizeof(double) + (size_t)sdpN * sizeof(int);
+    if (sdpN > 0 && psdnnz > 0 && dens >= 0.2 && lds <= 120 * 1024) {
+      std::vector<int> order(m);
+      for (sdm_int j = 0; j < m; j++) order[j] = (int)j;
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return Ajc[a + 1] - Ajc_psd[a] > Ajc[b + 1] - Ajc_psd[b]; });
+      const int ng = (int)((m + 63) / 64);
+      std::vector<int> grow((size_t)ng * 64, -1), glen(ng);
+      std::vector<int64_t> goff(ng + 1, 0);
+      for (int g = 0; g < ng; g++) {
+        int len = 0;
+        for (int l = 0; l < 64 && g * 64 + l < m; l++) { const int i = order[g * 64 + l]; grow[g * 64 + l] = i; len = std::max<int>(len, (int)(Ajc[i + 1] - Ajc_psd[i])); }
+        glen[g] = len; goff[g + 1] = goff[g] + len;
+      }
+      std::vector<double> gval((size_t)goff[ng] * 64, 0.0);
+      std::vector<int> gbu((size_t)goff[ng] * 128, 0);          // (block, position in U_k) pairs
+      for (int g = 0; g < ng; g++)
+        for (int l = 0; l < 64; l++) {
+          const int i = grow[g * 64 + l];
+          if (i < 0) continue;
+          for (sdm_int t = Ajc_psd[i]; t < Ajc[i + 1]; t++) {
+            const size_t pos = (size_t)(goff[g] + (t - Ajc_psd[i])) * 64 + l;
+            gval[pos] = Apr[t]; gbu[2 * pos] = Ablk[t]; gbu[2 * pos + 1] = Aupos[t];
+          }
+        }
+      // longest-processing-time assignment of the groups to the ELL_WAVES wavefronts of a workgroup
+      { std::vector<int64_t> load(ELL_WAVES, 0);
+        std::vector<std::vector<int>> mine(ELL_WAVES);
+        for (int g = 0; g < ng; g++) {                         // groups are already in descending length order
+          int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+          mine[w].push_back(g); load[w] += glen[g] + 8;
+        }
+        std::vector<int> wptr(ELL_WAVES + 1, 0), wlist;
+        for (int w = 0; w < ELL_WAVES; w++) { wlist.insert(wlist.end(), mine[w].begin(), mine[w].end()); wptr[w + 1] = (int)wlist.size(); }
+        A.g_wptr.upload(wptr); A.g_wlist.upload(wlist); }
+      A.ell_ng = ng;
+      A.g_row.upload(grow); A.g_len.upload(glen); A.g_off.upload(goff); A.g_val.upload(gval); A.g_bu.upload(gbu);
+      A.ell_ok = true;
+    }
+  }
   // ---- transposed-entry map of the ADA pattern
   std::vector<int> adaT((size_t)ADAjc[m], -1);
   { std::vector<sdm_int> nxt(ADAjc, ADAjc + m);
@@ -319,6 +372,122 @@ k_psd_stage2(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, 
   }
 }
 
+// ---- stage 2, dense-ish patterns: one workgroup per JB consecutive ADA columns.  Their z_j (all blocks touched
+// by constraint j) are staged in LDS once; every wavefront then sweeps groups of 64 rows, ONE ROW PER LANE, over
+// the interleaved (ELL) copy of the PSD nonzeros: coalesced loads (each feeding JB columns), LDS gathers, no
+// cross-lane reduction, one writer per entry.
+template <int JB>
+__global__ void __launch_bounds__(64 * ELL_WAVES)
+k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, const int64_t *Ajc,
+                 const int64_t *Ajc_psd, const double *Apr, const int *Ablk, const int *Aupos,
+                 const int64_t *c_taskptr, const int *t_blk, const int *t_ulen, const int64_t *t_zoff, const double *zbuf,
+                 const int *g_row, const int *g_len, const int64_t *g_off, const double *g_val, const int *g_bu,
+                 const int *g_wptr, const int *g_wlist, const int *invperm, int nblk, int zmax, int m) {
+  SDM_DYN_SMEM(smem);
+  double *zl = (double *)smem;                      // JB x (z_j, then one zero word at [zmax])
+  int *base = (int *)(zl + (size_t)JB * (zmax + 1));  // JB x (block -> offset of z_jk in zl_q, or -1)
+  __shared__ double absred[JB][ELL_WAVES];
+  const int j0 = blockIdx.x * JB;
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
+  for (int k = tid; k < nblk * JB; k += bs) base[k] = -1;
+  if (tid < JB) zl[(size_t)tid * (zmax + 1) + zmax] = 0.0;
+  __syncthreads();
+  bool jhas[JB];
+#pragma unroll
+  for (int q = 0; q < JB; q++) {
+    const int j = j0 + q;
+    jhas[q] = false;
+    if (j < m) {
+      const int64_t tb = c_taskptr[j], te = c_taskptr[j + 1];
+      jhas[q] = te > tb;
+      if (jhas[q]) {
+        const int64_t z0 = t_zoff[tb];
+        for (int64_t t = tb + tid; t < te; t += bs) base[q * nblk + t_blk[t]] = (int)(t_zoff[t] - z0);
+        const int64_t zlen = t_zoff[te - 1] + t_ulen[te - 1] - z0;
+        double *zq = zl + (size_t)q * (zmax + 1);
+        for (int64_t u = tid; u < zlen; u += bs) zq[u] = zbuf[z0 + u];
+      }
+    }
+  }
+  __syncthreads();
+  // absd(j) = ADA_jj (LP/Lorentz part so far) + sum |a_j[psd] .* z_j|   (getada3.c:341-347); 0 without PSD nonzeros
+#pragma unroll
+  for (int q = 0; q < JB; q++) {
+    double aabs = 0.0;
+    const int j = j0 + q;
+    if (jhas[q]) {
+      const double *zq = zl + (size_t)q * (zmax + 1);
+      for (int64_t t = Ajc_psd[j] + tid; t < Ajc[j + 1]; t += bs) aabs += fabs(Apr[t] * zq[base[q * nblk + Ablk[t]] + Aupos[t]]);
+    }
+    for (int off = 32; off > 0; off >>= 1) aabs += __shfl_down(aabs, off);
+    if (lane == 0) absred[q][wave] = aabs;
+  }
+  __syncthreads();
+  if (tid < JB && j0 + tid < m) {
+    const int j = j0 + tid;
+    double basev = 0.0;
+    int64_t lo = ADAjc[j], hi = ADAjc[j + 1];
+    const int64_t ce = hi;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ADAir[mid] < j) lo = mid + 1; else hi = mid; }
+    if (lo < ce && ADAir[lo] == j) basev = ada[lo];
+    double a = 0.0;
+    for (int w = 0; w < nw; w++) a += absred[tid][w];
+    absd[j] = jhas[tid] ? basev + a : 0.0;            // jhas[] is indexed by a per-lane value only in these JB lanes
+  }
+  __syncthreads();
+  for (int gi = g_wptr[wave]; gi < g_wptr[wave + 1]; gi++) {
+    const int g = g_wlist[gi];
+    const int i = g_row[g * 64 + lane];
+    int64_t e[JB];
+#pragma unroll
+    for (int q = 0; q < JB; q++) {
+      e[q] = -1;
+      const int j = j0 + q;
+      if (i >= 0 && jhas[q] && !(invperm && invperm[i] > invperm[j])) {
+        int64_t lo = ADAjc[j], hi = ADAjc[j + 1];
+        const int64_t ce = hi;
+        if (ce - lo == m) e[q] = lo + i;                     // full column: no search
+        else {
+          while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ADAir[mid] < i) lo = mid + 1; else hi = mid; }
+          if (lo < ce && ADAir[lo] == i) e[q] = lo;
+        }
+      }
+    }
+    const int len = g_len[g];
+    const double *gv = g_val + g_off[g] * 64 + lane;
+    const int *gb = g_bu + g_off[g] * 128 + 2 * lane;
+    double acc[JB];
+#pragma unroll
+    for (int q = 0; q < JB; q++) acc[q] = 0.0;
+    int t = 0;
+    for (; t + 8 <= len; t += 8) {                    // 8 entries per lane in flight
+      double v[8]; int blk[8], u[8];
+#pragma unroll
+      for (int x = 0; x < 8; x++) { v[x] = gv[(int64_t)(t + x) * 64]; blk[x] = gb[(int64_t)(t + x) * 128]; u[x] = gb[(int64_t)(t + x) * 128 + 1]; }
+#pragma unroll
+      for (int x = 0; x < 8; x++)
+#pragma unroll
+        for (int q = 0; q < JB; q++) {
+          const int b = base[q * nblk + blk[x]];
+          acc[q] += v[x] * zl[(size_t)q * (zmax + 1) + (b >= 0 ? b + u[x] : zmax)];
+        }
+    }
+    for (; t < len; t++) {
+      const double v = gv[(int64_t)t * 64];
+      const int blk = gb[(int64_t)t * 128], u = gb[(int64_t)t * 128 + 1];
+#pragma unroll
+      for (int q = 0; q < JB; q++) {
+        const int b = base[q * nblk + blk];
+        acc[q] += v * zl[(size_t)q * (zmax + 1) + (b >= 0 ? b + u : zmax)];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < JB; q++)
+      if (e[q] >= 0) ada[e[q]] += acc[q];
+  }
+}
+
 // spmakesym (getada3.c:151-180): out(i,j) = in(i,j) + in(j,i) for i != j
 __global__ void k_symmetrize(double *out, const double *in, const int64_t *ADAjc, const int *ADAir, const int *adaT, int m) {
   const int j = blockIdx.x;
@@ -382,6 +551,31 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
   if (sym_input) {
     SDM_KLAUNCH(P, k_symmetrize, dim3(m), dim3(128), 0, A.symtmp.p, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_ADAT.p, m);
     SDM_HIP_CHECK(hipMemcpyAsync(ada, A.symtmp.p, A.symtmp.n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
+  if (A.ell_ok) {
+    auto lds_of = [&](int jb) { return (size_t)jb * ((size_t)(A.zmax + 1) * sizeof(double) + (size_t)A.sdpN * sizeof(int)); };
+#define SDM_STAGE2_ELL(JB)                                                                                              \
+    do {                                                                                                                 \
+      const size_t lds = lds_of(JB);                                                                                    \
+      SDM_STAGE2_ATTR(JB, lds);                                                                                         \
+      SDM_KLAUNCH(P, k_psd_stage2_ell<JB>, dim3((m + JB - 1) / JB), dim3(64 * ELL_WAVES), lds, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, \
+                  A.d_Ajc.p, A.d_Ajc_psd.p, A.d_Apr.p, A.d_Ablk.p, A.d_Aupos.p, A.c_taskptr.p, A.t_blk.p, A.t_ulen.p,    \
+                  A.t_zoff.p, A.zbuf.p, A.g_row.p, A.g_len.p, A.g_off.p, A.g_val.p, A.g_bu.p, A.g_wptr.p, A.g_wlist.p, d_invperm,       \
+                  (int)A.sdpN, (int)A.zmax, m);                                                                          \
+    } while (0)
+#ifndef SDM_EMU
+#define SDM_STAGE2_ATTR(JB, lds) if ((lds) > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage2_ell<JB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)))
+#else
+#define SDM_STAGE2_ATTR(JB, lds) (void)(lds)
+#endif
+    // as many columns per workgroup as fit 96 KB of LDS (each coalesced load of the ELL copy then feeds JB columns)
+    if (lds_of(4) <= 96 * 1024 && m >= 2048) SDM_STAGE2_ELL(4);
+    else if (lds_of(2) <= 96 * 1024 && m >= 1024) SDM_STAGE2_ELL(2);
+    else SDM_STAGE2_ELL(1);
+#undef SDM_STAGE2_ELL
+#undef SDM_STAGE2_ATTR
+    SDM_HIP_CHECK(hipGetLastError());
+    return;
   }
   SDM_KLAUNCH(P, k_psd_stage2, dim3(m), dim3(256), (size_t)A.sdpN * 8, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p,
              A.d_Ajc_psd.p, A.d_Apr.p, A.d_Ablk.p, A.d_Aupos.p, A.c_taskptr.p, A.t_blk.p, A.t_zoff.p, A.zbuf.p, d_invperm,

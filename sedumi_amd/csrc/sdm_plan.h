@@ -9,6 +9,7 @@ namespace sdm {
 constexpr int NB = 64;     // factor panel width (columns)
 constexpr int TILE = 64;   // trailing-update tile (MFMA 4 waves x 32x32)
 constexpr int SNB = 64;    // solve panel width: one wavefront does the in-block TRSV, one lane per row
+constexpr int ELL_WAVES = 8;  // wavefronts per workgroup of the ELL stage-2 kernel of ADA'
 constexpr int SOLVE_LDS_MAX = 12288;  // doubles of the front-local vector kept in LDS (96 KB)
 constexpr int SOLVE_THREADS = 1024;   // workgroup of the per-front solve kernels (16 waves stream the panel)
 constexpr int PANEL_THREADS = 512;    // workgroup of the factor's panel kernel (8 wavefronts)
@@ -102,6 +103,13 @@ struct AdaPlan {
   DevBuf<int64_t> t_end, d_psd_start;
   DevBuf<double> dl, ddet, qpr, udsqr;
   size_t stage1_lds = 0;
+  // stage-2 fast path: interleaved (ELL) copy of the PSD nonzeros, rows sorted by length, groups of 64
+  bool ell_ok = false;
+  int ell_ng = 0;
+  int64_t zmax = 0;
+  DevBuf<int> g_row, g_len, g_bu, g_wptr, g_wlist;
+  DevBuf<int64_t> g_off;
+  DevBuf<double> g_val;
 };
 
 }  // namespace sdm

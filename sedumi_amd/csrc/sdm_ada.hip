@@ -321,6 +321,77 @@ k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY) {
   }
 }
 
+// ---- stage 1 on the FP64 matrix cores (blocks of order n <= S1_MAXN): per task Z = Y * D(cols,:) is a dense
+// n x n x nslot GEMM (Y = D X(:,cols) as above), accumulated over chunks of S1_KC slots; every wavefront owns a
+// fixed set of 16x16 tiles of Z in registers.  The targets are read off the finished Z in LDS:
+// z(r,c) = (Z[r][c] + Z[c][r]) / 2  -- the same two sums as spscale.c:283-304.
+__global__ void __launch_bounds__(64 * S1_WAVES)
+k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf) {
+  SDM_DYN_SMEM(smem);
+  const int task = blockIdx.x;
+  const int n = T.t_n[task], nslot = T.t_nslot[task], ulen = T.t_ulen[task];
+  const int np = (n + 15) & ~15, nt = np >> 4, ntile = nt * nt;
+  double *Yl = (double *)smem;                      // Yl[t*np + i], t < S1_KC
+  double *Dl = Yl + S1_KC * np;                     // Dl[t*np + j] = D[col_t][j]
+  double *Zl = Dl + S1_KC * np;                     // Zl[i*np + j]
+  const int64_t slot0 = T.t_slotptr[task], tend = T.t_end[task];
+  const double *D = udsqr + T.t_udoff[task];
+  const int *U = T.u_pos + T.t_uoff[task];
+  double *z = zbuf + T.t_zoff[task];
+  const int64_t rowbase = T.psd_start[T.t_blk[task]];
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  sdm_double4 acc[S1_MAXT];
+  for (int x = 0; x < S1_MAXT; x++) for (int r = 0; r < 4; r++) acc[x][r] = 0.0;
+  for (int c0 = 0; c0 < nslot; c0 += S1_KC) {
+    const int cc = min(S1_KC, nslot - c0);
+    for (int t = wave; t < S1_KC; t += nw) {
+      if (t < cc) {
+        const int64_t sb = T.s_nzptr[slot0 + c0 + t];
+        const int64_t se = (c0 + t + 1 < nslot) ? T.s_nzptr[slot0 + c0 + t + 1] : tend;
+        const int col = T.s_col[slot0 + c0 + t];
+        for (int i = lane; i < np; i += 64) {
+          double a = 0.0;
+          if (i < n)
+            for (int64_t u = sb; u < se; u++) a += T.Apr[u] * D[(int64_t)((int)(T.Air[u] - rowbase) - col * n) * n + i];
+          Yl[t * np + i] = a;
+          Dl[t * np + i] = i < n ? D[(int64_t)col * n + i] : 0.0;
+        }
+      } else {
+        for (int i = lane; i < np; i += 64) { Yl[t * np + i] = 0.0; Dl[t * np + i] = 0.0; }
+      }
+    }
+    __syncthreads();
+    for (int x = 0; x < S1_MAXT; x++) {
+      const int tile = wave + x * nw;
+      if (tile < ntile) {                               // wave-uniform
+        const int I = tile / nt, J = tile - I * nt;
+#pragma unroll
+        for (int q = 0; q < S1_KC / 4; q++) {
+          const double a = Yl[(4 * q + lk) * np + I * 16 + li];
+          const double b = Dl[(4 * q + lk) * np + J * 16 + li];
+          acc[x] = SDM_MFMA_F64_16x16x4(a, b, acc[x]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int x = 0; x < S1_MAXT; x++) {
+    const int tile = wave + x * nw;
+    if (tile < ntile) {
+      const int I = tile / nt, J = tile - I * nt;
+      for (int r = 0; r < 4; r++) Zl[(I * 16 + lk + 4 * r) * np + J * 16 + li] = acc[x][r];
+    }
+  }
+  __syncthreads();
+  for (int u = tid; u < ulen; u += bs) {
+    const int q = U[u];
+    const int c = q / n, r = q - c * n;
+    z[u] = (Zl[r * np + c] + Zl[c * np + r]) / 2;
+  }
+}
+
 // ---- stage 2: ADA(i,j) += a_i[psd]' z_j ; absd fused (getada3.c:333-351)
 __global__ void __launch_bounds__(256)
 k_psd_stage2(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, const int64_t *Ajc,
@@ -543,6 +614,14 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
 #ifndef SDM_EMU
     SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A.stage1_lds));
 #endif
+    if (A.maxn <= S1_MAXN && A.sdpN == A.rsdpN) {
+      const int np = (A.maxn + 15) & ~15;
+      const size_t lds = (size_t)(2 * S1_KC * np + np * np) * sizeof(double);
+#ifndef SDM_EMU
+      if (lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage1_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
+      SDM_KLAUNCH(P, k_psd_stage1_mfma, dim3((unsigned)A.ntask), dim3(64 * S1_WAVES), lds, T, A.udsqr.p, A.zbuf.p);
+    } else
     SDM_KLAUNCH(P, k_psd_stage1, dim3((unsigned)A.ntask), dim3(256), A.stage1_lds, T, A.udsqr.p, A.zbuf.p,
                (int)(A.stage1_lds / sizeof(double)));
   }

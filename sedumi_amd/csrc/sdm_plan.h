@@ -9,6 +9,10 @@ namespace sdm {
 constexpr int NB = 64;     // factor panel width (columns)
 constexpr int TILE = 64;   // trailing-update tile (MFMA 4 waves x 32x32)
 constexpr int SNB = 64;    // solve panel width: one wavefront does the in-block TRSV, one lane per row
+constexpr int S1_MAXN = 96;   // PSD blocks up to this order take the matrix-core stage 1 of ADA'
+constexpr int S1_KC = 16;     // slots (nonzero columns of A_jk) per GEMM chunk
+constexpr int S1_WAVES = 8;   // wavefronts per task
+constexpr int S1_MAXT = ((S1_MAXN / 16) * (S1_MAXN / 16) + S1_WAVES - 1) / S1_WAVES;   // 16x16 tiles of Z per wavefront
 constexpr int ELL_WAVES = 8;  // wavefronts per workgroup of the ELL stage-2 kernel of ADA'
 constexpr int SOLVE_LDS_MAX = 12288;  // doubles of the front-local vector kept in LDS (96 KB)
 constexpr int SOLVE_THREADS = 1024;   // workgroup of the per-front solve kernels (16 waves stream the panel)

@@ -146,27 +146,52 @@ def main():
     plan.kprof(False)
     nprof = min(args.steps, 50)
     m, nnzL = plan.m, plan.nnzL
-    solve_bytes = 8.0 * nnzL + 8.0 * m + 16.0 * m       # 8*nnz(L) + 8*len(lindx) + 16*m per solve
+    # ALGORITHMIC work per launch of each hot kernel (SURVEY.md 8(d) per-unit figures divided
+    # by the launches per unit).  bound "hbm": bytes, peak 8 TB/s; bound "mfma": FP64 flops, peak 78.6 TFLOP/s
+    # (on CDNA4 the FP64 matrix rate equals the FP64 vector rate).
+    solve_bytes = 8.0 * nnzL + 8.0 * m + 16.0 * m       # per triangular solve: 8*nnz(L) + 8*len(lindx) + 16*m
+    npan = (m + 63) // 64
+    model = {
+        "k_ldl_single": ("hbm", 2.0 * solve_bytes),                                  # forward + backward sweep in one launch
+        "k_fw_level": ("hbm", solve_bytes), "k_bw_level": ("hbm", solve_bytes),
+        "k_ldl_update": ("mfma", (m ** 3 / 3.0) / max(1, npan - 1)),                 # trailing updates carry the m^3/3 of the LDL'
+        "k_ldl_rows": ("mfma", (m ** 3 / 3.0) / max(1, npan - 1) * 64.0 / max(m, 64)),
+        "k_ldl_panel": ("mfma", 2.0 * 64 ** 3 / 3.0),                                # one 64x64 LDL' per launch (latency bound)
+        "k_psd_stage1_mfma": ("hbm", 8.0 * (ud.size + P.At.nnz + plan.nnzADA)),      # SURVEY.md 8(d) getada3 lower bound
+        "k_psd_stage1": ("hbm", 8.0 * (ud.size + P.At.nnz + plan.nnzADA)),
+        "k_psd_stage2": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)),
+        "k_ada_spdot": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)),
+    }
+    peaks = {"hbm": (HBM_PEAK_GBS, "GB/s", 1e9), "mfma": (78.6, "TFLOP/s", 1e12)}
     dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
     roof = None
     if dom:
         calls, ms = prof[dom]
         avg_s = ms / calls * 1e-3
-        if dom in ("k_fw_level", "k_bw_level", "k_ldl_single"):
-            alg_bytes = solve_bytes
-        elif dom in ("k_psd_stage1", "k_psd_stage2"):
-            alg_bytes = 8.0 * (ud.size + P.At.nnz + plan.nnzADA)          # SURVEY.md 8(d) getada3 lower bound
-        else:
-            alg_bytes = 8.0 * (plan.nnzADA / 2 + 2 * nnzL) / max(1, calls // nprof)   # factor: 8*(nnz(tril ADA)+2 nnz(L)) per unit
-        ach = alg_bytes / avg_s / 1e9
-        roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_per_step": calls / nprof,
-                "algorithmic_bytes_per_launch": alg_bytes,
+        key = dom.split("<")[0]
+        if key.startswith("k_psd_stage2"):
+            key = "k_psd_stage2"
+        bound, work = model.get(key, ("hbm", 8.0 * (plan.nnzADA / 2 + 2 * nnzL)))
+        peak, unit, scale = peaks[bound]
+        ach = work / avg_s / scale
+        roof = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                "frac": ach / peak, "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_per_step": calls / nprof,
+                "algorithmic_work_per_launch": work,
                 "stage_ms_per_step": {k: v[1] / nprof for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        # the solve kernel is the path's HBM-bound kernel (north_star): always reported beside the dominant one
+        for sk in ("k_ldl_single", "k_fw_level"):
+            if sk in prof:
+                c2, ms2 = prof[sk]
+                b2 = model[sk][1] * (1.0 if sk == "k_ldl_single" else 1.0)
+                roof["solve_kernel"] = {"kernel": sk, "avg_launch_us": ms2 / c2 * 1e3, "achieved_GBs": b2 / (ms2 / c2 * 1e-3) / 1e9,
+                                        "frac_of_hbm_peak": b2 / (ms2 / c2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b2}
+                break
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+        if pmcs:
             try:
-                roof["traffic"] = json.load(open(pmc)).get(dom)
+                roof["traffic"] = json.load(open(pmcs[-1])).get(dom)
+                roof["traffic_source"] = os.path.basename(pmcs[-1])
             except Exception:
                 pass
 

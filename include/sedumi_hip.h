@@ -153,6 +153,45 @@ int sdm_bwblkslv_sparse(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const
                         sdm_int n, const sdm_int *Bjc, const sdm_int *Bir, const double *Bpr,
                         const sdm_int *Yjc, const sdm_int *Yir, double *Ypr);
 
+/* --- dense columns (product-form rank-1 updates, deninfac.m:58-94) --------- */
+
+/* x = symbfwblk(L, b)            symbfwblk.c:270-377
+ * Pattern of L.L \ b(L.perm,:) for sparse b (m x n CSC pattern).  Two-call protocol: with Xir == NULL only
+ * Xjc[n+1] is written (Xjc[n] = nnz), the second call fills Xir[nnz] (row indices in the factor's order). */
+int sdm_symbfwblk(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm,
+                  sdm_int nsuper, const sdm_int *xsuper,
+                  sdm_int n, const sdm_int *Bjc, const sdm_int *Bir, sdm_int *Xjc, sdm_int *Xir);
+
+/* Lden = finsymbden(LAD, perm, dz, firstq)      finsymbden.c:112-214
+ * LAD m x n pattern (dense columns after the forward solve), perm[nperm] 0-based column order (nperm <= n:
+ * the n - nperm Lorentz trace columns are attached behind their block column), dz m x nperm with CUMULATIVE
+ * column pointers dzjc[nperm+1] over the row list dzir, firstq 0-based.  Out: perm_out[n], dzjc_out[n+1]
+ * (cumulative, duplicated for trace columns), first_out[n] (first affecting pivot, n = none), all 0-based. */
+int sdm_finsymbden(sdm_int m, sdm_int n, const sdm_int *LADjc, const sdm_int *LADir,
+                   sdm_int nperm, const sdm_int *perm, const sdm_int *dzjc, const sdm_int *dzir,
+                   sdm_int firstq, sdm_int *perm_out, sdm_int *dzjc_out, sdm_int *first_out);
+
+/* [Lden, Ld] = dpr1fact(x, d, Lsymb, smult, maxu)      dpr1fact.c:630-848 (prodformfact :549-621)
+ * x m x n CSC (dense columns, already forward-solved and scaled), d[m] in/out (L.d), Lsymb.dz as (dzjc[n+1]
+ * cumulative, dzir), Lsymb.perm -> colperm[n], Lsymb.first -> first[n] (0-based), smult[n], maxu.
+ * Out (caller allocates pnnz = sum_k dzjc[k+1] entries for beta, p, pivperm): betajc[n+1] 0-based, beta,
+ * p[pnnz], pivperm[*npivperm] (0-based row order of the reordered columns, full length each), dopiv[n]. */
+int sdm_dpr1fact(sdm_int m, sdm_int n, const sdm_int *Xjc, const sdm_int *Xir, const double *Xpr, double *d,
+                 const sdm_int *dzjc, const sdm_int *dzir, const sdm_int *colperm, const sdm_int *first,
+                 const double *smult, double maxu,
+                 sdm_int *betajc, double *beta, double *p, sdm_int *pivperm, sdm_int *npivperm, sdm_int *dopiv);
+
+/* y = fwdpr1(Lden, b)   y = PROD_k L(p_k,beta_k) \ b          fwdpr1.c:101-202, auxfwdpr1.c:44-122
+ * y = bwdpr1(Lden, b)   y = (PROD_k L(p_k,beta_k))' \ b       bwdpr1.c:170-275
+ * b, y m x nrhs column major; Lden as returned by sdm_dpr1fact plus dz (dzjc cumulative, dzir).
+ * nden == 0: y = b (fwdpr1.c:132-135). */
+int sdm_fwdpr1(sdm_int m, sdm_int nrhs, sdm_int nden, const sdm_int *dzjc, const sdm_int *dzir,
+               const sdm_int *betajc, const double *beta, const double *p,
+               const sdm_int *pivperm, sdm_int npivperm, const sdm_int *dopiv, const double *b, double *y);
+int sdm_bwdpr1(sdm_int m, sdm_int nrhs, sdm_int nden, const sdm_int *dzjc, const sdm_int *dzir,
+               const sdm_int *betajc, const double *beta, const double *p,
+               const sdm_int *pivperm, sdm_int npivperm, const sdm_int *dopiv, const double *b, double *y);
+
 /* ================================================================ tier (2) */
 typedef struct sdm_plan sdm_plan;
 

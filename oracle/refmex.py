@@ -49,6 +49,14 @@ def available() -> bool:
     return os.path.exists(os.path.join(REF_DIR, "libmexshim.so"))
 
 
+class RawSparse:
+    """A sparse matrix to be handed to a reference MEX exactly as stored (no index sorting): incorder's `dz`
+    lists the rows of every column in the order in which they were introduced (incorder.c:171-208)."""
+
+    def __init__(self, X):
+        self.X = sp.csc_matrix(X)
+
+
 class RefMexError(RuntimeError):
     pass
 
@@ -83,11 +91,14 @@ class RefMex:
             for k, val in v.items():
                 s.mxSetField(a, 0, k.encode(), self.to_mx(val))
             return a
-        if sp.issparse(v):
+        if isinstance(v, RawSparse):
+            v = v.X                                        # row order inside the columns is part of the data
+        elif sp.issparse(v):
             v = sp.csc_matrix(v)
             if not v.has_sorted_indices:
                 v = v.copy()
                 v.sort_indices()
+        if sp.issparse(v):
             m, n = v.shape
             nnz = int(v.indptr[-1])
             a = s.mxCreateSparse(m, n, max(nnz, 1), 0)

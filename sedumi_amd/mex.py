@@ -303,3 +303,119 @@ def symbchol(ADA, cachsz=512):
     L["tmpsiz"] = choltmpsiz(L)
     L["split"] = cholsplit(L, cachsz)
     return L
+
+
+# ------------------------------------------------------------- dense columns
+def symbfwblk(L, b):
+    """x = symbfwblk(L, b): sparsity pattern (values all 1) of L.L \\ b(L.perm,:)   (symbfwblk.c:270-377)"""
+    m, LL, Ljc, Lir, _, perm, xs = _Lstruct(L, False)
+    if not sp.issparse(b):
+        raise SdmError("B must be sparse")
+    B = _csc(b)
+    if B.shape[0] != m:
+        raise SdmError("L.perm size mismatches B")
+    n = B.shape[1]
+    Bjc, Bir = i64(B.indptr), i64(B.indices)
+    Xjc = np.zeros(n + 1, dtype=np.int64)
+    lib = capi.lib()
+    args = (C.c_int64(m), pi(Ljc), pi(Lir), pi(perm), C.c_int64(xs.size - 1), pi(xs), C.c_int64(n), pi(Bjc), pi(Bir))
+    check(lib.sdm_symbfwblk(*args, pi(Xjc), None))
+    Xir = np.zeros(max(int(Xjc[-1]), 1), dtype=np.int64)
+    check(lib.sdm_symbfwblk(*args, pi(Xjc), pi(Xir)))
+    nnz = int(Xjc[-1])
+    return sp.csc_matrix((np.ones(nnz), Xir[:nnz], Xjc), shape=(m, n))
+
+
+def finsymbden(LAD, perm, dz, firstq):
+    """Lden = finsymbden(LAD, perm, dz, firstq) -> dict(LAD, perm, dz, first)   (finsymbden.c:112-214)"""
+    LAD, dz = _csc(LAD), sp.csc_matrix(dz)                 # dz: row order inside the columns is data, never sorted
+    m, n = LAD.shape
+    p = i64(np.asarray(perm, dtype=np.float64)) - 1
+    nperm = p.size
+    if dz.shape != (m, nperm):
+        raise SdmError("dz size mismatch")
+    LADjc, LADir, dzjc, dzir = i64(LAD.indptr), i64(LAD.indices), i64(dz.indptr), i64(dz.indices)
+    po, jo, fo = np.zeros(max(n, 1), dtype=np.int64), np.zeros(n + 1, dtype=np.int64), np.zeros(max(n, 1), dtype=np.int64)
+    check(capi.lib().sdm_finsymbden(C.c_int64(m), C.c_int64(n), pi(LADjc), pi(LADir), C.c_int64(nperm), pi(p), pi(dzjc),
+                                    pi(dzir), C.c_int64(int(np.asarray(firstq).ravel()[0]) - 1), pi(po), pi(jo), pi(fo)))
+    # the reference keeps dz.ir / dz.pr and only swaps the column pointers (finsymbden.c:196-199)
+    nz = int(jo[n])
+    dznew = sp.csc_matrix((np.asarray(dz.data[:nz], dtype=np.float64), dzir[:nz].copy(), jo.copy()), shape=(m, n))
+    return {"LAD": LAD, "perm": (po[:n] + 1).astype(np.float64).reshape(-1, 1), "dz": dznew,
+            "first": (fo[:n] + 1).astype(np.float64).reshape(-1, 1)}
+
+
+def _dz(dz):
+    """Lden.dz / Lsymb.dz: either a scipy CSC matrix or the explicit {'jc','ir'} form produced by finsymbden."""
+    if isinstance(dz, dict):
+        return i64(dz["jc"]), i64(dz["ir"])
+    dz = sp.csc_matrix(dz)
+    return i64(dz.indptr), i64(dz.indices)
+
+
+def dpr1fact(x, d, Lsymb, smult, maxu):
+    """[Lden, Ld] = dpr1fact(x, d, Lsymb, smult, maxu)   (dpr1fact.c:630-848)
+    Lden = dict(betajc (1-based), beta, p, pivperm (0-based, as the reference), dopiv)."""
+    X = _csc(x)
+    m, n = X.shape
+    lab = f64(d).copy()
+    if lab.size != m:
+        raise SdmError("Size mismatch d.")
+    sm = f64(smult)
+    if sm.size != n:
+        raise SdmError("Size mismatch smult.")
+    dzjc, dzir = _dz(_field(Lsymb, "dz", "Lsymb"))
+    colperm = _perm0(_field(Lsymb, "perm", "Lsymb"), n, "Lsymb.perm")
+    first = i64(np.asarray(_field(Lsymb, "first", "Lsymb"), dtype=np.float64)) - 1
+    if first.size != n:
+        raise SdmError("Size mismatch Lsymb.first.")
+    pnnz = int(dzjc[1:n + 1].sum())
+    betajc = np.zeros(n + 1, dtype=np.int64)
+    beta, p = np.zeros(max(pnnz, 1)), np.zeros(max(pnnz, 1))
+    pivperm, dopiv = np.zeros(max(pnnz, 1), dtype=np.int64), np.zeros(max(n, 1), dtype=np.int64)
+    npp = C.c_int64(0)
+    Xjc, Xir, Xpr = i64(X.indptr), i64(X.indices), f64(X.data)
+    check(capi.lib().sdm_dpr1fact(C.c_int64(m), C.c_int64(n), pi(Xjc), pi(Xir), pf(Xpr), pf(lab), pi(dzjc), pi(dzir), pi(colperm),
+                                  pi(first), pf(sm), C.c_double(float(np.asarray(maxu).ravel()[0])), pi(betajc), pf(beta), pf(p),
+                                  pi(pivperm), C.byref(npp), pi(dopiv)))
+    Lden = {"betajc": (betajc + 1).astype(np.float64).reshape(-1, 1), "beta": beta[:int(betajc[n])].reshape(-1, 1),
+            "p": p[:pnnz].reshape(-1, 1), "pivperm": pivperm[:npp.value].astype(np.float64).reshape(-1, 1),
+            "dopiv": dopiv[:n].astype(np.float64).reshape(-1, 1)}
+    return Lden, lab.reshape(-1, 1)
+
+
+def _pr1(fw, Lden, b):
+    b = np.asarray(b, dtype=np.float64)
+    if sp.issparse(b):
+        raise SdmError("b should be full")
+    if b.ndim == 1:
+        b = b.reshape(-1, 1)
+    m, nrhs = b.shape
+    betajc = i64(np.asarray(_field(Lden, "betajc", "Lden"), dtype=np.float64)) - 1
+    nden = betajc.size - 1
+    if nden == 0:
+        return b.copy()                                   # fwdpr1.c:132-135: no dense columns
+    beta, p = f64(_field(Lden, "beta", "Lden")), f64(_field(Lden, "p", "Lden"))
+    dopiv = i64(np.asarray(_field(Lden, "dopiv", "Lden"), dtype=np.float64))
+    if dopiv.size != nden:
+        raise SdmError("Size mismatch Lden.dopiv.")
+    pivperm = i64(np.asarray(_field(Lden, "pivperm", "Lden"), dtype=np.float64))
+    dzjc, dzir = _dz(_field(Lden, "dz", "Lden"))
+    if beta.size != betajc[-1]:
+        raise SdmError("Size mismatch Lden.beta.")
+    y = np.zeros(m * nrhs)
+    fn = capi.lib().sdm_fwdpr1 if fw else capi.lib().sdm_bwdpr1
+    pv = pivperm if pivperm.size else np.zeros(1, dtype=np.int64)
+    check(fn(C.c_int64(m), C.c_int64(nrhs), C.c_int64(nden), pi(dzjc), pi(dzir), pi(betajc), pf(beta if beta.size else np.zeros(1)),
+             pf(p if p.size else np.zeros(1)), pi(pv), C.c_int64(pivperm.size), pi(dopiv), pf(f64(b)), pf(y)))
+    return y.reshape((m, nrhs), order="F")
+
+
+def fwdpr1(Lden, b):
+    """y = fwdpr1(Lden, b): y = PROD_k L(p_k, beta_k) \\ b   (fwdpr1.c:101-202)"""
+    return _pr1(True, Lden, b)
+
+
+def bwdpr1(Lden, b):
+    """y = bwdpr1(Lden, b): y = (PROD_k L(p_k, beta_k))' \\ b   (bwdpr1.c:170-275)"""
+    return _pr1(False, Lden, b)

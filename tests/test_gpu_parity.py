@@ -102,6 +102,15 @@ def test_pivot_decisions_skip_and_add(refmex, glue, case):
         assert relerr(o[1], r[1]) < 1e-8
 
 
+@pytest.mark.parametrize("m,n,ndense,seed,zero_d,maxuden", [(120, 900, 6, 2, 0, 500.0), (90, 700, 4, 3, 2, 500.0),
+                                                            (80, 600, 5, 4, 0, 1.5), (2000, 20000, 8, 1, 0, 500.0)])
+def test_dense_column_pipeline(refmex, glue, m, n, ndense, seed, zero_d, maxuden):
+    """symbfwblk / finsymbden / dpr1fact / fwdpr1 / bwdpr1 incl. the synthetic
+    config-3 variant of SURVEY.md 8(d): LP m=2000, N=20000, 8 dense columns."""
+    from test_dense_columns import check_dense_case, dense_case
+    check_dense_case(refmex, dense_case(refmex, glue, m, n, ndense, seed, zero_d, maxuden))
+
+
 def test_edge_cases_empty_and_tiny(refmex):
     from oracle import glue as gl
     from sedumi_amd import mex

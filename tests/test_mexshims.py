@@ -12,7 +12,8 @@ import scipy.sparse as sp
 
 from helpers import ROOT, TOL, ref_scaling, relerr, spd_pattern
 
-SHIMS = ["getada1", "getada2", "getada3", "blkchol", "fwblkslv", "bwblkslv", "ordmmdmex", "symfctmex", "choltmpsiz", "cholsplit"]
+SHIMS = ["getada1", "getada2", "getada3", "blkchol", "fwblkslv", "bwblkslv", "ordmmdmex", "symfctmex", "choltmpsiz", "cholsplit",
+         "symbfwblk", "finsymbden", "dpr1fact", "fwdpr1", "bwdpr1"]
 
 
 @pytest.fixture(scope="module")
@@ -78,6 +79,31 @@ def test_shims_symbolic_bit_exact(refmex, shimmex):
     assert np.array_equal(Lo["L"].indices, Lr["L"].indices) and np.array_equal(Lo["L"].indptr, Lr["L"].indptr)
     assert np.array_equal(shimmex.call("choltmpsiz", 1, Lr), refmex.call("choltmpsiz", 1, Lr))
     assert np.array_equal(shimmex.call("cholsplit", 1, Lr, 0.3), refmex.call("cholsplit", 1, Lr, 0.3))
+
+
+def test_shims_dense_column_path(refmex, glue, shimmex):
+    """symbfwblk, finsymbden, dpr1fact, fwdpr1, bwdpr1 through their mexFunction shims (struct outputs, 1-based
+    conversions, the unsorted `dz`) against the reference gateways."""
+    from oracle.refmex import RawSparse
+    from test_dense_columns import dense_case
+    c = dense_case(refmex, glue, 70, 500, 4, 9)
+    X = shimmex.call("symbfwblk", 1, c["L"], c["denseA"])
+    assert np.array_equal(X.indptr, c["LADsym"].indptr) and np.array_equal(X.indices, c["LADsym"].indices)
+    r = c["sym_ref"]
+    sym = shimmex.call("finsymbden", 1, c["LADsym"], c["perm"], RawSparse(c["dz"]), 5.0)
+    assert np.array_equal(sym["perm"], r["perm"]) and np.array_equal(sym["first"], r["first"])
+    assert np.array_equal(sym["dz"].indptr, r["dz"].indptr) and np.array_equal(sym["dz"].indices, r["dz"].indices)
+    sref = {"dz": RawSparse(r["dz"]), "perm": r["perm"], "first": r["first"]}
+    args = (c["LAD"], c["Ld"].reshape(-1, 1), sref, c["smult"].reshape(-1, 1), c["maxuden"])
+    (Lr, Ldr), (Lo, Ldo) = refmex.call("dpr1fact", 2, *args), shimmex.call("dpr1fact", 2, *args)
+    for k in ("betajc", "dopiv", "pivperm"):
+        assert np.array_equal(Lo[k], Lr[k])
+    assert relerr(Lo["p"], Lr["p"]) < TOL and relerr(Lo["beta"], Lr["beta"]) < TOL and relerr(Ldo, Ldr) < TOL
+    Lr2 = dict(Lr); Lr2["dz"] = RawSparse(r["dz"])
+    b = np.random.default_rng(1).standard_normal((c["Ld"].size, 2))
+    assert relerr(shimmex.call("fwdpr1", 1, Lr2, b), refmex.call("fwdpr1", 1, Lr2, b)) < TOL
+    assert relerr(shimmex.call("bwdpr1", 1, Lr2, b), refmex.call("bwdpr1", 1, Lr2, b)) < TOL
+    assert np.array_equal(shimmex.call("fwdpr1", 1, {"betajc": np.array([[1.0]])}, b), b)     # no dense columns
 
 
 def test_shim_errors_go_through_mexErrMsgTxt(shimmex):

@@ -46,7 +46,6 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
       for (sdm_int r = qblkstart[k]; r < qblkstart[k + 1] && r < A.nlq; r++) code[r] = (int)k;
     A.dsqr_code.upload(code);
   }
-  if (sdpN > rsdpN) throw std::runtime_error("Hermitian PSD blocks are not supported yet");
   // ---- PSD blocks
   A.psd_n.assign(sdpNL, sdpNL + sdpN);
   A.psd_start.assign(psd_blkstart, psd_blkstart + sdpN + (sdpN > 0 ? 1 : 0));
@@ -276,45 +275,77 @@ struct Stage1Tab {
 __global__ void __launch_bounds__(256)
 k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY) {
   SDM_DYN_SMEM(smem);
-  double *Y = (double *)smem;                       // Y[slot][row], chunk of CC slots
+  double *Y = (double *)smem;                       // Y[slot][row], chunk of CC slots (Hermitian: Re then Im plane)
   const int task = blockIdx.x;
   const int n = T.t_n[task], nslot = T.t_nslot[task], ulen = T.t_ulen[task];
+  const int herm = T.t_herm[task];
   const int64_t slot0 = T.t_slotptr[task], tend = T.t_end[task];
   const double *D = udsqr + T.t_udoff[task];
+  const double *Di = D + (int64_t)n * n;            // imaginary part of a Hermitian D_k (udsqr = [Re; Im], A.8)
   const int *U = T.u_pos + T.t_uoff[task];
   double *z = zbuf + T.t_zoff[task];
   const int64_t rowbase = T.psd_start[T.t_blk[task]];
   const int tid = threadIdx.x, bs = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
-  int CC = ldsY / n; if (CC < 1) CC = 1; if (CC > nslot) CC = nslot;
+  int CC = ldsY / (n * (herm ? 2 : 1)); if (CC < 1) CC = 1; if (CC > nslot) CC = nslot;
+  double *Yi = Y + (int64_t)CC * n;
   for (int c0 = 0; c0 < nslot; c0 += CC) {
     const int cc = min(CC, nslot - c0);
-    // (1) Y[:,t] = sum_{nz in slot} x * D[:, row(nz)]          (realdmulx, spscale.c:73-107)
+    // (1) Y[:,t] = sum_{nz in slot} x * D[:, row(nz)]          (realdmulx, spscale.c:73-107; cpxdmulx :128-224:
+    //     a nonzero of the imaginary plane contributes (i x) * d_row:  Re -= x Im(d),  Im += x Re(d))
     for (int t = wave; t < cc; t += nw) {
       const int64_t sb = T.s_nzptr[slot0 + c0 + t];
       const int64_t se = (c0 + t + 1 < nslot) ? T.s_nzptr[slot0 + c0 + t + 1] : tend;
-      const int col = T.s_col[slot0 + c0 + t];
+      const int sc = T.s_col[slot0 + c0 + t];
+      const int part = sc >= n ? 1 : 0, col = sc - part * n;
+      const int64_t sub0 = rowbase + (int64_t)part * n * n + (int64_t)col * n;
       for (int i = lane; i < n; i += 64) {
-        double acc = 0.0;
+        double ar = 0.0, ai = 0.0;
         for (int64_t u = sb; u < se; u++) {
-          const int rx = (int)(T.Air[u] - rowbase) - col * n;
-          acc += T.Apr[u] * D[(int64_t)rx * n + i];
+          const int rx = (int)(T.Air[u] - sub0);
+          const double x = T.Apr[u], dr = D[(int64_t)rx * n + i];
+          if (!herm) ar += x * dr;
+          else {
+            const double di = Di[(int64_t)rx * n + i];
+            if (part) { ar -= x * di; ai += x * dr; } else { ar += x * dr; ai += x * di; }
+          }
         }
-        Y[t * n + i] = acc;
+        Y[t * n + i] = ar;
+        if (herm) Yi[t * n + i] = ai;
       }
     }
     __syncthreads();
-    // (2) targets: z(r,c) (+)= ( sum_t Y[r,t] D[col_t,c] + Y[c,t] D[col_t,r] ) / 2   (spscale.c:283-304)
+    // (2) targets: with DXD_rc = sum_t Y[r,t] D[col_t,c],
+    //     real plane  z(r,c) (+)= Re(DXD_rc + DXD_cr) / 2     (spscale.c:283-304, :379-397)
+    //     imag plane  z(r,c) (+)= Im(DXD_rc - DXD_cr) / 2     (spscale.c:411-434)
     for (int u = tid; u < ulen; u += bs) {
-      const int q = U[u];
+      int q = U[u];
+      const int zpart = q >= n * n ? 1 : 0;
+      q -= zpart * n * n;
       const int c = q / n, r = q - c * n;
-      double a1 = 0.0, a2 = 0.0;
-      for (int t = 0; t < cc; t++) {
-        const double *Dc = D + (int64_t)T.s_col[slot0 + c0 + t] * n;
-        a1 += Y[t * n + r] * Dc[c];
-        a2 += Y[t * n + c] * Dc[r];
+      double v;
+      if (!herm) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int t = 0; t < cc; t++) {
+          const double *Dc = D + (int64_t)T.s_col[slot0 + c0 + t] * n;
+          a1 += Y[t * n + r] * Dc[c];
+          a2 += Y[t * n + c] * Dc[r];
+        }
+        v = (a1 + a2) / 2;
+      } else {
+        double rrc = 0.0, irc = 0.0, rcr = 0.0, icr = 0.0;      // Re/Im of DXD_rc and DXD_cr
+        for (int t = 0; t < cc; t++) {
+          const int sc = T.s_col[slot0 + c0 + t];
+          const int ct = sc >= n ? sc - n : sc;
+          // D[ct][j] (row ct, column j): Re = D[j*n+ct], Im = Di[j*n+ct]
+          const double drc = D[(int64_t)c * n + ct], dic = Di[(int64_t)c * n + ct];
+          const double drr = D[(int64_t)r * n + ct], dir = Di[(int64_t)r * n + ct];
+          const double yr_r = Y[t * n + r], yi_r = Yi[t * n + r], yr_c = Y[t * n + c], yi_c = Yi[t * n + c];
+          rrc += yr_r * drc - yi_r * dic; irc += yr_r * dic + yi_r * drc;
+          rcr += yr_c * drr - yi_c * dir; icr += yr_c * dir + yi_c * drr;
+        }
+        v = zpart ? (irc - icr) / 2 : (rrc + rcr) / 2;
       }
-      const double v = (a1 + a2) / 2;
       if (c0 == 0) z[u] = v; else z[u] += v;
     }
     __syncthreads();

@@ -20,18 +20,21 @@ import numpy as np
 import scipy.sparse as sp
 
 
-def make_K(lpN, q, s):
+def make_K(lpN, q, s, hs=()):
     """K struct (dict of float arrays, MATLAB conventions) as left by pretransfo.m:486-542.
-    lpN includes the artificial x0 row."""
+    lpN includes the artificial x0 row.  s = real symmetric PSD blocks, hs = Hermitian PSD blocks (stored behind
+    the real ones as [Re; Im], 2 n^2 rows each; K.s lists both, K.rsdpN = number of real blocks)."""
     q = np.asarray(q, dtype=np.float64).ravel()
-    s = np.asarray(s, dtype=np.float64).ravel()
-    blkstart = np.cumsum(np.concatenate(([lpN + 1, q.size], q - 1, s ** 2))).astype(np.float64)
+    sr = np.asarray(s, dtype=np.float64).ravel()
+    sh = np.asarray(hs, dtype=np.float64).ravel()
+    s = np.concatenate((sr, sh))
+    blkstart = np.cumsum(np.concatenate(([lpN + 1, q.size], q - 1, sr ** 2, 2 * sh ** 2))).astype(np.float64)
     mb = blkstart[np.cumsum([0, 1, q.size])]
     return {
         "f": 0.0, "l": float(lpN), "q": q.reshape(1, -1), "r": np.zeros((0, 1)), "s": s.reshape(1, -1),
-        "rsdpN": float(s.size), "N": float(blkstart[-1] - 1), "blkstart": blkstart.reshape(1, -1),
-        "rLen": float(s.sum()), "hLen": 0.0, "qMaxn": float(q.max() if q.size else 0),
-        "rMaxn": float(s.max() if s.size else 0), "hMaxn": 0.0, "mainblks": mb.reshape(1, -1),
+        "rsdpN": float(sr.size), "N": float(blkstart[-1] - 1), "blkstart": blkstart.reshape(1, -1),
+        "rLen": float(sr.sum()), "hLen": float(sh.sum()), "qMaxn": float(q.max() if q.size else 0),
+        "rMaxn": float(sr.max() if sr.size else 0), "hMaxn": float(sh.max() if sh.size else 0), "mainblks": mb.reshape(1, -1),
         "qblkstart": blkstart[1:2 + q.size].reshape(1, -1), "sblkstart": blkstart[1 + q.size:].reshape(1, -1),
         "lq": float(mb[-1] - 1),
     }
@@ -59,6 +62,7 @@ class Problem:
 
 
 def _psd_rows(K):
+    """0-based first row of every PSD block (real blocks n^2 rows, Hermitian blocks 2 n^2) and the block orders."""
     start = K["sblkstart"].ravel().astype(np.int64) - 1
     return start, K["s"].ravel().astype(np.int64)
 
@@ -119,17 +123,18 @@ def blockdiag_sdp(nblk=64, n=200, mper=150, nnz=20, seed=4):
     return Problem(At, K, f"blockdiag_sdp({nblk}x{n},m={m})")
 
 
-def random_sdp(m=30, lp=6, q=(3, 4), s=(5, 7, 4), dens=0.3, seed=0, block_local=False):
+def random_sdp(m=30, lp=6, q=(3, 4), s=(5, 7, 4), dens=0.3, seed=0, block_local=False, hs=()):
     """Small mixed LP + Lorentz + PSD problem.  block_local=True makes every constraint touch a single
     cone block (sparse ADA' pattern: exercises ordering / multi-supernode factor)."""
     rng = np.random.default_rng(seed)
-    K = make_K(lp + 1, q, s)
+    K = make_K(lp + 1, q, s, hs)
     N = int(K["N"])
     bs = K["blkstart"].ravel().astype(np.int64) - 1
     nq = len(q)
     start, ns = _psd_rows(K)
+    nreal = len(s)
     rows, cols, vals = [], [], []
-    nblocks = 1 + nq + len(s)
+    nblocks = 1 + nq + len(s) + len(hs)
     # block_local: keep the number of constraints per block below the block's dimension so that ADA' stays
     # nonsingular (otherwise the pivots of the dependent constraints are pure rounding noise)
     caps = [int(0.7 * lp)] + [int(0.7 * qk) for qk in q] + [int(0.7 * n * (n + 1) / 2) for n in ns]
@@ -165,6 +170,9 @@ def random_sdp(m=30, lp=6, q=(3, 4), s=(5, 7, 4), dens=0.3, seed=0, block_local=
                     if rng.random() < dens:
                         rows.append(start[k] + r + c * n); cols.append(j)
                         vals.append(rng.standard_normal() * (1.0 if r == c else 2.0))
+                    if k >= nreal and r > c and rng.random() < dens:      # imaginary plane: strictly lower, folded (x2)
+                        rows.append(start[k] + n * n + r + c * n); cols.append(j)
+                        vals.append(rng.standard_normal() * 2.0)
         if not any(cc == j for cc in cols[-1:]):      # never leave a constraint empty
             rows.append(1 if lp else start[0]); cols.append(j); vals.append(1.0)
     At = sp.csc_matrix((vals, (rows, cols)), shape=(N, m))
@@ -229,14 +237,21 @@ def spd_scaling(K, seed=0, cond=1e2, identity=False):
     else:
         dl, ddet = 10.0 ** rng.uniform(-e, e, lpN), 10.0 ** rng.uniform(-e / 2, e / 2, nq)
     ud = []
-    for n in K["s"].ravel().astype(int):
+    nreal = int(np.asarray(K.get("rsdpN", K["s"].size)).ravel()[0])
+    for k, n in enumerate(K["s"].ravel().astype(int)):
+        herm = k >= nreal
         if identity:
-            D = np.eye(n)
+            D = np.eye(n, dtype=complex if herm else float)
         else:
             R = rng.standard_normal((n, n)) / np.sqrt(n)
-            D = np.eye(n) + 0.1 * (R + R.T)
+            if herm:
+                R = R + 1j * rng.standard_normal((n, n)) / np.sqrt(n)
+            D = np.eye(n) + 0.1 * (R + R.conj().T)
             w = np.linalg.eigvalsh(D).min()
             if w < 0.2:
                 D += (0.2 - w) * np.eye(n)
-        ud.append(D.ravel(order="F"))
+        if herm:                                           # A.8: Hermitian blocks as [vec(Re); vec(Im)]
+            ud.append(np.concatenate((D.real.ravel(order="F"), D.imag.ravel(order="F"))))
+        else:
+            ud.append(D.ravel(order="F"))
     return {"l": dl, "det": ddet}, (np.concatenate(ud) if ud else np.zeros(0))

@@ -32,7 +32,9 @@ def test_golden_reference_examples(name, tag):
 @pytest.mark.parametrize("seed,kw", [(0, {}), (1, dict(m=20, lp=0, q=(), s=(6, 3))), (2, dict(m=35, lp=8, q=(4, 3, 5), s=())),
                                      (3, dict(m=40, block_local=True)), (4, dict(m=16, lp=3, q=(3,), s=(9,), dens=0.9)),
                                      (5, dict(m=120, lp=30, q=(6, 9, 3, 4), s=(12, 20, 7), dens=0.15)),
-                                     (6, dict(m=200, lp=10, q=(5,), s=(33, 10), dens=0.05, block_local=True))])
+                                     (6, dict(m=200, lp=10, q=(5,), s=(33, 10), dens=0.05, block_local=True)),
+                                     (11, dict(m=24, lp=3, q=(3,), s=(4,), hs=(5, 3))),          # Hermitian PSD blocks (spcpxdxd)
+                                     (12, dict(m=150, lp=10, q=(5,), s=(12,), hs=(14, 9), dens=0.2))])
 def test_iteration_unit_mixed_cones(glue, seed, kw):
     from sedumi_amd import problem
     P = problem.random_sdp(seed=seed, **kw)

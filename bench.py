@@ -81,12 +81,76 @@ def cpu_baseline(P, d, ud, rhs, budget_s=12.0):
         return {"value": None, "unit": "IPM iters/s", "cores": 1, "kind": "reference", "sample": f"failed: {e}"}
 
 
+def bench_subtrees(args, rank, local_rank, world, torch, dist):
+    """BASELINE.json configs[4]: block-diagonal SDP (default 64 PSD blocks of order 200, 150 constraints each).  The
+    64 independent elimination-tree subtrees are dealt to the ranks (sedumi_amd.dist.SubtreeShardedSolver): ADA',
+    factor and solves of a subtree never leave its rank; the only exchange is the all-gather of the solution
+    segments after each solve.  Total work is fixed: strong scaling."""
+    import torch.distributed as tdist
+    from sedumi_amd import dist as sd, problem
+    if dist is None:                                   # single process: a 1-rank group so that the same code runs
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        tdist.init_process_group(backend="gloo", rank=0, world_size=1)
+    parts = args.workload.split(":")
+    nblk, n, mper = (int(parts[1]), int(parts[2]), int(parts[3])) if len(parts) == 4 else (64, 200, 150)
+    P = problem.blockdiag_sdp(nblk=nblk, n=n, mper=mper, nnz=20, seed=4)
+    d, ud = problem.spd_scaling(P.K, seed=5)
+    rhs = np.random.default_rng(0).standard_normal(P.m)
+    dev = torch.device("cuda", local_rank) if dist is not None else torch.device("cpu")
+    solver = sd.SubtreeShardedSolver(P, device_index=local_rank, device=dev, pars=PARS)
+    solver.upload_scaling(d, ud, P)
+
+    def step():
+        solver.factor()
+        for _ in range(NSOLVE):
+            solver.solve(rhs)
+
+    def sync():
+        if solver.plan is not None:
+            solver.plan.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if solver.plan is not None:
+        solver.plan.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": args.steps / elapsed, "unit": "IPM iters/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{P.name}: block-diagonal SDP (BASELINE.json configs[4]), m={P.m}, {nblk} independent subtrees; "
+                                   f"unit = getada1+2+3, blkchol, {NSOLVE}x(fwblkslv,./d,bwblkslv)",
+                       "parallelism": f"{world} rank(s): subtrees per rank {[int(c.size // mper) for c in solver.cols_of]}, all-gather of y only"},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    else:
+        tdist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="control07")
+    ap.add_argument("--workload", default="control07",
+                    help="control07 (default, BASELINE configs[1]) | maxcut<n> (configs[3]) | blockdiag[:nblk:n:mper] (configs[4])")
+    ap.add_argument("--shard", default="auto", choices=["auto", "replicas", "columns"],
+                    help="N>1: replicas = independent units per rank (default for single-supernode workloads); "
+                         "columns = ONE unit per step, ADA' column panels per rank + RCCL all-gather, factor/solves replicated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -104,14 +168,25 @@ def main():
     torch.cuda.set_device(local_rank)
 
     from sedumi_amd.plan import Plan
-    P, L, ADA, Q, d, ud, rhs = build_workload(args.workload, seed=rank)
+    if args.workload.startswith("blockdiag"):
+        return bench_subtrees(args, rank, local_rank, world, torch, dist)
+    shard_cols = args.shard == "columns" and world > 1
+    P, L, ADA, Q, d, ud, rhs = build_workload(args.workload, seed=0 if shard_cols else rank)
     plan = Plan(local_rank)
     plan.set_chol(L, ADA)
     plan.set_ada(P.At, P.Ablkjc, P.K, Q)
     plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud); plan.upload("rhs", rhs)
 
+    cs = None
+    if shard_cols:
+        from sedumi_amd import dist as sd
+        cs = sd.ColumnShardedAda(plan, device=torch.device("cuda", local_rank))
+
     def step():
-        plan.getada()
+        if cs is not None:
+            cs.getada()
+        else:
+            plan.getada()
         plan.blkchol(PARS, True)
         for _ in range(NSOLVE):
             plan.ldlsolve()
@@ -200,16 +275,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(P, d, ud, rhs)
         out = {
-            "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": world * args.steps / elapsed, "unit": "IPM iters/s",
+            "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": (1 if shard_cols else world) * args.steps / elapsed, "unit": "IPM iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if shard_cols else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{P.name}: control07-shaped SDP (BASELINE.json configs[1]), m={P.m}, nnz(At)={P.At.nnz}, "
                                    f"dense ADA' {P.m}x{P.m}, nnz(L)={nnzL}; unit = getada1+2+3, blkchol, {NSOLVE}x(fwblkslv,./d,bwblkslv)",
-                       "parallelism": "replicas" if world > 1 else "single GPU"},
+                       "parallelism": ("ADA' column panels + RCCL all-gather, factor/solves replicated" if shard_cols else "replicas") if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": base,
         }
         if base and base.get("value"):
-            out["speedup_vs_cpu_reference"] = out["value"] / world / base["value"]
+            out["speedup_vs_cpu_reference"] = out["value"] / (1 if shard_cols else world) / base["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -228,6 +228,13 @@ int sdm_plan_download(sdm_plan *p, const char *name, double *dst, sdm_int nelem)
  * scaling buffers dl, ddet, qpr (values of DAt.q), udsqr.  Result in "ada"
  * (values in ADA pattern order, symmetric) and "absd". */
 int sdm_plan_getada(sdm_plan *p);
+/* The same restricted to the columns j0 <= j < j1 of ADA' (and absd[j0:j1]); the other entries of "ada" are left
+ * untouched.  Columns are independent given the scaling data, so the ranks of a multi-GPU job each form a panel
+ * and exchange panels (sedumi_amd/dist.py does the all-gather over RCCL). */
+int sdm_plan_getada_cols(sdm_plan *p, sdm_int j0, sdm_int j1);
+/* Device-to-device copy between a plan buffer (elements [offset, offset+nelem)) and memory owned by the caller
+ * (e.g. a torch tensor used as an RCCL send/receive buffer): to_plan != 0 copies devptr -> plan. */
+int sdm_plan_copy(sdm_plan *p, const char *name, void *devptr, sdm_int offset, sdm_int nelem, int to_plan);
 /* blkchol (sedumi.m:458) on the resident "ada"/"absd".  use_absd=0 takes
  * diag(ADA(perm,perm)) as in blkchol.c:380-381. */
 int sdm_plan_blkchol(sdm_plan *p, const sdm_cholpars *pars, int use_absd);

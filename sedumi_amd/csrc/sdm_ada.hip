@@ -124,6 +124,7 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
   }
   s_nzptr.push_back(A.nnzA);   // sentinel (only used through per-task end pointers)
   A.ntask = (sdm_int)t_col.size(); A.zlen = zlen;
+  A.h_taskptr = c_taskptr; A.col0 = 0; A.col1 = m;
   // per task: end of its last slot = start of next task's first nonzero; store explicit end pointers in s_nzptr
   // by giving every slot an (begin) and using the next slot's begin inside a task, and the task end via t_end:
   std::vector<int64_t> t_end(A.ntask);
@@ -242,8 +243,8 @@ __global__ void k_fill(double *x, double v, int64_t n) {
 //   val(i,j) = sum_r  M(r,i) * w(r) * M(r,j),   w = dsqr (getada1) or 1 (getada2)
 __global__ void __launch_bounds__(256)
 k_ada_spdot(double *ada, const int64_t *ADAjc, const int *ADAir, const int64_t *Mbeg, const int64_t *Mend,
-            const int *Mir, const double *Mpr, const double *wgt, const int *invperm, int accumulate) {
-  const int j = blockIdx.x;
+            const int *Mir, const double *Mpr, const double *wgt, const int *invperm, int accumulate, int jbase) {
+  const int j = blockIdx.x + jbase;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   const int64_t jb = Mbeg[j], je = Mend[j];
   const int ipj = invperm ? invperm[j] : 0;
@@ -273,10 +274,10 @@ struct Stage1Tab {
   const int64_t *psd_start;
 };
 __global__ void __launch_bounds__(256)
-k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY) {
+k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0) {
   SDM_DYN_SMEM(smem);
   double *Y = (double *)smem;                       // Y[slot][row], chunk of CC slots (Hermitian: Re then Im plane)
-  const int task = blockIdx.x;
+  const int task = blockIdx.x + task0;
   const int n = T.t_n[task], nslot = T.t_nslot[task], ulen = T.t_ulen[task];
   const int herm = T.t_herm[task];
   const int64_t slot0 = T.t_slotptr[task], tend = T.t_end[task];
@@ -357,9 +358,9 @@ k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY) {
 // fixed set of 16x16 tiles of Z in registers.  The targets are read off the finished Z in LDS:
 // z(r,c) = (Z[r][c] + Z[c][r]) / 2  -- the same two sums as spscale.c:283-304.
 __global__ void __launch_bounds__(64 * S1_WAVES)
-k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf) {
+k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0) {
   SDM_DYN_SMEM(smem);
-  const int task = blockIdx.x;
+  const int task = blockIdx.x + task0;
   const int n = T.t_n[task], nslot = T.t_nslot[task], ulen = T.t_ulen[task];
   const int np = (n + 15) & ~15, nt = np >> 4, ntile = nt * nt;
   double *Yl = (double *)smem;                      // Yl[t*np + i], t < S1_KC
@@ -428,10 +429,10 @@ __global__ void __launch_bounds__(256)
 k_psd_stage2(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, const int64_t *Ajc,
              const int64_t *Ajc_psd, const double *Apr, const int *Ablk, const int *Aupos,
              const int64_t *c_taskptr, const int *t_blk, const int64_t *t_zoff, const double *zbuf,
-             const int *invperm, int nblk, int thread_per_row) {
+             const int *invperm, int nblk, int thread_per_row, int jbase) {
   SDM_DYN_SMEM(smem);
   long long *zo = (long long *)smem;                // block -> offset of z_jk in zbuf (or -1)
-  const int j = blockIdx.x;
+  const int j = blockIdx.x + jbase;
   const int tid = threadIdx.x, bs = blockDim.x;
   for (int k = tid; k < nblk; k += bs) zo[k] = -1;
   __syncthreads();
@@ -484,12 +485,12 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
                  const int64_t *Ajc_psd, const double *Apr, const int *Ablk, const int *Aupos,
                  const int64_t *c_taskptr, const int *t_blk, const int *t_ulen, const int64_t *t_zoff, const double *zbuf,
                  const int *g_row, const int *g_len, const int64_t *g_off, const double *g_val, const int *g_bu,
-                 const int *g_wptr, const int *g_wlist, const int *invperm, int nblk, int zmax, int m) {
+                 const int *g_wptr, const int *g_wlist, const int *invperm, int nblk, int zmax, int m, int jbase, int jend) {
   SDM_DYN_SMEM(smem);
   double *zl = (double *)smem;                      // JB x (z_j, then one zero word at [zmax])
   int *base = (int *)(zl + (size_t)JB * (zmax + 1));  // JB x (block -> offset of z_jk in zl_q, or -1)
   __shared__ double absred[JB][ELL_WAVES];
-  const int j0 = blockIdx.x * JB;
+  const int j0 = jbase + blockIdx.x * JB;
   const int tid = threadIdx.x, bs = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
   for (int k = tid; k < nblk * JB; k += bs) base[k] = -1;
@@ -500,7 +501,7 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
   for (int q = 0; q < JB; q++) {
     const int j = j0 + q;
     jhas[q] = false;
-    if (j < m) {
+    if (j < jend) {
       const int64_t tb = c_taskptr[j], te = c_taskptr[j + 1];
       jhas[q] = te > tb;
       if (jhas[q]) {
@@ -526,7 +527,7 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
     if (lane == 0) absred[q][wave] = aabs;
   }
   __syncthreads();
-  if (tid < JB && j0 + tid < m) {
+  if (tid < JB && j0 + tid < jend) {
     const int j = j0 + tid;
     double basev = 0.0;
     int64_t lo = ADAjc[j], hi = ADAjc[j + 1];
@@ -610,19 +611,22 @@ __global__ void k_diag(double *absd, const double *ada, const int64_t *ADAjc, co
 }
 
 // ============================================================ host drivers
+// Column range [A.col0, A.col1) of ADA' (all columns by default): every stage below only touches those columns,
+// which is what lets the ranks of a job form disjoint column panels of one ADA' (sdm_plan_getada_cols).
 void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
   AdaPlan &A = P->ada;
+  if (A.col1 <= A.col0) return;
   hipStream_t st = P->stream;
   if (A.nlq > 0)
     SDM_KLAUNCH(P, k_dsqr, dim3((unsigned)((A.nlq + 255) / 256)), dim3(256), 0, A.dsqr.p, A.dsqr_code.p, A.dl.p, A.ddet.p, (int)A.nlq);
-  SDM_KLAUNCH(P, k_ada_spdot, dim3((unsigned)A.m), dim3(256), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p,
-             A.d_Air.p, A.d_Apr.p, A.dsqr.p, d_invperm, accumulate ? 1 : 0);
+  SDM_KLAUNCH(P, k_ada_spdot, dim3((unsigned)(A.col1 - A.col0)), dim3(256), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p,
+             A.d_Air.p, A.d_Apr.p, A.dsqr.p, d_invperm, accumulate ? 1 : 0, (int)A.col0);
 }
 void ada_q(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
   AdaPlan &A = P->ada;
-  if (A.lorN == 0 || A.nnzQ == 0) return;
-  SDM_KLAUNCH(P, k_ada_spdot, dim3((unsigned)A.m), dim3(256), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Qjc.p, A.d_Qjc.p + 1,
-             A.d_Qir.p, A.qpr.p, (const double *)nullptr, d_invperm, accumulate ? 1 : 0);
+  if (A.lorN == 0 || A.nnzQ == 0 || A.col1 <= A.col0) return;
+  SDM_KLAUNCH(P, k_ada_spdot, dim3((unsigned)(A.col1 - A.col0)), dim3(256), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Qjc.p, A.d_Qjc.p + 1,
+             A.d_Qir.p, A.qpr.p, (const double *)nullptr, d_invperm, accumulate ? 1 : 0, (int)A.col0);
 }
 void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
   AdaPlan &A = P->ada;
@@ -636,7 +640,10 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
     SDM_KLAUNCH(P, k_diag, dim3((m + 255) / 256), dim3(256), 0, P->absd.p, ada, A.d_ADAjc.p, A.d_ADAir.p, m);
     return;
   }
-  if (A.ntask > 0) {
+  if (A.col1 <= A.col0) return;
+  const int ncols = (int)(A.col1 - A.col0), jbase = (int)A.col0;
+  const int task0 = (int)A.h_taskptr[A.col0], ntask = (int)(A.h_taskptr[A.col1] - A.h_taskptr[A.col0]);
+  if (ntask > 0) {
     Stage1Tab T;
     T.t_n = A.t_n.p; T.t_nslot = A.t_nslot.p; T.t_ulen = A.t_ulen.p; T.t_herm = A.t_herm.p; T.s_col = A.s_col.p;
     T.u_pos = A.u_pos.p; T.Air = A.d_Air.p; T.t_slotptr = A.t_slotptr.p; T.t_udoff = A.t_udoff.p; T.t_uoff = A.t_uoff.p;
@@ -651,10 +658,10 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
 #ifndef SDM_EMU
       if (lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage1_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
-      SDM_KLAUNCH(P, k_psd_stage1_mfma, dim3((unsigned)A.ntask), dim3(64 * S1_WAVES), lds, T, A.udsqr.p, A.zbuf.p);
+      SDM_KLAUNCH(P, k_psd_stage1_mfma, dim3((unsigned)ntask), dim3(64 * S1_WAVES), lds, T, A.udsqr.p, A.zbuf.p, task0);
     } else
-    SDM_KLAUNCH(P, k_psd_stage1, dim3((unsigned)A.ntask), dim3(256), A.stage1_lds, T, A.udsqr.p, A.zbuf.p,
-               (int)(A.stage1_lds / sizeof(double)));
+    SDM_KLAUNCH(P, k_psd_stage1, dim3((unsigned)ntask), dim3(256), A.stage1_lds, T, A.udsqr.p, A.zbuf.p,
+               (int)(A.stage1_lds / sizeof(double)), task0);
   }
   // the reference first adds the PSD part on one triangle and symmetrises at the very end; summing the
   // transposed partial sums of getada1/2 first and adding the (symmetric) PSD part afterwards is the same sum.
@@ -668,10 +675,10 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
     do {                                                                                                                 \
       const size_t lds = lds_of(JB);                                                                                    \
       SDM_STAGE2_ATTR(JB, lds);                                                                                         \
-      SDM_KLAUNCH(P, k_psd_stage2_ell<JB>, dim3((m + JB - 1) / JB), dim3(64 * ELL_WAVES), lds, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, \
+      SDM_KLAUNCH(P, k_psd_stage2_ell<JB>, dim3((ncols + JB - 1) / JB), dim3(64 * ELL_WAVES), lds, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, \
                   A.d_Ajc.p, A.d_Ajc_psd.p, A.d_Apr.p, A.d_Ablk.p, A.d_Aupos.p, A.c_taskptr.p, A.t_blk.p, A.t_ulen.p,    \
                   A.t_zoff.p, A.zbuf.p, A.g_row.p, A.g_len.p, A.g_off.p, A.g_val.p, A.g_bu.p, A.g_wptr.p, A.g_wlist.p, d_invperm,       \
-                  (int)A.sdpN, (int)A.zmax, m);                                                                          \
+                  (int)A.sdpN, (int)A.zmax, m, jbase, jbase + ncols);                                                    \
     } while (0)
 #ifndef SDM_EMU
 #define SDM_STAGE2_ATTR(JB, lds) if ((lds) > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage2_ell<JB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)))
@@ -687,9 +694,9 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
     SDM_HIP_CHECK(hipGetLastError());
     return;
   }
-  SDM_KLAUNCH(P, k_psd_stage2, dim3(m), dim3(256), (size_t)A.sdpN * 8, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p,
+  SDM_KLAUNCH(P, k_psd_stage2, dim3(ncols), dim3(256), (size_t)A.sdpN * 8, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p,
              A.d_Ajc_psd.p, A.d_Apr.p, A.d_Ablk.p, A.d_Aupos.p, A.c_taskptr.p, A.t_blk.p, A.t_zoff.p, A.zbuf.p, d_invperm,
-             (int)A.sdpN, A.thread_per_row ? 1 : 0);
+             (int)A.sdpN, A.thread_per_row ? 1 : 0, jbase);
   SDM_HIP_CHECK(hipGetLastError());
 }
 

@@ -134,6 +134,29 @@ int sdm_plan_getada(sdm_plan *p) {
   ada_psd(p, p->ada_val.p, nullptr, false);
   SDM_CATCH
 }
+int sdm_plan_getada_cols(sdm_plan *p, sdm_int j0, sdm_int j1) {
+  SDM_TRY
+  if (!p->has_ada) throw std::runtime_error("sdm_plan_getada_cols: no ADA data set");
+  if (j0 < 0 || j1 > p->ada.m || j0 > j1) throw std::runtime_error("sdm_plan_getada_cols: column range out of bounds");
+  p->ada.col0 = j0; p->ada.col1 = j1;
+  try {
+    ada_lq(p, p->ada_val.p, nullptr, false);
+    ada_q(p, p->ada_val.p, nullptr, true);
+    ada_psd(p, p->ada_val.p, nullptr, false);
+  } catch (...) { p->ada.col0 = 0; p->ada.col1 = p->ada.m; throw; }
+  p->ada.col0 = 0; p->ada.col1 = p->ada.m;
+  SDM_CATCH
+}
+int sdm_plan_copy(sdm_plan *p, const char *name, void *devptr, sdm_int offset, sdm_int nelem, int to_plan) {
+  SDM_TRY
+  DevBuf<double> *b = plan_buf(p, name);
+  if (offset < 0 || nelem < 0 || (size_t)(offset + nelem) > b->n) throw std::runtime_error(std::string("sdm_plan_copy: range outside buffer ") + name);
+  if (std::string(name) == "lpr" && !to_plan) chol_extract(p, p->lpr.p);
+  if (to_plan) SDM_HIP_CHECK(hipMemcpyAsync(b->p + offset, devptr, (size_t)nelem * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  else SDM_HIP_CHECK(hipMemcpyAsync(devptr, b->p + offset, (size_t)nelem * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  SDM_CATCH
+}
 int sdm_plan_blkchol(sdm_plan *p, const sdm_cholpars *pars, int use_absd) {
   SDM_TRY
   if (!p->has_chol) throw std::runtime_error("sdm_plan_blkchol: no symbolic factor set");

@@ -90,6 +90,8 @@ struct AdaPlan {
   sdm_int lenud = 0, ntask = 0, zlen = 0, nnzQ = 0;
   int maxn = 0;
   bool thread_per_row = false;
+  sdm_int col0 = 0, col1 = 0;            // column range of ADA' formed by this plan (sdm_plan_getada_cols)
+  std::vector<int64_t> h_taskptr;       // host copy of c_taskptr
   std::vector<sdm_int> psd_n, psd_start, psd_udoff;
   DevBuf<int64_t> d_Ajc, d_Ajc_psd, d_Qjc, d_ADAjc;
   DevBuf<int> d_Air, d_Qir, d_ADAir, d_ADAT;

@@ -1,0 +1,167 @@
+"""Multi-GPU layer of the normal-equations hot path: one process per GPU, torch.distributed (backend "nccl" is
+RCCL over xGMI on ROCm; "gloo" in the CPU tests).  Two shardings, the ones SURVEY.md section 8(e) identifies:
+
+* ``ColumnShardedAda`` -- the columns of ADA' are independent once the scaling data is replicated
+  (getada3.c:311-351 walks constraint by constraint): every rank forms a contiguous column panel
+  (`sdm_plan_getada_cols`) and the panels are exchanged with ONE all-gather (values + absd).  This is the shard of a
+  problem whose ADA' is a single dense supernode (MAXCUT, control07): factor and solves then run replicated.
+* ``SubtreeShardedSolver`` -- independent elimination-tree subtrees (connected components of the ADA' pattern, e.g.
+  the 64 diagonal blocks of the block-diagonal config) are dealt to the ranks; ADA', factor and solves of a
+  component never leave its rank -- no data-path collective -- and the only exchange is the all-gather of the
+  solution segments y that the (host-side) IPM needs in full.
+
+Both classes take an already initialised process group; nothing here launches processes.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.csgraph as csgraph
+
+from . import problem
+from .plan import Plan
+
+
+def _torch():
+    import torch
+    import torch.distributed as dist
+    return torch, dist
+
+
+def balanced_ranges(weights, parts):
+    """Contiguous ranges [b_r, b_{r+1}) with roughly equal weight sums (prefix-sum cuts)."""
+    w = np.asarray(weights, dtype=np.float64)
+    cum = np.concatenate(([0.0], np.cumsum(w)))
+    cuts = [0]
+    for r in range(1, parts):
+        cuts.append(int(np.searchsorted(cum, cum[-1] * r / parts, side="left")))
+    cuts.append(w.size)
+    return np.maximum.accumulate(np.asarray(cuts))
+
+
+class ColumnShardedAda:
+    """ADA' formed as column panels, one per rank, all-gathered into every rank's resident plan."""
+
+    def __init__(self, plan: Plan, group=None, device=None, col_weights=None):
+        torch, dist = _torch()
+        self.plan, self.group = plan, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = device if device is not None else torch.device("cpu")
+        m = plan.m
+        jc = np.asarray(plan.ADA_pattern.indptr, dtype=np.int64)
+        w = np.diff(jc).astype(np.float64) if col_weights is None else np.asarray(col_weights, dtype=np.float64)
+        self.cols = balanced_ranges(w, self.world)                     # column cuts
+        self.voff = jc[self.cols]                                       # value offsets of the panels
+        self.maxv = int(np.max(np.diff(self.voff))) if self.world else 0
+        self.maxc = int(np.max(np.diff(self.cols))) if self.world else 0
+        self.chunk = self.maxv + self.maxc                              # [values | absd] padded to a common length
+        self.send = torch.zeros(self.chunk, dtype=torch.float64, device=self.device)
+        self.recv = torch.zeros(self.chunk * self.world, dtype=torch.float64, device=self.device)
+        assert m == self.cols[-1]
+
+    def getada(self):
+        torch, dist = _torch()
+        r = self.rank
+        j0, j1 = int(self.cols[r]), int(self.cols[r + 1])
+        self.plan.getada_cols(j0, j1)
+        nv = int(self.voff[r + 1] - self.voff[r])
+        if nv:
+            self.plan.copy("ada", self.send, int(self.voff[r]), nv, to_plan=False)
+        if j1 > j0:
+            self.plan.copy("absd", self.send[self.maxv:], j0, j1 - j0, to_plan=False)
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        for q in range(self.world):
+            if q == r:
+                continue
+            base = q * self.chunk
+            nvq, ncq = int(self.voff[q + 1] - self.voff[q]), int(self.cols[q + 1] - self.cols[q])
+            if nvq:
+                self.plan.copy("ada", self.recv[base:base + nvq], int(self.voff[q]), nvq, to_plan=True)
+            if ncq:
+                self.plan.copy("absd", self.recv[base + self.maxv:base + self.maxv + ncq], int(self.cols[q]), ncq, to_plan=True)
+
+
+# ----------------------------------------------------------------------------------------- subtree sharding
+def components(P):
+    """Connected components of the ADA' pattern of problem P = groups of constraints that share a cone variable
+    (entry level for LP rows, block level for Lorentz / PSD blocks: getsymbada.m:41-60).  Returns (labels[m], B)
+    with B the m x ngroups incidence matrix used for the pattern."""
+    B = problem.coupling_incidence(P)
+    ncomp, lab = csgraph.connected_components(sp.csr_matrix(B @ B.T), directed=False)
+    return ncomp, lab, B
+
+
+def split_problem(P, world):
+    """Deal the connected components of ADA' to `world` ranks (longest-processing-time first on an m_c^3 + nnz cost)
+    and build one sub-problem per rank: its constraints and exactly the cone blocks they touch, in SeDuMi's internal
+    row order.  Returns [(subproblem, constraint_indices, rowmap)] per rank (subproblem None for an idle rank);
+    rowmap = rows of P.At kept, in order."""
+    ncomp, lab, _ = components(P)
+    At = sp.csc_matrix(P.At)
+    sizes = np.bincount(lab, minlength=ncomp)
+    nnzc = np.bincount(lab, weights=np.diff(At.indptr), minlength=ncomp)
+    cost = sizes.astype(np.float64) ** 3 / 3 + nnzc
+    load = np.zeros(world)
+    owner = np.zeros(ncomp, dtype=np.int64)
+    for c in np.argsort(-cost, kind="stable"):
+        r = int(np.argmin(load))
+        owner[c] = r; load[r] += cost[c]
+    out = []
+    for r in range(world):
+        cols = np.flatnonzero(owner[lab] == r)
+        out.append(problem.subproblem(P, cols) + (cols,) if cols.size else (None, None, cols))
+    return [(sub, cols, rows) for (sub, rows, cols) in out]
+
+
+class SubtreeShardedSolver:
+    """Every rank owns whole connected components of ADA': local ADA', factor and solves; y is all-gathered."""
+
+    def __init__(self, P, group=None, device_index=0, device=None, pars=None):
+        torch, dist = _torch()
+        from . import mex
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = device if device is not None else torch.device("cpu")
+        self.m = P.m
+        parts = split_problem(P, self.world)
+        self.cols_of = [c for (_, c, _) in parts]
+        self.sub, self.cols, self.rows = parts[self.rank]
+        self.pars = pars
+        self.maxc = max((c.size for c in self.cols_of), default=0)
+        self.send = torch.zeros(max(self.maxc, 1), dtype=torch.float64, device=self.device)
+        self.recv = torch.zeros(max(self.maxc, 1) * self.world, dtype=torch.float64, device=self.device)
+        self.plan = None
+        if self.sub is not None:
+            ADApat = problem.symb_ada(self.sub)
+            L = mex.symbchol(ADApat)
+            self.plan = Plan(device_index)
+            self.plan.set_chol(L, ADApat)
+            self.plan.set_ada(self.sub.At, self.sub.Ablkjc, self.sub.K, problem.lorentz_pattern(self.sub))
+            self.L = L
+
+    def upload_scaling(self, d, ud, P):
+        """Scaling data of the FULL problem P (d.l, d.det, udsqr): every rank keeps its own rows / blocks."""
+        if self.plan is None:
+            return
+        dl, ddet, uds = problem.sub_scaling(P, self.sub, self.rows, d, ud)
+        self.plan.upload("dl", dl); self.plan.upload("ddet", ddet); self.plan.upload("udsqr", uds)
+
+    def factor(self):
+        if self.plan is not None:
+            self.plan.getada(); self.plan.blkchol(self.pars, True)
+
+    def solve(self, rhs):
+        """y = ADA' \\ rhs (full-length host vectors in, full-length host vector out)."""
+        torch, dist = _torch()
+        n = self.cols.size if self.cols is not None else 0
+        if self.plan is not None:
+            self.plan.upload("rhs", np.asarray(rhs, dtype=np.float64)[self.cols])
+            self.plan.ldlsolve()
+            self.plan.copy("y", self.send, 0, n, to_plan=False)
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)       # the only exchange: solution segments
+        out = np.zeros(self.m)
+        host = self.recv.cpu().numpy()
+        for q, c in enumerate(self.cols_of):
+            if c is not None and c.size:
+                out[c] = host[q * self.send.numel():q * self.send.numel() + c.size]
+        return out

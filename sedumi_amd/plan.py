@@ -105,6 +105,18 @@ class Plan:
     def getada(self):
         check(self._lib.sdm_plan_getada(C.c_void_p(self._p)))
 
+    def getada_cols(self, j0, j1):
+        """Columns j0 <= j < j1 of ADA' (and absd[j0:j1]) only; the rest of "ada" is left untouched."""
+        check(self._lib.sdm_plan_getada_cols(C.c_void_p(self._p), C.c_int64(int(j0)), C.c_int64(int(j1))))
+
+    def copy(self, name, tensor, offset, nelem, to_plan):
+        """Device-to-device copy between plan buffer `name`[offset:offset+nelem] and a contiguous float64 torch
+        tensor living on the plan's device (RCCL send / receive buffers of sedumi_amd.dist)."""
+        if tensor.dtype.itemsize != 8 or not tensor.is_contiguous() or tensor.numel() < nelem:
+            raise SdmError("copy: need a contiguous float64 tensor with at least nelem elements")
+        check(self._lib.sdm_plan_copy(C.c_void_p(self._p), name.encode(), C.c_void_p(tensor.data_ptr()), C.c_int64(int(offset)),
+                                      C.c_int64(int(nelem)), 1 if to_plan else 0))
+
     def blkchol(self, pars=None, use_absd=True):
         cp = capi.CholPars(1e-12, 5e5, 1e-20)          # checkpars.m:144-168
         if pars:

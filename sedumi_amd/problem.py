@@ -255,3 +255,86 @@ def spd_scaling(K, seed=0, cond=1e2, identity=False):
         else:
             ud.append(D.ravel(order="F"))
     return {"l": dl, "det": ddet}, (np.concatenate(ud) if ud else np.zeros(0))
+
+
+# ------------------------------------------------------------------ pattern of ADA' and independent sub-problems
+def _cone_layout(K):
+    """Row ranges of the internal variable order (A.1): lpN, Lorentz block sizes, first Lorentz trace row, first
+    norm-bound row of every Lorentz block, (first row, length) of every PSD block -- all 0-based."""
+    lpN = int(np.asarray(K["l"]).ravel()[0])
+    q = np.asarray(K["q"], dtype=np.float64).ravel().astype(np.int64)
+    s = np.asarray(K["s"], dtype=np.float64).ravel().astype(np.int64)
+    nreal = int(np.asarray(K.get("rsdpN", s.size)).ravel()[0])
+    bs = np.asarray(K["blkstart"], dtype=np.float64).ravel().astype(np.int64) - 1
+    qnorm = bs[1:1 + q.size + 1]                             # starts of the norm-bound parts (+ end)
+    psd = bs[1 + q.size:]                                     # starts of the PSD blocks (+ end)
+    return lpN, q, s, nreal, qnorm, psd
+
+
+def coupling_incidence(P):
+    """m x G 0/1 matrix: constraint j is incident to group g when it has a nonzero in it.  Groups = every LP and
+    Lorentz row on its own (entry-level coupling), every Lorentz block, every PSD block (block-level coupling) --
+    the three terms of getsymbada.m:41-60."""
+    At = sp.csc_matrix(P.At)
+    N, m = At.shape
+    lpN, q, s, nreal, qnorm, psd = _cone_layout(P.K)
+    psd0 = int(psd[0]) if s.size else N
+    rows = At.indices
+    cols = np.repeat(np.arange(m), np.diff(At.indptr))
+    grp = rows.astype(np.int64).copy()
+    ispsd = rows >= psd0
+    if s.size:
+        grp[ispsd] = psd0 + q.size + (np.searchsorted(psd, rows[ispsd], side="right") - 1)
+    B = sp.csr_matrix((np.ones(grp.size), (cols, grp)), shape=(m, psd0 + q.size + s.size))
+    if q.size:
+        Q = sp.csr_matrix(lorentz_pattern(P).T)              # m x nq
+        Qc = sp.csr_matrix((np.ones(Q.nnz), (Q.nonzero()[0], psd0 + Q.nonzero()[1])), shape=B.shape)
+        B = B + Qc
+    B.data[:] = 1.0
+    return sp.csr_matrix(B)
+
+
+def symb_ada(P):
+    """Nonzero pattern of ADA' as SeDuMi builds it (getsymbada.m:41-60), values all 1; dense when over 90 % full."""
+    B = coupling_incidence(P)
+    m = B.shape[0]
+    S = sp.csc_matrix(B @ B.T)
+    if m == 0 or S.nnz > 0.9 * m * m:
+        return sp.csc_matrix(np.ones((m, m)))
+    S = sp.csc_matrix((np.ones(S.nnz), S.indices, S.indptr), shape=S.shape)
+    S.sort_indices()
+    return S
+
+
+def subproblem(P, cols):
+    """The sub-problem made of the constraints `cols` and exactly the cone blocks they touch (row 0, the artificial
+    x0 variable, is always kept).  Returns (Problem, kept rows of P.At in order)."""
+    At = sp.csc_matrix(P.At)[:, np.asarray(cols, dtype=np.int64)]
+    lpN, q, s, nreal, qnorm, psd = _cone_layout(P.K)
+    touched = np.zeros(At.shape[0], dtype=bool)
+    touched[np.unique(At.indices)] = True
+    lp_rows = [0] + [r for r in range(1, lpN) if touched[r]]
+    qkeep = [k for k in range(q.size) if touched[lpN + k] or touched[qnorm[k]:qnorm[k + 1]].any()]
+    skeep = [k for k in range(s.size) if touched[psd[k]:psd[k + 1]].any()]
+    rows = list(lp_rows) + [lpN + k for k in qkeep]
+    for k in qkeep:
+        rows.extend(range(int(qnorm[k]), int(qnorm[k + 1])))
+    for k in skeep:
+        rows.extend(range(int(psd[k]), int(psd[k + 1])))
+    rows = np.asarray(rows, dtype=np.int64)
+    K = make_K(len(lp_rows), q[qkeep], [s[k] for k in skeep if k < nreal], [s[k] for k in skeep if k >= nreal])
+    sub = Problem(sp.csc_matrix(At.tocsr()[rows, :]), K, f"{P.name}[{len(cols)} constraints]")
+    sub.kept = {"lp": np.asarray(lp_rows), "q": np.asarray(qkeep, dtype=np.int64), "s": np.asarray(skeep, dtype=np.int64)}
+    return sub, rows
+
+
+def sub_scaling(P, sub, rows, d, ud):
+    """Scaling data (d.l, d.det, udsqr) of the full problem restricted to the cone blocks kept by `subproblem`."""
+    lpN, q, s, nreal, qnorm, psd = _cone_layout(P.K)
+    dl = np.asarray(d["l"], dtype=np.float64).ravel()[sub.kept["lp"]]
+    ddet = np.asarray(d["det"], dtype=np.float64).ravel()[sub.kept["q"]] if q.size else np.zeros(0)
+    lens = np.where(np.arange(s.size) < nreal, s ** 2, 2 * s ** 2)
+    off = np.concatenate(([0], np.cumsum(lens)))
+    ud = np.asarray(ud, dtype=np.float64).ravel()
+    uds = np.concatenate([ud[off[k]:off[k + 1]] for k in sub.kept["s"]]) if sub.kept["s"].size else np.zeros(0)
+    return dl, ddet, uds

@@ -90,6 +90,7 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
       psdnnz++;
     }
   A.thread_per_row = (m > 0 && psdnnz / (double)m < 16.0);
+  A.nnz_lq = A.nnzA - psdnnz;                                      // LP + Lorentz nonzeros of At
   // ---- stage-1 tasks and slots
   std::vector<int> t_col, t_blk, t_n, t_nslot, t_ulen, t_herm, s_col;
   std::vector<int64_t> t_slotptr, t_udoff, t_uoff, t_zoff, s_nzptr, c_taskptr(m + 1, 0);
@@ -617,6 +618,13 @@ void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
   AdaPlan &A = P->ada;
   if (A.col1 <= A.col0) return;
   hipStream_t st = P->stream;
+  if (A.nnz_lq == 0 && !accumulate && !d_invperm) {
+    // no LP / Lorentz nonzeros at all (e.g. MAXCUT): the LP part of ADA' is the zero matrix -- one memset of the
+    // column panel instead of nnz(ADA') empty sparse dot products
+    const sdm_int e0 = P->ada_jc[A.col0], e1 = P->ada_jc[A.col1];
+    if (e1 > e0) SDM_HIP_CHECK(hipMemsetAsync(ada + e0, 0, (size_t)(e1 - e0) * sizeof(double), P->stream));
+    return;
+  }
   if (A.nlq > 0)
     SDM_KLAUNCH(P, k_dsqr, dim3((unsigned)((A.nlq + 255) / 256)), dim3(256), 0, A.dsqr.p, A.dsqr_code.p, A.dl.p, A.ddet.p, (int)A.nlq);
   SDM_KLAUNCH(P, k_ada_spdot, dim3((unsigned)(A.col1 - A.col0)), dim3(256), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p,

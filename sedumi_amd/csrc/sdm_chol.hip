@@ -870,6 +870,112 @@ k_ldl_single(const double *F, const double *DT, int m, const int *perm, const do
   for (int i = tid; i < m; i += bs) { if (mode & 4) yout[perm[i]] = w[i]; else yout[i] = w[i]; }
 }
 
+// ---- big single fronts (m >= BIG_FRONT): one CU cannot stream the factor fast enough (~100 GB/s), so the sweeps
+// are cut into one launch per 64-column panel; the launches of a sweep are stream-ordered, there is no
+// inter-workgroup synchronisation inside a launch.
+// Forward launch p (p = -1 .. nblk-2): workgroup i owns row block r = p+1+i.  It applies panel p to its rows,
+// w_r -= L(r,p) x_p (x_p was finished by launch p-1), and workgroup 0 then solves the diagonal block r = p+1 so
+// that x_{p+1} is final for the next launch.  Launch -1 only solves block 0.
+__global__ void __launch_bounds__(256)
+k_big_fw(const double *Fs, int m, int ld, int p, double *w) {
+  __shared__ double Sd[SNB * SNB];
+  __shared__ double xb[SNB];
+  const int tid = threadIdx.x;
+  const int r = p + 1 + blockIdx.x, r0 = r * SNB, nr = min(SNB, m - r0);
+  if (blockIdx.x == 0) stage_block(Sd, Fs + (int64_t)r0 * ld + r0, ld, nr);
+  if (p >= 0) {
+    const int k0 = p * SNB;
+    if (tid < SNB) xb[tid] = w[k0 + tid];
+    __syncthreads();
+    // 32 row pairs x 8 column groups of 8 columns (lanes of one group read 256 contiguous bytes of a column)
+    const int pr = tid & 31, g = tid >> 5;
+    const int npair = (nr + 1) >> 1;
+    double a0 = 0.0, a1 = 0.0;
+    if (pr < npair) {
+      const int rr = r0 + 2 * pr;
+      const bool two = rr + 1 < m;
+      const double *col = Fs + (int64_t)(k0 + 8 * g) * ld + rr;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        if (two) { const sdm_double2 v = *(const sdm_double2 *)(col + (int64_t)c * ld); a0 += v.x * xb[8 * g + c]; a1 += v.y * xb[8 * g + c]; }
+        else a0 += col[(int64_t)c * ld] * xb[8 * g + c];
+      }
+    }
+    __shared__ double part[8][SNB];
+    part[g][2 * pr] = a0; part[g][2 * pr + 1] = a1;
+    __syncthreads();
+    if (tid < nr) {
+      double a = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) a += part[q][tid];             // fixed order: deterministic
+      w[r0 + tid] -= a;
+    }
+  }
+  if (blockIdx.x != 0) return;
+  __syncthreads();
+  if (tid < 64) {
+    double wi = tid < nr ? w[r0 + tid] : 0.0;
+#pragma unroll
+    for (int h = 0; h < SNB; h += TCH) {
+      double lr[TCH];
+#pragma unroll
+      for (int k = 0; k < TCH; k++) lr[k] = Sd[(h + k) * SNB + tid];
+#pragma unroll
+      for (int k = 0; k < TCH; k++) SDM_PIN(lr[k]);
+#pragma unroll
+      for (int k = 0; k < TCH; k++) wi -= lr[k] * sdm_bcast_lane(wi, h + k);
+    }
+    if (tid < nr) w[r0 + tid] = wi;
+  }
+}
+// Backward launch p (p = nblk .. 1): workgroup i owns column block q = p-1-i.  It applies row block p,
+// y_q -= L(p,q)' x_p (x_p final), and workgroup 0 then solves the transposed diagonal block q = p-1.
+// Launch nblk only solves the last block.
+__global__ void __launch_bounds__(256)
+k_big_bw(const double *Fs, const double *Ds, int m, int ld, int p, int nblk, double *w) {
+  __shared__ double Sd[SNB * SNB];
+  __shared__ double xb[SNB];
+  __shared__ double dots[SNB];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int q = p - 1 - (int)blockIdx.x, q0 = q * SNB, nq = min(SNB, m - q0);
+  if (blockIdx.x == 0) stage_blockT(Sd, Ds + (int64_t)q * SNB * SNB, nq);
+  if (p < nblk) {
+    const int p0 = p * SNB, np_ = min(SNB, m - p0);
+    if (tid < SNB) xb[tid] = tid < np_ ? w[p0 + tid] : 0.0;
+    __syncthreads();
+    // 4 wavefronts x 16 columns; lanes = 32 row pairs x 2 columns
+    const int pr = lane & 31, cs = lane >> 5;
+    for (int c = wave * 16 + cs; c < wave * 16 + 16; c += 2) {
+      double a = 0.0;
+      if (c < nq && 2 * pr < np_) {
+        const double *col = Fs + (int64_t)(q0 + c) * ld + p0 + 2 * pr;
+        if (2 * pr + 1 < np_) { const sdm_double2 v = *(const sdm_double2 *)col; a = v.x * xb[2 * pr] + v.y * xb[2 * pr + 1]; }
+        else a = col[0] * xb[2 * pr];
+      }
+      a += __shfl_xor(a, 16); a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+      if (pr == 0 && c < nq) dots[c] = a;
+    }
+    __syncthreads();
+    if (tid < nq) w[q0 + tid] -= dots[tid];
+  }
+  if (blockIdx.x != 0) return;
+  __syncthreads();
+  if (tid < 64) {
+    double yi = tid < nq ? w[q0 + tid] : 0.0;
+#pragma unroll
+    for (int h = SNB - TCH; h >= 0; h -= TCH) {
+      double lr[TCH];
+#pragma unroll
+      for (int k = 0; k < TCH; k++) lr[k] = Sd[(h + k) * SNB + tid];
+#pragma unroll
+      for (int k = 0; k < TCH; k++) SDM_PIN(lr[k]);
+#pragma unroll
+      for (int k = TCH - 1; k >= 0; k--) yi -= lr[k] * sdm_bcast_lane(yi, h + k);
+    }
+    if (tid < nq) w[q0 + tid] = yi;
+  }
+}
+
 __global__ void k_gather_perm(double *dst, const double *src, const int *perm, int m, int forward) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < m) { if (forward) dst[k] = src[perm[k]]; else dst[perm[k]] = src[k]; }
@@ -989,6 +1095,22 @@ void solve_bw(sdm_plan *P) {
 bool solve_single(sdm_plan *P, const double *rhs, double *yout, int mode) {
   CholPlan &C = P->chol;
   if (C.nsuper != 1) return false;
+  if (C.m >= BIG_FRONT) {
+    // big front: one launch per 64-column panel and sweep (k_big_fw / k_big_bw), w = ywork in HBM
+    const int m = (int)C.m, ld = C.sn_ld[0], nblk = (m + SNB - 1) / SNB;
+    if (mode & 1) vec_gather(P, P->ywork.p, rhs, true);
+    else SDM_HIP_CHECK(hipMemcpyAsync(P->ywork.p, rhs, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, P->stream));
+    if (mode & 1)
+      for (int p = -1; p <= nblk - 2; p++)
+        SDM_KLAUNCH(P, k_big_fw, dim3(p < 0 ? 1 : nblk - p - 1), dim3(256), 0, C.fronts.p, m, ld, p, P->ywork.p);
+    if (mode & 2) vec_divd(P, P->ywork.p);
+    if (mode & 4)
+      for (int p = nblk; p >= 1; p--)
+        SDM_KLAUNCH(P, k_big_bw, dim3(p == nblk ? 1 : p), dim3(256), 0, C.fronts.p, C.frontsT.p, m, ld, p, nblk, P->ywork.p);
+    if (mode & 4) vec_gather(P, yout, P->ywork.p, false);
+    else SDM_HIP_CHECK(hipMemcpyAsync(yout, P->ywork.p, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, P->stream));
+    return true;
+  }
   size_t lds; int use; solve_cfg(C, lds, use);
 #ifndef SDM_EMU
   if (lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -15,6 +15,7 @@ constexpr int S1_WAVES = 8;   // wavefronts per task
 constexpr int S1_MAXT = ((S1_MAXN / 16) * (S1_MAXN / 16) + S1_WAVES - 1) / S1_WAVES;   // 16x16 tiles of Z per wavefront
 constexpr int ELL_WAVES = 8;  // wavefronts per workgroup of the ELL stage-2 kernel of ADA'
 constexpr int SOLVE_LDS_MAX = 12288;  // doubles of the front-local vector kept in LDS (96 KB)
+constexpr int BIG_FRONT = 1024;       // single fronts from this order on: one launch per panel and sweep instead of one workgroup
 constexpr int SOLVE_THREADS = 1024;   // workgroup of the per-front solve kernels (16 waves stream the panel)
 constexpr int PANEL_THREADS = 512;    // workgroup of the factor's panel kernel (8 wavefronts)
 constexpr int TRSM_ROWS = 128;        // rows below the diagonal block solved per workgroup (16 per wavefront on the matrix cores)
@@ -87,7 +88,7 @@ struct CholPlan {
 struct AdaPlan {
   sdm_int N = 0, m = 0, nnzA = 0, lpN = 0, lorN = 0, sdpN = 0, rsdpN = 0;
   sdm_int nlq = 0;       // number of LP + Lorentz rows (= first PSD row)
-  sdm_int lenud = 0, ntask = 0, zlen = 0, nnzQ = 0;
+  sdm_int lenud = 0, ntask = 0, zlen = 0, nnzQ = 0, nnz_lq = 0;
   int maxn = 0;
   bool thread_per_row = false;
   sdm_int col0 = 0, col1 = 0;            // column range of ADA' formed by this plan (sdm_plan_getada_cols)

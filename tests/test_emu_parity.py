@@ -177,3 +177,16 @@ def test_bad_inputs_raise_like_mexErrMsgTxt():
         mex.fwblkslv(L, np.ones(5))
     with pytest.raises(SdmError):
         mex.fwblkslv(L, sp.csc_matrix(np.ones((4, 1))))       # sparse b needs ysymb (fwblkslv.c:243-244)
+
+
+def test_big_single_front_solves(refmex):
+    """Single dense front above BIG_FRONT rows: the sweeps run as one launch per 64-column panel (k_big_fw / k_big_bw)."""
+    from sedumi_amd import mex, problem
+    m = 1100
+    rng = np.random.default_rng(7)
+    Lv = np.tril(rng.standard_normal((m, m)) * (0.3 / np.sqrt(m)), -1) + np.eye(m)
+    L = problem.dense_symbolic(m)
+    L["L"] = sp.csc_matrix(Lv)
+    rhs = rng.standard_normal((m, 1))
+    assert relerr(mex.fwblkslv(L, rhs), refmex.call("fwblkslv", 1, L, rhs)) < TOL
+    assert relerr(mex.bwblkslv(L, rhs), refmex.call("bwblkslv", 1, L, rhs)) < TOL

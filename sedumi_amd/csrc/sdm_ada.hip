@@ -24,6 +24,7 @@
 #include "sdm_plan.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace sdm {
 
@@ -124,6 +125,17 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
     c_taskptr[j + 1] = (int64_t)t_col.size();
   }
   s_nzptr.push_back(A.nnzA);   // sentinel (only used through per-task end pointers)
+  { // dispatch order of the stage-1 tasks: decreasing cost (nonzeros x order + slots x order^2), so that the few heavy
+    // constraints do not form the tail of the launch
+    std::vector<int> order(t_col.size());
+    std::vector<double> cost(t_col.size());
+    for (size_t t = 0; t < t_col.size(); t++) {
+      order[t] = (int)t;
+      const double nz = (double)((t + 1 < t_slotptr.size() ? s_nzptr[t_slotptr[t + 1]] : A.nnzA) - s_nzptr[t_slotptr[t]]);
+      cost[t] = nz * t_n[t] + (double)t_nslot[t] * t_n[t] * t_n[t];
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    A.t_order.upload(order); }
   A.ntask = (sdm_int)t_col.size(); A.zlen = zlen;
   A.h_taskptr = c_taskptr; A.col0 = 0; A.col1 = m;
   // per task: end of its last slot = start of next task's first nonzero; store explicit end pointers in s_nzptr
@@ -137,19 +149,17 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
   // ---- stage-2 fast path (dense-ish ADA patterns): the PSD nonzeros of At re-packed for one-row-per-lane sweeps.
   // Rows (constraints) are sorted by their number of PSD nonzeros and cut into groups of 64; a group stores its
   // nonzeros interleaved (entry t of all 64 rows contiguous) and padded to the longest row of the group, so that
-  // every load of the sweep is one coalesced 512-byte line and no cross-lane reduction is needed.
+  // every load of the sweep is one coalesced 512-byte line and no cross-lane reduction is needed.  All wavefronts of
+  // a workgroup share every group (interleaved slices of the entry range).
   {
     A.ell_ok = false;
-    int64_t zmax = 0;
-    for (sdm_int j = 0; j < m; j++) {
-      int64_t zl = 0;
-      for (int64_t t = c_taskptr[j]; t < c_taskptr[j + 1]; t++) zl += t_ulen[t];
-      zmax = std::max(zmax, zl);
-    }
+    // z_j is staged in LDS at FULL length (all blocks, zeros where constraint j has no nonzero): an entry of the ELL
+    // copy then carries its final position uoff[k] + upos and the sweep needs one LDS gather per entry and column
+    const int64_t zmax = uoff[sdpN];
     A.zmax = zmax;
     const double dens = m > 0 ? (double)ADAjc[m] / ((double)m * (double)m) : 0.0;
-    const size_t lds = (size_t)(zmax + 1) * sizeof(double) + (size_t)sdpN * sizeof(int);
-    if (sdpN > 0 && psdnnz > 0 && dens >= 0.2 && lds <= 120 * 1024) {
+    const size_t lds = (size_t)zmax * sizeof(double);
+    if (sdpN > 0 && psdnnz > 0 && dens >= 0.2 && lds <= 96 * 1024) {
       std::vector<int> order(m);
       for (sdm_int j = 0; j < m; j++) order[j] = (int)j;
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return Ajc[a + 1] - Ajc_psd[a] > Ajc[b + 1] - Ajc_psd[b]; });
@@ -162,28 +172,19 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
         glen[g] = len; goff[g + 1] = goff[g] + len;
       }
       std::vector<double> gval((size_t)goff[ng] * 64, 0.0);
-      std::vector<int> gbu((size_t)goff[ng] * 128, 0);          // (block, position in U_k) pairs
+      std::vector<int> gbu((size_t)goff[ng] * 64, 0);           // position in the full-length z vector (padding: 0 with value 0)
       for (int g = 0; g < ng; g++)
         for (int l = 0; l < 64; l++) {
           const int i = grow[g * 64 + l];
           if (i < 0) continue;
           for (sdm_int t = Ajc_psd[i]; t < Ajc[i + 1]; t++) {
             const size_t pos = (size_t)(goff[g] + (t - Ajc_psd[i])) * 64 + l;
-            gval[pos] = Apr[t]; gbu[2 * pos] = Ablk[t]; gbu[2 * pos + 1] = Aupos[t];
+            gval[pos] = Apr[t]; gbu[pos] = (int)(uoff[Ablk[t]] + Aupos[t]);
           }
         }
-      // longest-processing-time assignment of the groups to the ELL_WAVES wavefronts of a workgroup
-      { std::vector<int64_t> load(ELL_WAVES, 0);
-        std::vector<std::vector<int>> mine(ELL_WAVES);
-        for (int g = 0; g < ng; g++) {                         // groups are already in descending length order
-          int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-          mine[w].push_back(g); load[w] += glen[g] + 8;
-        }
-        std::vector<int> wptr(ELL_WAVES + 1, 0), wlist;
-        for (int w = 0; w < ELL_WAVES; w++) { wlist.insert(wlist.end(), mine[w].begin(), mine[w].end()); wptr[w + 1] = (int)wlist.size(); }
-        A.g_wptr.upload(wptr); A.g_wlist.upload(wlist); }
       A.ell_ng = ng;
       A.g_row.upload(grow); A.g_len.upload(glen); A.g_off.upload(goff); A.g_val.upload(gval); A.g_bu.upload(gbu);
+      A.d_uoff.upload(uoff);
       A.ell_ok = true;
     }
   }
@@ -359,14 +360,15 @@ k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0
 // fixed set of 16x16 tiles of Z in registers.  The targets are read off the finished Z in LDS:
 // z(r,c) = (Z[r][c] + Z[c][r]) / 2  -- the same two sums as spscale.c:283-304.
 __global__ void __launch_bounds__(64 * S1_WAVES)
-k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0) {
+k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0, const int *order) {
   SDM_DYN_SMEM(smem);
-  const int task = blockIdx.x + task0;
+  const int task = order ? order[blockIdx.x] : blockIdx.x + task0;      // heaviest tasks first (full-range launches)
   const int n = T.t_n[task], nslot = T.t_nslot[task], ulen = T.t_ulen[task];
   const int np = (n + 15) & ~15, nt = np >> 4, ntile = nt * nt;
   double *Yl = (double *)smem;                      // Yl[t*np + i], t < S1_KC
   double *Dl = Yl + S1_KC * np;                     // Dl[t*np + j] = D[col_t][j]
-  double *Zl = Dl + S1_KC * np;                     // Zl[i*np + j]
+  double *Zl = (double *)smem;                      // Zl[i*np + j]: written after the last GEMM chunk, aliases Yl/Dl
+                                                    // (LDS per task = max(2*16*np, np*np) doubles -> several tasks per CU)
   const int64_t slot0 = T.t_slotptr[task], tend = T.t_end[task];
   const double *D = udsqr + T.t_udoff[task];
   const int *U = T.u_pos + T.t_uoff[task];
@@ -377,17 +379,46 @@ k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0) {
   const int li = lane & 15, lk = lane >> 4;
   sdm_double4 acc[S1_MAXT];
   for (int x = 0; x < S1_MAXT; x++) for (int r = 0; r < 4; r++) acc[x][r] = 0.0;
+  __shared__ double nzx[S1_NZ];                     // the task's nonzeros: value ...
+  __shared__ int nzr[S1_NZ];                        // ... and row offset inside the block
+  __shared__ int sbeg[S1_MAXN + 1], scol[S1_MAXN];  // slot -> first nonzero (relative), column of X_jk
+  SDM_PHASE_BEGIN();
+  // ONE round trip brings the whole task (nonzeros + slot table) into LDS: every later load of D depends on LDS only
+  const int64_t nzb = T.s_nzptr[slot0];
+  const bool staged = tend - nzb <= S1_NZ && nslot <= S1_MAXN;
+  if (staged) {
+    for (int64_t u = nzb + tid; u < tend; u += bs) { nzx[u - nzb] = T.Apr[u]; nzr[u - nzb] = (int)(T.Air[u] - rowbase); }
+    for (int t = tid; t <= nslot; t += bs) sbeg[t] = (int)((t < nslot ? T.s_nzptr[slot0 + t] : tend) - nzb);
+    for (int t = tid; t < nslot; t += bs) scol[t] = T.s_col[slot0 + t];
+  }
+  __syncthreads();
+  SDM_PHASE(0);
   for (int c0 = 0; c0 < nslot; c0 += S1_KC) {
     const int cc = min(S1_KC, nslot - c0);
     for (int t = wave; t < S1_KC; t += nw) {
       if (t < cc) {
-        const int64_t sb = T.s_nzptr[slot0 + c0 + t];
-        const int64_t se = (c0 + t + 1 < nslot) ? T.s_nzptr[slot0 + c0 + t + 1] : tend;
-        const int col = T.s_col[slot0 + c0 + t];
+        int sb, se, col;
+        if (staged) { sb = sbeg[c0 + t]; se = sbeg[c0 + t + 1]; col = scol[c0 + t]; }
+        else {
+          sb = (int)(T.s_nzptr[slot0 + c0 + t] - nzb);
+          se = (int)(((c0 + t + 1 < nslot) ? T.s_nzptr[slot0 + c0 + t + 1] : tend) - nzb);
+          col = T.s_col[slot0 + c0 + t];
+        }
         for (int i = lane; i < np; i += 64) {
           double a = 0.0;
-          if (i < n)
-            for (int64_t u = sb; u < se; u++) a += T.Apr[u] * D[(int64_t)((int)(T.Air[u] - rowbase) - col * n) * n + i];
+          if (i < n) {
+            if (staged) {
+              int u = sb;
+              for (; u + 4 <= se; u += 4) {               // 4 independent column loads of D in flight
+                const double d0 = D[(int64_t)(nzr[u] - col * n) * n + i], d1 = D[(int64_t)(nzr[u + 1] - col * n) * n + i];
+                const double d2 = D[(int64_t)(nzr[u + 2] - col * n) * n + i], d3 = D[(int64_t)(nzr[u + 3] - col * n) * n + i];
+                a += nzx[u] * d0; a += nzx[u + 1] * d1; a += nzx[u + 2] * d2; a += nzx[u + 3] * d3;
+              }
+              for (; u < se; u++) a += nzx[u] * D[(int64_t)(nzr[u] - col * n) * n + i];
+            } else {
+              for (int64_t u = nzb + sb; u < nzb + se; u++) a += T.Apr[u] * D[(int64_t)((int)(T.Air[u] - rowbase) - col * n) * n + i];
+            }
+          }
           Yl[t * np + i] = a;
           Dl[t * np + i] = i < n ? D[(int64_t)col * n + i] : 0.0;
         }
@@ -395,7 +426,9 @@ k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0) {
         for (int i = lane; i < np; i += 64) { Yl[t * np + i] = 0.0; Dl[t * np + i] = 0.0; }
       }
     }
+    SDM_PHASE(1);
     __syncthreads();
+    SDM_PHASE(2);
     for (int x = 0; x < S1_MAXT; x++) {
       const int tile = wave + x * nw;
       if (tile < ntile) {                               // wave-uniform
@@ -408,7 +441,9 @@ k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0) {
         }
       }
     }
+    SDM_PHASE(3);
     __syncthreads();
+    SDM_PHASE(4);
   }
   for (int x = 0; x < S1_MAXT; x++) {
     const int tile = wave + x * nw;
@@ -418,11 +453,16 @@ k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0) {
     }
   }
   __syncthreads();
+  SDM_PHASE(5);
   for (int u = tid; u < ulen; u += bs) {
     const int q = U[u];
     const int c = q / n, r = q - c * n;
     z[u] = (Zl[r * np + c] + Zl[c * np + r]) / 2;
   }
+  SDM_PHASE(6);
+#if defined(SDM_PHASES) && !defined(SDM_EMU)
+  if (tid == 0) { atomicAdd(&sdm_phase_acc[30], 1ull); if (n > 40) atomicAdd(&sdm_phase_acc[31], 1ull); }
+#endif
 }
 
 // ---- stage 2: ADA(i,j) += a_i[psd]' z_j ; absd fused (getada3.c:333-351)
@@ -477,7 +517,7 @@ k_psd_stage2(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, 
 }
 
 // ---- stage 2, dense-ish patterns: one workgroup per JB consecutive ADA columns.  Their z_j (all blocks touched
-// by constraint j) are staged in LDS once; every wavefront then sweeps groups of 64 rows, ONE ROW PER LANE, over
+// by constraint j) are staged in LDS once; the wavefronts then sweep the groups of 64 rows, ONE ROW PER LANE, over
 // the interleaved (ELL) copy of the PSD nonzeros: coalesced loads (each feeding JB columns), LDS gathers, no
 // cross-lane reduction, one writer per entry.
 template <int JB>
@@ -485,17 +525,16 @@ __global__ void __launch_bounds__(64 * ELL_WAVES)
 k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, const int64_t *Ajc,
                  const int64_t *Ajc_psd, const double *Apr, const int *Ablk, const int *Aupos,
                  const int64_t *c_taskptr, const int *t_blk, const int *t_ulen, const int64_t *t_zoff, const double *zbuf,
-                 const int *g_row, const int *g_len, const int64_t *g_off, const double *g_val, const int *g_bu,
-                 const int *g_wptr, const int *g_wlist, const int *invperm, int nblk, int zmax, int m, int jbase, int jend) {
+                 const int64_t *uoff, const int *g_row, const int *g_len, const int64_t *g_off, const double *g_val,
+                 const int *g_pos, int ngroups, const int *invperm, int zmax, int m, int jbase, int jend) {
   SDM_DYN_SMEM(smem);
-  double *zl = (double *)smem;                      // JB x (z_j, then one zero word at [zmax])
-  int *base = (int *)(zl + (size_t)JB * (zmax + 1));  // JB x (block -> offset of z_jk in zl_q, or -1)
+  double *zl = (double *)smem;                      // JB x z_j at full length (all blocks; zero where j has no nonzero)
   __shared__ double absred[JB][ELL_WAVES];
+  __shared__ double part[JB][ELL_WAVES][64];
   const int j0 = jbase + blockIdx.x * JB;
   const int tid = threadIdx.x, bs = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
-  for (int k = tid; k < nblk * JB; k += bs) base[k] = -1;
-  if (tid < JB) zl[(size_t)tid * (zmax + 1) + zmax] = 0.0;
+  for (int k = tid; k < zmax * JB; k += bs) zl[k] = 0.0;
   __syncthreads();
   bool jhas[JB];
 #pragma unroll
@@ -505,12 +544,12 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
     if (j < jend) {
       const int64_t tb = c_taskptr[j], te = c_taskptr[j + 1];
       jhas[q] = te > tb;
-      if (jhas[q]) {
-        const int64_t z0 = t_zoff[tb];
-        for (int64_t t = tb + tid; t < te; t += bs) base[q * nblk + t_blk[t]] = (int)(t_zoff[t] - z0);
-        const int64_t zlen = t_zoff[te - 1] + t_ulen[te - 1] - z0;
-        double *zq = zl + (size_t)q * (zmax + 1);
-        for (int64_t u = tid; u < zlen; u += bs) zq[u] = zbuf[z0 + u];
+      double *zq = zl + (size_t)q * zmax;
+      for (int64_t t = tb; t < te; t++) {                        // the blocks touched by constraint j
+        const double *src = zbuf + t_zoff[t];
+        double *dst = zq + uoff[t_blk[t]];
+        const int ul = t_ulen[t];
+        for (int u = tid; u < ul; u += bs) dst[u] = src[u];
       }
     }
   }
@@ -521,8 +560,8 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
     double aabs = 0.0;
     const int j = j0 + q;
     if (jhas[q]) {
-      const double *zq = zl + (size_t)q * (zmax + 1);
-      for (int64_t t = Ajc_psd[j] + tid; t < Ajc[j + 1]; t += bs) aabs += fabs(Apr[t] * zq[base[q * nblk + Ablk[t]] + Aupos[t]]);
+      const double *zq = zl + (size_t)q * zmax;
+      for (int64_t t = Ajc_psd[j] + tid; t < Ajc[j + 1]; t += bs) aabs += fabs(Apr[t] * zq[uoff[Ablk[t]] + Aupos[t]]);
     }
     for (int off = 32; off > 0; off >>= 1) aabs += __shfl_down(aabs, off);
     if (lane == 0) absred[q][wave] = aabs;
@@ -533,62 +572,62 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
     double basev = 0.0;
     int64_t lo = ADAjc[j], hi = ADAjc[j + 1];
     const int64_t ce = hi;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ADAir[mid] < j) lo = mid + 1; else hi = mid; }
+    if (ce - lo == m) lo += j;                           // full column: no search
+    else while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ADAir[mid] < j) lo = mid + 1; else hi = mid; }
     if (lo < ce && ADAir[lo] == j) basev = ada[lo];
     double a = 0.0;
     for (int w = 0; w < nw; w++) a += absred[tid][w];
     absd[j] = jhas[tid] ? basev + a : 0.0;            // jhas[] is indexed by a per-lane value only in these JB lanes
   }
   __syncthreads();
-  for (int gi = g_wptr[wave]; gi < g_wptr[wave + 1]; gi++) {
-    const int g = g_wlist[gi];
+  // Every group of 64 rows is swept by ALL wavefronts: wave w takes the entries t = w, w+nw, ... of the 64 rows (one
+  // row per lane), so the longest row costs len/nw dependent memory round trips instead of len; the nw partial
+  // sums of a row meet in LDS and are added in wave order (deterministic).
+  for (int g = 0; g < ngroups; g++) {
     const int i = g_row[g * 64 + lane];
-    int64_t e[JB];
-#pragma unroll
-    for (int q = 0; q < JB; q++) {
-      e[q] = -1;
-      const int j = j0 + q;
-      if (i >= 0 && jhas[q] && !(invperm && invperm[i] > invperm[j])) {
-        int64_t lo = ADAjc[j], hi = ADAjc[j + 1];
-        const int64_t ce = hi;
-        if (ce - lo == m) e[q] = lo + i;                     // full column: no search
-        else {
-          while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ADAir[mid] < i) lo = mid + 1; else hi = mid; }
-          if (lo < ce && ADAir[lo] == i) e[q] = lo;
-        }
-      }
-    }
     const int len = g_len[g];
     const double *gv = g_val + g_off[g] * 64 + lane;
-    const int *gb = g_bu + g_off[g] * 128 + 2 * lane;
+    const int *gp = g_pos + g_off[g] * 64 + lane;
     double acc[JB];
 #pragma unroll
     for (int q = 0; q < JB; q++) acc[q] = 0.0;
-    int t = 0;
-    for (; t + 8 <= len; t += 8) {                    // 8 entries per lane in flight
-      double v[8]; int blk[8], u[8];
+    int t = wave;
+    for (; t + 7 * nw < len; t += 8 * nw) {             // 8 entries per lane in flight
+      double v[8]; int pos[8];
 #pragma unroll
-      for (int x = 0; x < 8; x++) { v[x] = gv[(int64_t)(t + x) * 64]; blk[x] = gb[(int64_t)(t + x) * 128]; u[x] = gb[(int64_t)(t + x) * 128 + 1]; }
+      for (int x = 0; x < 8; x++) { const int64_t tt = t + x * nw; v[x] = gv[tt * 64]; pos[x] = gp[tt * 64]; }
 #pragma unroll
       for (int x = 0; x < 8; x++)
 #pragma unroll
-        for (int q = 0; q < JB; q++) {
-          const int b = base[q * nblk + blk[x]];
-          acc[q] += v[x] * zl[(size_t)q * (zmax + 1) + (b >= 0 ? b + u[x] : zmax)];
-        }
+        for (int q = 0; q < JB; q++) acc[q] += v[x] * zl[(size_t)q * zmax + pos[x]];
     }
-    for (; t < len; t++) {
+    for (; t < len; t += nw) {
       const double v = gv[(int64_t)t * 64];
-      const int blk = gb[(int64_t)t * 128], u = gb[(int64_t)t * 128 + 1];
+      const int pos = gp[(int64_t)t * 64];
 #pragma unroll
-      for (int q = 0; q < JB; q++) {
-        const int b = base[q * nblk + blk];
-        acc[q] += v * zl[(size_t)q * (zmax + 1) + (b >= 0 ? b + u : zmax)];
+      for (int q = 0; q < JB; q++) acc[q] += v * zl[(size_t)q * zmax + pos];
+    }
+#pragma unroll
+    for (int q = 0; q < JB; q++) part[q][wave][lane] = acc[q];
+    __syncthreads();
+    if (wave < JB && i >= 0) {                            // wave q finishes column j0+q of this group
+      const int q = wave, j = j0 + q;
+      if (jhas[q] && !(invperm && invperm[i] > invperm[j])) {
+        int64_t lo = ADAjc[j], hi = ADAjc[j + 1], e = -1;
+        const int64_t ce = hi;
+        if (ce - lo == m) e = lo + i;                     // full column: no search
+        else {
+          while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ADAir[mid] < i) lo = mid + 1; else hi = mid; }
+          if (lo < ce && ADAir[lo] == i) e = lo;
+        }
+        if (e >= 0) {
+          double a = 0.0;
+          for (int w2 = 0; w2 < nw; w2++) a += part[q][w2][lane];
+          ada[e] += a;
+        }
       }
     }
-#pragma unroll
-    for (int q = 0; q < JB; q++)
-      if (e[q] >= 0) ada[e[q]] += acc[q];
+    __syncthreads();
   }
 }
 
@@ -662,11 +701,12 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
 #endif
     if (A.maxn <= S1_MAXN && A.sdpN == A.rsdpN) {
       const int np = (A.maxn + 15) & ~15;
-      const size_t lds = (size_t)(2 * S1_KC * np + np * np) * sizeof(double);
+      const size_t lds = (size_t)std::max(2 * S1_KC * np, np * np) * sizeof(double);
 #ifndef SDM_EMU
       if (lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage1_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
-      SDM_KLAUNCH(P, k_psd_stage1_mfma, dim3((unsigned)ntask), dim3(64 * S1_WAVES), lds, T, A.udsqr.p, A.zbuf.p, task0);
+      SDM_KLAUNCH(P, k_psd_stage1_mfma, dim3((unsigned)ntask), dim3(64 * S1_WAVES), lds, T, A.udsqr.p, A.zbuf.p, task0,
+                  (ntask == (int)A.ntask) ? (const int *)A.t_order.p : (const int *)nullptr);
     } else
     SDM_KLAUNCH(P, k_psd_stage1, dim3((unsigned)ntask), dim3(256), A.stage1_lds, T, A.udsqr.p, A.zbuf.p,
                (int)(A.stage1_lds / sizeof(double)), task0);
@@ -678,15 +718,15 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
     SDM_HIP_CHECK(hipMemcpyAsync(ada, A.symtmp.p, A.symtmp.n * sizeof(double), hipMemcpyDeviceToDevice, st));
   }
   if (A.ell_ok) {
-    auto lds_of = [&](int jb) { return (size_t)jb * ((size_t)(A.zmax + 1) * sizeof(double) + (size_t)A.sdpN * sizeof(int)); };
+    auto lds_of = [&](int jb) { return (size_t)jb * (size_t)A.zmax * sizeof(double); };
 #define SDM_STAGE2_ELL(JB)                                                                                              \
     do {                                                                                                                 \
       const size_t lds = lds_of(JB);                                                                                    \
       SDM_STAGE2_ATTR(JB, lds);                                                                                         \
       SDM_KLAUNCH(P, k_psd_stage2_ell<JB>, dim3((ncols + JB - 1) / JB), dim3(64 * ELL_WAVES), lds, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, \
                   A.d_Ajc.p, A.d_Ajc_psd.p, A.d_Apr.p, A.d_Ablk.p, A.d_Aupos.p, A.c_taskptr.p, A.t_blk.p, A.t_ulen.p,    \
-                  A.t_zoff.p, A.zbuf.p, A.g_row.p, A.g_len.p, A.g_off.p, A.g_val.p, A.g_bu.p, A.g_wptr.p, A.g_wlist.p, d_invperm,       \
-                  (int)A.sdpN, (int)A.zmax, m, jbase, jbase + ncols);                                                    \
+                  A.t_zoff.p, A.zbuf.p, A.d_uoff.p, A.g_row.p, A.g_len.p, A.g_off.p, A.g_val.p, A.g_bu.p, A.ell_ng, d_invperm, \
+                  (int)A.zmax, m, jbase, jbase + ncols);                                                                 \
     } while (0)
 #ifndef SDM_EMU
 #define SDM_STAGE2_ATTR(JB, lds) if ((lds) > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage2_ell<JB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)))
@@ -694,8 +734,10 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
 #define SDM_STAGE2_ATTR(JB, lds) (void)(lds)
 #endif
     // as many columns per workgroup as fit 96 KB of LDS (each coalesced load of the ELL copy then feeds JB columns)
-    if (lds_of(4) <= 96 * 1024 && m >= 2048) SDM_STAGE2_ELL(4);
-    else if (lds_of(2) <= 96 * 1024 && m >= 1024) SDM_STAGE2_ELL(2);
+    const char *jbenv = getenv("SDM_STAGE2_JB");                       // tuning override (tools only)
+    const int jbforce = jbenv ? atoi(jbenv) : 0;
+    if (jbforce == 4 || (!jbforce && lds_of(4) <= 64 * 1024 && m >= 1024)) SDM_STAGE2_ELL(4);
+    else if (jbforce == 2 || (!jbforce && lds_of(2) <= 64 * 1024 && m >= 512)) SDM_STAGE2_ELL(2);
     else SDM_STAGE2_ELL(1);
 #undef SDM_STAGE2_ELL
 #undef SDM_STAGE2_ATTR
@@ -709,3 +751,12 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
 }
 
 }  // namespace sdm
+
+#if defined(SDM_PHASES) && !defined(SDM_EMU)
+// tools-only build (python -m sedumi_amd.build --phases): read / reset the in-kernel phase clocks of this file
+extern "C" int sdm_debug_phases_ada(unsigned long long *out32, int reset) {
+  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(sdm_phase_acc), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sdm_phase_acc), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif

@@ -10,8 +10,9 @@ constexpr int NB = 64;     // factor panel width (columns)
 constexpr int TILE = 64;   // trailing-update tile (MFMA 4 waves x 32x32)
 constexpr int SNB = 64;    // solve panel width: one wavefront does the in-block TRSV, one lane per row
 constexpr int S1_MAXN = 96;   // PSD blocks up to this order take the matrix-core stage 1 of ADA'
-constexpr int S1_KC = 16;     // slots (nonzero columns of A_jk) per GEMM chunk
+constexpr int S1_KC = 48;     // slots (nonzero columns of A_jk) per GEMM chunk
 constexpr int S1_WAVES = 8;   // wavefronts per task
+constexpr int S1_NZ = 1536;   // nonzeros of a chunk of slots staged in LDS (bigger chunks read At directly)
 constexpr int S1_MAXT = ((S1_MAXN / 16) * (S1_MAXN / 16) + S1_WAVES - 1) / S1_WAVES;   // 16x16 tiles of Z per wavefront
 constexpr int ELL_WAVES = 8;  // wavefronts per workgroup of the ELL stage-2 kernel of ADA'
 constexpr int SOLVE_LDS_MAX = 12288;  // doubles of the front-local vector kept in LDS (96 KB)
@@ -100,7 +101,7 @@ struct AdaPlan {
   DevBuf<double> d_Apr;
   DevBuf<int> d_Ablk, d_Aupos;            // per PSD nonzero of At: block id, position in U_k
   // stage-1 tasks (constraint j, PSD block k)
-  DevBuf<int> t_col, t_blk, t_n, t_nslot, t_ulen, t_herm;
+  DevBuf<int> t_col, t_blk, t_n, t_nslot, t_ulen, t_herm, t_order;
   DevBuf<int64_t> t_slotptr, t_udoff, t_uoff, t_zoff;
   DevBuf<int> s_col;                      // per slot: column of X_jk
   DevBuf<int64_t> s_nzptr;                // per slot (+1): nonzero range in At
@@ -115,8 +116,8 @@ struct AdaPlan {
   bool ell_ok = false;
   int ell_ng = 0;
   int64_t zmax = 0;
-  DevBuf<int> g_row, g_len, g_bu, g_wptr, g_wlist;
-  DevBuf<int64_t> g_off;
+  DevBuf<int> g_row, g_len, g_bu;
+  DevBuf<int64_t> g_off, d_uoff;
   DevBuf<double> g_val;
 };
 

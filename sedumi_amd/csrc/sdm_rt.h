@@ -49,9 +49,9 @@ __device__ __forceinline__ double sdm_bcast_lane(double v, int lane) {
 // Optional in-kernel phase clocks (tools/ubench builds only, -DSDM_PHASES): work-item 0 accumulates wall_clock64
 // ticks (100 MHz) between marks into sdm_phase_acc[].  Compiled out of the product library.
 #if defined(SDM_PHASES) && !defined(SDM_EMU)
-__device__ long long sdm_phase_acc[32];
+static __device__ unsigned long long sdm_phase_acc[32];
 #define SDM_PHASE_BEGIN() long long ph_t_ = wall_clock64()
-#define SDM_PHASE(n) do { const long long t_ = wall_clock64(); if (threadIdx.x == 0) sdm_phase_acc[n] += t_ - ph_t_; ph_t_ = t_; } while (0)
+#define SDM_PHASE(n) do { const long long t_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&sdm_phase_acc[n], (unsigned long long)(t_ - ph_t_)); ph_t_ = t_; } while (0)
 #else
 #define SDM_PHASE_BEGIN() do {} while (0)
 #define SDM_PHASE(n) do {} while (0)

@@ -1,0 +1,31 @@
+"""In-kernel phase clocks of the ADA' kernels on the bench workload (needs `python -m sedumi_amd.build --phases`).
+Work-item 0 of every workgroup adds wall_clock64 ticks (100 MHz) between marks; sums over workgroups are printed."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sedumi_amd import capi, problem  # noqa: E402
+from sedumi_amd.plan import Plan  # noqa: E402
+
+capi.use_library(os.path.join(ROOT, "sedumi_amd", "lib", "libsedumi_hip_phases.so"))
+lib = capi.lib()
+P = problem.control_like(seed=0)
+L, ADA, Q = problem.dense_symbolic(P.m), problem.dense_pattern(P.m), problem.lorentz_pattern(P)
+d, ud = problem.spd_scaling(P.K, seed=5)
+plan = Plan(0)
+plan.set_chol(L, ADA); plan.set_ada(P.At, P.Ablkjc, P.K, Q)
+plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud)
+for _ in range(3):
+    plan.getada()
+plan.sync()
+buf = (C.c_longlong * 32)()
+lib.sdm_debug_phases_ada(buf, 1)
+plan.getada(); plan.sync()
+lib.sdm_debug_phases_ada(buf, 0)
+v = np.array(list(buf), dtype=np.float64) / 100.0
+print("stage1 (us summed over %d tasks, %d with n>40): stage nz %.0f | Y %.0f | bar %.0f | mfma %.0f | bar %.0f | Z write+bar %.0f | targets %.0f"
+      % (buf[30], buf[31], v[0], v[1], v[2], v[3], v[4], v[5], v[6]))

@@ -24,7 +24,7 @@ int main(int argc, char **argv) {
   const size_t lds = (size_t)m * 8;
   SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   for (int mode : {1, 4, 7}) {
-    float ms = 0; long long z[32] = {0};
+    float ms = 0; unsigned long long z[32] = {0};
     for (int rep = 0; rep < 3; rep++) {
       SDM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(sdm_phase_acc), z, sizeof(z)));
       SDM_HIP_CHECK(hipEventRecord(a, st));

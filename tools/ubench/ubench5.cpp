@@ -17,14 +17,14 @@ int main(int argc, char **argv) {
   chol_build(&P, m, Ljc.data(), Lir.data(), perm.data(), 1, xs.data(), Ajc.data(), Air.data());
   SDM_HIP_CHECK(hipMemcpy(P.ada_val.p, A.data(), A.size() * 8, hipMemcpyHostToDevice));
   hipEvent_t a, b; SDM_HIP_CHECK(hipEventCreate(&a)); SDM_HIP_CHECK(hipEventCreate(&b));
-  float ms = 0; long long z[32] = {0};
+  float ms = 0; unsigned long long z[32] = {0};
   for (int rep = 0; rep < 3; rep++) {
     SDM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(sdm_phase_acc), z, sizeof(z)));
     SDM_HIP_CHECK(hipEventRecord(a, P.stream));
     chol_factor(&P, 1e-12, 5e5, 1e-20, 0);
     SDM_HIP_CHECK(hipEventRecord(b, P.stream)); SDM_HIP_CHECK(hipEventSynchronize(b)); SDM_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
   }
-  long long y[32]; SDM_HIP_CHECK(hipMemcpyFromSymbol(y, HIP_SYMBOL(sdm_phase_acc), sizeof(y)));
+  unsigned long long y[32]; SDM_HIP_CHECK(hipMemcpyFromSymbol(y, HIP_SYMBOL(sdm_phase_acc), sizeof(y)));
   const int np = (m + 63) / 64;
   printf("m=%d factor %.1f us (%d panels) | panel kernel, work-item 0 of every WG summed over WGs: load+bar %.1f sweep %.1f lc+trail %.1f bar %.1f | copy %.1f bar %.1f writeback %.1f rows %.1f\n",
          m, ms * 1e3, np, y[16] / 100., y[17] / 100., y[18] / 100., y[19] / 100., y[20] / 100., y[21] / 100., y[22] / 100., y[23] / 100.);

@@ -324,6 +324,7 @@ __device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int 
     for (int c4 = 0; c4 < NB / 4; c4++) { const int c = 4 * c4 + lk; Tw[c * 17 + li] = c < kb ? tv[c4] : 0.0; }
   }
   SDM_WAVE_SYNC();
+  SDM_PHASE_BEGIN();
   for (int b = 0; b < NB / 16; b++) {
     const int cb = 16 * b;
     if (cb >= kb) break;
@@ -346,21 +347,27 @@ __device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int 
     double x[16];
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = Tw[(cb + c) * 17 + li];
+    double lcol[16], dsv[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) { lcol[c] = c > 0 ? S[cb + c][cb] : 0.0; dsv[c] = ds[cb + c]; }
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-      if (ds[cb + j] <= 0.0) x[j] = 0.0;                                  // skipped pivot: column not used (blkchol2.c:157-161)
-      double lcol[16];
+      double lnext[16];                                                   // column j+1 is fetched while column j is applied
 #pragma unroll
-      for (int c = 0; c < 16; c++) lcol[c] = c > j ? S[cb + c][cb + j] : 0.0;
+      for (int c = 0; c < 16; c++) lnext[c] = (j + 1 < 16 && c > j + 1) ? S[cb + c][cb + j + 1] : 0.0;
+      if (dsv[j] <= 0.0) x[j] = 0.0;                                      // skipped pivot: column not used (blkchol2.c:157-161)
 #pragma unroll
       for (int c = 0; c < 16; c++)
         if (c > j) x[c] -= x[j] * lcol[c];
+#pragma unroll
+      for (int c = 0; c < 16; c++) lcol[c] = lnext[c];
     }
     SDM_WAVE_SYNC();
 #pragma unroll
     for (int c = 0; c < 16; c++) Tw[(cb + c) * 17 + li] = x[c];
     SDM_WAVE_SYNC();
   }
+  SDM_PHASE(26);
   for (int c4 = 0; c4 < NB / 4; c4++) {
     const int c = 4 * c4 + lk, row = R0 + li;
     if (c < kb && row < ms) {
@@ -579,8 +586,11 @@ k_ldl_rows(double *F, const double *DT, FrontTab tab, const int *list, int panel
   if (batch == 0)
     for (int i = ty; i < kb; i += ny)
       if (tx <= i) Fs[(int64_t)(k0 + tx) * ld + k0 + i] = Ds[i * NB + tx];
+  SDM_PHASE_BEGIN();
   __syncthreads();
+  SDM_PHASE(24);
   panel_rows(Fs, ld, ns, ms, k0, kb, batch, S, ds, RB);
+  SDM_PHASE(27);
 }
 
 // ---- K3: trailing update C -= L21 * D * L21' on the FP64 matrix cores.
@@ -606,6 +616,7 @@ k_ldl_update(double *F, FrontTab tab, const int *list, int panel, const double *
   double *Fs = F + tab.foff[s];
   const int tid = threadIdx.x;
   __shared__ double dsh[NB];
+  SDM_PHASE_BEGIN();
   if (tid < NB) dsh[tid] = tid < kb ? d[first + k0 + tid] : 0.0;
   {
     // all 32 loads of a work-item are issued before the first use (addresses clamped, masked afterwards): one
@@ -628,19 +639,36 @@ k_ldl_update(double *F, FrontTab tab, const int *list, int panel, const double *
     }
   }
   __syncthreads();
+  SDM_PHASE(28);
   const int w = tid >> 6, l = tid & 63;
   const int wi = w >> 1, wj = w & 1;
   sdm_double4 acc[2][2];
   for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) for (int r = 0; r < 4; r++) acc[a][b][r] = 0.0;
   const int lk = l >> 4, ll = l & 15;
+  // operands of step kk+4 are fetched from LDS while the 4 MFMAs of step kk issue (As/Bs rows beyond kb are zero)
+  double bv[2], av[2];
+#pragma unroll
+  for (int b = 0; b < 2; b++) bv[b] = Bs[lk][wj * 32 + b * 16 + ll];
+#pragma unroll
+  for (int a = 0; a < 2; a++) av[a] = As[lk][wi * 32 + a * 16 + ll];
+#pragma unroll
   for (int kk = 0; kk < NB; kk += 4) {
-    if (kk >= kb) break;
-    double bv[2], av[2];
-    for (int b = 0; b < 2; b++) bv[b] = Bs[kk + lk][wj * 32 + b * 16 + ll];
-    for (int a = 0; a < 2; a++) av[a] = As[kk + lk][wi * 32 + a * 16 + ll];
+    double bn[2], an[2];
+    const int kn = min(kk + 4, NB - 4);
+#pragma unroll
+    for (int b = 0; b < 2; b++) bn[b] = Bs[kn + lk][wj * 32 + b * 16 + ll];
+#pragma unroll
+    for (int a = 0; a < 2; a++) an[a] = As[kn + lk][wi * 32 + a * 16 + ll];
+#pragma unroll
     for (int a = 0; a < 2; a++)
+#pragma unroll
       for (int b = 0; b < 2; b++) acc[a][b] = SDM_MFMA_F64_16x16x4(bv[b], av[a], acc[a][b]);
+#pragma unroll
+    for (int b = 0; b < 2; b++) bv[b] = bn[b];
+#pragma unroll
+    for (int a = 0; a < 2; a++) av[a] = an[a];
   }
+  SDM_PHASE(29);
   // read-modify-write of the tile: the 16 loads first, then the 16 stores
   double cv[2][2][4];
 #pragma unroll
@@ -665,6 +693,7 @@ k_ldl_update(double *F, FrontTab tab, const int *list, int panel, const double *
         const int gj = r0 + J * TILE + wj * 32 + b * 16 + jj;
         if (gi < ms && gj < ms && gi >= gj) Fs[(int64_t)gj * ld + gi] = cv[a][b][r] - acc[a][b][r];
       }
+  SDM_PHASE(30);
 }
 
 // ================================================================== solves
@@ -1212,3 +1241,12 @@ void vec_divd(sdm_plan *P, double *v) {
 }
 
 }  // namespace sdm
+
+#if defined(SDM_PHASES) && !defined(SDM_EMU)
+// tools-only build (python -m sedumi_amd.build --phases): read / reset the in-kernel phase clocks of this file
+extern "C" int sdm_debug_phases_chol(unsigned long long *out32, int reset) {
+  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(sdm_phase_acc), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sdm_phase_acc), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif

@@ -29,3 +29,13 @@ lib.sdm_debug_phases_ada(buf, 0)
 v = np.array(list(buf), dtype=np.float64) / 100.0
 print("stage1 (us summed over %d tasks, %d with n>40): stage nz %.0f | Y %.0f | bar %.0f | mfma %.0f | bar %.0f | Z write+bar %.0f | targets %.0f"
       % (buf[30], buf[31], v[0], v[1], v[2], v[3], v[4], v[5], v[6]))
+
+plan.blkchol(None, True); plan.sync()
+lib.sdm_debug_phases_chol(buf, 1)
+plan.blkchol(None, True); plan.sync()
+lib.sdm_debug_phases_chol(buf, 0)
+v = np.array(list(buf), dtype=np.float64) / 100.0
+print("factor, work-item 0 of every workgroup, us summed: panel: load %.0f sweep %.0f trail %.0f bar %.0f copy %.0f bar %.0f wb %.0f rows %.0f"
+      % tuple(v[16:24]))
+print("  rows kernel: S load+bar %.0f | (per wave-0) blocked substitution %.0f | total rows fn %.0f   update kernel: loads+fill %.0f mfma %.0f rmw %.0f"
+      % (v[24], v[26], v[27], v[28], v[29], v[30]))

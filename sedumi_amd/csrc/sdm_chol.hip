@@ -459,14 +459,14 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   // after it is discarded: the block is redone by the general path), the bookkeeping of pivot gc lives in lane gc.
   bool bad = false;
   const double mylb = lbs[tx];
-  for (int c0 = 0; c0 < kb; c0 += 16) {
-    double x[16], lsc[16];
+  for (int c0 = 0; c0 < kb; c0 += SW) {
+    double x[SW], lsc[SW];
 #pragma unroll
-    for (int cc = 0; cc < 16; cc++) x[cc] = S[tx][c0 + cc];
+    for (int cc = 0; cc < SW; cc++) x[cc] = S[tx][c0 + cc];
     double dval = 0.0, pval = 0.0;
     int stat = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < SW; k++) {
       const int gc = c0 + k;
       const double xkk = sdm_bcast_lane(x[k], gc);
       const double lbk = sdm_bcast_lane(mylb, gc);
@@ -475,21 +475,21 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
       bad = bad || (accept && ms - (k0 + gc) > 1 && xkk < ub);       // needs the column probe: general path below
       const double l = accept ? x[k] / xkk : 0.0;                    // rows above the pivot hold 0; skipped pivot: unit column
 #pragma unroll
-      for (int j = k + 1; j < 16; j++) x[j] -= sdm_bcast_lane(l, c0 + j) * x[k];
+      for (int j = k + 1; j < SW; j++) x[j] -= sdm_bcast_lane(l, c0 + j) * x[k];
       lsc[k] = l;
       if (tx == gc) { dval = accept ? xkk : 0.0; stat = (live && !accept) ? 1 : 0; pval = xkk; }
     }
-    if (ty == 0 && tx >= c0 && tx < c0 + 16 && tx < kb) { ds[tx] = dval; stt[tx] = stat; pv[tx] = stat ? pval : 0.0; }
+    if (ty == 0 && tx >= c0 && tx < c0 + SW && tx < kb) { ds[tx] = dval; stt[tx] = stat; pv[tx] = stat ? pval : 0.0; }
     SDM_PHASE(17);
 #pragma unroll
-    for (int k = 0; k < 16; k++) Lc[(c0 + k) * NB + tx] = (tx > c0 + k) ? lsc[k] : 0.0;   // every wave writes the same values
+    for (int k = 0; k < SW; k++) Lc[(c0 + k) * NB + tx] = (tx > c0 + k) ? lsc[k] : 0.0;   // every wave writes the same values
     SDM_WAVE_SYNC();
-    for (int j0 = c0 + 16 + 4 * ty; j0 < kb; j0 += 4 * ny) {             // 4 columns per wavefront at a time: independent chains
+    for (int j0 = c0 + SW + 4 * ty; j0 < kb; j0 += 4 * ny) {             // 4 columns per wavefront at a time: independent chains
       double v[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) v[u] = S[tx][min(j0 + u, NB - 1)];
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
+      for (int k = 0; k < SW; k++) {
         double lj[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) lj[u] = Lc[(c0 + k) * NB + min(j0 + u, NB - 1)];

@@ -18,7 +18,8 @@ constexpr int ELL_WAVES = 8;  // wavefronts per workgroup of the ELL stage-2 ker
 constexpr int SOLVE_LDS_MAX = 12288;  // doubles of the front-local vector kept in LDS (96 KB)
 constexpr int BIG_FRONT = 1024;       // single fronts from this order on: one launch per panel and sweep instead of one workgroup
 constexpr int SOLVE_THREADS = 1024;   // workgroup of the per-front solve kernels (16 waves stream the panel)
-constexpr int LDL_THREADS = 256;      // workgroup of the diagonal-block kernel: 4 wavefronts, one per SIMD (every wave runs the same register sweep)
+constexpr int SW = 8;                 // columns of the diagonal block swept in registers at a time (readlane chain), rest via LDS
+constexpr int LDL_THREADS = 512;      // workgroup of the diagonal-block kernel: 4 wavefronts, one per SIMD (every wave runs the same register sweep)
 constexpr int PANEL_THREADS = 512;    // workgroup of the row-solve kernel (8 wavefronts)
 constexpr int TRSM_ROWS = 128;        // rows below the diagonal block solved per workgroup (16 per wavefront on the matrix cores)
 constexpr int MFMA_MIN_ROWS = 256;    // fronts with fewer rows below their first panel use the bit-faithful row substitution

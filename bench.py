@@ -81,7 +81,7 @@ def cpu_baseline(P, d, ud, rhs, budget_s=12.0):
         return {"value": None, "unit": "IPM iters/s", "cores": 1, "kind": "reference", "sample": f"failed: {e}"}
 
 
-def bench_subtrees(args, rank, local_rank, world, torch, dist):
+def bench_subtrees(args, rank, local_rank, world, torch, dist, coll_dev):
     """BASELINE.json configs[4]: block-diagonal SDP (default 64 PSD blocks of order 200, 150 constraints each).  The
     64 independent elimination-tree subtrees are dealt to the ranks (sedumi_amd.dist.SubtreeShardedSolver): ADA',
     factor and solves of a subtree never leave its rank; the only exchange is the all-gather of the solution
@@ -96,7 +96,7 @@ def bench_subtrees(args, rank, local_rank, world, torch, dist):
     P = problem.blockdiag_sdp(nblk=nblk, n=n, mper=mper, nnz=20, seed=4)
     d, ud = problem.spd_scaling(P.K, seed=5)
     rhs = np.random.default_rng(0).standard_normal(P.m)
-    dev = torch.device("cuda", local_rank) if dist is not None else torch.device("cpu")
+    dev = coll_dev if dist is not None else torch.device("cpu")
     solver = sd.SubtreeShardedSolver(P, device_index=local_rank, device=dev, pars=PARS)
     solver.upload_scaling(d, ud, P)
 
@@ -123,7 +123,7 @@ def bench_subtrees(args, rank, local_rank, world, torch, dist):
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
@@ -158,18 +158,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    # BENCH_SHARE_GPU=1 (smoke tests on a 1-GPU box only): all ranks use device 0 and the process group runs on gloo
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
+    dist = None
     torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    coll_dev = torch.device("cpu") if share else torch.device("cuda", local_rank)
 
     from sedumi_amd.plan import Plan
     if args.workload.startswith("blockdiag"):
-        return bench_subtrees(args, rank, local_rank, world, torch, dist)
+        return bench_subtrees(args, rank, local_rank, world, torch, dist, coll_dev)
     shard_cols = args.shard == "columns" and world > 1
     P, L, ADA, Q, d, ud, rhs = build_workload(args.workload, seed=0 if shard_cols else rank)
     plan = Plan(local_rank)
@@ -180,7 +187,7 @@ def main():
     cs = None
     if shard_cols:
         from sedumi_amd import dist as sd
-        cs = sd.ColumnShardedAda(plan, device=torch.device("cuda", local_rank))
+        cs = sd.ColumnShardedAda(plan, device=coll_dev)
 
     def step():
         if cs is not None:
@@ -208,7 +215,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

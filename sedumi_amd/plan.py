@@ -114,6 +114,17 @@ class Plan:
         tensor living on the plan's device (RCCL send / receive buffers of sedumi_amd.dist)."""
         if tensor.dtype.itemsize != 8 or not tensor.is_contiguous() or tensor.numel() < nelem:
             raise SdmError("copy: need a contiguous float64 tensor with at least nelem elements")
+        if not tensor.is_cuda and capi.backend() != "emu":
+            # host tensor next to a real GPU plan (gloo smoke runs): staged through the host copies of the buffer
+            import torch
+            n = {"ada": self.nnzADA, "lpr": self.nnzL}.get(name, self.m)
+            full = self.download(name, n)
+            if to_plan:
+                full[offset:offset + nelem] = tensor[:nelem].numpy()
+                self.upload(name, full)
+            else:
+                tensor[:nelem] = torch.from_numpy(full[offset:offset + nelem].copy())
+            return
         check(self._lib.sdm_plan_copy(C.c_void_p(self._p), name.encode(), C.c_void_p(tensor.data_ptr()), C.c_int64(int(offset)),
                                       C.c_int64(int(nelem)), 1 if to_plan else 0))
 

@@ -152,6 +152,7 @@ def main():
                     help="N>1: replicas = independent units per rank (default for single-supernode workloads); "
                          "columns = ONE unit per step, ADA' column panels per rank + RCCL all-gather, factor/solves replicated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (one launch per step)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -198,6 +199,16 @@ def main():
         for _ in range(NSOLVE):
             plan.ldlsolve()
 
+    if args.graph and cs is None:
+        eager_step = step
+        for _ in range(2):
+            eager_step()                       # first-use work (function attributes, allocations) outside the capture
+        plan.sync()
+        gid = plan.graph_capture(eager_step)
+
+        def step():                            # noqa: F811
+            plan.graph_launch(gid)
+
     def barrier():
         plan.sync()
         torch.cuda.synchronize()
@@ -222,8 +233,9 @@ def main():
     # ---- roofline leg: the dominant kernel's launches timed with HIP events on the plan's stream
     # (same steps, events around every launch; the un-instrumented loop above gives `value`).
     plan.kprof(True)
+    prof_step = eager_step if (args.graph and cs is None) else step
     for _ in range(min(args.steps, 50)):
-        step()
+        prof_step()
     prof = plan.kprof_summary()
     plan.kprof(False)
     nprof = min(args.steps, 50)

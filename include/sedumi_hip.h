@@ -248,6 +248,14 @@ int sdm_plan_fwsolve(sdm_plan *p);
 int sdm_plan_bwsolve(sdm_plan *p);
 int sdm_plan_ldlsolve(sdm_plan *p);
 
+/* hipGraph capture of a sequence of asynchronous plan calls (getada, blkchol, fw/bw/ldlsolve -- no uploads, downloads,
+ * pivots or timers inside): begin, issue the calls once (they are recorded, not executed), end -> graph id;
+ * sdm_plan_graph_launch replays the whole sequence with one launch on the plan's stream.  The captured sequence keeps
+ * the parameters (pivot tolerances, buffers) it was recorded with. */
+int sdm_plan_graph_begin(sdm_plan *p);
+int sdm_plan_graph_end(sdm_plan *p, int *graph_id);
+int sdm_plan_graph_launch(sdm_plan *p, int graph_id);
+
 /* Timing of named kernels with HIP events on the plan's stream (bench.py):
  * begin/end bracket a region; *_ms returns the elapsed milliseconds. */
 int sdm_plan_timer_begin(sdm_plan *p, int slot);

@@ -54,6 +54,7 @@ void sdm_plan_destroy(sdm_plan *p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
   (void)hipStreamSynchronize(p->stream);
+  for (auto g : p->graphs) (void)hipGraphExecDestroy(g);
   for (int i = 0; i < 16; i++) { if (p->ev_begin[i]) (void)hipEventDestroy(p->ev_begin[i]); if (p->ev_end[i]) (void)hipEventDestroy(p->ev_end[i]); }
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
@@ -213,6 +214,38 @@ int sdm_plan_ldlsolve(sdm_plan *p) {
   vec_gather(p, p->y.p, p->ywork.p, false);
   SDM_CATCH
 }
+// ---- hipGraph capture of a launch-bound sequence of plan calls (e.g. one whole iteration unit): everything the plan
+// enqueues on its stream between begin and end becomes one executable graph; replay costs one launch.
+int sdm_plan_graph_begin(sdm_plan *p) {
+  SDM_TRY
+  if (p->capturing) throw std::runtime_error("graph capture already in progress");
+  if (p->kprof.enabled) throw std::runtime_error("per-kernel timing must be off during graph capture");
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  SDM_HIP_CHECK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+  p->capturing = true;
+  SDM_CATCH
+}
+int sdm_plan_graph_end(sdm_plan *p, int *graph_id) {
+  SDM_TRY
+  if (!p->capturing) throw std::runtime_error("no graph capture in progress");
+  p->capturing = false;
+  hipGraph_t g = nullptr;
+  SDM_HIP_CHECK(hipStreamEndCapture(p->stream, &g));
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  SDM_HIP_CHECK(e);
+  p->graphs.push_back(ge);
+  if (graph_id) *graph_id = (int)p->graphs.size() - 1;
+  SDM_CATCH
+}
+int sdm_plan_graph_launch(sdm_plan *p, int graph_id) {
+  SDM_TRY
+  if (graph_id < 0 || graph_id >= (int)p->graphs.size()) throw std::runtime_error("unknown graph id");
+  SDM_HIP_CHECK(hipGraphLaunch(p->graphs[graph_id], p->stream));
+  SDM_CATCH
+}
+
 int sdm_plan_timer_begin(sdm_plan *p, int slot) {
   SDM_TRY
   if (slot < 0 || slot >= 16) throw std::runtime_error("timer slot out of range");

@@ -150,6 +150,8 @@ struct sdm_plan {
   sdm::DevBuf<double> ada_val, absd, rhs, y, ywork, lpr;
   std::vector<sdm_int> ada_jc, ada_ir;   // host copy of the ADA pattern
   hipEvent_t ev_begin[16] = {}, ev_end[16] = {};
+  bool capturing = false;
+  std::vector<hipGraphExec_t> graphs;   // captured launch sequences (sdm_plan_graph_*)
 };
 
 #define SDM_KLAUNCH(P, kernel, grid, block, shmem, ...)                                   \

@@ -154,6 +154,21 @@ class Plan:
     def ldlsolve(self):
         check(self._lib.sdm_plan_ldlsolve(C.c_void_p(self._p)))
 
+    # ---------------------------------------------------------------- graphs
+    def graph_capture(self, fn):
+        """Record the asynchronous plan calls made by fn() into one hipGraph; returns the id for graph_launch."""
+        check(self._lib.sdm_plan_graph_begin(C.c_void_p(self._p)))
+        try:
+            fn()
+        finally:
+            gid = C.c_int(-1)
+            rc = self._lib.sdm_plan_graph_end(C.c_void_p(self._p), C.byref(gid))
+        check(rc)
+        return gid.value
+
+    def graph_launch(self, gid):
+        check(self._lib.sdm_plan_graph_launch(C.c_void_p(self._p), C.c_int(gid)))
+
     def sync(self):
         check(self._lib.sdm_plan_sync(C.c_void_p(self._p)))
 

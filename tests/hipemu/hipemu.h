@@ -84,6 +84,17 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = 0);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 
+/* graphs: the emulator executes eagerly, so a "captured" sequence has already run once; replay is not supported */
+typedef struct emu_graph *hipGraph_t;
+typedef struct emu_graphexec *hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1 };
+inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorUnknown; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *) { return hipErrorUnknown; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t *, hipGraph_t, void *, void *, size_t) { return hipErrorUnknown; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorUnknown; }
+
 /* launch: runs every block sequentially, each as blockDim.x*y*z fibers */
 void emu_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body, const char *name = "?");
 #define SDM_LAUNCH(kernel, grid, block, shmem, stream, ...) \

@@ -160,6 +160,15 @@ def test_resident_plan_and_kernel_timers(glue):
     assert relerr(plan.download("y"), glue.solve_ref(S, it, rhs).ravel()) < TOL
     plan.kprof(True); plan.ldlsolve(); prof = plan.kprof_summary(); plan.kprof(False)
     assert sum(v[1] for k, v in prof.items() if k in ("k_ldl_single", "k_fw_level", "k_bw_level")) > 0
+    # the whole unit replayed from one captured hipGraph gives the same bits as the eager calls
+    y_eager, d_eager = plan.download("y"), plan.download("d")
+
+    def unit():
+        plan.getada(); plan.blkchol(None, True); plan.ldlsolve()
+    gid = plan.graph_capture(unit)
+    plan.upload("y", np.zeros(P.m)); plan.upload("ada", np.zeros(plan.nnzADA))
+    plan.graph_launch(gid); plan.sync()
+    assert np.array_equal(plan.download("y"), y_eager) and np.array_equal(plan.download("d"), d_eager)
     plan.close()
 
 

@@ -982,110 +982,98 @@ k_ldl_single(const double *F, const double *DT, int m, const int *perm, const do
   for (int i = tid; i < m; i += bs) { if (mode & 4) yout[perm[i]] = w[i]; else yout[i] = w[i]; }
 }
 
-// ---- big single fronts (m >= BIG_FRONT): one CU cannot stream the factor fast enough (~100 GB/s), so the sweeps
-// are cut into one launch per 64-column panel; the launches of a sweep are stream-ordered, there is no
-// inter-workgroup synchronisation inside a launch.
-// Forward launch p (p = -1 .. nblk-2): workgroup i owns row block r = p+1+i.  It applies panel p to its rows,
-// w_r -= L(r,p) x_p (x_p was finished by launch p-1), and workgroup 0 then solves the diagonal block r = p+1 so
-// that x_{p+1} is final for the next launch.  Launch -1 only solves block 0.
-__global__ void __launch_bounds__(256)
-k_big_fw(const double *Fs, int m, int ld, int p, double *w) {
+// ---- big single fronts (m >= BIG_FRONT): one CU cannot stream the factor fast enough (~100 GB/s) and a launch per
+// 64-column panel is launch bound (>= 4 us per dependent launch here), so the sweeps are cut into SUPER-panels of
+// BIGW = 256 columns, one launch each; the launches of a sweep are stream-ordered, there is no inter-workgroup
+// synchronisation inside a launch.
+// Forward launch P (P = -1 .. nsb-2): x_P (super-block P of the solution) is final.  Workgroup b owns 256 rows:
+// b = 0 the rows of super-block P+1, b >= 1 the rows (P+2)*BIGW + (b-1)*256 ...  It applies the 256 columns of
+// super-panel P to its rows (four 64-column panels through the same streaming code as front_fw); workgroup 0 then
+// solves the diagonal super-block P+1 with front_fw on that sub-front, so that x_{P+1} is final for the next launch.
+__global__ void __launch_bounds__(SOLVE_THREADS)
+k_big_fw(const double *Fs, int m, int ld, int P, double *w) {
+  __shared__ double wl[BIGW], xb[BIGW], wb[SNB];
   __shared__ double Sd[SNB * SNB];
-  __shared__ double xb[SNB];
-  const int tid = threadIdx.x;
-  const int r = p + 1 + blockIdx.x, r0 = r * SNB, nr = min(SNB, m - r0);
-  if (blockIdx.x == 0) stage_block(Sd, Fs + (int64_t)r0 * ld + r0, ld, nr);
-  if (p >= 0) {
-    const int k0 = p * SNB;
-    if (tid < SNB) xb[tid] = w[k0 + tid];
-    __syncthreads();
-    // 32 row pairs x 8 column groups of 8 columns (lanes of one group read 256 contiguous bytes of a column)
-    const int pr = tid & 31, g = tid >> 5;
-    const int npair = (nr + 1) >> 1;
-    double a0 = 0.0, a1 = 0.0;
-    if (pr < npair) {
-      const int rr = r0 + 2 * pr;
-      const bool two = rr + 1 < m;
-      const double *col = Fs + (int64_t)(k0 + 8 * g) * ld + rr;
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        if (two) { const sdm_double2 v = *(const sdm_double2 *)(col + (int64_t)c * ld); a0 += v.x * xb[8 * g + c]; a1 += v.y * xb[8 * g + c]; }
-        else a0 += col[(int64_t)c * ld] * xb[8 * g + c];
-      }
-    }
-    __shared__ double part[8][SNB];
-    part[g][2 * pr] = a0; part[g][2 * pr + 1] = a1;
-    __syncthreads();
-    if (tid < nr) {
-      double a = 0.0;
-#pragma unroll
-      for (int q = 0; q < 8; q++) a += part[q][tid];             // fixed order: deterministic
-      w[r0 + tid] -= a;
-    }
-  }
-  if (blockIdx.x != 0) return;
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int rbeg = (P + 1) * BIGW + (blockIdx.x == 0 ? 0 : BIGW + ((int)blockIdx.x - 1) * 256);
+  const int rend = min(m, rbeg + 256);
+  for (int i = tid; i < 256; i += bs) wl[i] = rbeg + i < rend ? w[rbeg + i] : 0.0;
+  if (P >= 0)
+    for (int i = tid; i < BIGW; i += bs) xb[i] = w[P * BIGW + i];
   __syncthreads();
-  if (tid < 64) {
-    double wi = tid < nr ? w[r0 + tid] : 0.0;
-#pragma unroll
-    for (int h = 0; h < SNB; h += TCH) {
-      double lr[TCH];
-#pragma unroll
-      for (int k = 0; k < TCH; k++) lr[k] = Sd[(h + k) * SNB + tid];
-#pragma unroll
-      for (int k = 0; k < TCH; k++) SDM_PIN(lr[k]);
-#pragma unroll
-      for (int k = 0; k < TCH; k++) wi -= lr[k] * sdm_bcast_lane(wi, h + k);
+  if (P >= 0) {
+    const int g = (tid >> 4) & 3, t0 = (tid >> 6) * 16 + (tid & 15), tstep = bs >> 2;
+    const int npair = (rend - rbeg) >> 1, lim = (npair + 15) & ~15;
+    double *wadj = wl - rbeg;                                    // fw_consume indexes by front row
+    for (int sub = 0; sub < BIGW / SNB; sub++) {
+      const int k0 = P * BIGW + sub * SNB;
+      for (int t = t0; t < lim; t += tstep) {
+        sdm_double2 v[16];
+        fw_issue(v, Fs, ld, k0, rbeg, npair, t, g);
+        fw_consume(v, xb + sub * SNB, wadj, rbeg, npair, t, g);
+      }
+      if (tid == bs - 1 && ((rend - rbeg) & 1)) {                // unpaired last row of the front
+        const int r = rend - 1;
+        double acc = 0.0;
+        for (int c = 0; c < SNB; c++) acc += Fs[(int64_t)(k0 + c) * ld + r] * xb[sub * SNB + c];
+        wl[r - rbeg] -= acc;
+      }
+      __syncthreads();
     }
-    if (tid < nr) w[r0 + tid] = wi;
   }
+  if (blockIdx.x == 0) {
+    const int ns = rend - rbeg;                                  // diagonal super-block P+1 as a front of its own
+    front_fw(Fs + (int64_t)rbeg * ld + rbeg, ns, ns, ld, wl, wb, Sd);
+  }
+  for (int i = tid; i < rend - rbeg; i += bs) w[rbeg + i] = wl[i];
 }
-// Backward launch p (p = nblk .. 1): workgroup i owns column block q = p-1-i.  It applies row block p,
-// y_q -= L(p,q)' x_p (x_p final), and workgroup 0 then solves the transposed diagonal block q = p-1.
-// Launch nblk only solves the last block.
-__global__ void __launch_bounds__(256)
-k_big_bw(const double *Fs, const double *Ds, int m, int ld, int p, int nblk, double *w) {
+// Backward launch P (P = nsb .. 1): x_P final.  Workgroup b owns the 256 columns of super-block q = P-1-b: it
+// applies the rows of super-block P, y_q -= L(P,q)' x_P, and workgroup 0 then solves the transposed diagonal
+// super-block P-1 with front_bw.  Launch nsb only solves the last super-block.
+__global__ void __launch_bounds__(SOLVE_THREADS)
+k_big_bw(const double *Fs, const double *DT, int m, int ld, int P, int nsb, double *w) {
+  __shared__ double yl[BIGW], xb[BIGW], dots[BIGW];
   __shared__ double Sd[SNB * SNB];
-  __shared__ double xb[SNB];
-  __shared__ double dots[SNB];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int q = p - 1 - (int)blockIdx.x, q0 = q * SNB, nq = min(SNB, m - q0);
-  if (blockIdx.x == 0) stage_blockT(Sd, Ds + (int64_t)q * SNB * SNB, nq);
-  if (p < nblk) {
-    const int p0 = p * SNB, np_ = min(SNB, m - p0);
-    if (tid < SNB) xb[tid] = tid < np_ ? w[p0 + tid] : 0.0;
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
+  const int q = P - 1 - (int)blockIdx.x, cbeg = q * BIGW, ncol = min(BIGW, m - cbeg);
+  for (int i = tid; i < BIGW; i += bs) yl[i] = i < ncol ? w[cbeg + i] : 0.0;
+  if (P < nsb) {
+    const int pbeg = P * BIGW, np_ = min(BIGW, m - pbeg);
+    for (int i = tid; i < BIGW; i += bs) xb[i] = i < np_ ? w[pbeg + i] : 0.0;
     __syncthreads();
-    // 4 wavefronts x 16 columns; lanes = 32 row pairs x 2 columns
-    const int pr = lane & 31, cs = lane >> 5;
-    for (int c = wave * 16 + cs; c < wave * 16 + 16; c += 2) {
-      double a = 0.0;
-      if (c < nq && 2 * pr < np_) {
-        const double *col = Fs + (int64_t)(q0 + c) * ld + p0 + 2 * pr;
-        if (2 * pr + 1 < np_) { const sdm_double2 v = *(const sdm_double2 *)col; a = v.x * xb[2 * pr] + v.y * xb[2 * pr + 1]; }
-        else a = col[0] * xb[2 * pr];
+    const int npair = np_ >> 1;
+    const double *xadj = xb - pbeg;                              // bw_consume indexes by front row
+    for (int cb0 = wave * 4; cb0 < ncol; cb0 += nw * 4) {
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int tb = lane; tb < npair; tb += 256) {
+        sdm_double2 v[16];
+        bw_issue(v, Fs, ld, cbeg, ncol, cb0, pbeg, npair, tb);
+        bw_consume(v, acc, xadj, pbeg, npair, tb);
       }
-      a += __shfl_xor(a, 16); a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
-      if (pr == 0 && c < nq) dots[c] = a;
+      if (lane == 0 && (np_ & 1))
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] += Fs[(int64_t)(cbeg + min(cb0 + u, ncol - 1)) * ld + pbeg + np_ - 1] * xb[np_ - 1];
+      {
+        const bool hi = lane >= 32;
+        const double s0 = hi ? acc[0] : acc[2], s1 = hi ? acc[1] : acc[3];
+        double k0v = (hi ? acc[2] : acc[0]) + __shfl_xor(s0, 32);
+        double k1v = (hi ? acc[3] : acc[1]) + __shfl_xor(s1, 32);
+        const bool od = (lane >> 4) & 1;
+        double a = (od ? k1v : k0v) + __shfl_xor(od ? k0v : k1v, 16);
+        a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+        const int u = (hi ? 2 : 0) + (od ? 1 : 0);
+        if ((lane & 15) == 0 && cb0 + u < ncol) dots[cb0 + u] = a;
+      }
     }
     __syncthreads();
-    if (tid < nq) w[q0 + tid] -= dots[tid];
+    for (int i = tid; i < ncol; i += bs) yl[i] -= dots[i];
   }
-  if (blockIdx.x != 0) return;
   __syncthreads();
-  if (tid < 64) {
-    double yi = tid < nq ? w[q0 + tid] : 0.0;
-#pragma unroll
-    for (int h = SNB - TCH; h >= 0; h -= TCH) {
-      double lr[TCH];
-#pragma unroll
-      for (int k = 0; k < TCH; k++) lr[k] = Sd[(h + k) * SNB + tid];
-#pragma unroll
-      for (int k = 0; k < TCH; k++) SDM_PIN(lr[k]);
-#pragma unroll
-      for (int k = TCH - 1; k >= 0; k--) yi -= lr[k] * sdm_bcast_lane(yi, h + k);
-    }
-    if (tid < nq) w[q0 + tid] = yi;
-  }
+  if (blockIdx.x == 0)
+    front_bw(Fs + (int64_t)cbeg * ld + cbeg, DT + (int64_t)(cbeg / SNB) * SNB * SNB, ncol, ncol, ld, yl, dots, Sd);
+  __syncthreads();
+  for (int i = tid; i < ncol; i += bs) w[cbeg + i] = yl[i];
 }
 
 __global__ void k_gather_perm(double *dst, const double *src, const int *perm, int m, int forward) {
@@ -1208,17 +1196,20 @@ bool solve_single(sdm_plan *P, const double *rhs, double *yout, int mode) {
   CholPlan &C = P->chol;
   if (C.nsuper != 1) return false;
   if (C.m >= BIG_FRONT) {
-    // big front: one launch per 64-column panel and sweep (k_big_fw / k_big_bw), w = ywork in HBM
-    const int m = (int)C.m, ld = C.sn_ld[0], nblk = (m + SNB - 1) / SNB;
+    // big front: one launch per 256-column super-panel and sweep (k_big_fw / k_big_bw), w = ywork in HBM
+    const int m = (int)C.m, ld = C.sn_ld[0], nsb = (m + BIGW - 1) / BIGW;
     if (mode & 1) vec_gather(P, P->ywork.p, rhs, true);
     else SDM_HIP_CHECK(hipMemcpyAsync(P->ywork.p, rhs, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, P->stream));
     if (mode & 1)
-      for (int p = -1; p <= nblk - 2; p++)
-        SDM_KLAUNCH(P, k_big_fw, dim3(p < 0 ? 1 : nblk - p - 1), dim3(256), 0, C.fronts.p, m, ld, p, P->ywork.p);
+      for (int p = -1; p <= nsb - 2; p++) {
+        const int below = m - (p + 2) * BIGW;                     // rows beyond super-block p+1
+        SDM_KLAUNCH(P, k_big_fw, dim3(p < 0 ? 1 : 1 + std::max(0, (below + 255) / 256)), dim3(SOLVE_THREADS), 0, C.fronts.p, m, ld,
+                    p, P->ywork.p);
+      }
     if (mode & 2) vec_divd(P, P->ywork.p);
     if (mode & 4)
-      for (int p = nblk; p >= 1; p--)
-        SDM_KLAUNCH(P, k_big_bw, dim3(p == nblk ? 1 : p), dim3(256), 0, C.fronts.p, C.frontsT.p, m, ld, p, nblk, P->ywork.p);
+      for (int p = nsb; p >= 1; p--)
+        SDM_KLAUNCH(P, k_big_bw, dim3(p == nsb ? 1 : p), dim3(SOLVE_THREADS), 0, C.fronts.p, C.frontsT.p, m, ld, p, nsb, P->ywork.p);
     if (mode & 4) vec_gather(P, yout, P->ywork.p, false);
     else SDM_HIP_CHECK(hipMemcpyAsync(yout, P->ywork.p, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, P->stream));
     return true;

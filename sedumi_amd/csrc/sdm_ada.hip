@@ -159,7 +159,7 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
     A.zmax = zmax;
     const double dens = m > 0 ? (double)ADAjc[m] / ((double)m * (double)m) : 0.0;
     const size_t lds = (size_t)zmax * sizeof(double);
-    if (sdpN > 0 && psdnnz > 0 && dens >= 0.2 && lds <= 96 * 1024) {
+    if (sdpN > 0 && psdnnz > 0 && dens >= 0.2 && lds <= 96 * 1024 && !A.thread_per_row) {   // very short rows: one pattern entry per work-item instead
       std::vector<int> order(m);
       for (sdm_int j = 0; j < m; j++) order[j] = (int)j;
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return Ajc[a + 1] - Ajc_psd[a] > Ajc[b + 1] - Ajc_psd[b]; });
@@ -296,13 +296,16 @@ k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0
     const int cc = min(CC, nslot - c0);
     // (1) Y[:,t] = sum_{nz in slot} x * D[:, row(nz)]          (realdmulx, spscale.c:73-107; cpxdmulx :128-224:
     //     a nonzero of the imaginary plane contributes (i x) * d_row:  Re -= x Im(d),  Im += x Re(d))
-    for (int t = wave; t < cc; t += nw) {
+    // slots x rows flattened over the whole workgroup when there are fewer slots than wavefronts (MAXCUT: one slot
+    // of 4000 rows), else one slot per wavefront at a time
+    const bool flat = cc < nw;
+    for (int t = flat ? 0 : wave; t < cc; t += flat ? 1 : nw) {
       const int64_t sb = T.s_nzptr[slot0 + c0 + t];
       const int64_t se = (c0 + t + 1 < nslot) ? T.s_nzptr[slot0 + c0 + t + 1] : tend;
       const int sc = T.s_col[slot0 + c0 + t];
       const int part = sc >= n ? 1 : 0, col = sc - part * n;
       const int64_t sub0 = rowbase + (int64_t)part * n * n + (int64_t)col * n;
-      for (int i = lane; i < n; i += 64) {
+      for (int i = flat ? tid : lane; i < n; i += flat ? bs : 64) {
         double ar = 0.0, ai = 0.0;
         for (int64_t u = sb; u < se; u++) {
           const int rx = (int)(T.Air[u] - sub0);

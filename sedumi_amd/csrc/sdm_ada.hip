@@ -90,7 +90,7 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
       Aupos[t] = (int)(std::lower_bound(U[k].begin(), U[k].end(), q) - U[k].begin());
       psdnnz++;
     }
-  A.thread_per_row = (m > 0 && psdnnz / (double)m < 16.0);
+  A.thread_per_row = (m > 0 && psdnnz / (double)m < 48.0);     // short rows: one pattern entry per work-item, else per wavefront
   A.nnz_lq = A.nnzA - psdnnz;                                      // LP + Lorentz nonzeros of At
   // ---- stage-1 tasks and slots
   std::vector<int> t_col, t_blk, t_n, t_nslot, t_ulen, t_herm, s_col;
@@ -138,6 +138,13 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
     A.t_order.upload(order); }
   A.ntask = (sdm_int)t_col.size(); A.zlen = zlen;
   A.h_taskptr = c_taskptr; A.col0 = 0; A.col1 = m;
+  { std::vector<int64_t> czl(m + 1, 0);                       // length of z_j (all tasks of constraint j)
+    A.zmaxj = 0;
+    for (sdm_int j = 0; j < m; j++) {
+      for (int64_t t = c_taskptr[j]; t < c_taskptr[j + 1]; t++) czl[j] += t_ulen[t];
+      A.zmaxj = std::max<int64_t>(A.zmaxj, czl[j]);
+    }
+    A.c_zlen.upload(czl); }
   // per task: end of its last slot = start of next task's first nonzero; store explicit end pointers in s_nzptr
   // by giving every slot an (begin) and using the next slot's begin inside a task, and the task end via t_end:
   std::vector<int64_t> t_end(A.ntask);
@@ -225,8 +232,9 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
   A.symtmp.alloc((size_t)std::max<sdm_int>(ADAjc[m], 1));
   // LDS budget for stage 1: Y chunk of CC slots x n rows
   A.stage1_lds = 96 * 1024;
-  if ((size_t)A.maxn * sizeof(double) > A.stage1_lds) A.stage1_lds = (size_t)A.maxn * sizeof(double);
-  if (A.stage1_lds > 160 * 1024 - 1024) throw std::runtime_error("PSD block too large for the LDS-staged D*A*D kernel (n > 20k)");
+  { const size_t need = (size_t)(sdpN > rsdpN ? 4 : 2) * (size_t)A.maxn * sizeof(double);     // one slot: Y (+Yi) and D(col,:) (+Im)
+    if (need > A.stage1_lds) A.stage1_lds = need; }
+  if (A.stage1_lds > 136 * 1024) throw std::runtime_error("PSD block too large for the LDS-staged D*A*D kernel (n > 8700)");
   P->has_ada = true;
 }
 
@@ -290,10 +298,22 @@ k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0
   const int64_t rowbase = T.psd_start[T.t_blk[task]];
   const int tid = threadIdx.x, bs = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
-  int CC = ldsY / (n * (herm ? 2 : 1)); if (CC < 1) CC = 1; if (CC > nslot) CC = nslot;
+  // LDS: Y (and Yi) plus the rows D(col_t,:) of the chunk's slots (Dl; Hermitian: Re and Im, D(ct,j) = conj(D(j,ct)))
+  int CC = ldsY / (n * (herm ? 4 : 2)); if (CC < 1) CC = 1; if (CC > nslot) CC = nslot;
   double *Yi = Y + (int64_t)CC * n;
+  double *Dl = Y + (int64_t)(herm ? 2 : 1) * CC * n;
+  double *Dli = Dl + (int64_t)CC * n;
+  __shared__ double nzx[S1_NZ];                     // the task's nonzeros: value, offset inside the block
+  __shared__ int nzr[S1_NZ];
+  __shared__ int scol[256];
+  const int64_t nzb = T.s_nzptr[slot0];
+  const bool staged = tend - nzb <= S1_NZ;
+  if (staged)
+    for (int64_t u = nzb + tid; u < tend; u += bs) { nzx[u - nzb] = T.Apr[u]; nzr[u - nzb] = (int)(T.Air[u] - rowbase); }
   for (int c0 = 0; c0 < nslot; c0 += CC) {
     const int cc = min(CC, nslot - c0);
+    for (int t = tid; t < min(cc, 256); t += bs) scol[t] = T.s_col[slot0 + c0 + t];
+    __syncthreads();
     // (1) Y[:,t] = sum_{nz in slot} x * D[:, row(nz)]          (realdmulx, spscale.c:73-107; cpxdmulx :128-224:
     //     a nonzero of the imaginary plane contributes (i x) * d_row:  Re -= x Im(d),  Im += x Re(d))
     // slots x rows flattened over the whole workgroup when there are fewer slots than wavefronts (MAXCUT: one slot
@@ -302,14 +322,14 @@ k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0
     for (int t = flat ? 0 : wave; t < cc; t += flat ? 1 : nw) {
       const int64_t sb = T.s_nzptr[slot0 + c0 + t];
       const int64_t se = (c0 + t + 1 < nslot) ? T.s_nzptr[slot0 + c0 + t + 1] : tend;
-      const int sc = T.s_col[slot0 + c0 + t];
+      const int sc = t < 256 ? scol[t] : T.s_col[slot0 + c0 + t];
       const int part = sc >= n ? 1 : 0, col = sc - part * n;
-      const int64_t sub0 = rowbase + (int64_t)part * n * n + (int64_t)col * n;
+      const int sub0 = part * n * n + col * n;                   // offset of the slot's column inside the block
       for (int i = flat ? tid : lane; i < n; i += flat ? bs : 64) {
         double ar = 0.0, ai = 0.0;
         for (int64_t u = sb; u < se; u++) {
-          const int rx = (int)(T.Air[u] - sub0);
-          const double x = T.Apr[u], dr = D[(int64_t)rx * n + i];
+          const int rx = (staged ? nzr[u - nzb] : (int)(T.Air[u] - rowbase)) - sub0;
+          const double x = staged ? nzx[u - nzb] : T.Apr[u], dr = D[(int64_t)rx * n + i];
           if (!herm) ar += x * dr;
           else {
             const double di = Di[(int64_t)rx * n + i];
@@ -317,7 +337,8 @@ k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0
           }
         }
         Y[t * n + i] = ar;
-        if (herm) Yi[t * n + i] = ai;
+        Dl[t * n + i] = D[(int64_t)col * n + i];                  // Re D(col, i) (symmetric)
+        if (herm) { Yi[t * n + i] = ai; Dli[t * n + i] = -Di[(int64_t)col * n + i]; }    // Im D(col, i) = -Im D(i, col)
       }
     }
     __syncthreads();
@@ -333,19 +354,14 @@ k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0
       if (!herm) {
         double a1 = 0.0, a2 = 0.0;
         for (int t = 0; t < cc; t++) {
-          const double *Dc = D + (int64_t)T.s_col[slot0 + c0 + t] * n;
-          a1 += Y[t * n + r] * Dc[c];
-          a2 += Y[t * n + c] * Dc[r];
+          a1 += Y[t * n + r] * Dl[t * n + c];
+          a2 += Y[t * n + c] * Dl[t * n + r];
         }
         v = (a1 + a2) / 2;
       } else {
         double rrc = 0.0, irc = 0.0, rcr = 0.0, icr = 0.0;      // Re/Im of DXD_rc and DXD_cr
         for (int t = 0; t < cc; t++) {
-          const int sc = T.s_col[slot0 + c0 + t];
-          const int ct = sc >= n ? sc - n : sc;
-          // D[ct][j] (row ct, column j): Re = D[j*n+ct], Im = Di[j*n+ct]
-          const double drc = D[(int64_t)c * n + ct], dic = Di[(int64_t)c * n + ct];
-          const double drr = D[(int64_t)r * n + ct], dir = Di[(int64_t)r * n + ct];
+          const double drc = Dl[t * n + c], dic = Dli[t * n + c], drr = Dl[t * n + r], dir = Dli[t * n + r];
           const double yr_r = Y[t * n + r], yi_r = Yi[t * n + r], yr_c = Y[t * n + c], yi_c = Yi[t * n + c];
           rrc += yr_r * drc - yi_r * dic; irc += yr_r * dic + yi_r * drc;
           rcr += yr_c * drr - yi_c * dir; icr += yr_c * dir + yi_c * drr;
@@ -468,32 +484,55 @@ k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0, con
 #endif
 }
 
-// ---- stage 2: ADA(i,j) += a_i[psd]' z_j ; absd fused (getada3.c:333-351)
+// ---- stage 2: ADA(i,j) += a_i[psd]' z_j ; absd fused (getada3.c:333-351).  Sparse ADA' patterns: one workgroup per
+// column j walks the pattern entries of the column.  Short constraint rows: one entry per work-item, z_j staged in
+// LDS when it fits (all entries of the column gather from it); long rows: one entry per wavefront.
 __global__ void __launch_bounds__(256)
 k_psd_stage2(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, const int64_t *Ajc,
              const int64_t *Ajc_psd, const double *Apr, const int *Ablk, const int *Aupos,
-             const int64_t *c_taskptr, const int *t_blk, const int64_t *t_zoff, const double *zbuf,
-             const int *invperm, int nblk, int thread_per_row, int jbase) {
+             const int64_t *c_taskptr, const int *t_blk, const int64_t *t_zoff, const int64_t *c_zlen, const double *zbuf,
+             const int *invperm, int nblk, int thread_per_row, int jbase, int zlds) {
   SDM_DYN_SMEM(smem);
-  long long *zo = (long long *)smem;                // block -> offset of z_jk in zbuf (or -1)
+  long long *zo = (long long *)smem;                // block -> offset of z_jk relative to z_j, or -1
+  double *zl = (double *)(zo + nblk);               // z_j staged in LDS (zlds doubles available)
   const int j = blockIdx.x + jbase;
   const int tid = threadIdx.x, bs = blockDim.x;
+  const int64_t tb0 = c_taskptr[j], te0 = c_taskptr[j + 1];
+  const bool jhas = te0 > tb0;
+  const int64_t z0 = jhas ? t_zoff[tb0] : 0;        // the tasks of one constraint are consecutive in zbuf
+  const int64_t zlen = c_zlen[j];
   for (int k = tid; k < nblk; k += bs) zo[k] = -1;
   __syncthreads();
-  for (int64_t t = c_taskptr[j] + tid; t < c_taskptr[j + 1]; t += bs) zo[t_blk[t]] = t_zoff[t];
+  for (int64_t t = tb0 + tid; t < te0; t += bs) zo[t_blk[t]] = t_zoff[t] - z0;
+  const bool staged = thread_per_row && jhas && zlen <= zlds;
+  if (staged)
+    for (int64_t u = tid; u < zlen; u += bs) zl[u] = zbuf[z0 + u];
   __syncthreads();
-  const bool jhas = c_taskptr[j + 1] > c_taskptr[j];
+  const double *zsrc = staged ? zl : zbuf + z0;
   const int ipj = invperm ? invperm[j] : 0;
   if (thread_per_row) {
     for (int64_t e = ADAjc[j] + tid; e < ADAjc[j + 1]; e += bs) {
       const int i = ADAir[e];
       if (invperm && invperm[i] > ipj) continue;
       double acc = 0.0, aabs = 0.0;
-      if (jhas)
-        for (int64_t t = Ajc_psd[i]; t < Ajc[i + 1]; t++) {
-          const long long off = zo[Ablk[t]];
-          if (off >= 0) { const double term = Apr[t] * zbuf[off + Aupos[t]]; acc += term; aabs += fabs(term); }
+      if (jhas) {
+        int64_t t = Ajc_psd[i];
+        const int64_t te = Ajc[i + 1];
+        for (; t + 4 <= te; t += 4) {                    // 4 nonzeros of a_i in flight
+          double x[4]; int b[4], u[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) { x[q] = Apr[t + q]; b[q] = Ablk[t + q]; u[q] = Aupos[t + q]; }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const long long off = zo[b[q]];
+            if (off >= 0) { const double term = x[q] * zsrc[off + u[q]]; acc += term; aabs += fabs(term); }
+          }
         }
+        for (; t < te; t++) {
+          const long long off = zo[Ablk[t]];
+          if (off >= 0) { const double term = Apr[t] * zsrc[off + Aupos[t]]; acc += term; aabs += fabs(term); }
+        }
+      }
       const double base = ada[e];
       ada[e] = base + acc;
       if (i == j) absd[j] = jhas ? base + aabs : 0.0;
@@ -507,7 +546,7 @@ k_psd_stage2(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, 
       if (jhas)
         for (int64_t t = Ajc_psd[i] + lane; t < Ajc[i + 1]; t += 64) {
           const long long off = zo[Ablk[t]];
-          if (off >= 0) { const double term = Apr[t] * zbuf[off + Aupos[t]]; acc += term; aabs += fabs(term); }
+          if (off >= 0) { const double term = Apr[t] * zsrc[off + Aupos[t]]; acc += term; aabs += fabs(term); }
         }
       for (int off = 32; off > 0; off >>= 1) { acc += __shfl_down(acc, off); aabs += __shfl_down(aabs, off); }
       if (lane == 0) {
@@ -747,9 +786,17 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
     SDM_HIP_CHECK(hipGetLastError());
     return;
   }
-  SDM_KLAUNCH(P, k_psd_stage2, dim3(ncols), dim3(256), (size_t)A.sdpN * 8, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p,
-             A.d_Ajc_psd.p, A.d_Apr.p, A.d_Ablk.p, A.d_Aupos.p, A.c_taskptr.p, A.t_blk.p, A.t_zoff.p, A.zbuf.p, d_invperm,
-             (int)A.sdpN, A.thread_per_row ? 1 : 0, jbase);
+  {
+    // z_j in LDS for the one-entry-per-work-item variant when the longest z_j fits 64 KB beside the block table
+    const int64_t zl = (A.thread_per_row && A.zmaxj * 8 <= 64 * 1024) ? A.zmaxj : 0;
+    const size_t lds = (size_t)A.sdpN * 8 + (size_t)zl * 8;
+#ifndef SDM_EMU
+    if (lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
+    SDM_KLAUNCH(P, k_psd_stage2, dim3(ncols), dim3(256), lds, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p,
+               A.d_Ajc_psd.p, A.d_Apr.p, A.d_Ablk.p, A.d_Aupos.p, A.c_taskptr.p, A.t_blk.p, A.t_zoff.p, A.c_zlen.p, A.zbuf.p,
+               d_invperm, (int)A.sdpN, A.thread_per_row ? 1 : 0, jbase, (int)zl);
+  }
   SDM_HIP_CHECK(hipGetLastError());
 }
 

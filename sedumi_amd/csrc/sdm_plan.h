@@ -117,7 +117,8 @@ struct AdaPlan {
   // stage-2 fast path: interleaved (ELL) copy of the PSD nonzeros, rows sorted by length, groups of 64
   bool ell_ok = false;
   int ell_ng = 0;
-  int64_t zmax = 0;
+  int64_t zmax = 0, zmaxj = 0;
+  DevBuf<int64_t> c_zlen;
   DevBuf<int> g_row, g_len, g_bu;
   DevBuf<int64_t> g_off, d_uoff;
   DevBuf<double> g_val;

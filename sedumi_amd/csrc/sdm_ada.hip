@@ -750,8 +750,16 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
       SDM_KLAUNCH(P, k_psd_stage1_mfma, dim3((unsigned)ntask), dim3(64 * S1_WAVES), lds, T, A.udsqr.p, A.zbuf.p, task0,
                   (ntask == (int)A.ntask) ? (const int *)A.t_order.p : (const int *)nullptr);
     } else
-    SDM_KLAUNCH(P, k_psd_stage1, dim3((unsigned)ntask), dim3(256), A.stage1_lds, T, A.udsqr.p, A.zbuf.p,
-               (int)(A.stage1_lds / sizeof(double)), task0);
+    {
+      // LDS per task: at least one slot (Y and D row, x2 for Hermitian); beyond that S1_GEN_LDS -- several tasks per CU
+      // hide each other's latencies better than one task with all its slots resident
+      const size_t one = (size_t)(A.sdpN > A.rsdpN ? 4 : 2) * (size_t)A.maxn * sizeof(double);
+      const size_t lds = std::max(one, std::min(A.stage1_lds, (size_t)S1_GEN_LDS));
+#ifndef SDM_EMU
+      SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
+      SDM_KLAUNCH(P, k_psd_stage1, dim3((unsigned)ntask), dim3(256), lds, T, A.udsqr.p, A.zbuf.p, (int)(lds / sizeof(double)), task0);
+    }
   }
   // the reference first adds the PSD part on one triangle and symmetrises at the very end; summing the
   // transposed partial sums of getada1/2 first and adding the (symmetric) PSD part afterwards is the same sum.

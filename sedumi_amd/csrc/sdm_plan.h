@@ -14,6 +14,7 @@ constexpr int S1_KC = 48;     // slots (nonzero columns of A_jk) per GEMM chunk
 constexpr int S1_WAVES = 8;   // wavefronts per task
 constexpr int S1_NZ = 1536;   // nonzeros of a chunk of slots staged in LDS (bigger chunks read At directly)
 constexpr int S1_MAXT = ((S1_MAXN / 16) * (S1_MAXN / 16) + S1_WAVES - 1) / S1_WAVES;   // 16x16 tiles of Z per wavefront
+constexpr int S1_GEN_LDS = 24 * 1024;   // LDS target per task of the generic stage-1 kernel (bytes)
 constexpr int ELL_WAVES = 8;  // wavefronts per workgroup of the ELL stage-2 kernel of ADA'
 constexpr int SOLVE_LDS_MAX = 12288;  // doubles of the front-local vector kept in LDS (96 KB)
 constexpr int BIG_FRONT = 1024;       // single fronts from this order on: one launch per super-panel and sweep instead of one workgroup

@@ -8,7 +8,7 @@ import time
 import numpy as np
 import scipy.sparse as sp
 
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, ROOT)
 from sedumi_amd import capi, mex, problem  # noqa: E402
 from sedumi_amd.plan import Plan  # noqa: E402

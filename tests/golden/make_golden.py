@@ -1,7 +1,7 @@
 """tests/golden/make_golden.py -- regenerates the golden fixtures from the reference's own example problems.
 
-Runs ONLY in the build container (needs /root/reference and oracle/_ref): loads examples/{arch0,control07}.mat
-(the problems of examples/test_sedumi.m:22-28), applies the restated pretransfo / setup glue, runs the
+Runs ONLY in the build container (needs /root/reference and oracle/_ref): loads examples/{arch0,control07,nb}.mat
+(the problems of examples/test_sedumi.m:22-28; nb.mat is the Lorentz-cone example, BASELINE.json configs[2]), applies the restated pretransfo / setup glue, runs the
 UNMODIFIED reference MEX (getada1/2/3, blkchol, fwblkslv, bwblkslv) and stores the hot-path inputs plus
 reference outputs as compressed .npz so that the parity tests can run where /root/reference does not exist.
 Large outputs (ADA', L) are stored as Frobenius norm + a fixed random sample of entries.
@@ -24,7 +24,7 @@ from oracle import glue  # noqa: E402
 def main():
     G = glue.Glue()
     rng = np.random.default_rng(2026)
-    for name in ("arch0", "control07"):
+    for name in ("arch0", "control07", "nb"):
         d = sio.loadmat(f"/root/reference/examples/{name}.mat")
         K = {k: d["K"][k][0, 0].astype(float).ravel() for k in d["K"].dtype.names}
         At, b, c, Ki = glue.pretransfo_real(d["At"], d["b"], d["c"], K)
@@ -40,6 +40,16 @@ def main():
         out["rhs"] = rhs
         for tag, (dd, ud) in (("init", glue.sdinit_scaling(Ki, b, c)), ("rand", glue.random_scaling(Ki, seed=7, cond=1e4))):
             it = G.iteration_ref(S, dd, ud)
+            if not Ki["s"].size:
+                # no PSD blocks: absd = diag(ADA') as getada3.c:549-552 documents it (the compiled cpspdiag is
+                # undefined behaviour there, see tests/helpers.py check_iteration); blkchol re-run with it
+                it["absd"] = it["ADA"].diagonal().reshape(-1, 1)
+                it["LL"], it["Ld"], it["Lskip"], it["Ladd"] = G.ref.call("blkchol", 4, S["L"], it["ADA"],
+                                                                           glue.default_pars_chol(), it["absd"])
+            Q = sp.csc_matrix(it["DAt"]["q"]); Q.sort_indices()
+            out.update({f"{tag}_DAtq_data": Q.data, f"{tag}_DAtq_indices": Q.indices.astype(np.int32),
+                        f"{tag}_DAtq_indptr": Q.indptr.astype(np.int64), f"{tag}_DAtq_shape": np.array(Q.shape),
+                        f"{tag}_ADA2_fro": np.linalg.norm(it["ADA2"].toarray())})
             y = G.solve_ref(S, it, rhs)
             Ld = it["Ld"].ravel()
             L = dict(S["L"]); L["L"] = it["LL"]

@@ -145,7 +145,13 @@ def check_golden(name, tag):
     Aord = {"lqperm": z["lqperm"], "qperm": z["qperm"], "sperm": z["sperm"]}
     A1 = mex.getada1(ADApat, At, z["Ablkjc"][:, 2], Aord["lqperm"], d, K["qblkstart"])
     assert abs(np.linalg.norm(A1.toarray()) - z[f"{tag}_ADA1_fro"]) <= 1e-12 * max(1.0, z[f"{tag}_ADA1_fro"])
-    A2 = mex.getada2(A1, {"q": sp.csc_matrix((0, m))}, Aord, K)
+    if f"{tag}_DAtq_data" in z.files:
+        Q = sp.csc_matrix((z[f"{tag}_DAtq_data"], z[f"{tag}_DAtq_indices"], z[f"{tag}_DAtq_indptr"]), shape=tuple(z[f"{tag}_DAtq_shape"]))
+    else:
+        Q = sp.csc_matrix((0, m))
+    A2 = mex.getada2(A1, {"q": Q}, Aord, K)
+    if f"{tag}_ADA2_fro" in z.files:
+        assert abs(np.linalg.norm(A2.toarray()) - z[f"{tag}_ADA2_fro"]) <= 1e-12 * max(1.0, z[f"{tag}_ADA2_fro"])
     A3, absd = mex.getada3(A2, At, z["Ablkjc"][:, 2], Aord, z[f"{tag}_udsqr"], K)
     ADA = A3.toarray()
     si, sj = z[f"{tag}_si"], z[f"{tag}_sj"]

@@ -42,9 +42,10 @@ def test_iteration_unit_block_diagonal_multi_supernode(glue):
     assert S["L"]["xsuper"].size - 1 > 1
 
 
-def test_golden_arch0():
+@pytest.mark.parametrize("name", ["arch0", "nb"])
+def test_golden_small_examples(name):
     for tag in ("init", "rand"):
-        errs = check_golden("arch0", tag)
+        errs = check_golden(name, tag)
         assert max(errs.values()) < TOL, errs
 
 

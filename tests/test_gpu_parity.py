@@ -21,9 +21,10 @@ def test_native_library_is_the_one_loaded():
     assert capi._lib_path is None and capi.lib()._name.endswith("sedumi_amd/lib/libsedumi_hip.so")
 
 
-@pytest.mark.parametrize("name,tag", [("arch0", "init"), ("arch0", "rand"), ("control07", "init"), ("control07", "rand")])
+@pytest.mark.parametrize("name,tag", [("arch0", "init"), ("arch0", "rand"), ("control07", "init"), ("control07", "rand"),
+                                      ("nb", "init"), ("nb", "rand")])
 def test_golden_reference_examples(name, tag):
-    """examples/arch0.mat and examples/control07.mat (BASELINE.json configs[0..1]) through getada1/2/3, blkchol,
+    """examples/arch0.mat, control07.mat and nb.mat (BASELINE.json configs[0..2]) through getada1/2/3, blkchol,
     fwblkslv, bwblkslv against the outputs of the unmodified reference MEX (tests/golden)."""
     errs = check_golden(name, tag)
     assert max(errs.values()) < TOL, errs

@@ -54,7 +54,7 @@ def test_restate_pivot_rule_matches_reference_decisions(refmex, glue, kind, m):
         assert relerr(dr, r[1].ravel()) < 1e-9
 
 
-@pytest.mark.parametrize("name", ["arch0", "control07"])
+@pytest.mark.parametrize("name", ["arch0", "control07", "nb"])
 def test_restate_against_golden_fixture(name):
     """The committed fixtures (reference MEX outputs on the reference's own example problems)."""
     from oracle import restate
@@ -64,7 +64,8 @@ def test_restate_against_golden_fixture(name):
         pytest.skip("dense numpy restatement is O(m^3): fixture checked through the HIP path instead")
     for tag in ("init", "rand"):
         d = {"l": z[f"{tag}_dl"], "det": z[f"{tag}_ddet"]}
-        ADA, absd = restate.getada(At, K, d, None, z[f"{tag}_udsqr"])
+        Q = sp.csc_matrix((z[f"{tag}_DAtq_data"], z[f"{tag}_DAtq_indices"], z[f"{tag}_DAtq_indptr"]), shape=tuple(z[f"{tag}_DAtq_shape"]))
+        ADA, absd = restate.getada(At, K, d, Q, z[f"{tag}_udsqr"])
         assert relerr(absd, z[f"{tag}_absd"]) < 1e-12
         assert relerr(np.diag(ADA), z[f"{tag}_ADA_diag"]) < 1e-12
         assert relerr(ADA[z[f"{tag}_si"], z[f"{tag}_sj"]], z[f"{tag}_ADA_s"]) < 1e-12

@@ -298,11 +298,14 @@ __device__ __noinline__ double pivot_probe(const double (*S)[NB + 1], const doub
 // overwrite the panel while the never-fail rule's column probe of K1 can still read its raw values.
 //
 // Diagonal block (bit-faithful to cholonBlk, blkchol2.c:114-161: column i -= (x_ik / x_kk) * x(:,k), one multiply
-// and one subtract per entry, columns in order): the 64 columns are swept 16 at a time.  Every wavefront holds
-// the 16 current columns of all 64 rows in registers (lane = row) and runs the sweep itself -- pivots and
-// multipliers travel by v_readlane, there is no LDS traffic and no barrier inside a sweep -- then the trailing
-// columns of the block are shared out among the wavefronts (x_rj -= l_jk * x_rk, k ascending: the same
-// operations in the same order as the column-by-column reference) and one barrier closes the 16 columns.
+// and one subtract per entry, columns in order): the 64 columns are swept SW at a time.  Wavefront 0 holds the SW
+// current columns of all 64 rows in registers (lane = row) and runs the sweep -- pivots and multipliers travel by
+// v_readlane, there is no LDS traffic and no barrier inside a sweep.  The sweep is a chain of dependent FP64
+// divisions (~120 clocks per column measured, tools/ubench/ubench6) and it is issue bound when several wavefronts
+// repeat it, so it is pipelined against the rest: while wavefront 0 first brings the NEXT SW columns up to date
+// (look-ahead) and sweeps them, the other wavefronts apply the sweep before to the remaining trailing columns
+// (x_rj -= l_jk * x_rk, k ascending: the same operations in the same order as the column-by-column reference).
+// One barrier per sweep.
 // A pivot that needs the never-fail rule's column probe (x_kk < ub) abandons this path; the block is reloaded
 // and factored by the general all-work-items loop, which can call pivot_probe.
 //
@@ -428,6 +431,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   double *Lc = RB;                                                // Lc[k*NB+i] = l_ik
   __shared__ double ds[NB], lbs[NB], pv[NB];
   __shared__ int stt[NB];
+  __shared__ int badflag;
   __shared__ double red_v[LDL_THREADS];
   __shared__ int red_i[LDL_THREADS];
   const int s = list[blockIdx.x];
@@ -451,59 +455,102 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
     }
   }
   if (tid < NB) { lbs[tid] = tid < kb ? lb[first + k0 + tid] : 0.0; ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
+  if (tid == 0) badflag = 0;
   SDM_PHASE_BEGIN();
   __syncthreads();
   SDM_PHASE(16);
-  // ---- LDL' of the block, register sweeps of 16 columns (see the header).  The sweep is straight-line code:
-  // a skipped pivot gives the multiplier 0, a pivot that needs the probe only raises `bad` (everything computed
-  // after it is discarded: the block is redone by the general path), the bookkeeping of pivot gc lives in lane gc.
-  bool bad = false;
-  const double mylb = lbs[tx];
-  for (int c0 = 0; c0 < kb; c0 += SW) {
-    double x[SW], lsc[SW];
+  // ---- LDL' of the block (see the header): wavefront 0 sweeps SW columns in registers while the other wavefronts
+  // apply the previous sweep to the trailing columns.  The sweep is straight-line code: a skipped pivot gives the
+  // multiplier 0, a pivot that needs the probe only raises `bad` (everything computed after it is discarded: the
+  // block is redone by the general path), the bookkeeping of pivot gc lives in lane gc.
+  const int nsw = (kb + SW - 1) / SW;
+  if (ty == 0) {
+    SDM_SETPRIO(3);
+    bool bad = false;
+    const double mylb = lbs[tx];
+    double xs[SW];                                                     // columns of the sweep just finished (unscaled)
+    for (int s = -1; s < nsw - 1; s++) {
+      const int c0 = s * SW, cn = c0 + SW;                             // sweep s is final; sweep columns cn .. cn+SW-1 now
+      double x[SW], lsc[SW];
 #pragma unroll
-    for (int cc = 0; cc < SW; cc++) x[cc] = S[tx][c0 + cc];
-    double dval = 0.0, pval = 0.0;
-    int stat = 0;
+      for (int cc = 0; cc < SW; cc++) x[cc] = S[tx][cn + cc];
+      if (s >= 0) {
+        // look-ahead: the columns of the next sweep receive sweep s here (x_rj -= l_jk * x_rk, k ascending)
+        // (multipliers fetched in two batches of SW/2 columns, all loads of a batch in flight before the first use)
 #pragma unroll
-    for (int k = 0; k < SW; k++) {
-      const int gc = c0 + k;
-      const double xkk = sdm_bcast_lane(x[k], gc);
-      const double lbk = sdm_bcast_lane(mylb, gc);
-      const bool live = gc < kb;                                     // uniform
-      const bool accept = live && xkk > lbk;                         // uniform
-      bad = bad || (accept && ms - (k0 + gc) > 1 && xkk < ub);       // needs the column probe: general path below
-      const double l = accept ? x[k] / xkk : 0.0;                    // rows above the pivot hold 0; skipped pivot: unit column
+        for (int kh = 0; kh < SW; kh += SW / 2) {
+          double lj[SW / 2][SW];
 #pragma unroll
-      for (int j = k + 1; j < SW; j++) x[j] -= sdm_bcast_lane(l, c0 + j) * x[k];
-      lsc[k] = l;
-      if (tx == gc) { dval = accept ? xkk : 0.0; stat = (live && !accept) ? 1 : 0; pval = xkk; }
-    }
-    if (ty == 0 && tx >= c0 && tx < c0 + SW && tx < kb) { ds[tx] = dval; stt[tx] = stat; pv[tx] = stat ? pval : 0.0; }
-    SDM_PHASE(17);
+          for (int k = 0; k < SW / 2; k++)
 #pragma unroll
-    for (int k = 0; k < SW; k++) Lc[(c0 + k) * NB + tx] = (tx > c0 + k) ? lsc[k] : 0.0;   // every wave writes the same values
-    SDM_WAVE_SYNC();
-    for (int j0 = c0 + SW + 4 * ty; j0 < kb; j0 += 4 * ny) {             // 4 columns per wavefront at a time: independent chains
-      double v[4];
+            for (int cc = 0; cc < SW; cc++) lj[k][cc] = Lc[(c0 + kh + k) * NB + cn + cc];
 #pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = S[tx][min(j0 + u, NB - 1)];
+          for (int k = 0; k < SW / 2; k++)
+#pragma unroll
+            for (int cc = 0; cc < SW; cc++) SDM_PIN(lj[k][cc]);
+#pragma unroll
+          for (int k = 0; k < SW / 2; k++)
+#pragma unroll
+            for (int cc = 0; cc < SW; cc++) x[cc] -= lj[k][cc] * xs[kh + k];
+        }
+      }
+      double dval = 0.0, pval = 0.0;
+      int stat = 0;
 #pragma unroll
       for (int k = 0; k < SW; k++) {
-        double lj[4];
+        const int gc = cn + k;
+        const double xkk = sdm_bcast_lane(x[k], gc);
+        const double lbk = sdm_bcast_lane(mylb, gc);
+        const bool live = gc < kb;                                     // uniform
+        const bool accept = live && xkk > lbk;                         // uniform
+        bad = bad || (accept && ms - (k0 + gc) > 1 && xkk < ub);       // needs the column probe: general path below
+        const double l = accept ? x[k] / xkk : 0.0;                    // skipped pivot: unit column
 #pragma unroll
-        for (int u = 0; u < 4; u++) lj[u] = Lc[(c0 + k) * NB + min(j0 + u, NB - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] -= lj[u] * x[k];
+        for (int j = k + 1; j < SW; j++) x[j] -= sdm_bcast_lane(l, cn + j) * x[k];
+        lsc[k] = l;
+        if (tx == gc) { dval = accept ? xkk : 0.0; stat = (live && !accept) ? 1 : 0; pval = xkk; }
       }
+      if (tx >= cn && tx < cn + SW && tx < kb) { ds[tx] = dval; stt[tx] = stat; pv[tx] = stat ? pval : 0.0; }
 #pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (j0 + u < kb && tx >= j0 + u) S[tx][j0 + u] = v[u];
+      for (int k = 0; k < SW; k++) {
+        Lc[(cn + k) * NB + tx] = (tx > cn + k) ? lsc[k] : 0.0;
+        if (tx >= cn + k) S[tx][cn + k] = x[k];                        // rows above the diagonal stay 0
+        xs[k] = x[k];
+      }
+      if (bad && tx == 0) badflag = 1;
+      SDM_PHASE(17);
+      __syncthreads();
+      SDM_PHASE(19);
     }
-    SDM_PHASE(18);
-    __syncthreads();
-    SDM_PHASE(19);
+    SDM_SETPRIO(0);
+  } else {
+    __syncthreads();                                                   // sweep 0
+    for (int s = 0; s < nsw - 1; s++) {
+      const int c0 = s * SW;
+      double xk[SW];
+#pragma unroll
+      for (int k = 0; k < SW; k++) xk[k] = S[tx][c0 + k];
+      for (int j0 = c0 + 2 * SW + 4 * (ty - 1); j0 < kb; j0 += 4 * (ny - 1)) {   // 4 columns per wavefront at a time
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = S[tx][min(j0 + u, NB - 1)];
+#pragma unroll
+        for (int k = 0; k < SW; k++) {
+          double lj[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) lj[u] = Lc[(c0 + k) * NB + min(j0 + u, NB - 1)];
+#pragma unroll
+          for (int u = 0; u < 4; u++) v[u] -= lj[u] * xk[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (j0 + u < kb && tx >= j0 + u) S[tx][j0 + u] = v[u];
+      }
+      SDM_PHASE(18);
+      __syncthreads();
+    }
   }
+  const bool bad = badflag != 0;
   const bool ok = !bad;
   if (!ok) {
     // ---- general path: one column per step by all work-items, pivot_probe available

@@ -16,6 +16,7 @@ inline double sdm_bcast_lane(double v, int lane) { return emu_shfl(v, lane, 0); 
 // wave-synchronous LDS hand-off between lanes of one wavefront: the emulator runs lanes as fibers and needs a
 // real rendezvous; on the GPU the lanes are in lockstep and LDS operations of a wave complete in order
 #define SDM_WAVE_SYNC() ((void)emu_shfl(0.0, 0, 0))
+#define SDM_SETPRIO(n) do {} while (0)
 #else
 #include <hip/hip_runtime.h>
 typedef double sdm_double4 __attribute__((ext_vector_type(4)));
@@ -25,6 +26,8 @@ typedef double2 sdm_double2;
 #define SDM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
   hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (stream), __VA_ARGS__)
 #define SDM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+// issue priority of the calling wavefront (s_setprio): the wave on a kernel's dependency chain ahead of its helpers
+#define SDM_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 // v_readlane_b32 x2: a scalar broadcast, no LDS crossbar round trip (ds_bpermute) on the dependency chain
 __device__ __forceinline__ double sdm_bcast_lane(double v, int lane) {
   union { double d; int i[2]; } u;

@@ -831,7 +831,7 @@ __device__ __forceinline__ void bw_consume(const sdm_double2 (&v)[16], double (&
   }
 }
 
-__device__ __forceinline__ void front_fw(const double *Fs, int ns, int ms, int ld, double *w, double *wb, double *Sd) {
+__device__ __forceinline__ void front_fw_small(const double *Fs, int ns, int ms, int ld, double *w, double *wb, double *Sd) {
   const int tid = threadIdx.x, bs = blockDim.x;
   const int g = (tid >> 4) & 3, t0 = (tid >> 6) * 16 + (tid & 15), tstep = bs >> 2;
   SDM_PHASE_BEGIN();
@@ -901,7 +901,7 @@ __device__ __forceinline__ void front_fw(const double *Fs, int ns, int ms, int l
   }
 }
 
-__device__ __forceinline__ void front_bw(const double *Fs, const double *Ds, int ns, int ms, int ld, double *w, double *dots, double *Sd) {
+__device__ __forceinline__ void front_bw_small(const double *Fs, const double *Ds, int ns, int ms, int ld, double *w, double *dots, double *Sd) {
   const int tid = threadIdx.x, bs = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
   const int npan = (ns + SNB - 1) / SNB;
@@ -966,15 +966,361 @@ __device__ __forceinline__ void front_bw(const double *Fs, const double *Ds, int
   }
 }
 
+
+// ---------------------------------------------------------------- pipelined sweeps (workgroups of SOLVE_THREADS)
+// The in-block triangular solve is a 64-step dependency chain (~1.1 us) on ONE wavefront; streaming the panel is
+// bandwidth work for the others.  The two overlap: the rows below a panel are split into the 64 rows right below it
+// (the next diagonal block: needed by the next in-block solve, handled right after the barrier from registers that
+// were loaded before it) and the rows beyond, which are streamed while wavefront 0 is already solving the next block.
+// Diagonal blocks are staged in LDS alternately in the two halves of Sd2; x_p / the partial dots are double-buffered.
+constexpr int FW_CRIT = 2;               // forward: wavefronts 1..2 own the 64 rows right below the panel
+constexpr int FW_FAR0 = 1 + FW_CRIT;     //          wavefronts 3..15 stream the rows beyond
+constexpr int BW_FARW = 13;              // backward: wavefronts 1..13 form the dots beyond (5 columns each), 14..15 stage
+constexpr int STG15 = (SNB * SNB + (SOLVE_THREADS - 64) - 1) / (SOLVE_THREADS - 64);   // staging by wavefronts 1..15
+
+__device__ __forceinline__ void stage15_load(double (&sv)[STG15], const double *blk, int ld, int kb) {
+#pragma unroll
+  for (int q = 0; q < STG15; q++) {
+    const int idx = min((int)threadIdx.x - 64 + q * (SOLVE_THREADS - 64), SNB * SNB - 1), i = idx & 63, c = idx >> 6;
+    sv[q] = blk[(int64_t)min(c, kb - 1) * ld + min(i, kb - 1)];
+  }
+}
+__device__ __forceinline__ void stage15_store(double *Sd, const double (&sv)[STG15], int kb) {
+#pragma unroll
+  for (int q = 0; q < STG15; q++) {
+    const int idx = (int)threadIdx.x - 64 + q * (SOLVE_THREADS - 64), i = idx & 63, c = idx >> 6;
+    if (idx < SNB * SNB) Sd[idx] = (c < i && i < kb) ? sv[q] : 0.0;
+  }
+}
+
+// in-block forward solve by one wavefront (lane = row): coefficients of TCH steps are pulled into registers at once
+// (one LDS round trip per TCH steps of the dependency chain); they are 0 for lanes <= k and for k >= kb
+__device__ __forceinline__ double trsv_fw_block(const double *Sd, double wi, int lane) {
+#pragma unroll
+  for (int h = 0; h < SNB; h += TCH) {
+    double lr[TCH];
+#pragma unroll
+    for (int k = 0; k < TCH; k++) lr[k] = Sd[(h + k) * SNB + lane];
+#pragma unroll
+    for (int k = 0; k < TCH; k++) SDM_PIN(lr[k]);
+#pragma unroll
+    for (int k = 0; k < TCH; k++) wi -= lr[k] * sdm_bcast_lane(wi, h + k);
+  }
+  return wi;
+}
+__device__ __forceinline__ double trsv_bw_block(const double *Sd, double yi, int lane) {
+#pragma unroll
+  for (int h = SNB - TCH; h >= 0; h -= TCH) {       // L(k0+k, k0+lane), 0 unless k > lane
+    double lr[TCH];
+#pragma unroll
+    for (int k = 0; k < TCH; k++) lr[k] = Sd[(h + k) * SNB + lane];
+#pragma unroll
+    for (int k = 0; k < TCH; k++) SDM_PIN(lr[k]);
+#pragma unroll
+    for (int k = TCH - 1; k >= 0; k--) yi -= lr[k] * sdm_bcast_lane(yi, h + k);
+  }
+  return yi;
+}
+// one row r below a kb-column panel (rows that do not pair up): w[r] -= L(r, k0:k0+kb) . x
+__device__ __forceinline__ void fw_single_row(const double *Fs, int ld, int k0, int kb, int r, const double *x, double *w) {
+  const double *col = Fs + (int64_t)k0 * ld + r;
+  double acc = 0.0;
+  for (int c = 0; c < kb; c++) acc += col[(int64_t)c * ld] * x[c];
+  w[r] -= acc;
+}
+// wave reduction of 4 column sums with 7 shuffles instead of 24: fold the columns into the lane index first (upper
+// half wave keeps columns 2,3, then odd 16-lane groups keep the odd column), then 4 plain steps; lanes with
+// (lane & 15) == 0 end up holding column q = 2*(lane >= 32) + ((lane >> 4) & 1)
+__device__ __forceinline__ double fold4(const double (&acc)[4], int lane) {
+  const bool hi = lane >= 32;
+  const double s0 = hi ? acc[0] : acc[2], s1 = hi ? acc[1] : acc[3];      // what the partner half keeps
+  double k0v = (hi ? acc[2] : acc[0]) + __shfl_xor(s0, 32);
+  double k1v = (hi ? acc[3] : acc[1]) + __shfl_xor(s1, 32);
+  const bool od = (lane >> 4) & 1;
+  double a = (od ? k1v : k0v) + __shfl_xor(od ? k0v : k1v, 16);
+  a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+  return a;
+}
+// dots[c] = sum over the rows [ra, ms) of L(r, k0+c) w[r] for the 4 columns cb0..cb0+3 (one wavefront; ra even)
+__device__ __forceinline__ void bw_far_quad(const double *Fs, int ld, int k0, int kb, int cb0, int ra, int ms, const double *w,
+                                            double *dots, int lane) {
+  const int npair = ms > ra ? (ms - ra) >> 1 : 0;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int tb = lane; tb < npair; tb += 256) {
+    sdm_double2 v[16];
+    bw_issue(v, Fs, ld, k0, kb, cb0, ra, npair, tb);
+    bw_consume(v, acc, w, ra, npair, tb);
+  }
+  if (lane == 0 && ms > ra && ((ms - ra) & 1)) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] += Fs[(int64_t)(k0 + min(cb0 + q, kb - 1)) * ld + ms - 1] * w[ms - 1];
+  }
+  const double a = fold4(acc, lane);
+  const int q = (lane >= 32 ? 2 : 0) + ((lane >> 4) & 1);
+  if ((lane & 15) == 0 && cb0 + q < kb) dots[cb0 + q] = a;
+}
+// dots over the rows [ra, ms) for the 5 columns c0 .. c0+4 of a full panel (one wavefront; columns beyond the panel
+// are clamped and dropped): BW_NCH chunks of 64 row pairs x 5 columns sixteen-byte loads per lane in flight
+constexpr int BW_NCH = 3;
+__device__ __forceinline__ void bw_far_five(const double *Fs, int ld, int k0, int c0, int ra, int ms, const double *w,
+                                            double *dots, int lane) {
+  const int npair = ms > ra ? (ms - ra) >> 1 : 0;
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  const sdm_double2 *cp = (const sdm_double2 *)(Fs + (int64_t)(k0 + c0) * ld + ra);
+  const int ld2 = ld >> 1;
+  for (int tb = lane; tb < npair; tb += 64 * BW_NCH) {
+    sdm_double2 v[5 * BW_NCH];
+#pragma unroll
+    for (int i = 0; i < BW_NCH; i++) {
+      const int tc = min(tb + 64 * i, npair - 1);
+#pragma unroll
+      for (int q = 0; q < 5; q++) v[5 * i + q] = cp[(int64_t)min(q, SNB - 1 - c0) * ld2 + tc];
+    }
+#pragma unroll
+    for (int i = 0; i < BW_NCH; i++) {
+      const int t = tb + 64 * i;
+      if (t < npair) {
+        const double w0 = w[ra + 2 * t], w1 = w[ra + 2 * t + 1];
+#pragma unroll
+        for (int q = 0; q < 5; q++) acc[q] += v[5 * i + q].x * w0 + v[5 * i + q].y * w1;
+      }
+    }
+  }
+  if (lane == 0 && ms > ra && ((ms - ra) & 1)) {
+#pragma unroll
+    for (int q = 0; q < 5; q++) acc[q] += Fs[(int64_t)(k0 + min(c0 + q, SNB - 1)) * ld + ms - 1] * w[ms - 1];
+  }
+  const double a4[4] = {acc[0], acc[1], acc[2], acc[3]};
+  const double a = fold4(a4, lane);
+  double e = acc[4];
+  e += __shfl_xor(e, 32); e += __shfl_xor(e, 16); e += __shfl_xor(e, 8); e += __shfl_xor(e, 4); e += __shfl_xor(e, 2); e += __shfl_xor(e, 1);
+  const int q = (lane >= 32 ? 2 : 0) + ((lane >> 4) & 1);
+  if ((lane & 15) == 0 && c0 + q < SNB) dots[c0 + q] = a;
+  if (lane == 1 && c0 + 4 < SNB) dots[c0 + 4] = e;
+}
+
+// forward sweep of one front, workgroup of SOLVE_THREADS; wb2 = 2*SNB doubles, Sd2 = 2*SNB*SNB doubles (LDS).
+// The three roles run their own loops over the full panels (two barriers per panel each, so the barrier counts
+// agree) -- separate loops keep the register live ranges of the roles apart.
+__device__ __forceinline__ void front_fw_pipe(const double *Fs, int ns, int ms, int ld, double *w, double *wb2, double *Sd2) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = (tid >> 4) & 3;
+  const int nfull = ns / SNB, rem = ns - nfull * SNB;
+  SDM_PHASE_BEGIN();
+  stage_block(Sd2, Fs, ld, min(SNB, ns));
+  __syncthreads();
+  SDM_PHASE(0);
+  if (wave == 0) {
+    // ---- in-block solves
+    for (int p = 0; p < nfull; p++) {
+      const int k0 = p * SNB;
+      const double wi = trsv_fw_block(Sd2 + (p & 1) * SNB * SNB, w[k0 + lane], lane);
+      w[k0 + lane] = wi;
+      wb2[(p & 1) * SNB + lane] = wi;
+      SDM_PHASE(1);
+      __syncthreads();
+      SDM_PHASE(2);
+      __syncthreads();
+      SDM_PHASE(3);
+    }
+  } else if (wave <= FW_CRIT) {
+    // ---- the 64 rows right below panel p: loads before the barrier, x_p applied after it
+    const int tcrit = (wave - 1) * 16 + (lane & 15);
+    for (int p = 0; p < nfull; p++) {
+      const int k0 = p * SNB, rb = k0 + SNB, k1 = rb;
+      const int ncrit = min(SNB, ms - rb), npc = max(ncrit, 0) >> 1;
+      sdm_double2 vc[16];
+      double sv[STG15];
+      if (k1 < ns) stage15_load(sv, Fs + (int64_t)k1 * ld + k1, ld, min(SNB, ns - k1));      // next diagonal block
+      if (npc > 0) fw_issue(vc, Fs, ld, k0, rb, npc, tcrit, g);
+      if (k1 < ns) stage15_store(Sd2 + ((p + 1) & 1) * SNB * SNB, sv, min(SNB, ns - k1));
+      __syncthreads();
+      if (npc > 0) fw_consume(vc, wb2 + (p & 1) * SNB, w, rb, npc, tcrit, g);
+      if (tid == 64 && ncrit > 0 && (ncrit & 1)) fw_single_row(Fs, ld, k0, SNB, rb + ncrit - 1, wb2 + (p & 1) * SNB, w);
+      __syncthreads();
+    }
+  } else {
+    // ---- the rows beyond: panel p-1 is streamed while wavefront 0 solves block p
+    for (int p = 0; p < nfull; p++) {
+      const int k0 = p * SNB, k1 = k0 + SNB;
+      double sv[STG15];
+      if (k1 < ns) stage15_load(sv, Fs + (int64_t)k1 * ld + k1, ld, min(SNB, ns - k1));      // next diagonal block: loads now
+      if (p > 0) {
+        const int kp = k0 - SNB, ra = k0 + SNB;                                              // rows beyond block p
+        const int npair = ms > ra ? (ms - ra) >> 1 : 0, lim = (npair + 15) & ~15;
+        const double *wbq = wb2 + ((p - 1) & 1) * SNB;
+        for (int t = (wave - FW_FAR0) * 16 + (lane & 15); t < lim; t += (SOLVE_THREADS / 64 - FW_FAR0) * 16) {
+          sdm_double2 v[16];
+          fw_issue(v, Fs, ld, kp, ra, npair, t, g);
+          fw_consume(v, wbq, w, ra, npair, t, g);
+        }
+        if (tid == SOLVE_THREADS - 1 && ms > ra && ((ms - ra) & 1)) fw_single_row(Fs, ld, kp, SNB, ms - 1, wbq, w);
+      }
+      if (k1 < ns) stage15_store(Sd2 + ((p + 1) & 1) * SNB * SNB, sv, min(SNB, ns - k1));    // ... LDS stores after the stream
+      SDM_PHASE(4);
+      __syncthreads();
+      __syncthreads();
+    }
+  }
+  // ---- common tail: what the last full panel still owes to the rows beyond, then a partial last panel
+  if (nfull > 0 && ms > nfull * SNB + SNB) {
+    const int kp = (nfull - 1) * SNB, ra = nfull * SNB + SNB;
+    const int npair = (ms - ra) >> 1, lim = (npair + 15) & ~15;
+    const double *wbq = wb2 + ((nfull - 1) & 1) * SNB;
+    for (int t = wave * 16 + (lane & 15); t < lim; t += SOLVE_THREADS / 4) {
+      sdm_double2 v[16];
+      fw_issue(v, Fs, ld, kp, ra, npair, t, g);
+      fw_consume(v, wbq, w, ra, npair, t, g);
+    }
+    if (tid == SOLVE_THREADS - 1 && ((ms - ra) & 1)) fw_single_row(Fs, ld, kp, SNB, ms - 1, wbq, w);
+    __syncthreads();
+  }
+  if (rem > 0) {
+    const int k0 = nfull * SNB, kb = rem, rb = ns;
+    double *wbp = wb2 + (nfull & 1) * SNB;
+    if (wave == 0) {
+      const double wi = trsv_fw_block(Sd2 + (nfull & 1) * SNB * SNB, lane < kb ? w[k0 + lane] : 0.0, lane);
+      if (lane < kb) w[k0 + lane] = wi;
+      wbp[lane] = wi;
+    }
+    __syncthreads();
+    if (rb < ms) {
+      const int ra = rb + (rb & 1), npair = ms > ra ? (ms - ra) >> 1 : 0;
+      for (int t = tid; t < npair; t += SOLVE_THREADS) {
+        const int r = ra + 2 * t;
+        const sdm_double2 *col = (const sdm_double2 *)(Fs + (int64_t)k0 * ld + r);
+        double a0 = 0.0, a1 = 0.0;
+        for (int c = 0; c < kb; c++) { const sdm_double2 x = col[(int64_t)c * (ld >> 1)]; a0 += x.x * wbp[c]; a1 += x.y * wbp[c]; }
+        w[r] -= a0; w[r + 1] -= a1;
+      }
+      if (tid == SOLVE_THREADS - 1 && (rb & 1)) fw_single_row(Fs, ld, k0, kb, rb, wbp, w);
+      if (tid == SOLVE_THREADS - 2 && ms > ra && ((ms - ra) & 1)) fw_single_row(Fs, ld, k0, kb, ms - 1, wbp, w);
+      __syncthreads();
+    }
+  }
+  SDM_PHASE(5);
+}
+
+// phase A of a backward step: dotsC[c] = sum over the (at most 64) rows right below full panel k0 of L(r, k0+c) w[r];
+// every wavefront 4 columns from the registers vc it loaded before the barrier
+__device__ __forceinline__ void bw_crit(const sdm_double2 (&vc)[4], const double *Fs, int ld, int k0, int rb, int ncrit, const double *w,
+                                        double *dotsC, int wave, int lane) {
+  const int npc = ncrit >> 1;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (lane < npc) {
+    const double w0 = w[rb + 2 * lane], w1 = w[rb + 2 * lane + 1];
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = vc[q].x * w0 + vc[q].y * w1;
+  }
+  if (lane == 32 && (ncrit & 1)) {
+    const int r = rb + ncrit - 1;
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = Fs[(int64_t)(k0 + 4 * wave + q) * ld + r] * w[r];
+  }
+  const double a = fold4(acc, lane);
+  if ((lane & 15) == 0) dotsC[4 * wave + (lane >= 32 ? 2 : 0) + ((lane >> 4) & 1)] = a;
+}
+__device__ __forceinline__ void bw_crit_load(sdm_double2 (&vc)[4], const double *Fs, int ld, int k0, int rb, int ncrit, int wave, int lane) {
+  const int npc = ncrit >> 1;
+  if (npc > 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) vc[q] = ((const sdm_double2 *)(Fs + (int64_t)(k0 + 4 * wave + q) * ld + rb))[min(lane, npc - 1)];
+  }
+}
+
+// backward sweep of one front, workgroup of SOLVE_THREADS; dots3 = 3*SNB doubles, Sd2 = 2*SNB*SNB doubles (LDS)
+__device__ __forceinline__ void front_bw_pipe(const double *Fs, const double *Ds, int ns, int ms, int ld, double *w, double *dots3,
+                                              double *Sd2) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int npan = (ns + SNB - 1) / SNB;
+  double *dotsC = dots3 + 2 * SNB;
+  sdm_double2 vc[4];                                       // this wavefront's 4 columns of the rows right below the panel
+  SDM_PHASE_BEGIN();
+  {
+    // last panel: nothing to overlap with
+    const int P = npan - 1, k0 = P * SNB, kb = ns - k0, rb = ns;
+    double *dF = dots3 + (P & 1) * SNB;
+    stage_blockT(Sd2 + (P & 1) * SNB * SNB, Ds + (int64_t)P * SNB * SNB, kb);
+    if (kb == SNB) {
+      bw_far_quad(Fs, ld, k0, kb, 4 * wave, rb + SNB, ms, w, dF, lane);
+      bw_crit_load(vc, Fs, ld, k0, rb, max(0, min(SNB, ms - rb)), wave, lane);
+    } else if (4 * wave < kb) {
+      // partial panel (rb may be odd): all rows below it in one go
+      const int ra = rb + (rb & 1), cb0 = 4 * wave;
+      bw_far_quad(Fs, ld, k0, kb, cb0, ra, ms, w, dF, lane);
+      SDM_WAVE_SYNC();
+      if (lane < 4 && cb0 + lane < kb && (rb & 1) && rb < ms) dF[cb0 + lane] += Fs[(int64_t)(k0 + cb0 + lane) * ld + rb] * w[rb];
+    }
+  }
+  SDM_PHASE(8);
+  __syncthreads();
+  if (wave == 0) {
+    for (int p = npan - 1; p >= 0; p--) {
+      const int k0 = p * SNB, kb = min(SNB, ns - k0), rb = k0 + kb;
+      const int ncrit = kb == SNB ? max(0, min(SNB, ms - rb)) : 0;
+      if (ncrit > 0) bw_crit(vc, Fs, ld, k0, rb, ncrit, w, dotsC, wave, lane);
+      __syncthreads();
+      SDM_PHASE(9);
+      if (p > 0) bw_crit_load(vc, Fs, ld, k0 - SNB, k0, min(SNB, ms - k0), wave, lane);     // for the next step, in flight during the solve
+      const double *dF = dots3 + (p & 1) * SNB;
+      double yi = lane < kb ? w[k0 + lane] - dF[lane] - (ncrit > 0 ? dotsC[lane] : 0.0) : 0.0;
+      yi = trsv_bw_block(Sd2 + (p & 1) * SNB * SNB, yi, lane);
+      if (lane < kb) w[k0 + lane] = yi;
+      SDM_PHASE(10);
+      __syncthreads();
+      SDM_PHASE(11);
+    }
+  } else {
+    for (int p = npan - 1; p >= 0; p--) {
+      const int k0 = p * SNB, kb = min(SNB, ns - k0), rb = k0 + kb;
+      const int ncrit = kb == SNB ? max(0, min(SNB, ms - rb)) : 0;
+      if (ncrit > 0) bw_crit(vc, Fs, ld, k0, rb, ncrit, w, dotsC, wave, lane);
+      __syncthreads();
+      if (p > 0) {
+        // what panel p-1 (full) can already know: its rows beyond block p are final.  Wavefronts 1..13 five columns
+        // each, wavefronts 14..15 fetch the transposed diagonal block p-1 from DT.
+        const int kq = k0 - SNB, ra = k0 + SNB;
+        bw_crit_load(vc, Fs, ld, kq, k0, min(SNB, ms - k0), wave, lane);
+        if (wave <= BW_FARW) {
+          bw_far_five(Fs, ld, kq, 5 * (wave - 1), ra, ms, w, dots3 + ((p - 1) & 1) * SNB, lane);
+        } else {
+          constexpr int NST = SOLVE_THREADS - 64 * (1 + BW_FARW), PER = SNB * SNB / 2 / NST;
+          const sdm_double2 *Dp = (const sdm_double2 *)(Ds + (int64_t)(p - 1) * SNB * SNB);
+          double *Sn = Sd2 + ((p - 1) & 1) * SNB * SNB;
+          const int t = tid - 64 * (1 + BW_FARW);
+          sdm_double2 sv[PER];
+#pragma unroll
+          for (int q = 0; q < PER; q++) sv[q] = Dp[t + q * NST];
+#pragma unroll
+          for (int q = 0; q < PER; q++) {
+            const int idx = 2 * (t + q * NST), i = idx & 63, c = idx >> 6;       // Sn[c*64 + i] = L(k0+c, k0+i) for i < c
+            Sn[idx] = c > i ? sv[q].x : 0.0;
+            Sn[idx + 1] = c > i + 1 ? sv[q].y : 0.0;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ void front_fw(const double *Fs, int ns, int ms, int ld, double *w, double *wb2, double *Sd2) {
+  if (blockDim.x == SOLVE_THREADS) front_fw_pipe(Fs, ns, ms, ld, w, wb2, Sd2);
+  else front_fw_small(Fs, ns, ms, ld, w, wb2, Sd2);
+}
+__device__ __forceinline__ void front_bw(const double *Fs, const double *Ds, int ns, int ms, int ld, double *w, double *dots3, double *Sd2) {
+  if (blockDim.x == SOLVE_THREADS) front_bw_pipe(Fs, Ds, ns, ms, ld, w, dots3, Sd2);
+  else front_bw_small(Fs, Ds, ns, ms, ld, w, dots3, Sd2);
+}
+
 __global__ void __launch_bounds__(SOLVE_THREADS)
 k_fw_level(const double *F, FrontTab tab, const int *list, double *wvec, double *y, int use_lds) {
   SDM_DYN_SMEM(smem);
-  __shared__ double wb[SNB];
-  __shared__ double Sd[SNB * SNB];
+  __shared__ double wb[3 * SNB];
+  double *Sd = (double *)smem;                                    // two diagonal blocks
   const int s = list[blockIdx.x];
   const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
   double *wg = wvec + tab.woff[s];
-  double *w = use_lds ? (double *)smem : wg;
+  double *w = use_lds ? (double *)smem + 2 * SNB * SNB : wg;
   const int tid = threadIdx.x, bs = blockDim.x;
   for (int i = tid; i < ms; i += bs) w[i] = i < ns ? y[first + i] : 0.0;
   __syncthreads();
@@ -994,12 +1340,12 @@ k_fw_level(const double *F, FrontTab tab, const int *list, double *wvec, double 
 __global__ void __launch_bounds__(SOLVE_THREADS)
 k_bw_level(const double *F, const double *DT, FrontTab tab, const int *list, double *wvec, double *y, int use_lds) {
   SDM_DYN_SMEM(smem);
-  __shared__ double dots[SNB];
-  __shared__ double Sd[SNB * SNB];
+  __shared__ double dots[3 * SNB];
+  double *Sd = (double *)smem;                                    // two diagonal blocks
   const int s = list[blockIdx.x];
   const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
   const int *rows = tab.lindx + tab.xl[s];
-  double *w = use_lds ? (double *)smem : wvec + tab.woff[s];
+  double *w = use_lds ? (double *)smem + 2 * SNB * SNB : wvec + tab.woff[s];
   const int tid = threadIdx.x, bs = blockDim.x;
   // rows below the supernode belong to ancestors, already final (bwblkslv.c:104-105 gathers them once)
   for (int i = tid; i < ms; i += bs) w[i] = i < ns ? y[first + i] : y[rows[i]];
@@ -1015,9 +1361,9 @@ __global__ void __launch_bounds__(SOLVE_THREADS)
 k_ldl_single(const double *F, const double *DT, int m, const int *perm, const double *dsolve, const double *rhs,
              double *yout, double *wglob, int use_lds, int mode) {
   SDM_DYN_SMEM(smem);
-  __shared__ double wb[SNB];
-  __shared__ double Sd[SNB * SNB];
-  double *w = use_lds ? (double *)smem : wglob;
+  __shared__ double wb[3 * SNB];
+  double *Sd = (double *)smem;                                    // two diagonal blocks
+  double *w = use_lds ? (double *)smem + 2 * SNB * SNB : wglob;
   const int tid = threadIdx.x, bs = blockDim.x;
   // mode bits: 1 forward sweep, 2 divide by d, 4 backward sweep; rhs is permuted on the way in iff forward,
   // the result on the way out iff backward (fwblkslv.c:298-303, bwblkslv.c:272-278)
@@ -1039,8 +1385,9 @@ k_ldl_single(const double *F, const double *DT, int m, const int *perm, const do
 // solves the diagonal super-block P+1 with front_fw on that sub-front, so that x_{P+1} is final for the next launch.
 __global__ void __launch_bounds__(SOLVE_THREADS)
 k_big_fw(const double *Fs, int m, int ld, int P, double *w) {
-  __shared__ double wl[BIGW], xb[BIGW], wb[SNB];
-  __shared__ double Sd[SNB * SNB];
+  SDM_DYN_SMEM(smem);
+  __shared__ double wl[BIGW], xb[BIGW], wb[3 * SNB];
+  double *Sd = (double *)smem;                                    // two diagonal blocks (workgroup 0)
   const int tid = threadIdx.x, bs = blockDim.x;
   const int rbeg = (P + 1) * BIGW + (blockIdx.x == 0 ? 0 : BIGW + ((int)blockIdx.x - 1) * 256);
   const int rend = min(m, rbeg + 256);
@@ -1079,8 +1426,9 @@ k_big_fw(const double *Fs, int m, int ld, int P, double *w) {
 // super-block P-1 with front_bw.  Launch nsb only solves the last super-block.
 __global__ void __launch_bounds__(SOLVE_THREADS)
 k_big_bw(const double *Fs, const double *DT, int m, int ld, int P, int nsb, double *w) {
+  SDM_DYN_SMEM(smem);
   __shared__ double yl[BIGW], xb[BIGW], dots[BIGW];
-  __shared__ double Sd[SNB * SNB];
+  double *Sd = (double *)smem;                                    // two diagonal blocks (workgroup 0)
   const int tid = threadIdx.x, bs = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
   const int q = P - 1 - (int)blockIdx.x, cbeg = q * BIGW, ncol = min(BIGW, m - cbeg);
@@ -1202,15 +1550,18 @@ void chol_load_factor(sdm_plan *P, const double *h_Lpr) {
   P->factored = true;
 }
 
-// the front-local vector goes to LDS when the largest front of the plan fits (96 KB), else it stays in HBM
+// dynamic LDS of the sweep kernels: two staged diagonal blocks, then the front-local vector when the largest front
+// of the plan fits (SOLVE_LDS_MAX doubles), else that vector stays in HBM
+constexpr size_t SOLVE_LDS_BLOCKS = 2 * SNB * SNB * sizeof(double);
 static void solve_cfg(CholPlan &C, size_t &bytes, int &use) {
   use = C.maxms <= SOLVE_LDS_MAX ? 1 : 0;
-  bytes = use ? (size_t)C.maxms * sizeof(double) : 0;
+  bytes = SOLVE_LDS_BLOCKS + (use ? (size_t)C.maxms * sizeof(double) : 0);
 }
 static int level_threads(const CholPlan &C, int l) {
   int mx = 0;
   for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) mx = std::max(mx, C.sn_ms[C.levlist[i]]);
-  return std::min(SOLVE_THREADS, std::max(64, (mx + 63) / 64 * 64));
+  if (mx >= PIPE_MIN_ROWS) return SOLVE_THREADS;              // full workgroup: look-ahead schedule (front_fw_pipe / front_bw_pipe)
+  return std::min(SOLVE_THREADS - 64, std::max(64, (mx + 63) / 64 * 64));
 }
 void solve_fw(sdm_plan *P) {
   CholPlan &C = P->chol;
@@ -1245,18 +1596,22 @@ bool solve_single(sdm_plan *P, const double *rhs, double *yout, int mode) {
   if (C.m >= BIG_FRONT) {
     // big front: one launch per 256-column super-panel and sweep (k_big_fw / k_big_bw), w = ywork in HBM
     const int m = (int)C.m, ld = C.sn_ld[0], nsb = (m + BIGW - 1) / BIGW;
+#ifndef SDM_EMU
+    SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_big_fw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS_BLOCKS));
+    SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_big_bw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS_BLOCKS));
+#endif
     if (mode & 1) vec_gather(P, P->ywork.p, rhs, true);
     else SDM_HIP_CHECK(hipMemcpyAsync(P->ywork.p, rhs, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, P->stream));
     if (mode & 1)
       for (int p = -1; p <= nsb - 2; p++) {
         const int below = m - (p + 2) * BIGW;                     // rows beyond super-block p+1
-        SDM_KLAUNCH(P, k_big_fw, dim3(p < 0 ? 1 : 1 + std::max(0, (below + 255) / 256)), dim3(SOLVE_THREADS), 0, C.fronts.p, m, ld,
+        SDM_KLAUNCH(P, k_big_fw, dim3(p < 0 ? 1 : 1 + std::max(0, (below + 255) / 256)), dim3(SOLVE_THREADS), SOLVE_LDS_BLOCKS, C.fronts.p, m, ld,
                     p, P->ywork.p);
       }
     if (mode & 2) vec_divd(P, P->ywork.p);
     if (mode & 4)
       for (int p = nsb; p >= 1; p--)
-        SDM_KLAUNCH(P, k_big_bw, dim3(p == nsb ? 1 : p), dim3(SOLVE_THREADS), 0, C.fronts.p, C.frontsT.p, m, ld, p, nsb, P->ywork.p);
+        SDM_KLAUNCH(P, k_big_bw, dim3(p == nsb ? 1 : p), dim3(SOLVE_THREADS), SOLVE_LDS_BLOCKS, C.fronts.p, C.frontsT.p, m, ld, p, nsb, P->ywork.p);
     if (mode & 4) vec_gather(P, yout, P->ywork.p, false);
     else SDM_HIP_CHECK(hipMemcpyAsync(yout, P->ywork.p, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, P->stream));
     return true;

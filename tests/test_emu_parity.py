@@ -191,3 +191,52 @@ def test_big_single_front_solves(refmex):
     rhs = rng.standard_normal((m, 1))
     assert relerr(mex.fwblkslv(L, rhs), refmex.call("fwblkslv", 1, L, rhs)) < TOL
     assert relerr(mex.bwblkslv(L, rhs), refmex.call("bwblkslv", 1, L, rhs)) < TOL
+
+
+def _bordered_blocks(n1, n2, nc, rng):
+    """Two dense diagonal blocks, each coupled to a dense trailing block: the leaf fronts have many rows below
+    their own columns (ms > ns)."""
+    m = n1 + n2 + nc
+    X = np.zeros((m, m))
+    X[:n1, :n1] = rng.standard_normal((n1, n1)); X[n1:n1 + n2, n1:n1 + n2] = rng.standard_normal((n2, n2))
+    X[n1 + n2:, :] = rng.standard_normal((nc, m))
+    X = 0.1 * (X + X.T) / np.sqrt(m)
+    X = X + np.diag(np.abs(X).sum(axis=1) + 1.0)
+    X = sp.csc_matrix(X); X.sort_indices()
+    return X
+
+
+@pytest.mark.parametrize("n1,n2,nc", [(100, 130, 900), (128, 65, 900), (64, 192, 900), (128, 200, 841)])
+def test_pipelined_sweeps_full_workgroup_fronts(refmex, glue, n1, n2, nc):
+    """Fronts of >= 961 rows run the sweeps with 16 wavefronts and the look-ahead schedule (front_fw_pipe /
+    front_bw_pipe): rows right below a panel from prefetched registers, rows beyond overlapped with the next in-block
+    solve, partial last panels, odd row counts, rows below the supernode's own columns."""
+    from oracle import glue as gl
+    from sedumi_amd import mex
+    rng = np.random.default_rng(n1 + nc)
+    X = _bordered_blocks(n1, n2, nc, rng)
+    L = glue.symbchol(X)
+    xs = L["xsuper"].ravel().astype(int)
+    assert xs.size - 1 >= 2 and np.diff(L["L"].indptr)[xs[0] - 1] >= 961 > xs[1] - xs[0]
+    r = refmex.call("blkchol", 4, L, X, gl.default_pars_chol())
+    L2 = dict(L); L2["L"] = r[0]
+    rhs = rng.standard_normal((X.shape[0], 2))
+    for rev in (0, 1):
+        _set_reverse(rev)
+        assert relerr(mex.fwblkslv(L2, rhs), refmex.call("fwblkslv", 1, L2, rhs)) < TOL
+        assert relerr(mex.bwblkslv(L2, rhs), refmex.call("bwblkslv", 1, L2, rhs)) < TOL
+    _set_reverse(0)
+
+
+@pytest.mark.parametrize("m", [961, 1000, 1023])
+def test_pipelined_sweeps_single_front(refmex, m):
+    """Single dense front just below BIG_FRONT rows: the whole solve in one launch (k_ldl_single) on the look-ahead
+    schedule; m = 1023 has an odd row count, m = 1000 a partial last panel."""
+    from sedumi_amd import mex, problem
+    rng = np.random.default_rng(m)
+    Lv = np.tril(rng.standard_normal((m, m)) * (0.3 / np.sqrt(m)), -1) + np.eye(m)
+    L = problem.dense_symbolic(m)
+    L["L"] = sp.csc_matrix(Lv)
+    rhs = rng.standard_normal((m, 1))
+    assert relerr(mex.fwblkslv(L, rhs), refmex.call("fwblkslv", 1, L, rhs)) < TOL
+    assert relerr(mex.bwblkslv(L, rhs), refmex.call("bwblkslv", 1, L, rhs)) < TOL

@@ -39,3 +39,14 @@ print("factor, work-item 0 of every workgroup, us summed: panel: load %.0f sweep
       % tuple(v[16:24]))
 print("  rows kernel: S load+bar %.0f | (per wave-0) blocked substitution %.0f | total rows fn %.0f   update kernel: loads+fill %.0f mfma %.0f rmw %.0f"
       % (v[24], v[26], v[27], v[28], v[29], v[30]))
+
+rhs = np.random.default_rng(0).standard_normal(P.m)
+plan.upload("rhs", rhs)
+plan.ldlsolve(); plan.sync()
+lib.sdm_debug_phases_chol(buf, 1)
+plan.ldlsolve(); plan.sync()
+lib.sdm_debug_phases_chol(buf, 0)
+v = np.array(list(buf), dtype=np.float64) / 100.0
+print("solve (one launch, work-item 0, us): fw: stage %.1f | in-block solves %.1f | wait for stream %.1f | wait for next-block rows %.1f | far-wave stream (n/a) %.1f | tail %.1f"
+      % tuple(v[0:6]))
+print("  bw: prologue %.1f | next-block dots + barrier %.1f | in-block solves %.1f | wait for stream %.1f" % (v[8], v[9], v[10], v[11]))

@@ -451,7 +451,8 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
 #pragma unroll
     for (int q = 0; q < NB / (LDL_THREADS / 64); q++) {
       const int j = ty + ny * q;
-      if (j < NB) { S[tx][j] = (tx < kb && j <= tx) ? sv[q] : 0.0; Lc[j * NB + tx] = 0.0; }
+      // (columns beyond a partial block: unit diagonal, so that the straight-line sweep stays finite there)
+      if (j < NB) { S[tx][j] = (tx < kb && j <= tx) ? sv[q] : ((tx == j && tx >= kb) ? 1.0 : 0.0); Lc[j * NB + tx] = 0.0; }
     }
   }
   if (tid < NB) { lbs[tid] = tid < kb ? lb[first + k0 + tid] : 0.0; ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
@@ -466,7 +467,6 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   const int nsw = (kb + SW - 1) / SW;
   if (ty == 0) {
     SDM_SETPRIO(3);
-    bool bad = false;
     const double mylb = lbs[tx];
     double xs[SW];                                                     // columns of the sweep just finished (unscaled)
     for (int s = -1; s < nsw - 1; s++) {
@@ -494,30 +494,32 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
             for (int cc = 0; cc < SW; cc++) x[cc] -= lj[k][cc] * xs[kh + k];
         }
       }
-      double dval = 0.0, pval = 0.0;
-      int stat = 0;
 #pragma unroll
       for (int k = 0; k < SW; k++) {
         const int gc = cn + k;
         const double xkk = sdm_bcast_lane(x[k], gc);
-        const double lbk = sdm_bcast_lane(mylb, gc);
-        const bool live = gc < kb;                                     // uniform
-        const bool accept = live && xkk > lbk;                         // uniform
-        bad = bad || (accept && ms - (k0 + gc) > 1 && xkk < ub);       // needs the column probe: general path below
+        const bool accept = sdm_lane_pred(x[k] > mylb, gc);           // uniform: the pivot's own lane decides (x_kk > lb_k)
         const double l = accept ? x[k] / xkk : 0.0;                    // skipped pivot: unit column
 #pragma unroll
         for (int j = k + 1; j < SW; j++) x[j] -= sdm_bcast_lane(l, cn + j) * x[k];
         lsc[k] = l;
-        if (tx == gc) { dval = accept ? xkk : 0.0; stat = (live && !accept) ? 1 : 0; pval = xkk; }
       }
-      if (tx >= cn && tx < cn + SW && tx < kb) { ds[tx] = dval; stt[tx] = stat; pv[tx] = stat ? pval : 0.0; }
+      // rows above the diagonal carry don't-care values from here on (nobody reads them: every consumer of S and Lc
+      // is restricted to the lower triangle), which saves the masks
 #pragma unroll
       for (int k = 0; k < SW; k++) {
-        Lc[(cn + k) * NB + tx] = (tx > cn + k) ? lsc[k] : 0.0;
-        if (tx >= cn + k) S[tx][cn + k] = x[k];                        // rows above the diagonal stay 0
+        Lc[(cn + k) * NB + tx] = lsc[k];
+        S[tx][cn + k] = x[k];
         xs[k] = x[k];
       }
-      if (bad && tx == 0) badflag = 1;
+      SDM_WAVE_SYNC();
+      if (tx >= cn && tx < cn + SW && tx < kb) {                       // bookkeeping of pivot tx in lane tx
+        const double pval = S[tx][tx];
+        const bool acc = pval > mylb;
+        ds[tx] = acc ? pval : 0.0;
+        if (!acc) { stt[tx] = 1; pv[tx] = pval; }
+        if (acc && ms - (k0 + tx) > 1 && pval < ub) badflag = 1;       // needs the column probe: general path below
+      }
       SDM_PHASE(17);
       __syncthreads();
       SDM_PHASE(19);

@@ -17,6 +17,8 @@ inline double sdm_bcast_lane(double v, int lane) { return emu_shfl(v, lane, 0); 
 // real rendezvous; on the GPU the lanes are in lockstep and LDS operations of a wave complete in order
 #define SDM_WAVE_SYNC() ((void)emu_shfl(0.0, 0, 0))
 #define SDM_SETPRIO(n) do {} while (0)
+// predicate of lane `lane` (uniform), delivered to every lane
+inline bool sdm_lane_pred(bool pred, int lane) { return emu_shfl(pred ? 1.0 : 0.0, lane, 0) != 0.0; }
 #else
 #include <hip/hip_runtime.h>
 typedef double sdm_double4 __attribute__((ext_vector_type(4)));
@@ -28,6 +30,8 @@ typedef double2 sdm_double2;
 #define SDM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 // issue priority of the calling wavefront (s_setprio): the wave on a kernel's dependency chain ahead of its helpers
 #define SDM_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+// predicate of lane `lane` (uniform), delivered to every lane: one compare into a lane mask, one scalar bit test
+__device__ __forceinline__ bool sdm_lane_pred(bool pred, int lane) { return (__ballot(pred) >> lane) & 1ull; }
 // v_readlane_b32 x2: a scalar broadcast, no LDS crossbar round trip (ds_bpermute) on the dependency chain
 __device__ __forceinline__ double sdm_bcast_lane(double v, int lane) {
   union { double d; int i[2]; } u;

@@ -132,7 +132,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
     for (int i = b; i < e; i++) maxms = std::max(maxms, C.sn_ms[C.levlist[i]]);
     C.lev_T[l] = std::max(1, std::min(128, maxms / 16));
     for (int p = 0; p * NB < maxns; p++) {
-      LevelLaunch L; L.level = l; L.panel = p; L.nactive = 0; L.maxrows = 0; L.maxtiles = 0;
+      LevelLaunch L; L.level = l; L.panel = p; L.nactive = 0; L.maxrows = 0; L.maxtiles = 0; L.lasttiles = 0;
       for (int i = b; i < e; i++) {
         int s = C.levlist[i];
         if (C.sn_ns[s] <= p * NB) break;
@@ -142,6 +142,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
         L.maxrows = std::max(L.maxrows, rows);
         int nt = (rows + TILE - 1) / TILE;
         L.maxtiles = std::max(L.maxtiles, nt * (nt + 1) / 2);
+        if (C.sn_ns[s] <= (p + 1) * NB) L.lasttiles = std::max(L.lasttiles, nt * (nt + 1) / 2);
       }
       C.launches.push_back(L);
     }
@@ -157,7 +158,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   C.frontsT.alloc((size_t)C.tsize);
   { std::vector<int64_t> l64(C.Ljc.begin(), C.Ljc.end()); C.d_Ljc.upload(l64); }
   C.fronts.alloc((size_t)C.fsize); C.wvec.alloc((size_t)C.wsize); C.colbuf.alloc((size_t)C.wsize + (size_t)nsuper);
-  C.d.alloc(m); C.dsolve.alloc(m); C.lb.alloc(m); C.pivval.alloc(m); C.pivstat.alloc(m); C.ub.alloc(2);
+  C.d.alloc(m); C.dsolve.alloc(m); C.lb.alloc(m); C.pivval.alloc(m); C.pivstat.alloc(m); C.ub.alloc(2); C.upd_cnt.alloc((size_t)std::max<sdm_int>(1, C.nsuper));
   P->ada_val.alloc((size_t)C.nnzADA); P->absd.alloc(m); P->lpr.alloc((size_t)C.nnzL);
   P->rhs.alloc(m); P->y.alloc(m); P->ywork.alloc(m);
   P->has_chol = true; P->factored = false;
@@ -191,8 +192,9 @@ __global__ void k_load_factor(double *F, double *FT, const double *Lpr, const in
 //   ub = max_j P(perm_j,perm_j) / maxu^2 ;  lb_j = max(abstol, canceltol * orgd_j)
 __global__ void k_prep_pivots(int m, const double *ada, const int *asm_src, const int64_t *Ljc, const int *perm,
                               const double *absd, int use_absd, double canceltol, double maxu, double abstol,
-                              double *lb, double *ub, int *pivstat, double *pivval) {
+                              double *lb, double *ub, int *pivstat, double *pivval, int nsuper, int *upd_cnt) {
   __shared__ double red[256];
+  for (int i = threadIdx.x; i < nsuper; i += blockDim.x) upd_cnt[i] = 0;     // tile counters of k_ldl_panel
   double mx = 0.0;
   for (int j = threadIdx.x; j < m; j += blockDim.x) {
     int s = asm_src[Ljc[j]];
@@ -291,6 +293,119 @@ __device__ __noinline__ double pivot_probe(const double (*S)[NB + 1], const doub
   return val;
 }
 
+// ---- K3: trailing update C -= L21 * D * L21' on the FP64 matrix cores, one 64x64 lower tile per workgroup.
+// NW wavefronts share the tile: 4 (32x32 quadrants of 2x2 v_mfma_f64_16x16x4_f64 tiles) in the stand-alone kernel,
+// 8 (32x16 blocks) when the update rides along with the next diagonal-block launch.  The product is formed
+// transposed (D^T = B * A^T) so that the 16 consecutive lanes of a result register map to 16 consecutive rows of
+// the column-major front: coalesced read-modify-write.  As[k][i] = L21[I-tile row i][k], Bs[k][j] = L21[J-tile
+// row j][k] * d_k, dsh = NB doubles (all LDS).
+// DIAG (tile (0,0) in the workgroup that factors the next diagonal block right away): the result also goes to LDS
+// as that kernel's S / Lc arrays (which overlay As / Bs), kbn = columns of the next panel.
+template <int NW, bool DIAG>
+__device__ __forceinline__ void update_tile(double *Fs, int ld, int ms, int first, int k0, int kb, int I, int J, const double *d,
+                                            double (*As)[TILE], double (*Bs)[TILE], double *dsh,
+                                            double (*S)[NB + 1] = nullptr, double *Lc = nullptr, int kbn = 0) {
+  constexpr int BJ = 8 / NW;                                  // 16-column MFMA tiles per wavefront along J
+  const int r0 = k0 + kb;
+  const int tid = threadIdx.x;
+  SDM_PHASE_BEGIN();
+  if (tid < NB) dsh[tid] = tid < kb ? d[first + k0 + tid] : 0.0;
+  const int w = tid >> 6, l = tid & 63;
+  const int wi = NW == 4 ? w >> 1 : w >> 2, wj = NW == 4 ? w & 1 : w & 3;
+  const int cj = wj * 16 * BJ;                                // first tile column of this wavefront
+  const int lk = l >> 4, ll = l & 15;
+  // read-modify-write of the tile: its loads go out together with the operands' (one memory round trip for both)
+  double cv[2][BJ][4];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < BJ; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int jj = lk + 4 * r;                 // result row  -> J dimension (front column)
+        const int gi = r0 + I * TILE + wi * 32 + a * 16 + ll;
+        const int gj = r0 + J * TILE + cj + b * 16 + jj;
+        cv[a][b][r] = Fs[(int64_t)min(gj, ms - 1) * ld + min(gi, ms - 1)];
+      }
+  {
+    // all loads of a work-item are issued before the first use (addresses clamped, masked afterwards): one
+    // memory round trip per tile instead of one per element
+    const int i = tid & 63, kq = tid >> 6;
+    const int ri = r0 + I * TILE + i, rj = r0 + J * TILE + i;
+    const double *pa = Fs + min(ri, ms - 1), *pb = Fs + min(rj, ms - 1);
+    double av[NB / NW], bv[NB / NW];
+#pragma unroll
+    for (int q = 0; q < NB / NW; q++) {
+      const int64_t off = (int64_t)(k0 + min(kq + NW * q, kb - 1)) * ld;
+      av[q] = pa[off]; bv[q] = pb[off];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NB / NW; q++) {
+      const int k = kq + NW * q;
+      As[k][i] = (k < kb && ri < ms) ? av[q] : 0.0;
+      Bs[k][i] = (k < kb && rj < ms) ? bv[q] * dsh[k] : 0.0;
+    }
+  }
+  __syncthreads();
+  SDM_PHASE(DIAG ? 14 : 28);
+  sdm_double4 acc[2][BJ];
+  for (int a = 0; a < 2; a++) for (int b = 0; b < BJ; b++) for (int r = 0; r < 4; r++) acc[a][b][r] = 0.0;
+  // operands of step kk+4 are fetched from LDS while the MFMAs of step kk issue (As/Bs rows beyond kb are zero)
+  double bv[BJ], av[2];
+#pragma unroll
+  for (int b = 0; b < BJ; b++) bv[b] = Bs[lk][cj + b * 16 + ll];
+#pragma unroll
+  for (int a = 0; a < 2; a++) av[a] = As[lk][wi * 32 + a * 16 + ll];
+#pragma unroll
+  for (int kk = 0; kk < NB; kk += 4) {
+    double bn[BJ], an[2];
+    const int kn = min(kk + 4, NB - 4);
+#pragma unroll
+    for (int b = 0; b < BJ; b++) bn[b] = Bs[kn + lk][cj + b * 16 + ll];
+#pragma unroll
+    for (int a = 0; a < 2; a++) an[a] = As[kn + lk][wi * 32 + a * 16 + ll];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < BJ; b++) acc[a][b] = SDM_MFMA_F64_16x16x4(bv[b], av[a], acc[a][b]);
+#pragma unroll
+    for (int b = 0; b < BJ; b++) bv[b] = bn[b];
+#pragma unroll
+    for (int a = 0; a < 2; a++) av[a] = an[a];
+  }
+  SDM_PHASE(DIAG ? 15 : 29);
+  if (DIAG) {
+    __syncthreads();                               // As / Bs are dead: S and Lc overlay them
+    const int tx = tid & 63, ty = tid >> 6;
+    for (int j = ty; j < NB; j += NW) { S[tx][j] = (tx == j && tx >= kbn) ? 1.0 : 0.0; Lc[j * NB + tx] = 0.0; }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < BJ; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int jj = lk + 4 * r;
+        const int ti = wi * 32 + a * 16 + ll, tj = cj + b * 16 + jj;
+        const int gi = r0 + I * TILE + ti, gj = r0 + J * TILE + tj;
+        if (gi < ms && gj < ms && gi >= gj) {
+          const double v = cv[a][b][r] - acc[a][b][r];
+          Fs[(int64_t)gj * ld + gi] = v;
+          if (DIAG && ti < kbn) S[ti][tj] = v;
+        }
+      }
+  SDM_PHASE(DIAG ? 31 : 30);
+}
+// lower tile t -> (I, J), I >= J
+__device__ __forceinline__ void tile_index(int t, int &I, int &J) {
+  I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((I + 1) * (I + 2) / 2 <= t) I++;
+  while (I * (I + 1) / 2 > t) I--;
+  J = t - I * (I + 1) / 2;
+}
+
 // ---- K1 (k_ldl_panel): one workgroup per front of a level, 64-column panel p: LDL' of the kb x kb diagonal
 // block; when the rows below the block fit one workgroup (<= TRSM_ROWS) they are solved here as well and the
 // block is written back in place.  Otherwise the factored block goes to the transposed copy DT only and
@@ -381,28 +496,28 @@ __device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int 
 }
 
 // rows [R, ...) of one batch below the diagonal block of panel p: S = scaled L11 (unit lower), ds = pivots (LDS)
-__device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, int k0, int kb, int batch,
+__device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, int k0, int kb, int batch, int brows,
                                            const double (*S)[NB + 1], const double *ds, double *RB) {
   SDM_FP_STRICT;
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = blockDim.x >> 6;
   const int r0 = k0 + kb;
   if (ms - min(NB, ns) >= MFMA_MIN_ROWS) {                         // per front, the same path for all its panels
     // 16 rows per wavefront at a time, blocked substitution with the GEMM part on the matrix cores
-    const int rend = min(ms, r0 + (batch + 1) * TRSM_ROWS);
-    for (int R0 = r0 + batch * TRSM_ROWS + 16 * ty; R0 < rend; R0 += 16 * ny)
+    const int rend = min(ms, r0 + (batch + 1) * brows);
+    for (int R0 = r0 + batch * brows + 16 * ty; R0 < rend; R0 += 16 * ny)
       panel_rows_mfma(Fs, ld, ms, k0, kb, R0, S, ds, RB + ty * (NB * 17), tx);
     return;
   }
   // few rows: faithful substitution, one row per work-item, 16-column chunks; x of earlier chunks parked in LDS
   double *Xs = RB;
-  const int r = r0 + batch * TRSM_ROWS + tid;
-  if (tid >= TRSM_ROWS || r >= ms) return;
+  const int r = r0 + batch * brows + tid;
+  if (tid >= brows || r >= ms) return;
   for (int c0 = 0; c0 < kb; c0 += CHK) {
     double acc[CHK], x[CHK];
 #pragma unroll
     for (int cc = 0; cc < CHK; cc++) acc[cc] = (c0 + cc < kb) ? Fs[(int64_t)(k0 + c0 + cc) * ld + r] : 0.0;
     for (int j = 0; j < c0; j++) {
-      const double xj = Xs[j * TRSM_ROWS + tid];
+      const double xj = Xs[j * brows + tid];
 #pragma unroll
       for (int cc = 0; cc < CHK; cc++) acc[cc] -= xj * S[c0 + cc][j];
     }
@@ -415,17 +530,63 @@ __device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, i
       const double dc = ds[c0 + cc];
       x[cc] = dc > 0.0 ? v : 0.0;
       if (c0 + cc < kb) Fs[(int64_t)(k0 + c0 + cc) * ld + r] = dc > 0.0 ? v / dc : 0.0;
-      if (c0 + CHK < NB) Xs[(c0 + cc) * TRSM_ROWS + tid] = x[cc];
+      if (c0 + CHK < NB) Xs[(c0 + cc) * brows + tid] = x[cc];
     }
   }
+}
+
+// Workgroup 0 of k_ldl_panel before it reads rows below its diagonal block: the tiles of the previous panel's update
+// that cover them are applied by the other workgroups of the same launch.  upd_cnt[s] counts finished tile workgroups
+// of front s since the factorisation began (reset by k_prep_pivots); all work-items call this.
+__device__ __forceinline__ void wait_prev_update(const int *cnt, int ms, int panel) {
+  if (threadIdx.x == 0) {
+    int target = 0;
+    for (int q = 1; q <= panel; q++) { const int nt = (ms - q * NB + TILE - 1) / TILE; target += nt * (nt + 1) / 2 - 1; }
+    while (sdm_signal_load(cnt) < target) SDM_SPIN_PAUSE();
+  }
+  __syncthreads();
+  SDM_ACQUIRE_FENCE();
 }
 
 __global__ void __launch_bounds__(LDL_THREADS)
 k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, double *d, double *lb, const double *ubp,
             int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src,
-            const int64_t *Ljc, int mtot) {
+            const int64_t *Ljc, int mtot, int *upd_cnt) {
   SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
   SDM_DYN_SMEM(smem);
+  // grid = (1 + tiles of the previous panel's trailing update, fronts).  Workgroup 0 of a front owns the diagonal
+  // block; the others each apply one tile of the update of panel-1 (k_ldl_update's job, hidden behind this kernel's
+  // dependency chain).  The emulator runs the workgroups of a launch one after the other: there the diagonal block
+  // comes last, so that its waits on the tile counter terminate.
+#ifdef SDM_EMU
+  const int bx = (int)gridDim.x - 1 - (int)blockIdx.x;
+#else
+  const int bx = blockIdx.x;
+#endif
+  {
+    const int s = list[blockIdx.y];
+    const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
+    if (panel > 0) {
+      const int kp = (panel - 1) * NB;                             // previous panel: full
+      const int nt = (ms - (kp + NB) + TILE - 1) / TILE;
+      if (bx >= nt * (nt + 1) / 2) return;
+      double (*As)[TILE] = (double (*)[TILE])smem;
+      double (*Bs)[TILE] = As + NB;
+      __shared__ double dsh[NB];
+      if (bx > 0) {
+        int I, J;
+        tile_index(bx, I, J);
+        update_tile<LDL_THREADS / 64, false>(F + tab.foff[s], ld, ms, first, kp, NB, I, J, d, As, Bs, dsh);
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) sdm_signal_add(&upd_cnt[s]);
+        return;
+      }
+      // tile (0,0) = this panel's diagonal block (and what lies right of / below it inside the tile): straight into S
+      update_tile<LDL_THREADS / 64, true>(F + tab.foff[s], ld, ms, first, kp, NB, 0, 0, d, As, Bs, dsh,
+                                          (double (*)[NB + 1])smem, (double *)smem + NB * (NB + 1), min(NB, ns - panel * NB));
+    } else if (bx > 0) return;
+  }
   double (*S)[NB + 1] = (double (*)[NB + 1])smem;                 // diagonal block, S[row][col]
   double *RB = (double *)smem + NB * (NB + 1);                    // Lc during the LDL', then Xs / the wave tiles of the row solve
   double *Lc = RB;                                                // Lc[k*NB+i] = l_ik
@@ -434,7 +595,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   __shared__ int badflag;
   __shared__ double red_v[LDL_THREADS];
   __shared__ int red_i[LDL_THREADS];
-  const int s = list[blockIdx.x];
+  const int s = list[blockIdx.y];
   const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
   const int k0 = panel * NB, kb = min(NB, ns - k0);
   const int r0 = k0 + kb, nrows = ms - r0;
@@ -443,7 +604,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   const int tid = threadIdx.x, bs = blockDim.x;
   const int tx = tid & 63, ty = tid >> 6, ny = bs >> 6;
   const double ub = ubp[0], maxu = ubp[1];
-  {
+  if (panel == 0) {
     double sv[NB / (LDL_THREADS / 64)];
     const double *pc = Fs + (int64_t)k0 * ld + k0 + min(tx, kb - 1);
 #pragma unroll
@@ -556,6 +717,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   const bool ok = !bad;
   if (!ok) {
     // ---- general path: one column per step by all work-items, pivot_probe available
+    if (panel > 0) wait_prev_update(upd_cnt + s, ms, panel);        // the probe reads the rows below the block
     for (int j = ty; j < NB; j += ny) { S[tx][j] = (tx < kb && j <= tx) ? Fs[(int64_t)(k0 + j) * ld + k0 + tx] : 0.0; Lc[j * NB + tx] = 0.0; }
     if (tid < NB) { ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
     __syncthreads();
@@ -604,11 +766,14 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
     }
   }
   SDM_PHASE(22);
-  if (nrows > 0 && nrows <= TRSM_ROWS) panel_rows(Fs, ld, ns, ms, k0, kb, 0, S, ds, RB);
+  if (nrows > 0 && nrows <= TRSM_ROWS) {
+    if (panel > 0 && ok) wait_prev_update(upd_cnt + s, ms, panel);
+    panel_rows(Fs, ld, ns, ms, k0, kb, 0, TRSM_ROWS, S, ds, RB);
+  }
   SDM_PHASE(23);
 }
 
-// ---- K1b: rows below the diagonal block for fronts with more than TRSM_ROWS of them.  grid = (row batches,
+// ---- K1b: rows below the diagonal block for fronts with more than TRSM_ROWS of them.  grid = (row batches of ROWS_BATCH,
 // fronts of the level); L11 and d come from K1 (DT / d), batch 0 copies the factored block in place.
 __global__ void __launch_bounds__(PANEL_THREADS)
 k_ldl_rows(double *F, const double *DT, FrontTab tab, const int *list, int panel, const double *d) {
@@ -620,16 +785,17 @@ k_ldl_rows(double *F, const double *DT, FrontTab tab, const int *list, int panel
   const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
   const int k0 = panel * NB, kb = min(NB, ns - k0);
   const int nrows = ms - (k0 + kb), batch = blockIdx.x;
-  if (nrows <= TRSM_ROWS || batch * TRSM_ROWS >= nrows) return;    // uniform (small fronts were finished by K1)
+  if (nrows <= TRSM_ROWS || batch * ROWS_BATCH >= nrows) return;   // uniform (small fronts were finished by K1)
   double *Fs = F + tab.foff[s];
   const double *Ds = DT + tab.toff[s] + (int64_t)panel * NB * NB;    // Ds[i*NB + j] = L(k0+i, k0+j)
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = blockDim.x >> 6;
   {
-    double sv[NB / 8];                                              // PANEL_THREADS = 8 wavefronts: 8 rows of L11 per work-item
+    constexpr int NQ = NB / (PANEL_THREADS / 64);                   // rows of L11 per work-item
+    double sv[NQ];
 #pragma unroll
-    for (int q = 0; q < NB / 8; q++) sv[q] = Ds[min(ty + ny * q, NB - 1) * NB + tx];
+    for (int q = 0; q < NQ; q++) sv[q] = Ds[min(ty + ny * q, NB - 1) * NB + tx];
 #pragma unroll
-    for (int q = 0; q < NB / 8; q++) { const int i = ty + ny * q; if (i < NB) S[i][tx] = (i < kb && tx < i) ? sv[q] : 0.0; }
+    for (int q = 0; q < NQ; q++) { const int i = ty + ny * q; if (i < NB) S[i][tx] = (i < kb && tx < i) ? sv[q] : 0.0; }
   }
   if (tid < NB) ds[tid] = tid < kb ? d[first + k0 + tid] : 0.0;
   if (batch == 0)
@@ -638,111 +804,28 @@ k_ldl_rows(double *F, const double *DT, FrontTab tab, const int *list, int panel
   SDM_PHASE_BEGIN();
   __syncthreads();
   SDM_PHASE(24);
-  panel_rows(Fs, ld, ns, ms, k0, kb, batch, S, ds, RB);
+  panel_rows(Fs, ld, ns, ms, k0, kb, batch, ROWS_BATCH, S, ds, RB);
   SDM_PHASE(27);
 }
 
-// ---- K3: trailing update C -= L21 * D * L21' on the FP64 matrix cores.
-// One 64x64 lower tile per workgroup (4 waves, each a 32x32 quadrant made of
-// 2x2 v_mfma_f64_16x16x4_f64 tiles).  The product is formed transposed
-// (D^T = B * A^T) so that the 16 consecutive lanes of a result register map to
-// 16 consecutive rows of the column-major front: coalesced read-modify-write.
+// stand-alone update: only for the LAST panel of a supernode (update of the rows beyond it, passed up to the parent);
+// the update of every other panel rides along with the diagonal-block launch of the next panel (k_ldl_panel)
 __global__ void __launch_bounds__(256)
 k_ldl_update(double *F, FrontTab tab, const int *list, int panel, const double *d) {
-  __shared__ double As[NB][TILE];   // As[k][i] = L21[I-tile row i][k]
-  __shared__ double Bs[NB][TILE];   // Bs[k][j] = L21[J-tile row j][k] * d_k
+  __shared__ double As[NB][TILE];
+  __shared__ double Bs[NB][TILE];
+  __shared__ double dsh[NB];
   const int s = list[blockIdx.y];
   const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
   const int k0 = panel * NB, kb = min(NB, ns - k0);
-  const int r0 = k0 + kb, nrem = ms - r0;
+  if (ns > k0 + NB) return;                                   // not the last panel
+  const int nrem = ms - (k0 + kb);
   const int nt = (nrem + TILE - 1) / TILE;
   const int t = blockIdx.x;
   if (t >= nt * (nt + 1) / 2) return;
-  int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while ((I + 1) * (I + 2) / 2 <= t) I++;
-  while (I * (I + 1) / 2 > t) I--;
-  const int J = t - I * (I + 1) / 2;
-  double *Fs = F + tab.foff[s];
-  const int tid = threadIdx.x;
-  __shared__ double dsh[NB];
-  SDM_PHASE_BEGIN();
-  if (tid < NB) dsh[tid] = tid < kb ? d[first + k0 + tid] : 0.0;
-  {
-    // all 32 loads of a work-item are issued before the first use (addresses clamped, masked afterwards): one
-    // memory round trip per tile instead of one per element
-    const int i = tid & 63, kq = tid >> 6;
-    const int ri = r0 + I * TILE + i, rj = r0 + J * TILE + i;
-    const double *pa = Fs + min(ri, ms - 1), *pb = Fs + min(rj, ms - 1);
-    double av[NB / 4], bv[NB / 4];
-#pragma unroll
-    for (int q = 0; q < NB / 4; q++) {
-      const int64_t off = (int64_t)(k0 + min(kq + 4 * q, kb - 1)) * ld;
-      av[q] = pa[off]; bv[q] = pb[off];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < NB / 4; q++) {
-      const int k = kq + 4 * q;
-      As[k][i] = (k < kb && ri < ms) ? av[q] : 0.0;
-      Bs[k][i] = (k < kb && rj < ms) ? bv[q] * dsh[k] : 0.0;
-    }
-  }
-  __syncthreads();
-  SDM_PHASE(28);
-  const int w = tid >> 6, l = tid & 63;
-  const int wi = w >> 1, wj = w & 1;
-  sdm_double4 acc[2][2];
-  for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) for (int r = 0; r < 4; r++) acc[a][b][r] = 0.0;
-  const int lk = l >> 4, ll = l & 15;
-  // operands of step kk+4 are fetched from LDS while the 4 MFMAs of step kk issue (As/Bs rows beyond kb are zero)
-  double bv[2], av[2];
-#pragma unroll
-  for (int b = 0; b < 2; b++) bv[b] = Bs[lk][wj * 32 + b * 16 + ll];
-#pragma unroll
-  for (int a = 0; a < 2; a++) av[a] = As[lk][wi * 32 + a * 16 + ll];
-#pragma unroll
-  for (int kk = 0; kk < NB; kk += 4) {
-    double bn[2], an[2];
-    const int kn = min(kk + 4, NB - 4);
-#pragma unroll
-    for (int b = 0; b < 2; b++) bn[b] = Bs[kn + lk][wj * 32 + b * 16 + ll];
-#pragma unroll
-    for (int a = 0; a < 2; a++) an[a] = As[kn + lk][wi * 32 + a * 16 + ll];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < 2; b++) acc[a][b] = SDM_MFMA_F64_16x16x4(bv[b], av[a], acc[a][b]);
-#pragma unroll
-    for (int b = 0; b < 2; b++) bv[b] = bn[b];
-#pragma unroll
-    for (int a = 0; a < 2; a++) av[a] = an[a];
-  }
-  SDM_PHASE(29);
-  // read-modify-write of the tile: the 16 loads first, then the 16 stores
-  double cv[2][2][4];
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int b = 0; b < 2; b++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int jj = lk + 4 * r;                 // result row  -> J dimension (front column)
-        const int gi = r0 + I * TILE + wi * 32 + a * 16 + ll;
-        const int gj = r0 + J * TILE + wj * 32 + b * 16 + jj;
-        cv[a][b][r] = Fs[(int64_t)min(gj, ms - 1) * ld + min(gi, ms - 1)];
-      }
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int b = 0; b < 2; b++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int jj = lk + 4 * r;
-        const int gi = r0 + I * TILE + wi * 32 + a * 16 + ll;
-        const int gj = r0 + J * TILE + wj * 32 + b * 16 + jj;
-        if (gi < ms && gj < ms && gi >= gj) Fs[(int64_t)gj * ld + gi] = cv[a][b][r] - acc[a][b][r];
-      }
-  SDM_PHASE(30);
+  int I, J;
+  tile_index(t, I, J);
+  update_tile<4, false>(F + tab.foff[s], ld, ms, first, k0, kb, I, J, d, As, Bs, dsh);
 }
 
 // ================================================================== solves
@@ -1514,21 +1597,23 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
   SDM_KLAUNCH(P, k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
              C.d_asm_dst.p, (int64_t)C.nnzL);
   SDM_KLAUNCH(P, k_prep_pivots, dim3(1), dim3(256), 0, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
-             P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p);
+             P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, (int)C.nsuper, C.upd_cnt.p);
   for (int l = 0; l < C.nlevels; l++) {
     const int *list = C.d_levlist.p + C.levptr[l];
     const int nfr = C.levptr[l + 1] - C.levptr[l];
     if (l > 0) SDM_KLAUNCH(P, k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, C.fronts.p, tab, list);
     for (int li = C.lev_first_launch[l]; li < C.lev_first_launch[l + 1]; li++) {
       const LevelLaunch &L = C.launches[li];
-      SDM_KLAUNCH(P, k_ldl_panel, dim3(L.nactive), dim3(LDL_THREADS), PANEL_LDS, C.fronts.p, C.frontsT.p, tab, list,
+      // the trailing update of the previous panel rides along (tiles 1.. in extra workgroups, tile 0 in workgroup 0)
+      const int ntile = L.panel > 0 ? std::max(1, C.launches[li - 1].maxtiles) : 1;
+      SDM_KLAUNCH(P, k_ldl_panel, dim3(ntile, L.nactive), dim3(LDL_THREADS), PANEL_LDS, C.fronts.p, C.frontsT.p, tab, list,
                   L.panel, C.d.p, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p,
-                  C.d_Ljc.p, m);
+                  C.d_Ljc.p, m, C.upd_cnt.p);
       if (L.maxrows > TRSM_ROWS)
-        SDM_KLAUNCH(P, k_ldl_rows, dim3((L.maxrows + TRSM_ROWS - 1) / TRSM_ROWS, L.nactive), dim3(PANEL_THREADS), PANEL_LDS,
+        SDM_KLAUNCH(P, k_ldl_rows, dim3((L.maxrows + ROWS_BATCH - 1) / ROWS_BATCH, L.nactive), dim3(PANEL_THREADS), PANEL_LDS,
                     C.fronts.p, C.frontsT.p, tab, list, L.panel, C.d.p);
-      if (L.maxrows > 0)
-        SDM_KLAUNCH(P, k_ldl_update, dim3(L.maxtiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p);
+      if (L.lasttiles > 0)                                           // supernodes that end with this panel and have rows beyond
+        SDM_KLAUNCH(P, k_ldl_update, dim3(L.lasttiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p);
     }
   }
   SDM_KLAUNCH(P, k_dsolve, dim3((m + 255) / 256), dim3(256), 0, C.dsolve.p, C.d.p, m);

@@ -22,14 +22,15 @@ constexpr int BIGW = 256;             // width of a super-panel of the big-front
 constexpr int PIPE_MIN_ROWS = 256;     // fronts with at least this many rows run the sweeps on the look-ahead schedule
 constexpr int SOLVE_THREADS = 1024;   // workgroup of the per-front solve kernels (16 waves stream the panel)
 constexpr int SW = 8;                 // columns of the diagonal block swept in registers at a time (readlane chain), rest via LDS
-constexpr int LDL_THREADS = 512;      // workgroup of the diagonal-block kernel: 4 wavefronts, one per SIMD (every wave runs the same register sweep)
-constexpr int PANEL_THREADS = 512;    // workgroup of the row-solve kernel (8 wavefronts)
-constexpr int TRSM_ROWS = 128;        // rows below the diagonal block solved per workgroup (16 per wavefront on the matrix cores)
+constexpr int LDL_THREADS = 512;      // workgroup of the diagonal-block kernel: wavefront 0 sweeps, the other 7 apply the previous sweep
+constexpr int PANEL_THREADS = 256;    // workgroup of the row-solve kernel: 4 wavefronts, one per SIMD (the solve is issue bound)
+constexpr int ROWS_BATCH = 16 * (PANEL_THREADS / 64);   // rows per workgroup of the row-solve kernel (16 per wavefront on the matrix cores)
+constexpr int TRSM_ROWS = 128;        // up to this many rows below the diagonal block are solved by the diagonal-block kernel itself
 constexpr int MFMA_MIN_ROWS = 256;    // fronts with fewer rows below their first panel use the bit-faithful row substitution
 constexpr int CHK = 16;               // column chunk of the row substitution held in registers
-constexpr int PANEL_RB = (PANEL_THREADS / 64) * NB * 17;   // doubles: max(Lc 64x64, Xs 48 x TRSM_ROWS, 8 wave tiles 64x17)
+constexpr int PANEL_RB = (LDL_THREADS / 64) * NB * 17;     // doubles: max(Lc 64x64, Xs 48 x TRSM_ROWS, 8 wave tiles 64x17)
 constexpr size_t PANEL_LDS = (size_t)(NB * (NB + 1) + PANEL_RB) * sizeof(double);
-static_assert(PANEL_RB >= NB * NB && PANEL_RB >= (NB - CHK) * TRSM_ROWS && TRSM_ROWS == 16 * (PANEL_THREADS / 64), "panel LDS layout");
+static_assert(PANEL_RB >= NB * NB && PANEL_RB >= (NB - CHK) * TRSM_ROWS && TRSM_ROWS == 16 * (LDL_THREADS / 64) && ROWS_BATCH <= TRSM_ROWS, "panel LDS layout");
 static_assert(NB == SNB, "the transposed diagonal blocks written by the factor are read by the solves");
 
 template <class T>
@@ -69,6 +70,7 @@ struct LevelLaunch {
   int nactive;          // fronts (prefix of the level list, sorted by n_s desc) with n_s > p*NB
   int maxrows;          // max over active fronts of rows below the panel's diagonal block
   int maxtiles;         // max number of TILE x TILE lower tiles in the trailing update
+  int lasttiles;        // the same over the fronts whose LAST panel this is (stand-alone update launch)
 };
 
 struct CholPlan {
@@ -88,6 +90,7 @@ struct CholPlan {
   DevBuf<int> d_asm_src;
   DevBuf<double> fronts, frontsT, wvec, colbuf, d, dsolve, lb, pivval, ub;
   DevBuf<int> pivstat;
+  DevBuf<int> upd_cnt;     // per front: finished tile workgroups of the updates that rode along with k_ldl_panel
 };
 
 // ----------------------------------------------------------------- ada plan

@@ -19,6 +19,11 @@ inline double sdm_bcast_lane(double v, int lane) { return emu_shfl(v, lane, 0); 
 #define SDM_SETPRIO(n) do {} while (0)
 // predicate of lane `lane` (uniform), delivered to every lane
 inline bool sdm_lane_pred(bool pred, int lane) { return emu_shfl(pred ? 1.0 : 0.0, lane, 0) != 0.0; }
+// completion counters between workgroups of one launch (the emulator runs workgroups one after the other)
+inline void sdm_signal_add(int *p) { *p += 1; }
+inline int sdm_signal_load(const int *p) { return *p; }
+#define SDM_ACQUIRE_FENCE() do {} while (0)
+#define SDM_SPIN_PAUSE() do { fprintf(stderr, "hipemu: waiting on a workgroup that has not run\n"); abort(); } while (0)
 #else
 #include <hip/hip_runtime.h>
 typedef double sdm_double4 __attribute__((ext_vector_type(4)));
@@ -30,6 +35,12 @@ typedef double2 sdm_double2;
 #define SDM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 // issue priority of the calling wavefront (s_setprio): the wave on a kernel's dependency chain ahead of its helpers
 #define SDM_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+// completion counters between workgroups of one launch: release on the producer side (after __threadfence() and a
+// barrier), acquire on the consumer side, device scope (the workgroups may sit on different XCDs / L2s)
+__device__ __forceinline__ void sdm_signal_add(int *p) { __hip_atomic_fetch_add(p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int sdm_signal_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+#define SDM_ACQUIRE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define SDM_SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
 // predicate of lane `lane` (uniform), delivered to every lane: one compare into a lane mask, one scalar bit test
 __device__ __forceinline__ bool sdm_lane_pred(bool pred, int lane) { return (__ballot(pred) >> lane) & 1ull; }
 // v_readlane_b32 x2: a scalar broadcast, no LDS crossbar round trip (ds_bpermute) on the dependency chain

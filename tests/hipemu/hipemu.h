@@ -55,6 +55,7 @@ char *emu_dyn_smem();
 
 void emu_syncthreads();
 #define __syncthreads() emu_syncthreads()
+inline void __threadfence() {}
 
 typedef int hipError_t;
 typedef void *hipStream_t;

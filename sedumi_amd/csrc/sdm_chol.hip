@@ -146,6 +146,12 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
       }
       C.launches.push_back(L);
     }
+    // q0: first panel of the level whose diagonal-block launch carries the previous panel's update tiles
+    // (maxtiles does not grow with p)
+    int q0 = 1 << 30;
+    for (int li = C.lev_first_launch[l] + 1; li < (int)C.launches.size(); li++)
+      if (C.launches[li - 1].maxtiles <= FUSE_MAX_TILES) { q0 = C.launches[li].panel; break; }
+    for (int li = C.lev_first_launch[l]; li < (int)C.launches.size(); li++) C.launches[li].q0 = q0;
   }
   C.lev_first_launch[nlev] = (int)C.launches.size();
   // upload
@@ -538,10 +544,10 @@ __device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, i
 // Workgroup 0 of k_ldl_panel before it reads rows below its diagonal block: the tiles of the previous panel's update
 // that cover them are applied by the other workgroups of the same launch.  upd_cnt[s] counts finished tile workgroups
 // of front s since the factorisation began (reset by k_prep_pivots); all work-items call this.
-__device__ __forceinline__ void wait_prev_update(const int *cnt, int ms, int panel) {
+__device__ __forceinline__ void wait_prev_update(const int *cnt, int ms, int panel, int q0) {
   if (threadIdx.x == 0) {
-    int target = 0;
-    for (int q = 1; q <= panel; q++) { const int nt = (ms - q * NB + TILE - 1) / TILE; target += nt * (nt + 1) / 2 - 1; }
+    int target = 0;                                            // launches q0 .. panel carried update tiles
+    for (int q = max(q0, 1); q <= panel; q++) { const int nt = (ms - q * NB + TILE - 1) / TILE; target += nt * (nt + 1) / 2 - 1; }
     while (sdm_signal_load(cnt) < target) SDM_SPIN_PAUSE();
   }
   __syncthreads();
@@ -551,13 +557,14 @@ __device__ __forceinline__ void wait_prev_update(const int *cnt, int ms, int pan
 __global__ void __launch_bounds__(LDL_THREADS)
 k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, double *d, double *lb, const double *ubp,
             int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src,
-            const int64_t *Ljc, int mtot, int *upd_cnt) {
+            const int64_t *Ljc, int mtot, int *upd_cnt, int q0) {
   SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
   SDM_DYN_SMEM(smem);
   // grid = (1 + tiles of the previous panel's trailing update, fronts).  Workgroup 0 of a front owns the diagonal
-  // block; the others each apply one tile of the update of panel-1 (k_ldl_update's job, hidden behind this kernel's
-  // dependency chain).  The emulator runs the workgroups of a launch one after the other: there the diagonal block
-  // comes last, so that its waits on the tile counter terminate.
+  // block and applies tile 0 of the update of panel-1 itself; when that update is small enough to hide behind this
+  // kernel's dependency chain (launches q0 .. : at most FUSE_MAX_TILES tiles) the other workgroups each apply one of
+  // its other tiles, otherwise k_ldl_update has done so before this launch.  The emulator runs the workgroups of a
+  // launch one after the other: there the diagonal block comes last, so that its waits on the tile counter terminate.
 #ifdef SDM_EMU
   const int bx = (int)gridDim.x - 1 - (int)blockIdx.x;
 #else
@@ -717,7 +724,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   const bool ok = !bad;
   if (!ok) {
     // ---- general path: one column per step by all work-items, pivot_probe available
-    if (panel > 0) wait_prev_update(upd_cnt + s, ms, panel);        // the probe reads the rows below the block
+    if (panel > 0) wait_prev_update(upd_cnt + s, ms, panel, q0);    // the probe reads the rows below the block
     for (int j = ty; j < NB; j += ny) { S[tx][j] = (tx < kb && j <= tx) ? Fs[(int64_t)(k0 + j) * ld + k0 + tx] : 0.0; Lc[j * NB + tx] = 0.0; }
     if (tid < NB) { ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
     __syncthreads();
@@ -767,7 +774,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   }
   SDM_PHASE(22);
   if (nrows > 0 && nrows <= TRSM_ROWS) {
-    if (panel > 0 && ok) wait_prev_update(upd_cnt + s, ms, panel);
+    if (panel > 0 && ok) wait_prev_update(upd_cnt + s, ms, panel, q0);
     panel_rows(Fs, ld, ns, ms, k0, kb, 0, TRSM_ROWS, S, ds, RB);
   }
   SDM_PHASE(23);
@@ -808,20 +815,22 @@ k_ldl_rows(double *F, const double *DT, FrontTab tab, const int *list, int panel
   SDM_PHASE(27);
 }
 
-// stand-alone update: only for the LAST panel of a supernode (update of the rows beyond it, passed up to the parent);
-// the update of every other panel rides along with the diagonal-block launch of the next panel (k_ldl_panel)
+// stand-alone update.  Supernodes that END with this panel: all tiles (the update of the rows beyond, passed up to the
+// parent).  Supernodes with a next panel: nothing when `riding` (their tiles ride along with the diagonal-block launch
+// of the next panel, k_ldl_panel), else every tile but tile 0 (which k_ldl_panel's workgroup 0 always applies itself).
 __global__ void __launch_bounds__(256)
-k_ldl_update(double *F, FrontTab tab, const int *list, int panel, const double *d) {
+k_ldl_update(double *F, FrontTab tab, const int *list, int panel, const double *d, int riding) {
   __shared__ double As[NB][TILE];
   __shared__ double Bs[NB][TILE];
   __shared__ double dsh[NB];
   const int s = list[blockIdx.y];
   const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
   const int k0 = panel * NB, kb = min(NB, ns - k0);
-  if (ns > k0 + NB) return;                                   // not the last panel
+  const bool has_next = ns > k0 + NB;
+  if (has_next && riding) return;
   const int nrem = ms - (k0 + kb);
   const int nt = (nrem + TILE - 1) / TILE;
-  const int t = blockIdx.x;
+  const int t = blockIdx.x + (has_next ? 1 : 0);
   if (t >= nt * (nt + 1) / 2) return;
   int I, J;
   tile_index(t, I, J);
@@ -1604,16 +1613,21 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
     if (l > 0) SDM_KLAUNCH(P, k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, C.fronts.p, tab, list);
     for (int li = C.lev_first_launch[l]; li < C.lev_first_launch[l + 1]; li++) {
       const LevelLaunch &L = C.launches[li];
-      // the trailing update of the previous panel rides along (tiles 1.. in extra workgroups, tile 0 in workgroup 0)
-      const int ntile = L.panel > 0 ? std::max(1, C.launches[li - 1].maxtiles) : 1;
+      // tile 0 of the previous panel's trailing update is applied by workgroup 0 of k_ldl_panel; the other tiles ride
+      // along in extra workgroups when there are few enough to hide behind the diagonal block, else k_ldl_update
+      // has applied them (riding = 0 below)
+      const bool ride = L.panel > 0 && C.launches[li - 1].maxtiles <= FUSE_MAX_TILES;
+      const int ntile = ride ? std::max(1, C.launches[li - 1].maxtiles) : 1;
       SDM_KLAUNCH(P, k_ldl_panel, dim3(ntile, L.nactive), dim3(LDL_THREADS), PANEL_LDS, C.fronts.p, C.frontsT.p, tab, list,
                   L.panel, C.d.p, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p,
-                  C.d_Ljc.p, m, C.upd_cnt.p);
+                  C.d_Ljc.p, m, C.upd_cnt.p, L.q0);
       if (L.maxrows > TRSM_ROWS)
         SDM_KLAUNCH(P, k_ldl_rows, dim3((L.maxrows + ROWS_BATCH - 1) / ROWS_BATCH, L.nactive), dim3(PANEL_THREADS), PANEL_LDS,
                     C.fronts.p, C.frontsT.p, tab, list, L.panel, C.d.p);
-      if (L.lasttiles > 0)                                           // supernodes that end with this panel and have rows beyond
-        SDM_KLAUNCH(P, k_ldl_update, dim3(L.lasttiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p);
+      const bool next_rides = L.maxtiles <= FUSE_MAX_TILES;         // what the NEXT diagonal-block launch will carry
+      const int upd_tiles = next_rides ? L.lasttiles : L.maxtiles;
+      if (upd_tiles > 0)
+        SDM_KLAUNCH(P, k_ldl_update, dim3(upd_tiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p, next_rides ? 1 : 0);
     }
   }
   SDM_KLAUNCH(P, k_dsolve, dim3((m + 255) / 256), dim3(256), 0, C.dsolve.p, C.d.p, m);

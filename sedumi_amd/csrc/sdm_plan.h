@@ -19,6 +19,7 @@ constexpr int ELL_WAVES = 8;  // wavefronts per workgroup of the ELL stage-2 ker
 constexpr int SOLVE_LDS_MAX = 8192;   // doubles of the front-local vector kept in LDS (64 KB, next to 64 KB of staged diagonal blocks)
 constexpr int BIG_FRONT = 1024;       // single fronts from this order on: one launch per super-panel and sweep instead of one workgroup
 constexpr int BIGW = 256;             // width of a super-panel of the big-front sweeps (a multiple of SNB)
+constexpr int FUSE_MAX_TILES = 136;    // trailing updates of at most this many tiles ride along with the next diagonal-block launch
 constexpr int PIPE_MIN_ROWS = 256;     // fronts with at least this many rows run the sweeps on the look-ahead schedule
 constexpr int SOLVE_THREADS = 1024;   // workgroup of the per-front solve kernels (16 waves stream the panel)
 constexpr int SW = 8;                 // columns of the diagonal block swept in registers at a time (readlane chain), rest via LDS
@@ -71,6 +72,7 @@ struct LevelLaunch {
   int maxrows;          // max over active fronts of rows below the panel's diagonal block
   int maxtiles;         // max number of TILE x TILE lower tiles in the trailing update
   int lasttiles;        // the same over the fronts whose LAST panel this is (stand-alone update launch)
+  int q0;               // first panel of the level whose diagonal-block launch carries the previous update's tiles
 };
 
 struct CholPlan {

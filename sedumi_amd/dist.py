@@ -150,6 +150,24 @@ class SubtreeShardedSolver:
         if self.plan is not None:
             self.plan.getada(); self.plan.blkchol(self.pars, True)
 
+    def upload_rhs(self, rhs):
+        """Right-hand side of the FULL problem: every rank keeps its own segment in HBM (for solve_resident)."""
+        if self.plan is not None:
+            self.plan.upload("rhs", np.asarray(rhs, dtype=np.float64)[self.cols])
+
+    def solve_resident(self):
+        """The solve of the resident right-hand side; the gathered solution segments stay in `self.recv` (device
+        tensor when the group's backend is RCCL): no host round trip -- the form the IPM loop would use."""
+        torch, dist = _torch()
+        n = self.cols.size if self.cols is not None else 0
+        if self.plan is not None:
+            self.plan.ldlsolve()
+            if self.world == 1 and self.device.type == "cpu":
+                return None                      # one rank without a device collective: y stays in the plan
+            self.plan.copy("y", self.send, 0, n, to_plan=False)
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)       # the only exchange: solution segments
+        return self.recv
+
     def solve(self, rhs):
         """y = ADA' \\ rhs (full-length host vectors in, full-length host vector out)."""
         torch, dist = _torch()

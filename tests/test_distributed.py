@@ -56,6 +56,11 @@ def _worker(rank, world, port, case, q):
             solver.upload_scaling(d, ud, P)
             solver.factor()
             y = solver.solve(rhs)
+            solver.upload_rhs(rhs)                      # the resident form: gathered segments stay in solver.recv
+            recv = solver.solve_resident().cpu().numpy()
+            seg = solver.send.numel()
+            for qq, c in enumerate(solver.cols_of):
+                assert np.array_equal(recv[qq * seg:qq * seg + c.size], y[c])
             # single-process answer on the whole problem
             ADApat = problem.symb_ada(P); L = mex.symbchol(ADApat)
             pl = Plan(0); pl.set_chol(L, ADApat); pl.set_ada(P.At, P.Ablkjc, P.K, problem.lorentz_pattern(P))

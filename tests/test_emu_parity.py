@@ -66,12 +66,13 @@ def test_sparse_factor_and_solves(refmex, glue, kind, m):
     assert relerr(mex.bwblkslv(L2, rhs), refmex.call("bwblkslv", 1, L2, rhs)) < TOL
 
 
-@pytest.mark.parametrize("m", [130, 200, 330])
+@pytest.mark.parametrize("m", [130, 200, 330, 1216])
 def test_dense_front_with_several_row_batches(refmex, m):
     """One dense supernode whose rows below the first 64-column panel span several workgroups of the panel
     kernel (matrix-core row solve, deferred in-place copy of the diagonal block).  The emulator runs the
     workgroups of a launch one after the other, which turns any in-place update another workgroup still has
-    to read into a deterministic failure."""
+    to read into a deterministic failure.  m = 1216: the first trailing updates have more than FUSE_MAX_TILES tiles
+    (stand-alone update launches), the later ones ride along with the next diagonal-block launch."""
     from oracle import glue as gl
     from sedumi_amd import mex, problem
     rng = np.random.default_rng(m)

@@ -1063,14 +1063,20 @@ __device__ __forceinline__ void front_bw_small(const double *Fs, const double *D
 
 // ---------------------------------------------------------------- pipelined sweeps (workgroups of SOLVE_THREADS)
 // The in-block triangular solve is a 64-step dependency chain (~1.1 us) on ONE wavefront; streaming the panel is
-// bandwidth work for the others.  The two overlap: the rows below a panel are split into the 64 rows right below it
-// (the next diagonal block: needed by the next in-block solve, handled right after the barrier from registers that
-// were loaded before it) and the rows beyond, which are streamed while wavefront 0 is already solving the next block.
-// Diagonal blocks are staged in LDS alternately in the two halves of Sd2; x_p / the partial dots are double-buffered.
-constexpr int FW_CRIT = 2;               // forward: wavefronts 1..2 own the 64 rows right below the panel
-constexpr int FW_FAR0 = 1 + FW_CRIT;     //          wavefronts 3..15 stream the rows beyond
+// bandwidth work for the others.  The two overlap.  The rows below a panel are split into
+//  * the 64 rows right below it (the next diagonal block, needed by the next in-block solve): their update is
+//    accumulated by wavefront 0 INSIDE the chain -- step k broadcasts x_k anyway, one more FMA with the coefficient
+//    of the sub-diagonal block costs nothing on a latency-bound chain -- so the next solve starts right after ONE
+//    barrier;
+//  * the rows beyond, streamed by the other wavefronts while wavefront 0 is already solving the next block.
+// The diagonal block and the sub-diagonal block of the next step are staged in LDS by the streaming wavefronts,
+// alternately in the two halves of Sd2 / Sb2 (the backward sweep stores the sub-diagonal block transposed, pitch
+// SBP); x_p / the dots of the rows beyond are double-buffered.
 constexpr int BW_FARW = 13;              // backward: wavefronts 1..13 form the dots beyond (5 columns each), 14..15 stage
 constexpr int STG15 = (SNB * SNB + (SOLVE_THREADS - 64) - 1) / (SOLVE_THREADS - 64);   // staging by wavefronts 1..15
+constexpr int SBP = SNB + 1;             // row pitch of the transposed sub-diagonal block
+constexpr int TCF = 8;                   // fused in-block solve: steps per batch of coefficients (two register sets in ping-pong)
+constexpr int SOLVE_STAGE_DOUBLES = 2 * SNB * SNB + 2 * SNB * SBP;   // Sd2 then Sb2 at the head of the dynamic LDS
 
 __device__ __forceinline__ void stage15_load(double (&sv)[STG15], const double *blk, int ld, int kb) {
 #pragma unroll
@@ -1112,6 +1118,39 @@ __device__ __forceinline__ double trsv_bw_block(const double *Sd, double yi, int
     for (int k = 0; k < TCH; k++) SDM_PIN(lr[k]);
 #pragma unroll
     for (int k = TCH - 1; k >= 0; k--) yi -= lr[k] * sdm_bcast_lane(yi, h + k);
+  }
+  return yi;
+}
+// the same chain with the update of the next block riding along: cacc += sum_k Sb[k*pitch + lane] * x_k.
+// Coefficients travel in batches of TCF steps, two register sets in ping-pong: the loads of a batch are issued when
+// the batch before it starts (SDM_ZERO_AFTER pins them there) and land while its TCF steps run.
+#define SDM_FUSED_LOAD(lr, ls, h, z, PITCH)                                                       \
+  _Pragma("unroll") for (int k = 0; k < TCF; k++) { lr[k] = Sd[((h) + k) * SNB + lane + (z)]; ls[k] = Sb[((h) + k) * (PITCH) + lane + (z)]; }
+__device__ __forceinline__ double trsv_fw_fused(const double *Sd, const double *Sb, double wi, double &cacc, int lane) {
+  double lrA[TCF], lsA[TCF], lrB[TCF], lsB[TCF];
+  SDM_FUSED_LOAD(lrA, lsA, 0, 0, SNB)
+#pragma unroll
+  for (int h = 0; h < SNB; h += 2 * TCF) {
+    { const int z = SDM_ZERO_AFTER(wi); SDM_FUSED_LOAD(lrB, lsB, h + TCF, z, SNB) }
+#pragma unroll
+    for (int k = 0; k < TCF; k++) { const double xk = sdm_bcast_lane(wi, h + k); wi -= lrA[k] * xk; cacc += lsA[k] * xk; }
+    if (h + 2 * TCF < SNB) { const int z = SDM_ZERO_AFTER(wi); SDM_FUSED_LOAD(lrA, lsA, h + 2 * TCF, z, SNB) }
+#pragma unroll
+    for (int k = 0; k < TCF; k++) { const double xk = sdm_bcast_lane(wi, h + TCF + k); wi -= lrB[k] * xk; cacc += lsB[k] * xk; }
+  }
+  return wi;
+}
+__device__ __forceinline__ double trsv_bw_fused(const double *Sd, const double *Sb, double yi, double &cacc, int lane) {
+  double lrA[TCF], lsA[TCF], lrB[TCF], lsB[TCF];
+  SDM_FUSED_LOAD(lrA, lsA, SNB - TCF, 0, SBP)
+#pragma unroll
+  for (int h = SNB - TCF; h >= 0; h -= 2 * TCF) {
+    { const int z = SDM_ZERO_AFTER(yi); SDM_FUSED_LOAD(lrB, lsB, h - TCF, z, SBP) }
+#pragma unroll
+    for (int k = TCF - 1; k >= 0; k--) { const double xk = sdm_bcast_lane(yi, h + k); yi -= lrA[k] * xk; cacc += lsA[k] * xk; }
+    if (h - 2 * TCF >= 0) { const int z = SDM_ZERO_AFTER(yi); SDM_FUSED_LOAD(lrA, lsA, h - 2 * TCF, z, SBP) }
+#pragma unroll
+    for (int k = TCF - 1; k >= 0; k--) { const double xk = sdm_bcast_lane(yi, h - TCF + k); yi -= lrB[k] * xk; cacc += lsB[k] * xk; }
   }
   return yi;
 }
@@ -1193,56 +1232,70 @@ __device__ __forceinline__ void bw_far_five(const double *Fs, int ld, int k0, in
   if (lane == 1 && c0 + 4 < SNB) dots[c0 + 4] = e;
 }
 
-// forward sweep of one front, workgroup of SOLVE_THREADS; wb2 = 2*SNB doubles, Sd2 = 2*SNB*SNB doubles (LDS).
-// The three roles run their own loops over the full panels (two barriers per panel each, so the barrier counts
-// agree) -- separate loops keep the register live ranges of the roles apart.
+// sub-diagonal block below full panel k0 for the forward sweep: Sb[k*64 + i] = L(k0+64+i, k0+k), 0 for rows >= ms
+__device__ __forceinline__ void stage15_sub_load(double (&sv)[STG15], const double *Fs, int ld, int k0, int ms) {
+  const int nsub = min(SNB, ms - (k0 + SNB));
+#pragma unroll
+  for (int q = 0; q < STG15; q++) {
+    const int idx = min((int)threadIdx.x - 64 + q * (SOLVE_THREADS - 64), SNB * SNB - 1), i = idx & 63, k = idx >> 6;
+    sv[q] = nsub > 0 ? Fs[(int64_t)(k0 + k) * ld + k0 + SNB + min(i, nsub - 1)] : 0.0;
+  }
+}
+__device__ __forceinline__ void stage15_sub_store(double *Sb, const double (&sv)[STG15], int k0, int ms) {
+  const int nsub = min(SNB, ms - (k0 + SNB));
+#pragma unroll
+  for (int q = 0; q < STG15; q++) {
+    const int idx = (int)threadIdx.x - 64 + q * (SOLVE_THREADS - 64), i = idx & 63;
+    if (idx < SNB * SNB) Sb[idx] = i < nsub ? sv[q] : 0.0;
+  }
+}
+
+// forward sweep of one front, workgroup of SOLVE_THREADS; wb2 = 2*SNB doubles, Sd2 = SOLVE_STAGE_DOUBLES (LDS).
+// Wavefront 0 and the others run their own loops over the full panels (one barrier per panel each) -- separate loops
+// keep the register live ranges of the roles apart.
 __device__ __forceinline__ void front_fw_pipe(const double *Fs, int ns, int ms, int ld, double *w, double *wb2, double *Sd2) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = (tid >> 4) & 3;
   const int nfull = ns / SNB, rem = ns - nfull * SNB;
+  double *Sb2 = Sd2 + 2 * SNB * SNB;
   SDM_PHASE_BEGIN();
   stage_block(Sd2, Fs, ld, min(SNB, ns));
+  if (nfull > 0) {
+    const int nsub = min(SNB, ms - SNB);
+    for (int idx = tid; idx < SNB * SNB; idx += SOLVE_THREADS) {
+      const int i = idx & 63, k = idx >> 6;
+      Sb2[idx] = i < nsub ? Fs[(int64_t)k * ld + SNB + i] : 0.0;
+    }
+  }
   __syncthreads();
   SDM_PHASE(0);
   if (wave == 0) {
-    // ---- in-block solves
+    // ---- in-block solves; cacc = what panel p owes to the rows of block p+1
+    SDM_SETPRIO(3);                                                // the dependency chain ahead of the streaming wavefronts
+    double cacc = 0.0;
     for (int p = 0; p < nfull; p++) {
       const int k0 = p * SNB;
-      const double wi = trsv_fw_block(Sd2 + (p & 1) * SNB * SNB, w[k0 + lane], lane);
+      double cnext = 0.0;
+      const double wi = trsv_fw_fused(Sd2 + (p & 1) * SNB * SNB, Sb2 + (p & 1) * SNB * SNB, w[k0 + lane] - cacc, cnext, lane);
+      cacc = cnext;
       w[k0 + lane] = wi;
       wb2[(p & 1) * SNB + lane] = wi;
       SDM_PHASE(1);
       __syncthreads();
       SDM_PHASE(2);
-      __syncthreads();
-      SDM_PHASE(3);
     }
-  } else if (wave <= FW_CRIT) {
-    // ---- the 64 rows right below panel p: loads before the barrier, x_p applied after it
-    const int tcrit = (wave - 1) * 16 + (lane & 15);
-    for (int p = 0; p < nfull; p++) {
-      const int k0 = p * SNB, rb = k0 + SNB, k1 = rb;
-      const int ncrit = min(SNB, ms - rb), npc = max(ncrit, 0) >> 1;
-      sdm_double2 vc[16];
-      double sv[STG15];
-      if (k1 < ns) stage15_load(sv, Fs + (int64_t)k1 * ld + k1, ld, min(SNB, ns - k1));      // next diagonal block
-      if (npc > 0) fw_issue(vc, Fs, ld, k0, rb, npc, tcrit, g);
-      if (k1 < ns) stage15_store(Sd2 + ((p + 1) & 1) * SNB * SNB, sv, min(SNB, ns - k1));
-      __syncthreads();
-      if (npc > 0) fw_consume(vc, wb2 + (p & 1) * SNB, w, rb, npc, tcrit, g);
-      if (tid == 64 && ncrit > 0 && (ncrit & 1)) fw_single_row(Fs, ld, k0, SNB, rb + ncrit - 1, wb2 + (p & 1) * SNB, w);
-      __syncthreads();
-    }
+    if (nfull > 0 && nfull * SNB + lane < ms) w[nfull * SNB + lane] -= cacc;      // rows right below the last full panel
   } else {
-    // ---- the rows beyond: panel p-1 is streamed while wavefront 0 solves block p
+    // ---- the rows beyond: panel p-1 is streamed while wavefront 0 solves block p; blocks of step p+1 staged
     for (int p = 0; p < nfull; p++) {
       const int k0 = p * SNB, k1 = k0 + SNB;
-      double sv[STG15];
+      double sv[STG15], sb[STG15];
       if (k1 < ns) stage15_load(sv, Fs + (int64_t)k1 * ld + k1, ld, min(SNB, ns - k1));      // next diagonal block: loads now
+      if (p + 1 < nfull) stage15_sub_load(sb, Fs, ld, k1, ms);
       if (p > 0) {
         const int kp = k0 - SNB, ra = k0 + SNB;                                              // rows beyond block p
         const int npair = ms > ra ? (ms - ra) >> 1 : 0, lim = (npair + 15) & ~15;
         const double *wbq = wb2 + ((p - 1) & 1) * SNB;
-        for (int t = (wave - FW_FAR0) * 16 + (lane & 15); t < lim; t += (SOLVE_THREADS / 64 - FW_FAR0) * 16) {
+        for (int t = (wave - 1) * 16 + (lane & 15); t < lim; t += (SOLVE_THREADS / 64 - 1) * 16) {
           sdm_double2 v[16];
           fw_issue(v, Fs, ld, kp, ra, npair, t, g);
           fw_consume(v, wbq, w, ra, npair, t, g);
@@ -1250,11 +1303,12 @@ __device__ __forceinline__ void front_fw_pipe(const double *Fs, int ns, int ms, 
         if (tid == SOLVE_THREADS - 1 && ms > ra && ((ms - ra) & 1)) fw_single_row(Fs, ld, kp, SNB, ms - 1, wbq, w);
       }
       if (k1 < ns) stage15_store(Sd2 + ((p + 1) & 1) * SNB * SNB, sv, min(SNB, ns - k1));    // ... LDS stores after the stream
+      if (p + 1 < nfull) stage15_sub_store(Sb2 + ((p + 1) & 1) * SNB * SNB, sb, k1, ms);
       SDM_PHASE(4);
-      __syncthreads();
       __syncthreads();
     }
   }
+  __syncthreads();
   // ---- common tail: what the last full panel still owes to the rows beyond, then a partial last panel
   if (nfull > 0 && ms > nfull * SNB + SNB) {
     const int kp = (nfull - 1) * SNB, ra = nfull * SNB + SNB;
@@ -1294,52 +1348,28 @@ __device__ __forceinline__ void front_fw_pipe(const double *Fs, int ns, int ms, 
   SDM_PHASE(5);
 }
 
-// phase A of a backward step: dotsC[c] = sum over the (at most 64) rows right below full panel k0 of L(r, k0+c) w[r];
-// every wavefront 4 columns from the registers vc it loaded before the barrier
-__device__ __forceinline__ void bw_crit(const sdm_double2 (&vc)[4], const double *Fs, int ld, int k0, int rb, int ncrit, const double *w,
-                                        double *dotsC, int wave, int lane) {
-  const int npc = ncrit >> 1;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  if (lane < npc) {
-    const double w0 = w[rb + 2 * lane], w1 = w[rb + 2 * lane + 1];
-#pragma unroll
-    for (int q = 0; q < 4; q++) acc[q] = vc[q].x * w0 + vc[q].y * w1;
-  }
-  if (lane == 32 && (ncrit & 1)) {
-    const int r = rb + ncrit - 1;
-#pragma unroll
-    for (int q = 0; q < 4; q++) acc[q] = Fs[(int64_t)(k0 + 4 * wave + q) * ld + r] * w[r];
-  }
-  const double a = fold4(acc, lane);
-  if ((lane & 15) == 0) dotsC[4 * wave + (lane >= 32 ? 2 : 0) + ((lane >> 4) & 1)] = a;
-}
-__device__ __forceinline__ void bw_crit_load(sdm_double2 (&vc)[4], const double *Fs, int ld, int k0, int rb, int ncrit, int wave, int lane) {
-  const int npc = ncrit >> 1;
-  if (npc > 0) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) vc[q] = ((const sdm_double2 *)(Fs + (int64_t)(k0 + 4 * wave + q) * ld + rb))[min(lane, npc - 1)];
-  }
-}
-
-// backward sweep of one front, workgroup of SOLVE_THREADS; dots3 = 3*SNB doubles, Sd2 = 2*SNB*SNB doubles (LDS)
+// backward sweep of one front, workgroup of SOLVE_THREADS; dots3 = 2*SNB doubles, Sd2 = SOLVE_STAGE_DOUBLES (LDS)
 __device__ __forceinline__ void front_bw_pipe(const double *Fs, const double *Ds, int ns, int ms, int ld, double *w, double *dots3,
                                               double *Sd2) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int npan = (ns + SNB - 1) / SNB;
-  double *dotsC = dots3 + 2 * SNB;
-  sdm_double2 vc[4];                                       // this wavefront's 4 columns of the rows right below the panel
+  double *Sb2 = Sd2 + 2 * SNB * SNB;
   SDM_PHASE_BEGIN();
   {
-    // last panel: nothing to overlap with
+    // last panel: nothing to overlap with.  Its dots over ALL rows below it; its diagonal block, and (transposed) the
+    // block left of it, which the in-block solve uses to form what panel P-1 gets from the rows of block P.
     const int P = npan - 1, k0 = P * SNB, kb = ns - k0, rb = ns;
     double *dF = dots3 + (P & 1) * SNB;
     stage_blockT(Sd2 + (P & 1) * SNB * SNB, Ds + (int64_t)P * SNB * SNB, kb);
-    if (kb == SNB) {
-      bw_far_quad(Fs, ld, k0, kb, 4 * wave, rb + SNB, ms, w, dF, lane);
-      bw_crit_load(vc, Fs, ld, k0, rb, max(0, min(SNB, ms - rb)), wave, lane);
-    } else if (4 * wave < kb) {
-      // partial panel (rb may be odd): all rows below it in one go
-      const int ra = rb + (rb & 1), cb0 = 4 * wave;
+    if (P > 0) {
+      double *Sn = Sb2 + (P & 1) * SNB * SBP;
+      for (int idx = tid; idx < SNB * SNB; idx += SOLVE_THREADS) {
+        const int i = idx & 63, c = idx >> 6;
+        Sn[i * SBP + c] = k0 + i < ms ? Fs[(int64_t)(k0 - SNB + c) * ld + k0 + i] : 0.0;   // incl. rows beyond a partial block
+      }
+    }
+    if (4 * wave < kb) {
+      const int ra = rb + (rb & 1), cb0 = 4 * wave;               // rb is odd only for a partial panel
       bw_far_quad(Fs, ld, k0, kb, cb0, ra, ms, w, dF, lane);
       SDM_WAVE_SYNC();
       if (lane < 4 && cb0 + lane < kb && (rb & 1) && rb < ms) dF[cb0 + lane] += Fs[(int64_t)(k0 + cb0 + lane) * ld + rb] * w[rb];
@@ -1348,16 +1378,18 @@ __device__ __forceinline__ void front_bw_pipe(const double *Fs, const double *Ds
   SDM_PHASE(8);
   __syncthreads();
   if (wave == 0) {
+    SDM_SETPRIO(3);
+    double cacc = 0.0;                                             // what the rows of block p+1 give to panel p
     for (int p = npan - 1; p >= 0; p--) {
-      const int k0 = p * SNB, kb = min(SNB, ns - k0), rb = k0 + kb;
-      const int ncrit = kb == SNB ? max(0, min(SNB, ms - rb)) : 0;
-      if (ncrit > 0) bw_crit(vc, Fs, ld, k0, rb, ncrit, w, dotsC, wave, lane);
-      __syncthreads();
-      SDM_PHASE(9);
-      if (p > 0) bw_crit_load(vc, Fs, ld, k0 - SNB, k0, min(SNB, ms - k0), wave, lane);     // for the next step, in flight during the solve
+      const int k0 = p * SNB, kb = min(SNB, ns - k0);
       const double *dF = dots3 + (p & 1) * SNB;
-      double yi = lane < kb ? w[k0 + lane] - dF[lane] - (ncrit > 0 ? dotsC[lane] : 0.0) : 0.0;
-      yi = trsv_bw_block(Sd2 + (p & 1) * SNB * SNB, yi, lane);
+      // lanes beyond a partial last block carry the (final) values of the rows below it: passive in the solve (their
+      // coefficients are 0), but panel p-1 gets their contribution through the same chain
+      double yi = lane < kb ? w[k0 + lane] - dF[lane] - cacc : (k0 + lane < ms ? w[k0 + lane] : 0.0);
+      double cnext = 0.0;
+      if (p > 0) yi = trsv_bw_fused(Sd2 + (p & 1) * SNB * SNB, Sb2 + (p & 1) * SNB * SBP, yi, cnext, lane);
+      else yi = trsv_bw_block(Sd2 + (p & 1) * SNB * SNB, yi, lane);
+      cacc = cnext;
       if (lane < kb) w[k0 + lane] = yi;
       SDM_PHASE(10);
       __syncthreads();
@@ -1365,17 +1397,34 @@ __device__ __forceinline__ void front_bw_pipe(const double *Fs, const double *Ds
     }
   } else {
     for (int p = npan - 1; p >= 0; p--) {
-      const int k0 = p * SNB, kb = min(SNB, ns - k0), rb = k0 + kb;
-      const int ncrit = kb == SNB ? max(0, min(SNB, ms - rb)) : 0;
-      if (ncrit > 0) bw_crit(vc, Fs, ld, k0, rb, ncrit, w, dotsC, wave, lane);
-      __syncthreads();
+      const int k0 = p * SNB;
       if (p > 0) {
         // what panel p-1 (full) can already know: its rows beyond block p are final.  Wavefronts 1..13 five columns
-        // each, wavefronts 14..15 fetch the transposed diagonal block p-1 from DT.
+        // each; wavefronts 14..15 stage the blocks of the next step: diagonal block p-1 (transposed copy DT) and the
+        // block left of it, transposed on the way into LDS.
         const int kq = k0 - SNB, ra = k0 + SNB;
-        bw_crit_load(vc, Fs, ld, kq, k0, min(SNB, ms - k0), wave, lane);
         if (wave <= BW_FARW) {
+          // this wavefront's share of the block left of diagonal block p-1 (rows kq.., columns kq-64..), transposed
+          // on the way into LDS: loads first, stores after the dots
+          constexpr int NFT = 64 * BW_FARW, PT = (SNB * SNB / 2 + NFT - 1) / NFT;
+          const int t = tid - 64;
+          sdm_double2 tv[PT];
+          if (p > 1) {
+#pragma unroll
+            for (int q = 0; q < PT; q++) {
+              const int e = min(t + q * NFT, SNB * SNB / 2 - 1), ip = e & 31, c = e >> 5;   // rows kq+2ip, kq+2ip+1 of column kq-64+c
+              tv[q] = ((const sdm_double2 *)(Fs + (int64_t)(kq - SNB + c) * ld + kq))[ip];
+            }
+          }
           bw_far_five(Fs, ld, kq, 5 * (wave - 1), ra, ms, w, dots3 + ((p - 1) & 1) * SNB, lane);
+          if (p > 1) {
+            double *Tn = Sb2 + ((p - 1) & 1) * SNB * SBP;
+#pragma unroll
+            for (int q = 0; q < PT; q++) {
+              const int e = t + q * NFT, ip = e & 31, c = e >> 5;
+              if (e < SNB * SNB / 2) { Tn[(2 * ip) * SBP + c] = tv[q].x; Tn[(2 * ip + 1) * SBP + c] = tv[q].y; }
+            }
+          }
         } else {
           constexpr int NST = SOLVE_THREADS - 64 * (1 + BW_FARW), PER = SNB * SNB / 2 / NST;
           const sdm_double2 *Dp = (const sdm_double2 *)(Ds + (int64_t)(p - 1) * SNB * SNB);
@@ -1386,7 +1435,7 @@ __device__ __forceinline__ void front_bw_pipe(const double *Fs, const double *Ds
           for (int q = 0; q < PER; q++) sv[q] = Dp[t + q * NST];
 #pragma unroll
           for (int q = 0; q < PER; q++) {
-            const int idx = 2 * (t + q * NST), i = idx & 63, c = idx >> 6;       // Sn[c*64 + i] = L(k0+c, k0+i) for i < c
+            const int idx = 2 * (t + q * NST), i = idx & 63, c = idx >> 6;       // Sn[c*64 + i] = L(kq+c, kq+i) for i < c
             Sn[idx] = c > i ? sv[q].x : 0.0;
             Sn[idx + 1] = c > i + 1 ? sv[q].y : 0.0;
           }
@@ -1406,15 +1455,14 @@ __device__ __forceinline__ void front_bw(const double *Fs, const double *Ds, int
   else front_bw_small(Fs, Ds, ns, ms, ld, w, dots3, Sd2);
 }
 
-__global__ void __launch_bounds__(SOLVE_THREADS)
-k_fw_level(const double *F, FrontTab tab, const int *list, double *wvec, double *y, int use_lds) {
-  SDM_DYN_SMEM(smem);
-  __shared__ double wb[3 * SNB];
-  double *Sd = (double *)smem;                                    // two diagonal blocks
-  const int s = list[blockIdx.x];
+// The sweep kernels keep the front-local vector w either in LDS or (fronts beyond SOLVE_LDS_MAX rows) in HBM.  Their
+// bodies are instantiated once per case, so that every access to w is a plain LDS or a plain global instruction: a
+// pointer that may be either compiles to FLAT accesses, which queue up behind the streaming loads of the other
+// wavefronts -- measured 2 us per in-block solve of wavefront 0 instead of 1.2.
+__device__ __forceinline__ void fw_level_body(const double *F, const FrontTab &tab, int s, double *wvec, double *y, double *w, bool copy_up,
+                                              double *wb, double *Sd) {
   const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
   double *wg = wvec + tab.woff[s];
-  double *w = use_lds ? (double *)smem + 2 * SNB * SNB : wg;
   const int tid = threadIdx.x, bs = blockDim.x;
   for (int i = tid; i < ms; i += bs) w[i] = i < ns ? y[first + i] : 0.0;
   __syncthreads();
@@ -1428,18 +1476,23 @@ k_fw_level(const double *F, FrontTab tab, const int *list, double *wvec, double 
   }
   front_fw(F + tab.foff[s], ns, ms, tab.ld[s], w, wb, Sd);
   for (int i = tid; i < ns; i += bs) y[first + i] = w[i];
-  if (use_lds) for (int i = ns + tid; i < ms; i += bs) wg[i] = w[i];      // update vector for the parent
+  if (copy_up) for (int i = ns + tid; i < ms; i += bs) wg[i] = w[i];      // update vector for the parent
+}
+__global__ void __launch_bounds__(SOLVE_THREADS)
+k_fw_level(const double *F, FrontTab tab, const int *list, double *wvec, double *y, int use_lds) {
+  SDM_DYN_SMEM(smem);
+  __shared__ double wb[3 * SNB];
+  double *Sd = (double *)smem;                                    // staged diagonal / sub-diagonal blocks
+  const int s = list[blockIdx.x];
+  // use_lds = offset of w behind the staged blocks, 0 = w in HBM
+  if (use_lds) fw_level_body(F, tab, s, wvec, y, (double *)smem + use_lds, true, wb, Sd);
+  else fw_level_body(F, tab, s, wvec, y, wvec + tab.woff[s], false, wb, Sd);
 }
 
-__global__ void __launch_bounds__(SOLVE_THREADS)
-k_bw_level(const double *F, const double *DT, FrontTab tab, const int *list, double *wvec, double *y, int use_lds) {
-  SDM_DYN_SMEM(smem);
-  __shared__ double dots[3 * SNB];
-  double *Sd = (double *)smem;                                    // two diagonal blocks
-  const int s = list[blockIdx.x];
+__device__ __forceinline__ void bw_level_body(const double *F, const double *DT, const FrontTab &tab, int s, double *y, double *w,
+                                              double *dots, double *Sd) {
   const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
   const int *rows = tab.lindx + tab.xl[s];
-  double *w = use_lds ? (double *)smem + 2 * SNB * SNB : wvec + tab.woff[s];
   const int tid = threadIdx.x, bs = blockDim.x;
   // rows below the supernode belong to ancestors, already final (bwblkslv.c:104-105 gathers them once)
   for (int i = tid; i < ms; i += bs) w[i] = i < ns ? y[first + i] : y[rows[i]];
@@ -1447,17 +1500,21 @@ k_bw_level(const double *F, const double *DT, FrontTab tab, const int *list, dou
   front_bw(F + tab.foff[s], DT + tab.toff[s], ns, ms, tab.ld[s], w, dots, Sd);
   for (int i = tid; i < ns; i += bs) y[first + i] = w[i];
 }
+__global__ void __launch_bounds__(SOLVE_THREADS)
+k_bw_level(const double *F, const double *DT, FrontTab tab, const int *list, double *wvec, double *y, int use_lds) {
+  SDM_DYN_SMEM(smem);
+  __shared__ double dots[3 * SNB];
+  double *Sd = (double *)smem;                                    // staged diagonal / sub-diagonal blocks
+  const int s = list[blockIdx.x];
+  if (use_lds) bw_level_body(F, DT, tab, s, y, (double *)smem + use_lds, dots, Sd);
+  else bw_level_body(F, DT, tab, s, y, wvec + tab.woff[s], dots, Sd);
+}
 
 // The whole  y(perm) = L' \ ((L \ rhs(perm)) ./ d)  of wrapPcg.m:56-59 in ONE launch when the factor is a single
 // front (the dense shortcut of symbchol.m:75-77 -- every shipped example): gather, forward sweep, diagonal
 // scaling, backward sweep and scatter without leaving the CU.
-__global__ void __launch_bounds__(SOLVE_THREADS)
-k_ldl_single(const double *F, const double *DT, int m, const int *perm, const double *dsolve, const double *rhs,
-             double *yout, double *wglob, int use_lds, int mode) {
-  SDM_DYN_SMEM(smem);
-  __shared__ double wb[3 * SNB];
-  double *Sd = (double *)smem;                                    // two diagonal blocks
-  double *w = use_lds ? (double *)smem + 2 * SNB * SNB : wglob;
+__device__ __forceinline__ void ldl_single_body(const double *F, const double *DT, int m, const int *perm, const double *dsolve,
+                                                const double *rhs, double *yout, double *w, int mode, double *wb, double *Sd) {
   const int tid = threadIdx.x, bs = blockDim.x;
   // mode bits: 1 forward sweep, 2 divide by d, 4 backward sweep; rhs is permuted on the way in iff forward,
   // the result on the way out iff backward (fwblkslv.c:298-303, bwblkslv.c:272-278)
@@ -1467,6 +1524,15 @@ k_ldl_single(const double *F, const double *DT, int m, const int *perm, const do
   if (mode & 2) { for (int i = tid; i < m; i += bs) w[i] /= dsolve[i]; __syncthreads(); }
   if (mode & 4) front_bw(F, DT, m, m, m + (m & 1), w, wb, Sd);
   for (int i = tid; i < m; i += bs) { if (mode & 4) yout[perm[i]] = w[i]; else yout[i] = w[i]; }
+}
+__global__ void __launch_bounds__(SOLVE_THREADS)
+k_ldl_single(const double *F, const double *DT, int m, const int *perm, const double *dsolve, const double *rhs,
+             double *yout, double *wglob, int use_lds, int mode) {
+  SDM_DYN_SMEM(smem);
+  __shared__ double wb[3 * SNB];
+  double *Sd = (double *)smem;                                    // staged diagonal / sub-diagonal blocks
+  if (use_lds) ldl_single_body(F, DT, m, perm, dsolve, rhs, yout, (double *)smem + use_lds, mode, wb, Sd);
+  else ldl_single_body(F, DT, m, perm, dsolve, rhs, yout, wglob, mode, wb, Sd);
 }
 
 // ---- big single fronts (m >= BIG_FRONT): one CU cannot stream the factor fast enough (~100 GB/s) and a launch per
@@ -1481,7 +1547,7 @@ __global__ void __launch_bounds__(SOLVE_THREADS)
 k_big_fw(const double *Fs, int m, int ld, int P, double *w) {
   SDM_DYN_SMEM(smem);
   __shared__ double wl[BIGW], xb[BIGW], wb[3 * SNB];
-  double *Sd = (double *)smem;                                    // two diagonal blocks (workgroup 0)
+  double *Sd = (double *)smem;                                    // staged blocks (workgroup 0)
   const int tid = threadIdx.x, bs = blockDim.x;
   const int rbeg = (P + 1) * BIGW + (blockIdx.x == 0 ? 0 : BIGW + ((int)blockIdx.x - 1) * 256);
   const int rend = min(m, rbeg + 256);
@@ -1522,7 +1588,7 @@ __global__ void __launch_bounds__(SOLVE_THREADS)
 k_big_bw(const double *Fs, const double *DT, int m, int ld, int P, int nsb, double *w) {
   SDM_DYN_SMEM(smem);
   __shared__ double yl[BIGW], xb[BIGW], dots[BIGW];
-  double *Sd = (double *)smem;                                    // two diagonal blocks (workgroup 0)
+  double *Sd = (double *)smem;                                    // staged blocks (workgroup 0)
   const int tid = threadIdx.x, bs = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
   const int q = P - 1 - (int)blockIdx.x, cbeg = q * BIGW, ncol = min(BIGW, m - cbeg);
@@ -1653,10 +1719,13 @@ void chol_load_factor(sdm_plan *P, const double *h_Lpr) {
 
 // dynamic LDS of the sweep kernels: two staged diagonal blocks, then the front-local vector when the largest front
 // of the plan fits (SOLVE_LDS_MAX doubles), else that vector stays in HBM
-constexpr size_t SOLVE_LDS_BLOCKS = 2 * SNB * SNB * sizeof(double);
+constexpr size_t SOLVE_LDS_BLOCKS = (size_t)SOLVE_STAGE_DOUBLES * sizeof(double);
+// use = 0: the front-local vector stays in HBM; else its offset (doubles) behind the staged blocks -- plans without a
+// front on the look-ahead schedule only ever stage one diagonal block
 static void solve_cfg(CholPlan &C, size_t &bytes, int &use) {
-  use = C.maxms <= SOLVE_LDS_MAX ? 1 : 0;
-  bytes = SOLVE_LDS_BLOCKS + (use ? (size_t)C.maxms * sizeof(double) : 0);
+  const int stage = C.maxms >= PIPE_MIN_ROWS ? SOLVE_STAGE_DOUBLES : SNB * SNB;
+  use = C.maxms <= SOLVE_LDS_MAX ? stage : 0;
+  bytes = (size_t)(stage + (use ? C.maxms : 0)) * sizeof(double);
 }
 static int level_threads(const CholPlan &C, int l) {
   int mx = 0;

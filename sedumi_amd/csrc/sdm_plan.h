@@ -16,7 +16,7 @@ constexpr int S1_NZ = 1536;   // nonzeros of a chunk of slots staged in LDS (big
 constexpr int S1_MAXT = ((S1_MAXN / 16) * (S1_MAXN / 16) + S1_WAVES - 1) / S1_WAVES;   // 16x16 tiles of Z per wavefront
 constexpr int S1_GEN_LDS = 24 * 1024;   // LDS target per task of the generic stage-1 kernel (bytes)
 constexpr int ELL_WAVES = 8;  // wavefronts per workgroup of the ELL stage-2 kernel of ADA'
-constexpr int SOLVE_LDS_MAX = 8192;   // doubles of the front-local vector kept in LDS (64 KB, next to 64 KB of staged diagonal blocks)
+constexpr int SOLVE_LDS_MAX = 3072;   // doubles of the front-local vector kept in LDS (24 KB, next to 129 KB of staged blocks)
 constexpr int BIG_FRONT = 1024;       // single fronts from this order on: one launch per super-panel and sweep instead of one workgroup
 constexpr int BIGW = 256;             // width of a super-panel of the big-front sweeps (a multiple of SNB)
 constexpr int FUSE_MAX_TILES = 136;    // trailing updates of at most this many tiles ride along with the next diagonal-block launch

@@ -58,10 +58,15 @@ __device__ __forceinline__ double sdm_bcast_lane(double v, int lane) {
 #ifdef SDM_EMU
 #define SDM_FP_STRICT do {} while (0)
 #define SDM_PIN(x) do {} while (0)
+#define SDM_ZERO_AFTER(v) 0
 #else
 #define SDM_FP_STRICT _Pragma("clang fp contract(off)")
 // keep a value materialised in a VGPR at this point (stops the scheduler from sinking its load next to the use)
 #define SDM_PIN(x) asm volatile("" : "+v"(x))
+// an integer 0 the compiler must assume to depend on `v`: added to an address it keeps the load BEHIND the point where
+// v is final (stops the scheduler from hoisting every batch of coefficients to the top and spilling them)
+__device__ __forceinline__ int sdm_zero_after(double v) { int z = 0; asm volatile("" : "+v"(z) : "v"(v)); return z; }
+#define SDM_ZERO_AFTER(v) sdm_zero_after(v)
 #endif
 
 // Optional in-kernel phase clocks (tools/ubench builds only, -DSDM_PHASES): work-item 0 accumulates wall_clock64

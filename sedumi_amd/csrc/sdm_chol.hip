@@ -1257,7 +1257,7 @@ __device__ __forceinline__ void front_fw_pipe(const double *Fs, int ns, int ms, 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = (tid >> 4) & 3;
   const int nfull = ns / SNB, rem = ns - nfull * SNB;
   double *Sb2 = Sd2 + 2 * SNB * SNB;
-  SDM_PHASE_BEGIN();
+  SDM_LPHASE_BEGIN();
   stage_block(Sd2, Fs, ld, min(SNB, ns));
   if (nfull > 0) {
     const int nsub = min(SNB, ms - SNB);
@@ -1267,7 +1267,7 @@ __device__ __forceinline__ void front_fw_pipe(const double *Fs, int ns, int ms, 
     }
   }
   __syncthreads();
-  SDM_PHASE(0);
+  SDM_LPHASE(0);
   if (wave == 0) {
     // ---- in-block solves; cacc = what panel p owes to the rows of block p+1
     SDM_SETPRIO(3);                                                // the dependency chain ahead of the streaming wavefronts
@@ -1279,9 +1279,9 @@ __device__ __forceinline__ void front_fw_pipe(const double *Fs, int ns, int ms, 
       cacc = cnext;
       w[k0 + lane] = wi;
       wb2[(p & 1) * SNB + lane] = wi;
-      SDM_PHASE(1);
+      SDM_LPHASE(1);
       __syncthreads();
-      SDM_PHASE(2);
+      SDM_LPHASE(2);
     }
     if (nfull > 0 && nfull * SNB + lane < ms) w[nfull * SNB + lane] -= cacc;      // rows right below the last full panel
   } else {
@@ -1304,7 +1304,7 @@ __device__ __forceinline__ void front_fw_pipe(const double *Fs, int ns, int ms, 
       }
       if (k1 < ns) stage15_store(Sd2 + ((p + 1) & 1) * SNB * SNB, sv, min(SNB, ns - k1));    // ... LDS stores after the stream
       if (p + 1 < nfull) stage15_sub_store(Sb2 + ((p + 1) & 1) * SNB * SNB, sb, k1, ms);
-      SDM_PHASE(4);
+      SDM_LPHASE(4);
       __syncthreads();
     }
   }
@@ -1345,7 +1345,8 @@ __device__ __forceinline__ void front_fw_pipe(const double *Fs, int ns, int ms, 
       __syncthreads();
     }
   }
-  SDM_PHASE(5);
+  SDM_LPHASE(5);
+  SDM_LPHASE_END();
 }
 
 // backward sweep of one front, workgroup of SOLVE_THREADS; dots3 = 2*SNB doubles, Sd2 = SOLVE_STAGE_DOUBLES (LDS)
@@ -1354,7 +1355,7 @@ __device__ __forceinline__ void front_bw_pipe(const double *Fs, const double *Ds
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int npan = (ns + SNB - 1) / SNB;
   double *Sb2 = Sd2 + 2 * SNB * SNB;
-  SDM_PHASE_BEGIN();
+  SDM_LPHASE_BEGIN();
   {
     // last panel: nothing to overlap with.  Its dots over ALL rows below it; its diagonal block, and (transposed) the
     // block left of it, which the in-block solve uses to form what panel P-1 gets from the rows of block P.
@@ -1375,7 +1376,7 @@ __device__ __forceinline__ void front_bw_pipe(const double *Fs, const double *Ds
       if (lane < 4 && cb0 + lane < kb && (rb & 1) && rb < ms) dF[cb0 + lane] += Fs[(int64_t)(k0 + cb0 + lane) * ld + rb] * w[rb];
     }
   }
-  SDM_PHASE(8);
+  SDM_LPHASE(8);
   __syncthreads();
   if (wave == 0) {
     SDM_SETPRIO(3);
@@ -1391,9 +1392,9 @@ __device__ __forceinline__ void front_bw_pipe(const double *Fs, const double *Ds
       else yi = trsv_bw_block(Sd2 + (p & 1) * SNB * SNB, yi, lane);
       cacc = cnext;
       if (lane < kb) w[k0 + lane] = yi;
-      SDM_PHASE(10);
+      SDM_LPHASE(10);
       __syncthreads();
-      SDM_PHASE(11);
+      SDM_LPHASE(11);
     }
   } else {
     for (int p = npan - 1; p >= 0; p--) {
@@ -1444,6 +1445,7 @@ __device__ __forceinline__ void front_bw_pipe(const double *Fs, const double *Ds
       __syncthreads();
     }
   }
+  SDM_LPHASE_END();
 }
 
 __device__ __forceinline__ void front_fw(const double *Fs, int ns, int ms, int ld, double *w, double *wb2, double *Sd2) {

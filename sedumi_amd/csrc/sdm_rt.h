@@ -75,9 +75,17 @@ __device__ __forceinline__ int sdm_zero_after(double v) { int z = 0; asm volatil
 static __device__ unsigned long long sdm_phase_acc[32];
 #define SDM_PHASE_BEGIN() long long ph_t_ = wall_clock64()
 #define SDM_PHASE(n) do { const long long t_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&sdm_phase_acc[n], (unsigned long long)(t_ - ph_t_)); ph_t_ = t_; } while (0)
+// the same through an LDS accumulator, flushed once at the end: no global atomics inside the timed region (their
+// completion would be waited for by whatever vmcnt wait the compiler placed in the loop)
+#define SDM_LPHASE_BEGIN() __shared__ unsigned long long ph_l_[32]; if (threadIdx.x < 32) ph_l_[threadIdx.x] = 0; long long ph_t_ = wall_clock64()
+#define SDM_LPHASE(n) do { const long long t_ = wall_clock64(); if (threadIdx.x == 0) ph_l_[n] += (unsigned long long)(t_ - ph_t_); ph_t_ = t_; } while (0)
+#define SDM_LPHASE_END() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 32; i_++) if (ph_l_[i_]) atomicAdd(&sdm_phase_acc[i_], ph_l_[i_]); } while (0)
 #else
 #define SDM_PHASE_BEGIN() do {} while (0)
 #define SDM_PHASE(n) do {} while (0)
+#define SDM_LPHASE_BEGIN() do {} while (0)
+#define SDM_LPHASE(n) do {} while (0)
+#define SDM_LPHASE_END() do {} while (0)
 #endif
 
 #include <cstdint>

@@ -192,6 +192,14 @@ int sdm_bwdpr1(sdm_int m, sdm_int nrhs, sdm_int nden, const sdm_int *dzjc, const
                const sdm_int *betajc, const double *beta, const double *p,
                const sdm_int *pivperm, sdm_int npivperm, const sdm_int *dopiv, const double *b, double *y);
 
+/* --- next row: the input of getada3 ------------------------ */
+
+/* y = invcholfac(u, K, perm)        invcholfac.c:59-168 (utmulx / prpiutmulx triuaux.c:175-221, invmatperm :61-70)
+ * For every PSD block k of order n_k: Y_k(perm_k, perm_k) = U_k' U_k with U_k = triu(u_k); Hermitian blocks are
+ * [Re; Im] planes, Im diag(U) taken as 0.  u, y: lenud = sum n_k^2 (2 n_k^2 Hermitian) doubles, blocks in K.s order;
+ * perm: 0-based, concatenated per block (sum n_k entries), NULL = identity.  y is the `udsqr` of sdm_getada3. */
+int sdm_invcholfac(const sdm_cone *K, const double *u, const sdm_int *perm, double *y);
+
 /* ================================================================ tier (2) */
 typedef struct sdm_plan sdm_plan;
 
@@ -228,6 +236,9 @@ int sdm_plan_download(sdm_plan *p, const char *name, double *dst, sdm_int nelem)
  * scaling buffers dl, ddet, qpr (values of DAt.q), udsqr.  Result in "ada"
  * (values in ADA pattern order, symmetric) and "absd". */
 int sdm_plan_getada(sdm_plan *p);
+/* udsqr = invcholfac(u, K, perm) on the device: reads plan buffer "u" (sdm_plan_upload), writes plan buffer "udsqr",
+ * which sdm_plan_getada then uses -- the scaled blocks never travel.  perm: host, 0-based per block, or NULL. */
+int sdm_plan_invcholfac(sdm_plan *p, const sdm_int *perm);
 /* The same restricted to the columns j0 <= j < j1 of ADA' (and absd[j0:j1]); the other entries of "ada" are left
  * untouched.  Columns are independent given the scaling data, so the ranks of a multi-GPU job each form a panel
  * and exchange panels (sedumi_amd/dist.py does the all-gather over RCCL). */

@@ -35,6 +35,7 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
                const sdm_int *Qjc, const sdm_int *Qir, const sdm_int *ADAjc, const sdm_int *ADAir) {
   AdaPlan &A = P->ada;
   A.N = N; A.m = m; A.nnzA = Ajc[m]; A.lpN = lpN; A.lorN = lorN; A.sdpN = sdpN; A.rsdpN = rsdpN;
+  A.ic_n.release(); A.ufac.release();                                // invcholfac tables belong to the old cone
   if (A.nnzA >= (sdm_int)1 << 31 || N >= (sdm_int)1 << 31) throw std::runtime_error("At too large for 32-bit row indices");
   (void)lorNL;
   A.nlq = sdpN > 0 ? psd_blkstart[0] : N;

@@ -97,6 +97,7 @@ static DevBuf<double> *plan_buf(sdm_plan *p, const char *name) {
   if (s == "rhs") return &p->rhs;
   if (s == "lpr") return &p->lpr;
   if (s == "udsqr") return &p->ada.udsqr;
+  if (s == "u") { if (p->ada.ufac.n < (size_t)std::max<sdm_int>(p->ada.lenud, 1)) p->ada.ufac.alloc((size_t)std::max<sdm_int>(p->ada.lenud, 1)); return &p->ada.ufac; }
   if (s == "dl") return &p->ada.dl;
   if (s == "ddet") return &p->ada.ddet;
   if (s == "qpr") return &p->ada.qpr;
@@ -471,4 +472,56 @@ int sdm_bwblkslv_sparse(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const
   SDM_CATCH
 }
 
+
+// ---- invcholfac
+static void cone_blocks(const sdm_cone *K, std::vector<int> &ns, sdm_int &lenud, sdm_int &plen) {
+  ns.resize((size_t)K->sdpN); lenud = 0; plen = 0;
+  for (sdm_int k = 0; k < K->sdpN; k++) {
+    ns[k] = (int)K->sdpNL[k];
+    lenud += (k < K->rsdpN ? 1 : 2) * K->sdpNL[k] * K->sdpNL[k];
+    plen += K->sdpNL[k];
+  }
+}
+static void perm32(const sdm_int *perm, const std::vector<int> &ns, std::vector<int> &out) {
+  out.clear();
+  size_t o = 0;
+  for (int n : ns) {
+    std::vector<char> seen((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+      const sdm_int v = perm[o + i];
+      if (v < 0 || v >= n || seen[(size_t)v]) throw std::runtime_error("perm is not a permutation of the block");
+      seen[(size_t)v] = 1; out.push_back((int)v);
+    }
+    o += (size_t)n;
+  }
+}
+int sdm_invcholfac(const sdm_cone *K, const double *u, const sdm_int *perm, double *y) {
+  SDM_TRY
+  std::vector<int> ns, p32; sdm_int lenud, plen;
+  cone_blocks(K, ns, lenud, plen);
+  if (lenud == 0) return 0;
+  PlanGuard G; sdm_plan *p = G.p;
+  DevBuf<double> du, dy; DevBuf<int> dp, dn, dpo; DevBuf<int64_t> doff;
+  du.upload(u, (size_t)lenud); dy.alloc((size_t)lenud);
+  if (perm) { perm32(perm, ns, p32); dp.upload(p32); }
+  psd_invcholfac(p->stream, du.p, dy.p, perm ? dp.p : nullptr, ns, (int)K->rsdpN, dn, doff, dpo, false);
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  SDM_HIP_CHECK(hipMemcpy(y, dy.p, (size_t)lenud * sizeof(double), hipMemcpyDeviceToHost));
+  SDM_CATCH
+}
+int sdm_plan_invcholfac(sdm_plan *p, const sdm_int *perm) {
+  SDM_TRY
+  AdaPlan &A = p->ada;
+  if (A.lenud == 0) return 0;
+  if (A.ufac.n < (size_t)A.lenud) throw std::runtime_error("invcholfac: upload buffer \"u\" first");
+  std::vector<int> ns(A.psd_n.begin(), A.psd_n.end()), p32;
+  if (perm) {
+    perm32(perm, ns, p32);
+    if (A.ic_perm.n < p32.size()) A.ic_perm.alloc(p32.size());
+    SDM_HIP_CHECK(hipMemcpyAsync(A.ic_perm.p, p32.data(), p32.size() * sizeof(int), hipMemcpyHostToDevice, p->stream));
+  }
+  const bool ready = A.ic_n.n == ns.size() && !ns.empty();           // block tables: once per plan (set_ada resets them)
+  psd_invcholfac(p->stream, A.ufac.p, A.udsqr.p, perm ? A.ic_perm.p : nullptr, ns, (int)A.rsdpN, A.ic_n, A.ic_off, A.ic_poff, ready);
+  SDM_CATCH
+}
 }  // extern "C"

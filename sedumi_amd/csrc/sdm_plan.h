@@ -120,6 +120,8 @@ struct AdaPlan {
   DevBuf<int> dsqr_code;
   DevBuf<int64_t> t_end, d_psd_start;
   DevBuf<double> dl, ddet, qpr, udsqr;
+  DevBuf<double> ufac;                    // d.u of the scaling (input of sdm_plan_invcholfac), lenud doubles
+  DevBuf<int> ic_n, ic_poff, ic_perm; DevBuf<int64_t> ic_off;   // invcholfac block tables
   size_t stage1_lds = 0;
   // stage-2 fast path: interleaved (ELL) copy of the PSD nonzeros, rows sorted by length, groups of 64
   bool ell_ok = false;
@@ -200,4 +202,7 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
 void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate);
 void ada_q(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate);
 void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input);
+// y(perm,perm) = u'u per PSD block (invcholfac.c); u, y device (lenud doubles), perm device int32 0-based or null
+void psd_invcholfac(hipStream_t st, const double *u, double *y, const int *perm, const std::vector<int> &ns, int rsdpN,
+                    DevBuf<int> &d_n, DevBuf<int64_t> &d_off, DevBuf<int> &d_poff, bool tables_ready);
 }  // namespace sdm

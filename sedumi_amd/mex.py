@@ -419,3 +419,26 @@ def fwdpr1(Lden, b):
 def bwdpr1(Lden, b):
     """y = bwdpr1(Lden, b): y = (PROD_k L(p_k, beta_k))' \\ b   (bwdpr1.c:170-275)"""
     return _pr1(False, Lden, b)
+
+
+# ------------------------------------------------------------- next row (SURVEY 8f N1)
+def invcholfac(u, K, perm=None):
+    """y = invcholfac(u, K, perm): y(perm,perm) = u'*u per PSD block, u upper triangular   (invcholfac.c:59-168).
+    u: lenud vector (blocks column-major, Hermitian blocks [Re; Im]); perm: 1-based, concatenated per block (d.perm of
+    the scaling), empty / None = no permutation.  Returns the lenud x 1 `udsqr` argument of getada3 (sedumi.m:452)."""
+    lpN, q, s, rsdpN = _Kfields(K)
+    lenud = int(np.sum(s[:rsdpN] ** 2) + 2 * np.sum(s[rsdpN:] ** 2))
+    u = f64(u)
+    if u.size != lenud:
+        raise SdmError("u size mismatch")
+    Kc, keep = capi.make_cone(lpN, q, s, rsdpN)
+    y = np.zeros(lenud, dtype=np.float64)
+    pp = None
+    if perm is not None and np.size(perm) > 0:
+        p1 = np.asarray(perm, dtype=np.float64).ravel()
+        if p1.size != int(np.sum(s)):
+            raise SdmError("perm size mismatch")
+        pp = i64(p1 - 1)                       # local to each block (invcholfac.c:129-131), 1-based
+    check(capi.lib().sdm_invcholfac(C.byref(Kc), pf(u), pi(pp) if pp is not None else None, pf(y)))
+    del keep
+    return y.reshape(-1, 1)

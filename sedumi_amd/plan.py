@@ -105,6 +105,15 @@ class Plan:
     def getada(self):
         check(self._lib.sdm_plan_getada(C.c_void_p(self._p)))
 
+    def invcholfac(self, perm=None):
+        """udsqr = invcholfac(u, K, perm) on the device (sedumi.m:452): reads plan buffer "u" (upload it first), leaves
+        the result in "udsqr" for getada().  perm: d.perm (1-based doubles, concatenated per block) or None."""
+        if perm is None:
+            check(self._lib.sdm_plan_invcholfac(C.c_void_p(self._p), None))
+        else:
+            p0 = np.ascontiguousarray(np.asarray(perm, dtype=np.float64).ravel() - 1, dtype=np.int64)
+            check(self._lib.sdm_plan_invcholfac(C.c_void_p(self._p), p0.ctypes.data_as(C.POINTER(C.c_int64))))
+
     def getada_cols(self, j0, j1):
         """Columns j0 <= j < j1 of ADA' (and absd[j0:j1]) only; the rest of "ada" is left untouched."""
         check(self._lib.sdm_plan_getada_cols(C.c_void_p(self._p), C.c_int64(int(j0)), C.c_int64(int(j1))))

@@ -268,3 +268,44 @@ def test_socp_nb_like_with_dense_columns(refmex, glue):
     from sedumi_amd import problem
     P = problem.random_sdp(m=123, lp=5, q=(3,) * 80, s=(), dens=0.12, seed=31)
     check_iteration(glue, P, seed=7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(7))
+def test_invcholfac_on_gpu(refmex, case):
+    """y = invcholfac(u, K, perm) on the device against the compiled reference (real and Hermitian
+    blocks, tile boundaries at 64/65/130/200, with and without perm)."""
+    from sedumi_amd import mex, problem
+    from test_invcholfac import CASES, scaling_factor_case
+    kw = CASES[case]
+    K = problem.make_K(1, [], kw.get("s", []), hs=kw.get("hs", ()))
+    u, perm = scaling_factor_case(K, seed=case)
+    for pm in (perm, None):
+        args = (u.reshape(-1, 1), K) + ((pm.reshape(-1, 1),) if pm is not None else ())
+        assert relerr(mex.invcholfac(u, K, pm), refmex.call("invcholfac", 1, *args)) < TOL
+
+
+@pytest.mark.gpu
+def test_invcholfac_chained_into_getada_full_size():
+    """MAXCUT-2000-sized block: invcholfac on the device feeding getada3's udsqr without a host round trip; checked
+    through the identity ADA_ij = (U'U)_ij^2 for A_i = e_i e_i'  on a sample of entries."""
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    n = 2000
+    P = problem.maxcut(n, seed=2)
+    rng = np.random.default_rng(1)
+    U = np.triu(rng.standard_normal((n, n)) * 0.02) + np.diag(1.0 + rng.random(n))
+    perm = rng.permutation(n) + 1.0
+    D = np.zeros((n, n)); p = perm.astype(int) - 1
+    D[np.ix_(p, p)] = U.T @ U
+    plan = Plan(0)
+    plan.set_chol(problem.dense_symbolic(P.m), problem.dense_pattern(P.m))
+    plan.set_ada(P.At, P.Ablkjc, P.K, problem.lorentz_pattern(P))
+    plan.upload("dl", np.ones(int(P.K["l"]))); plan.upload("ddet", np.zeros(0)); plan.upload("u", U.ravel(order="F"))
+    plan.invcholfac(perm); plan.getada()
+    ud = plan.download("udsqr", n * n).reshape(n, n, order="F")
+    assert relerr(ud, D) < TOL
+    ada = plan.download("ada").reshape(P.m, P.m, order="F")
+    ii, jj = rng.integers(0, n, 500), rng.integers(0, n, 500)
+    assert relerr(ada[ii, jj], D[ii, jj] ** 2) < 1e-9
+    plan.close()

@@ -13,7 +13,7 @@ import scipy.sparse as sp
 from helpers import ROOT, TOL, ref_scaling, relerr, spd_pattern
 
 SHIMS = ["getada1", "getada2", "getada3", "blkchol", "fwblkslv", "bwblkslv", "ordmmdmex", "symfctmex", "choltmpsiz", "cholsplit",
-         "symbfwblk", "finsymbden", "dpr1fact", "fwdpr1", "bwdpr1"]
+         "symbfwblk", "finsymbden", "dpr1fact", "fwdpr1", "bwdpr1", "invcholfac"]
 
 
 @pytest.fixture(scope="module")
@@ -111,3 +111,14 @@ def test_shim_errors_go_through_mexErrMsgTxt(shimmex):
     L = {"L": sp.csc_matrix(np.tril(np.ones((4, 4)))), "perm": np.arange(1, 5.0)}
     with pytest.raises(RefMexError, match="Missing field L.xsuper"):
         shimmex.call("fwblkslv", 1, L, np.ones((4, 1)))
+
+
+def test_shim_invcholfac(refmex, shimmex):
+    """y = invcholfac(u, K, perm) through its mexFunction shim against the reference gateway (real + Hermitian blocks,
+    with and without the permutation argument)."""
+    from test_invcholfac import scaling_factor_case
+    from sedumi_amd import problem
+    K = problem.make_K(1, [], [70, 5], hs=[9])
+    u, perm = scaling_factor_case(K, seed=3)
+    for args in ((u.reshape(-1, 1), K, perm.reshape(-1, 1)), (u.reshape(-1, 1), K)):
+        assert relerr(shimmex.call("invcholfac", 1, *args), refmex.call("invcholfac", 1, *args)) < TOL

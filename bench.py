@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 PARS = {"canceltol": 1e-12, "maxu": 5e5, "abstol": 1e-20}          # checkpars.m:144-168
 HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 NSOLVE = 4
+CONFIG_NOTE = {"contro": "control07-shaped SDP (BASELINE.json configs[1])", "nb": "nb-shaped SOCP (BASELINE.json configs[2])",
+               "maxcut": "MAXCUT SDP, one dense PSD block (BASELINE.json configs[3])"}
 
 
 def build_workload(name, seed):
@@ -34,6 +36,9 @@ def build_workload(name, seed):
         P = problem.control_like(seed=seed)
     elif name.startswith("maxcut"):
         P = problem.maxcut(int(name[6:] or 4000))
+    elif name == "nb":                                  # BASELINE.json configs[2] shape: 793 Lorentz cones of dimension 3, m = 123
+        P = problem.random_sdp(m=123, lp=4, q=(3,) * 793, s=(), dens=0.66, seed=31 + seed)
+        P.name = "nb_like(m=123,q=793x3)"
     else:
         raise SystemExit("unknown workload " + name)
     L, ADA, Q = problem.dense_symbolic(P.m), problem.dense_pattern(P.m), problem.lorentz_pattern(P)
@@ -148,7 +153,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="control07",
-                    help="control07 (default, BASELINE configs[1]) | maxcut<n> (configs[3]) | blockdiag[:nblk:n:mper] (configs[4])")
+                    help="control07 (default, BASELINE configs[1]) | nb (configs[2] shape) | maxcut<n> (configs[3]) | blockdiag[:nblk:n:mper] (configs[4])")
     ap.add_argument("--shard", default="auto", choices=["auto", "replicas", "columns"],
                     help="N>1: replicas = independent units per rank (default for single-supernode workloads); "
                          "columns = ONE unit per step, ADA' column panels per rank + RCCL all-gather, factor/solves replicated")
@@ -185,6 +190,8 @@ def main():
     plan.set_chol(L, ADA)
     plan.set_ada(P.At, P.Ablkjc, P.K, Q)
     plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud); plan.upload("rhs", rhs)
+    if Q.nnz:                                  # Lorentz cones: DAt.q values in the order of the pattern (getDAtm.m's product)
+        plan.upload("qpr", 0.1 * np.random.default_rng(3).standard_normal(Q.nnz))
 
     cs = None
     if shard_cols:
@@ -298,7 +305,7 @@ def main():
             "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": (1 if shard_cols else world) * args.steps / elapsed, "unit": "IPM iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong" if shard_cols else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{P.name}: control07-shaped SDP (BASELINE.json configs[1]), m={P.m}, nnz(At)={P.At.nnz}, "
+            "config": {"workload": f"{P.name}: {CONFIG_NOTE.get(args.workload[:6], CONFIG_NOTE['contro'])}, m={P.m}, nnz(At)={P.At.nnz}, "
                                    f"dense ADA' {P.m}x{P.m}, nnz(L)={nnzL}; unit = getada1+2+3, blkchol, {NSOLVE}x(fwblkslv,./d,bwblkslv)",
                        "parallelism": ("ADA' column panels + RCCL all-gather, factor/solves replicated" if shard_cols else "replicas") if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": base,

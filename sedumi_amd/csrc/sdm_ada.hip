@@ -231,6 +231,35 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
   A.dl.alloc((size_t)std::max<sdm_int>(lpN, 1)); A.ddet.alloc((size_t)std::max<sdm_int>(lorN, 1));
   A.qpr.alloc((size_t)std::max<sdm_int>(A.nnzQ, 1)); A.udsqr.alloc((size_t)std::max<sdm_int>(A.lenud, 1));
   A.symtmp.alloc((size_t)std::max<sdm_int>(ADAjc[m], 1));
+  // ---- dense-column form of the LP / Lorentz part.  A sparse-sparse dot per ADA' entry (k_ada_spdot) is the right
+  // tool for sparse columns; when the columns are dense-ish (nb.mat: 66 %) the same sums are a weighted Gram matrix
+  // A' diag(dsqr) A, i.e. GEMM-shaped work for the matrix cores.  Static data (At) is expanded once here.
+  {
+    sdm_int nz = 0;
+    for (sdm_int j = 0; j < m; j++) nz += Ajc_psd[j] - Ajc[j];
+    const double cells = (double)A.nlq * (double)m;
+    A.lq_dense = A.nlq > 0 && m > 1 && nz > 0 && (double)nz >= 0.10 * cells && cells * 8.0 <= 1.0e9;
+    A.q_dense = lorN > 0 && A.nnzQ > 0 && (double)A.nnzQ >= 0.10 * (double)lorN * (double)m && (double)lorN * m * 8.0 <= 1.0e9;
+    if (A.lq_dense) {
+      std::vector<double> D((size_t)A.nlq * (size_t)m, 0.0);
+      for (sdm_int j = 0; j < m; j++)
+        for (sdm_int t = Ajc[j]; t < Ajc_psd[j]; t++) D[(size_t)j * (size_t)A.nlq + (size_t)Air[t]] = Apr[t];
+      A.Alq_d.upload(D);
+    } else A.Alq_d.release();
+    if (A.q_dense) {
+      std::vector<int64_t> dst((size_t)A.nnzQ);
+      for (sdm_int j = 0; j < m; j++)
+        for (sdm_int t = Qjc[j]; t < Qjc[j + 1]; t++) dst[(size_t)t] = (int64_t)j * lorN + Qir[t];
+      A.q_dst.upload(dst);
+      A.Q_d.alloc((size_t)lorN * (size_t)m);
+    } else { A.Q_d.release(); A.q_dst.release(); }
+    if (A.lq_dense || A.q_dense) {
+      const int nt = (int)((m + TILE - 1) / TILE), T = nt * (nt + 1) / 2;
+      const sdm_int rows = std::max(A.lq_dense ? A.nlq : 0, A.q_dense ? lorN : 0);
+      A.gram_split = (int)std::max<sdm_int>(1, std::min<sdm_int>((rows + TILE - 1) / TILE, std::max(1, 512 / T)));
+      A.gram_part.alloc((size_t)A.gram_split * (size_t)m * (size_t)m);
+    } else A.gram_part.release();
+  }
   // LDS budget for stage 1: Y chunk of CC slots x n rows
   A.stage1_lds = 96 * 1024;
   { const size_t need = (size_t)(sdpN > rsdpN ? 4 : 2) * (size_t)A.maxn * sizeof(double);     // one slot: Y (+Yi) and D(col,:) (+Im)
@@ -274,6 +303,88 @@ k_ada_spdot(double *ada, const int64_t *ADAjc, const int *ADAir, const int64_t *
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if (lane == 0) { if (accumulate) ada[e] += acc; else ada[e] = acc; }
   }
+}
+
+// ---- dense-column form: G = M' diag(w) M for a dense column-major R x m matrix M (rows = LP/Lorentz rows of At, or
+// the rows of DAt.q with w = 1).  grid (lower 64x64 tiles, K splits): workgroup (t, s) forms tile t over the rows of
+// split s on v_mfma_f64_16x16x4_f64 and writes it to part[s] (m x m, lower tiles); k_gram_scatter adds the splits in
+// fixed order and stores into the ADA' pattern (same masks / accumulate semantics as k_ada_spdot).
+__global__ void __launch_bounds__(256)
+k_gram_tile(const double *M, const double *wgt, int R, int m, int nsplit, double *part) {
+  __shared__ double As[TILE][TILE], Bs[TILE][TILE];
+  const int t = blockIdx.x, sp = blockIdx.y;
+  int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((I + 1) * (I + 2) / 2 <= t) I++;
+  while (I * (I + 1) / 2 > t) I--;
+  const int J = t - I * (I + 1) / 2;
+  const int nch = (R + TILE - 1) / TILE;
+  const int c0 = (int)((int64_t)nch * sp / nsplit), c1 = (int)((int64_t)nch * (sp + 1) / nsplit);
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int wi = w >> 1, wj = w & 1, lk = l >> 4, ll = l & 15;
+  sdm_double4 acc[2][2];
+  for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) for (int r = 0; r < 4; r++) acc[a][b][r] = 0.0;
+  for (int ch = c0; ch < c1; ch++) {
+    {
+      const int tt = tid & 63, cq = tid >> 6, r = ch * TILE + tt;
+      double av[TILE / 4], bv[TILE / 4];
+      const double wr = (wgt && r < R) ? wgt[r] : 1.0;
+#pragma unroll
+      for (int q = 0; q < TILE / 4; q++) {
+        const int ci = I * TILE + cq + 4 * q, cj = J * TILE + cq + 4 * q;
+        av[q] = M[(int64_t)min(ci, m - 1) * R + min(r, R - 1)];
+        bv[q] = M[(int64_t)min(cj, m - 1) * R + min(r, R - 1)];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < TILE / 4; q++) {
+        const int ci = I * TILE + cq + 4 * q, cj = J * TILE + cq + 4 * q;
+        As[tt][cq + 4 * q] = (ci < m && r < R) ? av[q] : 0.0;
+        Bs[tt][cq + 4 * q] = (cj < m && r < R) ? bv[q] * wr : 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < TILE; kk += 4) {
+      double ar[2], br[2];
+#pragma unroll
+      for (int a = 0; a < 2; a++) ar[a] = As[kk + lk][wi * 32 + a * 16 + ll];
+#pragma unroll
+      for (int b = 0; b < 2; b++) br[b] = Bs[kk + lk][wj * 32 + b * 16 + ll];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = SDM_MFMA_F64_16x16x4(br[b], ar[a], acc[a][b]);
+    }
+    __syncthreads();
+  }
+  double *out = part + (int64_t)sp * m * m;
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int i = I * TILE + wi * 32 + a * 16 + ll, j = J * TILE + wj * 32 + b * 16 + lk + 4 * r;
+        if (i < m && j < m) out[(int64_t)j * m + i] = acc[a][b][r];       // G(i,j), tiles I >= J (diagonal tiles in full)
+      }
+}
+__global__ void k_gram_scatter(double *ada, const int64_t *ADAjc, const int *ADAir, const double *part, int nsplit, int m,
+                               const int *invperm, int accumulate, int jbase) {
+  const int j = blockIdx.x + jbase;
+  const int ipj = invperm ? invperm[j] : 0;
+  for (int64_t e = ADAjc[j] + threadIdx.x; e < ADAjc[j + 1]; e += blockDim.x) {
+    const int i = ADAir[e];
+    if (invperm && invperm[i] > ipj) continue;
+    // tile (I,J) with I >= J holds G(i,j) at [j*m + i]; inside a diagonal tile both orders are present
+    const int a = (i / TILE >= j / TILE) ? i : j, b = (i / TILE >= j / TILE) ? j : i;
+    double v = 0.0;
+    for (int s = 0; s < nsplit; s++) v += part[(int64_t)s * m * m + (int64_t)b * m + a];
+    if (accumulate) ada[e] += v; else ada[e] = v;
+  }
+}
+__global__ void k_q_densify(double *Qd, const double *qpr, const int64_t *dst, int64_t nnz) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nnz) Qd[dst[t]] = qpr[t];
 }
 
 // ---- stage 1: z_jk = (D_k sym(X_jk) D_k)[U_k]    (spscale.c:249-305)
@@ -688,9 +799,10 @@ __global__ void k_symmetrize(double *out, const double *in, const int64_t *ADAjc
 __global__ void k_diag(double *absd, const double *ada, const int64_t *ADAjc, const int *ADAir, int m) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
-  double v = 0.0;
-  for (int64_t e = ADAjc[j]; e < ADAjc[j + 1]; e++) if (ADAir[e] == j) { v = ada[e]; break; }
-  absd[j] = v;
+  int64_t lo = ADAjc[j], hi = ADAjc[j + 1];            // sorted row indices: binary search for the diagonal
+  const int64_t ce = hi;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ADAir[mid] < j) lo = mid + 1; else hi = mid; }
+  absd[j] = (lo < ce && ADAir[lo] == j) ? ada[lo] : 0.0;
 }
 
 // ============================================================ host drivers
@@ -709,12 +821,30 @@ void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
   }
   if (A.nlq > 0)
     SDM_KLAUNCH(P, k_dsqr, dim3((unsigned)((A.nlq + 255) / 256)), dim3(256), 0, A.dsqr.p, A.dsqr_code.p, A.dl.p, A.ddet.p, (int)A.nlq);
+  if (A.lq_dense) {
+    const int m = (int)A.m, nt = (m + TILE - 1) / TILE;
+    SDM_KLAUNCH(P, k_gram_tile, dim3(nt * (nt + 1) / 2, A.gram_split), dim3(256), 0, A.Alq_d.p, A.dsqr.p, (int)A.nlq, m, A.gram_split,
+                A.gram_part.p);
+    SDM_KLAUNCH(P, k_gram_scatter, dim3((unsigned)(A.col1 - A.col0)), dim3(128), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.gram_part.p,
+                A.gram_split, m, d_invperm, accumulate ? 1 : 0, (int)A.col0);
+    return;
+  }
   SDM_KLAUNCH(P, k_ada_spdot, dim3((unsigned)(A.col1 - A.col0)), dim3(256), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p,
              A.d_Air.p, A.d_Apr.p, A.dsqr.p, d_invperm, accumulate ? 1 : 0, (int)A.col0);
 }
 void ada_q(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
   AdaPlan &A = P->ada;
   if (A.lorN == 0 || A.nnzQ == 0 || A.col1 <= A.col0) return;
+  if (A.q_dense) {
+    const int m = (int)A.m, nt = (m + TILE - 1) / TILE;
+    SDM_HIP_CHECK(hipMemsetAsync(A.Q_d.p, 0, (size_t)A.lorN * (size_t)m * sizeof(double), P->stream));
+    SDM_KLAUNCH(P, k_q_densify, dim3((unsigned)((A.nnzQ + 255) / 256)), dim3(256), 0, A.Q_d.p, A.qpr.p, A.q_dst.p, (int64_t)A.nnzQ);
+    SDM_KLAUNCH(P, k_gram_tile, dim3(nt * (nt + 1) / 2, A.gram_split), dim3(256), 0, A.Q_d.p, (const double *)nullptr, (int)A.lorN, m,
+                A.gram_split, A.gram_part.p);
+    SDM_KLAUNCH(P, k_gram_scatter, dim3((unsigned)(A.col1 - A.col0)), dim3(128), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.gram_part.p,
+                A.gram_split, m, d_invperm, accumulate ? 1 : 0, (int)A.col0);
+    return;
+  }
   SDM_KLAUNCH(P, k_ada_spdot, dim3((unsigned)(A.col1 - A.col0)), dim3(256), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Qjc.p, A.d_Qjc.p + 1,
              A.d_Qir.p, A.qpr.p, (const double *)nullptr, d_invperm, accumulate ? 1 : 0, (int)A.col0);
 }

@@ -20,7 +20,7 @@ constexpr int SOLVE_LDS_MAX = 3072;   // doubles of the front-local vector kept 
 constexpr int BIG_FRONT = 1024;       // single fronts from this order on: one launch per super-panel and sweep instead of one workgroup
 constexpr int BIGW = 256;             // width of a super-panel of the big-front sweeps (a multiple of SNB)
 constexpr int FUSE_MAX_TILES = 136;    // trailing updates of at most this many tiles ride along with the next diagonal-block launch
-constexpr int PIPE_MIN_ROWS = 256;     // fronts with at least this many rows run the sweeps on the look-ahead schedule
+constexpr int PIPE_MIN_ROWS = 96;      // fronts with at least this many rows run the sweeps on the look-ahead schedule
 constexpr int SOLVE_THREADS = 1024;   // workgroup of the per-front solve kernels (16 waves stream the panel)
 constexpr int SW = 8;                 // columns of the diagonal block swept in registers at a time (readlane chain), rest via LDS
 constexpr int LDL_THREADS = 512;      // workgroup of the diagonal-block kernel: wavefront 0 sweeps, the other 7 apply the previous sweep
@@ -118,6 +118,12 @@ struct AdaPlan {
   DevBuf<int64_t> c_taskptr;              // per constraint: its tasks
   DevBuf<double> zbuf, dsqr, symtmp;
   DevBuf<int> dsqr_code;
+  // dense-column form of the LP / Lorentz part (ada_build decides): At(0:nlq, :) and DAt.q as dense column-major
+  // arrays, ADA' contributions as weighted Gram matrices on the FP64 matrix cores (split-K, fixed-order reduction)
+  bool lq_dense = false, q_dense = false;
+  int gram_split = 1;
+  DevBuf<double> Alq_d, Q_d, gram_part;
+  DevBuf<int64_t> q_dst;
   DevBuf<int64_t> t_end, d_psd_start;
   DevBuf<double> dl, ddet, qpr, udsqr;
   DevBuf<double> ufac;                    // d.u of the scaling (input of sdm_plan_invcholfac), lenud doubles

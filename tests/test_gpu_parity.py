@@ -309,3 +309,41 @@ def test_invcholfac_chained_into_getada_full_size():
     ii, jj = rng.integers(0, n, 500), rng.integers(0, n, 500)
     assert relerr(ada[ii, jj], D[ii, jj] ** 2) < 1e-9
     plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["control", "rank_deficient"])
+def test_factor_and_solve_are_run_to_run_deterministic(kind):
+    """The trailing update tiles that ride along with the next diagonal-block launch, their completion counter and the
+    look-ahead sweeps have no atomics on data and a fixed summation order: 30 repetitions give bitwise identical L, d,
+    pivot decisions and y (a lost wait or a race between workgroups shows up as a flaky bit here)."""
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    rng = np.random.default_rng(5)
+    if kind == "control":
+        P = problem.control_like(seed=1)
+        L, ADApat = problem.dense_symbolic(P.m), problem.dense_pattern(P.m)
+        d, ud = problem.spd_scaling(P.K, seed=2)
+        plan = Plan(0); plan.set_chol(L, ADApat); plan.set_ada(P.At, P.Ablkjc, P.K, problem.lorentz_pattern(P))
+        plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud)
+        m = P.m
+        prep = plan.getada
+    else:
+        m = 450                                             # 8 panels, rank 300: skips, added pivots and column probes
+        B = rng.standard_normal((m, 300))
+        X = B @ B.T + np.diag(10.0 ** rng.uniform(-13, -3, m))
+        plan = Plan(0); plan.set_chol(problem.dense_symbolic(m), problem.dense_pattern(m))
+        Xv = X.ravel(order="F").copy()
+        prep = lambda: plan.upload("ada", Xv)
+    plan.upload("rhs", rng.standard_normal(m))
+    ref = None
+    for rep in range(30):
+        prep(); plan.blkchol(None, kind == "control"); plan.ldlsolve()
+        out = (plan.download("lpr"), plan.download("d"), plan.download("y"), plan.pivots())
+        if ref is None:
+            ref = out
+        else:
+            assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
+            assert np.array_equal(out[2], ref[2], equal_nan=True)
+            assert all(np.array_equal(a, b) for x, y in zip(out[3], ref[3]) for a, b in zip(x, y))
+    plan.close()

@@ -239,6 +239,10 @@ int sdm_plan_getada(sdm_plan *p);
 /* udsqr = invcholfac(u, K, perm) on the device: reads plan buffer "u" (sdm_plan_upload), writes plan buffer "udsqr",
  * which sdm_plan_getada then uses -- the scaled blocks never travel.  perm: host, 0-based per block, or NULL. */
 int sdm_plan_invcholfac(sdm_plan *p, const sdm_int *perm);
+/* qpr = values of DAt.q = diag(d.q1) * A(trace rows, :) + ddot(d.q2, A, K.qblkstart, Ablkjc)  (getDAtm.m:39-44, ddot.c:66-160;
+ * SURVEY 8f N3) in the order of the Qjc/Qir pattern given to sdm_plan_set_ada: reads plan buffers "q1" (lorN doubles)
+ * and "q2" (sum(K.q)-lorN doubles), writes "qpr" -- the Lorentz input of sdm_plan_getada stays on the device. */
+int sdm_plan_getdatq(sdm_plan *p);
 /* The same restricted to the columns j0 <= j < j1 of ADA' (and absd[j0:j1]); the other entries of "ada" are left
  * untouched.  Columns are independent given the scaling data, so the ranks of a multi-GPU job each form a panel
  * and exchange panels (sedumi_amd/dist.py does the all-gather over RCCL). */

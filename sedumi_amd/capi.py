@@ -57,7 +57,7 @@ def lib():
     L.sdm_plan_destroy.argtypes = [C.c_void_p]
     L.sdm_plan_devptr.restype = C.c_void_p
     L.sdm_plan_devptr.argtypes = [C.c_void_p, C.c_char_p, I64P]
-    for name in ("sdm_plan_sync", "sdm_plan_getada", "sdm_plan_fwsolve", "sdm_plan_bwsolve", "sdm_plan_ldlsolve"):
+    for name in ("sdm_plan_sync", "sdm_plan_getada", "sdm_plan_getdatq", "sdm_plan_fwsolve", "sdm_plan_bwsolve", "sdm_plan_ldlsolve"):
         getattr(L, name).argtypes = [C.c_void_p]
     L.sdm_plan_blkchol.argtypes = [C.c_void_p, C.POINTER(CholPars), C.c_int]
     L.sdm_plan_upload.argtypes = [C.c_void_p, C.c_char_p, F64P, C.c_int64]

@@ -230,6 +230,9 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
   A.dsqr.alloc((size_t)std::max<sdm_int>(A.nlq, 1));
   A.dl.alloc((size_t)std::max<sdm_int>(lpN, 1)); A.ddet.alloc((size_t)std::max<sdm_int>(lorN, 1));
   A.qpr.alloc((size_t)std::max<sdm_int>(A.nnzQ, 1)); A.udsqr.alloc((size_t)std::max<sdm_int>(A.lenud, 1));
+  { std::vector<int64_t> v(lorN + 1, A.nlq); for (sdm_int k = 0; k <= lorN && lorN > 0; k++) v[k] = qblkstart[k]; A.d_qblk.upload(v); }
+  A.q1.alloc((size_t)std::max<sdm_int>(lorN, 1));
+  A.q2.alloc((size_t)std::max<sdm_int>(lorN > 0 ? qblkstart[lorN] - qblkstart[0] : 0, 1));
   A.symtmp.alloc((size_t)std::max<sdm_int>(ADAjc[m], 1));
   // ---- dense-column form of the LP / Lorentz part.  A sparse-sparse dot per ADA' entry (k_ada_spdot) is the right
   // tool for sparse columns; when the columns are dense-ish (nb.mat: 66 %) the same sums are a weighted Gram matrix
@@ -385,6 +388,33 @@ __global__ void k_gram_scatter(double *ada, const int64_t *ADAjc, const int *ADA
 __global__ void k_q_densify(double *Qd, const double *qpr, const int64_t *dst, int64_t nnz) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < nnz) Qd[dst[t]] = qpr[t];
+}
+
+// ---- DAt.q (getDAtm.m:39-44): q(k,j) = d.q1(k) * A(trace row of cone k, j) + d.q2(cone k)' * A(norm-bound rows of
+// cone k, j)  [extractA + spdiags product + ddot.c:66-160], one work-item per entry of the pattern, sums in row order
+__global__ void k_datq(double *qpr, const int64_t *Qjc, const int *Qir, const int64_t *Ajc, const int64_t *Aend, const int *Air,
+                       const double *Apr, const double *q1, const double *q2, const int64_t *qblk, int lpN) {
+  const int j = blockIdx.x;
+  const int64_t cb = Ajc[j], ce = Aend[j];
+  for (int64_t e = Qjc[j] + threadIdx.x; e < Qjc[j + 1]; e += blockDim.x) {
+    const int k = Qir[e];
+    double v = 0.0;
+    {
+      const int rt = lpN + k;                                   // trace entry of cone k
+      int64_t lo = cb, hi = ce;
+      while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (Air[mid] < rt) lo = mid + 1; else hi = mid; }
+      if (lo < ce && Air[lo] == rt) v = q1[k] * Apr[lo];
+    }
+    {
+      const int64_t r0 = qblk[k], r1 = qblk[k + 1], base = qblk[0];
+      int64_t lo = cb, hi = ce;
+      while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (Air[mid] < r0) lo = mid + 1; else hi = mid; }
+      double acc = 0.0;
+      for (; lo < ce && Air[lo] < r1; lo++) acc += q2[Air[lo] - base] * Apr[lo];
+      v += acc;
+    }
+    qpr[e] = v;
+  }
 }
 
 // ---- stage 1: z_jk = (D_k sym(X_jk) D_k)[U_k]    (spscale.c:249-305)
@@ -831,6 +861,12 @@ void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
   }
   SDM_KLAUNCH(P, k_ada_spdot, dim3((unsigned)(A.col1 - A.col0)), dim3(256), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p,
              A.d_Air.p, A.d_Apr.p, A.dsqr.p, d_invperm, accumulate ? 1 : 0, (int)A.col0);
+}
+void ada_datq(sdm_plan *P) {
+  AdaPlan &A = P->ada;
+  if (A.lorN == 0 || A.nnzQ == 0) return;
+  SDM_KLAUNCH(P, k_datq, dim3((unsigned)A.m), dim3(128), 0, A.qpr.p, A.d_Qjc.p, A.d_Qir.p, A.d_Ajc.p, A.d_Ajc_psd.p, A.d_Air.p, A.d_Apr.p,
+              A.q1.p, A.q2.p, A.d_qblk.p, (int)A.lpN);
 }
 void ada_q(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
   AdaPlan &A = P->ada;

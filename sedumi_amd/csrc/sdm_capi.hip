@@ -101,6 +101,8 @@ static DevBuf<double> *plan_buf(sdm_plan *p, const char *name) {
   if (s == "dl") return &p->ada.dl;
   if (s == "ddet") return &p->ada.ddet;
   if (s == "qpr") return &p->ada.qpr;
+  if (s == "q1") return &p->ada.q1;
+  if (s == "q2") return &p->ada.q2;
   throw std::runtime_error("unknown plan buffer: " + s);
 }
 void *sdm_plan_devptr(sdm_plan *p, const char *name, sdm_int *nelem) {
@@ -134,6 +136,12 @@ int sdm_plan_getada(sdm_plan *p) {
   ada_lq(p, p->ada_val.p, nullptr, false);
   ada_q(p, p->ada_val.p, nullptr, true);
   ada_psd(p, p->ada_val.p, nullptr, false);
+  SDM_CATCH
+}
+int sdm_plan_getdatq(sdm_plan *p) {
+  SDM_TRY
+  if (!p->has_ada) throw std::runtime_error("sdm_plan_getdatq: no ADA data set");
+  ada_datq(p);
   SDM_CATCH
 }
 int sdm_plan_getada_cols(sdm_plan *p, sdm_int j0, sdm_int j1) {

@@ -126,6 +126,8 @@ struct AdaPlan {
   DevBuf<int64_t> q_dst;
   DevBuf<int64_t> t_end, d_psd_start;
   DevBuf<double> dl, ddet, qpr, udsqr;
+  DevBuf<double> q1, q2;                  // d.q1 (per Lorentz cone), d.q2 (norm-bound parts): inputs of sdm_plan_getdatq
+  DevBuf<int64_t> d_qblk;                 // qblkstart (0-based rows of the norm-bound parts), lorN+1
   DevBuf<double> ufac;                    // d.u of the scaling (input of sdm_plan_invcholfac), lenud doubles
   DevBuf<int> ic_n, ic_poff, ic_perm; DevBuf<int64_t> ic_off;   // invcholfac block tables
   size_t stage1_lds = 0;
@@ -208,6 +210,7 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
 void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate);
 void ada_q(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate);
 void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input);
+void ada_datq(sdm_plan *P);     // qpr = values of DAt.q (getDAtm.m:39-44) from the resident d.q1, d.q2
 // y(perm,perm) = u'u per PSD block (invcholfac.c); u, y device (lenud doubles), perm device int32 0-based or null
 void psd_invcholfac(hipStream_t st, const double *u, double *y, const int *perm, const std::vector<int> &ns, int rsdpN,
                     DevBuf<int> &d_n, DevBuf<int64_t> &d_off, DevBuf<int> &d_poff, bool tables_ready);

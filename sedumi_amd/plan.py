@@ -114,6 +114,10 @@ class Plan:
             p0 = np.ascontiguousarray(np.asarray(perm, dtype=np.float64).ravel() - 1, dtype=np.int64)
             check(self._lib.sdm_plan_invcholfac(C.c_void_p(self._p), p0.ctypes.data_as(C.POINTER(C.c_int64))))
 
+    def getdatq(self):
+        """qpr = values of DAt.q (getDAtm.m:39-44) from the resident "q1", "q2" (upload them first)."""
+        check(self._lib.sdm_plan_getdatq(C.c_void_p(self._p)))
+
     def getada_cols(self, j0, j1):
         """Columns j0 <= j < j1 of ADA' (and absd[j0:j1]) only; the rest of "ada" is left untouched."""
         check(self._lib.sdm_plan_getada_cols(C.c_void_p(self._p), C.c_int64(int(j0)), C.c_int64(int(j1))))

@@ -347,3 +347,27 @@ def test_factor_and_solve_are_run_to_run_deterministic(kind):
             assert np.array_equal(out[2], ref[2], equal_nan=True)
             assert all(np.array_equal(a, b) for x, y in zip(out[3], ref[3]) for a, b in zip(x, y))
     plan.close()
+
+
+@pytest.mark.gpu
+def test_datq_on_gpu(glue):
+    """SURVEY 8f N3 (Lorentz half of getDAtm.m): DAt.q formed on the device from d.q1 / d.q2 on an nb-shaped problem
+    (793 cones of dimension 3) against the reference's extractA + ddot chain."""
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    P = problem.random_sdp(m=123, lp=4, q=(3,) * 793, s=(), dens=0.66, seed=31)
+    S = glue.setup(P.At, P.K)
+    d, ud = ref_scaling(P, 3)
+    DAt = glue.getDAtm(S, d)
+    Qpat = sp.csc_matrix(problem.lorentz_pattern(P))
+    plan = Plan(0)
+    plan.set_chol(S["L"], S["ADA"]); plan.set_ada(P.At, P.Ablkjc, P.K, Qpat)
+    plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("q1", d["q1"]); plan.upload("q2", d["q2"])
+    plan.getdatq()
+    cols = np.repeat(np.arange(P.m), np.diff(Qpat.indptr))
+    want = np.asarray(sp.csc_matrix(DAt["q"])[Qpat.indices, cols]).ravel()
+    assert relerr(plan.download("qpr", Qpat.nnz), want) < TOL
+    plan.getada()
+    it = glue.iteration_ref(S, d, ud)
+    assert relerr(plan.download("ada"), it["ADA"].data) < TOL
+    plan.close()

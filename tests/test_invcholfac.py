@@ -100,3 +100,32 @@ def test_invcholfac_bad_inputs():
         mex.invcholfac(np.ones(15), K)
     with pytest.raises(SdmError):
         mex.invcholfac(np.ones(16), K, np.array([1.0, 1.0, 2.0, 3.0]))     # not a permutation
+
+
+@pytest.mark.parametrize("kw", [dict(m=35, lp=8, q=(4, 3, 5), s=()), dict(m=24, lp=3, q=(3,) * 40, s=(4,), dens=0.6),
+                                dict(m=30, lp=0, q=(6, 2), s=(5,), dens=0.2)])
+def test_datq_on_device_matches_getDAtm(glue, kw):
+    """SURVEY 8f N3 (the Lorentz half of getDAtm.m:39-44): DAt.q = diag(d.q1) * A(trace rows,:) + ddot(d.q2, A, ...) formed
+    on the device from the resident d.q1 / d.q2, against the reference's extractA + ddot MEX chain, then through
+    getada2's resident counterpart."""
+    import scipy.sparse as sp
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    from helpers import ref_scaling
+    P = problem.random_sdp(seed=17, **kw)
+    S = glue.setup(P.At, P.K)
+    d, ud = ref_scaling(P, 3)
+    DAt = glue.getDAtm(S, d)
+    Qpat = sp.csc_matrix(problem.lorentz_pattern(P))
+    plan = Plan(0)
+    plan.set_chol(S["L"], S["ADA"]); plan.set_ada(P.At, P.Ablkjc, P.K, Qpat)
+    plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud)
+    plan.upload("q1", d["q1"]); plan.upload("q2", d["q2"])
+    plan.getdatq()
+    cols = np.repeat(np.arange(P.m), np.diff(Qpat.indptr))
+    want = np.asarray(sp.csc_matrix(DAt["q"])[Qpat.indices, cols]).ravel()
+    assert relerr(plan.download("qpr", Qpat.nnz), want) < TOL
+    plan.getada()
+    it = glue.iteration_ref(S, d, ud)
+    assert relerr(plan.download("ada"), it["ADA"].data) < TOL
+    plan.close()

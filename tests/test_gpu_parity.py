@@ -371,3 +371,24 @@ def test_datq_on_gpu(glue):
     it = glue.iteration_ref(S, d, ud)
     assert relerr(plan.download("ada"), it["ADA"].data) < TOL
     plan.close()
+
+
+@pytest.mark.gpu
+def test_sweeps_with_front_vector_in_hbm(refmex, glue):
+    """Fronts beyond SOLVE_LDS_MAX (3072) rows keep their front-local vector in HBM (the second instantiation of the
+    sweep bodies): multi-front factor whose leaves have 3100+ rows below their own columns."""
+    from oracle import glue as gl
+    from sedumi_amd import mex
+    from test_emu_parity import _bordered_blocks
+    rng = np.random.default_rng(9)
+    X = _bordered_blocks(100, 130, 3100, rng)
+    L = glue.symbchol(X)
+    xs = L["xsuper"].ravel().astype(int)
+    assert xs.size - 1 >= 2 and np.diff(L["L"].indptr)[xs[0] - 1] > 3072
+    r = refmex.call("blkchol", 4, L, X, gl.default_pars_chol())
+    o = mex.blkchol(L, X, gl.default_pars_chol())
+    assert relerr(o[0], r[0]) < TOL and relerr(o[1], r[1]) < TOL
+    L2 = dict(L); L2["L"] = r[0]
+    rhs = rng.standard_normal((X.shape[0], 2))
+    assert relerr(mex.fwblkslv(L2, rhs), refmex.call("fwblkslv", 1, L2, rhs)) < TOL
+    assert relerr(mex.bwblkslv(L2, rhs), refmex.call("bwblkslv", 1, L2, rhs)) < TOL

@@ -19,7 +19,7 @@ constexpr int ELL_WAVES = 8;  // wavefronts per workgroup of the ELL stage-2 ker
 constexpr int SOLVE_LDS_MAX = 3072;   // doubles of the front-local vector kept in LDS (24 KB, next to 129 KB of staged blocks)
 constexpr int BIG_FRONT = 1024;       // single fronts from this order on: one launch per super-panel and sweep instead of one workgroup
 constexpr int BIGW = 256;             // width of a super-panel of the big-front sweeps (a multiple of SNB)
-constexpr int FUSE_MAX_TILES = 136;    // trailing updates of at most this many tiles ride along with the next diagonal-block launch
+constexpr int FUSE_MAX_TILES = 78;     // trailing updates of at most this many tiles ride along with the next diagonal-block launch
 constexpr int PIPE_MIN_ROWS = 96;      // fronts with at least this many rows run the sweeps on the look-ahead schedule
 constexpr int SOLVE_THREADS = 1024;   // workgroup of the per-front solve kernels (16 waves stream the panel)
 constexpr int SW = 8;                 // columns of the diagonal block swept in registers at a time (readlane chain), rest via LDS

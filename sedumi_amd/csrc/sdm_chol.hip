@@ -164,7 +164,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   C.frontsT.alloc((size_t)C.tsize);
   { std::vector<int64_t> l64(C.Ljc.begin(), C.Ljc.end()); C.d_Ljc.upload(l64); }
   C.fronts.alloc((size_t)C.fsize); C.wvec.alloc((size_t)C.wsize); C.colbuf.alloc((size_t)C.wsize + (size_t)nsuper);
-  C.d.alloc(m); C.dsolve.alloc(m); C.lb.alloc(m); C.pivval.alloc(m); C.pivstat.alloc(m); C.ub.alloc(2); C.upd_cnt.alloc((size_t)std::max<sdm_int>(1, C.nsuper));
+  C.d.alloc(m); C.dsolve.alloc(m); C.lb.alloc(m); C.pivval.alloc(m); C.pivstat.alloc(m); C.ub.alloc(3); C.upd_cnt.alloc((size_t)std::max<sdm_int>(1, C.nsuper));
   P->ada_val.alloc((size_t)C.nnzADA); P->absd.alloc(m); P->lpr.alloc((size_t)C.nnzL);
   P->rhs.alloc(m); P->y.alloc(m); P->ywork.alloc(m);
   P->has_chol = true; P->factored = false;
@@ -194,15 +194,18 @@ __global__ void k_load_factor(double *F, double *FT, const double *Lpr, const in
   for (; t < nnzL; t += stride) { const double v = Lpr[t]; F[dst[t]] = v; if (dstT[t] >= 0) FT[dstT[t]] = v; }
 }
 
-// ---- pivot thresholds (blkchol.c:168-184): one workgroup.
+// ---- pivot thresholds (blkchol.c:168-184), grid-stride over the columns.
 //   ub = max_j P(perm_j,perm_j) / maxu^2 ;  lb_j = max(abstol, canceltol * orgd_j)
+// ub[2] collects max_j as the bit pattern of a non-negative double (ordered like the unsigned integer: atomicMax is
+// exact and order independent); ub[1] = maxu; k_ldl_panel forms ub from them.  ub[2] is zeroed by the host before.
 __global__ void k_prep_pivots(int m, const double *ada, const int *asm_src, const int64_t *Ljc, const int *perm,
                               const double *absd, int use_absd, double canceltol, double maxu, double abstol,
                               double *lb, double *ub, int *pivstat, double *pivval, int nsuper, int *upd_cnt) {
   __shared__ double red[256];
-  for (int i = threadIdx.x; i < nsuper; i += blockDim.x) upd_cnt[i] = 0;     // tile counters of k_ldl_panel
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
+  for (int i = gid; i < nsuper; i += gstride) upd_cnt[i] = 0;             // tile counters of k_ldl_panel
   double mx = 0.0;
-  for (int j = threadIdx.x; j < m; j += blockDim.x) {
+  for (int j = gid; j < m; j += gstride) {
     int s = asm_src[Ljc[j]];
     double dj = s < 0 ? 0.0 : ada[s];
     if (dj > mx) mx = dj;
@@ -217,7 +220,11 @@ __global__ void k_prep_pivots(int m, const double *ada, const int *asm_src, cons
     if ((int)threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) { ub[0] = red[0] / (maxu * maxu); ub[1] = maxu; }
+  if (threadIdx.x == 0) {
+    union { double d; unsigned long long u; } b; b.d = red[0];
+    atomicMax((unsigned long long *)&ub[2], b.u);
+    ub[1] = maxu;
+  }
 }
 
 // ---- extend-add: parent front += children's Schur complements.
@@ -610,7 +617,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   double *cb = colbuf + tab.woff[s] + s;                          // probe scratch: ms + 1 doubles per front
   const int tid = threadIdx.x, bs = blockDim.x;
   const int tx = tid & 63, ty = tid >> 6, ny = bs >> 6;
-  const double ub = ubp[0], maxu = ubp[1];
+  const double maxu = ubp[1], ub = ubp[2] / (maxu * maxu);      // ubp[2] = max diagonal (k_prep_pivots)
   if (panel == 0) {
     double sv[NB / (LDL_THREADS / 64)];
     const double *pc = Fs + (int64_t)k0 * ld + k0 + min(tx, kb - 1);
@@ -1673,7 +1680,8 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
   SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), st));
   SDM_KLAUNCH(P, k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
              C.d_asm_dst.p, (int64_t)C.nnzL);
-  SDM_KLAUNCH(P, k_prep_pivots, dim3(1), dim3(256), 0, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
+  SDM_HIP_CHECK(hipMemsetAsync(C.ub.p, 0, 3 * sizeof(double), st));
+  SDM_KLAUNCH(P, k_prep_pivots, dim3(grid1d(m, 256, 64)), dim3(256), 0, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
              P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, (int)C.nsuper, C.upd_cnt.p);
   for (int l = 0; l < C.nlevels; l++) {
     const int *list = C.d_levlist.p + C.levptr[l];

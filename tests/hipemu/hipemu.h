@@ -123,6 +123,7 @@ inline double atomicAdd(double *p, double v) { double o = *p; *p = o + v; return
 inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
+inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 inline int atomicExch(int *p, int v) { int o = *p; *p = v; return o; }
 
 /* scheduling order knob: 0 ascending lanes, 1 descending (exposes missing barriers) */

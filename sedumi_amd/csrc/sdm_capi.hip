@@ -216,11 +216,9 @@ int sdm_plan_ldlsolve(sdm_plan *p) {
   SDM_TRY
   if (!p->factored) throw std::runtime_error("ldlsolve: no factor resident");
   if (solve_single(p, p->rhs.p, p->y.p, 7)) return 0;
-  vec_gather(p, p->ywork.p, p->rhs.p, true);
-  solve_fw(p);
-  vec_divd(p, p->ywork.p);
-  solve_bw(p);
-  vec_gather(p, p->y.p, p->ywork.p, false);
+  // gather through perm, ./d and the scatter of y(perm) ride inside the first / last level launches
+  solve_fw(p, p->rhs.p);
+  solve_bw(p, true, p->y.p);
   SDM_CATCH
 }
 // ---- hipGraph capture of a launch-bound sequence of plan calls (e.g. one whole iteration unit): everything the plan

@@ -1469,11 +1469,13 @@ __device__ __forceinline__ void front_bw(const double *Fs, const double *Ds, int
 // pointer that may be either compiles to FLAT accesses, which queue up behind the streaming loads of the other
 // wavefronts -- measured 2 us per in-block solve of wavefront 0 instead of 1.2.
 __device__ __forceinline__ void fw_level_body(const double *F, const FrontTab &tab, int s, double *wvec, double *y, double *w, bool copy_up,
-                                              double *wb, double *Sd) {
+                                              double *wb, double *Sd, const double *src, const int *perm) {
   const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
   double *wg = wvec + tab.woff[s];
   const int tid = threadIdx.x, bs = blockDim.x;
-  for (int i = tid; i < ms; i += bs) w[i] = i < ns ? y[first + i] : 0.0;
+  // src != null: the right-hand side is gathered through perm on the way in (fwblkslv.c:298-303) instead of by a
+  // separate launch
+  for (int i = tid; i < ms; i += bs) w[i] = i < ns ? (src ? src[perm[first + i]] : y[first + i]) : 0.0;
   __syncthreads();
   for (int ci = tab.childptr[s]; ci < tab.childptr[s + 1]; ci++) {   // children's update vectors, fixed order
     const int c = tab.childlist[ci];
@@ -1488,35 +1490,40 @@ __device__ __forceinline__ void fw_level_body(const double *F, const FrontTab &t
   if (copy_up) for (int i = ns + tid; i < ms; i += bs) wg[i] = w[i];      // update vector for the parent
 }
 __global__ void __launch_bounds__(SOLVE_THREADS)
-k_fw_level(const double *F, FrontTab tab, const int *list, double *wvec, double *y, int use_lds) {
+k_fw_level(const double *F, FrontTab tab, const int *list, double *wvec, double *y, int use_lds, const double *src, const int *perm) {
   SDM_DYN_SMEM(smem);
   __shared__ double wb[3 * SNB];
   double *Sd = (double *)smem;                                    // staged diagonal / sub-diagonal blocks
   const int s = list[blockIdx.x];
   // use_lds = offset of w behind the staged blocks, 0 = w in HBM
-  if (use_lds) fw_level_body(F, tab, s, wvec, y, (double *)smem + use_lds, true, wb, Sd);
-  else fw_level_body(F, tab, s, wvec, y, wvec + tab.woff[s], false, wb, Sd);
+  if (use_lds) fw_level_body(F, tab, s, wvec, y, (double *)smem + use_lds, true, wb, Sd, src, perm);
+  else fw_level_body(F, tab, s, wvec, y, wvec + tab.woff[s], false, wb, Sd, src, perm);
 }
 
 __device__ __forceinline__ void bw_level_body(const double *F, const double *DT, const FrontTab &tab, int s, double *y, double *w,
-                                              double *dots, double *Sd) {
+                                              double *dots, double *Sd, const double *dscale, double *yout, const int *perm) {
   const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
   const int *rows = tab.lindx + tab.xl[s];
   const int tid = threadIdx.x, bs = blockDim.x;
-  // rows below the supernode belong to ancestors, already final (bwblkslv.c:104-105 gathers them once)
-  for (int i = tid; i < ms; i += bs) w[i] = i < ns ? y[first + i] : y[rows[i]];
+  // rows below the supernode belong to ancestors, already final (bwblkslv.c:104-105 gathers them once); dscale != null:
+  // the ./d between the sweeps (wrapPcg.m:57) is applied to the supernode's own entries on the way in
+  for (int i = tid; i < ms; i += bs) w[i] = i < ns ? (dscale ? y[first + i] / dscale[first + i] : y[first + i]) : y[rows[i]];
   __syncthreads();
   front_bw(F + tab.foff[s], DT + tab.toff[s], ns, ms, tab.ld[s], w, dots, Sd);
-  for (int i = tid; i < ns; i += bs) y[first + i] = w[i];
+  for (int i = tid; i < ns; i += bs) {
+    y[first + i] = w[i];                                           // descendants read it from here
+    if (yout) yout[perm[first + i]] = w[i];                        // y(perm) = ... (bwblkslv.c:272-278) without a scatter launch
+  }
 }
 __global__ void __launch_bounds__(SOLVE_THREADS)
-k_bw_level(const double *F, const double *DT, FrontTab tab, const int *list, double *wvec, double *y, int use_lds) {
+k_bw_level(const double *F, const double *DT, FrontTab tab, const int *list, double *wvec, double *y, int use_lds,
+           const double *dscale, double *yout, const int *perm) {
   SDM_DYN_SMEM(smem);
   __shared__ double dots[3 * SNB];
   double *Sd = (double *)smem;                                    // staged diagonal / sub-diagonal blocks
   const int s = list[blockIdx.x];
-  if (use_lds) bw_level_body(F, DT, tab, s, y, (double *)smem + use_lds, dots, Sd);
-  else bw_level_body(F, DT, tab, s, y, wvec + tab.woff[s], dots, Sd);
+  if (use_lds) bw_level_body(F, DT, tab, s, y, (double *)smem + use_lds, dots, Sd, dscale, yout, perm);
+  else bw_level_body(F, DT, tab, s, y, wvec + tab.woff[s], dots, Sd, dscale, yout, perm);
 }
 
 // The whole  y(perm) = L' \ ((L \ rhs(perm)) ./ d)  of wrapPcg.m:56-59 in ONE launch when the factor is a single
@@ -1743,7 +1750,7 @@ static int level_threads(const CholPlan &C, int l) {
   if (mx >= PIPE_MIN_ROWS) return SOLVE_THREADS;              // full workgroup: look-ahead schedule (front_fw_pipe / front_bw_pipe)
   return std::min(SOLVE_THREADS - 64, std::max(64, (mx + 63) / 64 * 64));
 }
-void solve_fw(sdm_plan *P) {
+void solve_fw(sdm_plan *P, const double *src) {
   CholPlan &C = P->chol;
   FrontTab tab = front_tab(C);
   size_t lds; int use; solve_cfg(C, lds, use);
@@ -1753,10 +1760,10 @@ void solve_fw(sdm_plan *P) {
   for (int l = 0; l < C.nlevels; l++) {
     const int nfr = C.levptr[l + 1] - C.levptr[l];
     SDM_KLAUNCH(P, k_fw_level, dim3(nfr), dim3(level_threads(C, l)), lds, C.fronts.p, tab, C.d_levlist.p + C.levptr[l], C.wvec.p,
-                P->ywork.p, use);
+                P->ywork.p, use, src, C.d_perm.p);
   }
 }
-void solve_bw(sdm_plan *P) {
+void solve_bw(sdm_plan *P, bool divide, double *yout) {
   CholPlan &C = P->chol;
   FrontTab tab = front_tab(C);
   size_t lds; int use; solve_cfg(C, lds, use);
@@ -1766,7 +1773,7 @@ void solve_bw(sdm_plan *P) {
   for (int l = C.nlevels - 1; l >= 0; l--) {
     const int nfr = C.levptr[l + 1] - C.levptr[l];
     SDM_KLAUNCH(P, k_bw_level, dim3(nfr), dim3(level_threads(C, l)), lds, C.fronts.p, C.frontsT.p, tab, C.d_levlist.p + C.levptr[l],
-                C.wvec.p, P->ywork.p, use);
+                C.wvec.p, P->ywork.p, use, divide ? (const double *)C.dsolve.p : (const double *)nullptr, yout, C.d_perm.p);
   }
 }
 // single-front factor: the complete solve (mode bits 1 fw | 2 ./d | 4 bw) in one launch, rhs -> yout

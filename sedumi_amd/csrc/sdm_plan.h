@@ -194,8 +194,8 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
 void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd);
 void chol_extract(sdm_plan *P, double *d_Lpr_out);           // device pointer, nnzL doubles
 void chol_load_factor(sdm_plan *P, const double *h_Lpr);     // host L values -> fronts (for stand-alone solves)
-void solve_fw(sdm_plan *P);   // in place on P->ywork
-void solve_bw(sdm_plan *P);   // in place on P->ywork
+void solve_fw(sdm_plan *P, const double *src = nullptr);   // src: unpermuted right-hand side gathered on the way in (else ywork holds it)
+void solve_bw(sdm_plan *P, bool divide = false, double *yout = nullptr);   // divide: ./d on the way in; yout: y(perm) scattered on the way out
 bool solve_single(sdm_plan *P, const double *rhs, double *yout, int mode);  // single-front plans: whole solve in one launch
 void vec_gather(sdm_plan *P, double *dst, const double *src, bool forward);  // dst[k]=src[perm[k]] / dst[perm[k]]=src[k]
 void vec_divd(sdm_plan *P, double *v);

@@ -314,13 +314,15 @@ __device__ __noinline__ double pivot_probe(const double (*S)[NB + 1], const doub
 // row j][k] * d_k, dsh = NB doubles (all LDS).
 // DIAG (tile (0,0) in the workgroup that factors the next diagonal block right away): the result also goes to LDS
 // as that kernel's S / Lc arrays (which overlay As / Bs), kbn = columns of the next panel.
-template <int NW, bool DIAG>
+template <int NW, bool DIAG, bool WT = false>
 __device__ __forceinline__ void update_tile(double *Fs, int ld, int ms, int first, int k0, int kb, int I, int J, const double *d,
                                             double (*As)[TILE], double (*Bs)[TILE], double *dsh,
-                                            double (*S)[NB + 1] = nullptr, double *Lc = nullptr, int kbn = 0) {
+                                            double (*S)[NB + 1] = nullptr, double *Lc = nullptr, int kbn = 0,
+                                            int tid = threadIdx.x, bool active = true) {
+  // tid: position inside the group of NW wavefronts that shares the tile (two groups of one workgroup may run two
+  // tiles side by side: same barriers); active = false: go through the motions (barriers) without storing
   constexpr int BJ = 8 / NW;                                  // 16-column MFMA tiles per wavefront along J
   const int r0 = k0 + kb;
-  const int tid = threadIdx.x;
   SDM_PHASE_BEGIN();
   if (tid < NB) dsh[tid] = tid < kb ? d[first + k0 + tid] : 0.0;
   const int w = tid >> 6, l = tid & 63;
@@ -403,9 +405,9 @@ __device__ __forceinline__ void update_tile(double *Fs, int ld, int ms, int firs
         const int jj = lk + 4 * r;
         const int ti = wi * 32 + a * 16 + ll, tj = cj + b * 16 + jj;
         const int gi = r0 + I * TILE + ti, gj = r0 + J * TILE + tj;
-        if (gi < ms && gj < ms && gi >= gj) {
+        if (active && gi < ms && gj < ms && gi >= gj) {
           const double v = cv[a][b][r] - acc[a][b][r];
-          Fs[(int64_t)gj * ld + gi] = v;
+          if (WT) sdm_store_wt(&Fs[(int64_t)gj * ld + gi], v); else Fs[(int64_t)gj * ld + gi] = v;
           if (DIAG && ti < kbn) S[ti][tj] = v;
         }
       }
@@ -554,7 +556,7 @@ __device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, i
 __device__ __forceinline__ void wait_prev_update(const int *cnt, int ms, int panel, int q0) {
   if (threadIdx.x == 0) {
     int target = 0;                                            // launches q0 .. panel carried update tiles
-    for (int q = max(q0, 1); q <= panel; q++) { const int nt = (ms - q * NB + TILE - 1) / TILE; target += nt * (nt + 1) / 2 - 1; }
+    for (int q = max(q0, 1); q <= panel; q++) { const int nt = (ms - q * NB + TILE - 1) / TILE; target += (nt * (nt + 1) / 2 - 1 + 1) / 2; }
     while (sdm_signal_load(cnt) < target) SDM_SPIN_PAUSE();
   }
   __syncthreads();
@@ -583,15 +585,20 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
     if (panel > 0) {
       const int kp = (panel - 1) * NB;                             // previous panel: full
       const int nt = (ms - (kp + NB) + TILE - 1) / TILE;
-      if (bx >= nt * (nt + 1) / 2) return;
+      if (bx > 0 && 1 + 2 * (bx - 1) >= nt * (nt + 1) / 2) return;
       double (*As)[TILE] = (double (*)[TILE])smem;
       double (*Bs)[TILE] = As + NB;
       __shared__ double dsh[NB];
       if (bx > 0) {
+        // two tiles side by side, 4 wavefronts each (the stand-alone kernel's shape: same tiles per CU and second)
+        const int half = threadIdx.x >> 8, t = 1 + 2 * (bx - 1) + half;
+        const bool active = t < nt * (nt + 1) / 2;
         int I, J;
-        tile_index(bx, I, J);
-        update_tile<LDL_THREADS / 64, false>(F + tab.foff[s], ld, ms, first, kp, NB, I, J, d, As, Bs, dsh);
-        __threadfence();
+        tile_index(active ? t : 1, I, J);
+        __shared__ double dsh2[2][NB];
+        update_tile<4, false, true>(F + tab.foff[s], ld, ms, first, kp, NB, I, J, d, As + half * 2 * NB, Bs + half * 2 * NB, dsh2[half],
+                                    nullptr, nullptr, 0, (int)threadIdx.x & 255, active);
+        SDM_STORES_DONE();
         __syncthreads();
         if (threadIdx.x == 0) sdm_signal_add(&upd_cnt[s]);
         return;
@@ -1681,7 +1688,7 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
   const int m = (int)C.m;
   
 #ifndef SDM_EMU
-  SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS));
+  SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_RIDE));
   SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS));
 #endif
   SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), st));
@@ -1700,8 +1707,8 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
       // along in extra workgroups when there are few enough to hide behind the diagonal block, else k_ldl_update
       // has applied them (riding = 0 below)
       const bool ride = L.panel > 0 && C.launches[li - 1].maxtiles <= FUSE_MAX_TILES;
-      const int ntile = ride ? std::max(1, C.launches[li - 1].maxtiles) : 1;
-      SDM_KLAUNCH(P, k_ldl_panel, dim3(ntile, L.nactive), dim3(LDL_THREADS), PANEL_LDS, C.fronts.p, C.frontsT.p, tab, list,
+      const int ntile = ride ? 1 + C.launches[li - 1].maxtiles / 2 : 1;      // workgroup 0 + two tiles per further workgroup
+      SDM_KLAUNCH(P, k_ldl_panel, dim3(ntile, L.nactive), dim3(LDL_THREADS), ride ? PANEL_LDS_RIDE : PANEL_LDS, C.fronts.p, C.frontsT.p, tab, list,
                   L.panel, C.d.p, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p,
                   C.d_Ljc.p, m, C.upd_cnt.p, L.q0);
       if (L.maxrows > TRSM_ROWS)

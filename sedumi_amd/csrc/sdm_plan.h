@@ -19,7 +19,7 @@ constexpr int ELL_WAVES = 8;  // wavefronts per workgroup of the ELL stage-2 ker
 constexpr int SOLVE_LDS_MAX = 3072;   // doubles of the front-local vector kept in LDS (24 KB, next to 129 KB of staged blocks)
 constexpr int BIG_FRONT = 1024;       // single fronts from this order on: one launch per super-panel and sweep instead of one workgroup
 constexpr int BIGW = 256;             // width of a super-panel of the big-front sweeps (a multiple of SNB)
-constexpr int FUSE_MAX_TILES = 78;     // trailing updates of at most this many tiles ride along with the next diagonal-block launch
+constexpr int FUSE_MAX_TILES = 1 << 20; // trailing updates of at most this many tiles ride along with the next diagonal-block launch (in effect: all)
 constexpr int PIPE_MIN_ROWS = 96;      // fronts with at least this many rows run the sweeps on the look-ahead schedule
 constexpr int SOLVE_THREADS = 1024;   // workgroup of the per-front solve kernels (16 waves stream the panel)
 constexpr int SW = 8;                 // columns of the diagonal block swept in registers at a time (readlane chain), rest via LDS
@@ -31,6 +31,7 @@ constexpr int MFMA_MIN_ROWS = 256;    // fronts with fewer rows below their firs
 constexpr int CHK = 16;               // column chunk of the row substitution held in registers
 constexpr int PANEL_RB = (LDL_THREADS / 64) * NB * 17;     // doubles: max(Lc 64x64, Xs 48 x TRSM_ROWS, 8 wave tiles 64x17)
 constexpr size_t PANEL_LDS = (size_t)(NB * (NB + 1) + PANEL_RB) * sizeof(double);
+constexpr size_t PANEL_LDS_RIDE = std::max(PANEL_LDS, (size_t)4 * NB * TILE * sizeof(double));   // two update tiles side by side
 static_assert(PANEL_RB >= NB * NB && PANEL_RB >= (NB - CHK) * TRSM_ROWS && TRSM_ROWS == 16 * (LDL_THREADS / 64) && ROWS_BATCH <= TRSM_ROWS, "panel LDS layout");
 static_assert(NB == SNB, "the transposed diagonal blocks written by the factor are read by the solves");
 

@@ -21,6 +21,8 @@ inline double sdm_bcast_lane(double v, int lane) { return emu_shfl(v, lane, 0); 
 inline bool sdm_lane_pred(bool pred, int lane) { return emu_shfl(pred ? 1.0 : 0.0, lane, 0) != 0.0; }
 // completion counters between workgroups of one launch (the emulator runs workgroups one after the other)
 inline void sdm_signal_add(int *p) { *p += 1; }
+inline void sdm_store_wt(double *p, double v) { *p = v; }
+#define SDM_STORES_DONE() do {} while (0)
 inline int sdm_signal_load(const int *p) { return *p; }
 #define SDM_ACQUIRE_FENCE() do {} while (0)
 #define SDM_SPIN_PAUSE() do { fprintf(stderr, "hipemu: waiting on a workgroup that has not run\n"); abort(); } while (0)
@@ -37,7 +39,13 @@ typedef double2 sdm_double2;
 #define SDM_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 // completion counters between workgroups of one launch: release on the producer side (after __threadfence() and a
 // barrier), acquire on the consumer side, device scope (the workgroups may sit on different XCDs / L2s)
-__device__ __forceinline__ void sdm_signal_add(int *p) { __hip_atomic_fetch_add(p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+// The producers' data stores are write-through to the device-wide coherence point (sdm_store_wt: agent-scope relaxed
+// atomic stores -- a release fence instead would write back the whole L2 of the XCD, microseconds per workgroup when a
+// big trailing matrix is dirty); SDM_STORES_DONE waits for this wavefront's stores, a barrier collects the workgroup,
+// then one relaxed increment publishes it.
+__device__ __forceinline__ void sdm_signal_add(int *p) { __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sdm_store_wt(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define SDM_STORES_DONE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
 __device__ __forceinline__ int sdm_signal_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 #define SDM_ACQUIRE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define SDM_SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)

@@ -71,8 +71,8 @@ def test_dense_front_with_several_row_batches(refmex, m):
     """One dense supernode whose rows below the first 64-column panel span several workgroups of the panel
     kernel (matrix-core row solve, deferred in-place copy of the diagonal block).  The emulator runs the
     workgroups of a launch one after the other, which turns any in-place update another workgroup still has
-    to read into a deterministic failure.  m = 1216: the first trailing updates have more than FUSE_MAX_TILES tiles
-    (stand-alone update launches), the later ones ride along with the next diagonal-block launch."""
+    to read into a deterministic failure.  m = 1216: 19 panels, up to 171 update tiles riding along with a
+    diagonal-block launch, two per workgroup."""
     from oracle import glue as gl
     from sedumi_amd import mex, problem
     rng = np.random.default_rng(m)

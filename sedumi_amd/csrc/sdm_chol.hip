@@ -132,7 +132,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
     for (int i = b; i < e; i++) maxms = std::max(maxms, C.sn_ms[C.levlist[i]]);
     C.lev_T[l] = std::max(1, std::min(128, maxms / 16));
     for (int p = 0; p * NB < maxns; p++) {
-      LevelLaunch L; L.level = l; L.panel = p; L.nactive = 0; L.maxrows = 0; L.maxtiles = 0; L.lasttiles = 0;
+      LevelLaunch L; L.level = l; L.panel = p; L.nactive = 0; L.maxrows = 0; L.maxtiles = 0; L.lasttiles = 0; L.ride_wgs = 0;
       for (int i = b; i < e; i++) {
         int s = C.levlist[i];
         if (C.sn_ns[s] <= p * NB) break;
@@ -143,6 +143,14 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
         int nt = (rows + TILE - 1) / TILE;
         L.maxtiles = std::max(L.maxtiles, nt * (nt + 1) / 2);
         if (C.sn_ns[s] <= (p + 1) * NB) L.lasttiles = std::max(L.lasttiles, nt * (nt + 1) / 2);
+        // workgroups of k_ldl_panel beyond the diagonal-block one (see the kernel): row solves, then pairs of update tiles
+        const int nrw = rows > TRSM_ROWS ? (C.sn_ms[s] - (p * NB + NB) + ROWS_BATCH - 1) / ROWS_BATCH : 0;
+        int tw = 0;
+        if (p > 0) {
+          const int ntp = (C.sn_ms[s] - p * NB + TILE - 1) / TILE;            // tile rows of the update of panel p-1
+          tw = nrw > 0 ? ((ntp - 1) * ntp / 2 + 1) / 2 : (ntp * (ntp + 1) / 2 - 1 + 1) / 2;
+        }
+        L.ride_wgs = std::max(L.ride_wgs, nrw + tw);
       }
       C.launches.push_back(L);
     }
@@ -164,7 +172,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   C.frontsT.alloc((size_t)C.tsize);
   { std::vector<int64_t> l64(C.Ljc.begin(), C.Ljc.end()); C.d_Ljc.upload(l64); }
   C.fronts.alloc((size_t)C.fsize); C.wvec.alloc((size_t)C.wsize); C.colbuf.alloc((size_t)C.wsize + (size_t)nsuper);
-  C.d.alloc(m); C.dsolve.alloc(m); C.lb.alloc(m); C.pivval.alloc(m); C.pivstat.alloc(m); C.ub.alloc(3); C.upd_cnt.alloc((size_t)std::max<sdm_int>(1, C.nsuper));
+  C.d.alloc(m); C.dsolve.alloc(m); C.lb.alloc(m); C.pivval.alloc(m); C.pivstat.alloc(m); C.ub.alloc(3); C.upd_cnt.alloc((size_t)std::max<sdm_int>(1, C.nsuper)); C.diag_cnt.alloc((size_t)std::max<sdm_int>(1, C.nsuper));
   P->ada_val.alloc((size_t)C.nnzADA); P->absd.alloc(m); P->lpr.alloc((size_t)C.nnzL);
   P->rhs.alloc(m); P->y.alloc(m); P->ywork.alloc(m);
   P->has_chol = true; P->factored = false;
@@ -200,10 +208,10 @@ __global__ void k_load_factor(double *F, double *FT, const double *Lpr, const in
 // exact and order independent); ub[1] = maxu; k_ldl_panel forms ub from them.  ub[2] is zeroed by the host before.
 __global__ void k_prep_pivots(int m, const double *ada, const int *asm_src, const int64_t *Ljc, const int *perm,
                               const double *absd, int use_absd, double canceltol, double maxu, double abstol,
-                              double *lb, double *ub, int *pivstat, double *pivval, int nsuper, int *upd_cnt) {
+                              double *lb, double *ub, int *pivstat, double *pivval, int nsuper, int *upd_cnt, int *diag_cnt) {
   __shared__ double red[256];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
-  for (int i = gid; i < nsuper; i += gstride) upd_cnt[i] = 0;             // tile counters of k_ldl_panel
+  for (int i = gid; i < nsuper; i += gstride) { upd_cnt[i] = 0; diag_cnt[i] = 0; }     // counters of k_ldl_panel
   double mx = 0.0;
   for (int j = gid; j < m; j += gstride) {
     int s = asm_src[Ljc[j]];
@@ -424,7 +432,7 @@ __device__ __forceinline__ void tile_index(int t, int &I, int &J) {
 // ---- K1 (k_ldl_panel): one workgroup per front of a level, 64-column panel p: LDL' of the kb x kb diagonal
 // block; when the rows below the block fit one workgroup (<= TRSM_ROWS) they are solved here as well and the
 // block is written back in place.  Otherwise the factored block goes to the transposed copy DT only and
-// K1b (k_ldl_rows, grid = row batches x fronts) solves the rows and copies the block in place -- nobody may
+// the row-solve workgroups of the same launch solve the rows and copy the block in place -- nobody may
 // overwrite the panel while the never-fail rule's column probe of K1 can still read its raw values.
 //
 // Diagonal block (bit-faithful to cholonBlk, blkchol2.c:114-161: column i -= (x_ik / x_kk) * x(:,k), one multiply
@@ -511,22 +519,22 @@ __device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int 
 }
 
 // rows [R, ...) of one batch below the diagonal block of panel p: S = scaled L11 (unit lower), ds = pivots (LDS)
-__device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, int k0, int kb, int batch, int brows,
+// rows [rbeg, rend) below the diagonal block of panel k0 (at most brows = TRSM_ROWS of them per call)
+__device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, int k0, int kb, int rbeg, int rend, int brows,
                                            const double (*S)[NB + 1], const double *ds, double *RB) {
   SDM_FP_STRICT;
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = blockDim.x >> 6;
-  const int r0 = k0 + kb;
+  rend = min(rend, ms);
   if (ms - min(NB, ns) >= MFMA_MIN_ROWS) {                         // per front, the same path for all its panels
     // 16 rows per wavefront at a time, blocked substitution with the GEMM part on the matrix cores
-    const int rend = min(ms, r0 + (batch + 1) * brows);
-    for (int R0 = r0 + batch * brows + 16 * ty; R0 < rend; R0 += 16 * ny)
-      panel_rows_mfma(Fs, ld, ms, k0, kb, R0, S, ds, RB + ty * (NB * 17), tx);
+    for (int R0 = rbeg + 16 * ty; R0 < rend; R0 += 16 * ny)
+      panel_rows_mfma(Fs, ld, rend, k0, kb, R0, S, ds, RB + ty * (NB * 17), tx);
     return;
   }
   // few rows: faithful substitution, one row per work-item, 16-column chunks; x of earlier chunks parked in LDS
   double *Xs = RB;
-  const int r = r0 + batch * brows + tid;
-  if (tid >= brows || r >= ms) return;
+  const int r = rbeg + tid;
+  if (tid >= brows || r >= rend) return;
   for (int c0 = 0; c0 < kb; c0 += CHK) {
     double acc[CHK], x[CHK];
 #pragma unroll
@@ -551,29 +559,46 @@ __device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, i
 }
 
 // Workgroup 0 of k_ldl_panel before it reads rows below its diagonal block: the tiles of the previous panel's update
-// that cover them are applied by the other workgroups of the same launch.  upd_cnt[s] counts finished tile workgroups
-// of front s since the factorisation began (reset by k_prep_pivots); all work-items call this.
-__device__ __forceinline__ void wait_prev_update(const int *cnt, int ms, int panel, int q0) {
-  if (threadIdx.x == 0) {
-    int target = 0;                                            // launches q0 .. panel carried update tiles
-    for (int q = max(q0, 1); q <= panel; q++) { const int nt = (ms - q * NB + TILE - 1) / TILE; target += (nt * (nt + 1) / 2 - 1 + 1) / 2; }
-    while (sdm_signal_load(cnt) < target) SDM_SPIN_PAUSE();
-  }
+// that cover them (block column 0) are applied by other workgroups of the same launch -- by the row-solve workgroups
+// when the panel has them (more than TRSM_ROWS rows below the block: one signal each), else by the tile workgroups
+// (one signal per pair of tiles).  upd_cnt[s] counts those signals since the factorisation began (reset by
+// k_prep_pivots); all work-items call this.  The spin gives up after a few seconds rather than hang the device.
+__device__ __forceinline__ int panel_row_wgs(int ns, int ms, int q) {
+  const int kbq = min(NB, ns - q * NB), nrows = ms - (q * NB + kbq);
+  return nrows > TRSM_ROWS ? (ms - (q * NB + NB) + ROWS_BATCH - 1) / ROWS_BATCH : 0;
+}
+__device__ __forceinline__ void spin_until(const int *cnt, int target) {
+  if (threadIdx.x == 0)
+    for (long it = 0; sdm_signal_load(cnt) < target && it < (1L << 26); it++) SDM_SPIN_PAUSE();
   __syncthreads();
   SDM_ACQUIRE_FENCE();
+}
+__device__ __forceinline__ void wait_prev_update(const int *cnt, int ns, int ms, int panel, int q0) {
+  int target = 0;                                              // launches q0 .. panel carried update tiles
+  for (int q = max(q0, 1); q <= panel; q++) {
+    const int nt = (ms - q * NB + TILE - 1) / TILE, nrw = panel_row_wgs(ns, ms, q);
+    target += nrw > 0 ? nrw : (nt * (nt + 1) / 2) / 2;
+  }
+  spin_until(cnt, target);
 }
 
 __global__ void __launch_bounds__(LDL_THREADS)
 k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, double *d, double *lb, const double *ubp,
             int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src,
-            const int64_t *Ljc, int mtot, int *upd_cnt, int q0) {
+            const int64_t *Ljc, int mtot, int *upd_cnt, int *diag_cnt, int q0, int phase) {
   SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
   SDM_DYN_SMEM(smem);
-  // grid = (1 + tiles of the previous panel's trailing update, fronts).  Workgroup 0 of a front owns the diagonal
-  // block and applies tile 0 of the update of panel-1 itself; when that update is small enough to hide behind this
-  // kernel's dependency chain (launches q0 .. : at most FUSE_MAX_TILES tiles) the other workgroups each apply one of
-  // its other tiles, otherwise k_ldl_update has done so before this launch.  The emulator runs the workgroups of a
-  // launch one after the other: there the diagonal block comes last, so that its waits on the tile counter terminate.
+  // ONE launch per 64-column panel p.  grid = (workgroups, fronts); per front:
+  //   workgroup 0        tile (0,0) of the trailing update of panel p-1 (its own diagonal block), then the LDL' of the
+  //                      block, published (DT, d) for the row-solve workgroups;
+  //   1 .. nrw           (fronts with more than TRSM_ROWS rows below the block) row solve of ROWS_BATCH rows each: first
+  //                      the tile of the previous update that covers exactly those rows in this panel's columns, then
+  //                      -- once workgroup 0 has published the factored block -- the substitution;
+  //   the rest           the other tiles of the previous update, two side by side per workgroup (nobody in this launch
+  //                      reads them, except in fronts without row-solve workgroups, where they signal).
+  // All of this hides behind workgroup 0's dependency chain.  The emulator runs workgroups one after the other:
+  // phase 1 (everything but the substitution, diagonal block last) and phase 2 (the substitution) are two launches
+  // there; the GPU runs phase 0 = both.
 #ifdef SDM_EMU
   const int bx = (int)gridDim.x - 1 - (int)blockIdx.x;
 #else
@@ -582,31 +607,77 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   {
     const int s = list[blockIdx.y];
     const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
-    if (panel > 0) {
-      const int kp = (panel - 1) * NB;                             // previous panel: full
-      const int nt = (ms - (kp + NB) + TILE - 1) / TILE;
-      if (bx > 0 && 1 + 2 * (bx - 1) >= nt * (nt + 1) / 2) return;
-      double (*As)[TILE] = (double (*)[TILE])smem;
-      double (*Bs)[TILE] = As + NB;
-      __shared__ double dsh[NB];
-      if (bx > 0) {
-        // two tiles side by side, 4 wavefronts each (the stand-alone kernel's shape: same tiles per CU and second)
-        const int half = threadIdx.x >> 8, t = 1 + 2 * (bx - 1) + half;
-        const bool active = t < nt * (nt + 1) / 2;
-        int I, J;
-        tile_index(active ? t : 1, I, J);
-        __shared__ double dsh2[2][NB];
-        update_tile<4, false, true>(F + tab.foff[s], ld, ms, first, kp, NB, I, J, d, As + half * 2 * NB, Bs + half * 2 * NB, dsh2[half],
-                                    nullptr, nullptr, 0, (int)threadIdx.x & 255, active);
+    const int k0c = panel * NB, kbc = min(NB, ns - k0c), nrowsc = ms - (k0c + kbc);
+    const int nrw = nrowsc > TRSM_ROWS ? (ms - (k0c + NB) + ROWS_BATCH - 1) / ROWS_BATCH : 0;   // tile rows below the first
+    const int kp = (panel - 1) * NB;                               // previous panel (full when there is a panel p)
+    const int nt = panel > 0 ? (ms - (kp + NB) + TILE - 1) / TILE : 0;
+    double (*As)[TILE] = (double (*)[TILE])smem;
+    double (*Bs)[TILE] = As + NB;
+    __shared__ double dsh[NB];
+    if (bx > 0 && bx <= nrw) {
+      // ---- row-solve workgroup b
+      const int b = bx - 1;
+      double *Fs = F + tab.foff[s];
+      if (phase != 2 && panel > 0) {
+        update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, kp, NB, b + 1, 0, d, As, Bs, dsh);
         SDM_STORES_DONE();
         __syncthreads();
         if (threadIdx.x == 0) sdm_signal_add(&upd_cnt[s]);
-        return;
       }
+      if (phase == 1) return;
+      spin_until(diag_cnt + s, panel + 1);                         // the factored diagonal block is in DT, its pivots in d
+      double (*S)[NB + 1] = (double (*)[NB + 1])smem;
+      double *RB = (double *)smem + NB * (NB + 1);
+      __shared__ double dsr[NB];
+      const double *Ds = DT + tab.toff[s] + (int64_t)panel * NB * NB;    // Ds[i*NB + j] = L(k0+i, k0+j)
+      const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = blockDim.x >> 6;
+      {
+        constexpr int NQ = NB / (LDL_THREADS / 64);
+        double sv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) sv[q] = Ds[min(ty + ny * q, NB - 1) * NB + tx];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { const int i = ty + ny * q; if (i < NB) S[i][tx] = (i < kbc && tx < i) ? sv[q] : 0.0; }
+      }
+      if (tid < NB) dsr[tid] = tid < kbc ? d[first + k0c + tid] : 0.0;
+      __syncthreads();
+      panel_rows(Fs, ld, ns, ms, k0c, kbc, k0c + NB * (b + 1), k0c + NB * (b + 2), ROWS_BATCH, S, dsr, RB);      // = tile row b+1
+      return;
+    }
+    if (bx > nrw) {
+      // ---- tile workgroup: two tiles side by side, 4 wavefronts each (the stand-alone kernel's shape)
+      if (phase == 2 || panel == 0) return;
+      const int w = bx - 1 - nrw, half = threadIdx.x >> 8, u = 2 * w + half;
+      int I, J, ntl;
+      bool active;
+      if (nrw > 0) {                                               // block column 0 belongs to the row-solve workgroups
+        ntl = (nt - 1) * nt / 2;
+        if (2 * w >= ntl) return;
+        active = u < ntl;
+        tile_index(active ? u : 0, I, J);
+        I++; J++;
+      } else {
+        ntl = nt * (nt + 1) / 2 - 1;                               // all tiles but (0,0)
+        if (2 * w >= ntl) return;
+        active = u < ntl;
+        tile_index(active ? u + 1 : 1, I, J);
+      }
+      __shared__ double dsh2[2][NB];
+      update_tile<4, false, true>(F + tab.foff[s], ld, ms, first, kp, NB, I, J, d, As + half * 2 * NB, Bs + half * 2 * NB, dsh2[half],
+                                  nullptr, nullptr, 0, (int)threadIdx.x & 255, active);
+      if (nrw == 0) {                                              // readers in this launch: workgroup 0's row solve / probe
+        SDM_STORES_DONE();
+        __syncthreads();
+        if (threadIdx.x == 0) sdm_signal_add(&upd_cnt[s]);
+      }
+      return;
+    }
+    // ---- workgroup 0
+    if (phase == 2) return;
+    if (panel > 0)
       // tile (0,0) = this panel's diagonal block (and what lies right of / below it inside the tile): straight into S
       update_tile<LDL_THREADS / 64, true>(F + tab.foff[s], ld, ms, first, kp, NB, 0, 0, d, As, Bs, dsh,
-                                          (double (*)[NB + 1])smem, (double *)smem + NB * (NB + 1), min(NB, ns - panel * NB));
-    } else if (bx > 0) return;
+                                          (double (*)[NB + 1])smem, (double *)smem + NB * (NB + 1), kbc);
   }
   double (*S)[NB + 1] = (double (*)[NB + 1])smem;                 // diagonal block, S[row][col]
   double *RB = (double *)smem + NB * (NB + 1);                    // Lc during the LDL', then Xs / the wave tiles of the row solve
@@ -738,7 +809,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   const bool ok = !bad;
   if (!ok) {
     // ---- general path: one column per step by all work-items, pivot_probe available
-    if (panel > 0) wait_prev_update(upd_cnt + s, ms, panel, q0);    // the probe reads the rows below the block
+    if (panel > 0) wait_prev_update(upd_cnt + s, ns, ms, panel, q0);  // the probe reads the rows below the block
     for (int j = ty; j < NB; j += ny) { S[tx][j] = (tx < kb && j <= tx) ? Fs[(int64_t)(k0 + j) * ld + k0 + tx] : 0.0; Lc[j * NB + tx] = 0.0; }
     if (tid < NB) { ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
     __syncthreads();
@@ -773,60 +844,39 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   SDM_PHASE(21);
   {
     double *Ds = DT + tab.toff[s] + (int64_t)panel * NB * NB;
-    const bool inplace = nrows <= TRSM_ROWS;
+    // the factored block goes in place from THIS workgroup in every case: it also stored the raw updated block (tile
+    // (0,0) of the previous update), and two workgroups writing the same lines in one launch may sit behind different
+    // L2s whose write-back order is not defined
+    const bool inplace = true;
     for (int j = ty; j < kb; j += ny)
       if (tx < kb && tx >= j) {
         const double v = (tx == j) ? 1.0 : S[tx][j];                // unit diagonal stored explicitly (blkchol2.c:136)
         if (inplace) Fs[(int64_t)(k0 + j) * ld + k0 + tx] = v;
-        Ds[tx * NB + j] = v;                                        // transposed copy of the block (backward solve)
+        sdm_store_wt(&Ds[tx * NB + j], v);                          // transposed copy of the block (backward solve, row solve)
       }
     if (tid < kb) {
       const int gk = first + k0 + tid;
-      d[gk] = ds[tid];
+      sdm_store_wt(&d[gk], ds[tid]);
       if (stt[tid]) { pivstat[gk] = stt[tid]; pivval[gk] = pv[tid]; }   // pivval = amount added (what blkchol2.c:127 keeps in lb[k])
     }
   }
+  if (nrows > TRSM_ROWS) {                                         // the row-solve workgroups of this launch are waiting
+    SDM_STORES_DONE();
+    __syncthreads();
+    if (tid == 0) sdm_signal_add(&diag_cnt[s]);
+    // a partial block (kb < 64, last panel of the supernode) leaves rows r0 .. k0+63 in this workgroup's own tile row:
+    // they were updated by its tile (0,0) and are solved here (the row-solve workgroups own whole tile rows)
+    if (kb < NB) {
+      SDM_ACQUIRE_FENCE();                                       // its own tile-(0,0) stores, not a cached copy from before them
+      panel_rows(Fs, ld, ns, ms, k0, kb, r0, k0 + NB, TRSM_ROWS, S, ds, RB);
+    }
+  } else if (tid == 0) sdm_signal_add(&diag_cnt[s]);               // keeps the count = panels done
   SDM_PHASE(22);
   if (nrows > 0 && nrows <= TRSM_ROWS) {
-    if (panel > 0 && ok) wait_prev_update(upd_cnt + s, ms, panel, q0);
-    panel_rows(Fs, ld, ns, ms, k0, kb, 0, TRSM_ROWS, S, ds, RB);
+    if (panel > 0 && ok) wait_prev_update(upd_cnt + s, ns, ms, panel, q0);
+    panel_rows(Fs, ld, ns, ms, k0, kb, r0, ms, TRSM_ROWS, S, ds, RB);
   }
   SDM_PHASE(23);
-}
-
-// ---- K1b: rows below the diagonal block for fronts with more than TRSM_ROWS of them.  grid = (row batches of ROWS_BATCH,
-// fronts of the level); L11 and d come from K1 (DT / d), batch 0 copies the factored block in place.
-__global__ void __launch_bounds__(PANEL_THREADS)
-k_ldl_rows(double *F, const double *DT, FrontTab tab, const int *list, int panel, const double *d) {
-  SDM_DYN_SMEM(smem);
-  double (*S)[NB + 1] = (double (*)[NB + 1])smem;
-  double *RB = (double *)smem + NB * (NB + 1);
-  __shared__ double ds[NB];
-  const int s = list[blockIdx.y];
-  const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
-  const int k0 = panel * NB, kb = min(NB, ns - k0);
-  const int nrows = ms - (k0 + kb), batch = blockIdx.x;
-  if (nrows <= TRSM_ROWS || batch * ROWS_BATCH >= nrows) return;   // uniform (small fronts were finished by K1)
-  double *Fs = F + tab.foff[s];
-  const double *Ds = DT + tab.toff[s] + (int64_t)panel * NB * NB;    // Ds[i*NB + j] = L(k0+i, k0+j)
-  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = blockDim.x >> 6;
-  {
-    constexpr int NQ = NB / (PANEL_THREADS / 64);                   // rows of L11 per work-item
-    double sv[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) sv[q] = Ds[min(ty + ny * q, NB - 1) * NB + tx];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) { const int i = ty + ny * q; if (i < NB) S[i][tx] = (i < kb && tx < i) ? sv[q] : 0.0; }
-  }
-  if (tid < NB) ds[tid] = tid < kb ? d[first + k0 + tid] : 0.0;
-  if (batch == 0)
-    for (int i = ty; i < kb; i += ny)
-      if (tx <= i) Fs[(int64_t)(k0 + tx) * ld + k0 + i] = Ds[i * NB + tx];
-  SDM_PHASE_BEGIN();
-  __syncthreads();
-  SDM_PHASE(24);
-  panel_rows(Fs, ld, ns, ms, k0, kb, batch, ROWS_BATCH, S, ds, RB);
-  SDM_PHASE(27);
 }
 
 // stand-alone update.  Supernodes that END with this panel: all tiles (the update of the rows beyond, passed up to the
@@ -1689,35 +1739,31 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
   
 #ifndef SDM_EMU
   SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_RIDE));
-  SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS));
 #endif
   SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), st));
   SDM_KLAUNCH(P, k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
              C.d_asm_dst.p, (int64_t)C.nnzL);
   SDM_HIP_CHECK(hipMemsetAsync(C.ub.p, 0, 3 * sizeof(double), st));
   SDM_KLAUNCH(P, k_prep_pivots, dim3(grid1d(m, 256, 64)), dim3(256), 0, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
-             P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, (int)C.nsuper, C.upd_cnt.p);
+             P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, (int)C.nsuper, C.upd_cnt.p, C.diag_cnt.p);
   for (int l = 0; l < C.nlevels; l++) {
     const int *list = C.d_levlist.p + C.levptr[l];
     const int nfr = C.levptr[l + 1] - C.levptr[l];
     if (l > 0) SDM_KLAUNCH(P, k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, C.fronts.p, tab, list);
     for (int li = C.lev_first_launch[l]; li < C.lev_first_launch[l + 1]; li++) {
       const LevelLaunch &L = C.launches[li];
-      // tile 0 of the previous panel's trailing update is applied by workgroup 0 of k_ldl_panel; the other tiles ride
-      // along in extra workgroups when there are few enough to hide behind the diagonal block, else k_ldl_update
-      // has applied them (riding = 0 below)
-      const bool ride = L.panel > 0 && C.launches[li - 1].maxtiles <= FUSE_MAX_TILES;
-      const int ntile = ride ? 1 + C.launches[li - 1].maxtiles / 2 : 1;      // workgroup 0 + two tiles per further workgroup
-      SDM_KLAUNCH(P, k_ldl_panel, dim3(ntile, L.nactive), dim3(LDL_THREADS), ride ? PANEL_LDS_RIDE : PANEL_LDS, C.fronts.p, C.frontsT.p, tab, list,
-                  L.panel, C.d.p, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p,
-                  C.d_Ljc.p, m, C.upd_cnt.p, L.q0);
-      if (L.maxrows > TRSM_ROWS)
-        SDM_KLAUNCH(P, k_ldl_rows, dim3((L.maxrows + ROWS_BATCH - 1) / ROWS_BATCH, L.nactive), dim3(PANEL_THREADS), PANEL_LDS,
-                    C.fronts.p, C.frontsT.p, tab, list, L.panel, C.d.p);
-      const bool next_rides = L.maxtiles <= FUSE_MAX_TILES;         // what the NEXT diagonal-block launch will carry
-      const int upd_tiles = next_rides ? L.lasttiles : L.maxtiles;
-      if (upd_tiles > 0)
-        SDM_KLAUNCH(P, k_ldl_update, dim3(upd_tiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p, next_rides ? 1 : 0);
+      // ONE launch per panel: diagonal block (+ tile 0 of the previous panel's update), the row solves and the rest of
+      // the previous update (see k_ldl_panel).  The emulator runs it in two phases (workgroups are sequential there).
+#ifdef SDM_EMU
+      for (int phase = 1; phase <= 2; phase++)
+#else
+      const int phase = 0;
+#endif
+        SDM_KLAUNCH(P, k_ldl_panel, dim3(1 + L.ride_wgs, L.nactive), dim3(LDL_THREADS), PANEL_LDS_RIDE, C.fronts.p, C.frontsT.p, tab, list,
+                    L.panel, C.d.p, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p,
+                    C.d_Ljc.p, m, C.upd_cnt.p, C.diag_cnt.p, 1, phase);
+      if (L.lasttiles > 0)                                           // supernodes that end with this panel and have rows beyond
+        SDM_KLAUNCH(P, k_ldl_update, dim3(L.lasttiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p, 1);
     }
   }
   SDM_KLAUNCH(P, k_dsolve, dim3((m + 255) / 256), dim3(256), 0, C.dsolve.p, C.d.p, m);

@@ -74,6 +74,7 @@ struct LevelLaunch {
   int maxtiles;         // max number of TILE x TILE lower tiles in the trailing update
   int lasttiles;        // the same over the fronts whose LAST panel this is (stand-alone update launch)
   int q0;               // first panel of the level whose diagonal-block launch carries the previous update's tiles
+  int ride_wgs;         // workgroups of k_ldl_panel beyond workgroup 0 (row solves + pairs of update tiles), max over fronts
 };
 
 struct CholPlan {
@@ -93,6 +94,7 @@ struct CholPlan {
   DevBuf<int> d_asm_src;
   DevBuf<double> fronts, frontsT, wvec, colbuf, d, dsolve, lb, pivval, ub;
   DevBuf<int> pivstat;
+  DevBuf<int> diag_cnt;    // per front: panels whose factored diagonal block has been published (k_ldl_panel)
   DevBuf<int> upd_cnt;     // per front: finished tile workgroups of the updates that rode along with k_ldl_panel
 };
 

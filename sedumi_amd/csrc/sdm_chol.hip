@@ -322,11 +322,13 @@ __device__ __noinline__ double pivot_probe(const double (*S)[NB + 1], const doub
 // row j][k] * d_k, dsh = NB doubles (all LDS).
 // DIAG (tile (0,0) in the workgroup that factors the next diagonal block right away): the result also goes to LDS
 // as that kernel's S / Lc arrays (which overlay As / Bs), kbn = columns of the next panel.
-template <int NW, bool DIAG, bool WT = false>
+template <int NW, bool DIAG, bool WT = false, bool TW = false>
 __device__ __forceinline__ void update_tile(double *Fs, int ld, int ms, int first, int k0, int kb, int I, int J, const double *d,
                                             double (*As)[TILE], double (*Bs)[TILE], double *dsh,
                                             double (*S)[NB + 1] = nullptr, double *Lc = nullptr, int kbn = 0,
-                                            int tid = threadIdx.x, bool active = true) {
+                                            int tid = threadIdx.x, bool active = true, double *tw = nullptr) {
+  // TW: the result also goes to LDS as the row solve's wave tiles (tw[(row/16)*NB*17 + col*17 + row%16], columns
+  // beyond kbn zeroed) -- the workgroup that solves these rows next needs no second trip to HBM
   // tid: position inside the group of NW wavefronts that shares the tile (two groups of one workgroup may run two
   // tiles side by side: same barriers); active = false: go through the motions (barriers) without storing
   constexpr int BJ = 8 / NW;                                  // 16-column MFMA tiles per wavefront along J
@@ -398,6 +400,7 @@ __device__ __forceinline__ void update_tile(double *Fs, int ld, int ms, int firs
     for (int a = 0; a < 2; a++) av[a] = an[a];
   }
   SDM_PHASE(DIAG ? 15 : 29);
+  if (TW) __syncthreads();                         // As / Bs are dead: the wave tiles overlay them
   if (DIAG) {
     __syncthreads();                               // As / Bs are dead: S and Lc overlay them
     const int tx = tid & 63, ty = tid >> 6;
@@ -417,6 +420,7 @@ __device__ __forceinline__ void update_tile(double *Fs, int ld, int ms, int firs
           const double v = cv[a][b][r] - acc[a][b][r];
           if (WT) sdm_store_wt(&Fs[(int64_t)gj * ld + gi], v); else Fs[(int64_t)gj * ld + gi] = v;
           if (DIAG && ti < kbn) S[ti][tj] = v;
+          if (TW) tw[(ti >> 4) * (NB * 17) + tj * 17 + (ti & 15)] = tj < kbn ? v : 0.0;
         }
       }
   SDM_PHASE(DIAG ? 31 : 30);
@@ -454,9 +458,9 @@ __device__ __forceinline__ void tile_index(int t, int &I, int &J) {
 // (no inverse is formed: the never-fail pivot rule allows multipliers up to maxu = 5e5); results agree with the
 // plain substitution to rounding.
 __device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int k0, int kb, int R0, const double (*S)[NB + 1],
-                                                const double *ds, double *Tw, int lane) {
+                                                const double *ds, double *Tw, int lane, bool staged = false) {
   const int li = lane & 15, lk = lane >> 4;
-  {                                                           // 16 rows x 64 columns -> LDS tile Tw[col*17 + row]
+  if (!staged) {                                              // 16 rows x 64 columns -> LDS tile Tw[col*17 + row]
     double tv[NB / 4];
     const double *pr = Fs + min(R0 + li, ms - 1);
 #pragma unroll
@@ -521,14 +525,14 @@ __device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int 
 // rows [R, ...) of one batch below the diagonal block of panel p: S = scaled L11 (unit lower), ds = pivots (LDS)
 // rows [rbeg, rend) below the diagonal block of panel k0 (at most brows = TRSM_ROWS of them per call)
 __device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, int k0, int kb, int rbeg, int rend, int brows,
-                                           const double (*S)[NB + 1], const double *ds, double *RB) {
+                                           const double (*S)[NB + 1], const double *ds, double *RB, bool staged = false) {
   SDM_FP_STRICT;
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = blockDim.x >> 6;
   rend = min(rend, ms);
   if (ms - min(NB, ns) >= MFMA_MIN_ROWS) {                         // per front, the same path for all its panels
     // 16 rows per wavefront at a time, blocked substitution with the GEMM part on the matrix cores
     for (int R0 = rbeg + 16 * ty; R0 < rend; R0 += 16 * ny)
-      panel_rows_mfma(Fs, ld, rend, k0, kb, R0, S, ds, RB + ty * (NB * 17), tx);
+      panel_rows_mfma(Fs, ld, rend, k0, kb, R0, S, ds, RB + ty * (NB * 17), tx, staged);
     return;
   }
   // few rows: faithful substitution, one row per work-item, 16-column chunks; x of earlier chunks parked in LDS
@@ -618,8 +622,13 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
       // ---- row-solve workgroup b
       const int b = bx - 1;
       double *Fs = F + tab.foff[s];
+      const bool mfma_rows = ms - min(NB, ns) >= MFMA_MIN_ROWS;
       if (phase != 2 && panel > 0) {
-        update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, kp, NB, b + 1, 0, d, As, Bs, dsh);
+        if (mfma_rows)                                              // the result doubles as the row solve's wave tiles in LDS
+          update_tile<LDL_THREADS / 64, false, true, true>(Fs, ld, ms, first, kp, NB, b + 1, 0, d, As, Bs, dsh, nullptr, nullptr, kbc,
+                                                            threadIdx.x, true, (double *)smem + NB * (NB + 1));
+        else
+          update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, kp, NB, b + 1, 0, d, As, Bs, dsh);
         SDM_STORES_DONE();
         __syncthreads();
         if (threadIdx.x == 0) sdm_signal_add(&upd_cnt[s]);
@@ -641,7 +650,8 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
       }
       if (tid < NB) dsr[tid] = tid < kbc ? d[first + k0c + tid] : 0.0;
       __syncthreads();
-      panel_rows(Fs, ld, ns, ms, k0c, kbc, k0c + NB * (b + 1), k0c + NB * (b + 2), ROWS_BATCH, S, dsr, RB);      // = tile row b+1
+      panel_rows(Fs, ld, ns, ms, k0c, kbc, k0c + NB * (b + 1), k0c + NB * (b + 2), ROWS_BATCH, S, dsr, RB,
+                 phase == 0 && panel > 0 && mfma_rows);          // = tile row b+1, already staged by the update above
       return;
     }
     if (bx > nrw) {

@@ -457,62 +457,62 @@ __device__ __forceinline__ void tile_index(int t, int &I, int &J) {
 // T_b = A_b - sum_{b'<b} X_b' L_bb'^T runs on the FP64 matrix cores, the 16x16 triangle is solved by substitution
 // (no inverse is formed: the never-fail pivot rule allows multipliers up to maxu = 5e5); results agree with the
 // plain substitution to rounding.
-__device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int k0, int kb, int R0, const double (*S)[NB + 1],
-                                                const double *ds, double *Tw, int lane, bool staged = false) {
+// 16 rows x 64 columns of the panel -> LDS wave tile Tw[col*17 + row]
+__device__ __forceinline__ void rows_stage(const double *Fs, int ld, int ms, int k0, int kb, int R0, double *Tw, int lane) {
   const int li = lane & 15, lk = lane >> 4;
-  if (!staged) {                                              // 16 rows x 64 columns -> LDS tile Tw[col*17 + row]
-    double tv[NB / 4];
-    const double *pr = Fs + min(R0 + li, ms - 1);
+  double tv[NB / 4];
+  const double *pr = Fs + min(R0 + li, ms - 1);
 #pragma unroll
-    for (int c4 = 0; c4 < NB / 4; c4++) tv[c4] = pr[(int64_t)(k0 + min(4 * c4 + lk, kb - 1)) * ld];    // 16 loads in flight
+  for (int c4 = 0; c4 < NB / 4; c4++) tv[c4] = pr[(int64_t)(k0 + min(4 * c4 + lk, kb - 1)) * ld];    // 16 loads in flight
 #pragma unroll
-    for (int c4 = 0; c4 < NB / 4; c4++) { const int c = 4 * c4 + lk; Tw[c * 17 + li] = c < kb ? tv[c4] : 0.0; }
+  for (int c4 = 0; c4 < NB / 4; c4++) { const int c = 4 * c4 + lk; Tw[c * 17 + li] = c < kb ? tv[c4] : 0.0; }
+}
+// 16-column block b of the blocked substitution on the wave tile: needs columns 0 .. 16b+15 of S (L11) and ds
+__device__ __forceinline__ void rows_block(int b, const double (*S)[NB + 1], const double *ds, double *Tw, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  const int cb = 16 * b;
+  if (b > 0) {
+    // T = A_b - sum_{b'<b} X_b' L_bb'^T on the matrix cores (D layout: lane holds rows lk+4r of column li)
+    sdm_double4 acc;
+    for (int r = 0; r < 4; r++) acc[r] = Tw[(cb + li) * 17 + lk + 4 * r];
+    for (int bp = 0; bp < b; bp++)
+      for (int q = 0; q < 4; q++) {
+        const double a = Tw[(16 * bp + 4 * q + lk) * 17 + li];          // X_bp[row li][k]
+        const double bv = S[cb + li][16 * bp + 4 * q + lk];             // L11[cb + j][k]
+        acc = SDM_MFMA_F64_16x16x4(-a, bv, acc);
+      }
+    for (int r = 0; r < 4; r++) Tw[(cb + li) * 17 + lk + 4 * r] = acc[r];
+    SDM_WAVE_SYNC();
+  }
+  // the 16x16 triangle by substitution, lane li = row (the 4 lane groups lk compute the same row redundantly),
+  // column-oriented: once x_j is final, x_c -= x_j l_cj for all c > j (independent updates, one LDS round trip
+  // per column of the triangle) -- no inverse of the block is formed (multipliers may be as large as maxu)
+  double x[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) x[c] = Tw[(cb + c) * 17 + li];
+  double lcol[16], dsv[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) { lcol[c] = c > 0 ? S[cb + c][cb] : 0.0; dsv[c] = ds[cb + c]; }
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    double lnext[16];                                                   // column j+1 is fetched while column j is applied
+#pragma unroll
+    for (int c = 0; c < 16; c++) lnext[c] = (j + 1 < 16 && c > j + 1) ? S[cb + c][cb + j + 1] : 0.0;
+    if (dsv[j] <= 0.0) x[j] = 0.0;                                      // skipped pivot: column not used (blkchol2.c:157-161)
+#pragma unroll
+    for (int c = 0; c < 16; c++)
+      if (c > j) x[c] -= x[j] * lcol[c];
+#pragma unroll
+    for (int c = 0; c < 16; c++) lcol[c] = lnext[c];
   }
   SDM_WAVE_SYNC();
-  SDM_PHASE_BEGIN();
-  for (int b = 0; b < NB / 16; b++) {
-    const int cb = 16 * b;
-    if (cb >= kb) break;
-    if (b > 0) {
-      // T = A_b - sum_{b'<b} X_b' L_bb'^T on the matrix cores (D layout: lane holds rows lk+4r of column li)
-      sdm_double4 acc;
-      for (int r = 0; r < 4; r++) acc[r] = Tw[(cb + li) * 17 + lk + 4 * r];
-      for (int bp = 0; bp < b; bp++)
-        for (int q = 0; q < 4; q++) {
-          const double a = Tw[(16 * bp + 4 * q + lk) * 17 + li];          // X_bp[row li][k]
-          const double bv = S[cb + li][16 * bp + 4 * q + lk];             // L11[cb + j][k]
-          acc = SDM_MFMA_F64_16x16x4(-a, bv, acc);
-        }
-      for (int r = 0; r < 4; r++) Tw[(cb + li) * 17 + lk + 4 * r] = acc[r];
-      SDM_WAVE_SYNC();
-    }
-    // the 16x16 triangle by substitution, lane li = row (the 4 lane groups lk compute the same row redundantly),
-    // column-oriented: once x_j is final, x_c -= x_j l_cj for all c > j (independent updates, one LDS round trip
-    // per column of the triangle) -- no inverse of the block is formed (multipliers may be as large as maxu)
-    double x[16];
 #pragma unroll
-    for (int c = 0; c < 16; c++) x[c] = Tw[(cb + c) * 17 + li];
-    double lcol[16], dsv[16];
-#pragma unroll
-    for (int c = 0; c < 16; c++) { lcol[c] = c > 0 ? S[cb + c][cb] : 0.0; dsv[c] = ds[cb + c]; }
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      double lnext[16];                                                   // column j+1 is fetched while column j is applied
-#pragma unroll
-      for (int c = 0; c < 16; c++) lnext[c] = (j + 1 < 16 && c > j + 1) ? S[cb + c][cb + j + 1] : 0.0;
-      if (dsv[j] <= 0.0) x[j] = 0.0;                                      // skipped pivot: column not used (blkchol2.c:157-161)
-#pragma unroll
-      for (int c = 0; c < 16; c++)
-        if (c > j) x[c] -= x[j] * lcol[c];
-#pragma unroll
-      for (int c = 0; c < 16; c++) lcol[c] = lnext[c];
-    }
-    SDM_WAVE_SYNC();
-#pragma unroll
-    for (int c = 0; c < 16; c++) Tw[(cb + c) * 17 + li] = x[c];
-    SDM_WAVE_SYNC();
-  }
-  SDM_PHASE(26);
+  for (int c = 0; c < 16; c++) Tw[(cb + c) * 17 + li] = x[c];
+  SDM_WAVE_SYNC();
+}
+// l = x / d out of the wave tile into the front
+__device__ __forceinline__ void rows_store(double *Fs, int ld, int ms, int k0, int kb, int R0, const double *ds, const double *Tw, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
   for (int c4 = 0; c4 < NB / 4; c4++) {
     const int c = 4 * c4 + lk, row = R0 + li;
     if (c < kb && row < ms) {
@@ -521,8 +521,16 @@ __device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int 
     }
   }
 }
+__device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int k0, int kb, int R0, const double (*S)[NB + 1],
+                                                const double *ds, double *Tw, int lane, bool staged = false) {
+  if (!staged) rows_stage(Fs, ld, ms, k0, kb, R0, Tw, lane);
+  SDM_WAVE_SYNC();
+  SDM_PHASE_BEGIN();
+  for (int b = 0; b < NB / 16 && 16 * b < kb; b++) rows_block(b, S, ds, Tw, lane);
+  SDM_PHASE(26);
+  rows_store(Fs, ld, ms, k0, kb, R0, ds, Tw, lane);
+}
 
-// rows [R, ...) of one batch below the diagonal block of panel p: S = scaled L11 (unit lower), ds = pivots (LDS)
 // rows [rbeg, rend) below the diagonal block of panel k0 (at most brows = TRSM_ROWS of them per call)
 __device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, int k0, int kb, int rbeg, int rend, int brows,
                                            const double (*S)[NB + 1], const double *ds, double *RB, bool staged = false) {
@@ -634,24 +642,43 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
         if (threadIdx.x == 0) sdm_signal_add(&upd_cnt[s]);
       }
       if (phase == 1) return;
-      spin_until(diag_cnt + s, panel + 1);                         // the factored diagonal block is in DT, its pivots in d
       double (*S)[NB + 1] = (double (*)[NB + 1])smem;
       double *RB = (double *)smem + NB * (NB + 1);
       __shared__ double dsr[NB];
       const double *Ds = DT + tab.toff[s] + (int64_t)panel * NB * NB;    // Ds[i*NB + j] = L(k0+i, k0+j)
       const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = blockDim.x >> 6;
-      {
+      const int rbeg = k0c + NB * (b + 1), rend = min(ms, k0c + NB * (b + 2));      // = tile row b+1
+      if (!mfma_rows) {
+        // few rows: the faithful substitution needs the whole block
+        spin_until(diag_cnt + s, 4 * (panel + 1));
         constexpr int NQ = NB / (LDL_THREADS / 64);
         double sv[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) sv[q] = Ds[min(ty + ny * q, NB - 1) * NB + tx];
 #pragma unroll
         for (int q = 0; q < NQ; q++) { const int i = ty + ny * q; if (i < NB) S[i][tx] = (i < kbc && tx < i) ? sv[q] : 0.0; }
+        if (tid < NB) dsr[tid] = tid < kbc ? d[first + k0c + tid] : 0.0;
+        __syncthreads();
+        panel_rows(Fs, ld, ns, ms, k0c, kbc, rbeg, rend, ROWS_BATCH, S, dsr, RB);
+        return;
       }
-      if (tid < NB) dsr[tid] = tid < kbc ? d[first + k0c + tid] : 0.0;
-      __syncthreads();
-      panel_rows(Fs, ld, ns, ms, k0c, kbc, k0c + NB * (b + 1), k0c + NB * (b + 2), ROWS_BATCH, S, dsr, RB,
-                 phase == 0 && panel > 0 && mfma_rows);          // = tile row b+1, already staged by the update above
+      // blocked substitution, 16 rows per wavefront (4 of the 8 are busy), following the diagonal block as workgroup 0
+      // publishes it 16 columns at a time
+      const int R0 = rbeg + 16 * ty;
+      const bool busy = R0 < rend;
+      double *Tw = RB + ty * (NB * 17);
+      if (!(phase == 0 && panel > 0) && busy) rows_stage(Fs, ld, rend, k0c, kbc, R0, Tw, tx);      // else staged by the update above
+      for (int blk = 0; blk < NB / 16 && 16 * blk < kbc; blk++) {
+        spin_until(diag_cnt + s, 4 * panel + blk + 1);             // columns 16 blk .. of L11 and their pivots are in DT / d
+        for (int e = tid; e < NB * 16; e += LDL_THREADS) {
+          const int i = e >> 4, j = 16 * blk + (e & 15);
+          S[i][j] = (i < kbc && j < i) ? Ds[i * NB + j] : 0.0;
+        }
+        if (tid < 16) dsr[16 * blk + tid] = 16 * blk + tid < kbc ? d[first + k0c + 16 * blk + tid] : 0.0;
+        __syncthreads();
+        if (busy) rows_block(blk, S, dsr, Tw, tx);
+      }
+      if (busy) rows_store(Fs, ld, rend, k0c, kbc, R0, dsr, Tw, tx);
       return;
     }
     if (bx > nrw) {
@@ -694,7 +721,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   double *Lc = RB;                                                // Lc[k*NB+i] = l_ik
   __shared__ double ds[NB], lbs[NB], pv[NB];
   __shared__ int stt[NB];
-  __shared__ int badflag;
+  __shared__ int badflag, npub;
   __shared__ double red_v[LDL_THREADS];
   __shared__ int red_i[LDL_THREADS];
   const int s = list[blockIdx.y];
@@ -719,7 +746,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
     }
   }
   if (tid < NB) { lbs[tid] = tid < kb ? lb[first + k0 + tid] : 0.0; ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
-  if (tid == 0) badflag = 0;
+  if (tid == 0) { badflag = 0; npub = 0; }
   SDM_PHASE_BEGIN();
   __syncthreads();
   SDM_PHASE(16);
@@ -788,14 +815,14 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
       SDM_PHASE(19);
     }
     SDM_SETPRIO(0);
-  } else {
+  } else if (ty < ny - 1) {
     __syncthreads();                                                   // sweep 0
     for (int s = 0; s < nsw - 1; s++) {
       const int c0 = s * SW;
       double xk[SW];
 #pragma unroll
       for (int k = 0; k < SW; k++) xk[k] = S[tx][c0 + k];
-      for (int j0 = c0 + 2 * SW + 4 * (ty - 1); j0 < kb; j0 += 4 * (ny - 1)) {   // 4 columns per wavefront at a time
+      for (int j0 = c0 + 2 * SW + 4 * (ty - 1); j0 < kb; j0 += 4 * (ny - 2)) {   // 4 columns per wavefront at a time
         double v[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) v[u] = S[tx][min(j0 + u, NB - 1)];
@@ -814,6 +841,49 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
       SDM_PHASE(18);
       __syncthreads();
     }
+  } else {
+    // ---- the last wavefront publishes the factor as it grows: after every second sweep 16 more columns of L11 (and
+    // their pivots) are final; they go to DT / d write-through and, one sweep later (the stores have been acknowledged
+    // by then), the count the row-solve workgroups of this launch poll goes up by one.  Nothing is published from a
+    // sweep on in which a pivot asked for the probe (the block is redone by the general path; what was published
+    // before is what the general path computes again).
+    double *Dsp = DT + tab.toff[s] + (int64_t)panel * NB * NB;
+    int issued = 0, signalled = 0;
+    __syncthreads();                                                   // sweep 0
+    for (int sw = 0; sw < nsw - 1; sw++) {
+      if (nrows > TRSM_ROWS) {
+        if (issued > signalled) {                                      // columns stored during the previous sweep
+          SDM_STORES_DONE();
+          if (tx == 0) sdm_signal_add(&diag_cnt[s]);
+          signalled = issued;
+        }
+        const int g = issued;                                          // sweeps 0 .. sw are final: columns < 8 (sw+1)
+        if (SW * (sw + 1) >= 16 * (g + 1) && badflag == 0) {
+#pragma unroll
+          for (int c = 0; c < 16; c++) {
+            const int j = 16 * g + c;
+            if (tx >= j) sdm_store_wt(&Dsp[tx * NB + j], tx == j ? 1.0 : Lc[j * NB + tx]);
+          }
+          if (tx < 16 && 16 * g + tx < kb) sdm_store_wt(&d[first + k0 + 16 * g + tx], ds[16 * g + tx]);
+          issued = g + 1;
+        }
+      }
+      __syncthreads();
+    }
+    // after the last sweep: what is left of the block, right away (the epilogue below would be 2-3 us later)
+    if (nrows > TRSM_ROWS && badflag == 0) {
+      for (int g = issued; 16 * g < kb; g++) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+          const int j = 16 * g + c;
+          if (tx >= j) sdm_store_wt(&Dsp[tx * NB + j], tx == j ? 1.0 : Lc[j * NB + tx]);
+        }
+        if (tx < 16 && 16 * g + tx < kb) sdm_store_wt(&d[first + k0 + 16 * g + tx], ds[16 * g + tx]);
+        issued = g + 1;
+      }
+    }
+    if (issued > signalled) { SDM_STORES_DONE(); if (tx == 0) sdm_signal_add(&diag_cnt[s], issued - signalled); }
+    if (tx == 0) npub = issued;
   }
   const bool bad = badflag != 0;
   const bool ok = !bad;
@@ -871,16 +941,16 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
     }
   }
   if (nrows > TRSM_ROWS) {                                         // the row-solve workgroups of this launch are waiting
-    SDM_STORES_DONE();
+    if (16 * npub < kb) SDM_STORES_DONE();                         // (uniform) something of the block is still unpublished
     __syncthreads();
-    if (tid == 0) sdm_signal_add(&diag_cnt[s]);
+    if (tid == 0) sdm_signal_add(&diag_cnt[s], 4 - npub);          // 4 counts per panel: one per 16 columns of the block
     // a partial block (kb < 64, last panel of the supernode) leaves rows r0 .. k0+63 in this workgroup's own tile row:
     // they were updated by its tile (0,0) and are solved here (the row-solve workgroups own whole tile rows)
     if (kb < NB) {
       SDM_ACQUIRE_FENCE();                                       // its own tile-(0,0) stores, not a cached copy from before them
       panel_rows(Fs, ld, ns, ms, k0, kb, r0, k0 + NB, TRSM_ROWS, S, ds, RB);
     }
-  } else if (tid == 0) sdm_signal_add(&diag_cnt[s]);               // keeps the count = panels done
+  } else if (tid == 0) sdm_signal_add(&diag_cnt[s], 4);            // keeps the count = 4 x panels done
   SDM_PHASE(22);
   if (nrows > 0 && nrows <= TRSM_ROWS) {
     if (panel > 0 && ok) wait_prev_update(upd_cnt + s, ns, ms, panel, q0);

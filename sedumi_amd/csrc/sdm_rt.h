@@ -20,7 +20,7 @@ inline double sdm_bcast_lane(double v, int lane) { return emu_shfl(v, lane, 0); 
 // predicate of lane `lane` (uniform), delivered to every lane
 inline bool sdm_lane_pred(bool pred, int lane) { return emu_shfl(pred ? 1.0 : 0.0, lane, 0) != 0.0; }
 // completion counters between workgroups of one launch (the emulator runs workgroups one after the other)
-inline void sdm_signal_add(int *p) { *p += 1; }
+inline void sdm_signal_add(int *p, int n = 1) { *p += n; }
 inline void sdm_store_wt(double *p, double v) { *p = v; }
 #define SDM_STORES_DONE() do {} while (0)
 inline int sdm_signal_load(const int *p) { return *p; }
@@ -43,7 +43,7 @@ typedef double2 sdm_double2;
 // atomic stores -- a release fence instead would write back the whole L2 of the XCD, microseconds per workgroup when a
 // big trailing matrix is dirty); SDM_STORES_DONE waits for this wavefront's stores, a barrier collects the workgroup,
 // then one relaxed increment publishes it.
-__device__ __forceinline__ void sdm_signal_add(int *p) { __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sdm_signal_add(int *p, int n = 1) { __hip_atomic_fetch_add(p, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sdm_store_wt(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #define SDM_STORES_DONE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
 __device__ __forceinline__ int sdm_signal_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }

@@ -257,8 +257,7 @@ def main():
         "k_ldl_single": ("hbm", 2.0 * solve_bytes),                                  # forward + backward sweep in one launch
         "k_fw_level": ("hbm", solve_bytes), "k_bw_level": ("hbm", solve_bytes),
         "k_ldl_update": ("mfma", (m ** 3 / 3.0) / max(1, npan - 1)),                 # trailing updates carry the m^3/3 of the LDL'
-        "k_ldl_rows": ("mfma", (m ** 3 / 3.0) / max(1, npan - 1) * 64.0 / max(m, 64)),
-        # one 64x64 LDL' per launch (latency bound) + the trailing update of the previous panel when it rides along
+        # one launch per panel: 64x64 LDL' (latency bound), row solves and the previous panel's trailing update
         "k_ldl_panel": ("mfma", 2.0 * 64 ** 3 / 3.0 + (0.0 if "k_ldl_update" in prof else (m ** 3 / 3.0) / max(1, npan - 1))),
         "k_psd_stage1_mfma": ("hbm", 8.0 * (ud.size + P.At.nnz + plan.nnzADA)),      # SURVEY.md 8(d) getada3 lower bound
         "k_psd_stage1": ("hbm", 8.0 * (ud.size + P.At.nnz + plan.nnzADA)),

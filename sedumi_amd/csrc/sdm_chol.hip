@@ -10,11 +10,12 @@
 // independent fronts of an elimination-tree level are factored by the same
 // launches; children pass their Schur complements to the parent by a
 // deterministic, ownership-partitioned extend-add (no atomics).  Inside a
-// front the elimination is blocked by 64 columns, two launches per panel: (1) the
-// diagonal block is factored in LDS (pivot rule applied column by column) and the
-// rows below it are solved one row per work-item, (2) the trailing update
-// C -= L21*D*L21'  runs on the FP64 matrix cores (v_mfma_f64_16x16x4_f64, 64x64
-// tile per 4-wave workgroup).
+// front the elimination is blocked by 64 columns, ONE launch per panel
+// (k_ldl_panel): workgroup 0 factors the diagonal block in registers / LDS (pivot
+// rule applied column by column), further workgroups solve the rows below it as
+// the block is published 16 columns at a time, and the trailing update
+// C -= L21*D*L21' of the PREVIOUS panel (FP64 matrix cores, 64x64 tiles) rides
+// along in the remaining workgroups; per-front counters in HBM order them.
 // The result is the same L, d (unit diagonal stored explicitly, skipped
 // columns returned as unit vectors, blkchol.c:409-414) up to rounding, and the
 // pivot DECISIONS follow blkchol2.c:114-161 including the idamax quirk of

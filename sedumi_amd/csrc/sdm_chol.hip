@@ -582,7 +582,7 @@ __device__ __forceinline__ int panel_row_wgs(int ns, int ms, int q) {
 }
 __device__ __forceinline__ void spin_until(const int *cnt, int target) {
   if (threadIdx.x == 0)
-    for (long it = 0; sdm_signal_load(cnt) < target && it < (1L << 26); it++) SDM_SPIN_PAUSE();
+    for (long it = 0; sdm_signal_load(cnt) < target && it < (1L << 21); it++) SDM_SPIN_PAUSE();
   __syncthreads();
   SDM_ACQUIRE_FENCE();
 }
@@ -612,11 +612,6 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   // All of this hides behind workgroup 0's dependency chain.  The emulator runs workgroups one after the other:
   // phase 1 (everything but the substitution, diagonal block last) and phase 2 (the substitution) are two launches
   // there; the GPU runs phase 0 = both.
-#ifdef SDM_EMU
-  const int bx = (int)gridDim.x - 1 - (int)blockIdx.x;
-#else
-  const int bx = blockIdx.x;
-#endif
   {
     const int s = list[blockIdx.y];
     const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
@@ -624,6 +619,23 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
     const int nrw = nrowsc > TRSM_ROWS ? (ms - (k0c + NB) + ROWS_BATCH - 1) / ROWS_BATCH : 0;   // tile rows below the first
     const int kp = (panel - 1) * NB;                               // previous panel (full when there is a panel p)
     const int nt = panel > 0 ? (ms - (kp + NB) + TILE - 1) / TILE : 0;
+    // Roles by "logical" index bx: 0 = diagonal block, 1..nrw = row solves, beyond = update tiles.  The hardware hands
+    // out workgroups in launch order, and a workgroup that waits must wait for one handed out BEFORE it (or for one
+    // that does not wait before it signals), else a full device of waiting workgroups could keep the awaited one out:
+    //   fronts with row-solve workgroups:  diagonal block < row solves (wait for it) < tiles (nobody waits for them);
+    //   small fronts:                      tiles (never wait) < diagonal block (its in-workgroup row solve waits for them).
+    // The emulator runs them one after the other in the order  tiles, row solves (phase 1: their update tile only),
+    // diagonal block.
+#ifdef SDM_EMU
+    const int bx = (int)gridDim.x - 1 - (int)blockIdx.x;
+#else
+    int bx = blockIdx.x;
+    if (nrw == 0) {
+      const int ntw = panel > 0 ? (nt * (nt + 1) / 2) / 2 : 0;
+      if (bx > ntw) return;
+      bx = bx < ntw ? 1 + bx : 0;
+    }
+#endif
     double (*As)[TILE] = (double (*)[TILE])smem;
     double (*Bs)[TILE] = As + NB;
     __shared__ double dsh[NB];

@@ -392,3 +392,25 @@ def test_sweeps_with_front_vector_in_hbm(refmex, glue):
     rhs = rng.standard_normal((X.shape[0], 2))
     assert relerr(mex.fwblkslv(L2, rhs), refmex.call("fwblkslv", 1, L2, rhs)) < TOL
     assert relerr(mex.bwblkslv(L2, rhs), refmex.call("bwblkslv", 1, L2, rhs)) < TOL
+
+
+@pytest.mark.gpu
+def test_many_small_multi_panel_fronts_in_one_level(refmex):
+    """400 independent dense 200 x 200 blocks = 400 fronts in one etree level, every one with waits inside the panel
+    launch (row-solve workgroups on the diagonal block in panel 0; the diagonal-block workgroup on its update tiles in
+    panels 1-3): more waiting workgroups than the device can hold at once, so the launch order of the roles matters."""
+    from oracle import glue as gl
+    from sedumi_amd import mex
+    rng = np.random.default_rng(3)
+    nb, n = 400, 200
+    blocks = []
+    for _ in range(nb):
+        B = rng.standard_normal((n, n)) / np.sqrt(n)
+        blocks.append(sp.csc_matrix(B @ B.T + np.eye(n)))
+    X = sp.block_diag(blocks, format="csc"); X.sort_indices()
+    L = mex.symbchol(X)
+    assert L["xsuper"].size - 1 >= nb
+    pars = gl.default_pars_chol()
+    r = refmex.call("blkchol", 4, L, X, pars)
+    o = mex.blkchol(L, X, pars)
+    assert relerr(o[1], r[1]) < TOL and relerr(o[0], r[0]) < TOL

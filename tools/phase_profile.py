@@ -35,11 +35,11 @@ lib.sdm_debug_phases_chol(buf, 1)
 plan.blkchol(None, True); plan.sync()
 lib.sdm_debug_phases_chol(buf, 0)
 v = np.array(list(buf), dtype=np.float64) / 100.0
-print("factor, work-item 0 of every workgroup, us summed: panel: load %.0f sweep %.0f trail %.0f bar %.0f copy %.0f bar %.0f wb %.0f rows %.0f"
-      % tuple(v[16:24]))
+print("factor (k_ldl_panel), workgroup 0 of every panel launch, us summed: load %.0f | sweeps (wavefront 0) %.0f | trailing (helpers) %.0f | "
+      "barrier %.0f | copy %.0f | barrier %.0f | write-back + publish %.0f | rows solved in the workgroup %.0f" % tuple(v[16:24]))
 print("  diagonal tile of the previous update in workgroup 0: loads+fill %.0f mfma %.0f to S + HBM %.0f" % (v[14], v[15], v[31]))
-print("  rows kernel: S load+bar %.0f | (per wave-0) blocked substitution %.0f | total rows fn %.0f   update kernel: loads+fill %.0f mfma %.0f rmw %.0f"
-      % (v[24], v[26], v[27], v[28], v[29], v[30]))
+print("  in-workgroup blocked substitution %.0f   ride-along update tiles (work-item 0 of each tile group): loads+fill %.0f mfma %.0f rmw %.0f"
+      % (v[26], v[28], v[29], v[30]))
 
 rhs = np.random.default_rng(0).standard_normal(P.m)
 plan.upload("rhs", rhs)

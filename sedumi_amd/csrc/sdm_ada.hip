@@ -192,6 +192,7 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
         }
       A.ell_ng = ng;
       A.g_row.upload(grow); A.g_len.upload(glen); A.g_off.upload(goff); A.g_val.upload(gval); A.g_bu.upload(gbu);
+      { std::vector<int> pos((size_t)m); for (sdm_int p = 0; p < m; p++) pos[(size_t)order[p]] = (int)p; A.ell_pos.upload(pos); }
       A.d_uoff.upload(uoff);
       A.ell_ok = true;
     }
@@ -710,7 +711,7 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
                  const int64_t *Ajc_psd, const double *Apr, const int *Ablk, const int *Aupos,
                  const int64_t *c_taskptr, const int *t_blk, const int *t_ulen, const int64_t *t_zoff, const double *zbuf,
                  const int64_t *uoff, const int *g_row, const int *g_len, const int64_t *g_off, const double *g_val,
-                 const int *g_pos, int ngroups, const int *invperm, int zmax, int m, int jbase, int jend) {
+                 const int *g_pos, int ngroups, const int *invperm, int zmax, int m, int jbase, int jend, const int *ell_pos) {
   SDM_DYN_SMEM(smem);
   double *zl = (double *)smem;                      // JB x z_j at full length (all blocks; zero where j has no nonzero)
   __shared__ double absred[JB][ELL_WAVES];
@@ -751,7 +752,9 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
     if (lane == 0) absred[q][wave] = aabs;
   }
   __syncthreads();
-  if (tid < JB && j0 + tid < jend) {
+  // (the row groups are split over gridDim.y workgroups: the one that owns row j's group is the only writer of
+  // entry (j,j) and reads its LP/Lorentz value here, before it adds to it)
+  if (tid < JB && j0 + tid < jend && (int)blockIdx.y == (ell_pos[j0 + tid] >> 6) % (int)gridDim.y) {
     const int j = j0 + tid;
     double basev = 0.0;
     int64_t lo = ADAjc[j], hi = ADAjc[j + 1];
@@ -767,7 +770,7 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
   // Every group of 64 rows is swept by ALL wavefronts: wave w takes the entries t = w, w+nw, ... of the 64 rows (one
   // row per lane), so the longest row costs len/nw dependent memory round trips instead of len; the nw partial
   // sums of a row meet in LDS and are added in wave order (deterministic).
-  for (int g = 0; g < ngroups; g++) {
+  for (int g = blockIdx.y; g < ngroups; g += gridDim.y) {
     const int i = g_row[g * 64 + lane];
     const int len = g_len[g];
     const double *gv = g_val + g_off[g] * 64 + lane;
@@ -940,10 +943,10 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
     do {                                                                                                                 \
       const size_t lds = lds_of(JB);                                                                                    \
       SDM_STAGE2_ATTR(JB, lds);                                                                                         \
-      SDM_KLAUNCH(P, k_psd_stage2_ell<JB>, dim3((ncols + JB - 1) / JB), dim3(64 * ELL_WAVES), lds, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, \
+      SDM_KLAUNCH(P, k_psd_stage2_ell<JB>, dim3((ncols + JB - 1) / JB, gsplit), dim3(64 * ELL_WAVES), lds, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, \
                   A.d_Ajc.p, A.d_Ajc_psd.p, A.d_Apr.p, A.d_Ablk.p, A.d_Aupos.p, A.c_taskptr.p, A.t_blk.p, A.t_ulen.p,    \
                   A.t_zoff.p, A.zbuf.p, A.d_uoff.p, A.g_row.p, A.g_len.p, A.g_off.p, A.g_val.p, A.g_bu.p, A.ell_ng, d_invperm, \
-                  (int)A.zmax, m, jbase, jbase + ncols);                                                                 \
+                  (int)A.zmax, m, jbase, jbase + ncols, A.ell_pos.p);                                                    \
     } while (0)
 #ifndef SDM_EMU
 #define SDM_STAGE2_ATTR(JB, lds) if ((lds) > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage2_ell<JB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)))
@@ -951,6 +954,11 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
 #define SDM_STAGE2_ATTR(JB, lds) (void)(lds)
 #endif
     // as many columns per workgroup as fit 96 KB of LDS (each coalesced load of the ELL copy then feeds JB columns)
+    // The row groups of a column set (distinct rows = distinct output entries, nothing to combine) are dealt to a few
+    // workgroups: a small gain only (measured 65 -> 62 us on the bench workload with 3) -- the sweep is bound by its
+    // LDS gathers and L2 re-reads, not by the chain of groups inside one workgroup.
+    const char *gsenv = getenv("SDM_STAGE2_GS");                       // tuning override (tools only)
+    const int gsplit = gsenv ? std::max(1, atoi(gsenv)) : (A.ell_ng >= 9 ? 3 : (A.ell_ng >= 4 ? 2 : 1));
     const char *jbenv = getenv("SDM_STAGE2_JB");                       // tuning override (tools only)
     const int jbforce = jbenv ? atoi(jbenv) : 0;
     if (jbforce == 4 || (!jbforce && lds_of(4) <= 64 * 1024 && m >= 1024)) SDM_STAGE2_ELL(4);

@@ -140,6 +140,7 @@ struct AdaPlan {
   int64_t zmax = 0, zmaxj = 0;
   DevBuf<int64_t> c_zlen;
   DevBuf<int> g_row, g_len, g_bu;
+  DevBuf<int> ell_pos;                     // constraint -> position in the ELL row order (its group = pos / 64)
   DevBuf<int64_t> g_off, d_uoff;
   DevBuf<double> g_val;
 };

@@ -954,11 +954,12 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
 #define SDM_STAGE2_ATTR(JB, lds) (void)(lds)
 #endif
     // as many columns per workgroup as fit 96 KB of LDS (each coalesced load of the ELL copy then feeds JB columns)
-    // The row groups of a column set (distinct rows = distinct output entries, nothing to combine) are dealt to a few
-    // workgroups: a small gain only (measured 65 -> 62 us on the bench workload with 3) -- the sweep is bound by its
-    // LDS gathers and L2 re-reads, not by the chain of groups inside one workgroup.
+    // The row groups of a column set (distinct rows = distinct output entries, nothing to combine) can be dealt to
+    // several workgroups (gridDim.y).  Measured on the bench workload with 3: 65 -> 62 us, but 2.3x the HBM traffic
+    // (z_j staged once per workgroup) -- the sweep is bound by its LDS gathers and L2 re-reads, not by the chain of
+    // groups inside one workgroup.  Off by default.
     const char *gsenv = getenv("SDM_STAGE2_GS");                       // tuning override (tools only)
-    const int gsplit = gsenv ? std::max(1, atoi(gsenv)) : (A.ell_ng >= 9 ? 3 : (A.ell_ng >= 4 ? 2 : 1));
+    const int gsplit = gsenv ? std::max(1, atoi(gsenv)) : 1;
     const char *jbenv = getenv("SDM_STAGE2_JB");                       // tuning override (tools only)
     const int jbforce = jbenv ? atoi(jbenv) : 0;
     if (jbforce == 4 || (!jbforce && lds_of(4) <= 64 * 1024 && m >= 1024)) SDM_STAGE2_ELL(4);

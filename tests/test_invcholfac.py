@@ -129,3 +129,32 @@ def test_datq_on_device_matches_getDAtm(glue, kw):
     it = glue.iteration_ref(S, d, ud)
     assert relerr(plan.download("ada"), it["ADA"].data) < TOL
     plan.close()
+
+
+def test_next_row_calls_are_noops_without_their_cones(glue):
+    """invcholfac without PSD blocks and getdatq without Lorentz cones leave the plan untouched (the MATLAB calls return
+    empty arrays there: invcholfac.c:95-96 with lenud = 0, getDAtm.m:41 with nq = 0)."""
+    from sedumi_amd import mex, problem
+    from sedumi_amd.plan import Plan
+    P = problem.random_sdp(m=12, lp=9, q=(), s=(), seed=2)             # LP only
+    S = glue.setup(P.At, P.K)
+    plan = Plan(0)
+    plan.set_chol(S["L"], S["ADA"]); plan.set_ada(P.At, P.Ablkjc, P.K, problem.lorentz_pattern(P))
+    plan.upload("dl", np.ones(int(P.K["l"]))); plan.upload("ddet", np.zeros(0))
+    plan.invcholfac(None); plan.getdatq(); plan.getada()
+    it = glue.iteration_ref(S, {"l": np.ones(int(P.K["l"])), "det": np.zeros(0), "q1": np.zeros(0), "q2": np.zeros(0)}, np.zeros(0))
+    assert relerr(plan.download("ada"), it["ADA"].data) < TOL
+    plan.close()
+    assert mex.invcholfac(np.zeros(0), P.K).size == 0
+
+
+def test_bench_workloads_build():
+    """bench.py's workload table (BASELINE.json configs[1..3] shapes) builds its inputs on the host."""
+    import importlib.util, os
+    from helpers import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    for name, m in (("control07", 666), ("nb", 123), ("maxcut300", 300)):
+        P, L, ADA, Q, d, ud, rhs = bench.build_workload(name, seed=0)
+        assert P.m == m and ADA.shape == (m, m) and rhs.size == m
+        assert ud.size == int(np.sum(P.K["s"].ravel() ** 2)) and d["l"].size == int(P.K["l"])

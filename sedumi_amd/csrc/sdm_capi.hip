@@ -62,6 +62,7 @@ void sdm_plan_destroy(sdm_plan *p) {
 int sdm_plan_sync(sdm_plan *p) {
   SDM_TRY
   SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  if (chol_wait_timeouts()) throw std::runtime_error("blkchol: a workgroup timed out waiting for another one inside a panel launch");
   SDM_CATCH
 }
 
@@ -127,6 +128,7 @@ int sdm_plan_download(sdm_plan *p, const char *name, double *dst, sdm_int nelem)
   if ((size_t)nelem > b->n) throw std::runtime_error(std::string("download: too many elements for buffer ") + name);
   SDM_HIP_CHECK(hipMemcpyAsync(dst, b->p, (size_t)nelem * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  if (chol_wait_timeouts()) throw std::runtime_error("blkchol: a workgroup timed out waiting for another one inside a panel launch");
   SDM_CATCH
 }
 

@@ -580,9 +580,13 @@ __device__ __forceinline__ int panel_row_wgs(int ns, int ms, int q) {
   const int kbq = min(NB, ns - q * NB), nrows = ms - (q * NB + kbq);
   return nrows > TRSM_ROWS ? (ms - (q * NB + NB) + ROWS_BATCH - 1) / ROWS_BATCH : 0;
 }
+__device__ int sdm_wait_timeouts;                             // spins that gave up (the host turns a non-zero count into an error)
 __device__ __forceinline__ void spin_until(const int *cnt, int target) {
-  if (threadIdx.x == 0)
-    for (long it = 0; sdm_signal_load(cnt) < target && it < (1L << 21); it++) SDM_SPIN_PAUSE();
+  if (threadIdx.x == 0) {
+    long it = 0;
+    for (; sdm_signal_load(cnt) < target && it < (1L << 21); it++) SDM_SPIN_PAUSE();
+    if (it == (1L << 21)) atomicAdd(&sdm_wait_timeouts, 1);
+  }
   __syncthreads();
   SDM_ACQUIRE_FENCE();
 }
@@ -1862,6 +1866,18 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
   SDM_KLAUNCH(P, k_dsolve, dim3((m + 255) / 256), dim3(256), 0, C.dsolve.p, C.d.p, m);
   SDM_HIP_CHECK(hipGetLastError());
   P->factored = true;
+}
+
+// Non-zero when a workgroup gave up waiting for another one inside a launch (never expected; the results of that
+// factorisation are then unusable).  Reads and clears the counter; call after a stream synchronise.
+int chol_wait_timeouts() {
+  int n = 0;
+#ifndef SDM_EMU
+  const int zero = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(sdm_wait_timeouts), sizeof(int)) != hipSuccess) return 0;
+  if (n) (void)hipMemcpyToSymbol(HIP_SYMBOL(sdm_wait_timeouts), &zero, sizeof(int));
+#endif
+  return n;
 }
 
 void chol_extract(sdm_plan *P, double *d_Lpr_out) {

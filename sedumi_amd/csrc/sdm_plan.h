@@ -196,6 +196,7 @@ void set_error(const std::string &msg);
 void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm,
                 sdm_int nsuper, const sdm_int *xsuper, const sdm_int *ADAjc, const sdm_int *ADAir);
 void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd);
+int chol_wait_timeouts();   // spins inside k_ldl_panel that gave up since the last call (0 = fine)
 void chol_extract(sdm_plan *P, double *d_Lpr_out);           // device pointer, nnzL doubles
 void chol_load_factor(sdm_plan *P, const double *h_Lpr);     // host L values -> fronts (for stand-alone solves)
 void solve_fw(sdm_plan *P, const double *src = nullptr);   // src: unpermuted right-hand side gathered on the way in (else ywork holds it)

@@ -91,11 +91,7 @@ def bench_subtrees(args, rank, local_rank, world, torch, dist, coll_dev):
     64 independent elimination-tree subtrees are dealt to the ranks (sedumi_amd.dist.SubtreeShardedSolver): ADA',
     factor and solves of a subtree never leave its rank; the only exchange is the all-gather of the solution
     segments after each solve.  Total work is fixed: strong scaling."""
-    import torch.distributed as tdist
     from sedumi_amd import dist as sd, problem
-    if dist is None:                                   # single process: a 1-rank group so that the same code runs
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
-        tdist.init_process_group(backend="gloo", rank=0, world_size=1)
     parts = args.workload.split(":")
     nblk, n, mper = (int(parts[1]), int(parts[2]), int(parts[3])) if len(parts) == 4 else (64, 200, 150)
     P = problem.blockdiag_sdp(nblk=nblk, n=n, mper=mper, nnz=20, seed=4)
@@ -143,8 +139,6 @@ def bench_subtrees(args, rank, local_rank, world, torch, dist, coll_dev):
             "roofline": None, "cpu_baseline": None}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
-    else:
-        tdist.destroy_process_group()
 
 
 def main():

@@ -45,7 +45,10 @@ class ColumnShardedAda:
     def __init__(self, plan: Plan, group=None, device=None, col_weights=None):
         torch, dist = _torch()
         self.plan, self.group = plan, group
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if dist.is_available() and dist.is_initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:                                        # single process without a process group
+            self.world, self.rank = 1, 0
         self.device = device if device is not None else torch.device("cpu")
         m = plan.m
         jc = np.asarray(plan.ADA_pattern.indptr, dtype=np.int64)
@@ -120,7 +123,10 @@ class SubtreeShardedSolver:
         torch, dist = _torch()
         from . import mex
         self.group = group
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if dist.is_available() and dist.is_initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:                                        # single process without a process group
+            self.world, self.rank = 1, 0
         self.device = device if device is not None else torch.device("cpu")
         self.m = P.m
         parts = split_problem(P, self.world)
@@ -165,7 +171,10 @@ class SubtreeShardedSolver:
             if self.world == 1 and self.device.type == "cpu":
                 return None                      # one rank without a device collective: y stays in the plan
             self.plan.copy("y", self.send, 0, n, to_plan=False)
-        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)       # the only exchange: solution segments
+        if self.world == 1:
+            self.recv[:self.send.numel()] = self.send
+        else:
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)   # the only exchange: solution segments
         return self.recv
 
     def solve(self, rhs):
@@ -176,7 +185,10 @@ class SubtreeShardedSolver:
             self.plan.upload("rhs", np.asarray(rhs, dtype=np.float64)[self.cols])
             self.plan.ldlsolve()
             self.plan.copy("y", self.send, 0, n, to_plan=False)
-        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)       # the only exchange: solution segments
+        if self.world == 1:
+            self.recv[:self.send.numel()] = self.send
+        else:
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)   # the only exchange: solution segments
         out = np.zeros(self.m)
         host = self.recv.cpu().numpy()
         for q, c in enumerate(self.cols_of):

@@ -284,6 +284,19 @@ int sdm_plan_kprof_enable(sdm_plan *p, int on);
 int sdm_plan_kprof_get(sdm_plan *p, const char *kernel, sdm_int *calls, double *total_ms);
 int sdm_plan_kprof_summary(sdm_plan *p, char *buf, sdm_int buflen);
 
+/* ---- one process-wide resident plan for the mexFunction shims: every .mex binary is its own
+ * shared object, so the cache lives in this library.  sdm_mexcache_plan returns the plan of the symbolic factor
+ * (L.{L pattern, perm, xsuper}) and ADA pattern given, creating it on a miss (NULL + sdm_last_error on failure).
+ * blkchol calls sdm_mexcache_remember_factor with the L.L values it returned; fwblkslv / bwblkslv get the plan back
+ * from sdm_mexcache_factor_plan only if the values they were handed ARE that factor (content fingerprint: a sampled
+ * hash always, the full hash when the array is not the very one blkchol returned), else NULL (stateless path). */
+sdm_plan *sdm_mexcache_plan(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm, sdm_int nsuper,
+                            const sdm_int *xsuper, const sdm_int *Xjc, const sdm_int *Xir);
+void sdm_mexcache_remember_factor(const double *Lpr_host, sdm_int nnz);
+sdm_plan *sdm_mexcache_factor_plan(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const double *Lpr,
+                                   const sdm_int *perm, sdm_int nsuper, const sdm_int *xsuper);
+void sdm_mexcache_clear(void);
+
 #ifdef __cplusplus
 }
 #endif

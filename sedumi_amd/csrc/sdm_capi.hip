@@ -11,6 +11,12 @@ void set_error(const std::string &msg) { g_err = msg; }
 }  // namespace sdm
 using namespace sdm;
 
+// every read-back of a plan passes through here after its stream synchronise: a spin inside one of THIS plan's panel
+// launches that gave up makes the results unusable (the plan is marked not factored by chol_wait_timeouts)
+static void check_plan_health(sdm_plan *p) {
+  if (chol_wait_timeouts(p)) throw std::runtime_error("blkchol: a workgroup timed out waiting for another one inside a panel launch");
+}
+
 #define SDM_TRY try {
 #define SDM_CATCH                                              \
   }                                                            \
@@ -61,8 +67,9 @@ void sdm_plan_destroy(sdm_plan *p) {
 }
 int sdm_plan_sync(sdm_plan *p) {
   SDM_TRY
+  SDM_HIP_CHECK(hipSetDevice(p->device));
   SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
-  if (chol_wait_timeouts()) throw std::runtime_error("blkchol: a workgroup timed out waiting for another one inside a panel launch");
+  check_plan_health(p);
   SDM_CATCH
 }
 
@@ -128,7 +135,7 @@ int sdm_plan_download(sdm_plan *p, const char *name, double *dst, sdm_int nelem)
   if ((size_t)nelem > b->n) throw std::runtime_error(std::string("download: too many elements for buffer ") + name);
   SDM_HIP_CHECK(hipMemcpyAsync(dst, b->p, (size_t)nelem * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
-  if (chol_wait_timeouts()) throw std::runtime_error("blkchol: a workgroup timed out waiting for another one inside a panel launch");
+  check_plan_health(p);
   SDM_CATCH
 }
 
@@ -167,6 +174,7 @@ int sdm_plan_copy(sdm_plan *p, const char *name, void *devptr, sdm_int offset, s
   if (to_plan) SDM_HIP_CHECK(hipMemcpyAsync(b->p + offset, devptr, (size_t)nelem * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   else SDM_HIP_CHECK(hipMemcpyAsync(devptr, b->p + offset, (size_t)nelem * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  check_plan_health(p);
   SDM_CATCH
 }
 int sdm_plan_blkchol(sdm_plan *p, const sdm_cholpars *pars, int use_absd) {
@@ -184,7 +192,9 @@ int sdm_plan_pivots(sdm_plan *p, sdm_int *nskip, sdm_int *skip_idx, double *skip
   const sdm_int m = p->chol.m;
   std::vector<int> st(m);
   std::vector<double> val(m);
+  SDM_HIP_CHECK(hipSetDevice(p->device));
   SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  check_plan_health(p);
   SDM_HIP_CHECK(hipMemcpy(st.data(), p->chol.pivstat.p, m * sizeof(int), hipMemcpyDeviceToHost));
   SDM_HIP_CHECK(hipMemcpy(val.data(), p->chol.pivval.p, m * sizeof(double), hipMemcpyDeviceToHost));
   sdm_int ns = 0, na = 0;
@@ -524,9 +534,17 @@ int sdm_plan_invcholfac(sdm_plan *p, const sdm_int *perm) {
   if (A.ufac.n < (size_t)A.lenud) throw std::runtime_error("invcholfac: upload buffer \"u\" first");
   std::vector<int> ns(A.psd_n.begin(), A.psd_n.end()), p32;
   if (perm) {
+    // the permutation is staged in a plan-owned pinned buffer that outlives the call (the copy is asynchronous);
+    // inside a graph capture the copy node would keep reading that buffer at every replay, so a NEW permutation
+    // cannot be handed over there -- upload it before the capture
+    if (p->capturing) throw std::runtime_error("sdm_plan_invcholfac: a permutation cannot be uploaded inside a graph capture (the captured copy would replay from the staging buffer)");
     perm32(perm, ns, p32);
     if (A.ic_perm.n < p32.size()) A.ic_perm.alloc(p32.size());
-    SDM_HIP_CHECK(hipMemcpyAsync(A.ic_perm.p, p32.data(), p32.size() * sizeof(int), hipMemcpyHostToDevice, p->stream));
+    A.ic_perm_host.ensure(p32.size());
+    SDM_HIP_CHECK(hipStreamSynchronize(p->stream));                 // an earlier copy out of the staging buffer may be pending
+    memcpy(A.ic_perm_host.p, p32.data(), p32.size() * sizeof(int));
+    SDM_HIP_CHECK(hipMemcpyAsync(A.ic_perm.p, A.ic_perm_host.p, p32.size() * sizeof(int), hipMemcpyHostToDevice, p->stream));
+    A.ic_has_perm = true;
   }
   const bool ready = A.ic_n.n == ns.size() && !ns.empty();           // block tables: once per plan (set_ada resets them)
   psd_invcholfac(p->stream, A.ufac.p, A.udsqr.p, perm ? A.ic_perm.p : nullptr, ns, (int)A.rsdpN, A.ic_n, A.ic_off, A.ic_poff, ready);

@@ -580,29 +580,30 @@ __device__ __forceinline__ int panel_row_wgs(int ns, int ms, int q) {
   const int kbq = min(NB, ns - q * NB), nrows = ms - (q * NB + kbq);
   return nrows > TRSM_ROWS ? (ms - (q * NB + NB) + ROWS_BATCH - 1) / ROWS_BATCH : 0;
 }
-__device__ int sdm_wait_timeouts;                             // spins that gave up (the host turns a non-zero count into an error)
-__device__ __forceinline__ void spin_until(const int *cnt, int target) {
+// tmo: the plan's own time-out flag (pinned host memory, CholPlan::tmo): a spin that gives up raises it; the host turns
+// it into an error at the next read-back of that plan (chol_wait_timeouts)
+__device__ __forceinline__ void spin_until(const int *cnt, int target, int *tmo) {
   if (threadIdx.x == 0) {
     long it = 0;
     for (; sdm_signal_load(cnt) < target && it < (1L << 21); it++) SDM_SPIN_PAUSE();
-    if (it == (1L << 21)) atomicAdd(&sdm_wait_timeouts, 1);
+    if (it == (1L << 21)) sdm_raise_flag(tmo);
   }
   __syncthreads();
   SDM_ACQUIRE_FENCE();
 }
-__device__ __forceinline__ void wait_prev_update(const int *cnt, int ns, int ms, int panel, int q0) {
+__device__ __forceinline__ void wait_prev_update(const int *cnt, int ns, int ms, int panel, int q0, int *tmo) {
   int target = 0;                                              // launches q0 .. panel carried update tiles
   for (int q = max(q0, 1); q <= panel; q++) {
     const int nt = (ms - q * NB + TILE - 1) / TILE, nrw = panel_row_wgs(ns, ms, q);
     target += nrw > 0 ? nrw : (nt * (nt + 1) / 2) / 2;
   }
-  spin_until(cnt, target);
+  spin_until(cnt, target, tmo);
 }
 
 __global__ void __launch_bounds__(LDL_THREADS)
 k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, double *d, double *lb, const double *ubp,
             int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src,
-            const int64_t *Ljc, int mtot, int *upd_cnt, int *diag_cnt, int q0, int phase) {
+            const int64_t *Ljc, int mtot, int *upd_cnt, int *diag_cnt, int q0, int phase, int *tmo) {
   SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
   SDM_DYN_SMEM(smem);
   // ONE launch per 64-column panel p.  grid = (workgroups, fronts); per front:
@@ -667,7 +668,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
       const int rbeg = k0c + NB * (b + 1), rend = min(ms, k0c + NB * (b + 2));      // = tile row b+1
       if (!mfma_rows) {
         // few rows: the faithful substitution needs the whole block
-        spin_until(diag_cnt + s, 4 * (panel + 1));
+        spin_until(diag_cnt + s, 4 * (panel + 1), tmo);
         constexpr int NQ = NB / (LDL_THREADS / 64);
         double sv[NQ];
 #pragma unroll
@@ -686,7 +687,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
       double *Tw = RB + ty * (NB * 17);
       if (!(phase == 0 && panel > 0) && busy) rows_stage(Fs, ld, rend, k0c, kbc, R0, Tw, tx);      // else staged by the update above
       for (int blk = 0; blk < NB / 16 && 16 * blk < kbc; blk++) {
-        spin_until(diag_cnt + s, 4 * panel + blk + 1);             // columns 16 blk .. of L11 and their pivots are in DT / d
+        spin_until(diag_cnt + s, 4 * panel + blk + 1, tmo);            // columns 16 blk .. of L11 and their pivots are in DT / d
         for (int e = tid; e < NB * 16; e += LDL_THREADS) {
           const int i = e >> 4, j = 16 * blk + (e & 15);
           S[i][j] = (i < kbc && j < i) ? Ds[i * NB + j] : 0.0;
@@ -906,7 +907,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   const bool ok = !bad;
   if (!ok) {
     // ---- general path: one column per step by all work-items, pivot_probe available
-    if (panel > 0) wait_prev_update(upd_cnt + s, ns, ms, panel, q0);  // the probe reads the rows below the block
+    if (panel > 0) wait_prev_update(upd_cnt + s, ns, ms, panel, q0, tmo);  // the probe reads the rows below the block
     for (int j = ty; j < NB; j += ny) { S[tx][j] = (tx < kb && j <= tx) ? Fs[(int64_t)(k0 + j) * ld + k0 + tx] : 0.0; Lc[j * NB + tx] = 0.0; }
     if (tid < NB) { ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
     __syncthreads();
@@ -967,11 +968,18 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
       SDM_ACQUIRE_FENCE();                                       // its own tile-(0,0) stores, not a cached copy from before them
       panel_rows(Fs, ld, ns, ms, k0, kb, r0, k0 + NB, TRSM_ROWS, S, ds, RB);
     }
-  } else if (tid == 0) sdm_signal_add(&diag_cnt[s], 4);            // keeps the count = 4 x panels done
+  }
   SDM_PHASE(22);
   if (nrows > 0 && nrows <= TRSM_ROWS) {
-    if (panel > 0 && ok) wait_prev_update(upd_cnt + s, ns, ms, panel, q0);
+    if (panel > 0 && ok) wait_prev_update(upd_cnt + s, ns, ms, panel, q0, tmo);
     panel_rows(Fs, ld, ns, ms, k0, kb, r0, ms, TRSM_ROWS, S, ds, RB);
+  }
+  if (nrows <= TRSM_ROWS) {
+    // nobody in this launch waits for this block: the count (= 4 x panels done) goes up at the very end, behind the
+    // same stores-acknowledged / barrier sequence as every other publication
+    SDM_STORES_DONE();
+    __syncthreads();
+    if (tid == 0) sdm_signal_add(&diag_cnt[s], 4);
   }
   SDM_PHASE(23);
 }
@@ -1858,7 +1866,7 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
 #endif
         SDM_KLAUNCH(P, k_ldl_panel, dim3(1 + L.ride_wgs, L.nactive), dim3(LDL_THREADS), PANEL_LDS_RIDE, C.fronts.p, C.frontsT.p, tab, list,
                     L.panel, C.d.p, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p,
-                    C.d_Ljc.p, m, C.upd_cnt.p, C.diag_cnt.p, 1, phase);
+                    C.d_Ljc.p, m, C.upd_cnt.p, C.diag_cnt.p, 1, phase, C.tmo.dev());
       if (L.lasttiles > 0)                                           // supernodes that end with this panel and have rows beyond
         SDM_KLAUNCH(P, k_ldl_update, dim3(L.lasttiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p, 1);
     }
@@ -1869,14 +1877,13 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
 }
 
 // Non-zero when a workgroup gave up waiting for another one inside a launch (never expected; the results of that
-// factorisation are then unusable).  Reads and clears the counter; call after a stream synchronise.
-int chol_wait_timeouts() {
-  int n = 0;
-#ifndef SDM_EMU
-  const int zero = 0;
-  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(sdm_wait_timeouts), sizeof(int)) != hipSuccess) return 0;
-  if (n) (void)hipMemcpyToSymbol(HIP_SYMBOL(sdm_wait_timeouts), &zero, sizeof(int));
-#endif
+// factorisation are then unusable: the plan is marked "not factored", so the solves refuse to run on it).  Reads and
+// clears the plan's own flag (pinned host memory the kernels of THIS plan write to); call after a stream synchronise.
+int chol_wait_timeouts(sdm_plan *P) {
+  CholPlan &C = P->chol;
+  if (!C.tmo.host) return 0;
+  const int n = *(volatile int *)C.tmo.host;
+  if (n) { *(volatile int *)C.tmo.host = 0; P->factored = false; }
   return n;
 }
 

@@ -62,6 +62,43 @@ struct DevBuf {
   }
 };
 
+// one int in pinned host memory that kernels of a plan can raise (rare error reports: no copy, no symbol lookup;
+// the host reads it after a stream synchronise)
+struct HostFlag {
+  int *host = nullptr;
+  HostFlag() = default;
+  HostFlag(const HostFlag &) = delete;
+  HostFlag &operator=(const HostFlag &) = delete;
+  ~HostFlag() { if (host) (void)hipHostFree(host); }
+  void ensure() {
+    if (host) return;
+    SDM_HIP_CHECK(hipHostMalloc((void **)&host, sizeof(int), 0));
+    *host = 0;
+  }
+  int *dev() {
+    ensure();
+    void *d = nullptr;
+    SDM_HIP_CHECK(hipHostGetDevicePointer(&d, host, 0));
+    return (int *)d;
+  }
+};
+
+// pinned host staging buffer of ints
+struct PinnedInts {
+  int *p = nullptr; size_t n = 0;
+  PinnedInts() = default;
+  PinnedInts(const PinnedInts &) = delete;
+  PinnedInts &operator=(const PinnedInts &) = delete;
+  ~PinnedInts() { if (p) (void)hipHostFree(p); }
+  void ensure(size_t count) {
+    if (count <= n) return;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; n = 0;
+    SDM_HIP_CHECK(hipHostMalloc((void **)&p, (count ? count : 1) * sizeof(int), 0));
+    n = count;
+  }
+};
+
 // ---------------------------------------------------------------- chol plan
 // Supernodal elimination tree of the symbolic factor L laid
 // out for a level-scheduled multifrontal LDL': every supernode s owns a dense
@@ -96,6 +133,7 @@ struct CholPlan {
   DevBuf<int> pivstat;
   DevBuf<int> diag_cnt;    // per front: panels whose factored diagonal block has been published (k_ldl_panel)
   DevBuf<int> upd_cnt;     // per front: finished tile workgroups of the updates that rode along with k_ldl_panel
+  HostFlag tmo;            // raised by a spin inside a panel launch of THIS plan that gave up (chol_wait_timeouts)
 };
 
 // ----------------------------------------------------------------- ada plan
@@ -133,6 +171,7 @@ struct AdaPlan {
   DevBuf<int64_t> d_qblk;                 // qblkstart (0-based rows of the norm-bound parts), lorN+1
   DevBuf<double> ufac;                    // d.u of the scaling (input of sdm_plan_invcholfac), lenud doubles
   DevBuf<int> ic_n, ic_poff, ic_perm; DevBuf<int64_t> ic_off;   // invcholfac block tables
+  PinnedInts ic_perm_host; bool ic_has_perm = false;            // staging of the permutation handed to sdm_plan_invcholfac
   size_t stage1_lds = 0;
   // stage-2 fast path: interleaved (ELL) copy of the PSD nonzeros, rows sorted by length, groups of 64
   bool ell_ok = false;
@@ -196,7 +235,7 @@ void set_error(const std::string &msg);
 void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm,
                 sdm_int nsuper, const sdm_int *xsuper, const sdm_int *ADAjc, const sdm_int *ADAir);
 void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd);
-int chol_wait_timeouts();   // spins inside k_ldl_panel that gave up since the last call (0 = fine)
+int chol_wait_timeouts(sdm_plan *P);   // non-zero: a spin inside a panel launch of this plan gave up since the last call (call after a stream sync)
 void chol_extract(sdm_plan *P, double *d_Lpr_out);           // device pointer, nnzL doubles
 void chol_load_factor(sdm_plan *P, const double *h_Lpr);     // host L values -> fronts (for stand-alone solves)
 void solve_fw(sdm_plan *P, const double *src = nullptr);   // src: unpermuted right-hand side gathered on the way in (else ywork holds it)

@@ -24,6 +24,7 @@ inline void sdm_signal_add(int *p, int n = 1) { *p += n; }
 inline void sdm_store_wt(double *p, double v) { *p = v; }
 #define SDM_STORES_DONE() do {} while (0)
 inline int sdm_signal_load(const int *p) { return *p; }
+inline void sdm_raise_flag(int *p) { *p = 1; }
 #define SDM_ACQUIRE_FENCE() do {} while (0)
 #define SDM_SPIN_PAUSE() do { fprintf(stderr, "hipemu: waiting on a workgroup that has not run\n"); abort(); } while (0)
 #else
@@ -41,12 +42,16 @@ typedef double2 sdm_double2;
 // barrier), acquire on the consumer side, device scope (the workgroups may sit on different XCDs / L2s)
 // The producers' data stores are write-through to the device-wide coherence point (sdm_store_wt: agent-scope relaxed
 // atomic stores -- a release fence instead would write back the whole L2 of the XCD, microseconds per workgroup when a
-// big trailing matrix is dirty); SDM_STORES_DONE waits for this wavefront's stores, a barrier collects the workgroup,
-// then one relaxed increment publishes it.
+// big trailing matrix is dirty); SDM_STORES_DONE waits for this wavefront's stores (an explicit s_waitcnt vmcnt(0):
+// a workgroup-scope release fence emits NOTHING for global stores on gfx950, and inline asm is invisible to the
+// compiler pass that drops waits it believes redundant -- MI355X_MICROARCH.md "Compiler hazard"), a barrier collects
+// the workgroup, then one relaxed increment publishes it.  tests/test_abi.py checks the disassembly for the wait.
 __device__ __forceinline__ void sdm_signal_add(int *p, int n = 1) { __hip_atomic_fetch_add(p, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sdm_store_wt(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#define SDM_STORES_DONE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#define SDM_STORES_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 __device__ __forceinline__ int sdm_signal_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+// error flag in pinned host memory (HostFlag): one system-scope store, read by the host after a stream synchronise
+__device__ __forceinline__ void sdm_raise_flag(int *p) { __hip_atomic_store(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 #define SDM_ACQUIRE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define SDM_SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
 // predicate of lane `lane` (uniform), delivered to every lane: one compare into a lane mask, one scalar bit test

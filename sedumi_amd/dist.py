@@ -146,11 +146,20 @@ class SubtreeShardedSolver:
             self.L = L
 
     def upload_scaling(self, d, ud, P):
-        """Scaling data of the FULL problem P (d.l, d.det, udsqr): every rank keeps its own rows / blocks."""
+        """Scaling data of the FULL problem P (d.l, d.det, udsqr and, with Lorentz cones, d.q1 / d.q2): every rank
+        keeps its own rows / blocks.  With Lorentz cones the values of DAt.q (getDAtm.m:39-44, the input of the
+        getada2 term) are formed on the device from the rank's q1 / q2 right here."""
         if self.plan is None:
             return
         dl, ddet, uds = problem.sub_scaling(P, self.sub, self.rows, d, ud)
         self.plan.upload("dl", dl); self.plan.upload("ddet", ddet); self.plan.upload("udsqr", uds)
+        if self.sub.K["q"].size:
+            if "q1" not in d or "q2" not in d:
+                raise ValueError("SubtreeShardedSolver.upload_scaling: the problem has Lorentz cones; d must carry "
+                                 "q1 and q2 (getDAtm.m:39-44) so that DAt.q can be formed for the getada2 term")
+            q1, q2 = problem.sub_scaling_q(P, self.sub, d)
+            self.plan.upload("q1", q1); self.plan.upload("q2", q2)
+            self.plan.getdatq()
 
     def factor(self):
         if self.plan is not None:

@@ -36,42 +36,23 @@ void read_cone(const mxArray *mxK, ConeK &o) {
 }
 
 // ------------------------------------------------------------------ plan cache
+// The cache itself lives inside libsedumi_hip.so (sdm_mexcache_*, sdm_mexcache.cpp): every .mex binary is its own
+// shared object, statics here would not be shared between blkchol.mex and fwblkslv.mex.
 namespace {
-struct Cache {
-  sdm_plan *plan = NULL;
-  sdm_int m = -1, nnzL = -1, nsuper = -1, nnzX = -1;
-  unsigned long long hperm = 0, hxs = 0;
-  const double *last_Lpr = NULL;
-  size_t last_nnz = 0;
-  bool atexit_set = false;
-} g;
-unsigned long long hash(const ivec &v) {
-  unsigned long long h = 1469598103934665603ull;
-  for (size_t i = 0; i < v.size(); i++) { h ^= (unsigned long long)v[i]; h *= 1099511628211ull; }
-  return h;
-}
-void teardown(void) { if (g.plan) sdm_plan_destroy(g.plan); g.plan = NULL; g.last_Lpr = NULL; }
+bool atexit_set = false;
+void teardown(void) { sdm_mexcache_clear(); }
 }  // namespace
 
 sdm_plan *cached_plan(const SymbL &L, const mwIndex *Xjc, const mwIndex *Xir) {
-  const sdm_int nnzX = (sdm_int)Xjc[L.m];
-  const unsigned long long hp = hash(L.perm), hx = hash(L.xsuper);
-  if (g.plan && g.m == L.m && g.nnzL == L.jc[L.m] && g.nsuper == L.nsuper && g.nnzX == nnzX && g.hperm == hp && g.hxs == hx)
-    return g.plan;
-  teardown();
-  const char *dev = getenv("SEDUMI_HIP_DEVICE");
-  g.plan = sdm_plan_create(dev ? atoi(dev) : 0, NULL);
-  if (!g.plan) mexErrMsgTxt(sdm_last_error());
-  if (!g.atexit_set) { mexAtExit(teardown); g.atexit_set = true; }
-  ivec xjc = idx_from_mw(Xjc, L.m + 1), xir = idx_from_mw(Xir, (size_t)nnzX);
-  if (sdm_plan_set_chol(g.plan, L.m, L.jc.data(), L.ir.data(), L.perm.data(), L.nsuper, L.xsuper.data(), xjc.data(), xir.data())) {
-    teardown(); mexErrMsgTxt(sdm_last_error());
-  }
-  g.m = L.m; g.nnzL = L.jc[L.m]; g.nsuper = L.nsuper; g.nnzX = nnzX; g.hperm = hp; g.hxs = hx;
-  return g.plan;
+  ivec xjc = idx_from_mw(Xjc, L.m + 1), xir = idx_from_mw(Xir, (size_t)Xjc[L.m]);
+  if (!atexit_set) { mexAtExit(teardown); atexit_set = true; }
+  sdm_plan *p = sdm_mexcache_plan(L.m, L.jc.data(), L.ir.data(), L.perm.data(), L.nsuper, L.xsuper.data(), xjc.data(), xir.data());
+  if (!p) mexErrMsgTxt(sdm_last_error());
+  return p;
 }
-void remember_factor(const double *Lpr_host, size_t nnz) { g.last_Lpr = Lpr_host; g.last_nnz = nnz; }
+void remember_factor(const double *Lpr_host, size_t nnz) { sdm_mexcache_remember_factor(Lpr_host, (sdm_int)nnz); }
+// non-null iff the values of L.L ARE the factor the cached plan holds (content fingerprint, not just the host address)
 sdm_plan *plan_for_factor(const SymbL &L) {
-  if (g.plan && g.last_Lpr == L.pr && g.last_nnz == (size_t)L.jc[L.m] && g.m == L.m && g.hxs == hash(L.xsuper)) return g.plan;
-  return NULL;
+  if (!atexit_set) { mexAtExit(teardown); atexit_set = true; }
+  return sdm_mexcache_factor_plan(L.m, L.jc.data(), L.ir.data(), L.pr, L.perm.empty() ? NULL : L.perm.data(), L.nsuper, L.xsuper.data());
 }

@@ -37,4 +37,4 @@ void read_cone(const mxArray *mxK, ConeK &out);
 // one resident plan per symbolic factor, torn down at mexAtExit (INTEGRATION.md "Keeping data on the device")
 sdm_plan *cached_plan(const SymbL &L, const mwIndex *Xjc, const mwIndex *Xir);
 void remember_factor(const double *Lpr_host, size_t nnz);
-sdm_plan *plan_for_factor(const SymbL &L);     // non-null iff L.L is the array the last blkchol returned
+sdm_plan *plan_for_factor(const SymbL &L);     // non-null iff the values of L.L are the factor the last blkchol left resident

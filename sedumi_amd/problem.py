@@ -338,3 +338,15 @@ def sub_scaling(P, sub, rows, d, ud):
     ud = np.asarray(ud, dtype=np.float64).ravel()
     uds = np.concatenate([ud[off[k]:off[k + 1]] for k in sub.kept["s"]]) if sub.kept["s"].size else np.zeros(0)
     return dl, ddet, uds
+
+
+def sub_scaling_q(P, sub, d):
+    """d.q1 (one per Lorentz cone) and d.q2 (norm-bound parts, concatenated) of the full problem restricted to the
+    Lorentz cones kept by `subproblem` -- the inputs of getDAtm.m:39-44 for the sub-problem's DAt.q."""
+    lpN, q, s, nreal, qnorm, psd = _cone_layout(P.K)
+    keep = sub.kept["q"]
+    q1 = np.asarray(d["q1"], dtype=np.float64).ravel()[keep]
+    q2f = np.asarray(d["q2"], dtype=np.float64).ravel()
+    base = int(qnorm[0]) if q.size else 0
+    q2 = np.concatenate([q2f[int(qnorm[k]) - base:int(qnorm[k + 1]) - base] for k in keep]) if keep.size else np.zeros(0)
+    return q1, q2

@@ -55,6 +55,42 @@ def test_code_object_targets_gfx950_and_uses_fp64_mfma(hiplib):
     assert "gfx950" in out
 
 
+def test_panel_launch_publishes_only_after_its_stores_are_acknowledged(hiplib, tmp_path):
+    """Inter-workgroup hand-overs inside k_ldl_panel: write-through (sc1) data stores, then an explicit
+    `s_waitcnt vmcnt(0)` (SDM_STORES_DONE -- a workgroup-scope fence emits nothing for global stores on gfx950), then
+    the relaxed counter increment.  Disassembly check: between every signal add and the nearest write-through store
+    before it there is a vmcnt(0) wait."""
+    import shutil
+    lib = shutil.copy(hiplib, tmp_path / "lib.so")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    subprocess.run([objdump, "--offloading", str(lib)], capture_output=True, text=True, cwd=tmp_path)
+    body = None
+    for f in sorted(os.listdir(tmp_path)):
+        if "gfx950" not in f:
+            continue
+        dis = subprocess.run([objdump, "-d", str(tmp_path / f)], capture_output=True, text=True).stdout
+        m = re.search(r"^[0-9a-f]+ <[^>]*k_ldl_panel[^>]*>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)", dis, flags=re.S | re.M)
+        if m:
+            body = m.group(1).split("\n")
+            break
+    assert body, "k_ldl_panel not found in the gfx950 code objects"
+    signals = [i for i, l in enumerate(body) if re.search(r"\bglobal_atomic_add\b", l)]
+    assert len(signals) >= 4
+    checked = 0
+    for i in signals:
+        j, waited = i - 1, False
+        while j >= 0 and not re.search(r"\bglobal_store\w* .*\bsc1\b", body[j]):
+            waited = waited or "s_waitcnt vmcnt(0)" in body[j]
+            if re.search(r"\bglobal_atomic_add\b", body[j]):
+                j = -1                      # an earlier signal lies in between: nothing new to publish here
+                break
+            j -= 1
+        if j >= 0:
+            assert waited, f"signal add at disassembly line {i} can overtake the write-through store at line {j}"
+            checked += 1
+    assert checked >= 2
+
+
 def test_loader_fails_loudly_without_library(tmp_path):
     from sedumi_amd import capi
     capi.use_library(str(tmp_path / "nope.so"))

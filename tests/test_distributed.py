@@ -49,8 +49,15 @@ def _worker(rank, world, port, case, q):
             err = max(np.abs(sh.download("ada") - ref.download("ada")).max(), np.abs(sh.download("absd") - ref.download("absd")).max())
             q.put((rank, float(err), [int(c) for c in cs.cols]))
         else:
-            P = problem.blockdiag_sdp(nblk=5, n=9, mper=7, nnz=5, seed=3)
-            d, ud = problem.spd_scaling(P.K, seed=4)
+            if case == "subtrees_lorentz":
+                # components with Lorentz cones: the getada2 term needs every rank's own DAt.q (formed on the device
+                # from its d.q1 / d.q2 in upload_scaling)
+                from helpers import ref_scaling
+                P = problem.random_sdp(m=30, lp=0, q=(8, 7, 9), s=(6, 5), dens=0.5, seed=7, block_local=True)
+                d, ud = ref_scaling(P, 4)
+            else:
+                P = problem.blockdiag_sdp(nblk=5, n=9, mper=7, nnz=5, seed=3)
+                d, ud = problem.spd_scaling(P.K, seed=4)
             rhs = np.random.default_rng(1).standard_normal(P.m)
             solver = sd.SubtreeShardedSolver(P, pars=pars)
             solver.upload_scaling(d, ud, P)
@@ -65,6 +72,8 @@ def _worker(rank, world, port, case, q):
             ADApat = problem.symb_ada(P); L = mex.symbchol(ADApat)
             pl = Plan(0); pl.set_chol(L, ADApat); pl.set_ada(P.At, P.Ablkjc, P.K, problem.lorentz_pattern(P))
             pl.upload("dl", d["l"]); pl.upload("ddet", d["det"]); pl.upload("udsqr", ud); pl.upload("rhs", rhs)
+            if case == "subtrees_lorentz":
+                pl.upload("q1", d["q1"]); pl.upload("q2", d["q2"]); pl.getdatq()
             pl.getada(); pl.blkchol(pars, True); pl.ldlsolve()
             y1 = pl.download("y")
             q.put((rank, float(np.abs(y - y1).max() / np.abs(y1).max()), [int(c.size) for c in solver.cols_of]))
@@ -74,7 +83,7 @@ def _worker(rank, world, port, case, q):
         q.put((rank, "ERR " + traceback.format_exc(), None))
 
 
-@pytest.mark.parametrize("case", ["columns", "subtrees"])
+@pytest.mark.parametrize("case", ["columns", "subtrees", "subtrees_lorentz"])
 def test_two_ranks_gloo(case):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -89,7 +98,7 @@ def test_two_ranks_gloo(case):
     for rank, err, info in res:
         assert not isinstance(err, str), err
         assert err < 1e-12, (rank, err)
-        assert info is not None and (len(info) == 3 if case == "columns" else sum(info) == 35 and min(info) > 0)
+        assert info is not None and (len(info) == 3 if case == "columns" else sum(info) == (35 if case == "subtrees" else 30) and min(info) > 0)
 
 
 def test_split_problem_components():

@@ -122,3 +122,46 @@ def test_shim_invcholfac(refmex, shimmex):
     u, perm = scaling_factor_case(K, seed=3)
     for args in ((u.reshape(-1, 1), K, perm.reshape(-1, 1)), (u.reshape(-1, 1), K)):
         assert relerr(shimmex.call("invcholfac", 1, *args), refmex.call("invcholfac", 1, *args)) < TOL
+
+
+def test_factor_cache_is_shared_between_mex_binaries_and_validated_by_content(glue, refmex, shimmex):
+    """blkchol.mex leaves the factor resident in the plan cached inside the library (sdm_mexcache_*); fwblkslv.mex /
+    bwblkslv.mex -- separate shared objects -- reuse it only when the L.L values they are handed ARE that factor.
+    Two blkchol calls on the same symbolic factor, then solves with the FIRST factor's values: the cache holds the
+    second factor, so the content check must reject it and the stateless path must give the first factor's answer."""
+    import ctypes
+    from oracle import glue as gl
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+    import build_emu
+    lib = ctypes.CDLL(build_emu.build())
+    lib.sdm_mexcache_factor_plan.restype = ctypes.c_void_p
+    rng = np.random.default_rng(12)
+    X1 = spd_pattern("rand", 120, rng, 0.05)
+    X2 = sp.csc_matrix(X1 + sp.diags(rng.random(120) + 0.5)); X2.sort_indices()
+    L = glue.symbchol(X1)
+    pars = gl.default_pars_chol()
+    LL1, Ld1, _, _ = shimmex.call("blkchol", 4, L, X1, pars)
+    LL2, Ld2, _, _ = shimmex.call("blkchol", 4, L, X2, pars)
+    assert relerr(LL2, refmex.call("blkchol", 4, L, X2, pars)[0]) < TOL
+    rhs = rng.standard_normal((120, 2))
+
+    def resident(LLv):
+        LL = sp.csc_matrix(LLv); LL.sort_indices()
+        jc, ir = LL.indptr.astype(np.int64), LL.indices.astype(np.int64)
+        pr = np.ascontiguousarray(LL.data, dtype=np.float64)
+        perm = (np.asarray(L["perm"]).ravel() - 1).astype(np.int64)
+        xs = (np.asarray(L["xsuper"]).ravel() - 1).astype(np.int64)
+        P = ctypes.POINTER(ctypes.c_int64)
+        return lib.sdm_mexcache_factor_plan(ctypes.c_int64(120), jc.ctypes.data_as(P), ir.ctypes.data_as(P),
+                                            pr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), perm.ctypes.data_as(P),
+                                            ctypes.c_int64(xs.size - 1), xs.ctypes.data_as(P))
+    assert resident(LL2) and not resident(LL1)                # the second factor is resident, the first is not
+    stale = LL2.copy(); stale.data[stale.nnz // 3] += 1e-9    # same shape, one value differs: not the resident factor
+    assert not resident(stale)
+    for LLv in (LL2, LL1):                                    # resident path, then content-check fallback
+        Lf = dict(L); Lf["L"] = LLv
+        assert relerr(shimmex.call("fwblkslv", 1, Lf, rhs), refmex.call("fwblkslv", 1, Lf, rhs)) < TOL
+        assert relerr(shimmex.call("bwblkslv", 1, Lf, rhs), refmex.call("bwblkslv", 1, Lf, rhs)) < TOL
+    lib.sdm_mexcache_clear()
+    assert not resident(LL2)

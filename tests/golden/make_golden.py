@@ -4,7 +4,8 @@ Runs ONLY in the build container (needs /root/reference and oracle/_ref): loads 
 (the problems of examples/test_sedumi.m:22-28; nb.mat is the Lorentz-cone example, BASELINE.json configs[2]), applies the restated pretransfo / setup glue, runs the
 UNMODIFIED reference MEX (getada1/2/3, blkchol, fwblkslv, bwblkslv) and stores the hot-path inputs plus
 reference outputs as compressed .npz so that the parity tests can run where /root/reference does not exist.
-Large outputs (ADA', L) are stored as Frobenius norm + a fixed random sample of entries.
+ADA' (upper triangle) and L (lower triangle) are stored IN FULL (control07: for the "rand" scaling only, 2 x 1.8 MB),
+next to their Frobenius norms and a fixed random sample of entries.
 
     python tests/golden/make_golden.py
 """
@@ -63,6 +64,9 @@ def main():
                         f"{tag}_si": si, f"{tag}_sj": sj, f"{tag}_ADA_s": ADA[si, sj], f"{tag}_L_s": LL[lo[0], lo[1]],
                         f"{tag}_nskip": it["Lskip"].nnz, f"{tag}_nadd": it["Ladd"].nnz,
                         f"{tag}_ADA1_fro": np.linalg.norm(it["ADA1"].toarray()), f"{tag}_ADA_diag": np.diag(ADA)})
+            if name != "control07" or tag == "rand":
+                assert np.array_equal(ADA, ADA.T)
+                out.update({f"{tag}_ADA_triu": ADA[np.triu_indices(m)], f"{tag}_L_tril": LL[np.tril_indices(m)]})
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **out)
         print(name, "->", path, os.path.getsize(path) // 1024, "KiB")

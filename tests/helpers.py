@@ -165,6 +165,11 @@ def check_golden(name, tag):
     errs["L_s"] = relerr(Lf[np.maximum(si, sj), np.minimum(si, sj)], z[f"{tag}_L_s"])
     errs["L_fro"] = abs(np.linalg.norm(Lf) - z[f"{tag}_L_fro"]) / z[f"{tag}_L_fro"]
     assert Lskip.nnz == int(z[f"{tag}_nskip"]) and Ladd.nnz == int(z[f"{tag}_nadd"])
+    if f"{tag}_L_tril" in z.files:                    # the full arrays, entry by entry
+        errs["ADA_full"] = relerr(ADA[np.triu_indices(m)], z[f"{tag}_ADA_triu"])
+        errs["ADA_sym"] = relerr(ADA, ADA.T)
+        errs["L_full"] = relerr(Lf[np.tril_indices(m)], z[f"{tag}_L_tril"])
+        errs["L_maxabs"] = float(np.abs(Lf[np.tril_indices(m)] - z[f"{tag}_L_tril"]).max() / np.abs(z[f"{tag}_L_tril"]).max())
     Ls = dict(L); Ls["L"] = LL
     yfw = mex.fwblkslv(Ls, z["rhs"])
     errs["yfw"] = relerr(yfw.ravel(), z[f"{tag}_yfw"])

@@ -414,3 +414,75 @@ def test_many_small_multi_panel_fronts_in_one_level(refmex):
     r = refmex.call("blkchol", 4, L, X, pars)
     o = mex.blkchol(L, X, pars)
     assert relerr(o[1], r[1]) < TOL and relerr(o[0], r[0]) < TOL
+
+
+# ---------------------------------------------------------------- BASELINE.json configs[3], [4] and the big-front /
+# sparse-RHS paths pinned against the compiled reference ON the GPU
+def test_blockdiag_64x200_against_reference(glue):
+    """BASELINE.json configs[4] at FULL size (64 PSD blocks of order 200, m = 9600, 64 independent subtrees through our
+    own ordmmd/symfct): getada1/2/3, blkchol, fwblkslv, bwblkslv stage by stage against the compiled reference MEX
+    (the reference needs about 1 s for this unit)."""
+    from sedumi_amd import problem
+    P = problem.blockdiag_sdp(nblk=64, n=200, mper=150, nnz=20, seed=4)
+    errs, S, _ = check_iteration(glue, P, seed=5)
+    assert S["L"]["xsuper"].size - 1 >= 64
+
+
+@pytest.mark.parametrize("n", [1100, 2000, 4000])
+def test_maxcut_big_front_against_reference(glue, n):
+    """BASELINE.json configs[3] (n = 4000) and two smaller big fronts (>= BIG_FRONT = 1024 rows: the per-super-panel
+    sweeps and the >256-column super-panel logic of the factor): the whole unit stage by stage against the compiled
+    reference MEX (reference: 0.3 s / 2.6 s / 15 s per unit)."""
+    from sedumi_amd import problem
+    check_iteration(glue, problem.maxcut(n), seed=3)
+
+
+@pytest.mark.parametrize("m,kind,dens,ncol", [(80, "rand", 0.05, 4), (600, "rand", 0.01, 9), (900, "grid", 0, 6),
+                                              (400, "arrow", 0, 5), (1300, "dense", 0, 3)])
+def test_sparse_rhs_solves_on_gpu(refmex, glue, m, kind, dens, ncol):
+    """fwblkslv(L,b,ysymb) / bwblkslv(L,b,ysymb) with sparse right-hand sides on the symbfwblk pattern
+    (fwblkslv.c:150-183 selfwsolve, bwblkslv.c:141-172 selbwsolve; deninfac.m:67 is the caller)."""
+    from oracle import glue as gl
+    from sedumi_amd import mex, problem
+    rng = np.random.default_rng(m)
+    if kind == "dense":
+        B0 = rng.standard_normal((m, m)) / np.sqrt(m)
+        X = sp.csc_matrix(B0 @ B0.T + np.eye(m))
+        L = problem.dense_symbolic(m)
+    else:
+        X = spd_pattern(kind, m, rng, dens)
+        L = glue.symbchol(X)
+    r = refmex.call("blkchol", 4, L, X, gl.default_pars_chol())
+    L2 = dict(L); L2["L"] = r[0]
+    B = sp.random(m, ncol, density=min(1.0, 6.0 / m), random_state=rng, format="csc")
+    B = sp.csc_matrix(B + sp.csc_matrix(([1.0], ([m - 1], [0])), shape=(m, ncol)))      # never an empty first column
+    B.sort_indices()
+    Ys = refmex.call("symbfwblk", 1, L2, B)
+    yr = refmex.call("fwblkslv", 1, L2, B, Ys)
+    yo = mex.fwblkslv(L2, B, Ys)
+    assert np.array_equal(yo.indices, yr.indices) and np.array_equal(yo.indptr, yr.indptr) and relerr(yo, yr) < TOL
+    # the backward variant works on whatever pattern it is given and ignores L.perm (bwblkslv.c:279-291): a pattern
+    # closed under the backward solve is the full column
+    Bd = sp.csc_matrix(rng.standard_normal((m, 2)))
+    Yfull = sp.csc_matrix(np.ones((m, 2)))
+    zr = refmex.call("bwblkslv", 1, L2, Bd, Yfull)
+    zo = mex.bwblkslv(L2, Bd, Yfull)
+    assert relerr(zo, zr) < TOL
+
+
+@pytest.mark.parametrize("kind,dens,m", [("rand", 0.02, 300), ("band", 0, 257), ("arrow", 0, 120), ("blockdiag", 0, 400),
+                                         ("grid", 0, 625), ("rand", 0.3, 150), ("rand", 0.0005, 6000)])
+def test_ordering_and_symbolic_bit_exact_in_the_gpu_suite(refmex, kind, dens, m):
+    """ordmmdmex / symfctmex / choltmpsiz / cholsplit (host code of libsedumi_hip.so): integer outputs identical to
+    the reference -- the same check as tests/test_oracle.py, repeated here so that the driver's GPU record shows it on
+    the hipcc-built library."""
+    from sedumi_amd import mex
+    rng = np.random.default_rng(1000 * m + int(100 * dens))
+    X = spd_pattern(kind, m, rng, dens)
+    pr = refmex.call("ordmmdmex", 1, X)
+    assert np.array_equal(mex.ordmmdmex(X), pr)
+    Lr, Lo = refmex.call("symfctmex", 1, X, pr), mex.symfctmex(X, pr)
+    assert np.array_equal(Lo["perm"], Lr["perm"]) and np.array_equal(Lo["xsuper"], Lr["xsuper"])
+    assert np.array_equal(Lo["L"].indptr, Lr["L"].indptr) and np.array_equal(Lo["L"].indices, Lr["L"].indices)
+    assert np.array_equal(mex.choltmpsiz(Lr), refmex.call("choltmpsiz", 1, Lr))
+    assert np.array_equal(mex.cholsplit(Lr, 512.0), refmex.call("cholsplit", 1, Lr, 512.0))

@@ -3,14 +3,19 @@
 
 One "step" = one IPM iteration unit (sedumi.m:450-473) on frozen, HBM-resident inputs:
     1 x (getada1 + getada2 + getada3)  ->  1 x blkchol  ->  4 x (fwblkslv, ./L.d, bwblkslv)   (single RHS each)
-Workload at N=1: the control07-shaped SDP of BASELINE.json configs[1] (m=666, K.s=[70 35], dense ADA',
-synthetic data of that shape -- the reference's examples do not travel to the GPU box).
+Workload at N=1: BASELINE.json configs[1], examples/control07.mat itself -- the hot-path inputs of the reference's
+example (At after pretransfo, K, the scaling of the "rand" golden tag, rhs) travel as tests/golden/control07.npz
+(generated from /root/reference by tests/golden/make_golden.py).  `--workload control07_like` is the synthetic
+problem of the same shape; `nb`, `maxcut<n>`, `blockdiag` are the shapes of configs[2..4].  The default N=1 run also
+measures those other configs briefly in the same process and reports them under "other_configs".
 
-N>1 (launched with torch.distributed.run, one rank per GPU): the single dense supernode of this workload
-does not shard, so every rank runs an independent replica of the unit ("replicas
-only") -- weak scaling, no data-path collective; barrier + max-over-ranks timing.
+N>1 (launched with torch.distributed.run, one rank per GPU): ONE unit per step, sharded the way the workload shards
+(SURVEY.md 8e): single-supernode workloads form ADA' as column panels per rank + one RCCL all-gather (factor and
+solves replicated -- they do not shard); the block-diagonal workload deals its independent subtrees to the ranks
+(all-gather of the solution only).  `--shard replicas` runs independent units per rank instead (weak scaling).
 
-Prints ONE JSON line (rank 0) with the fields the driver expects plus `roofline` and `cpu_baseline`.
+Prints ONE JSON line (rank 0) with the fields the driver expects plus `roofline`, `cpu_baseline` (the unmodified
+reference MEX, naive BLAS-1) and `cpu_baseline_blas` (the same linked to the host's OpenBLAS), `pcie_inclusive`.
 """
 import argparse
 import json
@@ -25,49 +30,91 @@ sys.path.insert(0, ROOT)
 
 PARS = {"canceltol": 1e-12, "maxu": 5e5, "abstol": 1e-20}          # checkpars.m:144-168
 HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_MATRIX_PEAK_TFS = 78.6                                         # v_mfma_f64_16x16x4_f64: = the FP64 vector rate on CDNA4
 NSOLVE = 4
-CONFIG_NOTE = {"contro": "control07-shaped SDP (BASELINE.json configs[1])", "nb": "nb-shaped SOCP (BASELINE.json configs[2])",
+CONFIG_NOTE = {"contro": "examples/control07.mat (BASELINE.json configs[1])", "nb": "nb-shaped SOCP (BASELINE.json configs[2])",
                "maxcut": "MAXCUT SDP, one dense PSD block (BASELINE.json configs[3])"}
 
 
 def build_workload(name, seed):
-    from sedumi_amd import problem
+    """(P, L, ADApattern, Qpattern, d, udsqr, rhs, qpr, data_note)"""
+    import scipy.sparse as sp
+    from sedumi_amd import mex, problem
+    qpr = None
     if name == "control07":
-        P = problem.control_like(seed=seed)
-    elif name.startswith("maxcut"):
-        P = problem.maxcut(int(name[6:] or 4000))
-    elif name == "nb":                                  # BASELINE.json configs[2] shape: 793 Lorentz cones of dimension 3, m = 123
-        P = problem.random_sdp(m=123, lp=4, q=(3,) * 793, s=(), dens=0.66, seed=31 + seed)
-        P.name = "nb_like(m=123,q=793x3)"
+        z = np.load(os.path.join(ROOT, "tests", "golden", "control07.npz"))
+        At = sp.csc_matrix((z["At_data"], z["At_indices"], z["At_indptr"]), shape=tuple(z["At_shape"]))
+        K = problem.make_K(int(z["K_l"]), z["K_q"].ravel(), z["K_s"].ravel())
+        P = problem.Problem(At, K, "control07.mat")
+        assert np.array_equal(P.Ablkjc, z["Ablkjc"])
+        d = {"l": z["rand_dl"], "det": z["rand_ddet"]}
+        ud, rhs = z["rand_udsqr"], z["rhs"]
+        note = "examples/control07.mat inputs (tests/golden/control07.npz), scaling of the golden 'rand' tag"
     else:
-        raise SystemExit("unknown workload " + name)
-    L, ADA, Q = problem.dense_symbolic(P.m), problem.dense_pattern(P.m), problem.lorentz_pattern(P)
-    d, ud = problem.spd_scaling(P.K, seed=seed + 5)
-    rhs = np.random.default_rng(seed).standard_normal(P.m)
-    return P, L, ADA, Q, d, ud, rhs
+        if name == "control07_like":
+            P = problem.control_like(seed=seed)
+        elif name.startswith("maxcut"):
+            P = problem.maxcut(int(name[6:] or 4000))
+        elif name == "nb":                              # BASELINE.json configs[2] shape: 793 Lorentz cones of dimension 3, m = 123
+            P = problem.random_sdp(m=123, lp=4, q=(3,) * 793, s=(), dens=0.66, seed=31 + seed)
+            P.name = "nb_like(m=123,q=793x3)"
+        elif name.startswith("blockdiag"):
+            parts = name.split(":")
+            nblk, n, mper = (int(parts[1]), int(parts[2]), int(parts[3])) if len(parts) == 4 else (64, 200, 150)
+            P = problem.blockdiag_sdp(nblk=nblk, n=n, mper=mper, nnz=20, seed=4)
+        else:
+            raise SystemExit("unknown workload " + name)
+        d, ud = problem.spd_scaling(P.K, seed=seed + 5)
+        rhs = np.random.default_rng(seed).standard_normal(P.m)
+        note = "synthetic"
+    if name.startswith("blockdiag"):
+        ADA = problem.symb_ada(P)
+        L = mex.symbchol(ADA)                           # our own ordmmd + symfct (bit-exact with the reference)
+    else:
+        L, ADA = problem.dense_symbolic(P.m), problem.dense_pattern(P.m)
+    Q = problem.lorentz_pattern(P)
+    if Q.nnz:                                           # Lorentz cones: DAt.q values in the order of the pattern (getDAtm.m's product)
+        qpr = 0.1 * np.random.default_rng(3).standard_normal(Q.nnz)
+    return P, L, ADA, Q, d, ud, rhs, qpr, note
 
 
-def cpu_baseline(P, d, ud, rhs, budget_s=12.0):
-    """The compiled reference MEX (oracle/_ref) timed on this host, one thread, on a bounded sample of the
-    same workload: repeated iteration units until ~budget_s of CPU time is spent."""
+def make_plan(device, P, L, ADA, Q, d, ud, rhs, qpr):
+    from sedumi_amd.plan import Plan
+    plan = Plan(device)
+    plan.set_chol(L, ADA)
+    plan.set_ada(P.At, P.Ablkjc, P.K, Q)
+    plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud); plan.upload("rhs", rhs)
+    if qpr is not None:
+        plan.upload("qpr", qpr)
+    return plan
+
+
+def cpu_baseline(P, d, ud, rhs, budget_s=12.0, blas=None):
+    """The compiled reference MEX (oracle/_ref) timed on this host, one thread, on a bounded sample of the same
+    workload: repeated iteration units until ~budget_s of CPU time is spent.  blas = (path, prefix, suffix): the
+    reference's BLAS-1 calls bound to that host BLAS instead of the shim's naive loops."""
+    kind = {"value": None, "unit": "IPM iters/s", "cores": 1, "kind": "reference"}
     try:
         from oracle import glue as gl, refmex
         if not refmex.available():
             return None
         G = gl.Glue()
         ref = G.ref
+        if blas is not None and not ref.use_blas(blas):
+            return dict(kind, sample="failed: could not bind " + blas[0])
         S = G.setup(P.At, P.K)
         K = P.K
         dd = {"l": d["l"], "det": d["det"], "q1": np.ones(K["q"].size),
               "q2": np.zeros(int(K["mainblks"].ravel()[2] - K["mainblks"].ravel()[1]))}
         DAt = G.getDAtm(S, dd)
-        dstruct = {"l": dd["l"].reshape(-1, 1), "det": dd["det"].reshape(-1, 1)}
+        dstruct = {"l": np.asarray(dd["l"]).reshape(-1, 1), "det": np.asarray(dd["det"]).reshape(-1, 1)}
         units, tot = 0, 0.0
+        stage = np.zeros(4)
         t_wall = time.perf_counter()
         while True:
             t1, ADA1 = ref.timed_call("getada1", 1, (S["ADA"], S["A"], S["Ablkjc"][:, 2], S["Aord"]["lqperm"], dstruct, K["qblkstart"]))
             t2, ADA2 = ref.timed_call("getada2", 1, (ADA1, DAt, S["Aord"], K))
-            t3, (ADA3, absd) = ref.timed_call("getada3", 2, (ADA2, S["A"], S["Ablkjc"][:, 2], S["Aord"], ud.reshape(-1, 1), K))
+            t3, (ADA3, absd) = ref.timed_call("getada3", 2, (ADA2, S["A"], S["Ablkjc"][:, 2], S["Aord"], np.asarray(ud).reshape(-1, 1), K))
             t4, (LL, Ld, _, _) = ref.timed_call("blkchol", 4, (S["L"], ADA3, dict(PARS), absd))
             L = dict(S["L"]); L["L"] = LL
             ts = 0.0
@@ -76,14 +123,190 @@ def cpu_baseline(P, d, ud, rhs, budget_s=12.0):
                 tb, _y = ref.timed_call("bwblkslv", 1, (L, p / Ld))
                 ts += tf[0] + tb[0]
             tot += t1[0] + t2[0] + t3[0] + t4[0] + ts
+            stage += [t1[0] + t2[0], t3[0], t4[0], ts]
             units += 1
             if tot >= budget_s or time.perf_counter() - t_wall > 3 * budget_s or units >= 400:
                 break
-        return {"value": units / tot, "unit": "IPM iters/s", "cores": 1, "kind": "reference",
-                "sample": f"{units} iteration units of {P.name} through oracle/_ref (unmodified reference C, gcc -O2, "
-                          f"naive BLAS-1), MEX calls only ({tot:.1f} s CPU)"}
+        if blas is not None:
+            ref.use_blas(None)
+        what = "OpenBLAS BLAS-1 (" + os.path.basename(blas[0]) + ", 1 thread)" if blas else "naive BLAS-1"
+        return dict(kind, value=units / tot,
+                    sample=f"{units} iteration units of {P.name} through oracle/_ref (unmodified reference C, gcc -O2, {what}), "
+                           f"MEX calls only ({tot:.1f} s CPU)",
+                    stage_ms_per_unit={"getada1+2": 1e3 * stage[0] / units, "getada3": 1e3 * stage[1] / units,
+                                       "blkchol": 1e3 * stage[2] / units, "solves": 1e3 * stage[3] / units})
     except Exception as e:  # the baseline must never break the bench line
-        return {"value": None, "unit": "IPM iters/s", "cores": 1, "kind": "reference", "sample": f"failed: {e}"}
+        return dict(kind, sample=f"failed: {e}")
+
+
+def unit_fn(plan):
+    def step():
+        plan.getada()
+        plan.blkchol(PARS, True)
+        for _ in range(NSOLVE):
+            plan.ldlsolve()
+    return step
+
+
+def time_steps(plan, step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    plan.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    plan.sync()
+    return time.perf_counter() - t0
+
+
+def profile_unit(plan, P, ud, nprof):
+    """Roofline leg: the same steps with HIP events on the plan's stream -- around every launch (per-kernel times)
+    and, in a second pass, around the three phases of the unit (ADA', factor incl. the inverses for the solves, the
+    four solves).  Returns (roofline dict, phases dict)."""
+    m, nnzL = plan.m, plan.nnzL
+    step = unit_fn(plan)
+    plan.kprof(True)
+    for _ in range(nprof):
+        step()
+    prof = plan.kprof_summary()
+    plan.kprof(False)
+    ph = np.zeros(3)
+    for _ in range(nprof):
+        plan.timer_begin(0); plan.getada(); plan.timer_end(0)
+        plan.timer_begin(1); plan.blkchol(PARS, True); plan.timer_end(1)
+        plan.timer_begin(2)
+        for _ in range(NSOLVE):
+            plan.ldlsolve()
+        plan.timer_end(2)
+        ph += [plan.timer_ms(0), plan.timer_ms(1), plan.timer_ms(2)]
+    ph /= nprof
+    # ALGORITHMIC work per launch of each hot kernel (DESIGN.md section 3; SURVEY.md 8(d) per-unit figures divided
+    # by the launches per unit).  bound "hbm": bytes, peak 8 TB/s; bound "mfma": FP64 flops, peak 78.6 TFLOP/s.
+    lind = int(np.sum(np.diff(plan.L_pattern.indptr)[(np.asarray(plan_xsuper(plan)) - 1)[:-1]])) if hasattr(plan, "L_pattern") else m
+    solve_bytes = 8.0 * nnzL + 8.0 * lind + 16.0 * m    # per triangular sweep: 8*nnz(L) + 8*len(lindx) + 16*m
+    fac_flops = factor_flops(plan)
+    npanel = max(1, prof.get("k_ldl_panel", (1, 0))[0] // nprof)
+    ada_bytes = 8.0 * (ud.size + P.At.nnz + plan.nnzADA)
+    model = {
+        "k_ldl_panel": ("mfma", fac_flops / npanel),                               # the panel launches carry the whole LDL'
+        "k_ldl_update": ("mfma", fac_flops / npanel),
+        "k_psd_stage1_mfma": ("mfma", None), "k_psd_stage1": ("mfma", None),       # flops filled below from the task list
+        "k_psd_stage2": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)), "k_psd_stage2_ell": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)),
+        "k_ada_spdot": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)),
+        "k_sfw_step": ("hbm", None), "k_sbw_step": ("hbm", None),
+    }
+    peaks = {"hbm": (HBM_PEAK_GBS, "GB/s", 1e9), "mfma": (FP64_MATRIX_PEAK_TFS, "TFLOP/s", 1e12)}
+    dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
+    roof = None
+    if dom:
+        calls, ms = prof[dom]
+        avg_s = ms / calls * 1e-3
+        key = dom.split("<")[0]
+        bound, work = model.get(key, ("hbm", None))
+        if work is None and key.startswith("k_psd_stage1"):
+            work = stage1_flops(P) / max(1, calls // nprof)
+        if work is None and key in ("k_sfw_step", "k_sbw_step"):
+            work = solve_bytes / max(1, calls // (nprof * NSOLVE))
+        if work is None:
+            work = ada_bytes
+        peak, unit, scale = peaks[bound]
+        ach = work / avg_s / scale
+        roof = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_per_step": calls / nprof,
+                "algorithmic_work_per_launch": work,
+                "timing": "HIP events around every launch on the plan's stream (adds ~2 us per launch; kernels shorter than "
+                          "~7 us read as ~7 us: see phases_ms_per_step for those)",
+                "stage_ms_per_step": {k: v[1] / nprof for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+        if pmcs:
+            try:
+                roof["traffic_from_committed_profile"] = {"bytes_per_launch": json.load(open(pmcs[-1])).get(dom),
+                                                          "source": "profiles/" + os.path.basename(pmcs[-1]) + " (rocprofv3 PMC passes of an earlier run of this command, not measured in this run)"}
+            except Exception:
+                pass
+    nlaunch = sum(v[0] for k, v in prof.items() if k.startswith("k_sfw") or k.startswith("k_sbw")) / max(1, nprof * NSOLVE)
+    t_solve = ph[2] / NSOLVE * 1e-3
+    nb, nbad, growth = plan.solve_stats()
+    phases = {"ada_ms": ph[0], "factor_ms": ph[1], "solves_ms": ph[2],
+              "solve": {"us_per_solve": 1e6 * t_solve, "launches_per_solve": nlaunch, "us_per_launch": 1e6 * t_solve / max(nlaunch, 1),
+                        "algorithmic_bytes_per_solve": 2.0 * solve_bytes, "achieved_GBs": 2.0 * solve_bytes / t_solve / 1e9,
+                        "frac_of_hbm_peak": 2.0 * solve_bytes / t_solve / 1e9 / HBM_PEAK_GBS,
+                        "dependency_chain": f"{nlaunch:.0f} dependent launches per solve x measured {1e6 * t_solve / max(nlaunch, 1):.2f} us per launch "
+                                            "(launch boundary + one memory round trip): the chain, not HBM, bounds a single-RHS solve",
+                        "super_blocks": nb, "blocks_on_substitution_fallback": nbad, "max_growth": growth},
+              "factor": {"flops": fac_flops, "achieved_TFLOPs": fac_flops / (ph[1] * 1e-3) / 1e12,
+                         "frac_of_fp64_matrix_peak": fac_flops / (ph[1] * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFS}}
+    return roof, phases
+
+
+def plan_xsuper(plan):
+    return getattr(plan, "_xsuper", [1, plan.m + 1])
+
+
+def factor_flops(plan):
+    """sum over supernodes of n*m^2 - n^2*m + n^3/3 from the symbolic factor."""
+    Ljc = np.asarray(plan.L_pattern.indptr, dtype=np.float64)
+    xs = np.asarray(plan_xsuper(plan), dtype=np.int64) - 1
+    tot = 0.0
+    for a, b in zip(xs[:-1], xs[1:]):
+        n = float(b - a); ms = float(Ljc[a + 1] - Ljc[a])
+        tot += n * ms * ms - n * n * ms + n ** 3 / 3.0
+    return tot
+
+
+def stage1_flops(P):
+    """2 * n_k^2 * (nonzero columns of A_jk) summed over the (constraint, block) tasks."""
+    s = P.K["s"].ravel().astype(np.int64)
+    return float(2.0 * np.sum(s.astype(np.float64) ** 2 * s) * P.m) if s.size else 0.0
+
+
+def measure_config(name, device, steps, warmup, nprof):
+    """One of the other BASELINE configs, measured briefly in this process: ms/unit, dominant kernel, solve rate."""
+    try:
+        t0 = time.perf_counter()
+        P, L, ADA, Q, d, ud, rhs, qpr, note = build_workload(name, 0)
+        plan = make_plan(device, P, L, ADA, Q, d, ud, rhs, qpr)
+        plan._xsuper = np.asarray(L["xsuper"]).ravel().astype(np.int64)
+        step = unit_fn(plan)
+        el = time_steps(plan, step, steps, warmup)
+        roof, phases = profile_unit(plan, P, ud, nprof)
+        out = {"workload": name, "problem": P.name, "m": int(P.m), "nnzL": int(plan.nnzL), "nsuper": int(plan._xsuper.size - 1),
+               "ms_per_step": 1e3 * el / steps, "iters_per_s": steps / el, "steps": steps,
+               "dominant_kernel": roof and {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step")},
+               "phases_ms_per_step": {k: phases[k] for k in ("ada_ms", "factor_ms", "solves_ms")},
+               "solve": phases["solve"], "factor": phases["factor"], "setup_s": time.perf_counter() - t0 - el}
+        plan.close()
+        return out
+    except Exception as e:  # never break the bench line
+        return {"workload": name, "error": repr(e)}
+
+
+def pcie_inclusive(plan, P, d, ud, rhs, steps):
+    """The same unit with every MEX-boundary transfer of the tier-1 flow inside the timed region (host buffers in and
+    out around each of the six calls, as the mexFunction shims with the cached plan do): never `value`."""
+    m = plan.m
+    nA, nL = plan.nnzADA, plan.nnzL
+
+    def step():
+        plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud)
+        plan.getada()
+        ada = plan.download("ada", nA); absd = plan.download("absd", m)          # getada3 returns ADA, absd
+        plan.upload("ada", ada); plan.upload("absd", absd)                         # blkchol(L, ADA, pars, absd)
+        plan.blkchol(PARS, True)
+        plan.download("lpr", nL); dd = plan.download("d", m)                       # [L.L, L.d, ...]
+        for _ in range(NSOLVE):
+            plan.upload("rhs", rhs); plan.fwsolve(); y = plan.download("y", m)     # fwblkslv
+            plan.upload("rhs", y / np.where(dd > 0, dd, 1.0)); plan.bwsolve(); plan.download("y", m)   # ./L.d in MATLAB, bwblkslv
+    for _ in range(2):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    el = time.perf_counter() - t0
+    return {"value": steps / el, "unit": "IPM iters/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+            "note": "host buffers cross PCIe around every one of the 6 + 2x4 MEX-equivalent calls (pageable numpy memory, "
+                    f"synchronous copies): {8 * (3 * nA + 2 * nL) / 1e6:.1f} MB per unit"}
 
 
 def bench_subtrees(args, rank, local_rank, world, torch, dist, coll_dev):
@@ -147,11 +370,13 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="control07",
-                    help="control07 (default, BASELINE configs[1]) | nb (configs[2] shape) | maxcut<n> (configs[3]) | blockdiag[:nblk:n:mper] (configs[4])")
+                    help="control07 (default: examples/control07.mat, BASELINE configs[1]) | control07_like (synthetic, same shape) | "
+                         "nb (configs[2] shape) | maxcut<n> (configs[3]) | blockdiag[:nblk:n:mper] (configs[4])")
     ap.add_argument("--shard", default="auto", choices=["auto", "replicas", "columns"],
-                    help="N>1: replicas = independent units per rank (default for single-supernode workloads); "
-                         "columns = ONE unit per step, ADA' column panels per rank + RCCL all-gather, factor/solves replicated")
+                    help="N>1: columns (auto for single-supernode workloads) = ONE unit per step, ADA' column panels per rank + RCCL "
+                         "all-gather, factor/solves replicated; replicas = independent units per rank (weak scaling, no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the brief measurements of configs[2..4]")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (one launch per step)")
     args = ap.parse_args()
 
@@ -175,17 +400,12 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     coll_dev = torch.device("cpu") if share else torch.device("cuda", local_rank)
 
-    from sedumi_amd.plan import Plan
-    if args.workload.startswith("blockdiag"):
+    if args.workload.startswith("blockdiag") and (world > 1 or args.shard != "auto"):
         return bench_subtrees(args, rank, local_rank, world, torch, dist, coll_dev)
-    shard_cols = args.shard == "columns" and world > 1
-    P, L, ADA, Q, d, ud, rhs = build_workload(args.workload, seed=0 if shard_cols else rank)
-    plan = Plan(local_rank)
-    plan.set_chol(L, ADA)
-    plan.set_ada(P.At, P.Ablkjc, P.K, Q)
-    plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud); plan.upload("rhs", rhs)
-    if Q.nnz:                                  # Lorentz cones: DAt.q values in the order of the pattern (getDAtm.m's product)
-        plan.upload("qpr", 0.1 * np.random.default_rng(3).standard_normal(Q.nnz))
+    shard_cols = world > 1 and args.shard in ("auto", "columns")
+    P, L, ADA, Q, d, ud, rhs, qpr, data_note = build_workload(args.workload, seed=0 if (shard_cols or world == 1) else rank)
+    plan = make_plan(local_rank, P, L, ADA, Q, d, ud, rhs, qpr)
+    plan._xsuper = np.asarray(L["xsuper"]).ravel().astype(np.int64)
 
     cs = None
     if shard_cols:
@@ -201,8 +421,8 @@ def main():
         for _ in range(NSOLVE):
             plan.ldlsolve()
 
+    eager_step = step
     if args.graph and cs is None:
-        eager_step = step
         for _ in range(2):
             eager_step()                       # first-use work (function attributes, allocations) outside the capture
         plan.sync()
@@ -232,80 +452,42 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline leg: the dominant kernel's launches timed with HIP events on the plan's stream
-    # (same steps, events around every launch; the un-instrumented loop above gives `value`).
-    plan.kprof(True)
-    prof_step = eager_step if (args.graph and cs is None) else step
-    for _ in range(min(args.steps, 50)):
-        prof_step()
-    prof = plan.kprof_summary()
-    plan.kprof(False)
-    nprof = min(args.steps, 50)
-    m, nnzL = plan.m, plan.nnzL
-    # ALGORITHMIC work per launch of each hot kernel (SURVEY.md 8(d) per-unit figures divided
-    # by the launches per unit).  bound "hbm": bytes, peak 8 TB/s; bound "mfma": FP64 flops, peak 78.6 TFLOP/s
-    # (on CDNA4 the FP64 matrix rate equals the FP64 vector rate).
-    solve_bytes = 8.0 * nnzL + 8.0 * m + 16.0 * m       # per triangular solve: 8*nnz(L) + 8*len(lindx) + 16*m
-    npan = (m + 63) // 64
-    model = {
-        "k_ldl_single": ("hbm", 2.0 * solve_bytes),                                  # forward + backward sweep in one launch
-        "k_fw_level": ("hbm", solve_bytes), "k_bw_level": ("hbm", solve_bytes),
-        "k_ldl_update": ("mfma", (m ** 3 / 3.0) / max(1, npan - 1)),                 # trailing updates carry the m^3/3 of the LDL'
-        # one launch per panel: 64x64 LDL' (latency bound), row solves and the previous panel's trailing update
-        "k_ldl_panel": ("mfma", 2.0 * 64 ** 3 / 3.0 + (0.0 if "k_ldl_update" in prof else (m ** 3 / 3.0) / max(1, npan - 1))),
-        "k_psd_stage1_mfma": ("hbm", 8.0 * (ud.size + P.At.nnz + plan.nnzADA)),      # SURVEY.md 8(d) getada3 lower bound
-        "k_psd_stage1": ("hbm", 8.0 * (ud.size + P.At.nnz + plan.nnzADA)),
-        "k_psd_stage2": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)),
-        "k_ada_spdot": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)),
-    }
-    peaks = {"hbm": (HBM_PEAK_GBS, "GB/s", 1e9), "mfma": (78.6, "TFLOP/s", 1e12)}
-    dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
-    roof = None
-    if dom:
-        calls, ms = prof[dom]
-        avg_s = ms / calls * 1e-3
-        key = dom.split("<")[0]
-        if key.startswith("k_psd_stage2"):
-            key = "k_psd_stage2"
-        bound, work = model.get(key, ("hbm", 8.0 * (plan.nnzADA / 2 + 2 * nnzL)))
-        peak, unit, scale = peaks[bound]
-        ach = work / avg_s / scale
-        roof = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                "frac": ach / peak, "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_per_step": calls / nprof,
-                "algorithmic_work_per_launch": work,
-                "stage_ms_per_step": {k: v[1] / nprof for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
-        # the solve kernel is the path's HBM-bound kernel (north_star): always reported beside the dominant one
-        for sk in ("k_ldl_single", "k_fw_level"):
-            if sk in prof:
-                c2, ms2 = prof[sk]
-                b2 = model[sk][1] * (1.0 if sk == "k_ldl_single" else 1.0)
-                roof["solve_kernel"] = {"kernel": sk, "avg_launch_us": ms2 / c2 * 1e3, "achieved_GBs": b2 / (ms2 / c2 * 1e-3) / 1e9,
-                                        "frac_of_hbm_peak": b2 / (ms2 / c2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b2}
-                break
-        import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-        if pmcs:
-            try:
-                roof["traffic"] = json.load(open(pmcs[-1])).get(dom)
-                roof["traffic_source"] = os.path.basename(pmcs[-1])
-            except Exception:
-                pass
+    roof, phases = profile_unit(plan, P, ud, min(args.steps, 50))
 
     if rank == 0:
-        base = None
-        if world == 1 and not args.no_cpu_baseline:
-            base = cpu_baseline(P, d, ud, rhs)
+        base = base_blas = pcie = None
+        others = []
+        if world == 1:
+            pcie = pcie_inclusive(plan, P, d, ud, rhs, min(args.steps, 20))
+            if not args.no_cpu_baseline:
+                base = cpu_baseline(P, d, ud, rhs)
+                try:
+                    from oracle import refmex
+                    ob = refmex.find_openblas()
+                except Exception:
+                    ob = None
+                if ob:
+                    base_blas = cpu_baseline(P, d, ud, rhs, budget_s=8.0, blas=ob)
+            if not args.no_other_configs and args.workload == "control07":
+                for nm, st, wu, npf in (("control07_like", 100, 5, 20), ("nb", 100, 5, 20), ("maxcut4000", 10, 2, 5), ("blockdiag", 20, 3, 10)):
+                    others.append(measure_config(nm, local_rank, st, wu, npf))
+        mult = 1 if (shard_cols or world == 1) else world
         out = {
-            "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": (1 if shard_cols else world) * args.steps / elapsed, "unit": "IPM iters/s",
+            "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": mult * args.steps / elapsed, "unit": "IPM iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong" if shard_cols else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{P.name}: {CONFIG_NOTE.get(args.workload[:6], CONFIG_NOTE['contro'])}, m={P.m}, nnz(At)={P.At.nnz}, "
-                                   f"dense ADA' {P.m}x{P.m}, nnz(L)={nnzL}; unit = getada1+2+3, blkchol, {NSOLVE}x(fwblkslv,./d,bwblkslv)",
-                       "parallelism": ("ADA' column panels + RCCL all-gather, factor/solves replicated" if shard_cols else "replicas") if world > 1 else "single GPU"},
-            "roofline": roof, "cpu_baseline": base,
+            "higher_is_better": True, "scaling": "strong" if shard_cols else "weak", "vs_baseline": None, "dtype": "f64",
+            "data": data_note,
+            "config": {"workload": f"{P.name}: {CONFIG_NOTE.get(args.workload[:6], 'synthetic')}, m={P.m}, nnz(At)={P.At.nnz}, "
+                                   f"nnz(ADA')={plan.nnzADA}, nnz(L)={plan.nnzL}; unit = getada1+2+3, blkchol, {NSOLVE}x(fwblkslv,./d,bwblkslv)",
+                       "parallelism": (("ADA' column panels per rank + RCCL all-gather, factor/solves replicated (they do not shard: one dense supernode)"
+                                        if shard_cols else "replicas: independent units per rank, no collective") if world > 1 else "single GPU")},
+            "roofline": roof, "phases_ms_per_step": phases, "cpu_baseline": base, "cpu_baseline_blas": base_blas,
+            "pcie_inclusive": pcie, "other_configs": others,
         }
         if base and base.get("value"):
-            out["speedup_vs_cpu_reference"] = out["value"] / (1 if shard_cols else world) / base["value"]
+            out["speedup_vs_cpu_reference"] = out["value"] / mult / base["value"]
+        if base_blas and base_blas.get("value"):
+            out["speedup_vs_cpu_reference_blas"] = out["value"] / mult / base_blas["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -284,6 +284,13 @@ int sdm_plan_kprof_enable(sdm_plan *p, int on);
 int sdm_plan_kprof_get(sdm_plan *p, const char *kernel, sdm_int *calls, double *total_ms);
 int sdm_plan_kprof_summary(sdm_plan *p, char *buf, sdm_int buflen);
 
+/* The solves apply the 256-column diagonal super-blocks of L as explicit inverses (sdm_solve.hip) unless a block's
+ * growth  max|inv(L_PP)| * max|L_PP|  exceeds growth_max (default 1e4): such a block is solved by substitution like
+ * fwblkslv.c:109-114 / bwblkslv.c:113-122.  growth_max = 0 forces substitution everywhere.  Takes effect at the next
+ * factorisation (sdm_plan_blkchol).  solve_stats reports the blocks of the last factorisation (synchronises). */
+int sdm_plan_set_growth_max(sdm_plan *p, double growth_max);
+int sdm_plan_solve_stats(sdm_plan *p, sdm_int *nblocks, sdm_int *nbad, double *max_growth);
+
 /* ---- one process-wide resident plan for the mexFunction shims: every .mex binary is its own
  * shared object, so the cache lives in this library.  sdm_mexcache_plan returns the plan of the symbolic factor
  * (L.{L pattern, perm, xsuper}) and ADA pattern given, creating it on a miss (NULL + sdm_last_error on failure).

@@ -49,6 +49,15 @@ def available() -> bool:
     return os.path.exists(os.path.join(REF_DIR, "libmexshim.so"))
 
 
+def find_openblas():
+    """The ILP64 OpenBLAS inside numpy's wheel (Fortran entry points scipy_<name>_64_): (path, prefix, suffix) or None."""
+    import glob
+    for base in (os.path.join(os.path.dirname(np.__file__) + ".libs"), os.path.join(os.path.dirname(os.path.dirname(np.__file__)), "scipy.libs")):
+        for f in sorted(glob.glob(os.path.join(base, "libscipy_openblas64_*.so"))):
+            return f, "scipy_", "_64_"
+    return None
+
+
 class RawSparse:
     """A sparse matrix to be handed to a reference MEX exactly as stored (no index sorting): incorder's `dz`
     lists the rows of every column in the order in which they were introduced (incorder.c:171-208)."""
@@ -178,6 +187,15 @@ class RefMex:
                     if plhs[i]:
                         self.shim.mxDestroyArray(plhs[i])
         return outs[0] if nlhs <= 1 else outs
+
+    def use_blas(self, lib=None):
+        """Bind the BLAS-1 calls of the reference (ddot, daxpy, dscal, dcopy, idamax) to an optimised host BLAS
+        (lib = (path, prefix, suffix), see find_openblas) or back to the shim's naive loops (lib = None)."""
+        self.shim.shim_use_blas.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+        if lib is None:
+            return self.shim.shim_use_blas(None, None, None) == 0
+        os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+        return self.shim.shim_use_blas(lib[0].encode(), lib[1].encode(), lib[2].encode()) == 0
 
     def timed_call(self, name, nlhs, args, reps=1):
         """Like call() but marshals once and times only mexFunction itself.

@@ -209,28 +209,31 @@ int sdm_plan_pivots(sdm_plan *p, sdm_int *nskip, sdm_int *skip_idx, double *skip
 int sdm_plan_fwsolve(sdm_plan *p) {
   SDM_TRY
   if (!p->factored) throw std::runtime_error("fwsolve: no factor resident");
-  if (solve_single(p, p->rhs.p, p->y.p, 1)) return 0;
-  vec_gather(p, p->ywork.p, p->rhs.p, true);
-  solve_fw(p);
-  SDM_HIP_CHECK(hipMemcpyAsync(p->y.p, p->ywork.p, p->chol.m * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  solve_run(p, p->rhs.p, p->y.p, 1);
   SDM_CATCH
 }
 int sdm_plan_bwsolve(sdm_plan *p) {
   SDM_TRY
   if (!p->factored) throw std::runtime_error("bwsolve: no factor resident");
-  if (solve_single(p, p->rhs.p, p->y.p, 4)) return 0;
-  SDM_HIP_CHECK(hipMemcpyAsync(p->ywork.p, p->rhs.p, p->chol.m * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
-  solve_bw(p);
-  vec_gather(p, p->y.p, p->ywork.p, false);
+  solve_run(p, p->rhs.p, p->y.p, 4);
   SDM_CATCH
 }
 int sdm_plan_ldlsolve(sdm_plan *p) {
   SDM_TRY
   if (!p->factored) throw std::runtime_error("ldlsolve: no factor resident");
-  if (solve_single(p, p->rhs.p, p->y.p, 7)) return 0;
-  // gather through perm, ./d and the scatter of y(perm) ride inside the first / last level launches
-  solve_fw(p, p->rhs.p);
-  solve_bw(p, true, p->y.p);
+  solve_run(p, p->rhs.p, p->y.p, 7);
+  SDM_CATCH
+}
+int sdm_plan_set_growth_max(sdm_plan *p, double growth_max) {
+  SDM_TRY
+  if (!(growth_max >= 0.0)) throw std::runtime_error("growth_max must be >= 0");
+  p->chol.growth_max = growth_max;
+  SDM_CATCH
+}
+int sdm_plan_solve_stats(sdm_plan *p, sdm_int *nblocks, sdm_int *nbad, double *max_growth) {
+  SDM_TRY
+  if (!p->has_chol) throw std::runtime_error("sdm_plan_solve_stats: no symbolic factor set");
+  solve_stats(p, nblocks, nbad, max_growth);
   SDM_CATCH
 }
 // ---- hipGraph capture of a launch-bound sequence of plan calls (e.g. one whole iteration unit): everything the plan

@@ -172,19 +172,16 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   C.d_asm_src.upload(asm_src); C.d_asm_dst.upload(asm_dst); C.d_asm_dstT.upload(asm_dstT); C.d_toff.upload(C.sn_toff);
   C.frontsT.alloc((size_t)C.tsize);
   { std::vector<int64_t> l64(C.Ljc.begin(), C.Ljc.end()); C.d_Ljc.upload(l64); }
-  C.fronts.alloc((size_t)C.fsize); C.wvec.alloc((size_t)C.wsize); C.colbuf.alloc((size_t)C.wsize + (size_t)nsuper);
+  C.fronts.alloc((size_t)C.fsize + 128);                          // + padding: k_sinv128 reads up to 63 rows past a partial block
+  C.wvec.alloc((size_t)C.wsize); C.colbuf.alloc((size_t)C.wsize + (size_t)nsuper);
   C.d.alloc(m); C.dsolve.alloc(m); C.lb.alloc(m); C.pivval.alloc(m); C.pivstat.alloc(m); C.ub.alloc(3); C.upd_cnt.alloc((size_t)std::max<sdm_int>(1, C.nsuper)); C.diag_cnt.alloc((size_t)std::max<sdm_int>(1, C.nsuper));
   P->ada_val.alloc((size_t)C.nnzADA); P->absd.alloc(m); P->lpr.alloc((size_t)C.nnzL);
   P->rhs.alloc(m); P->y.alloc(m); P->ywork.alloc(m);
   P->has_chol = true; P->factored = false;
+  solve_build(P);
 }
 
 // ================================================================= kernels
-struct FrontTab {
-  const int *first, *ns, *ms, *ld;
-  const int64_t *foff, *xl, *woff, *roff, *toff;
-  const int *childptr, *childlist, *lindx, *relidx;
-};
 
 // ---- permuteP: scatter tril(ADA(perm,perm)) into the (zeroed) fronts
 __global__ void k_assemble(double *F, const double *ada, const int *src, const int64_t *dst, int64_t nnzL) {
@@ -1007,808 +1004,8 @@ k_ldl_update(double *F, FrontTab tab, const int *list, int panel, const double *
 }
 
 // ================================================================== solves
-// One workgroup per front; fronts of an etree level are independent.  The front-local vector w lives in LDS
-// (HBM scratch for fronts beyond SOLVE_LDS_MAX rows).  Per 64-column panel ONE wavefront does the in-block
-// triangular solve -- lane i owns row i, its 64 coefficients sit in registers (prefetched while the previous
-// panel streams) and the dependency chain is a v_readlane broadcast + one FMA per column (no LDS, no barrier)
-// -- while all waves stream the panel below the block exactly once with coalesced reads:
-//   forward  (fwblkslv.c:77-134): one row per work-item, 16 independent loads in flight per lane;
-//   backward (bwblkslv.c:73-125): one column per wavefront at a time (contiguous reads), wave reduction.
-// The transposed in-block solve of the backward sweep reads the 64x64 diagonal blocks from the compact
-// transposed copy DT written by the factor (coalesced for lane = column).
-// Stage the strictly lower triangle of a kb x kb diagonal block into LDS (Sd[c*64 + i] = L(k0+i, k0+c) for
-// c < i < kb, 0 elsewhere) -- all work-items, coalesced along the rows.  The in-block triangular solve then
-// reads its coefficient of step k with one conflict-free ds_read (address independent of the dependency chain).
-__device__ __forceinline__ void stage_block(double *Sd, const double *blk, int ld, int kb) {
-  for (int idx = threadIdx.x; idx < SNB * SNB; idx += blockDim.x) {
-    const int i = idx & 63, c = idx >> 6;
-    Sd[idx] = (c < i && i < kb) ? blk[(int64_t)c * ld + i] : 0.0;
-  }
-}
-// the same in two halves for workgroups of SOLVE_THREADS work-items: the (clamped, unconditional) loads are issued
-// early, the masked LDS stores are done after other memory traffic has been issued
-constexpr int STG = SNB * SNB / SOLVE_THREADS;
-__device__ __forceinline__ void stage_block_load(double (&sv)[STG], const double *blk, int ld, int kb) {
-#pragma unroll
-  for (int q = 0; q < STG; q++) {
-    const int idx = threadIdx.x + q * SOLVE_THREADS, i = idx & 63, c = idx >> 6;
-    sv[q] = blk[(int64_t)min(c, kb - 1) * ld + min(i, kb - 1)];
-  }
-}
-__device__ __forceinline__ void stage_block_store(double *Sd, const double (&sv)[STG], int kb) {
-#pragma unroll
-  for (int q = 0; q < STG; q++) {
-    const int idx = threadIdx.x + q * SOLVE_THREADS, i = idx & 63, c = idx >> 6;
-    Sd[idx] = (c < i && i < kb) ? sv[q] : 0.0;
-  }
-}
-// the same from the transposed copy DT (Dp[c*64 + i] = L(k0+c, k0+i)): Sd[c*64 + i] = L(k0+c, k0+i) for i < c < kb
-__device__ __forceinline__ void stage_blockT(double *Sd, const double *Dp, int kb) {
-  for (int idx = threadIdx.x; idx < SNB * SNB; idx += blockDim.x) {
-    const int i = idx & 63, c = idx >> 6;
-    Sd[idx] = (c > i && c < kb) ? Dp[idx] : 0.0;
-  }
-}
-
-constexpr int TCH = 32;  // in-block solve: coefficients fetched from LDS per batch (one LDS round trip per TCH steps of the chain)
-
-// ---- panel streaming helpers.  The panel below a diagonal block is read exactly once, with 16-byte loads (ld
-// and the first row `ra` of the pair range are even), 16 loads per lane in flight.
-// Forward: a row pair is shared by the 4 lanes {l, l+16, l+32, l+48} of a wavefront (g = lane >> 4), each owning
-// 16 of the 64 columns, so that the 16 lanes of one g read 256 contiguous bytes of one column (lanes that are
-// neighbours in a quad must not straddle columns: the L1 coalescer then handles one line per lane, measured 4x
-// slower); the 4 partial sums meet in a fixed-order reduction across g (deterministic).
-__device__ __forceinline__ void fw_issue(sdm_double2 (&v)[16], const double *Fs, int ld, int k0, int ra, int npair, int t, int g) {
-  const sdm_double2 *col = (const sdm_double2 *)(Fs + (int64_t)(k0 + 16 * g) * ld + ra + 2 * min(t, npair - 1));
-  const int ld2 = ld >> 1;
-#pragma unroll
-  for (int c = 0; c < 16; c++) v[c] = col[(int64_t)c * ld2];
-}
-__device__ __forceinline__ void fw_consume(const sdm_double2 (&v)[16], const double *wb, double *w, int ra, int npair, int t, int g) {
-  double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-  for (int c = 0; c < 16; c++) { a0 += v[c].x * wb[16 * g + c]; a1 += v[c].y * wb[16 * g + c]; }
-  a0 += __shfl_xor(a0, 16); a1 += __shfl_xor(a1, 16);
-  a0 += __shfl_xor(a0, 32); a1 += __shfl_xor(a1, 32);
-  if (g == 0 && t < npair) { w[ra + 2 * t] -= a0; w[ra + 2 * t + 1] -= a1; }
-}
-// Backward: a wavefront sweeps 4 columns at a time, lanes along the row pairs, 4 pair-chunks of 64 per round.
-__device__ __forceinline__ void bw_issue(sdm_double2 (&v)[16], const double *Fs, int ld, int k0, int kb, int cb0, int ra, int npair, int t0) {
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int tc = min(t0 + 64 * i, npair - 1);
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-      v[4 * i + q] = ((const sdm_double2 *)(Fs + (int64_t)(k0 + min(cb0 + q, kb - 1)) * ld + ra))[tc];
-  }
-}
-__device__ __forceinline__ void bw_consume(const sdm_double2 (&v)[16], double (&acc)[4], const double *w, int ra, int npair, int t0) {
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int t = t0 + 64 * i;
-    if (t < npair) {
-      const double w0 = w[ra + 2 * t], w1 = w[ra + 2 * t + 1];
-#pragma unroll
-      for (int q = 0; q < 4; q++) acc[q] += v[4 * i + q].x * w0 + v[4 * i + q].y * w1;
-    }
-  }
-}
-
-__device__ __forceinline__ void front_fw_small(const double *Fs, int ns, int ms, int ld, double *w, double *wb, double *Sd) {
-  const int tid = threadIdx.x, bs = blockDim.x;
-  const int g = (tid >> 4) & 3, t0 = (tid >> 6) * 16 + (tid & 15), tstep = bs >> 2;
-  SDM_PHASE_BEGIN();
-  stage_block(Sd, Fs, ld, min(SNB, ns));
-  __syncthreads();
-  SDM_PHASE(0);
-  for (int k0 = 0; k0 < ns; k0 += SNB) {
-    const int kb = min(SNB, ns - k0);
-    if (tid < 64) {
-      double wi = tid < kb ? w[k0 + tid] : 0.0;
-      // coefficients of TCH steps are pulled into registers at once (one LDS round trip per TCH steps of the
-      // dependency chain instead of one per step); 0 for lanes <= k and for k >= kb
-#pragma unroll
-      for (int h = 0; h < SNB; h += TCH) {
-        double lr[TCH];
-#pragma unroll
-        for (int k = 0; k < TCH; k++) lr[k] = Sd[(h + k) * SNB + tid];
-#pragma unroll
-        for (int k = 0; k < TCH; k++) SDM_PIN(lr[k]);
-#pragma unroll
-        for (int k = 0; k < TCH; k++) wi -= lr[k] * sdm_bcast_lane(wi, h + k);
-      }
-      if (tid < kb) { w[k0 + tid] = wi; wb[tid] = wi; }
-    }
-    SDM_PHASE(1);
-    __syncthreads();
-    SDM_PHASE(2);
-    const int k1 = k0 + SNB;
-    const bool fast_stage = k1 < ns && bs == SOLVE_THREADS;
-    double sv[STG];
-    if (fast_stage) stage_block_load(sv, Fs + (int64_t)k1 * ld + k1, ld, min(SNB, ns - k1));   // next diagonal block: loads now
-    else if (k1 < ns) stage_block(Sd, Fs + (int64_t)k1 * ld + k1, ld, min(SNB, ns - k1));
-    SDM_PHASE(3);
-    const int rb = k0 + kb, ra = rb + (rb & 1);
-    const int npair = ms > ra ? (ms - ra) >> 1 : 0;
-    if (kb == SNB) {
-      const int lim = (npair + 15) & ~15;                // whole quads / waves stay converged for the shuffles
-      for (int t = t0; t < lim; t += tstep) {
-        sdm_double2 v[16];
-        fw_issue(v, Fs, ld, k0, ra, npair, t, g);
-        fw_consume(v, wb, w, ra, npair, t, g);
-      }
-    } else {
-      for (int t = tid; t < npair; t += bs) {
-        const int r = ra + 2 * t;
-        const sdm_double2 *col = (const sdm_double2 *)(Fs + (int64_t)k0 * ld + r);
-        double a0 = 0.0, a1 = 0.0;
-        for (int c = 0; c < kb; c++) { const sdm_double2 x = col[(int64_t)c * (ld >> 1)]; a0 += x.x * wb[c]; a1 += x.y * wb[c]; }
-        w[r] -= a0; w[r + 1] -= a1;
-      }
-    }
-    {  // the (at most two) unpaired rows: rb when odd, the last row when the pair range leaves one over
-      int r = -1;
-      if (tid == bs - 1 && (rb & 1) && rb < ms) r = rb;
-      if (tid == bs - 2 && ms > ra && ((ms - ra) & 1)) r = ms - 1;
-      if (r >= 0) {
-        const double *col = Fs + (int64_t)k0 * ld + r;
-        double acc = 0.0;
-        for (int c = 0; c < kb; c++) acc += col[(int64_t)c * ld] * wb[c];
-        w[r] -= acc;
-      }
-    }
-    if (fast_stage) stage_block_store(Sd, sv, min(SNB, ns - k1));                 // ... LDS stores after the panel stream
-    SDM_PHASE(4);
-    __syncthreads();
-    SDM_PHASE(5);
-  }
-}
-
-__device__ __forceinline__ void front_bw_small(const double *Fs, const double *Ds, int ns, int ms, int ld, double *w, double *dots, double *Sd) {
-  const int tid = threadIdx.x, bs = blockDim.x;
-  const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
-  const int npan = (ns + SNB - 1) / SNB;
-  SDM_PHASE_BEGIN();
-  for (int pnl = npan - 1; pnl >= 0; pnl--) {
-    const int k0 = pnl * SNB, kb = min(SNB, ns - k0);
-    const int rb = k0 + kb, ra = rb + (rb & 1);
-    const int npair = ms > ra ? (ms - ra) >> 1 : 0;
-    stage_blockT(Sd, Ds + (int64_t)pnl * SNB * SNB, kb);
-    // dots[c] = sum_{r >= rb} L(r, k0+c) * w[r]
-    if (rb < ms) {
-      for (int cb0 = wave * 4; cb0 < kb; cb0 += nw * 4) {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int tb = lane; tb < npair; tb += 256) {
-          sdm_double2 v[16];
-          bw_issue(v, Fs, ld, k0, kb, cb0, ra, npair, tb);
-          bw_consume(v, acc, w, ra, npair, tb);
-        }
-        if (lane == 0) {
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const double *colp = Fs + (int64_t)(k0 + min(cb0 + q, kb - 1)) * ld;
-            if (rb & 1) acc[q] += colp[rb] * w[rb];
-            if (ms > ra && ((ms - ra) & 1)) acc[q] += colp[ms - 1] * w[ms - 1];
-          }
-        }
-        // wave reduction of the 4 column sums with 7 shuffles instead of 24: fold the columns into the lane index
-        // first (upper half wave keeps columns 2,3, then odd 16-lane groups keep the odd column), then 4 plain steps
-        {
-          const bool hi = lane >= 32;
-          const double s0 = hi ? acc[0] : acc[2], s1 = hi ? acc[1] : acc[3];      // what the partner half keeps
-          double k0v = (hi ? acc[2] : acc[0]) + __shfl_xor(s0, 32);
-          double k1v = (hi ? acc[3] : acc[1]) + __shfl_xor(s1, 32);
-          const bool od = (lane >> 4) & 1;
-          double a = (od ? k1v : k0v) + __shfl_xor(od ? k0v : k1v, 16);
-          a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
-          const int q = (hi ? 2 : 0) + (od ? 1 : 0);                               // column held by this 16-lane group
-          if ((lane & 15) == 0 && cb0 + q < kb) dots[cb0 + q] = a;
-        }
-      }
-    }
-    SDM_PHASE(8);
-    __syncthreads();
-    SDM_PHASE(9);
-    if (tid < 64) {
-      double yi = tid < kb ? w[k0 + tid] - (rb < ms ? dots[tid] : 0.0) : 0.0;
-#pragma unroll
-      for (int h = SNB - TCH; h >= 0; h -= TCH) {       // L(k0+k, k0+tid), 0 unless k > tid
-        double lr[TCH];
-#pragma unroll
-        for (int k = 0; k < TCH; k++) lr[k] = Sd[(h + k) * SNB + tid];
-#pragma unroll
-        for (int k = 0; k < TCH; k++) SDM_PIN(lr[k]);
-#pragma unroll
-        for (int k = TCH - 1; k >= 0; k--) yi -= lr[k] * sdm_bcast_lane(yi, h + k);
-      }
-      if (tid < kb) w[k0 + tid] = yi;
-    }
-    SDM_PHASE(10);
-    __syncthreads();
-    SDM_PHASE(11);
-  }
-}
-
-
-// ---------------------------------------------------------------- pipelined sweeps (workgroups of SOLVE_THREADS)
-// The in-block triangular solve is a 64-step dependency chain (~1.1 us) on ONE wavefront; streaming the panel is
-// bandwidth work for the others.  The two overlap.  The rows below a panel are split into
-//  * the 64 rows right below it (the next diagonal block, needed by the next in-block solve): their update is
-//    accumulated by wavefront 0 INSIDE the chain -- step k broadcasts x_k anyway, one more FMA with the coefficient
-//    of the sub-diagonal block costs nothing on a latency-bound chain -- so the next solve starts right after ONE
-//    barrier;
-//  * the rows beyond, streamed by the other wavefronts while wavefront 0 is already solving the next block.
-// The diagonal block and the sub-diagonal block of the next step are staged in LDS by the streaming wavefronts,
-// alternately in the two halves of Sd2 / Sb2 (the backward sweep stores the sub-diagonal block transposed, pitch
-// SBP); x_p / the dots of the rows beyond are double-buffered.
-constexpr int BW_FARW = 13;              // backward: wavefronts 1..13 form the dots beyond (5 columns each), 14..15 stage
-constexpr int STG15 = (SNB * SNB + (SOLVE_THREADS - 64) - 1) / (SOLVE_THREADS - 64);   // staging by wavefronts 1..15
-constexpr int SBP = SNB + 1;             // row pitch of the transposed sub-diagonal block
-constexpr int TCF = 8;                   // fused in-block solve: steps per batch of coefficients (two register sets in ping-pong)
-constexpr int SOLVE_STAGE_DOUBLES = 2 * SNB * SNB + 2 * SNB * SBP;   // Sd2 then Sb2 at the head of the dynamic LDS
-
-__device__ __forceinline__ void stage15_load(double (&sv)[STG15], const double *blk, int ld, int kb) {
-#pragma unroll
-  for (int q = 0; q < STG15; q++) {
-    const int idx = min((int)threadIdx.x - 64 + q * (SOLVE_THREADS - 64), SNB * SNB - 1), i = idx & 63, c = idx >> 6;
-    sv[q] = blk[(int64_t)min(c, kb - 1) * ld + min(i, kb - 1)];
-  }
-}
-__device__ __forceinline__ void stage15_store(double *Sd, const double (&sv)[STG15], int kb) {
-#pragma unroll
-  for (int q = 0; q < STG15; q++) {
-    const int idx = (int)threadIdx.x - 64 + q * (SOLVE_THREADS - 64), i = idx & 63, c = idx >> 6;
-    if (idx < SNB * SNB) Sd[idx] = (c < i && i < kb) ? sv[q] : 0.0;
-  }
-}
-
-// in-block forward solve by one wavefront (lane = row): coefficients of TCH steps are pulled into registers at once
-// (one LDS round trip per TCH steps of the dependency chain); they are 0 for lanes <= k and for k >= kb
-__device__ __forceinline__ double trsv_fw_block(const double *Sd, double wi, int lane) {
-#pragma unroll
-  for (int h = 0; h < SNB; h += TCH) {
-    double lr[TCH];
-#pragma unroll
-    for (int k = 0; k < TCH; k++) lr[k] = Sd[(h + k) * SNB + lane];
-#pragma unroll
-    for (int k = 0; k < TCH; k++) SDM_PIN(lr[k]);
-#pragma unroll
-    for (int k = 0; k < TCH; k++) wi -= lr[k] * sdm_bcast_lane(wi, h + k);
-  }
-  return wi;
-}
-__device__ __forceinline__ double trsv_bw_block(const double *Sd, double yi, int lane) {
-#pragma unroll
-  for (int h = SNB - TCH; h >= 0; h -= TCH) {       // L(k0+k, k0+lane), 0 unless k > lane
-    double lr[TCH];
-#pragma unroll
-    for (int k = 0; k < TCH; k++) lr[k] = Sd[(h + k) * SNB + lane];
-#pragma unroll
-    for (int k = 0; k < TCH; k++) SDM_PIN(lr[k]);
-#pragma unroll
-    for (int k = TCH - 1; k >= 0; k--) yi -= lr[k] * sdm_bcast_lane(yi, h + k);
-  }
-  return yi;
-}
-// the same chain with the update of the next block riding along: cacc += sum_k Sb[k*pitch + lane] * x_k.
-// Coefficients travel in batches of TCF steps, two register sets in ping-pong: the loads of a batch are issued when
-// the batch before it starts (SDM_ZERO_AFTER pins them there) and land while its TCF steps run.
-#define SDM_FUSED_LOAD(lr, ls, h, z, PITCH)                                                       \
-  _Pragma("unroll") for (int k = 0; k < TCF; k++) { lr[k] = Sd[((h) + k) * SNB + lane + (z)]; ls[k] = Sb[((h) + k) * (PITCH) + lane + (z)]; }
-__device__ __forceinline__ double trsv_fw_fused(const double *Sd, const double *Sb, double wi, double &cacc, int lane) {
-  double lrA[TCF], lsA[TCF], lrB[TCF], lsB[TCF];
-  SDM_FUSED_LOAD(lrA, lsA, 0, 0, SNB)
-#pragma unroll
-  for (int h = 0; h < SNB; h += 2 * TCF) {
-    { const int z = SDM_ZERO_AFTER(wi); SDM_FUSED_LOAD(lrB, lsB, h + TCF, z, SNB) }
-#pragma unroll
-    for (int k = 0; k < TCF; k++) { const double xk = sdm_bcast_lane(wi, h + k); wi -= lrA[k] * xk; cacc += lsA[k] * xk; }
-    if (h + 2 * TCF < SNB) { const int z = SDM_ZERO_AFTER(wi); SDM_FUSED_LOAD(lrA, lsA, h + 2 * TCF, z, SNB) }
-#pragma unroll
-    for (int k = 0; k < TCF; k++) { const double xk = sdm_bcast_lane(wi, h + TCF + k); wi -= lrB[k] * xk; cacc += lsB[k] * xk; }
-  }
-  return wi;
-}
-__device__ __forceinline__ double trsv_bw_fused(const double *Sd, const double *Sb, double yi, double &cacc, int lane) {
-  double lrA[TCF], lsA[TCF], lrB[TCF], lsB[TCF];
-  SDM_FUSED_LOAD(lrA, lsA, SNB - TCF, 0, SBP)
-#pragma unroll
-  for (int h = SNB - TCF; h >= 0; h -= 2 * TCF) {
-    { const int z = SDM_ZERO_AFTER(yi); SDM_FUSED_LOAD(lrB, lsB, h - TCF, z, SBP) }
-#pragma unroll
-    for (int k = TCF - 1; k >= 0; k--) { const double xk = sdm_bcast_lane(yi, h + k); yi -= lrA[k] * xk; cacc += lsA[k] * xk; }
-    if (h - 2 * TCF >= 0) { const int z = SDM_ZERO_AFTER(yi); SDM_FUSED_LOAD(lrA, lsA, h - 2 * TCF, z, SBP) }
-#pragma unroll
-    for (int k = TCF - 1; k >= 0; k--) { const double xk = sdm_bcast_lane(yi, h - TCF + k); yi -= lrB[k] * xk; cacc += lsB[k] * xk; }
-  }
-  return yi;
-}
-// one row r below a kb-column panel (rows that do not pair up): w[r] -= L(r, k0:k0+kb) . x
-__device__ __forceinline__ void fw_single_row(const double *Fs, int ld, int k0, int kb, int r, const double *x, double *w) {
-  const double *col = Fs + (int64_t)k0 * ld + r;
-  double acc = 0.0;
-  for (int c = 0; c < kb; c++) acc += col[(int64_t)c * ld] * x[c];
-  w[r] -= acc;
-}
-// wave reduction of 4 column sums with 7 shuffles instead of 24: fold the columns into the lane index first (upper
-// half wave keeps columns 2,3, then odd 16-lane groups keep the odd column), then 4 plain steps; lanes with
-// (lane & 15) == 0 end up holding column q = 2*(lane >= 32) + ((lane >> 4) & 1)
-__device__ __forceinline__ double fold4(const double (&acc)[4], int lane) {
-  const bool hi = lane >= 32;
-  const double s0 = hi ? acc[0] : acc[2], s1 = hi ? acc[1] : acc[3];      // what the partner half keeps
-  double k0v = (hi ? acc[2] : acc[0]) + __shfl_xor(s0, 32);
-  double k1v = (hi ? acc[3] : acc[1]) + __shfl_xor(s1, 32);
-  const bool od = (lane >> 4) & 1;
-  double a = (od ? k1v : k0v) + __shfl_xor(od ? k0v : k1v, 16);
-  a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
-  return a;
-}
-// dots[c] = sum over the rows [ra, ms) of L(r, k0+c) w[r] for the 4 columns cb0..cb0+3 (one wavefront; ra even)
-__device__ __forceinline__ void bw_far_quad(const double *Fs, int ld, int k0, int kb, int cb0, int ra, int ms, const double *w,
-                                            double *dots, int lane) {
-  const int npair = ms > ra ? (ms - ra) >> 1 : 0;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int tb = lane; tb < npair; tb += 256) {
-    sdm_double2 v[16];
-    bw_issue(v, Fs, ld, k0, kb, cb0, ra, npair, tb);
-    bw_consume(v, acc, w, ra, npair, tb);
-  }
-  if (lane == 0 && ms > ra && ((ms - ra) & 1)) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) acc[q] += Fs[(int64_t)(k0 + min(cb0 + q, kb - 1)) * ld + ms - 1] * w[ms - 1];
-  }
-  const double a = fold4(acc, lane);
-  const int q = (lane >= 32 ? 2 : 0) + ((lane >> 4) & 1);
-  if ((lane & 15) == 0 && cb0 + q < kb) dots[cb0 + q] = a;
-}
-// dots over the rows [ra, ms) for the 5 columns c0 .. c0+4 of a full panel (one wavefront; columns beyond the panel
-// are clamped and dropped): BW_NCH chunks of 64 row pairs x 5 columns sixteen-byte loads per lane in flight
-constexpr int BW_NCH = 3;
-__device__ __forceinline__ void bw_far_five(const double *Fs, int ld, int k0, int c0, int ra, int ms, const double *w,
-                                            double *dots, int lane) {
-  const int npair = ms > ra ? (ms - ra) >> 1 : 0;
-  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  const sdm_double2 *cp = (const sdm_double2 *)(Fs + (int64_t)(k0 + c0) * ld + ra);
-  const int ld2 = ld >> 1;
-  for (int tb = lane; tb < npair; tb += 64 * BW_NCH) {
-    sdm_double2 v[5 * BW_NCH];
-#pragma unroll
-    for (int i = 0; i < BW_NCH; i++) {
-      const int tc = min(tb + 64 * i, npair - 1);
-#pragma unroll
-      for (int q = 0; q < 5; q++) v[5 * i + q] = cp[(int64_t)min(q, SNB - 1 - c0) * ld2 + tc];
-    }
-#pragma unroll
-    for (int i = 0; i < BW_NCH; i++) {
-      const int t = tb + 64 * i;
-      if (t < npair) {
-        const double w0 = w[ra + 2 * t], w1 = w[ra + 2 * t + 1];
-#pragma unroll
-        for (int q = 0; q < 5; q++) acc[q] += v[5 * i + q].x * w0 + v[5 * i + q].y * w1;
-      }
-    }
-  }
-  if (lane == 0 && ms > ra && ((ms - ra) & 1)) {
-#pragma unroll
-    for (int q = 0; q < 5; q++) acc[q] += Fs[(int64_t)(k0 + min(c0 + q, SNB - 1)) * ld + ms - 1] * w[ms - 1];
-  }
-  const double a4[4] = {acc[0], acc[1], acc[2], acc[3]};
-  const double a = fold4(a4, lane);
-  double e = acc[4];
-  e += __shfl_xor(e, 32); e += __shfl_xor(e, 16); e += __shfl_xor(e, 8); e += __shfl_xor(e, 4); e += __shfl_xor(e, 2); e += __shfl_xor(e, 1);
-  const int q = (lane >= 32 ? 2 : 0) + ((lane >> 4) & 1);
-  if ((lane & 15) == 0 && c0 + q < SNB) dots[c0 + q] = a;
-  if (lane == 1 && c0 + 4 < SNB) dots[c0 + 4] = e;
-}
-
-// sub-diagonal block below full panel k0 for the forward sweep: Sb[k*64 + i] = L(k0+64+i, k0+k), 0 for rows >= ms
-__device__ __forceinline__ void stage15_sub_load(double (&sv)[STG15], const double *Fs, int ld, int k0, int ms) {
-  const int nsub = min(SNB, ms - (k0 + SNB));
-#pragma unroll
-  for (int q = 0; q < STG15; q++) {
-    const int idx = min((int)threadIdx.x - 64 + q * (SOLVE_THREADS - 64), SNB * SNB - 1), i = idx & 63, k = idx >> 6;
-    sv[q] = nsub > 0 ? Fs[(int64_t)(k0 + k) * ld + k0 + SNB + min(i, nsub - 1)] : 0.0;
-  }
-}
-__device__ __forceinline__ void stage15_sub_store(double *Sb, const double (&sv)[STG15], int k0, int ms) {
-  const int nsub = min(SNB, ms - (k0 + SNB));
-#pragma unroll
-  for (int q = 0; q < STG15; q++) {
-    const int idx = (int)threadIdx.x - 64 + q * (SOLVE_THREADS - 64), i = idx & 63;
-    if (idx < SNB * SNB) Sb[idx] = i < nsub ? sv[q] : 0.0;
-  }
-}
-
-// forward sweep of one front, workgroup of SOLVE_THREADS; wb2 = 2*SNB doubles, Sd2 = SOLVE_STAGE_DOUBLES (LDS).
-// Wavefront 0 and the others run their own loops over the full panels (one barrier per panel each) -- separate loops
-// keep the register live ranges of the roles apart.
-__device__ __forceinline__ void front_fw_pipe(const double *Fs, int ns, int ms, int ld, double *w, double *wb2, double *Sd2) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = (tid >> 4) & 3;
-  const int nfull = ns / SNB, rem = ns - nfull * SNB;
-  double *Sb2 = Sd2 + 2 * SNB * SNB;
-  SDM_LPHASE_BEGIN();
-  stage_block(Sd2, Fs, ld, min(SNB, ns));
-  if (nfull > 0) {
-    const int nsub = min(SNB, ms - SNB);
-    for (int idx = tid; idx < SNB * SNB; idx += SOLVE_THREADS) {
-      const int i = idx & 63, k = idx >> 6;
-      Sb2[idx] = i < nsub ? Fs[(int64_t)k * ld + SNB + i] : 0.0;
-    }
-  }
-  __syncthreads();
-  SDM_LPHASE(0);
-  if (wave == 0) {
-    // ---- in-block solves; cacc = what panel p owes to the rows of block p+1
-    SDM_SETPRIO(3);                                                // the dependency chain ahead of the streaming wavefronts
-    double cacc = 0.0;
-    for (int p = 0; p < nfull; p++) {
-      const int k0 = p * SNB;
-      double cnext = 0.0;
-      const double wi = trsv_fw_fused(Sd2 + (p & 1) * SNB * SNB, Sb2 + (p & 1) * SNB * SNB, w[k0 + lane] - cacc, cnext, lane);
-      cacc = cnext;
-      w[k0 + lane] = wi;
-      wb2[(p & 1) * SNB + lane] = wi;
-      SDM_LPHASE(1);
-      __syncthreads();
-      SDM_LPHASE(2);
-    }
-    if (nfull > 0 && nfull * SNB + lane < ms) w[nfull * SNB + lane] -= cacc;      // rows right below the last full panel
-  } else {
-    // ---- the rows beyond: panel p-1 is streamed while wavefront 0 solves block p; blocks of step p+1 staged
-    for (int p = 0; p < nfull; p++) {
-      const int k0 = p * SNB, k1 = k0 + SNB;
-      double sv[STG15], sb[STG15];
-      if (k1 < ns) stage15_load(sv, Fs + (int64_t)k1 * ld + k1, ld, min(SNB, ns - k1));      // next diagonal block: loads now
-      if (p + 1 < nfull) stage15_sub_load(sb, Fs, ld, k1, ms);
-      if (p > 0) {
-        const int kp = k0 - SNB, ra = k0 + SNB;                                              // rows beyond block p
-        const int npair = ms > ra ? (ms - ra) >> 1 : 0, lim = (npair + 15) & ~15;
-        const double *wbq = wb2 + ((p - 1) & 1) * SNB;
-        for (int t = (wave - 1) * 16 + (lane & 15); t < lim; t += (SOLVE_THREADS / 64 - 1) * 16) {
-          sdm_double2 v[16];
-          fw_issue(v, Fs, ld, kp, ra, npair, t, g);
-          fw_consume(v, wbq, w, ra, npair, t, g);
-        }
-        if (tid == SOLVE_THREADS - 1 && ms > ra && ((ms - ra) & 1)) fw_single_row(Fs, ld, kp, SNB, ms - 1, wbq, w);
-      }
-      if (k1 < ns) stage15_store(Sd2 + ((p + 1) & 1) * SNB * SNB, sv, min(SNB, ns - k1));    // ... LDS stores after the stream
-      if (p + 1 < nfull) stage15_sub_store(Sb2 + ((p + 1) & 1) * SNB * SNB, sb, k1, ms);
-      SDM_LPHASE(4);
-      __syncthreads();
-    }
-  }
-  __syncthreads();
-  // ---- common tail: what the last full panel still owes to the rows beyond, then a partial last panel
-  if (nfull > 0 && ms > nfull * SNB + SNB) {
-    const int kp = (nfull - 1) * SNB, ra = nfull * SNB + SNB;
-    const int npair = (ms - ra) >> 1, lim = (npair + 15) & ~15;
-    const double *wbq = wb2 + ((nfull - 1) & 1) * SNB;
-    for (int t = wave * 16 + (lane & 15); t < lim; t += SOLVE_THREADS / 4) {
-      sdm_double2 v[16];
-      fw_issue(v, Fs, ld, kp, ra, npair, t, g);
-      fw_consume(v, wbq, w, ra, npair, t, g);
-    }
-    if (tid == SOLVE_THREADS - 1 && ((ms - ra) & 1)) fw_single_row(Fs, ld, kp, SNB, ms - 1, wbq, w);
-    __syncthreads();
-  }
-  if (rem > 0) {
-    const int k0 = nfull * SNB, kb = rem, rb = ns;
-    double *wbp = wb2 + (nfull & 1) * SNB;
-    if (wave == 0) {
-      const double wi = trsv_fw_block(Sd2 + (nfull & 1) * SNB * SNB, lane < kb ? w[k0 + lane] : 0.0, lane);
-      if (lane < kb) w[k0 + lane] = wi;
-      wbp[lane] = wi;
-    }
-    __syncthreads();
-    if (rb < ms) {
-      const int ra = rb + (rb & 1), npair = ms > ra ? (ms - ra) >> 1 : 0;
-      for (int t = tid; t < npair; t += SOLVE_THREADS) {
-        const int r = ra + 2 * t;
-        const sdm_double2 *col = (const sdm_double2 *)(Fs + (int64_t)k0 * ld + r);
-        double a0 = 0.0, a1 = 0.0;
-        for (int c = 0; c < kb; c++) { const sdm_double2 x = col[(int64_t)c * (ld >> 1)]; a0 += x.x * wbp[c]; a1 += x.y * wbp[c]; }
-        w[r] -= a0; w[r + 1] -= a1;
-      }
-      if (tid == SOLVE_THREADS - 1 && (rb & 1)) fw_single_row(Fs, ld, k0, kb, rb, wbp, w);
-      if (tid == SOLVE_THREADS - 2 && ms > ra && ((ms - ra) & 1)) fw_single_row(Fs, ld, k0, kb, ms - 1, wbp, w);
-      __syncthreads();
-    }
-  }
-  SDM_LPHASE(5);
-  SDM_LPHASE_END();
-}
-
-// backward sweep of one front, workgroup of SOLVE_THREADS; dots3 = 2*SNB doubles, Sd2 = SOLVE_STAGE_DOUBLES (LDS)
-__device__ __forceinline__ void front_bw_pipe(const double *Fs, const double *Ds, int ns, int ms, int ld, double *w, double *dots3,
-                                              double *Sd2) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int npan = (ns + SNB - 1) / SNB;
-  double *Sb2 = Sd2 + 2 * SNB * SNB;
-  SDM_LPHASE_BEGIN();
-  {
-    // last panel: nothing to overlap with.  Its dots over ALL rows below it; its diagonal block, and (transposed) the
-    // block left of it, which the in-block solve uses to form what panel P-1 gets from the rows of block P.
-    const int P = npan - 1, k0 = P * SNB, kb = ns - k0, rb = ns;
-    double *dF = dots3 + (P & 1) * SNB;
-    stage_blockT(Sd2 + (P & 1) * SNB * SNB, Ds + (int64_t)P * SNB * SNB, kb);
-    if (P > 0) {
-      double *Sn = Sb2 + (P & 1) * SNB * SBP;
-      for (int idx = tid; idx < SNB * SNB; idx += SOLVE_THREADS) {
-        const int i = idx & 63, c = idx >> 6;
-        Sn[i * SBP + c] = k0 + i < ms ? Fs[(int64_t)(k0 - SNB + c) * ld + k0 + i] : 0.0;   // incl. rows beyond a partial block
-      }
-    }
-    if (4 * wave < kb) {
-      const int ra = rb + (rb & 1), cb0 = 4 * wave;               // rb is odd only for a partial panel
-      bw_far_quad(Fs, ld, k0, kb, cb0, ra, ms, w, dF, lane);
-      SDM_WAVE_SYNC();
-      if (lane < 4 && cb0 + lane < kb && (rb & 1) && rb < ms) dF[cb0 + lane] += Fs[(int64_t)(k0 + cb0 + lane) * ld + rb] * w[rb];
-    }
-  }
-  SDM_LPHASE(8);
-  __syncthreads();
-  if (wave == 0) {
-    SDM_SETPRIO(3);
-    double cacc = 0.0;                                             // what the rows of block p+1 give to panel p
-    for (int p = npan - 1; p >= 0; p--) {
-      const int k0 = p * SNB, kb = min(SNB, ns - k0);
-      const double *dF = dots3 + (p & 1) * SNB;
-      // lanes beyond a partial last block carry the (final) values of the rows below it: passive in the solve (their
-      // coefficients are 0), but panel p-1 gets their contribution through the same chain
-      double yi = lane < kb ? w[k0 + lane] - dF[lane] - cacc : (k0 + lane < ms ? w[k0 + lane] : 0.0);
-      double cnext = 0.0;
-      if (p > 0) yi = trsv_bw_fused(Sd2 + (p & 1) * SNB * SNB, Sb2 + (p & 1) * SNB * SBP, yi, cnext, lane);
-      else yi = trsv_bw_block(Sd2 + (p & 1) * SNB * SNB, yi, lane);
-      cacc = cnext;
-      if (lane < kb) w[k0 + lane] = yi;
-      SDM_LPHASE(10);
-      __syncthreads();
-      SDM_LPHASE(11);
-    }
-  } else {
-    for (int p = npan - 1; p >= 0; p--) {
-      const int k0 = p * SNB;
-      if (p > 0) {
-        // what panel p-1 (full) can already know: its rows beyond block p are final.  Wavefronts 1..13 five columns
-        // each; wavefronts 14..15 stage the blocks of the next step: diagonal block p-1 (transposed copy DT) and the
-        // block left of it, transposed on the way into LDS.
-        const int kq = k0 - SNB, ra = k0 + SNB;
-        if (wave <= BW_FARW) {
-          // this wavefront's share of the block left of diagonal block p-1 (rows kq.., columns kq-64..), transposed
-          // on the way into LDS: loads first, stores after the dots
-          constexpr int NFT = 64 * BW_FARW, PT = (SNB * SNB / 2 + NFT - 1) / NFT;
-          const int t = tid - 64;
-          sdm_double2 tv[PT];
-          if (p > 1) {
-#pragma unroll
-            for (int q = 0; q < PT; q++) {
-              const int e = min(t + q * NFT, SNB * SNB / 2 - 1), ip = e & 31, c = e >> 5;   // rows kq+2ip, kq+2ip+1 of column kq-64+c
-              tv[q] = ((const sdm_double2 *)(Fs + (int64_t)(kq - SNB + c) * ld + kq))[ip];
-            }
-          }
-          bw_far_five(Fs, ld, kq, 5 * (wave - 1), ra, ms, w, dots3 + ((p - 1) & 1) * SNB, lane);
-          if (p > 1) {
-            double *Tn = Sb2 + ((p - 1) & 1) * SNB * SBP;
-#pragma unroll
-            for (int q = 0; q < PT; q++) {
-              const int e = t + q * NFT, ip = e & 31, c = e >> 5;
-              if (e < SNB * SNB / 2) { Tn[(2 * ip) * SBP + c] = tv[q].x; Tn[(2 * ip + 1) * SBP + c] = tv[q].y; }
-            }
-          }
-        } else {
-          constexpr int NST = SOLVE_THREADS - 64 * (1 + BW_FARW), PER = SNB * SNB / 2 / NST;
-          const sdm_double2 *Dp = (const sdm_double2 *)(Ds + (int64_t)(p - 1) * SNB * SNB);
-          double *Sn = Sd2 + ((p - 1) & 1) * SNB * SNB;
-          const int t = tid - 64 * (1 + BW_FARW);
-          sdm_double2 sv[PER];
-#pragma unroll
-          for (int q = 0; q < PER; q++) sv[q] = Dp[t + q * NST];
-#pragma unroll
-          for (int q = 0; q < PER; q++) {
-            const int idx = 2 * (t + q * NST), i = idx & 63, c = idx >> 6;       // Sn[c*64 + i] = L(kq+c, kq+i) for i < c
-            Sn[idx] = c > i ? sv[q].x : 0.0;
-            Sn[idx + 1] = c > i + 1 ? sv[q].y : 0.0;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  SDM_LPHASE_END();
-}
-
-__device__ __forceinline__ void front_fw(const double *Fs, int ns, int ms, int ld, double *w, double *wb2, double *Sd2) {
-  if (blockDim.x == SOLVE_THREADS) front_fw_pipe(Fs, ns, ms, ld, w, wb2, Sd2);
-  else front_fw_small(Fs, ns, ms, ld, w, wb2, Sd2);
-}
-__device__ __forceinline__ void front_bw(const double *Fs, const double *Ds, int ns, int ms, int ld, double *w, double *dots3, double *Sd2) {
-  if (blockDim.x == SOLVE_THREADS) front_bw_pipe(Fs, Ds, ns, ms, ld, w, dots3, Sd2);
-  else front_bw_small(Fs, Ds, ns, ms, ld, w, dots3, Sd2);
-}
-
-// The sweep kernels keep the front-local vector w either in LDS or (fronts beyond SOLVE_LDS_MAX rows) in HBM.  Their
-// bodies are instantiated once per case, so that every access to w is a plain LDS or a plain global instruction: a
-// pointer that may be either compiles to FLAT accesses, which queue up behind the streaming loads of the other
-// wavefronts -- measured 2 us per in-block solve of wavefront 0 instead of 1.2.
-__device__ __forceinline__ void fw_level_body(const double *F, const FrontTab &tab, int s, double *wvec, double *y, double *w, bool copy_up,
-                                              double *wb, double *Sd, const double *src, const int *perm) {
-  const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
-  double *wg = wvec + tab.woff[s];
-  const int tid = threadIdx.x, bs = blockDim.x;
-  // src != null: the right-hand side is gathered through perm on the way in (fwblkslv.c:298-303) instead of by a
-  // separate launch
-  for (int i = tid; i < ms; i += bs) w[i] = i < ns ? (src ? src[perm[first + i]] : y[first + i]) : 0.0;
-  __syncthreads();
-  for (int ci = tab.childptr[s]; ci < tab.childptr[s + 1]; ci++) {   // children's update vectors, fixed order
-    const int c = tab.childlist[ci];
-    const int nc = tab.ns[c], mu = tab.ms[c] - nc;
-    const int *rel = tab.relidx + tab.roff[c];
-    const double *wc = wvec + tab.woff[c] + nc;
-    for (int i = tid; i < mu; i += bs) w[rel[i]] += wc[i];
-    __syncthreads();
-  }
-  front_fw(F + tab.foff[s], ns, ms, tab.ld[s], w, wb, Sd);
-  for (int i = tid; i < ns; i += bs) y[first + i] = w[i];
-  if (copy_up) for (int i = ns + tid; i < ms; i += bs) wg[i] = w[i];      // update vector for the parent
-}
-__global__ void __launch_bounds__(SOLVE_THREADS)
-k_fw_level(const double *F, FrontTab tab, const int *list, double *wvec, double *y, int use_lds, const double *src, const int *perm) {
-  SDM_DYN_SMEM(smem);
-  __shared__ double wb[3 * SNB];
-  double *Sd = (double *)smem;                                    // staged diagonal / sub-diagonal blocks
-  const int s = list[blockIdx.x];
-  // use_lds = offset of w behind the staged blocks, 0 = w in HBM
-  if (use_lds) fw_level_body(F, tab, s, wvec, y, (double *)smem + use_lds, true, wb, Sd, src, perm);
-  else fw_level_body(F, tab, s, wvec, y, wvec + tab.woff[s], false, wb, Sd, src, perm);
-}
-
-__device__ __forceinline__ void bw_level_body(const double *F, const double *DT, const FrontTab &tab, int s, double *y, double *w,
-                                              double *dots, double *Sd, const double *dscale, double *yout, const int *perm) {
-  const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
-  const int *rows = tab.lindx + tab.xl[s];
-  const int tid = threadIdx.x, bs = blockDim.x;
-  // rows below the supernode belong to ancestors, already final (bwblkslv.c:104-105 gathers them once); dscale != null:
-  // the ./d between the sweeps (wrapPcg.m:57) is applied to the supernode's own entries on the way in
-  for (int i = tid; i < ms; i += bs) w[i] = i < ns ? (dscale ? y[first + i] / dscale[first + i] : y[first + i]) : y[rows[i]];
-  __syncthreads();
-  front_bw(F + tab.foff[s], DT + tab.toff[s], ns, ms, tab.ld[s], w, dots, Sd);
-  for (int i = tid; i < ns; i += bs) {
-    y[first + i] = w[i];                                           // descendants read it from here
-    if (yout) yout[perm[first + i]] = w[i];                        // y(perm) = ... (bwblkslv.c:272-278) without a scatter launch
-  }
-}
-__global__ void __launch_bounds__(SOLVE_THREADS)
-k_bw_level(const double *F, const double *DT, FrontTab tab, const int *list, double *wvec, double *y, int use_lds,
-           const double *dscale, double *yout, const int *perm) {
-  SDM_DYN_SMEM(smem);
-  __shared__ double dots[3 * SNB];
-  double *Sd = (double *)smem;                                    // staged diagonal / sub-diagonal blocks
-  const int s = list[blockIdx.x];
-  if (use_lds) bw_level_body(F, DT, tab, s, y, (double *)smem + use_lds, dots, Sd, dscale, yout, perm);
-  else bw_level_body(F, DT, tab, s, y, wvec + tab.woff[s], dots, Sd, dscale, yout, perm);
-}
-
-// The whole  y(perm) = L' \ ((L \ rhs(perm)) ./ d)  of wrapPcg.m:56-59 in ONE launch when the factor is a single
-// front (the dense shortcut of symbchol.m:75-77 -- every shipped example): gather, forward sweep, diagonal
-// scaling, backward sweep and scatter without leaving the CU.
-__device__ __forceinline__ void ldl_single_body(const double *F, const double *DT, int m, const int *perm, const double *dsolve,
-                                                const double *rhs, double *yout, double *w, int mode, double *wb, double *Sd) {
-  const int tid = threadIdx.x, bs = blockDim.x;
-  // mode bits: 1 forward sweep, 2 divide by d, 4 backward sweep; rhs is permuted on the way in iff forward,
-  // the result on the way out iff backward (fwblkslv.c:298-303, bwblkslv.c:272-278)
-  for (int i = tid; i < m; i += bs) w[i] = (mode & 1) ? rhs[perm[i]] : rhs[i];
-  __syncthreads();
-  if (mode & 1) front_fw(F, m, m, m + (m & 1), w, wb, Sd);
-  if (mode & 2) { for (int i = tid; i < m; i += bs) w[i] /= dsolve[i]; __syncthreads(); }
-  if (mode & 4) front_bw(F, DT, m, m, m + (m & 1), w, wb, Sd);
-  for (int i = tid; i < m; i += bs) { if (mode & 4) yout[perm[i]] = w[i]; else yout[i] = w[i]; }
-}
-__global__ void __launch_bounds__(SOLVE_THREADS)
-k_ldl_single(const double *F, const double *DT, int m, const int *perm, const double *dsolve, const double *rhs,
-             double *yout, double *wglob, int use_lds, int mode) {
-  SDM_DYN_SMEM(smem);
-  __shared__ double wb[3 * SNB];
-  double *Sd = (double *)smem;                                    // staged diagonal / sub-diagonal blocks
-  if (use_lds) ldl_single_body(F, DT, m, perm, dsolve, rhs, yout, (double *)smem + use_lds, mode, wb, Sd);
-  else ldl_single_body(F, DT, m, perm, dsolve, rhs, yout, wglob, mode, wb, Sd);
-}
-
-// ---- big single fronts (m >= BIG_FRONT): one CU cannot stream the factor fast enough (~100 GB/s) and a launch per
-// 64-column panel is launch bound (>= 4 us per dependent launch here), so the sweeps are cut into SUPER-panels of
-// BIGW = 256 columns, one launch each; the launches of a sweep are stream-ordered, there is no inter-workgroup
-// synchronisation inside a launch.
-// Forward launch P (P = -1 .. nsb-2): x_P (super-block P of the solution) is final.  Workgroup b owns 256 rows:
-// b = 0 the rows of super-block P+1, b >= 1 the rows (P+2)*BIGW + (b-1)*256 ...  It applies the 256 columns of
-// super-panel P to its rows (four 64-column panels through the same streaming code as front_fw); workgroup 0 then
-// solves the diagonal super-block P+1 with front_fw on that sub-front, so that x_{P+1} is final for the next launch.
-__global__ void __launch_bounds__(SOLVE_THREADS)
-k_big_fw(const double *Fs, int m, int ld, int P, double *w) {
-  SDM_DYN_SMEM(smem);
-  __shared__ double wl[BIGW], xb[BIGW], wb[3 * SNB];
-  double *Sd = (double *)smem;                                    // staged blocks (workgroup 0)
-  const int tid = threadIdx.x, bs = blockDim.x;
-  const int rbeg = (P + 1) * BIGW + (blockIdx.x == 0 ? 0 : BIGW + ((int)blockIdx.x - 1) * 256);
-  const int rend = min(m, rbeg + 256);
-  for (int i = tid; i < 256; i += bs) wl[i] = rbeg + i < rend ? w[rbeg + i] : 0.0;
-  if (P >= 0)
-    for (int i = tid; i < BIGW; i += bs) xb[i] = w[P * BIGW + i];
-  __syncthreads();
-  if (P >= 0) {
-    const int g = (tid >> 4) & 3, t0 = (tid >> 6) * 16 + (tid & 15), tstep = bs >> 2;
-    const int npair = (rend - rbeg) >> 1, lim = (npair + 15) & ~15;
-    double *wadj = wl - rbeg;                                    // fw_consume indexes by front row
-    for (int sub = 0; sub < BIGW / SNB; sub++) {
-      const int k0 = P * BIGW + sub * SNB;
-      for (int t = t0; t < lim; t += tstep) {
-        sdm_double2 v[16];
-        fw_issue(v, Fs, ld, k0, rbeg, npair, t, g);
-        fw_consume(v, xb + sub * SNB, wadj, rbeg, npair, t, g);
-      }
-      if (tid == bs - 1 && ((rend - rbeg) & 1)) {                // unpaired last row of the front
-        const int r = rend - 1;
-        double acc = 0.0;
-        for (int c = 0; c < SNB; c++) acc += Fs[(int64_t)(k0 + c) * ld + r] * xb[sub * SNB + c];
-        wl[r - rbeg] -= acc;
-      }
-      __syncthreads();
-    }
-  }
-  if (blockIdx.x == 0) {
-    const int ns = rend - rbeg;                                  // diagonal super-block P+1 as a front of its own
-    front_fw(Fs + (int64_t)rbeg * ld + rbeg, ns, ns, ld, wl, wb, Sd);
-  }
-  for (int i = tid; i < rend - rbeg; i += bs) w[rbeg + i] = wl[i];
-}
-// Backward launch P (P = nsb .. 1): x_P final.  Workgroup b owns the 256 columns of super-block q = P-1-b: it
-// applies the rows of super-block P, y_q -= L(P,q)' x_P, and workgroup 0 then solves the transposed diagonal
-// super-block P-1 with front_bw.  Launch nsb only solves the last super-block.
-__global__ void __launch_bounds__(SOLVE_THREADS)
-k_big_bw(const double *Fs, const double *DT, int m, int ld, int P, int nsb, double *w) {
-  SDM_DYN_SMEM(smem);
-  __shared__ double yl[BIGW], xb[BIGW], dots[BIGW];
-  double *Sd = (double *)smem;                                    // staged blocks (workgroup 0)
-  const int tid = threadIdx.x, bs = blockDim.x;
-  const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
-  const int q = P - 1 - (int)blockIdx.x, cbeg = q * BIGW, ncol = min(BIGW, m - cbeg);
-  for (int i = tid; i < BIGW; i += bs) yl[i] = i < ncol ? w[cbeg + i] : 0.0;
-  if (P < nsb) {
-    const int pbeg = P * BIGW, np_ = min(BIGW, m - pbeg);
-    for (int i = tid; i < BIGW; i += bs) xb[i] = i < np_ ? w[pbeg + i] : 0.0;
-    __syncthreads();
-    const int npair = np_ >> 1;
-    const double *xadj = xb - pbeg;                              // bw_consume indexes by front row
-    for (int cb0 = wave * 4; cb0 < ncol; cb0 += nw * 4) {
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int tb = lane; tb < npair; tb += 256) {
-        sdm_double2 v[16];
-        bw_issue(v, Fs, ld, cbeg, ncol, cb0, pbeg, npair, tb);
-        bw_consume(v, acc, xadj, pbeg, npair, tb);
-      }
-      if (lane == 0 && (np_ & 1))
-#pragma unroll
-        for (int u = 0; u < 4; u++) acc[u] += Fs[(int64_t)(cbeg + min(cb0 + u, ncol - 1)) * ld + pbeg + np_ - 1] * xb[np_ - 1];
-      {
-        const bool hi = lane >= 32;
-        const double s0 = hi ? acc[0] : acc[2], s1 = hi ? acc[1] : acc[3];
-        double k0v = (hi ? acc[2] : acc[0]) + __shfl_xor(s0, 32);
-        double k1v = (hi ? acc[3] : acc[1]) + __shfl_xor(s1, 32);
-        const bool od = (lane >> 4) & 1;
-        double a = (od ? k1v : k0v) + __shfl_xor(od ? k0v : k1v, 16);
-        a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
-        const int u = (hi ? 2 : 0) + (od ? 1 : 0);
-        if ((lane & 15) == 0 && cb0 + u < ncol) dots[cb0 + u] = a;
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < ncol; i += bs) yl[i] -= dots[i];
-  }
-  __syncthreads();
-  if (blockIdx.x == 0)
-    front_bw(Fs + (int64_t)cbeg * ld + cbeg, DT + (int64_t)(cbeg / SNB) * SNB * SNB, ncol, ncol, ld, yl, dots, Sd);
-  __syncthreads();
-  for (int i = tid; i < ncol; i += bs) w[cbeg + i] = yl[i];
-}
-
+// The triangular solves live in sdm_solve.hip (explicit inverses of the diagonal super-blocks, one GEMV launch per
+// super-block column).  Only the small vector helpers they share with the factor remain here.
 __global__ void k_gather_perm(double *dst, const double *src, const int *perm, int m, int forward) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < m) { if (forward) dst[k] = src[perm[k]]; else dst[perm[k]] = src[k]; }
@@ -1824,8 +1021,9 @@ __global__ void k_dsolve(double *ds, const double *d, int m) {
 }
 
 // ============================================================ host drivers
-static FrontTab front_tab(CholPlan &C) {
+FrontTab front_tab(CholPlan &C) {
   FrontTab t;
+  t.soff = C.d_soff.p; t.sld = C.d_sld.p; t.sboff = C.d_sboff.p;
   t.first = C.d_first.p; t.ns = C.d_ns.p; t.ms = C.d_ms.p; t.ld = C.d_ld.p;
   t.foff = C.d_foff.p; t.xl = C.d_xl.p; t.woff = C.d_woff.p; t.roff = C.d_roff.p; t.toff = C.d_toff.p;
   t.childptr = C.d_childptr.p; t.childlist = C.d_childlist.p; t.lindx = C.d_lindx.p; t.relidx = C.d_relidx.p;
@@ -1872,6 +1070,7 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
     }
   }
   SDM_KLAUNCH(P, k_dsolve, dim3((m + 255) / 256), dim3(256), 0, C.dsolve.p, C.d.p, m);
+  solve_prepare(P);                                                  // inverses of the diagonal super-blocks for the solves
   SDM_HIP_CHECK(hipGetLastError());
   P->factored = true;
 }
@@ -1897,89 +1096,15 @@ void chol_load_factor(sdm_plan *P, const double *h_Lpr) {
   CholPlan &C = P->chol;
   DevBuf<double> tmp;
   tmp.upload(h_Lpr, (size_t)C.nnzL);
+  SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), P->stream));    // padding rows / Schur parts: defined
+  SDM_HIP_CHECK(hipMemsetAsync(C.frontsT.p, 0, (size_t)C.tsize * sizeof(double), P->stream));
   SDM_KLAUNCH(P, k_load_factor, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, C.frontsT.p, tmp.p, C.d_asm_dst.p,
               C.d_asm_dstT.p, (int64_t)C.nnzL);
+  solve_prepare(P);
   SDM_HIP_CHECK(hipStreamSynchronize(P->stream));
   P->factored = true;
 }
 
-// dynamic LDS of the sweep kernels: two staged diagonal blocks, then the front-local vector when the largest front
-// of the plan fits (SOLVE_LDS_MAX doubles), else that vector stays in HBM
-constexpr size_t SOLVE_LDS_BLOCKS = (size_t)SOLVE_STAGE_DOUBLES * sizeof(double);
-// use = 0: the front-local vector stays in HBM; else its offset (doubles) behind the staged blocks -- plans without a
-// front on the look-ahead schedule only ever stage one diagonal block
-static void solve_cfg(CholPlan &C, size_t &bytes, int &use) {
-  const int stage = C.maxms >= PIPE_MIN_ROWS ? SOLVE_STAGE_DOUBLES : SNB * SNB;
-  use = C.maxms <= SOLVE_LDS_MAX ? stage : 0;
-  bytes = (size_t)(stage + (use ? C.maxms : 0)) * sizeof(double);
-}
-static int level_threads(const CholPlan &C, int l) {
-  int mx = 0;
-  for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) mx = std::max(mx, C.sn_ms[C.levlist[i]]);
-  if (mx >= PIPE_MIN_ROWS) return SOLVE_THREADS;              // full workgroup: look-ahead schedule (front_fw_pipe / front_bw_pipe)
-  return std::min(SOLVE_THREADS - 64, std::max(64, (mx + 63) / 64 * 64));
-}
-void solve_fw(sdm_plan *P, const double *src) {
-  CholPlan &C = P->chol;
-  FrontTab tab = front_tab(C);
-  size_t lds; int use; solve_cfg(C, lds, use);
-#ifndef SDM_EMU
-  if (lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_fw_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-#endif
-  for (int l = 0; l < C.nlevels; l++) {
-    const int nfr = C.levptr[l + 1] - C.levptr[l];
-    SDM_KLAUNCH(P, k_fw_level, dim3(nfr), dim3(level_threads(C, l)), lds, C.fronts.p, tab, C.d_levlist.p + C.levptr[l], C.wvec.p,
-                P->ywork.p, use, src, C.d_perm.p);
-  }
-}
-void solve_bw(sdm_plan *P, bool divide, double *yout) {
-  CholPlan &C = P->chol;
-  FrontTab tab = front_tab(C);
-  size_t lds; int use; solve_cfg(C, lds, use);
-#ifndef SDM_EMU
-  if (lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_bw_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-#endif
-  for (int l = C.nlevels - 1; l >= 0; l--) {
-    const int nfr = C.levptr[l + 1] - C.levptr[l];
-    SDM_KLAUNCH(P, k_bw_level, dim3(nfr), dim3(level_threads(C, l)), lds, C.fronts.p, C.frontsT.p, tab, C.d_levlist.p + C.levptr[l],
-                C.wvec.p, P->ywork.p, use, divide ? (const double *)C.dsolve.p : (const double *)nullptr, yout, C.d_perm.p);
-  }
-}
-// single-front factor: the complete solve (mode bits 1 fw | 2 ./d | 4 bw) in one launch, rhs -> yout
-bool solve_single(sdm_plan *P, const double *rhs, double *yout, int mode) {
-  CholPlan &C = P->chol;
-  if (C.nsuper != 1) return false;
-  if (C.m >= BIG_FRONT) {
-    // big front: one launch per 256-column super-panel and sweep (k_big_fw / k_big_bw), w = ywork in HBM
-    const int m = (int)C.m, ld = C.sn_ld[0], nsb = (m + BIGW - 1) / BIGW;
-#ifndef SDM_EMU
-    SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_big_fw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS_BLOCKS));
-    SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_big_bw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS_BLOCKS));
-#endif
-    if (mode & 1) vec_gather(P, P->ywork.p, rhs, true);
-    else SDM_HIP_CHECK(hipMemcpyAsync(P->ywork.p, rhs, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, P->stream));
-    if (mode & 1)
-      for (int p = -1; p <= nsb - 2; p++) {
-        const int below = m - (p + 2) * BIGW;                     // rows beyond super-block p+1
-        SDM_KLAUNCH(P, k_big_fw, dim3(p < 0 ? 1 : 1 + std::max(0, (below + 255) / 256)), dim3(SOLVE_THREADS), SOLVE_LDS_BLOCKS, C.fronts.p, m, ld,
-                    p, P->ywork.p);
-      }
-    if (mode & 2) vec_divd(P, P->ywork.p);
-    if (mode & 4)
-      for (int p = nsb; p >= 1; p--)
-        SDM_KLAUNCH(P, k_big_bw, dim3(p == nsb ? 1 : p), dim3(SOLVE_THREADS), SOLVE_LDS_BLOCKS, C.fronts.p, C.frontsT.p, m, ld, p, nsb, P->ywork.p);
-    if (mode & 4) vec_gather(P, yout, P->ywork.p, false);
-    else SDM_HIP_CHECK(hipMemcpyAsync(yout, P->ywork.p, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, P->stream));
-    return true;
-  }
-  size_t lds; int use; solve_cfg(C, lds, use);
-#ifndef SDM_EMU
-  if (lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-#endif
-  SDM_KLAUNCH(P, k_ldl_single, dim3(1), dim3(level_threads(C, 0)), lds, C.fronts.p, C.frontsT.p, (int)C.m, C.d_perm.p, C.dsolve.p,
-              rhs, yout, C.wvec.p, use, mode);
-  return true;
-}
 void vec_gather(sdm_plan *P, double *dst, const double *src, bool forward) {
   const int m = (int)P->chol.m;
   SDM_KLAUNCH(P, k_gather_perm, dim3((m + 255) / 256), dim3(256), 0, dst, src, P->chol.d_perm.p, m, forward ? 1 : 0);

@@ -8,7 +8,6 @@ namespace sdm {
 
 constexpr int NB = 64;     // factor panel width (columns)
 constexpr int TILE = 64;   // trailing-update tile (MFMA 4 waves x 32x32)
-constexpr int SNB = 64;    // solve panel width: one wavefront does the in-block TRSV, one lane per row
 constexpr int S1_MAXN = 96;   // PSD blocks up to this order take the matrix-core stage 1 of ADA'
 constexpr int S1_KC = 48;     // slots (nonzero columns of A_jk) per GEMM chunk
 constexpr int S1_WAVES = 8;   // wavefronts per task
@@ -16,12 +15,10 @@ constexpr int S1_NZ = 1536;   // nonzeros of a chunk of slots staged in LDS (big
 constexpr int S1_MAXT = ((S1_MAXN / 16) * (S1_MAXN / 16) + S1_WAVES - 1) / S1_WAVES;   // 16x16 tiles of Z per wavefront
 constexpr int S1_GEN_LDS = 24 * 1024;   // LDS target per task of the generic stage-1 kernel (bytes)
 constexpr int ELL_WAVES = 8;  // wavefronts per workgroup of the ELL stage-2 kernel of ADA'
-constexpr int SOLVE_LDS_MAX = 3072;   // doubles of the front-local vector kept in LDS (24 KB, next to 129 KB of staged blocks)
-constexpr int BIG_FRONT = 1024;       // single fronts from this order on: one launch per super-panel and sweep instead of one workgroup
-constexpr int BIGW = 256;             // width of a super-panel of the big-front sweeps (a multiple of SNB)
+constexpr int SOLVE_LDS_MAX = 3072;   // doubles of a product-form right-hand side kept in LDS (k_pr1_solve)
 constexpr int FUSE_MAX_TILES = 1 << 20; // trailing updates of at most this many tiles ride along with the next diagonal-block launch (in effect: all)
-constexpr int PIPE_MIN_ROWS = 96;      // fronts with at least this many rows run the sweeps on the look-ahead schedule
-constexpr int SOLVE_THREADS = 1024;   // workgroup of the per-front solve kernels (16 waves stream the panel)
+constexpr int SBW = 256;              // super-block width of the solves (columns whose diagonal block is applied as ONE explicit inverse)
+constexpr int SROWS = 16;             // rows (forward) / columns (backward) of a front handled by one workgroup of the solve kernels
 constexpr int SW = 8;                 // columns of the diagonal block swept in registers at a time (readlane chain), rest via LDS
 constexpr int LDL_THREADS = 512;      // workgroup of the diagonal-block kernel: wavefront 0 sweeps, the other 7 apply the previous sweep
 constexpr int PANEL_THREADS = 256;    // workgroup of the row-solve kernel: 4 wavefronts, one per SIMD (the solve is issue bound)
@@ -33,7 +30,6 @@ constexpr int PANEL_RB = (LDL_THREADS / 64) * NB * 17;     // doubles: max(Lc 64
 constexpr size_t PANEL_LDS = (size_t)(NB * (NB + 1) + PANEL_RB) * sizeof(double);
 constexpr size_t PANEL_LDS_RIDE = std::max(PANEL_LDS, (size_t)4 * NB * TILE * sizeof(double));   // two update tiles side by side
 static_assert(PANEL_RB >= NB * NB && PANEL_RB >= (NB - CHK) * TRSM_ROWS && TRSM_ROWS == 16 * (LDL_THREADS / 64) && ROWS_BATCH <= TRSM_ROWS, "panel LDS layout");
-static_assert(NB == SNB, "the transposed diagonal blocks written by the factor are read by the solves");
 
 template <class T>
 struct DevBuf {
@@ -114,6 +110,15 @@ struct LevelLaunch {
   int ride_wgs;         // workgroups of k_ldl_panel beyond workgroup 0 (row solves + pairs of update tiles), max over fronts
 };
 
+// one etree level of the solves (sdm_solve.hip)
+struct SolveLevel {
+  int nfronts = 0, maxns = 0, maxms = 0, nsb = 0;   // nsb = super-blocks of the widest front
+  bool children = false;                             // some front of the level has children (assembly launch needed)
+  bool below = false;                                // some front has rows below its own columns
+  std::vector<int> nact_fw, nact_bw;                 // fronts (prefix of the level list, sorted by ns desc) active in step P / Q
+  std::vector<int> maxslab_fw, maxslab_bw;           // grid.x of the step launches
+};
+
 struct CholPlan {
   sdm_int m = 0, nsuper = 0, nnzL = 0, nnzADA = 0;
   int nlevels = 0;
@@ -134,6 +139,27 @@ struct CholPlan {
   DevBuf<int> diag_cnt;    // per front: panels whose factored diagonal block has been published (k_ldl_panel)
   DevBuf<int> upd_cnt;     // per front: finished tile workgroups of the updates that rode along with k_ldl_panel
   HostFlag tmo;            // raised by a spin inside a panel launch of THIS plan that gave up (chol_wait_timeouts)
+  // ---- solves (sdm_solve.hip): per front the ns x ns "S" array = explicit inverses of the SBW-wide diagonal
+  // super-blocks and the block rows left of them premultiplied by those inverses
+  int64_t ssize = 0; int nsbtot = 0;
+  std::vector<int64_t> sn_soff; std::vector<int> sn_sld, sn_sboff;
+  DevBuf<int64_t> d_soff; DevBuf<int> d_sld, d_sboff;
+  DevBuf<double> S, xfin, ttmp;
+  DevBuf<unsigned long long> sb_g;   // per super-block: bit patterns of max|inverse| and max|L block| (growth check)
+  DevBuf<int> sb_cnt;                // per super-block: arrival tickets of the (rare) substitution fallback
+  DevBuf<int> l_i128, l_t3, l_pm;    // work lists of the inversion / premultiplication launches (4 ints per item)
+  int n_i128 = 0, n_t3 = 0, n_pm = 0;
+  std::vector<SolveLevel> slev;
+  double growth_max = 1e4;           // a super-block whose max|inv| * max|L| exceeds this is solved by substitution
+  double growth_used = 1e4;          // the bound in force at the last solve_prepare
+};
+
+// device view of the front tables
+struct FrontTab {
+  const int *first, *ns, *ms, *ld;
+  const int64_t *foff, *xl, *woff, *roff, *toff;
+  const int *childptr, *childlist, *lindx, *relidx;
+  const int64_t *soff; const int *sld, *sboff;
 };
 
 // ----------------------------------------------------------------- ada plan
@@ -238,11 +264,14 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
 int chol_wait_timeouts(sdm_plan *P);   // non-zero: a spin inside a panel launch of this plan gave up since the last call (call after a stream sync)
 void chol_extract(sdm_plan *P, double *d_Lpr_out);           // device pointer, nnzL doubles
 void chol_load_factor(sdm_plan *P, const double *h_Lpr);     // host L values -> fronts (for stand-alone solves)
-void solve_fw(sdm_plan *P, const double *src = nullptr);   // src: unpermuted right-hand side gathered on the way in (else ywork holds it)
-void solve_bw(sdm_plan *P, bool divide = false, double *yout = nullptr);   // divide: ./d on the way in; yout: y(perm) scattered on the way out
-bool solve_single(sdm_plan *P, const double *rhs, double *yout, int mode);  // single-front plans: whole solve in one launch
 void vec_gather(sdm_plan *P, double *dst, const double *src, bool forward);  // dst[k]=src[perm[k]] / dst[perm[k]]=src[k]
 void vec_divd(sdm_plan *P, double *v);
+FrontTab front_tab(CholPlan &C);
+// sdm_solve.hip: inverse-block solves
+void solve_build(sdm_plan *P);                      // host tables + buffers (end of chol_build)
+void solve_prepare(sdm_plan *P);                    // after a factorisation: diagonal super-block inverses, premultiplied block rows
+void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode);   // mode bits 1 fw | 2 ./d | 4 bw
+void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growth);
 // sdm_ada.hip
 void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_int *Air, const double *Apr,
                const sdm_int *Ajc_psd, sdm_int lpN, sdm_int lorN, const sdm_int *lorNL, sdm_int sdpN,

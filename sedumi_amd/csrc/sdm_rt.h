@@ -25,6 +25,7 @@ inline void sdm_store_wt(double *p, double v) { *p = v; }
 #define SDM_STORES_DONE() do {} while (0)
 inline int sdm_signal_load(const int *p) { return *p; }
 inline void sdm_raise_flag(int *p) { *p = 1; }
+#define SDM_UNIFORM_INT(x) (x)
 #define SDM_ACQUIRE_FENCE() do {} while (0)
 #define SDM_SPIN_PAUSE() do { fprintf(stderr, "hipemu: waiting on a workgroup that has not run\n"); abort(); } while (0)
 #else
@@ -53,6 +54,9 @@ __device__ __forceinline__ int sdm_signal_load(const int *p) { return __hip_atom
 // error flag in pinned host memory (HostFlag): one system-scope store, read by the host after a stream synchronise
 __device__ __forceinline__ void sdm_raise_flag(int *p) { __hip_atomic_store(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 #define SDM_ACQUIRE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+// a wave-uniform integer the compiler cannot prove uniform (e.g. threadIdx.x >> 6): moved to a scalar register, so that
+// addresses built from it stay scalar and loads through them become s_load
+#define SDM_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane(x)
 #define SDM_SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
 // predicate of lane `lane` (uniform), delivered to every lane: one compare into a lane mask, one scalar bit test
 __device__ __forceinline__ bool sdm_lane_pred(bool pred, int lane) { return (__ballot(pred) >> lane) & 1ull; }

@@ -1,0 +1,827 @@
+// sdm_solve.hip -- triangular solves  y = L \ b(perm),  y(perm) = L' \ b  (fwblkslv.c:77-134, bwblkslv.c:73-125)
+// for gfx950, built around EXPLICIT INVERSES of the diagonal super-blocks.
+//
+// The reference substitutes column by column -- a chain of m dependent steps.  A single right-hand side leaves a
+// GPU nothing to batch over (the four solves of an IPM iteration depend on each other, wrapPcg.m:56-59), so the chain
+// itself has to go.  After every factorisation (solve_prepare) each front gets a second array S (ns x ns):
+//   * the diagonal super-blocks of SBW = 256 columns are inverted explicitly:  S_PP = inv(L_PP)  (unit lower
+//     triangular; 64x64 blocks by substitution in registers, then two levels of  X21 = -inv(C) B inv(A)  on the FP64
+//     matrix cores),
+//   * the block rows left of them are premultiplied:  S_PQ = inv(L_PP) L_PQ  (FP64 matrix cores),
+// i.e. L = D~ L~ with D~ = blockdiag(L_PP) and L~ = S with identity diagonal super-blocks.  Then
+//   forward   y_P = inv(L_PP) b_P - sum_{Q<P} S_PQ y_Q          : one GEMV launch for all inv(L_PP) b_P, then one GEMV
+//                                                                  launch per super-block column P ("step"),
+//   backward  v_P = z_P - sum_{Q>P} S_QP' v_Q ,  x_P = inv(L_PP)' v_P : the mirror image,
+// every launch a plain HBM-streaming matrix-vector product over MANY workgroups (16 rows or columns each) with no
+// dependency inside it: m/256 dependent steps per sweep instead of m.  Rows below a supernode's own columns (they
+// belong to its ancestors) are never premultiplied and are read from the factor itself.
+//
+// Never-fail pivoting admits multipliers up to maxu = 5e5 (blkchol2.c:114-161), so an explicit inverse can be
+// ill-conditioned.  The growth of every super-block is therefore measured when it is inverted
+// (max|inv(L_PP)| * max|L_PP|); a block beyond CholPlan::growth_max keeps its rows unpremultiplied and is solved by
+// substitution by the workgroup that completes its right-hand side (an arrival ticket among the workgroups that
+// update it) -- per block, decided on the device, no host round trip.  Everything is deterministic (fixed summation
+// orders, no atomics on data).
+#include "sdm_plan.h"
+#include <algorithm>
+
+namespace sdm {
+
+constexpr int ST = 256;          // work-items per workgroup of every kernel in this file
+constexpr int TP = 65;           // LDS pitch of staged 64-wide operand blocks (conflict-free transposing stores)
+constexpr size_t INV_LDS = (size_t)4 * 64 * TP * sizeof(double);      // k_sinv128: four staged 64x64 blocks
+constexpr size_t TILE_LDS = (size_t)2 * 64 * TP * sizeof(double);     // k_stile: one A and one B operand block
+
+// ---------------------------------------------------------------- host tables
+void solve_build(sdm_plan *P) {
+  CholPlan &C = P->chol;
+  const int nsuper = (int)C.nsuper;
+  C.sn_soff.assign(nsuper, 0); C.sn_sld.assign(nsuper, 0); C.sn_sboff.assign(nsuper, 0);
+  std::vector<int> i128, t3, pm;
+  int64_t soff = 0; int sb = 0, tslots = 0;
+  for (int s = 0; s < nsuper; s++) {
+    const int ns = C.sn_ns[s], sld = ns + (ns & 1);
+    C.sn_soff[s] = soff; C.sn_sld[s] = sld; C.sn_sboff[s] = sb;
+    soff += (int64_t)sld * ns;
+    const int nsb = (ns + SBW - 1) / SBW;
+    for (int h = 0; 128 * h < ns; h++) { i128.push_back(s); i128.push_back(h); i128.push_back(0); i128.push_back(0); }
+    for (int Pb = 0; Pb < nsb; Pb++) {
+      const int k0 = Pb * SBW, nb = std::min(SBW, ns - k0);
+      if (nb > 128) {                                              // level 3:  X = -inv(C2) B2 inv(A2), via T = B2 inv(A2)
+        const int nc = nb - 128;
+        for (int I = 0; 64 * I < nc; I++)
+          for (int J = 0; J < 2; J++) { t3.push_back(s); t3.push_back(Pb); t3.push_back(2 * I + J); t3.push_back(tslots); }
+        tslots++;
+      }
+      if (Pb > 0)
+        for (int I = 0; 64 * I < nb; I++)
+          for (int J = 0; J < 4 * Pb; J++) { pm.push_back(s); pm.push_back(Pb); pm.push_back(I); pm.push_back(J); }
+    }
+    sb += nsb;
+  }
+  C.ssize = soff; C.nsbtot = sb;
+  C.n_i128 = (int)i128.size() / 4; C.n_t3 = (int)t3.size() / 4; C.n_pm = (int)pm.size() / 4;
+  C.l_i128.upload(i128); C.l_t3.upload(t3); C.l_pm.upload(pm);
+  C.d_soff.upload(C.sn_soff); C.d_sld.upload(C.sn_sld); C.d_sboff.upload(C.sn_sboff);
+  C.S.alloc((size_t)std::max<int64_t>(soff, 1));
+  SDM_HIP_CHECK(hipMemset(C.S.p, 0, (size_t)std::max<int64_t>(soff, 1) * sizeof(double)));   // upper triangles stay zero for good
+  C.xfin.alloc((size_t)std::max<sdm_int>(C.m, 1));
+  C.ttmp.alloc((size_t)std::max(tslots, 1) * 128 * 128);
+  C.sb_g.alloc((size_t)std::max(2 * sb, 2)); C.sb_cnt.alloc((size_t)std::max(sb, 1));
+  SDM_HIP_CHECK(hipMemset(C.sb_g.p, 0, (size_t)std::max(2 * sb, 2) * sizeof(unsigned long long)));
+  SDM_HIP_CHECK(hipMemset(C.sb_cnt.p, 0, (size_t)std::max(sb, 1) * sizeof(int)));
+  // levels
+  C.slev.assign(C.nlevels, SolveLevel());
+  for (int l = 0; l < C.nlevels; l++) {
+    SolveLevel &L = C.slev[l];
+    L.nfronts = C.levptr[l + 1] - C.levptr[l];
+    int nsteps = 0;
+    for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) {
+      const int s = C.levlist[i], ns = C.sn_ns[s], ms = C.sn_ms[s];
+      L.maxns = std::max(L.maxns, ns); L.maxms = std::max(L.maxms, ms);
+      if (C.childptr[s + 1] > C.childptr[s]) L.children = true;
+      if (ms > ns) L.below = true;
+      const int nsb = (ns + SBW - 1) / SBW;
+      nsteps = std::max(nsteps, nsb - 1 + (ms > ns ? 1 : 0));
+    }
+    L.nsb = (L.maxns + SBW - 1) / SBW;
+    L.maxslab_fw.assign(nsteps, 0);
+    for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) {
+      const int s = C.levlist[i], ns = C.sn_ns[s], ms = C.sn_ms[s];
+      for (int Pb = 0; Pb < nsteps && Pb * SBW < ns; Pb++) {
+        const int ra = (Pb + 1) * SBW;
+        const int slabsA = ns > ra ? (ns - ra + SROWS - 1) / SROWS : 0;
+        const int slabsB = ms > ns ? (ms - (ns & ~1) + SROWS - 1) / SROWS : 0;
+        L.maxslab_fw[Pb] = std::max(L.maxslab_fw[Pb], slabsA + slabsB);
+      }
+    }
+  }
+}
+
+// ================================================================ device helpers
+__device__ __forceinline__ double bits_to_double(unsigned long long u) { union { unsigned long long u; double d; } b; b.u = u; return b.d; }
+__device__ __forceinline__ unsigned long long double_to_bits(double d) { union { unsigned long long u; double d; } b; b.d = d; return b.u; }
+// growth check of super-block sb: max|inv| * max|L| within bounds (NaN counts as bad)
+__device__ __forceinline__ bool sb_is_bad(const unsigned long long *g, int sb, double thr) {
+  return !(bits_to_double(g[2 * sb]) * bits_to_double(g[2 * sb + 1]) <= thr);
+}
+// max over the wavefront, then one order-independent atomicMax on the bit pattern of a non-negative double
+__device__ __forceinline__ void wave_atomic_max(unsigned long long *dst, double v, int lane) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o); v = (t > v || t != t) ? t : v; }      // NaN wins
+  if (lane == 0 && v > 0.0) atomicMax(dst, double_to_bits(v));
+  if (lane == 0 && !(v == v)) atomicMax(dst, 0x7ff8000000000000ull);   // NaN: larger than every finite pattern
+}
+
+// ---- 64x64 (x K) product tiles on the FP64 matrix cores.  Workgroup of 256: wavefront w owns the 32x32 quadrant
+// (w & 1, w >> 1) = 2 x 2 tiles of v_mfma_f64_16x16x4_f64.  Operands staged in LDS as As[k*TP + row], Bs[k*TP + col].
+struct Acc22 { sdm_double4 t[2][2]; };
+__device__ __forceinline__ void acc_zero(Acc22 &a) {
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) a.t[i][j][r] = 0.0;
+}
+__device__ __forceinline__ void mma_block(Acc22 &acc, const double *As, const double *Bs, int wave, int lane) {
+  const int rb = 32 * (wave & 1) + (lane & 15), cb = 32 * (wave >> 1) + (lane & 15), kq = lane >> 4;
+#pragma unroll 4
+  for (int kk = 0; kk < 64; kk += 4) {
+    const double a0 = As[(kk + kq) * TP + rb], a1 = As[(kk + kq) * TP + rb + 16];
+    const double b0 = Bs[(kk + kq) * TP + cb], b1 = Bs[(kk + kq) * TP + cb + 16];
+    acc.t[0][0] = SDM_MFMA_F64_16x16x4(a0, b0, acc.t[0][0]);
+    acc.t[0][1] = SDM_MFMA_F64_16x16x4(a0, b1, acc.t[0][1]);
+    acc.t[1][0] = SDM_MFMA_F64_16x16x4(a1, b0, acc.t[1][0]);
+    acc.t[1][1] = SDM_MFMA_F64_16x16x4(a1, b1, acc.t[1][1]);
+  }
+}
+// accumulator -> LDS as Cs[row*TP + col] (the layout of a B operand whose k index is the row) scaled by sgn
+__device__ __forceinline__ void acc_to_lds_rowmajor(const Acc22 &acc, double *Cs, int wave, int lane, double sgn) {
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 32 * (wave & 1) + 16 * i + (lane >> 4) + 4 * r, col = 32 * (wave >> 1) + 16 * j + (lane & 15);
+        Cs[row * TP + col] = sgn * acc.t[i][j][r];
+      }
+}
+// Operand staging in two halves -- all global loads of a 64x64 block first (16 per work-item, addresses clamped,
+// unconditional), the LDS stores later -- so that one memory latency is paid per block, not one per element.
+// column-major operand: dst[k*TP + r] = src[k*ld + r] for r < nr, k < nk, zero elsewhere
+constexpr int SPT = 64 * 64 / ST;      // elements per work-item
+__device__ __forceinline__ void stage_colmajor_load(double (&v)[SPT], const double *src, int64_t ld, int nr, int nk, int tid) {
+  const int r = min(tid & 63, nr - 1), kq = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < SPT; j++) v[j] = src[(int64_t)min(kq + (ST / 64) * j, nk - 1) * ld + r];
+}
+__device__ __forceinline__ double stage_colmajor_store(double *dst, const double (&v)[SPT], int nr, int nk, int tid) {
+  const int r = tid & 63, kq = tid >> 6;
+  double mx = 0.0;
+#pragma unroll
+  for (int j = 0; j < SPT; j++) {
+    const int k = kq + (ST / 64) * j;
+    const double x = (r < nr && k < nk) ? v[j] : 0.0;
+    dst[k * TP + r] = x;
+    mx = fabs(x) > mx ? fabs(x) : mx;
+  }
+  return mx;
+}
+// the same transposed: dst[k*TP + c] = src[c*ld + k] for k < nk, c < nc, zero elsewhere
+__device__ __forceinline__ void stage_transposed_load(double (&v)[SPT], const double *src, int64_t ld, int nk, int nc, int tid) {
+  const int k = min(tid & 63, nk - 1), cq = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < SPT; j++) v[j] = src[(int64_t)min(cq + (ST / 64) * j, nc - 1) * ld + k];
+}
+__device__ __forceinline__ void stage_transposed_store(double *dst, const double (&v)[SPT], int nk, int nc, int tid) {
+  const int k = tid & 63, cq = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < SPT; j++) {
+    const int c = cq + (ST / 64) * j;
+    dst[k * TP + c] = (k < nk && c < nc) ? v[j] : 0.0;
+  }
+}
+// Cs[row*TP + col] (LDS) -> column-major destination, rows < nr, cols < nc; returns max |value| written
+__device__ __forceinline__ double store_tile(double *dst, int64_t ld, const double *Cs, int nr, int nc, int tid) {
+  const int r = tid & 63, cq = tid >> 6;
+  double mx = 0.0;
+#pragma unroll 4
+  for (int c = cq; c < 64; c += ST / 64)
+    if (r < nr && c < nc) { const double v = Cs[r * TP + c]; dst[(int64_t)c * ld + r] = v; mx = fabs(v) > mx ? fabs(v) : mx; }
+  return mx;
+}
+
+// ================================================================ inversion of the diagonal super-blocks
+// One workgroup per 128-column block h of a front, bottom-up, everything in LDS / registers:
+//   32x32  each of the four wavefronts inverts one 32x32 unit lower triangular diagonal block by rows (lane i owns
+//          row i of the block and of its inverse in registers; the finished row k reaches the other lanes through
+//          v_readlane -- no memory on the 496-step chain);
+//   64x64  X10 = -inv(A11) (A10 inv(A00)) for the two 64-column blocks A and C (plain FMAs from LDS, two wavefronts each);
+//   128    X21 = -inv(C) (B inv(A)) on the FP64 matrix cores, B = L(C rows, A columns) requested at the very start.
+// Results go to S; max|inv| and max|L| to sb_g (growth check).
+__global__ void __launch_bounds__(ST)
+k_sinv128(const double *__restrict__ F, double *__restrict__ S, FrontTab tab, const int *items, unsigned long long *sb_g) {
+  SDM_DYN_SMEM(smem);
+  double *bufA = (double *)smem, *bufC = bufA + 64 * TP, *bufB = bufC + 64 * TP, *bufT = bufB + 64 * TP;
+  const int s = items[4 * blockIdx.x], h = items[4 * blockIdx.x + 1];
+  const int ns = tab.ns[s], ld = tab.ld[s], sld = tab.sld[s];
+  const double *Fs = F + tab.foff[s];
+  double *Ss = S + tab.soff[s];
+  const int k0 = 128 * h, nbA = min(64, ns - k0), nbC = max(0, min(64, ns - k0 - 64));
+  unsigned long long *gP = sb_g + 2 * (tab.sboff[s] + k0 / SBW);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double vB[SPT];
+  if (nbC > 0) stage_colmajor_load(vB, Fs + (int64_t)k0 * ld + k0 + 64, ld, nbC, 64, tid);     // B(row, k) = L(k0+64+row, k0+k)
+  // raw strictly lower triangles, column-major: rawA[k*TP + i] = L(k0+i, k0+k) (bufT), rawC likewise (bufB); the
+  // destination buffers start as zero
+  double *rawA = bufT, *rawC = bufB;
+  double lmx = 0.0;
+  {
+    double va[SPT], vc[SPT];
+    const int i = tid & 63, kq = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < SPT; j++) {
+      const int k = kq + (ST / 64) * j;
+      va[j] = Fs[(int64_t)(k0 + min(k, nbA - 1)) * ld + k0 + min(i, nbA - 1)];
+      vc[j] = nbC > 0 ? Fs[(int64_t)(k0 + 64 + min(k, nbC - 1)) * ld + k0 + 64 + min(i, nbC - 1)] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < SPT; j++) {
+      const int k = kq + (ST / 64) * j;
+      const double a = (i > k && i < nbA) ? va[j] : 0.0, c = (i > k && i < nbC) ? vc[j] : 0.0;
+      rawA[k * TP + i] = a; rawC[k * TP + i] = c;
+      bufA[k * TP + i] = 0.0; bufC[k * TP + i] = 0.0;
+      lmx = fmax(lmx, fmax(fabs(a), fabs(c)));
+    }
+  }
+  __syncthreads();
+  const int blk = wave >> 1, q = wave & 1;                          // wavefront -> (64-block A / C, 32-block inside it)
+  const double *raw = blk == 0 ? rawA : rawC;
+  double *dst = blk == 0 ? bufA : bufC;
+  {
+    // ---- 32x32 by rows: x[j] = inv(i, j), l[k] = L(i, k) of lane i's row (zero for k >= i, and for the idle lanes)
+    const int i = lane & 31;
+    double l[32], x[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) { l[k] = lane < 32 ? raw[(32 * q + k) * TP + 32 * q + i] : 0.0; x[k] = (k == i && lane < 32) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int k = 0; k < 31; k++) {
+#pragma unroll
+      for (int j = 0; j <= k; j++) x[j] -= l[k] * sdm_bcast_lane(x[j], k);      // row k is final: lane k has l[k' >= k] = 0
+    }
+    double gm = 0.0;
+    if (lane < 32) {
+#pragma unroll
+      for (int j = 0; j < 32; j++) {
+        gm = fmax(gm, fabs(x[j]));
+        // inv(A) is kept as a B operand [k*TP + col] = inv(k, col); inv(C) as an A operand [k*TP + row] = inv(row, k)
+        if (blk == 0) dst[(32 * q + i) * TP + 32 * q + j] = x[j]; else dst[(32 * q + j) * TP + 32 * q + i] = x[j];
+      }
+    }
+    wave_atomic_max(gP, gm, lane);
+  }
+  __syncthreads();
+  {
+    // ---- 64x64: X10 = -inv11 (L10 inv00), two wavefronts per block, plain FMAs from LDS.  T1 goes to the unused
+    // upper right quadrant of the raw buffer (rows 32.., columns < 32 of raw[k*TP + i] hold zeros of the upper triangle)
+    const int t = tid & 127, c = t & 31, rq = t >> 5;
+    double *Ts = (blk == 0 ? rawA : rawC) + 32 * TP;                 // Ts[r*TP + c]
+    double acc[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) acc[jj] = 0.0;
+    for (int k = 0; k < 32; k++) {
+      const double inv00 = blk == 0 ? dst[k * TP + c] : dst[c * TP + k];            // inv00(k, c)
+#pragma unroll
+      for (int jj = 0; jj < 8; jj++) acc[jj] += raw[k * TP + 32 + rq + 4 * jj] * inv00;   // L10(r, k)
+    }
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) Ts[(rq + 4 * jj) * TP + c] = acc[jj];
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) acc[jj] = 0.0;
+    for (int k = 0; k < 32; k++) {
+      const double tk = Ts[k * TP + c];
+#pragma unroll
+      for (int jj = 0; jj < 8; jj++) {
+        const int r = rq + 4 * jj;
+        const double inv11 = blk == 0 ? dst[(32 + r) * TP + 32 + k] : dst[(32 + k) * TP + 32 + r];   // inv11(r, k)
+        acc[jj] += inv11 * tk;
+      }
+    }
+    double gm = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) {
+      const int r = rq + 4 * jj;
+      const double v = -acc[jj];
+      gm = fmax(gm, fabs(v));
+      if (blk == 0) dst[(32 + r) * TP + c] = v; else dst[c * TP + 32 + r] = v;
+    }
+    wave_atomic_max(gP, gm, lane);
+  }
+  __syncthreads();                                                  // bufA = inv(A) (B operand), bufC = inv(C) (A operand); raw buffers free
+  if (nbC > 0) lmx = fmax(lmx, stage_colmajor_store(bufB, vB, nbC, 64, tid));
+  wave_atomic_max(gP + 1, lmx, lane);
+  // inverses to S (lower triangles incl. the unit diagonal; the upper triangles of S are zero and stay zero)
+  for (int e = tid; e < 64 * 64; e += ST) {
+    const int i = e & 63, j = e >> 6;
+    if (i >= j && i < nbA) Ss[(int64_t)(k0 + j) * sld + k0 + i] = bufA[i * TP + j];
+    if (i >= j && i < nbC) Ss[(int64_t)(k0 + 64 + j) * sld + k0 + 64 + i] = bufC[j * TP + i];
+  }
+  if (nbC <= 0) return;
+  __syncthreads();
+  Acc22 acc;
+  acc_zero(acc);
+  mma_block(acc, bufB, bufA, wave, lane);                           // T = B inv(A)
+  acc_to_lds_rowmajor(acc, bufT, wave, lane, 1.0);                  // bufT[k*TP + col] = T(k, col): a B operand
+  __syncthreads();
+  acc_zero(acc);
+  mma_block(acc, bufC, bufT, wave, lane);                           // inv(C) T
+  __syncthreads();                                                  // bufB is free: stage the result for coalesced stores
+  acc_to_lds_rowmajor(acc, bufB, wave, lane, -1.0);
+  __syncthreads();
+  const double gm = store_tile(Ss + (int64_t)k0 * sld + k0 + 64, sld, bufB, nbC, 64, tid);
+  wave_atomic_max(gP, gm, lane);
+}
+
+// Generic product tile  C(64x64) = sgn * sum_k A(:,k) B(k,:)  for the remaining stages:
+//   mode 0  T(I,J)  = sum_{K>=J} B2(I,K) inv(A2)(K,J)          (level 3, first half; into the scratch ttmp)
+//   mode 1  X(I,J)  = - sum_{K<=I} inv(C2)(I,K) T(K,J)         (level 3, second half; into S)
+//   mode 2  S_PQ tile (I,J) = sum_{K<=I} inv(L_PP)(I,K) L(P rows K, columns J)     (premultiplication; into S)
+__global__ void __launch_bounds__(ST)
+k_stile(const double *F, double *S, double *ttmp, FrontTab tab, const int *items, unsigned long long *sb_g, int mode, double thr) {
+  SDM_DYN_SMEM(smem);
+  double *As = (double *)smem, *Bs = As + 64 * TP;
+  const int *it = items + 4 * blockIdx.x;
+  const int s = it[0], Pb = it[1];
+  const int ns = tab.ns[s], ld = tab.ld[s], sld = tab.sld[s];
+  const double *Fs = F + tab.foff[s];
+  double *Ss = S + tab.soff[s];
+  const int k0 = Pb * SBW, nb = min(SBW, ns - k0);
+  unsigned long long *gP = sb_g + 2 * (tab.sboff[s] + Pb);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const double *Ap, *Bp; double *Cp;
+  int64_t lda, ldb, ldc;
+  int arows, kvalid;
+  double sgn = 1.0;
+  bool track_l = false, track_g = false;
+  if (mode == 0) {
+    const int I = it[2] >> 1, J = it[2] & 1;
+    arows = min(64, nb - 128 - 64 * I); kvalid = 128 - 64 * J;
+    Ap = Fs + (int64_t)(k0 + 64 * J) * ld + k0 + 128 + 64 * I; lda = ld;
+    Bp = Ss + (int64_t)(k0 + 64 * J) * sld + k0 + 64 * J; ldb = sld;
+    Cp = ttmp + (int64_t)it[3] * 128 * 128 + (int64_t)(64 * J) * 128 + 64 * I; ldc = 128;
+    track_l = true;
+  } else if (mode == 1) {
+    const int I = it[2] >> 1, J = it[2] & 1;
+    arows = min(64, nb - 128 - 64 * I); kvalid = min(64 * (I + 1), nb - 128);
+    Ap = Ss + (int64_t)(k0 + 128) * sld + k0 + 128 + 64 * I; lda = sld;
+    Bp = ttmp + (int64_t)it[3] * 128 * 128 + (int64_t)(64 * J) * 128; ldb = 128;
+    Cp = Ss + (int64_t)(k0 + 64 * J) * sld + k0 + 128 + 64 * I; ldc = sld;
+    sgn = -1.0; track_g = true;
+  } else {
+    if (sb_is_bad(sb_g, tab.sboff[s] + Pb, thr)) return;            // this block row stays unpremultiplied
+    const int I = it[2], J = it[3];
+    arows = min(64, nb - 64 * I); kvalid = min(64 * (I + 1), nb);
+    Ap = Ss + (int64_t)k0 * sld + k0 + 64 * I; lda = sld;
+    Bp = Fs + (int64_t)(64 * J) * ld + k0; ldb = ld;
+    Cp = Ss + (int64_t)(64 * J) * sld + k0 + 64 * I; ldc = sld;
+  }
+  Acc22 acc;
+  acc_zero(acc);
+  double lmx = 0.0;
+  double va[SPT], vb[SPT];
+  stage_colmajor_load(va, Ap, lda, arows, kvalid, tid);
+  stage_transposed_load(vb, Bp, ldb, kvalid, 64, tid);
+  for (int kb = 0; kb < kvalid; kb += 64) {
+    lmx = fmax(lmx, stage_colmajor_store(As, va, arows, kvalid - kb, tid));
+    stage_transposed_store(Bs, vb, kvalid - kb, 64, tid);
+    __syncthreads();
+    if (kb + 64 < kvalid) {                                          // next K block: loads in flight during the products
+      stage_colmajor_load(va, Ap + (int64_t)(kb + 64) * lda, lda, arows, kvalid - kb - 64, tid);
+      stage_transposed_load(vb, Bp + kb + 64, ldb, kvalid - kb - 64, 64, tid);
+    }
+    mma_block(acc, As, Bs, wave, lane);
+    __syncthreads();
+  }
+  if (track_l) wave_atomic_max(gP + 1, lmx, lane);
+  acc_to_lds_rowmajor(acc, As, wave, lane, sgn);
+  __syncthreads();
+  const double gm = store_tile(Cp, ldc, As, arows, 64, tid);
+  if (track_g) wave_atomic_max(gP, gm, lane);
+}
+
+// ================================================================ substitution fallback for one super-block
+// Rare path (growth check failed): L_PP y = r  /  L_PP' x = v  in place on nb <= SBW entries at yp, by ONE workgroup.
+// Fs = front, (k0, k0) = position of the block.  Sd = 64*TP doubles, w = SBW doubles of LDS.
+__device__ __noinline__ void block_solve_fw(const double *Fs, int ld, int k0, int nb, double *yp, double *w, double *Sd) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < nb; i += ST) w[i] = yp[i];
+  __syncthreads();
+  for (int kk = 0; kk < nb; kk += 64) {
+    const int kb = min(64, nb - kk);
+    for (int e = tid; e < 64 * 64; e += ST) {
+      const int i = e & 63, c = e >> 6;
+      Sd[c * TP + i] = (i > c && i < kb) ? Fs[(int64_t)(k0 + kk + c) * ld + k0 + kk + i] : 0.0;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      double wi = lane < kb ? w[kk + lane] : 0.0;
+      for (int k = 0; k < 64; k++) wi -= Sd[k * TP + lane] * sdm_bcast_lane(wi, k);
+      if (lane < kb) w[kk + lane] = wi;
+    }
+    __syncthreads();
+    for (int r = kk + kb + tid; r < nb; r += ST) {
+      double acc = 0.0;
+      for (int c = 0; c < kb; c++) acc += Fs[(int64_t)(k0 + kk + c) * ld + k0 + r] * w[kk + c];
+      w[r] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < nb; i += ST) yp[i] = w[i];
+}
+__device__ __noinline__ void block_solve_bw(const double *Fs, int ld, int k0, int nb, double *yp, double *w, double *Sd) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < nb; i += ST) w[i] = yp[i];
+  __syncthreads();
+  for (int kk = ((nb - 1) / 64) * 64; kk >= 0; kk -= 64) {
+    const int kb = min(64, nb - kk);
+    for (int e = tid; e < 64 * 64; e += ST) {
+      const int i = e & 63, c = e >> 6;
+      Sd[c * TP + i] = (i > c && i < kb) ? Fs[(int64_t)(k0 + kk + c) * ld + k0 + kk + i] : 0.0;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      double xj = lane < kb ? w[kk + lane] : 0.0;
+      for (int k = 63; k >= 0; k--) xj -= Sd[lane * TP + k] * sdm_bcast_lane(xj, k);      // L(k, lane), zero unless k > lane
+      if (lane < kb) w[kk + lane] = xj;
+    }
+    __syncthreads();
+    for (int c = tid; c < kk; c += ST) {
+      double acc = 0.0;
+      for (int r = 0; r < kb; r++) acc += Fs[(int64_t)(k0 + c) * ld + k0 + kk + r] * w[kk + r];
+      w[c] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < nb; i += ST) yp[i] = w[i];
+}
+// The nsl workgroups that complete the right-hand side of a BAD super-block each call this after their stores; the
+// last arriver solves the block in place.  (All stores acknowledged, barrier, agent-scope release by one work-item,
+// ticket; the winner acquires.)
+template <bool FW>
+__device__ __forceinline__ void bad_block_arrive(const double *Fs, int ld, int k0, int nb, double *yp, int *cnt, int nsl, double *w,
+                                                 double *Sd) {
+  __shared__ int last;
+  SDM_STORES_DONE();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int t = atomicAdd(cnt, 1);
+    last = t == nsl - 1;
+    if (last) atomicExch(cnt, 0);                                   // ready for the next solve
+  }
+  __syncthreads();
+  if (!last) return;
+  SDM_ACQUIRE_FENCE();
+  if (FW) block_solve_fw(Fs, ld, k0, nb, yp, w, Sd); else block_solve_bw(Fs, ld, k0, nb, yp, w, Sd);
+}
+
+// ================================================================ forward sweep
+// assembly of a front's right-hand side (levels above the leaves): own entries through perm, children's update vectors
+__global__ void __launch_bounds__(ST)
+k_sfw_init(FrontTab tab, const int *list, double *wv, const double *src, const int *perm, const double *y) {
+  const int s = list[blockIdx.x];
+  const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
+  double *a = wv + tab.woff[s];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < ms; i += ST) a[i] = i < ns ? (src ? src[perm[first + i]] : y[first + i]) : 0.0;
+  __syncthreads();
+  for (int ci = tab.childptr[s]; ci < tab.childptr[s + 1]; ci++) {   // fixed order: deterministic
+    const int c = tab.childlist[ci];
+    const int nc = tab.ns[c], mu = tab.ms[c] - nc;
+    const int *rel = tab.relidx + tab.roff[c];
+    const double *wc = wv + tab.woff[c] + nc;
+    for (int i = tid; i < mu; i += ST) a[rel[i]] += wc[i];
+    __syncthreads();
+  }
+}
+
+// ---- slab products.  Every kernel below issues its matrix loads FIRST (registers), then fetches the vector it
+// multiplies with (written by the previous launch) into LDS, then multiplies: the two memory latencies overlap.
+// Forward: sum_c M(r, cbase + c) xs[c] for the SROWS rows rbase .. of one slab.  Work-item (p = tid & 7, g = tid >> 3)
+// owns row pair p and the columns g, g+32, ... (ncols <= SBW = 8 x 32); 16-byte loads, 8 in flight; fixed-order
+// reduction over g.  rbase even; rows are clamped to the last valid pair (rlast = last valid row).
+constexpr int NLD = SBW / 32;
+__device__ __forceinline__ void slab_issue(sdm_double2 (&v)[NLD], const double *M, int64_t ldm, int cbase, int ncols, int rbase, int rlast) {
+  const int tid = threadIdx.x, p = tid & 7, g = tid >> 3;
+  const int r = min(rbase + 2 * p, rlast & ~1);
+  const sdm_double2 *col = (const sdm_double2 *)(M + (int64_t)cbase * ldm + r);
+  const int64_t ld2 = ldm >> 1;
+#pragma unroll
+  for (int j = 0; j < NLD; j++) v[j] = col[(int64_t)min(g + 32 * j, ncols - 1) * ld2];
+}
+// result for row rbase + t in work-items t < SROWS
+__device__ __forceinline__ double slab_consume(const sdm_double2 (&v)[NLD], int ncols, const double *xs, double *red) {
+  const int tid = threadIdx.x, p = tid & 7, g = tid >> 3;
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int j = 0; j < NLD; j++) {
+    const int c = g + 32 * j;
+    const double xc = c < ncols ? xs[c] : 0.0;
+    a0 += v[j].x * xc; a1 += v[j].y * xc;
+  }
+  red[g * SROWS + 2 * p] = a0; red[g * SROWS + 2 * p + 1] = a1;
+  __syncthreads();
+  double sum = 0.0;
+  if (tid < SROWS) {
+#pragma unroll
+    for (int q = 0; q < ST / 8; q++) sum += red[q * SROWS + tid];
+  }
+  return sum;
+}
+
+// y_P = inv(L_PP) a_P for every super-block of every front of a level (bad blocks: copy, then substitution)
+__global__ void __launch_bounds__(ST)
+k_sfw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, const double *wv, const double *src,
+           const int *perm, double *y, const unsigned long long *sb_g, int *sb_cnt, double thr, int gather) {
+  __shared__ double xs[SBW], red[(ST / 8) * SROWS], wsub[SBW];
+  __shared__ double Sd[64 * TP];
+  const int s = list[blockIdx.y];
+  const int ns = tab.ns[s], first = tab.first[s];
+  const int r0 = SROWS * blockIdx.x;
+  if (r0 >= ns) return;
+  const int Pb = r0 / SBW, c0 = Pb * SBW, nb = min(SBW, ns - c0);
+  const int sb = tab.sboff[s] + Pb;
+  const int tid = threadIdx.x;
+  const int ncols = min(nb, r0 + SROWS - c0);                       // lower triangular: columns up to the slab's last row
+  sdm_double2 v[NLD];
+  slab_issue(v, S + tab.soff[s], tab.sld[s], c0, ncols, r0, ns - 1);
+  const bool bad = sb_is_bad(sb_g, sb, thr);
+  const double *a = wv + tab.woff[s];
+  // the block's right-hand side: gathered through perm (leaves) or taken from the assembled vector
+  for (int c = tid; c < nb; c += ST) xs[c] = gather ? src[perm[first + c0 + c]] : a[c0 + c];
+  __syncthreads();
+  if (bad) {
+    if (tid < SROWS && r0 + tid < ns) y[first + r0 + tid] = xs[r0 - c0 + tid];
+    // block 0 has nothing left of it: its right-hand side is complete here; later blocks are completed by step Pb-1
+    if (Pb == 0) bad_block_arrive<true>(F + tab.foff[s], tab.ld[s], c0, nb, y + first + c0, sb_cnt + sb, (nb + SROWS - 1) / SROWS, wsub, Sd);
+    return;
+  }
+  const double sum = slab_consume(v, ncols, xs, red);
+  if (tid < SROWS && r0 + tid < ns) y[first + r0 + tid] = sum;
+}
+
+// step P: y_P is final; every row beyond super-block P receives  - M(r, P) y_P   (M = S for the front's own rows
+// -- F for the rows of a bad super-block -- and F for the rows below the supernode, whose sums are the update
+// vector passed to the parent)
+__global__ void __launch_bounds__(ST)
+k_sfw_step(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, double *wv, double *y,
+           const unsigned long long *sb_g, int *sb_cnt, double thr, int Pb, int first_assign) {
+  __shared__ double xs[SBW], red[(ST / 8) * SROWS], wsub[SBW];
+  __shared__ double Sd[64 * TP];
+  const int s = list[blockIdx.y];
+  const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s], ld = tab.ld[s];
+  const int c0 = Pb * SBW;
+  if (c0 >= ns) return;
+  const int nb = min(SBW, ns - c0), ra = c0 + SBW;
+  const int slabsA = ns > ra ? (ns - ra + SROWS - 1) / SROWS : 0;
+  const int ebase = ns & ~1;
+  const int slabsB = ms > ns ? (ms - ebase + SROWS - 1) / SROWS : 0;
+  const int bx = blockIdx.x;
+  if (bx >= slabsA + slabsB) return;
+  const int tid = threadIdx.x;
+  const double *Fs = F + tab.foff[s];
+  const bool regA = bx < slabsA;
+  const int r0 = regA ? ra + SROWS * bx : ebase + SROWS * (bx - slabsA);
+  sdm_double2 v[NLD];
+  // the front's own rows come from S (issued before the growth flag of their block is known: S is valid memory
+  // either way); the rows below the supernode from the factor itself
+  if (regA) slab_issue(v, S + tab.soff[s], tab.sld[s], c0, nb, r0, ns - 1);
+  else slab_issue(v, Fs, ld, c0, nb, r0, ms - 1);
+  const int Pr = r0 / SBW, sbr = tab.sboff[s] + Pr;
+  const bool bad = regA && sb_is_bad(sb_g, sbr, thr);
+  for (int c = tid; c < nb; c += ST) xs[c] = y[first + c0 + c];
+  __syncthreads();
+  if (bad) slab_issue(v, Fs, ld, c0, nb, r0, ns - 1);               // rare: the rows of a bad block were not premultiplied
+  const double sum = slab_consume(v, nb, xs, red);
+  if (regA) {
+    if (tid < SROWS && r0 + tid < ns) y[first + r0 + tid] -= sum;
+    if (bad && Pr == Pb + 1) {                                      // this step completes the right-hand side of block Pr
+      const int nbr = min(SBW, ns - Pr * SBW);
+      bad_block_arrive<true>(Fs, ld, Pr * SBW, nbr, y + first + Pr * SBW, sb_cnt + sbr, (nbr + SROWS - 1) / SROWS, wsub, Sd);
+    }
+  } else {
+    double *u = wv + tab.woff[s];
+    const int r = r0 + tid;
+    if (tid < SROWS && r >= ns && r < ms) u[r] = first_assign ? -sum : u[r] - sum;
+  }
+}
+
+// ================================================================ backward sweep
+// sum_r M(rbase + r, c) xs[r] for the SROWS columns cbase .. of one slab over at most SBW rows: wavefront w owns 4
+// columns, lanes run down the row pairs (contiguous 16-byte loads, 8 in flight), wave reduction in a fixed order.
+// rbase even.  Result for column cbase + 4*w + q in every lane of wavefront w as out[q].
+__device__ __forceinline__ void slabT_issue(sdm_double2 (&v)[8], const double *M, int64_t ldm, int cbase, int ncols, int rbase, int nrows) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int plast = max(((nrows + 1) >> 1) - 1, 0);
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c = min(cbase + 4 * wave + q, cbase + ncols - 1);
+      v[4 * h + q] = ((const sdm_double2 *)(M + (int64_t)c * ldm + rbase))[min(lane + 64 * h, plast)];
+    }
+}
+__device__ __forceinline__ void slabT_consume(const sdm_double2 (&v)[8], int nrows, const double *xs, double (&out)[4]) {
+  const int lane = threadIdx.x & 63;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int pi = lane + 64 * h;
+    // rows beyond the range are dropped by selects on BOTH factors: a padding row of the front may hold anything
+    const bool in0 = 2 * pi < nrows, in1 = 2 * pi + 1 < nrows;
+    const double x0 = in0 ? xs[2 * pi] : 0.0, x1 = in1 ? xs[2 * pi + 1] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] += (in0 ? v[4 * h + q].x : 0.0) * x0 + (in1 ? v[4 * h + q].y : 0.0) * x1;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    double a = acc[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    out[q] = a;
+  }
+}
+
+// v = z ./ d  -  (rows below the supernode)' x_ancestors   for every column of every front of a level
+__global__ void __launch_bounds__(ST)
+k_sbw_init(const double *__restrict__ F, FrontTab tab, const int *list, double *y, const double *xfin, const double *dscale,
+           const unsigned long long *sb_g, int *sb_cnt, double thr) {
+  __shared__ double xs[SBW], wsub[SBW];
+  __shared__ double Sd[64 * TP];
+  const int s = list[blockIdx.y];
+  const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s], ld = tab.ld[s];
+  const int c0 = SROWS * blockIdx.x;
+  if (c0 >= ns) return;
+  const int ncols = min(SROWS, ns - c0);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const double *Fs = F + tab.foff[s];
+  const int *rows = tab.lindx + tab.xl[s];
+  double tot[4] = {0.0, 0.0, 0.0, 0.0};
+  const int ebase = ns & ~1;
+  if (ms > ns) {
+    for (int rb = ebase; rb < ms; rb += SBW) {                      // ancestors' entries, gathered SBW at a time
+      const int nr = min(SBW, ms - rb);
+      sdm_double2 v[8];
+      slabT_issue(v, Fs, ld, c0, ncols, rb, nr);
+      __syncthreads();
+      for (int i = tid; i < nr; i += ST) xs[i] = rb + i >= ns ? xfin[rows[rb + i]] : 0.0;
+      __syncthreads();
+      double part[4];
+      slabT_consume(v, nr, xs, part);
+#pragma unroll
+      for (int q = 0; q < 4; q++) tot[q] += part[q];
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c = c0 + 4 * wave + q;
+      if (c < ns) { const double z = y[first + c]; y[first + c] = (dscale ? z / dscale[first + c] : z) - tot[q]; }
+    }
+  }
+  // the last super-block of a front has nothing above it in this sweep: if bad, it is solved once all its columns are set
+  const int nsb = (ns + SBW - 1) / SBW, Pl = nsb - 1;
+  if (c0 / SBW == Pl && sb_is_bad(sb_g, tab.sboff[s] + Pl, thr)) {
+    const int nbl = ns - Pl * SBW;
+    bad_block_arrive<false>(Fs, ld, Pl * SBW, nbl, y + first + Pl * SBW, sb_cnt + tab.sboff[s] + Pl, (nbl + SROWS - 1) / SROWS, wsub, Sd);
+  }
+}
+
+// step Q: v_Q (x_Q for a bad block) is final; every column left of super-block Q receives  - M(Q rows, c)' v_Q
+__global__ void __launch_bounds__(ST)
+k_sbw_step(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, double *y,
+           const unsigned long long *sb_g, int *sb_cnt, double thr, int Q) {
+  __shared__ double xs[SBW], wsub[SBW];
+  __shared__ double Sd[64 * TP];
+  const int s = list[blockIdx.y];
+  const int ns = tab.ns[s], first = tab.first[s], ld = tab.ld[s];
+  const int rb = Q * SBW;
+  if (rb >= ns) return;
+  const int nbq = min(SBW, ns - rb);
+  const int c0 = SROWS * blockIdx.x;                                // < rb by the grid
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const double *Fs = F + tab.foff[s];
+  sdm_double2 v[8];
+  slabT_issue(v, S + tab.soff[s], tab.sld[s], c0, SROWS, rb, nbq);  // before the growth flag is known (S is valid memory either way)
+  const bool badq = sb_is_bad(sb_g, tab.sboff[s] + Q, thr);
+  for (int i = tid; i < nbq; i += ST) xs[i] = y[first + rb + i];
+  __syncthreads();
+  if (badq) slabT_issue(v, Fs, ld, c0, SROWS, rb, nbq);             // rare: the rows of a bad block were not premultiplied
+  double part[4];
+  slabT_consume(v, nbq, xs, part);
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) y[first + c0 + 4 * wave + q] -= part[q];
+  }
+  const int Pc = c0 / SBW;
+  if (Pc == Q - 1 && sb_is_bad(sb_g, tab.sboff[s] + Pc, thr))      // this step completes v of block Q-1
+    bad_block_arrive<false>(Fs, ld, Pc * SBW, SBW, y + first + Pc * SBW, sb_cnt + tab.sboff[s] + Pc, SBW / SROWS, wsub, Sd);
+}
+
+// x_P = inv(L_PP)' v_P ; the result goes to xfin (descendants read it) and, scattered through perm, to yout
+__global__ void __launch_bounds__(ST)
+k_sbw_diag(const double *__restrict__ S, FrontTab tab, const int *list, const double *y, double *xfin, double *yout, const int *perm,
+           const unsigned long long *sb_g, double thr) {
+  __shared__ double xs[SBW];
+  const int s = list[blockIdx.y];
+  const int ns = tab.ns[s], first = tab.first[s];
+  const int c0 = SROWS * blockIdx.x;
+  if (c0 >= ns) return;
+  const int Pb = c0 / SBW, rb = Pb * SBW, nb = min(SBW, ns - rb);
+  const int ncols = min(SROWS, ns - c0);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nr = rb + nb - c0;                                       // rows c0 .. end of the block (upper part of S is zero)
+  sdm_double2 v[8];
+  slabT_issue(v, S + tab.soff[s], tab.sld[s], c0, ncols, c0, nr);
+  const bool bad = sb_is_bad(sb_g, tab.sboff[s] + Pb, thr);
+  for (int i = tid; i < nr; i += ST) xs[i] = y[first + c0 + i];
+  __syncthreads();
+  double part[4];
+  if (bad) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int c = c0 + 4 * wave + q; part[q] = c < ns ? xs[c - c0] : 0.0; }
+  } else {
+    slabT_consume(v, nr, xs, part);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c = c0 + 4 * wave + q;
+      if (c < ns) { xfin[first + c] = part[q]; if (yout) yout[perm[first + c]] = part[q]; }
+    }
+  }
+}
+
+// ================================================================ host drivers
+void solve_prepare(sdm_plan *P) {
+  CholPlan &C = P->chol;
+  FrontTab tab = front_tab(C);
+#ifndef SDM_EMU
+  static bool attr = false;
+  if (!attr) {
+    SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_sinv128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)INV_LDS));
+    SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_stile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS));
+    attr = true;
+  }
+#endif
+  C.growth_used = C.growth_max;                                     // the solves decide with the bound the premultiplication saw
+  SDM_HIP_CHECK(hipMemsetAsync(C.sb_g.p, 0, (size_t)std::max(2 * C.nsbtot, 2) * sizeof(unsigned long long), P->stream));
+  if (C.n_i128) SDM_KLAUNCH(P, k_sinv128, dim3(C.n_i128), dim3(ST), INV_LDS, C.fronts.p, C.S.p, tab, C.l_i128.p, C.sb_g.p);
+  if (C.n_t3) {
+    SDM_KLAUNCH(P, k_stile, dim3(C.n_t3), dim3(ST), TILE_LDS, C.fronts.p, C.S.p, C.ttmp.p, tab, C.l_t3.p, C.sb_g.p, 0, C.growth_used);
+    SDM_KLAUNCH(P, k_stile, dim3(C.n_t3), dim3(ST), TILE_LDS, C.fronts.p, C.S.p, C.ttmp.p, tab, C.l_t3.p, C.sb_g.p, 1, C.growth_used);
+  }
+  if (C.n_pm) SDM_KLAUNCH(P, k_stile, dim3(C.n_pm), dim3(ST), TILE_LDS, C.fronts.p, C.S.p, C.ttmp.p, tab, C.l_pm.p, C.sb_g.p, 2, C.growth_used);
+}
+
+// growth statistics of the last solve_prepare (host read-back; tests and bench reporting)
+void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growth) {
+  CholPlan &C = P->chol;
+  std::vector<unsigned long long> g((size_t)std::max(2 * C.nsbtot, 2));
+  SDM_HIP_CHECK(hipStreamSynchronize(P->stream));
+  SDM_HIP_CHECK(hipMemcpy(g.data(), C.sb_g.p, g.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  sdm_int bad = 0; double mx = 0.0;
+  for (int i = 0; i < C.nsbtot; i++) {
+    union { unsigned long long u; double d; } a, b; a.u = g[2 * i]; b.u = g[2 * i + 1];
+    const double gr = a.d * b.d;
+    if (!(gr <= C.growth_used)) bad++;
+    if (gr > mx || gr != gr) mx = gr;
+  }
+  if (nblocks) *nblocks = C.nsbtot;
+  if (nbad) *nbad = bad;
+  if (max_growth) *max_growth = mx;
+}
+
+void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode) {
+  CholPlan &C = P->chol;
+  FrontTab tab = front_tab(C);
+  const size_t mb = (size_t)C.m * sizeof(double);
+  double *y = P->ywork.p;
+  const double thr = C.growth_used;
+  if (mode & 1) {
+    for (int l = 0; l < C.nlevels; l++) {
+      const SolveLevel &L = C.slev[l];
+      const int *list = C.d_levlist.p + C.levptr[l];
+      const int gather = L.children ? 0 : 1;
+      if (!gather) SDM_KLAUNCH(P, k_sfw_init, dim3(L.nfronts), dim3(ST), 0, tab, list, C.wvec.p, rhs, C.d_perm.p, y);
+      SDM_KLAUNCH(P, k_sfw_diag, dim3((L.maxns + SROWS - 1) / SROWS, L.nfronts), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, C.wvec.p, rhs,
+                  C.d_perm.p, y, C.sb_g.p, C.sb_cnt.p, thr, gather);
+      for (int Pb = 0; Pb < (int)L.maxslab_fw.size(); Pb++)
+        if (L.maxslab_fw[Pb] > 0)
+          SDM_KLAUNCH(P, k_sfw_step, dim3(L.maxslab_fw[Pb], L.nfronts), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, C.wvec.p, y, C.sb_g.p,
+                      C.sb_cnt.p, thr, Pb, (gather && Pb == 0) ? 1 : 0);
+    }
+    if (!(mode & 4)) {
+      if (mode & 2) vec_divd(P, y);
+      SDM_HIP_CHECK(hipMemcpyAsync(yout, y, mb, hipMemcpyDeviceToDevice, P->stream));
+      return;
+    }
+  } else {
+    SDM_HIP_CHECK(hipMemcpyAsync(y, rhs, mb, hipMemcpyDeviceToDevice, P->stream));
+  }
+  for (int l = C.nlevels - 1; l >= 0; l--) {
+    const SolveLevel &L = C.slev[l];
+    const int *list = C.d_levlist.p + C.levptr[l];
+    const int ncs = (L.maxns + SROWS - 1) / SROWS;
+    SDM_KLAUNCH(P, k_sbw_init, dim3(ncs, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p,
+                (mode & 2) ? (const double *)C.dsolve.p : (const double *)nullptr, C.sb_g.p, C.sb_cnt.p, thr);
+    for (int Q = L.nsb - 1; Q >= 1; Q--)
+      SDM_KLAUNCH(P, k_sbw_step, dim3(Q * (SBW / SROWS), L.nfronts), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, y, C.sb_g.p, C.sb_cnt.p, thr, Q);
+    SDM_KLAUNCH(P, k_sbw_diag, dim3(ncs, L.nfronts), dim3(ST), 0, C.S.p, tab, list, y, C.xfin.p, yout, C.d_perm.p, C.sb_g.p, thr);
+  }
+}
+
+}  // namespace sdm

@@ -114,6 +114,17 @@ class Plan:
             p0 = np.ascontiguousarray(np.asarray(perm, dtype=np.float64).ravel() - 1, dtype=np.int64)
             check(self._lib.sdm_plan_invcholfac(C.c_void_p(self._p), p0.ctypes.data_as(C.POINTER(C.c_int64))))
 
+    def set_growth_max(self, growth_max):
+        """Growth bound above which a diagonal super-block of L is solved by substitution instead of its explicit
+        inverse (0 = substitution everywhere); effective from the next blkchol."""
+        check(self._lib.sdm_plan_set_growth_max(C.c_void_p(self._p), C.c_double(float(growth_max))))
+
+    def solve_stats(self):
+        """(super-blocks, blocks on the substitution fallback, largest growth) of the last factorisation."""
+        nb, bad, g = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
+        check(self._lib.sdm_plan_solve_stats(C.c_void_p(self._p), C.byref(nb), C.byref(bad), C.byref(g)))
+        return nb.value, bad.value, g.value
+
     def getdatq(self):
         """qpr = values of DAt.q (getDAtm.m:39-44) from the resident "q1", "q2" (upload them first)."""
         check(self._lib.sdm_plan_getdatq(C.c_void_p(self._p)))

@@ -164,7 +164,7 @@ def test_resident_plan_matches_reference(glue):
     assert len(si) == it["Lskip"].nnz and len(ai) == it["Ladd"].nnz
     prof_before = plan.kprof_summary()
     plan.kprof(True); plan.ldlsolve(); prof = plan.kprof_summary(); plan.kprof(False)
-    assert not prof_before and ("k_ldl_single" in prof or ("k_fw_level" in prof and "k_bw_level" in prof))
+    assert not prof_before and "k_sfw_diag" in prof and "k_sbw_diag" in prof
     plan.close()
 
 
@@ -182,7 +182,7 @@ def test_bad_inputs_raise_like_mexErrMsgTxt():
 
 
 def test_big_single_front_solves(refmex):
-    """Single dense front above BIG_FRONT rows: the sweeps run as one launch per 64-column panel (k_big_fw / k_big_bw)."""
+    """Single dense front of 1100 rows = five 256-column super-blocks: diagonal inverses at all three levels (64 / 128 / 256), premultiplied block rows, four steps per sweep."""
     from sedumi_amd import mex, problem
     m = 1100
     rng = np.random.default_rng(7)
@@ -231,7 +231,7 @@ def test_pipelined_sweeps_full_workgroup_fronts(refmex, glue, n1, n2, nc):
 
 @pytest.mark.parametrize("m", [961, 1000, 1023])
 def test_pipelined_sweeps_single_front(refmex, m):
-    """Single dense front just below BIG_FRONT rows: the whole solve in one launch (k_ldl_single) on the look-ahead
+    """Single dense front of about 1000 rows (four super-blocks, the last one partial) on the look-ahead
     schedule; m = 1023 has an odd row count, m = 1000 a partial last panel."""
     from sedumi_amd import mex, problem
     rng = np.random.default_rng(m)
@@ -241,3 +241,74 @@ def test_pipelined_sweeps_single_front(refmex, m):
     rhs = rng.standard_normal((m, 1))
     assert relerr(mex.fwblkslv(L, rhs), refmex.call("fwblkslv", 1, L, rhs)) < TOL
     assert relerr(mex.bwblkslv(L, rhs), refmex.call("bwblkslv", 1, L, rhs)) < TOL
+
+
+@pytest.mark.parametrize("m,thr", [(700, 0.0), (700, 1e-3), (300, 0.0), (90, 0.0)])
+def test_solves_with_substitution_fallback_blocks(refmex, m, thr):
+    """The solves apply the 256-column diagonal super-blocks of L as explicit inverses unless a block's growth
+    max|inv| * max|L| exceeds the plan's bound; such a block keeps its rows unpremultiplied and is solved by
+    substitution by the last workgroup that updates it.  Bound 0: every block on the fallback; bound 1e-3 on a factor
+    whose middle super-block has tiny multipliers: good and bad blocks mixed in one front."""
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    rng = np.random.default_rng(m)
+    Lv = np.tril(rng.standard_normal((m, m)) * (0.5 / np.sqrt(m)), -1) + np.eye(m)
+    if thr > 0:
+        Lv[256:512, 256:512] = np.tril(Lv[256:512, 256:512], -1) * 1e-3 + np.eye(256)      # growth ~ 1e-4: stays on the inverse
+    d = 0.5 + rng.random(m)
+    X = Lv @ np.diag(d) @ Lv.T
+    L = problem.dense_symbolic(m)
+    plan = Plan(0); plan.set_chol(L, problem.dense_pattern(m))
+    plan.set_growth_max(thr)
+    plan.upload("ada", X.ravel(order="F"))
+    plan.blkchol(None, False)
+    nb, bad, _ = plan.solve_stats()
+    assert nb == (m + 255) // 256 and bad == (nb if thr == 0 else nb - 1)
+    Ll = dict(L); Ll["L"] = sp.csc_matrix(np.tril(plan_dense_L(plan, m)))
+    rhs = rng.standard_normal((m, 1))
+    plan.upload("rhs", rhs.ravel()); plan.fwsolve()
+    assert relerr(plan.download("y"), refmex.call("fwblkslv", 1, Ll, rhs).ravel()) < TOL
+    plan.bwsolve()
+    assert relerr(plan.download("y"), refmex.call("bwblkslv", 1, Ll, rhs).ravel()) < TOL
+    plan.ldlsolve()
+    dd = plan.download("d")
+    want = refmex.call("bwblkslv", 1, Ll, refmex.call("fwblkslv", 1, Ll, rhs) / dd.reshape(-1, 1)).ravel()
+    assert relerr(plan.download("y"), want) < TOL
+    plan.close()
+
+
+def plan_dense_L(plan, m):
+    Lp = plan.download("lpr")
+    out = np.zeros((m, m))
+    out[np.tril_indices(m)[::-1]] = 0
+    M = sp.csc_matrix((Lp, plan.L_pattern.indices, plan.L_pattern.indptr), shape=(m, m))
+    return M.toarray()
+
+
+@pytest.mark.parametrize("kind,m,thr", [("rand", 200, 0.0), ("grid", 144, 0.0), ("bordered", 0, 0.0), ("bordered", 0, 1e4), ("arrow", 80, 0.0)])
+def test_multifront_solves_with_and_without_fallback(refmex, glue, kind, m, thr):
+    """Multi-front factors (children's update vectors, rows below the supernodes, several etree levels) through the
+    resident solves with every super-block on the substitution fallback (bound 0) and on the inverse path."""
+    from oracle import glue as gl
+    from sedumi_amd.plan import Plan
+    rng = np.random.default_rng(17)
+    X = _bordered_blocks(300, 70, 40, rng) if kind == "bordered" else spd_pattern(kind, m, rng, 0.04)
+    L = glue.symbchol(X)
+    n = X.shape[0]
+    r = refmex.call("blkchol", 4, L, X, gl.default_pars_chol())
+    plan = Plan(0); plan.set_chol(L, X)
+    plan.set_growth_max(thr)
+    plan.upload("ada", sp.csc_matrix(X).data)
+    plan.blkchol(gl.default_pars_chol(), False)
+    nb, bad, _ = plan.solve_stats()
+    assert (0 < bad <= nb) if thr == 0 else bad == 0          # 1 x 1 blocks have growth 0: never "bad"
+    assert relerr(plan.download("lpr"), r[0].data) < TOL
+    Lr = dict(L); Lr["L"] = r[0]
+    rhs = rng.standard_normal((n, 1))
+    plan.upload("rhs", rhs.ravel())
+    plan.fwsolve(); assert relerr(plan.download("y"), refmex.call("fwblkslv", 1, Lr, rhs).ravel()) < TOL
+    plan.bwsolve(); assert relerr(plan.download("y"), refmex.call("bwblkslv", 1, Lr, rhs).ravel()) < TOL
+    plan.ldlsolve()
+    want = refmex.call("bwblkslv", 1, Lr, refmex.call("fwblkslv", 1, Lr, rhs) / r[1].reshape(-1, 1)).ravel()
+    assert relerr(plan.download("y"), want) < TOL
+    plan.close()

@@ -115,6 +115,16 @@ int sdm_getada3(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, double *A
                 const sdm_int *Ajc1, const sdm_int *sperm, const double *udsqr,
                 const sdm_cone *K, const sdm_int *psd_blkstart, double *absd);
 
+/* absd = getada(A, K, d, DAt)  [global ADA_sedumi_]      getada.m:13-40, called by sedumi.m:446-448 when sum(K.s)==0
+ * The whole ADA' of an LP / SOCP problem:  DAt.q' DAt.q + Alq' diag([d.l; -d.det; d.det(k) per norm-bound row]) Alq,
+ * Alq = A(1:K.mainblks(3)-1,:).  ADApr[nnz(ADA)] out on the pattern of the global ADA_sedumi_ (symmetric, both
+ * triangles; entries MATLAB's sparse() would drop come out as explicit zeros), absd[m] = diag(ADA) out.
+ * DAt.q lorN x m CSC (ignored when lorN == 0); qblkstart[lorN+1] 0-based. */
+int sdm_getada(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir,
+               sdm_int N, const sdm_int *Ajc, const sdm_int *Air, const double *Apr,
+               sdm_int lpN, const double *dl, sdm_int lorN, const double *ddet, const sdm_int *qblkstart,
+               const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, double *ADApr, double *absd);
+
 /* --- numeric factor / solves ---------------------------------------------- */
 
 /* [L.L,L.d,L.skip,L.add] = blkchol(L, X, pars, absd)    blkchol.c:239-440

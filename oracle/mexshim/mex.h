@@ -75,6 +75,9 @@ void mexErrMsgTxt(const char *msg);
 void mexWarnMsgTxt(const char *msg);
 int mexPrintf(const char *fmt, ...);
 int mexAtExit(void (*fn)(void));
+/* --- workspace variables (only the "global" workspace exists here; sedumi.m keeps ADA_sedumi_ there) --- */
+const mxArray *mexGetVariablePtr(const char *workspace, const char *name);
+int mexPutVariable(const char *workspace, const char *name, const mxArray *value);   /* stores a copy; 0 = ok */
 
 #ifdef NDEBUG
 #define mxAssert(c, msg) ((void)0)
@@ -95,6 +98,8 @@ int shim_nfields(const mxArray *a);
 const char *shim_fieldname(const mxArray *a, int i);
 mxArray *shim_fieldval(const mxArray *a, int i);
 mxArray *shim_new_struct(void);
+void shim_set_global(const char *name, const mxArray *value);   /* copy in (NULL clears) */
+const mxArray *shim_get_global(const char *name);
 
 #ifdef __cplusplus
 }

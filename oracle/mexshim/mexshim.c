@@ -168,6 +168,33 @@ int shim_nfields(const mxArray *a) { return a->nfields; }
 const char *shim_fieldname(const mxArray *a, int i) { return a->fnames[i]; }
 mxArray *shim_fieldval(const mxArray *a, int i) { return a->fvals[i]; }
 
+/* ------------------------------------------------- "global" workspace */
+#define SHIM_NGLOB 8
+static struct { char name[64]; mxArray *val; } g_glob[SHIM_NGLOB];
+const mxArray *shim_get_global(const char *name) {
+  int i;
+  for (i = 0; i < SHIM_NGLOB; i++) if (g_glob[i].val && !strcmp(g_glob[i].name, name)) return g_glob[i].val;
+  return NULL;
+}
+void shim_set_global(const char *name, const mxArray *value) {
+  int i, slot = -1;
+  for (i = 0; i < SHIM_NGLOB; i++) if (g_glob[i].val && !strcmp(g_glob[i].name, name)) slot = i;
+  if (slot < 0) for (i = 0; i < SHIM_NGLOB && slot < 0; i++) if (!g_glob[i].val) slot = i;
+  if (slot < 0) return;
+  if (g_glob[slot].val) mxDestroyArray(g_glob[slot].val);
+  g_glob[slot].val = value ? mxDuplicateArray(value) : NULL;
+  strncpy(g_glob[slot].name, name, sizeof g_glob[slot].name - 1);
+}
+const mxArray *mexGetVariablePtr(const char *workspace, const char *name) {
+  if (strcmp(workspace, "global")) return NULL;
+  return shim_get_global(name);
+}
+int mexPutVariable(const char *workspace, const char *name, const mxArray *value) {
+  if (strcmp(workspace, "global")) return 1;
+  shim_set_global(name, value);
+  return 0;
+}
+
 /* ------------------------------------------------- BLAS-1, Fortran semantics
  * Two back-ends behind the names the reference links against (blksdp.h:43-62, non-OCTAVE branch):
  *   naive   plain sequential loops (deterministic; the default, used by every parity test), and

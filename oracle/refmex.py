@@ -188,6 +188,21 @@ class RefMex:
                         self.shim.mxDestroyArray(plhs[i])
         return outs[0] if nlhs <= 1 else outs
 
+    def set_global(self, name, value):
+        """MATLAB `global name; name = value` for the MEX files that use mexGetVariablePtr / mexPutVariable."""
+        self.shim.shim_set_global.argtypes = [C.c_char_p, _MxP]
+        mx = self.to_mx(value)
+        try:
+            self.shim.shim_set_global(name.encode(), mx)
+        finally:
+            self.shim.mxDestroyArray(mx)
+
+    def get_global(self, name):
+        self.shim.shim_get_global.restype = _MxP
+        self.shim.shim_get_global.argtypes = [C.c_char_p]
+        mx = self.shim.shim_get_global(name.encode())
+        return self.from_mx(mx) if mx else None
+
     def use_blas(self, lib=None):
         """Bind the BLAS-1 calls of the reference (ddot, daxpy, dscal, dcopy, idamax) to an optimised host BLAS
         (lib = (path, prefix, suffix), see find_openblas) or back to the shim's naive loops (lib = None)."""

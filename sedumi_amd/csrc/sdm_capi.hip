@@ -410,6 +410,31 @@ int sdm_getada3(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, double *A
   SDM_CATCH
 }
 
+// absd = getada(A, K, d, DAt) with the global ADA_sedumi_ : the whole ADA' of a problem WITHOUT PSD blocks
+// (sedumi.m:446-448 -> getada.m:13-40):  ADA = DAt.q' DAt.q + Alq' diag([d.l; -d.det; d.det per norm-bound row]) Alq
+// on the pattern of the global (both triangles), absd = diag(ADA) (getada.m:40).
+int sdm_getada(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc, const sdm_int *Air,
+               const double *Apr, sdm_int lpN, const double *dl, sdm_int lorN, const double *ddet, const sdm_int *qblkstart,
+               const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, double *ADApr, double *absd) {
+  SDM_TRY
+  PlanGuard G; sdm_plan *p = G.p;
+  set_trivial_chol(p, m, ADAjc, ADAir);
+  const sdm_int nlq = lorN > 0 ? qblkstart[lorN] : lpN;             // = K.mainblks(3)-1: rows of Alq (getada.m:25)
+  std::vector<sdm_int> ajc2(m), zq(m + 1, 0);
+  for (sdm_int j = 0; j < m; j++) ajc2[j] = std::lower_bound(Air + Ajc[j], Air + Ajc[j + 1], nlq) - Air;
+  (void)N;
+  ada_build(p, nlq, m, Ajc, Air, Apr, ajc2.data(), lpN, lorN, nullptr, 0, 0, nullptr, qblkstart, nullptr,
+            lorN > 0 ? Qjc : zq.data(), lorN > 0 ? Qir : nullptr, ADAjc, ADAir);
+  if (lpN) SDM_HIP_CHECK(hipMemcpy(p->ada.dl.p, dl, lpN * sizeof(double), hipMemcpyHostToDevice));
+  if (lorN) SDM_HIP_CHECK(hipMemcpy(p->ada.ddet.p, ddet, lorN * sizeof(double), hipMemcpyHostToDevice));
+  if (lorN && Qjc[m]) SDM_HIP_CHECK(hipMemcpy(p->ada.qpr.p, Qpr, Qjc[m] * sizeof(double), hipMemcpyHostToDevice));
+  if (sdm_plan_getada(p)) throw std::runtime_error(g_err);
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  SDM_HIP_CHECK(hipMemcpy(ADApr, p->ada_val.p, (size_t)ADAjc[m] * sizeof(double), hipMemcpyDeviceToHost));
+  SDM_HIP_CHECK(hipMemcpy(absd, p->absd.p, m * sizeof(double), hipMemcpyDeviceToHost));
+  SDM_CATCH
+}
+
 int sdm_blkchol(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm, sdm_int nsuper,
                 const sdm_int *xsuper, const sdm_int *Xjc, const sdm_int *Xir, const double *Xpr,
                 const sdm_cholpars *pars, const double *absd, double *Lpr, double *d, sdm_int *nskip,

@@ -106,6 +106,38 @@ def getada2(ADA, DAt, Aord, K):
     return _same_pattern(ADA, out)
 
 
+def getada(ADA, A, K, d, DAt):
+    """[ADA, absd] = the effect of `absd = getada(A,K,d,DAt)` on the global ADA_sedumi_ (getada.m:13-40; sedumi.m:446-448
+    takes this route when sum(K.s)==0).  Python has no MATLAB globals: the global's pattern comes in as `ADA`, its new
+    value goes out first.  Entries that MATLAB's sparse() would drop are kept as explicit zeros."""
+    ADA, A = _csc(ADA), _csc(A)
+    m = A.shape[1]
+    if ADA.shape != (m, m):
+        raise SdmError("Size mismatch ADA.")
+    lpN, q, s, _ = _Kfields(K)
+    if np.sum(s) != 0:
+        raise SdmError("getada is the path of problems without PSD blocks (sedumi.m:446).")
+    dl, ddet = f64(_field(d, "l", "d")), f64(_field(d, "det", "d"))
+    if dl.size != lpN or ddet.size != q.size:
+        raise SdmError("Size mismatch d.l / d.det.")
+    qb = i64(np.asarray(_field(K, "qblkstart", "K"), dtype=np.float64)) - 1
+    jc, ir = i64(ADA.indptr), i64(ADA.indices)
+    Ajc, Air, Apr = i64(A.indptr), i64(A.indices), f64(A.data)
+    if q.size:
+        Q = _csc(_field(DAt, "q", "DAt"))
+        if Q.shape != (q.size, m):
+            raise SdmError("Size mismatch DAt.q.")
+        Qjc, Qir, Qpr = i64(Q.indptr), i64(Q.indices), f64(Q.data)
+    else:
+        Qjc, Qir, Qpr = np.zeros(m + 1, dtype=np.int64), np.zeros(1, dtype=np.int64), np.zeros(1)
+        qb = np.zeros(1, dtype=np.int64)
+    out = np.zeros(ADA.nnz, dtype=np.float64)
+    absd = np.zeros(m, dtype=np.float64)
+    check(capi.lib().sdm_getada(C.c_int64(m), pi(jc), pi(ir), C.c_int64(A.shape[0]), pi(Ajc), pi(Air), pf(Apr), C.c_int64(lpN),
+                                pf(dl), C.c_int64(q.size), pf(ddet), pi(qb), pi(Qjc), pi(Qir), pf(Qpr), pf(out), pf(absd)))
+    return _same_pattern(ADA, out), absd.reshape(-1, 1)
+
+
 def getada3(ADA, A, Ajc1, Aord, udsqr, K):
     """[ADA, absd] = getada3(ADA, A, Ajc1, Aord, udsqr, K)   (getada3.c:370-569)"""
     ADA, A = _csc(ADA), _csc(A)

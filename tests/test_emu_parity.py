@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from helpers import TOL, check_golden, check_iteration, relerr, spd_pattern, use_emu
+from helpers import TOL, check_golden, check_iteration, load_golden, ref_scaling, relerr, spd_pattern, use_emu
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -312,3 +312,43 @@ def test_multifront_solves_with_and_without_fallback(refmex, glue, kind, m, thr)
     want = refmex.call("bwblkslv", 1, Lr, refmex.call("fwblkslv", 1, Lr, rhs) / r[1].reshape(-1, 1)).ravel()
     assert relerr(plan.download("y"), want) < TOL
     plan.close()
+
+
+@pytest.mark.parametrize("kw", [dict(m=35, lp=8, q=(4, 3, 5), s=()), dict(m=20, lp=12, q=(), s=()), dict(m=40, lp=0, q=(6, 9, 3), s=(), dens=0.5)])
+def test_getada_gateway_no_psd(glue, kw):
+    """absd = getada(A,K,d,DAt) (getada.m:13-40, the route of sedumi.m:446-448 for sum(K.s)==0): the whole ADA' of an
+    LP / SOCP problem in one call, against the reference's getada1 -> getada2 -> getada3 chain (whose result for a
+    problem without PSD blocks is the same symmetric matrix) and absd = diag(ADA')."""
+    from sedumi_amd import mex, problem
+    P = problem.random_sdp(seed=23, **kw)
+    S = glue.setup(P.At, P.K)
+    d, ud = ref_scaling(P, 5)
+    it = glue.iteration_ref(S, d, ud)
+    ADA, absd = mex.getada(S["ADA"], S["A"], P.K, d, it["DAt"])
+    assert relerr(ADA, it["ADA"]) < TOL
+    assert relerr(absd.ravel(), it["ADA"].diagonal()) < TOL
+    # the MATLAB formula itself
+    A = sp.csc_matrix(S["A"]).toarray()
+    nlq = int(P.K["mainblks"].ravel()[2]) - 1
+    sv = np.concatenate((d["l"], -d["det"], np.zeros(nlq - int(P.K["l"]) - P.K["q"].size)))
+    qb = P.K["qblkstart"].ravel().astype(int) - 1
+    for i in range(P.K["q"].size):
+        sv[qb[i]:qb[i + 1]] = d["det"][i]
+    Q = sp.csc_matrix(it["DAt"]["q"]).toarray() if P.K["q"].size else np.zeros((0, P.m))
+    want = Q.T @ Q + A[:nlq].T @ np.diag(sv) @ A[:nlq]
+    assert relerr(ADA.toarray(), want) < 1e-12
+
+
+def test_getada_gateway_on_the_nb_example():
+    """examples/nb.mat (BASELINE.json configs[2]; sum(K.s)==0, so sedumi.m forms ADA' through getada): the committed
+    reference ADA' / absd of the golden fixture through the getada gateway."""
+    from sedumi_amd import mex, problem
+    z, At, K = load_golden("nb")
+    m = At.shape[1]
+    for tag in ("init", "rand"):
+        d = {"l": z[f"{tag}_dl"], "det": z[f"{tag}_ddet"]}
+        Q = sp.csc_matrix((z[f"{tag}_DAtq_data"], z[f"{tag}_DAtq_indices"], z[f"{tag}_DAtq_indptr"]), shape=tuple(z[f"{tag}_DAtq_shape"]))
+        ADA, absd = mex.getada(problem.dense_pattern(m), At, K, d, {"q": Q})
+        A = ADA.toarray()
+        assert relerr(A[np.triu_indices(m)], z[f"{tag}_ADA_triu"]) < TOL and relerr(A, A.T) < 1e-14
+        assert relerr(absd.ravel(), z[f"{tag}_absd"]) < TOL

@@ -486,3 +486,26 @@ def test_ordering_and_symbolic_bit_exact_in_the_gpu_suite(refmex, kind, dens, m)
     assert np.array_equal(Lo["L"].indptr, Lr["L"].indptr) and np.array_equal(Lo["L"].indices, Lr["L"].indices)
     assert np.array_equal(mex.choltmpsiz(Lr), refmex.call("choltmpsiz", 1, Lr))
     assert np.array_equal(mex.cholsplit(Lr, 512.0), refmex.call("cholsplit", 1, Lr, 512.0))
+
+
+def test_getada_gateway_nb_example_on_gpu():
+    """BASELINE.json configs[2] = examples/nb.mat: sum(K.s)==0, so an unmodified sedumi.m:446-448 forms ADA' through
+    getada -- the gateway that shadows getada.m -- then blkchol / fwblkslv / bwblkslv: the committed reference outputs
+    of the golden fixture, entry by entry."""
+    from helpers import load_golden
+    from sedumi_amd import mex, problem
+    z, At, K = load_golden("nb")
+    m = At.shape[1]
+    L = problem.dense_symbolic(m)
+    for tag in ("init", "rand"):
+        d = {"l": z[f"{tag}_dl"], "det": z[f"{tag}_ddet"]}
+        Q = sp.csc_matrix((z[f"{tag}_DAtq_data"], z[f"{tag}_DAtq_indices"], z[f"{tag}_DAtq_indptr"]), shape=tuple(z[f"{tag}_DAtq_shape"]))
+        ADA, absd = mex.getada(problem.dense_pattern(m), At, K, d, {"q": Q})
+        A = ADA.toarray()
+        assert relerr(A[np.triu_indices(m)], z[f"{tag}_ADA_triu"]) < TOL and relerr(absd.ravel(), z[f"{tag}_absd"]) < TOL
+        LL, Ld, Lskip, Ladd = mex.blkchol(L, ADA, {"canceltol": 1e-12, "maxu": 5e5, "abstol": 1e-20}, absd)
+        assert relerr(LL.toarray()[np.tril_indices(m)], z[f"{tag}_L_tril"]) < TOL and relerr(Ld.ravel(), z[f"{tag}_Ld"]) < TOL
+        assert Lskip.nnz == int(z[f"{tag}_nskip"]) and Ladd.nnz == int(z[f"{tag}_nadd"])
+        Ls = dict(L); Ls["L"] = LL
+        y = mex.bwblkslv(Ls, mex.fwblkslv(Ls, z["rhs"]) / Ld)
+        assert relerr(y.ravel(), z[f"{tag}_y"]) < TOL

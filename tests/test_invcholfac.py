@@ -154,7 +154,9 @@ def test_bench_workloads_build():
     from helpers import ROOT
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
-    for name, m in (("control07", 666), ("nb", 123), ("maxcut300", 300)):
-        P, L, ADA, Q, d, ud, rhs = bench.build_workload(name, seed=0)
+    for name, m in (("control07", 666), ("control07_like", 666), ("nb", 123), ("maxcut300", 300), ("blockdiag:4:10:6", 24)):
+        P, L, ADA, Q, d, ud, rhs, qpr, note = bench.build_workload(name, seed=0)
         assert P.m == m and ADA.shape == (m, m) and rhs.size == m
-        assert ud.size == int(np.sum(P.K["s"].ravel() ** 2)) and d["l"].size == int(P.K["l"])
+        assert ud.size == int(np.sum(P.K["s"].ravel() ** 2)) and np.asarray(d["l"]).size == int(P.K["l"])
+        assert (qpr is None) == (Q.nnz == 0)
+    assert "control07.mat" in bench.build_workload("control07", 0)[8]

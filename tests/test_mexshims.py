@@ -12,7 +12,7 @@ import scipy.sparse as sp
 
 from helpers import ROOT, TOL, ref_scaling, relerr, spd_pattern
 
-SHIMS = ["getada1", "getada2", "getada3", "blkchol", "fwblkslv", "bwblkslv", "ordmmdmex", "symfctmex", "choltmpsiz", "cholsplit",
+SHIMS = ["getada", "getada1", "getada2", "getada3", "blkchol", "fwblkslv", "bwblkslv", "ordmmdmex", "symfctmex", "choltmpsiz", "cholsplit",
          "symbfwblk", "finsymbden", "dpr1fact", "fwdpr1", "bwdpr1", "invcholfac"]
 
 
@@ -165,3 +165,26 @@ def test_factor_cache_is_shared_between_mex_binaries_and_validated_by_content(gl
         assert relerr(shimmex.call("bwblkslv", 1, Lf, rhs), refmex.call("bwblkslv", 1, Lf, rhs)) < TOL
     lib.sdm_mexcache_clear()
     assert not resident(LL2)
+
+
+def test_getada_shim_updates_the_global(glue, refmex, shimmex):
+    """getada.mex shadows getada.m (sedumi.m:446-448, problems without PSD blocks): it reads the pattern of the GLOBAL
+    ADA_sedumi_ (mexGetVariablePtr), writes ADA' back into it (mexPutVariable) and returns absd = diag(ADA')."""
+    from oracle.refmex import RefMexError
+    from sedumi_amd import problem
+    P = problem.random_sdp(m=30, lp=7, q=(4, 5, 3), s=(), seed=33)
+    S = glue.setup(P.At, P.K)
+    d, ud = ref_scaling(P, 6)
+    it = glue.iteration_ref(S, d, ud)
+    dstruct = {"l": d["l"].reshape(-1, 1), "det": d["det"].reshape(-1, 1)}
+    shimmex.set_global("ADA_sedumi_", S["ADA"])
+    absd = shimmex.call("getada", 1, S["A"], P.K, dstruct, it["DAt"])
+    ADA = shimmex.get_global("ADA_sedumi_")
+    assert relerr(ADA, it["ADA"]) < TOL and relerr(absd.ravel(), it["ADA"].diagonal()) < TOL
+    # a full (dense) DAt.q is accepted too (getada.m:21-24 densifies it itself)
+    shimmex.set_global("ADA_sedumi_", S["ADA"])
+    absd2 = shimmex.call("getada", 1, S["A"], P.K, dstruct, {"q": sp.csc_matrix(it["DAt"]["q"]).toarray()})
+    assert relerr(shimmex.get_global("ADA_sedumi_"), it["ADA"]) < TOL and relerr(absd2, absd) < 1e-14
+    shimmex.set_global("ADA_sedumi_", None)
+    with pytest.raises(RefMexError, match="ADA_sedumi_ does not exist"):
+        shimmex.call("getada", 1, S["A"], P.K, dstruct, it["DAt"])

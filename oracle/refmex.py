@@ -191,6 +191,9 @@ class RefMex:
     def set_global(self, name, value):
         """MATLAB `global name; name = value` for the MEX files that use mexGetVariablePtr / mexPutVariable."""
         self.shim.shim_set_global.argtypes = [C.c_char_p, _MxP]
+        if value is None:                       # `clear global name`
+            self.shim.shim_set_global(name.encode(), None)
+            return
         mx = self.to_mx(value)
         try:
             self.shim.shim_set_global(name.encode(), mx)

@@ -78,6 +78,73 @@ def build_workload(name, seed):
     return P, L, ADA, Q, d, ud, rhs, qpr, note
 
 
+def build_lpdense(seed=1, m=2000, n=20000, ndense=8):
+    """SURVEY.md 8(d) config 3 variant: sparse LP (m=2000, N=20000, 1 % density) with 8 fully dense variables, the case
+    that exercises the dense-column leg of the unit: + sparse fwblkslv + dpr1fact + 4 x (fwdpr1 + bwdpr1).  Symbolic
+    side (sedumi.m:356-392, symbcholden.m:43-55) through this library's own ordmmd / symfct / symbfwblk / incorder /
+    finsymbden."""
+    import scipy.sparse as sp
+    from sedumi_amd import mex, problem
+    rng = np.random.default_rng(seed)
+    P0 = problem.lp_dense_cols(m=m, n=n, dens=0.01, ndense=ndense, seed=seed)
+    At = sp.csc_matrix(P0.At)
+    rows_dense = 1 + np.arange(ndense)
+    denseA = sp.csc_matrix(At[rows_dense, :].T)                       # m x ndense (sedumi.m:359)
+    keep = np.ones(At.shape[0]); keep[rows_dense] = 0.0
+    P = problem.Problem(sp.csc_matrix(sp.diags(keep) @ At), P0.K, f"lp_dense_cols(m={m},n={n},dense={ndense})")   # sedumi.m:360
+    P.At.eliminate_zeros()
+    P = problem.Problem(P.At, P0.K, P.name)
+    dl = 10.0 ** rng.uniform(-1, 1, At.shape[0])
+    ADA = sp.csc_matrix(P.At.T @ P.At); ADA.data[:] = 1.0; ADA.sort_indices()
+    L = mex.symbchol(ADA)
+    LADsym = mex.symbfwblk(L, denseA)
+    perm, dz = mex.incorder(LADsym)
+    sym = mex.finsymbden(LADsym, perm, dz, float(ndense + 1))
+    return P, L, ADA, {"l": dl, "det": np.zeros(0)}, np.zeros(0), rng.standard_normal(m), sym, denseA, dl[rows_dense]
+
+
+def bench_lpdense(args, device):
+    """One GPU, the unit WITH the dense-column leg: getada (LP part), blkchol, deninfac (LAD = L \\ Ad for the 8 columns at
+    once + dpr1fact), 4 x (fwblkslv, fwdpr1, ./Ld, bwdpr1, bwblkslv)."""
+    from sedumi_amd import problem
+    P, L, ADA, d, ud, rhs, sym, denseA, smult = build_lpdense()
+    plan = make_plan(device, P, L, ADA, problem.lorentz_pattern(P), d, ud, rhs, None)
+    plan.set_dense(sym)
+    plan.upload("ad", np.asarray(denseA.todense()).ravel(order="F"))
+    host = [False]
+
+    def step():
+        plan.getada()
+        plan.blkchol(PARS, True)
+        host[0] = plan.deninfac(smult, 500.0) or host[0]
+        for _ in range(NSOLVE):
+            plan.ldlsolve()
+    el = time_steps(plan, step, args.steps, args.warmup)
+    ph = np.zeros(4)
+    nprof = min(args.steps, 20)
+    for _ in range(nprof):
+        plan.timer_begin(0); plan.getada(); plan.timer_end(0)
+        plan.timer_begin(1); plan.blkchol(PARS, True); plan.timer_end(1)
+        t0 = time.perf_counter(); plan.deninfac(smult, 500.0); plan.sync(); ph[2] += 1e3 * (time.perf_counter() - t0)
+        plan.timer_begin(3)
+        for _ in range(NSOLVE):
+            plan.ldlsolve()
+        plan.timer_end(3)
+        ph[[0, 1, 3]] += [plan.timer_ms(0), plan.timer_ms(1), plan.timer_ms(3)]
+    ph /= nprof
+    print(json.dumps({
+        "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": args.steps / el, "unit": "IPM iters/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{P.name}: sparse LP with dense columns (SURVEY.md 8(d) config 3 variant), m={P.m}, nnz(L)={plan.nnzL}, "
+                               f"nsuper={np.asarray(L['xsuper']).size - 1}; unit = getada, blkchol, deninfac (sparse fwblkslv x 8 + dpr1fact), "
+                               f"{NSOLVE}x(fwblkslv, fwdpr1, ./Ld, bwdpr1, bwblkslv)", "parallelism": "single GPU"},
+        "roofline": None, "cpu_baseline": None,
+        "phases_ms_per_step": {"ada_ms": ph[0], "factor_ms": ph[1], "deninfac_ms_host_timed": ph[2], "solves_ms": ph[3],
+                               "dpr1fact_on_host_fallback": bool(host[0])}}), flush=True)
+    plan.close()
+
+
 def make_plan(device, P, L, ADA, Q, d, ud, rhs, qpr):
     from sedumi_amd.plan import Plan
     plan = Plan(device)
@@ -371,7 +438,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="control07",
                     help="control07 (default: examples/control07.mat, BASELINE configs[1]) | control07_like (synthetic, same shape) | "
-                         "nb (configs[2] shape) | maxcut<n> (configs[3]) | blockdiag[:nblk:n:mper] (configs[4])")
+                         "nb (configs[2] shape) | lpdense (configs[2] dense-column variant) | maxcut<n> (configs[3]) | blockdiag[:nblk:n:mper] (configs[4])")
     ap.add_argument("--shard", default="auto", choices=["auto", "replicas", "columns"],
                     help="N>1: columns (auto for single-supernode workloads) = ONE unit per step, ADA' column panels per rank + RCCL "
                          "all-gather, factor/solves replicated; replicas = independent units per rank (weak scaling, no collective)")
@@ -400,6 +467,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     coll_dev = torch.device("cpu") if share else torch.device("cuda", local_rank)
 
+    if args.workload == "lpdense":
+        return bench_lpdense(args, local_rank)
     if args.workload.startswith("blockdiag") and (world > 1 or args.shard != "auto"):
         return bench_subtrees(args, rank, local_rank, world, torch, dist, coll_dev)
     shard_cols = world > 1 and args.shard in ("auto", "columns")

@@ -84,6 +84,13 @@ int sdm_choltmpsiz(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, sdm_int ns
 int sdm_cholsplit(sdm_int m, const sdm_int *Ljc, sdm_int nsuper, const sdm_int *xsuper,
                   double cachsz_kb, sdm_int *split);
 
+/* [perm, dz] = incorder(At, Ajc1, ifirst)          incorder.c:216-330 -> :140-209  (structure prep of getada3,
+ * sedumi.m:378, and of the dense columns, symbcholden.m:50).  Bit-exact with the reference's greedy
+ * scan, in O((nnz + m) log m) instead of O(m^2).  perm[m] 0-based; dzjc[m+1]; dzir (row subscripts of At, in the order
+ * the columns list them) needs min(N - first, nonzeros in range) entries.  Ajc1 NULL = whole columns (first = 0). */
+int sdm_incorder(sdm_int N, sdm_int m, const sdm_int *Atjc, const sdm_int *Atir, const sdm_int *Ajc1, sdm_int first,
+                 sdm_int *perm, sdm_int *dzjc, sdm_int *dzir);
+
 /* --- ADA' ------------------------------------------------------------------ */
 
 /* ADA = getada1(ADA, A, Ajc2, perm, d, blkstart)        getada1.c:161-261
@@ -293,6 +300,25 @@ int sdm_plan_timer_ms(sdm_plan *p, int slot, float *ms);
 int sdm_plan_kprof_enable(sdm_plan *p, int on);
 int sdm_plan_kprof_get(sdm_plan *p, const char *kernel, sdm_int *calls, double *total_ms);
 int sdm_plan_kprof_summary(sdm_plan *p, char *buf, sdm_int buflen);
+
+/* Make a factor computed elsewhere resident: Lpr[nnz(L)] on the pattern given to sdm_plan_set_chol, d[m] = L.d
+ * (NULL: only the solves without ./d are meaningful).  No pivot report (skip / add) is attached to it. */
+int sdm_plan_load_factor(sdm_plan *p, const double *Lpr, const double *d);
+
+/* Resident dense-column unit (deninfac.m:58-94; SURVEY.md 8(d): "+ sparse fwblkslv + dpr1fact + 4 x (fwdpr1+bwdpr1)").
+ * set_dense (once per solve, after set_chol): the symbolic data of symbcholden.m:43-55 -- pattern of LAD = symLden.LAD
+ * (m x nden CSC), dz (cumulative dzjc[nden+1], dzir), colperm = symLden.perm-1, first = symLden.first-1.
+ * Every iteration: upload the dense columns Ad (m x nden column major, deninfac.m:58-59) into plan buffer "ad", then
+ * sdm_plan_deninfac(smult[nden] (deninfac.m:60-62), maxuden): LAD = L \ Ad(perm,:) for all columns in one set of
+ * launches, then dpr1fact on the device (scan form of the recurrences; *host_fallback = 1 when a postponed pivot, a
+ * dependent row or a Lorentz trace column sent it through the general host algorithm).  Afterwards sdm_plan_ldlsolve
+ * is the whole wrapPcg.m:56-59 body: fwblkslv, fwdpr1, ./Ld, bwdpr1, bwblkslv.  sdm_plan_lden downloads the factors
+ * (layout of sdm_dpr1fact; buffers sized pnnz = sum_k dzjc[k+1], Ld[m]). */
+int sdm_plan_set_dense(sdm_plan *p, sdm_int nden, const sdm_int *LADjc, const sdm_int *LADir, const sdm_int *dzjc,
+                       const sdm_int *dzir, const sdm_int *colperm, const sdm_int *first);
+int sdm_plan_deninfac(sdm_plan *p, const double *smult, double maxuden, int *host_fallback);
+int sdm_plan_lden(sdm_plan *p, sdm_int *betajc, double *beta, double *pv, sdm_int *pivperm, sdm_int *npivperm,
+                  sdm_int *dopiv, double *Ld);
 
 /* The solves apply the 256-column diagonal super-blocks of L as explicit inverses (sdm_solve.hip) unless a block's
  * growth  max|inv(L_PP)| * max|L_PP|  exceeds growth_max (default 1e4): such a block is solved by substitution like

@@ -111,6 +111,9 @@ static DevBuf<double> *plan_buf(sdm_plan *p, const char *name) {
   if (s == "qpr") return &p->ada.qpr;
   if (s == "q1") return &p->ada.q1;
   if (s == "q2") return &p->ada.q2;
+  if (s == "ad") return &p->dense.ad;       // dense columns Ad (m x nden, column major; deninfac.m:58-59)
+  if (s == "lad") return &p->dense.lad;     // LAD = L \ Ad(perm,:) of the last sdm_plan_deninfac
+  if (s == "dden") return &p->dense.dden;   // Ld of the last sdm_plan_deninfac
   throw std::runtime_error("unknown plan buffer: " + s);
 }
 void *sdm_plan_devptr(sdm_plan *p, const char *name, sdm_int *nelem) {
@@ -183,7 +186,16 @@ int sdm_plan_blkchol(sdm_plan *p, const sdm_cholpars *pars, int use_absd) {
   sdm_cholpars q = {1e-12, 5e2, 1e-20};           // blkchol.c:292-294 defaults
   if (pars) q = *pars;
   if (q.abstol < 0.0) q.abstol = 0.0;              // blkchol.c:303
+  p->dense.factored = false;                        // the dense-column factors belong to the previous L, d
   chol_factor(p, q.canceltol, q.maxu, q.abstol, use_absd);
+  SDM_CATCH
+}
+int sdm_plan_load_factor(sdm_plan *p, const double *Lpr, const double *d) {
+  SDM_TRY
+  if (!p->has_chol) throw std::runtime_error("sdm_plan_load_factor: no symbolic factor set");
+  SDM_HIP_CHECK(hipSetDevice(p->device));
+  p->dense.factored = false;
+  chol_load_factor(p, Lpr, d);
   SDM_CATCH
 }
 int sdm_plan_pivots(sdm_plan *p, sdm_int *nskip, sdm_int *skip_idx, double *skip_val, sdm_int *nadd,
@@ -234,6 +246,38 @@ int sdm_plan_solve_stats(sdm_plan *p, sdm_int *nblocks, sdm_int *nbad, double *m
   SDM_TRY
   if (!p->has_chol) throw std::runtime_error("sdm_plan_solve_stats: no symbolic factor set");
   solve_stats(p, nblocks, nbad, max_growth);
+  SDM_CATCH
+}
+// ---- resident dense-column unit (deninfac.m:58-94)
+int sdm_plan_set_dense(sdm_plan *p, sdm_int nden, const sdm_int *LADjc, const sdm_int *LADir, const sdm_int *dzjc, const sdm_int *dzir,
+                       const sdm_int *colperm, const sdm_int *first) {
+  SDM_TRY
+  if (!p->has_chol) throw std::runtime_error("sdm_plan_set_dense: call sdm_plan_set_chol first");
+  SDM_HIP_CHECK(hipSetDevice(p->device));
+  dense_set(p, nden, LADjc, LADir, dzjc, dzir, colperm, first);
+  SDM_CATCH
+}
+int sdm_plan_deninfac(sdm_plan *p, const double *smult, double maxuden, int *host_fallback) {
+  SDM_TRY
+  if (p->capturing) throw std::runtime_error("sdm_plan_deninfac synchronises (it reads the stability flag): not inside a graph capture");
+  dense_factor(p, smult, maxuden, host_fallback);
+  SDM_CATCH
+}
+int sdm_plan_lden(sdm_plan *p, sdm_int *betajc, double *beta, double *pv, sdm_int *pivperm, sdm_int *npivperm, sdm_int *dopiv, double *Ld) {
+  SDM_TRY
+  DensePlan &D = p->dense;
+  if (!D.factored) throw std::runtime_error("sdm_plan_lden: no dense-column factor resident");
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  const sdm_int nden = D.nden, nb = D.betajc[nden], np = D.permoff[nden];
+  for (sdm_int k = 0; k <= nden; k++) betajc[k] = D.betajc[k];
+  for (sdm_int k = 0; k < nden; k++) dopiv[k] = D.dopiv[k];
+  if (nb) SDM_HIP_CHECK(hipMemcpy(beta, D.beta.p, nb * sizeof(double), hipMemcpyDeviceToHost));
+  if (D.pnnz) SDM_HIP_CHECK(hipMemcpy(pv, D.p.p, D.pnnz * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<int> pp((size_t)std::max<sdm_int>(np, 1));
+  if (np) SDM_HIP_CHECK(hipMemcpy(pp.data(), D.d_pivperm.p, np * sizeof(int), hipMemcpyDeviceToHost));
+  for (sdm_int i = 0; i < np; i++) pivperm[i] = pp[i];
+  *npivperm = np;
+  SDM_HIP_CHECK(hipMemcpy(Ld, D.dden.p, p->chol.m * sizeof(double), hipMemcpyDeviceToHost));
   SDM_CATCH
 }
 // ---- hipGraph capture of a launch-bound sequence of plan calls (e.g. one whole iteration unit): everything the plan

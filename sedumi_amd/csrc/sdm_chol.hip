@@ -1092,8 +1092,16 @@ void chol_extract(sdm_plan *P, double *d_Lpr_out) {
              (int64_t)C.nnzL);
 }
 
-void chol_load_factor(sdm_plan *P, const double *h_Lpr) {
+void chol_load_factor(sdm_plan *P, const double *h_Lpr, const double *h_d) {
   CholPlan &C = P->chol;
+  if (h_d) {                                                         // an externally computed factor with its d: no pivot report
+    const int m = (int)C.m;
+    SDM_HIP_CHECK(hipMemcpyAsync(C.d.p, h_d, (size_t)m * sizeof(double), hipMemcpyHostToDevice, P->stream));
+    SDM_HIP_CHECK(hipMemsetAsync(C.pivstat.p, 0, (size_t)m * sizeof(int), P->stream));
+    SDM_HIP_CHECK(hipMemsetAsync(C.lb.p, 0, (size_t)m * sizeof(double), P->stream));
+    SDM_KLAUNCH(P, k_dsolve, dim3((m + 255) / 256), dim3(256), 0, C.dsolve.p, C.d.p, m);
+    SDM_HIP_CHECK(hipStreamSynchronize(P->stream));                  // h_d may be pageable
+  }
   DevBuf<double> tmp;
   tmp.upload(h_Lpr, (size_t)C.nnzL);
   SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), P->stream));    // padding rows / Schur parts: defined

@@ -38,6 +38,8 @@ struct DevBuf {
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
   ~DevBuf() { release(); }
   void release() {
     if (p) (void)hipFree(p);
@@ -65,6 +67,8 @@ struct HostFlag {
   HostFlag() = default;
   HostFlag(const HostFlag &) = delete;
   HostFlag &operator=(const HostFlag &) = delete;
+  HostFlag(HostFlag &&o) noexcept : host(o.host) { o.host = nullptr; }
+  HostFlag &operator=(HostFlag &&o) noexcept { if (this != &o) { if (host) (void)hipHostFree(host); host = o.host; o.host = nullptr; } return *this; }
   ~HostFlag() { if (host) (void)hipHostFree(host); }
   void ensure() {
     if (host) return;
@@ -227,8 +231,26 @@ struct KProf {
 };
 }  // namespace sdm
 
+namespace sdm {
+// resident dense-column unit: the dense columns of A re-enter the normal equations as a product of rank-1 factors
+// (deninfac.m:58-94); symbolic data once per solve (dense_set), LAD = L \ Ad and the product-form factors every iteration
+struct DensePlan {
+  sdm_int nden = 0, dznnz = 0, pnnz = 0;
+  bool active = false, factored = false;
+  std::vector<sdm_int> LADjc, LADir, dzjc, dzir, colperm, first;
+  std::vector<int64_t> poff, betajc, permoff;
+  std::vector<int> dopiv;
+  std::vector<std::vector<int>> later;            // per factor k: the later columns its inverse is applied to (first <= k)
+  DevBuf<int> d_dzir, d_colperm, d_pivperm, d_dopiv, d_later;
+  DevBuf<int64_t> d_dzjc, d_poff, d_betajc, d_permoff;
+  DevBuf<double> ad, lad, wvb, p, beta, dgat, smult, dden;
+  HostFlag need_host;                             // raised by k_dpr1_factor: a column needs the general (host) path
+};
+}  // namespace sdm
+
 struct sdm_plan {
   int device = 0;
+  sdm::DensePlan dense;
   sdm::KProf kprof;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -263,7 +285,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
 void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd);
 int chol_wait_timeouts(sdm_plan *P);   // non-zero: a spin inside a panel launch of this plan gave up since the last call (call after a stream sync)
 void chol_extract(sdm_plan *P, double *d_Lpr_out);           // device pointer, nnzL doubles
-void chol_load_factor(sdm_plan *P, const double *h_Lpr);     // host L values -> fronts (for stand-alone solves)
+void chol_load_factor(sdm_plan *P, const double *h_Lpr, const double *h_d = nullptr);   // host L values (and d) -> fronts (stand-alone solves)
 void vec_gather(sdm_plan *P, double *dst, const double *src, bool forward);  // dst[k]=src[perm[k]] / dst[perm[k]]=src[k]
 void vec_divd(sdm_plan *P, double *v);
 FrontTab front_tab(CholPlan &C);
@@ -272,6 +294,17 @@ void solve_build(sdm_plan *P);                      // host tables + buffers (en
 void solve_prepare(sdm_plan *P);                    // after a factorisation: diagonal super-block inverses, premultiplied block rows
 void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode);   // mode bits 1 fw | 2 ./d | 4 bw
 void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growth);
+void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *y, int64_t y_stride, double *wv, int nrhs);
+// sdm_dpr1.hip: resident dense-column unit (deninfac.m:58-94)
+void dense_set(sdm_plan *P, sdm_int nden, const sdm_int *LADjc, const sdm_int *LADir, const sdm_int *dzjc, const sdm_int *dzir,
+               const sdm_int *colperm, const sdm_int *first);
+void dense_factor(sdm_plan *P, const double *smult, double maxuden, int *host_fallback);
+void dense_prodform(sdm_plan *P, double *y, bool with_divide);       // y <- bwdpr1(Lden, fwdpr1(Lden, y) ./ Ld)   (permuted order)
+// sdm_dense.hip
+void dpr1fact_host(sdm_int m, sdm_int n, const sdm_int *Xjc, const sdm_int *Xir, const double *Xpr, double *lab,
+                   const sdm_int *dzjc, const sdm_int *dzir, const sdm_int *colperm, const sdm_int *firstpiv,
+                   const double *smult, double maxu, std::vector<sdm_int> &betajc, std::vector<double> &beta,
+                   std::vector<double> &p, std::vector<sdm_int> &pivperm, std::vector<int> &ordered);
 // sdm_ada.hip
 void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_int *Air, const double *Apr,
                const sdm_int *Ajc_psd, sdm_int lpN, sdm_int lorN, const sdm_int *lorNL, sdm_int sdpN,

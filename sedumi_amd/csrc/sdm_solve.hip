@@ -469,11 +469,15 @@ __device__ __forceinline__ void bad_block_arrive(const double *Fs, int ld, int k
 }
 
 // ================================================================ forward sweep
+// several right-hand sides side by side (blockIdx.z): element strides of the right-hand sides, of the result, of the
+// update-vector scratch and of the fallback tickets (all 0 for a single right-hand side)
+struct FwBatch { int64_t src, y, wv, cnt; };
 // assembly of a front's right-hand side (levels above the leaves): own entries through perm, children's update vectors
 __global__ void __launch_bounds__(ST)
-k_sfw_init(FrontTab tab, const int *list, double *wv, const double *src, const int *perm, const double *y) {
+k_sfw_init(FrontTab tab, const int *list, double *wv, const double *src, const int *perm, const double *y, FwBatch bt) {
   const int s = list[blockIdx.x];
   const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s];
+  wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; if (src) src += (int64_t)blockIdx.z * bt.src;
   double *a = wv + tab.woff[s];
   const int tid = threadIdx.x;
   for (int i = tid; i < ms; i += ST) a[i] = i < ns ? (src ? src[perm[first + i]] : y[first + i]) : 0.0;
@@ -525,13 +529,15 @@ __device__ __forceinline__ double slab_consume(const sdm_double2 (&v)[NLD], int 
 // y_P = inv(L_PP) a_P for every super-block of every front of a level (bad blocks: copy, then substitution)
 __global__ void __launch_bounds__(ST)
 k_sfw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, const double *wv, const double *src,
-           const int *perm, double *y, const unsigned long long *sb_g, int *sb_cnt, double thr, int gather) {
+           const int *perm, double *y, const unsigned long long *sb_g, int *sb_cnt, double thr, int gather, FwBatch bt) {
   __shared__ double xs[SBW], red[(ST / 8) * SROWS], wsub[SBW];
   __shared__ double Sd[64 * TP];
   const int s = list[blockIdx.y];
   const int ns = tab.ns[s], first = tab.first[s];
   const int r0 = SROWS * blockIdx.x;
   if (r0 >= ns) return;
+  wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; if (src) src += (int64_t)blockIdx.z * bt.src;
+  sb_cnt += (int64_t)blockIdx.z * bt.cnt;
   const int Pb = r0 / SBW, c0 = Pb * SBW, nb = min(SBW, ns - c0);
   const int sb = tab.sboff[s] + Pb;
   const int tid = threadIdx.x;
@@ -558,13 +564,14 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
 // vector passed to the parent)
 __global__ void __launch_bounds__(ST)
 k_sfw_step(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, double *wv, double *y,
-           const unsigned long long *sb_g, int *sb_cnt, double thr, int Pb, int first_assign) {
+           const unsigned long long *sb_g, int *sb_cnt, double thr, int Pb, int first_assign, FwBatch bt) {
   __shared__ double xs[SBW], red[(ST / 8) * SROWS], wsub[SBW];
   __shared__ double Sd[64 * TP];
   const int s = list[blockIdx.y];
   const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s], ld = tab.ld[s];
   const int c0 = Pb * SBW;
   if (c0 >= ns) return;
+  wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; sb_cnt += (int64_t)blockIdx.z * bt.cnt;
   const int nb = min(SBW, ns - c0), ra = c0 + SBW;
   const int slabsA = ns > ra ? (ns - ra + SROWS - 1) / SROWS : 0;
   const int ebase = ns & ~1;
@@ -785,25 +792,55 @@ void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growt
   if (max_growth) *max_growth = mx;
 }
 
-void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode) {
+// forward sweeps of nrhs right-hand sides side by side (grid.z): rhs + z*rhs_stride -> y + z*y_stride (permuted order);
+// wv = update-vector scratch of wsize doubles per right-hand side
+void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *y, int64_t y_stride, double *wv, int nrhs) {
   CholPlan &C = P->chol;
   FrontTab tab = front_tab(C);
-  const size_t mb = (size_t)C.m * sizeof(double);
+  const double thr = C.growth_used;
+  if ((size_t)C.nsbtot * (size_t)nrhs > C.sb_cnt.n) throw std::runtime_error("solve_fw_batch: ticket array too small for this many right-hand sides");
+  FwBatch bt;
+  bt.src = nrhs > 1 ? rhs_stride : 0; bt.y = nrhs > 1 ? y_stride : 0; bt.wv = nrhs > 1 ? C.wsize : 0; bt.cnt = nrhs > 1 ? C.nsbtot : 0;
+  for (int l = 0; l < C.nlevels; l++) {
+    const SolveLevel &L = C.slev[l];
+    const int *list = C.d_levlist.p + C.levptr[l];
+    const int gather = L.children ? 0 : 1;
+    if (!gather) SDM_KLAUNCH(P, k_sfw_init, dim3(L.nfronts, 1, nrhs), dim3(ST), 0, tab, list, wv, rhs, C.d_perm.p, y, bt);
+    SDM_KLAUNCH(P, k_sfw_diag, dim3((L.maxns + SROWS - 1) / SROWS, L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, wv, rhs,
+                C.d_perm.p, y, C.sb_g.p, C.sb_cnt.p, thr, gather, bt);
+    for (int Pb = 0; Pb < (int)L.maxslab_fw.size(); Pb++)
+      if (L.maxslab_fw[Pb] > 0)
+        SDM_KLAUNCH(P, k_sfw_step, dim3(L.maxslab_fw[Pb], L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, wv, y, C.sb_g.p,
+                    C.sb_cnt.p, thr, Pb, (gather && Pb == 0) ? 1 : 0, bt);
+  }
+}
+
+// backward sweep of the vector in ywork (permuted order); divide: ./d on the way in; dscale = that d
+static void solve_bw_inplace(sdm_plan *P, double *yout, const double *dscale) {
+  CholPlan &C = P->chol;
+  FrontTab tab = front_tab(C);
   double *y = P->ywork.p;
   const double thr = C.growth_used;
+  for (int l = C.nlevels - 1; l >= 0; l--) {
+    const SolveLevel &L = C.slev[l];
+    const int *list = C.d_levlist.p + C.levptr[l];
+    const int ncs = (L.maxns + SROWS - 1) / SROWS;
+    SDM_KLAUNCH(P, k_sbw_init, dim3(ncs, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, dscale, C.sb_g.p, C.sb_cnt.p, thr);
+    for (int Q = L.nsb - 1; Q >= 1; Q--)
+      SDM_KLAUNCH(P, k_sbw_step, dim3(Q * (SBW / SROWS), L.nfronts), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, y, C.sb_g.p, C.sb_cnt.p, thr, Q);
+    SDM_KLAUNCH(P, k_sbw_diag, dim3(ncs, L.nfronts), dim3(ST), 0, C.S.p, tab, list, y, C.xfin.p, yout, C.d_perm.p, C.sb_g.p, thr);
+  }
+}
+
+void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode) {
+  CholPlan &C = P->chol;
+  const size_t mb = (size_t)C.m * sizeof(double);
+  double *y = P->ywork.p;
+  // with a resident dense-column factor (sdm_plan_deninfac) the complete solve is wrapPcg.m:56-59:
+  //   p = fwdpr1(Lden, L \ r(perm)) ;  y = p ./ L.d ;  y(perm) = L' \ bwdpr1(Lden, y)
+  const bool dense = (mode == 7) && P->dense.factored;
   if (mode & 1) {
-    for (int l = 0; l < C.nlevels; l++) {
-      const SolveLevel &L = C.slev[l];
-      const int *list = C.d_levlist.p + C.levptr[l];
-      const int gather = L.children ? 0 : 1;
-      if (!gather) SDM_KLAUNCH(P, k_sfw_init, dim3(L.nfronts), dim3(ST), 0, tab, list, C.wvec.p, rhs, C.d_perm.p, y);
-      SDM_KLAUNCH(P, k_sfw_diag, dim3((L.maxns + SROWS - 1) / SROWS, L.nfronts), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, C.wvec.p, rhs,
-                  C.d_perm.p, y, C.sb_g.p, C.sb_cnt.p, thr, gather);
-      for (int Pb = 0; Pb < (int)L.maxslab_fw.size(); Pb++)
-        if (L.maxslab_fw[Pb] > 0)
-          SDM_KLAUNCH(P, k_sfw_step, dim3(L.maxslab_fw[Pb], L.nfronts), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, C.wvec.p, y, C.sb_g.p,
-                      C.sb_cnt.p, thr, Pb, (gather && Pb == 0) ? 1 : 0);
-    }
+    solve_fw_batch(P, rhs, 0, y, 0, C.wvec.p, 1);
     if (!(mode & 4)) {
       if (mode & 2) vec_divd(P, y);
       SDM_HIP_CHECK(hipMemcpyAsync(yout, y, mb, hipMemcpyDeviceToDevice, P->stream));
@@ -812,15 +849,11 @@ void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode) {
   } else {
     SDM_HIP_CHECK(hipMemcpyAsync(y, rhs, mb, hipMemcpyDeviceToDevice, P->stream));
   }
-  for (int l = C.nlevels - 1; l >= 0; l--) {
-    const SolveLevel &L = C.slev[l];
-    const int *list = C.d_levlist.p + C.levptr[l];
-    const int ncs = (L.maxns + SROWS - 1) / SROWS;
-    SDM_KLAUNCH(P, k_sbw_init, dim3(ncs, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p,
-                (mode & 2) ? (const double *)C.dsolve.p : (const double *)nullptr, C.sb_g.p, C.sb_cnt.p, thr);
-    for (int Q = L.nsb - 1; Q >= 1; Q--)
-      SDM_KLAUNCH(P, k_sbw_step, dim3(Q * (SBW / SROWS), L.nfronts), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, y, C.sb_g.p, C.sb_cnt.p, thr, Q);
-    SDM_KLAUNCH(P, k_sbw_diag, dim3(ncs, L.nfronts), dim3(ST), 0, C.S.p, tab, list, y, C.xfin.p, yout, C.d_perm.p, C.sb_g.p, thr);
+  if (dense) {
+    dense_prodform(P, y, /*with_divide=*/true);                      // fwdpr1, ./ Ld, bwdpr1 in one launch
+    solve_bw_inplace(P, yout, nullptr);
+  } else {
+    solve_bw_inplace(P, yout, (mode & 2) ? (const double *)C.dsolve.p : (const double *)nullptr);
   }
 }
 

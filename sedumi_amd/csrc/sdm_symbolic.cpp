@@ -14,6 +14,7 @@
 #include "../../include/sedumi_hip.h"
 #include <algorithm>
 #include <cmath>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -560,6 +561,72 @@ int sdm_cholsplit(sdm_int m, const sdm_int *Ljc, sdm_int nsuper, const sdm_int *
         else { split[j] = k - j; j = k; used = 2 * mk; }
       }
       if (j < nextk) split[j] = nextk - j;
+    }
+    return 0;
+  } catch (const std::exception &e) { set_error(e.what()); return 1; }
+}
+
+// [perm, dz] = incorder(At, Ajc1, ifirst)                                    incorder.c:140-209
+// Greedy ordering of the columns of At(first:end, :): step k takes the remaining column with the fewest subscripts not
+// yet covered (ties: the one standing EARLIEST in the current perm array, which the swaps of earlier steps have
+// rearranged -- incorder.c:172-182), dz(:,k) = its newly covered subscripts in the order they appear in the column.
+// The reference rescans all remaining columns at every step (O(m^2)); here the remaining columns sit in an ordered set
+// keyed on (remaining length, position in perm), updated when a covered subscript shortens a column and when a swap
+// moves one: O((nnz + m) log m), same output bit for bit.
+// Ajc1 = start offsets of the rows >= first per column (NULL: column starts, first = 0).  dzir needs room for
+// min(N - first, number of nonzeros in range) entries.
+int sdm_incorder(sdm_int N, sdm_int m, const sdm_int *Atjc, const sdm_int *Atir, const sdm_int *Ajc1, sdm_int first,
+                 sdm_int *perm, sdm_int *dzjc, sdm_int *dzir) {
+  try {
+    if (first < 0 || first > N) throw std::runtime_error("incorder: first subscript out of range");
+    const Int lenud = N - first;
+    std::vector<Int> beg(m), len(m), pos(m);
+    for (Int j = 0; j < m; j++) {
+      beg[j] = Ajc1 ? Ajc1[j] : Atjc[j];
+      if (beg[j] < Atjc[j] || beg[j] > Atjc[j + 1]) throw std::runtime_error("incorder: Ajc1 outside its column");
+      len[j] = Atjc[j + 1] - beg[j];
+      perm[j] = j; pos[j] = j;
+    }
+    // A = At(first:end,:)' : for every subscript the columns that contain it (spPartTransp, incorder.c:78-118)
+    std::vector<Int> Ajc((size_t)lenud + 1, 0), Air;
+    for (Int j = 0; j < m; j++)
+      for (Int t = beg[j]; t < Atjc[j + 1]; t++) {
+        if (Atir[t] < first || Atir[t] >= N) throw std::runtime_error("incorder: subscript outside first:end");
+        Ajc[(size_t)(Atir[t] - first) + 1]++;
+      }
+    for (Int i = 0; i < lenud; i++) Ajc[i + 1] += Ajc[i];
+    Air.resize((size_t)Ajc[lenud]);
+    { std::vector<Int> nxt(Ajc.begin(), Ajc.end() - 1);
+      for (Int j = 0; j < m; j++) for (Int t = beg[j]; t < Atjc[j + 1]; t++) Air[(size_t)nxt[Atir[t] - first]++] = j; }
+    std::set<std::pair<Int, Int>> rem;                          // (remaining length, position in perm) of the columns not yet taken
+    for (Int j = 0; j < m; j++) rem.insert({len[j], j});
+    std::vector<char> covered((size_t)std::max<Int>(lenud, 1), 0);
+    dzjc[0] = 0;
+    for (Int k = 0; k < m; k++) {
+      const std::pair<Int, Int> best = *rem.begin();            // fewest uncovered subscripts, earliest position
+      rem.erase(rem.begin());
+      const Int kmin = best.second, permk = perm[kmin];
+      if (kmin != k) {                                          // the swap of incorder.c:180-182
+        const Int other = perm[k];
+        rem.erase({len[other], k});
+        perm[kmin] = other; pos[other] = kmin;
+        rem.insert({len[other], kmin});
+        perm[k] = permk; pos[permk] = k;
+      }
+      Int jnz = dzjc[k];
+      for (Int t = beg[permk]; t < Atjc[permk + 1]; t++) {
+        const Int i = Atir[t] - first;
+        if (!covered[(size_t)i]) { covered[(size_t)i] = 1; dzir[jnz++] = Atir[t]; }
+      }
+      dzjc[k + 1] = jnz;
+      for (Int q = dzjc[k]; q < jnz; q++) {
+        const Int i = dzir[q] - first;
+        for (Int t = Ajc[(size_t)i]; t < Ajc[(size_t)i + 1]; t++) {
+          const Int j = Air[(size_t)t];
+          if (pos[j] > k) { rem.erase({len[j], pos[j]}); len[j]--; rem.insert({len[j], pos[j]}); }
+          else len[j]--;
+        }
+      }
     }
     return 0;
   } catch (const std::exception &e) { set_error(e.what()); return 1; }

@@ -323,6 +323,33 @@ def cholsplit(L, cachsz):
     return split[:m].astype(np.float64).reshape(-1, 1)
 
 
+def incorder(At, Ajc1=None, ifirst=None):
+    """[perm, dz] = incorder(At [, Ajc1, ifirst])   (incorder.c:216-330).  perm 1-based m x 1; dz N x m sparse whose
+    columns list their row subscripts in the order incorder introduced them (NOT sorted: the order is data for
+    finsymbden / getada3 -- the returned csc_matrix keeps it as long as nobody sorts its indices)."""
+    if not sp.issparse(At):
+        raise SdmError("At must be a sparse matrix.")
+    At = sp.csc_matrix(At)
+    N, m = At.shape
+    jc, ir = i64(At.indptr), i64(At.indices)
+    first = 0
+    a1 = None
+    if Ajc1 is not None:
+        a1 = i64(np.asarray(Ajc1, dtype=np.float64))
+        if a1.size < m:
+            raise SdmError("Ajc1 size mismatch")
+        first = int(np.asarray(ifirst).ravel()[0]) - 1
+    nin = int(np.sum(jc[1:] - (a1[:m] if a1 is not None else jc[:-1])))
+    perm = np.zeros(max(m, 1), dtype=np.int64)
+    dzjc = np.zeros(m + 1, dtype=np.int64)
+    dzir = np.zeros(max(min(N - first, nin), 1), dtype=np.int64)
+    check(capi.lib().sdm_incorder(C.c_int64(N), C.c_int64(m), pi(jc), pi(ir), pi(a1) if a1 is not None else None, C.c_int64(first),
+                                  pi(perm), pi(dzjc), pi(dzir)))
+    nnz = int(dzjc[m])
+    dz = sp.csc_matrix((np.ones(nnz), dzir[:nnz].astype(np.int32), dzjc.astype(np.int32)), shape=(N, m))
+    return (perm[:m] + 1).astype(np.float64).reshape(-1, 1), dz
+
+
 def symbchol(ADA, cachsz=512):
     """symbchol.m:62-83 on top of the entry points above (MATLAB glue, host only)."""
     ADA = _csc(ADA)

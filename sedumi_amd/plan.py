@@ -114,6 +114,47 @@ class Plan:
             p0 = np.ascontiguousarray(np.asarray(perm, dtype=np.float64).ravel() - 1, dtype=np.int64)
             check(self._lib.sdm_plan_invcholfac(C.c_void_p(self._p), p0.ctypes.data_as(C.POINTER(C.c_int64))))
 
+    def load_factor(self, LL, Ld=None):
+        """Make an externally computed factor resident: L.L values on the plan's pattern and L.d."""
+        LL = sp.csc_matrix(LL); LL.sort_indices()
+        if not (np.array_equal(LL.indptr, self.L_pattern.indptr) and np.array_equal(LL.indices, self.L_pattern.indices)):
+            raise SdmError("load_factor: L.L does not have the plan's pattern")
+        v = f64(LL.data)
+        dd = f64(Ld) if Ld is not None else None
+        check(self._lib.sdm_plan_load_factor(C.c_void_p(self._p), pf(v), pf(dd) if dd is not None else None))
+
+    def set_dense(self, symLden):
+        """Symbolic data of the dense columns (symbcholden.m:43-55): symLden = {LAD, dz, perm, first} as finsymbden
+        returns it (1-based perm / first).  Call after set_chol."""
+        LAD = sp.csc_matrix(symLden["LAD"]); LAD.sort_indices()
+        dz = symLden["dz"]
+        dz = dz.X if hasattr(dz, "X") else sp.csc_matrix(dz)          # rows in the order incorder introduced them
+        nden = LAD.shape[1]
+        jc, ir = i64(LAD.indptr), i64(LAD.indices)
+        dzjc, dzir = i64(dz.indptr[:nden + 1]), i64(dz.indices)
+        cp = i64(np.asarray(symLden["perm"], dtype=np.float64)) - 1
+        fi = i64(np.asarray(symLden["first"], dtype=np.float64)) - 1
+        check(self._lib.sdm_plan_set_dense(C.c_void_p(self._p), C.c_int64(nden), pi(jc), pi(ir), pi(dzjc), pi(dzir), pi(cp), pi(fi)))
+        self.nden, self._dz_pnnz = nden, int(np.sum(dzjc[1:]))
+
+    def deninfac(self, smult, maxuden=500.0):
+        """LAD = L \\ Ad(perm,:), Lden = dpr1fact(LAD, L.d, symLden, smult, maxuden) on the device (upload "ad" first).
+        Returns True when the general host algorithm had to take over (postponed pivots, dependent rows, ...)."""
+        sm = f64(smult)
+        fb = C.c_int(0)
+        check(self._lib.sdm_plan_deninfac(C.c_void_p(self._p), pf(sm), C.c_double(float(maxuden)), C.byref(fb)))
+        return bool(fb.value)
+
+    def lden(self):
+        """The resident product-form factors as dpr1fact returns them: ({betajc (1-based), beta, p, pivperm, dopiv}, Ld)."""
+        n, pn = self.nden, max(self._dz_pnnz, 1)
+        betajc, dopiv, pivperm = np.zeros(n + 1, dtype=np.int64), np.zeros(n, dtype=np.int64), np.zeros(pn, dtype=np.int64)
+        beta, p, Ld = np.zeros(pn), np.zeros(pn), np.zeros(self.m)
+        npp = C.c_int64(0)
+        check(self._lib.sdm_plan_lden(C.c_void_p(self._p), pi(betajc), pf(beta), pf(p), pi(pivperm), C.byref(npp), pi(dopiv), pf(Ld)))
+        return ({"betajc": (betajc + 1).astype(np.float64), "beta": beta[:betajc[-1]], "p": p[:self._dz_pnnz],
+                 "pivperm": pivperm[:npp.value].astype(np.float64), "dopiv": dopiv.astype(np.float64)}, Ld)
+
     def set_growth_max(self, growth_max):
         """Growth bound above which a diagonal super-block of L is solved by substitution instead of its explicit
         inverse (0 = substitution everywhere); effective from the next blkchol."""

@@ -112,3 +112,51 @@ def test_no_dense_columns_is_identity():
     b = np.arange(6.0).reshape(3, 2)
     Lden = {"betajc": np.array([[1.0]])}                       # deninfac.m:81 -> betajc = 0 in MATLAB is 1 entry: nden = 0
     assert np.array_equal(mex.fwdpr1(Lden, b), b) and np.array_equal(mex.bwdpr1(Lden, b), b)
+
+
+def check_resident_dense_unit(refmex, c, expect_host=None):
+    """The dense-column unit resident on the plan ("+ sparse fwblkslv + dpr1fact + 4 x (fwdpr1+bwdpr1)"):
+    LAD = L \\ Ad(perm,:) for all columns at once, dpr1fact on the device (host algorithm when a column needs the general
+    path), then the whole wrapPcg.m:56-59 body -- against the reference chain fwblkslv(L,Ad,ysymb) -> dpr1fact ->
+    fwblkslv, fwdpr1, ./Ld, bwdpr1, bwblkslv."""
+    from oracle.refmex import RawSparse
+    from sedumi_amd.plan import Plan
+    r = c["sym_ref"]
+    L, Lf, m = c["L"], c["Lf"], c["Ld"].size
+    nden = c["denseA"].shape[1]
+    plan = Plan(0)
+    plan.set_chol(L, sp.identity(m, format="csc"))              # the ADA' pattern plays no role here
+    plan.load_factor(Lf["L"], c["Ld"])
+    plan.set_dense({"LAD": r["LAD"], "dz": r["dz"], "perm": r["perm"], "first": r["first"]})
+    plan.upload("ad", np.asarray(c["denseA"].todense()).ravel(order="F"))
+    host = plan.deninfac(c["smult"], c["maxuden"])
+    if expect_host is not None:
+        assert host == expect_host
+    assert relerr(plan.download("lad", m * nden).reshape(m, nden, order="F"), c["LAD"]) < TOL
+    sref = {"dz": RawSparse(r["dz"]), "perm": r["perm"], "first": r["first"]}
+    Lden_r, Ld_r = refmex.call("dpr1fact", 2, c["LAD"], c["Ld"].reshape(-1, 1), sref, c["smult"].reshape(-1, 1), c["maxuden"])
+    Lden, Ld = plan.lden()
+    assert np.array_equal(Lden["betajc"], np.asarray(Lden_r["betajc"]).ravel())
+    assert np.array_equal(Lden["dopiv"], np.asarray(Lden_r["dopiv"]).ravel())
+    if np.array_equal(Lden["pivperm"], np.asarray(Lden_r["pivperm"]).ravel()):
+        rv = lambda a: np.asarray(a).ravel()
+        assert relerr(Lden["p"], rv(Lden_r["p"])) < TOL and relerr(Lden["beta"], rv(Lden_r["beta"])) < TOL and relerr(Ld, rv(Ld_r)) < TOL
+        # the complete solve of wrapPcg.m:56-59 with the reference's factors
+        Lr_ref = dict(Lden_r); Lr_ref["dz"] = RawSparse(r["dz"])
+        rhs = c["rng"].standard_normal((m, 1))
+        Ldr = np.asarray(Ld_r).reshape(-1, 1)
+        if np.all(Ldr > 0):
+            pvec = refmex.call("fwdpr1", 1, Lr_ref, refmex.call("fwblkslv", 1, Lf, rhs))
+            want = refmex.call("bwblkslv", 1, Lf, refmex.call("bwdpr1", 1, Lr_ref, pvec / Ldr))
+            plan.upload("rhs", rhs.ravel()); plan.ldlsolve()
+            assert relerr(plan.download("y"), want.ravel()) < TOL
+    plan.close()
+    return host
+
+
+@pytest.mark.parametrize("m,n,ndense,seed,zero_d,maxuden,expect_host", [(60, 400, 3, 1, 0, 500.0, False), (120, 900, 6, 2, 0, 500.0, False),
+                                                                        (90, 700, 4, 3, 2, 500.0, True), (80, 600, 5, 4, 0, 1.5, True),
+                                                                        (700, 3000, 4, 5, 0, 500.0, False)])
+def test_resident_dense_column_unit(refmex, glue, m, n, ndense, seed, zero_d, maxuden, expect_host):
+    c = dense_case(refmex, glue, m, n, ndense, seed, zero_d, maxuden)
+    check_resident_dense_unit(refmex, c, expect_host)

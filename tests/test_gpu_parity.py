@@ -509,3 +509,13 @@ def test_getada_gateway_nb_example_on_gpu():
         Ls = dict(L); Ls["L"] = LL
         y = mex.bwblkslv(Ls, mex.fwblkslv(Ls, z["rhs"]) / Ld)
         assert relerr(y.ravel(), z[f"{tag}_y"]) < TOL
+
+
+@pytest.mark.parametrize("m,n,ndense,seed,zero_d,maxuden,expect_host", [(120, 900, 6, 2, 0, 500.0, False), (90, 700, 4, 3, 2, 500.0, True),
+                                                                        (80, 600, 5, 4, 0, 1.5, True), (2000, 20000, 8, 1, 0, 500.0, False)])
+def test_resident_dense_column_unit_on_gpu(refmex, glue, m, n, ndense, seed, zero_d, maxuden, expect_host):
+    """The dense-column leg of the iteration unit resident on the plan: batched sparse-RHS forward
+    solves, dpr1fact as device scans (general cases through the host algorithm), and the whole wrapPcg.m:56-59 body,
+    against the reference chain -- incl. the synthetic config-3 variant LP m=2000, N=20000, 8 dense columns."""
+    from test_dense_columns import check_resident_dense_unit, dense_case
+    check_resident_dense_unit(refmex, dense_case(refmex, glue, m, n, ndense, seed, zero_d, maxuden), expect_host)

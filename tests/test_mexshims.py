@@ -13,7 +13,7 @@ import scipy.sparse as sp
 from helpers import ROOT, TOL, ref_scaling, relerr, spd_pattern
 
 SHIMS = ["getada", "getada1", "getada2", "getada3", "blkchol", "fwblkslv", "bwblkslv", "ordmmdmex", "symfctmex", "choltmpsiz", "cholsplit",
-         "symbfwblk", "finsymbden", "dpr1fact", "fwdpr1", "bwdpr1", "invcholfac"]
+         "symbfwblk", "finsymbden", "dpr1fact", "fwdpr1", "bwdpr1", "invcholfac", "incorder"]
 
 
 @pytest.fixture(scope="module")
@@ -79,6 +79,15 @@ def test_shims_symbolic_bit_exact(refmex, shimmex):
     assert np.array_equal(Lo["L"].indices, Lr["L"].indices) and np.array_equal(Lo["L"].indptr, Lr["L"].indptr)
     assert np.array_equal(shimmex.call("choltmpsiz", 1, Lr), refmex.call("choltmpsiz", 1, Lr))
     assert np.array_equal(shimmex.call("cholsplit", 1, Lr, 0.3), refmex.call("cholsplit", 1, Lr, 0.3))
+
+
+def test_shim_incorder(refmex, shimmex):
+    rng = np.random.default_rng(8)
+    At = sp.random(120, 50, density=0.08, random_state=rng, format="csc"); At.sort_indices()
+    Ajc1 = np.array([At.indptr[j] + np.searchsorted(At.indices[At.indptr[j]:At.indptr[j + 1]], 30) for j in range(50)], dtype=np.float64)
+    for args in ((At,), (At, Ajc1.reshape(-1, 1), 31.0)):
+        (pr, dzr), (po, dzo) = refmex.call("incorder", 2, *args), shimmex.call("incorder", 2, *args)
+        assert np.array_equal(po, pr) and np.array_equal(dzo.indptr, dzr.indptr) and np.array_equal(dzo.indices, dzr.indices)
 
 
 def test_shims_dense_column_path(refmex, glue, shimmex):

@@ -110,3 +110,30 @@ def test_ordering_marker_wraparound_large(refmex):
     assert np.array_equal(mex.ordmmdmex(X), pr)
     Lr, Lo = refmex.call("symfctmex", 1, X, pr), mex.symfctmex(X, pr)
     assert np.array_equal(Lo["perm"], Lr["perm"]) and np.array_equal(Lo["L"].indices, Lr["L"].indices)
+
+
+@pytest.mark.parametrize("N,m,dens,first,seed", [(60, 25, 0.15, 0, 1), (300, 120, 0.05, 40, 2), (90, 90, 0.3, 10, 3), (50, 1, 0.5, 0, 4),
+                                                 (400, 333, 0.01, 100, 5), (30, 40, 0.0, 0, 6), (2000, 900, 0.004, 500, 7)])
+def test_incorder_is_bit_exact(refmex, N, m, dens, first, seed):
+    """[perm, dz] = incorder(At [, Ajc1, ifirst]) (incorder.c:140-209): the greedy order with its position-dependent
+    tie-breaking and the per-column subscript order of dz, from the ordered-set formulation, against the reference's
+    O(m^2) scan -- whole columns (symbcholden.m:50) and the rows from ifirst on (sedumi.m:378)."""
+    from oracle.refmex import RawSparse
+    from sedumi_amd import mex
+    rng = np.random.default_rng(seed)
+    At = sp.random(N, m, density=dens, random_state=rng, format="csc")
+    At.data[:] = 1.0
+    At.sort_indices()
+    if dens > 0:                                   # many equal lengths: the tie-breaking decides
+        At = sp.csc_matrix(sp.hstack([At, At[:, : m // 3]]))[:, :m] if m > 3 else At
+        At.sort_indices()
+    for use_first in (False, True):
+        if use_first:
+            Ajc1 = np.array([At.indptr[j] + np.searchsorted(At.indices[At.indptr[j]:At.indptr[j + 1]], first) for j in range(m)], dtype=np.float64)
+            pr, dzr = refmex.call("incorder", 2, At, Ajc1.reshape(-1, 1), float(first + 1))
+            po, dzo = mex.incorder(At, Ajc1, float(first + 1))
+        else:
+            pr, dzr = refmex.call("incorder", 2, At)
+            po, dzo = mex.incorder(At)
+        assert np.array_equal(po.ravel(), np.asarray(pr).ravel())
+        assert np.array_equal(dzo.indptr, dzr.indptr) and np.array_equal(dzo.indices, dzr.indices)

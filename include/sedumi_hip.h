@@ -301,6 +301,18 @@ int sdm_plan_kprof_enable(sdm_plan *p, int on);
 int sdm_plan_kprof_get(sdm_plan *p, const char *kernel, sdm_int *calls, double *total_ms);
 int sdm_plan_kprof_summary(sdm_plan *p, char *buf, sdm_int buflen);
 
+/* Dense Lorentz columns of getDAtm.m:45 / deninfac.m:61 (host, O(nnz of the dense columns)):
+ * Ad = adendotd(dense, d, sparAd, Ablk, blkstart)   adendotd.c:74-127   values adpr on the pattern (adjc, adir) of Ablk
+ * smult = adenscale(dense, d, blkstart)             adenscale.c:62-80
+ * aden = dense.A(:, dense.l+1:end) as CSC with adenjc[nq+nden+1] absolute offsets; q, dencols 0-based; blkend[k] =
+ * blkstart(q(k)+2)-1; d2 = d.q2 indexed by (global subscript - firstQ), firstQ = blkstart(1)-1. */
+int sdm_adendotd(sdm_int m, sdm_int nq, sdm_int nden, const sdm_int *adjc, const sdm_int *adir, double *adpr,
+                 const sdm_int *sjc, const sdm_int *sir, const double *spr, const sdm_int *adenjc, const sdm_int *adenir,
+                 const double *adenpr, const double *d1, const double *d2, sdm_int firstQ, const sdm_int *q,
+                 const sdm_int *dencols, const sdm_int *blkend);
+int sdm_adenscale(sdm_int nq, sdm_int nden, const double *detd, const sdm_int *q, const sdm_int *dencols,
+                  const sdm_int *blkend, double *smult);
+
 /* Make a factor computed elsewhere resident: Lpr[nnz(L)] on the pattern given to sdm_plan_set_chol, d[m] = L.d
  * (NULL: only the solves without ./d are meaningful).  No pivot report (skip / add) is attached to it. */
 int sdm_plan_load_factor(sdm_plan *p, const double *Lpr, const double *d);

@@ -450,6 +450,53 @@ int sdm_dpr1fact(sdm_int m, sdm_int n, const sdm_int *Xjc, const sdm_int *Xir, c
   SDM_CATCH
 }
 
+// Ad = adendotd(dense, d, sparAd, Ablk, blkstart)      adendotd.c:74-127 (gateway :135-232), called by getDAtm.m:45
+// For the nq dense Lorentz blocks q(k): column k of the result = sparAd(:,k) (the sparse part's a_i[k]'d[k])
+//   + d.q1(q(k)) * (Lorentz-trace column k of dense.A) + sum over the dense norm-bound columns j of block q(k) of
+//   d.q2(dencols(j)) * (their column of dense.A), written on the pattern of Ablk (adjc / adir).
+// aden = dense.A(:, dense.l+1:end): m x (nq + nden) CSC given by adenjc[nq+nden+1] (may start beyond 0), adenir, adenpr.
+// q[nq], dencols[nden] 0-based; blkend[nq] = 0-based one-past-last subscript of block q(k); d2 indexed by the global
+// subscript minus firstQ (the gateway passes d2 - firstQ).
+int sdm_adendotd(sdm_int m, sdm_int nq, sdm_int nden, const sdm_int *adjc, const sdm_int *adir, double *adpr,
+                 const sdm_int *sjc, const sdm_int *sir, const double *spr, const sdm_int *adenjc, const sdm_int *adenir,
+                 const double *adenpr, const double *d1, const double *d2, sdm_int firstQ, const sdm_int *q,
+                 const sdm_int *dencols, const sdm_int *blkend) {
+  SDM_TRY
+  std::vector<double> fwork((size_t)std::max<sdm_int>(m, 1), 0.0);
+  const sdm_int *aden2jc = adenjc + nq;                     // the norm-bound columns follow the nq trace columns
+  sdm_int j = 0, inz = nden > 0 || nq > 0 ? aden2jc[0] : 0;
+  for (sdm_int k = 0; k < nq; k++) {
+    for (sdm_int i = adjc[k]; i < adjc[k + 1]; i++) fwork[adir[i]] = 0.0;
+    for (sdm_int i = sjc[k]; i < sjc[k + 1]; i++) fwork[sir[i]] = spr[i];
+    double dj = d1[q[k]];
+    for (sdm_int i = adenjc[k]; i < adenjc[k + 1]; i++) fwork[adenir[i]] += dj * adenpr[i];
+    for (; j < nden; j++) {
+      const sdm_int c = dencols[j];
+      if (c >= blkend[k]) break;
+      dj = d2[c - firstQ];
+      for (; inz < aden2jc[j + 1]; inz++) fwork[adenir[inz]] += dj * adenpr[inz];
+    }
+    for (sdm_int i = adjc[k]; i < adjc[k + 1]; i++) adpr[i] = fwork[adir[i]];
+  }
+  SDM_CATCH
+}
+
+// smult(norm-bound part) = adenscale(dense, d, blkstart)      adenscale.c:62-80: det(d_k) of the Lorentz block each dense
+// norm-bound column belongs to (deninfac.m:61)
+int sdm_adenscale(sdm_int nq, sdm_int nden, const double *detd, const sdm_int *q, const sdm_int *dencols, const sdm_int *blkend,
+                  double *smult) {
+  SDM_TRY
+  sdm_int j = 0;
+  for (sdm_int k = 0; k < nq; k++) {
+    const double detdk = detd[q[k]];
+    while (j < nden) {
+      if (dencols[j] >= blkend[k]) break;
+      smult[j++] = detdk;
+    }
+  }
+  SDM_CATCH
+}
+
 static void to_int(const sdm_int *dopiv, sdm_int nden, std::vector<int> &v) { v.resize(std::max<sdm_int>(nden, 1)); for (sdm_int k = 0; k < nden; k++) v[k] = (int)dopiv[k]; }
 
 int sdm_fwdpr1(sdm_int m, sdm_int nrhs, sdm_int nden, const sdm_int *dzjc, const sdm_int *dzir, const sdm_int *betajc,

@@ -480,6 +480,58 @@ def bwdpr1(Lden, b):
     return _pr1(False, Lden, b)
 
 
+def _dense_struct(dense, nlor):
+    nl = int(np.asarray(_field(dense, "l", "dense")).ravel()[0])
+    q = i64(np.asarray(_field(dense, "q", "dense"), dtype=np.float64)) - 1
+    cols = np.asarray(_field(dense, "cols", "dense"), dtype=np.float64).ravel()
+    nden = cols.size - nl - q.size
+    if nden < 0:
+        raise SdmError("dense.q size mismatch.")
+    dencols = i64(cols[nl + q.size:]) - 1
+    if q.size and (q.min() < 0 or q.max() >= nlor):
+        raise SdmError("dense.q out of range")
+    return nl, q, dencols, nden
+
+
+def adendotd(dense, d, sparAd, Ablk, blkstart):
+    """Ad = adendotd(dense, d, sparAd, Ablk, blkstart)   (adendotd.c:135-232; getDAtm.m:45)"""
+    d1, d2 = f64(_field(d, "q1", "d")), f64(_field(d, "q2", "d"))
+    nl, q, dencols, nden = _dense_struct(dense, d1.size)
+    A = _csc(_field(dense, "A", "dense"))
+    m = A.shape[0]
+    if A.shape[1] - nl != q.size + nden:
+        raise SdmError("dense.A size mismatch")
+    S, B = _csc(sparAd), _csc(Ablk)
+    if S.shape[1] != q.size or B.shape[1] != q.size:
+        raise SdmError("Size mismatch sparAD")
+    bs = np.asarray(blkstart, dtype=np.float64).ravel()
+    if bs.size != d1.size + 1:
+        raise SdmError("blkstart size mismatch")
+    firstQ = int(bs[0]) - 1
+    blkend = i64(bs[q + 1]) - 1 if q.size else np.zeros(1, dtype=np.int64)
+    out = np.zeros(max(B.nnz, 1), dtype=np.float64)
+    adenjc = i64(A.indptr[nl:])
+    check(capi.lib().sdm_adendotd(C.c_int64(m), C.c_int64(q.size), C.c_int64(nden), pi(i64(B.indptr)), pi(i64(B.indices)), pf(out),
+                                  pi(i64(S.indptr)), pi(i64(S.indices)), pf(f64(S.data)), pi(adenjc), pi(i64(A.indices)), pf(f64(A.data)),
+                                  pf(d1), pf(d2), C.c_int64(firstQ), pi(q if q.size else np.zeros(1, dtype=np.int64)),
+                                  pi(dencols if nden else np.zeros(1, dtype=np.int64)), pi(blkend)))
+    return _same_pattern(B, out[:B.nnz])
+
+
+def adenscale(dense, d, blkstart):
+    """smult = adenscale(dense, d, blkstart)   (adenscale.c:87-160; deninfac.m:61)"""
+    detd = f64(_field(d, "det", "d"))
+    nl, q, dencols, nden = _dense_struct(dense, detd.size)
+    bs = np.asarray(blkstart, dtype=np.float64).ravel()
+    if bs.size != detd.size + 1:
+        raise SdmError("blkstart size mismatch")
+    blkend = i64(bs[q + 1]) - 1 if q.size else np.zeros(1, dtype=np.int64)
+    out = np.zeros(max(nden, 1), dtype=np.float64)
+    check(capi.lib().sdm_adenscale(C.c_int64(q.size), C.c_int64(nden), pf(detd), pi(q if q.size else np.zeros(1, dtype=np.int64)),
+                                   pi(dencols if nden else np.zeros(1, dtype=np.int64)), pi(blkend), pf(out)))
+    return out[:nden].reshape(-1, 1)
+
+
 # ------------------------------------------------------------- next row (SURVEY 8f N1)
 def invcholfac(u, K, perm=None):
     """y = invcholfac(u, K, perm): y(perm,perm) = u'*u per PSD block, u upper triangular   (invcholfac.c:59-168).

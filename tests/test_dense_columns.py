@@ -160,3 +160,34 @@ def check_resident_dense_unit(refmex, c, expect_host=None):
 def test_resident_dense_column_unit(refmex, glue, m, n, ndense, seed, zero_d, maxuden, expect_host):
     c = dense_case(refmex, glue, m, n, ndense, seed, zero_d, maxuden)
     check_resident_dense_unit(refmex, c, expect_host)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_adendotd_and_adenscale_match_reference(refmex, seed):
+    """SURVEY 8f N3, dense-column half of getDAtm.m:45 / deninfac.m:61: dense Lorentz blocks (their trace columns and
+    some dense norm-bound columns) on a synthetic `dense` structure, bit for bit against adendotd.c / adenscale.c."""
+    from sedumi_amd import mex
+    rng = np.random.default_rng(seed)
+    m, lorN = 40, 6
+    qdims = rng.integers(3, 7, lorN)
+    firstQ = 20                                                    # 1-based subscript of the first norm-bound variable = blkstart(1)
+    blkstart = np.concatenate(([firstQ], firstQ + np.cumsum(qdims - 1))).astype(np.float64)
+    dq = np.sort(rng.choice(lorN, 3, replace=False))               # dense Lorentz blocks (0-based)
+    nl = 2
+    dencols = []                                                    # dense norm-bound columns: global subscripts inside the dense blocks
+    for k in dq:
+        lo, hi = int(blkstart[k]), int(blkstart[k + 1])
+        dencols += sorted(rng.choice(np.arange(lo, hi), min(2, hi - lo), replace=False).tolist())
+    nden = len(dencols)
+    cols = np.concatenate((np.arange(1, nl + 1), 10 + dq + 1, np.asarray(dencols))).astype(np.float64)
+    A = sp.random(m, nl + dq.size + nden, density=0.4, random_state=rng, format="csc"); A.sort_indices()
+    dense = {"l": float(nl), "q": (dq + 1.0).reshape(-1, 1), "cols": cols.reshape(-1, 1), "A": A}
+    d = {"q1": 1.0 + rng.random(lorN), "q2": rng.standard_normal(int(blkstart[-1] - firstQ)), "det": 0.5 + rng.random(lorN)}
+    sparAd = sp.random(m, dq.size, density=0.3, random_state=rng, format="csc"); sparAd.sort_indices()
+    Ablk = sp.csc_matrix(((abs(sparAd) + abs(A[:, nl:nl + dq.size]) + sum(abs(A[:, nl + dq.size + j]) @ sp.csc_matrix(([1.0], ([0], [int(np.searchsorted(blkstart[dq + 1], dencols[j], side="right"))])), shape=(1, dq.size)) for j in range(nden))) != 0).astype(np.float64))
+    Ablk.sort_indices()
+    dm = {"q1": d["q1"].reshape(-1, 1), "q2": d["q2"].reshape(-1, 1), "det": d["det"].reshape(-1, 1)}
+    want = refmex.call("adendotd", 1, dense, dm, sparAd, Ablk, blkstart.reshape(-1, 1))
+    got = mex.adendotd(dense, d, sparAd, Ablk, blkstart)
+    assert np.array_equal(got.indices, want.indices) and np.array_equal(got.data, want.data)
+    assert np.array_equal(mex.adenscale(dense, d, blkstart), refmex.call("adenscale", 1, dense, dm, blkstart.reshape(-1, 1)))

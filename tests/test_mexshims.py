@@ -13,7 +13,7 @@ import scipy.sparse as sp
 from helpers import ROOT, TOL, ref_scaling, relerr, spd_pattern
 
 SHIMS = ["getada", "getada1", "getada2", "getada3", "blkchol", "fwblkslv", "bwblkslv", "ordmmdmex", "symfctmex", "choltmpsiz", "cholsplit",
-         "symbfwblk", "finsymbden", "dpr1fact", "fwdpr1", "bwdpr1", "invcholfac", "incorder"]
+         "symbfwblk", "finsymbden", "dpr1fact", "fwdpr1", "bwdpr1", "invcholfac", "incorder", "adendotd", "adenscale"]
 
 
 @pytest.fixture(scope="module")

@@ -313,6 +313,19 @@ int sdm_adendotd(sdm_int m, sdm_int nq, sdm_int nden, const sdm_int *adjc, const
 int sdm_adenscale(sdm_int nq, sdm_int nden, const double *detd, const sdm_int *q, const sdm_int *dencols,
                   const sdm_int *blkend, double *smult);
 
+/* The operators wrapPcg.m:47-66 / loopPcg.m apply around the solves, on the resident plan.  Work
+ * vectors are plan buffers: "xN" (a cone-space vector, N doubles), "psd" (lenud doubles), "rhs" / "y" (m doubles).
+ *   pcg_init   (optional) dense columns of Amul.m:50-56: dense_cols[nden] 0-based rows of At, denseA m x nden column major
+ *   amul(0)    "rhs" = At' "xN" (+ dense.A xN(dense.cols))         Amul.m:46,52
+ *   amul(1)    "xN"  = At "y"   (xN(dense.cols) = dense.A' y)      Amul.m:48,54
+ *   vecsym     PSD part of "xN" symmetrised in place                vecsym.c:50-125
+ *   psdscale   "psd" = psdscale(ud, PSD part of "xN", K, transp): vec(Ld' X Ld) / vec(Ud' X Ud), ud.u = plan buffer "u",
+ *              ud.perm = the pivot order last given to sdm_plan_invcholfac when use_perm != 0   psdscale.m:76-119 */
+int sdm_plan_pcg_init(sdm_plan *p, sdm_int nden, const sdm_int *dense_cols, const double *denseA);
+int sdm_plan_amul(sdm_plan *p, int transp);
+int sdm_plan_vecsym(sdm_plan *p);
+int sdm_plan_psdscale(sdm_plan *p, int transp, int use_perm);
+
 /* Make a factor computed elsewhere resident: Lpr[nnz(L)] on the pattern given to sdm_plan_set_chol, d[m] = L.d
  * (NULL: only the solves without ./d are meaningful).  No pivot report (skip / add) is attached to it. */
 int sdm_plan_load_factor(sdm_plan *p, const double *Lpr, const double *d);

@@ -92,6 +92,9 @@ int sdm_plan_set_ada(sdm_plan *p, sdm_int N, sdm_int m, const sdm_int *Ajc, cons
   if (m != p->chol.m) throw std::runtime_error("sdm_plan_set_ada: m mismatch");
   ada_build(p, N, m, Ajc, Air, Apr, Ajc_psd, K->lpN, K->lorN, K->lorNL, K->sdpN, K->rsdpN, K->sdpNL, qblkstart,
             psd_blkstart, Qjc, Qir, p->ada_jc.data(), p->ada_ir.data());
+  // host copy of At for the operators of sdm_pcg.hip (their device tables are built on first use)
+  p->ada.h_Ajc.assign(Ajc, Ajc + m + 1); p->ada.h_Air.assign(Air, Air + Ajc[m]); p->ada.h_Apr.assign(Apr, Apr + Ajc[m]);
+  p->ada.pcg_ready = false; p->ada.aden_n = 0;
   SDM_CATCH
 }
 
@@ -111,6 +114,8 @@ static DevBuf<double> *plan_buf(sdm_plan *p, const char *name) {
   if (s == "qpr") return &p->ada.qpr;
   if (s == "q1") return &p->ada.q1;
   if (s == "q2") return &p->ada.q2;
+  if (s == "xN") { if (p->ada.xN.n == 0) throw std::runtime_error("buffer xN exists after the first sdm_plan_amul / vecsym / psdscale / pcg_init"); return &p->ada.xN; }
+  if (s == "psd") { if (p->ada.psd.n == 0) throw std::runtime_error("buffer psd exists after sdm_plan_pcg_init"); return &p->ada.psd; }
   if (s == "ad") return &p->dense.ad;       // dense columns Ad (m x nden, column major; deninfac.m:58-59)
   if (s == "lad") return &p->dense.lad;     // LAD = L \ Ad(perm,:) of the last sdm_plan_deninfac
   if (s == "dden") return &p->dense.dden;   // Ld of the last sdm_plan_deninfac
@@ -246,6 +251,32 @@ int sdm_plan_solve_stats(sdm_plan *p, sdm_int *nblocks, sdm_int *nbad, double *m
   SDM_TRY
   if (!p->has_chol) throw std::runtime_error("sdm_plan_solve_stats: no symbolic factor set");
   solve_stats(p, nblocks, nbad, max_growth);
+  SDM_CATCH
+}
+// ---- the operators around the solves in wrapPcg.m / loopPcg.m
+int sdm_plan_pcg_init(sdm_plan *p, sdm_int nden, const sdm_int *dense_cols, const double *denseA) {
+  SDM_TRY
+  if (!p->has_ada) throw std::runtime_error("sdm_plan_pcg_init: no problem data set (sdm_plan_set_ada)");
+  SDM_HIP_CHECK(hipSetDevice(p->device));
+  pcg_set_dense(p, nden, dense_cols, denseA);
+  SDM_CATCH
+}
+int sdm_plan_amul(sdm_plan *p, int transp) {
+  SDM_TRY
+  if (!p->has_ada) throw std::runtime_error("sdm_plan_amul: no problem data set (sdm_plan_set_ada)");
+  pcg_amul(p, transp);
+  SDM_CATCH
+}
+int sdm_plan_vecsym(sdm_plan *p) {
+  SDM_TRY
+  if (!p->has_ada) throw std::runtime_error("sdm_plan_vecsym: no problem data set (sdm_plan_set_ada)");
+  pcg_vecsym(p);
+  SDM_CATCH
+}
+int sdm_plan_psdscale(sdm_plan *p, int transp, int use_perm) {
+  SDM_TRY
+  if (!p->has_ada) throw std::runtime_error("sdm_plan_psdscale: no problem data set (sdm_plan_set_ada)");
+  pcg_psdscale(p, transp, use_perm != 0);
   SDM_CATCH
 }
 // ---- resident dense-column unit (deninfac.m:58-94)

@@ -202,6 +202,13 @@ struct AdaPlan {
   DevBuf<double> ufac;                    // d.u of the scaling (input of sdm_plan_invcholfac), lenud doubles
   DevBuf<int> ic_n, ic_poff, ic_perm; DevBuf<int64_t> ic_off;   // invcholfac block tables
   PinnedInts ic_perm_host; bool ic_has_perm = false;            // staging of the permutation handed to sdm_plan_invcholfac
+  // ---- Amul / vecsym / psdscale (sdm_pcg.hip): host copy of At (set by sdm_plan_set_ada), its transposed
+  // device copy, the cone-space work vectors and the PSD block tables -- built on first use
+  std::vector<sdm_int> h_Ajc, h_Air; std::vector<double> h_Apr;
+  bool pcg_ready = false;
+  DevBuf<int64_t> d_Tjc, pb_off; DevBuf<int> d_Tir, pb_n, pb_herm, pb_poff, pb_items, aden_cols;
+  DevBuf<double> d_Tpr, xN, psd, psdtmp, aden;
+  int pcg_ntiles = 0, aden_n = 0;
   size_t stage1_lds = 0;
   // stage-2 fast path: interleaved (ELL) copy of the PSD nonzeros, rows sorted by length, groups of 64
   bool ell_ok = false;
@@ -295,6 +302,11 @@ void solve_prepare(sdm_plan *P);                    // after a factorisation: di
 void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode);   // mode bits 1 fw | 2 ./d | 4 bw
 void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growth);
 void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *y, int64_t y_stride, double *wv, int nrhs);
+// sdm_pcg.hip: Amul / vecsym / psdscale on the plan
+void pcg_amul(sdm_plan *P, int transp);
+void pcg_set_dense(sdm_plan *P, sdm_int nden, const sdm_int *cols, const double *Aden);
+void pcg_vecsym(sdm_plan *P);
+void pcg_psdscale(sdm_plan *P, int transp, bool with_perm);
 // sdm_dpr1.hip: resident dense-column unit (deninfac.m:58-94)
 void dense_set(sdm_plan *P, sdm_int nden, const sdm_int *LADjc, const sdm_int *LADir, const sdm_int *dzjc, const sdm_int *dzir,
                const sdm_int *colperm, const sdm_int *first);

@@ -114,6 +114,26 @@ class Plan:
             p0 = np.ascontiguousarray(np.asarray(perm, dtype=np.float64).ravel() - 1, dtype=np.int64)
             check(self._lib.sdm_plan_invcholfac(C.c_void_p(self._p), p0.ctypes.data_as(C.POINTER(C.c_int64))))
 
+    # ------------------------------------------- operators around the solves (wrapPcg.m / loopPcg.m)
+    def pcg_init(self, dense_cols=None, denseA=None):
+        """Work vectors "xN" / "psd" and, optionally, the dense columns of Amul.m:50-56 (dense.cols 1-based, dense.A m x nden)."""
+        if dense_cols is None or np.size(dense_cols) == 0:
+            check(self._lib.sdm_plan_pcg_init(C.c_void_p(self._p), C.c_int64(0), None, None))
+        else:
+            c0 = i64(np.asarray(dense_cols, dtype=np.float64)) - 1
+            Ad = f64(np.asarray(denseA.todense() if sp.issparse(denseA) else denseA).ravel(order="F"))
+            check(self._lib.sdm_plan_pcg_init(C.c_void_p(self._p), C.c_int64(c0.size), pi(c0), pf(Ad)))
+
+    def amul(self, transp=0):
+        """transp = 0: "rhs" = At' * "xN" (+ dense part); transp = 1: "xN" = At * "y"   (Amul.m:43-56)."""
+        check(self._lib.sdm_plan_amul(C.c_void_p(self._p), int(transp)))
+
+    def vecsym(self):
+        check(self._lib.sdm_plan_vecsym(C.c_void_p(self._p)))
+
+    def psdscale(self, transp=0, use_perm=False):
+        check(self._lib.sdm_plan_psdscale(C.c_void_p(self._p), int(transp), 1 if use_perm else 0))
+
     def load_factor(self, LL, Ld=None):
         """Make an externally computed factor resident: L.L values on the plan's pattern and L.d."""
         LL = sp.csc_matrix(LL); LL.sort_indices()

@@ -519,3 +519,11 @@ def test_resident_dense_column_unit_on_gpu(refmex, glue, m, n, ndense, seed, zer
     against the reference chain -- incl. the synthetic config-3 variant LP m=2000, N=20000, 8 dense columns."""
     from test_dense_columns import check_resident_dense_unit, dense_case
     check_resident_dense_unit(refmex, dense_case(refmex, glue, m, n, ndense, seed, zero_d, maxuden), expect_host)
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_pcg_operators_on_gpu(refmex, case):
+    """Amul (sparse + dense columns), vecsym and psdscale (real and Hermitian blocks, with and without the
+    pivot order) on the resident plan against vecsym.c and the restated Amul.m / psdscale.m."""
+    from test_pcg_ops import CASES, check_pcg_ops
+    check_pcg_ops(refmex, CASES[case], seed=case)

@@ -439,9 +439,11 @@ def main():
     ap.add_argument("--workload", default="control07",
                     help="control07 (default: examples/control07.mat, BASELINE configs[1]) | control07_like (synthetic, same shape) | "
                          "nb (configs[2] shape) | lpdense (configs[2] dense-column variant) | maxcut<n> (configs[3]) | blockdiag[:nblk:n:mper] (configs[4])")
-    ap.add_argument("--shard", default="auto", choices=["auto", "replicas", "columns"],
-                    help="N>1: columns (auto for single-supernode workloads) = ONE unit per step, ADA' column panels per rank + RCCL "
-                         "all-gather, factor/solves replicated; replicas = independent units per rank (weak scaling, no collective)")
+    ap.add_argument("--shard", default="auto", choices=["auto", "replicas", "columns", "blocks"],
+                    help="N>1, ONE unit per step: blocks = PSD blocks dealt to the ranks, partial ADA' + one RCCL all-reduce (auto when "
+                         "the problem has at least N PSD blocks); columns = ADA' column panels per rank + RCCL all-gather (auto otherwise); "
+                         "factor/solves replicated in both (one dense supernode does not shard); replicas = independent units per "
+                         "rank (weak scaling, no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the brief measurements of configs[2..4]")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (one launch per step)")
@@ -471,19 +473,31 @@ def main():
         return bench_lpdense(args, local_rank)
     if args.workload.startswith("blockdiag") and (world > 1 or args.shard != "auto"):
         return bench_subtrees(args, rank, local_rank, world, torch, dist, coll_dev)
-    shard_cols = world > 1 and args.shard in ("auto", "columns")
-    P, L, ADA, Q, d, ud, rhs, qpr, data_note = build_workload(args.workload, seed=0 if (shard_cols or world == 1) else rank)
-    plan = make_plan(local_rank, P, L, ADA, Q, d, ud, rhs, qpr)
+    P, L, ADA, Q, d, ud, rhs, qpr, data_note = build_workload(args.workload, seed=0 if (world == 1 or args.shard != "replicas") else rank)
+    nblk = int(np.asarray(P.K["s"]).size)
+    shard = "none" if world == 1 else args.shard
+    if shard == "auto":                                 # the way the workload shards
+        shard = "blocks" if nblk >= world else "columns"
+    shard_cols = shard in ("columns", "blocks")         # ONE unit per step, strong scaling
+    cs = bs = None
+    if shard == "blocks":
+        from sedumi_amd import dist as sd
+        bs = sd.BlockShardedAda(P, L, ADA, device_index=local_rank, device=coll_dev)
+        bs.upload_scaling(d, ud, qpr)
+        plan = bs.plan
+        plan.upload("rhs", rhs)
+    else:
+        plan = make_plan(local_rank, P, L, ADA, Q, d, ud, rhs, qpr)
     plan._xsuper = np.asarray(L["xsuper"]).ravel().astype(np.int64)
-
-    cs = None
-    if shard_cols:
+    if shard == "columns":
         from sedumi_amd import dist as sd
         cs = sd.ColumnShardedAda(plan, device=coll_dev)
 
     def step():
         if cs is not None:
             cs.getada()
+        elif bs is not None:
+            bs.getada()
         else:
             plan.getada()
         plan.blkchol(PARS, True)
@@ -491,7 +505,7 @@ def main():
             plan.ldlsolve()
 
     eager_step = step
-    if args.graph and cs is None:
+    if args.graph and cs is None and bs is None:
         for _ in range(2):
             eager_step()                       # first-use work (function attributes, allocations) outside the capture
         plan.sync()
@@ -548,8 +562,9 @@ def main():
             "data": data_note,
             "config": {"workload": f"{P.name}: {CONFIG_NOTE.get(args.workload[:6], 'synthetic')}, m={P.m}, nnz(At)={P.At.nnz}, "
                                    f"nnz(ADA')={plan.nnzADA}, nnz(L)={plan.nnzL}; unit = getada1+2+3, blkchol, {NSOLVE}x(fwblkslv,./d,bwblkslv)",
-                       "parallelism": (("ADA' column panels per rank + RCCL all-gather, factor/solves replicated (they do not shard: one dense supernode)"
-                                        if shard_cols else "replicas: independent units per rank, no collective") if world > 1 else "single GPU")},
+                       "parallelism": ({"columns": "ADA' column panels per rank + RCCL all-gather, factor/solves replicated (they do not shard: one dense supernode)",
+                                         "blocks": "PSD blocks dealt to the ranks, partial ADA' + RCCL all-reduce, factor/solves replicated",
+                                         "replicas": "replicas: independent units per rank, no collective"}[shard] if world > 1 else "single GPU")},
             "roofline": roof, "phases_ms_per_step": phases, "cpu_baseline": base, "cpu_baseline_blas": base_blas,
             "pcie_inclusive": pcie, "other_configs": others,
         }

@@ -84,6 +84,72 @@ class ColumnShardedAda:
                 self.plan.copy("absd", self.recv[base + self.maxv:base + self.maxv + ncq], int(self.cols[q]), ncq, to_plan=True)
 
 
+class BlockShardedAda:
+    """ADA' = sum over PSD blocks of their contributions (getada3.c:305-359 / spscale.c:473-491 treat the blocks
+    independently): the PSD blocks are dealt to the ranks (longest-processing-time first on n_k^2 x touching
+    constraints), rank 0 also carries the LP / Lorentz rows; every rank forms its partial ADA' and absd on the COMMON
+    pattern in its own resident plan, and ONE all-reduce (sum) over [values | absd] assembles ADA' on every rank --
+    the form a replicated factorisation wants; a reduce to one owner is the same call with dist.reduce.  This is the
+    shard for problems with at least as many PSD blocks as ranks; single-block problems use ColumnShardedAda."""
+
+    def __init__(self, P, L, ADApattern, group=None, device_index=0, device=None):
+        torch, dist = _torch()
+        self.group = group
+        if dist.is_available() and dist.is_initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        self.device = device if device is not None else torch.device("cpu")
+        s = np.asarray(P.K["s"], dtype=np.float64).ravel()
+        At = sp.csc_matrix(P.At)
+        _, _, _, _, _, psd = problem._cone_layout(P.K)
+        # cost of a block: n_k^2 per constraint that touches it
+        touch = np.zeros(s.size)
+        rows = At.indices
+        if s.size:
+            inb = np.searchsorted(psd, rows, side="right") - 1
+            ok = rows >= psd[0]
+            cols = np.repeat(np.arange(At.shape[1]), np.diff(At.indptr))
+            pairs = np.unique(np.stack((inb[ok], cols[ok])), axis=1)
+            touch = np.bincount(pairs[0], minlength=s.size).astype(np.float64)
+        cost = s ** 2 * np.maximum(touch, 1.0)
+        load = np.zeros(self.world)
+        owner = np.zeros(s.size, dtype=np.int64)
+        for k in np.argsort(-cost, kind="stable"):
+            r = int(np.argmin(load)); owner[k] = r; load[r] += cost[k]
+        self.blocks_of = [np.flatnonzero(owner == r) for r in range(self.world)]
+        self.P = P
+        mine = self.blocks_of[self.rank]
+        self.sub, self.rows = problem.block_subproblem(P, mine, keep_lq=(self.rank == 0))
+        self.plan = Plan(device_index)
+        self.plan.set_chol(L, ADApattern)
+        self.plan.set_ada(self.sub.At, self.sub.Ablkjc, self.sub.K, problem.lorentz_pattern(self.sub))
+        self.nv, self.m = self.plan.nnzADA, self.plan.m
+        self.buf = torch.zeros(self.nv + self.m, dtype=torch.float64, device=self.device)
+
+    def upload_scaling(self, d, ud, qpr=None):
+        """Scaling of the FULL problem: rank 0 keeps d.l / d.det (and the DAt.q values), every rank its blocks of udsqr."""
+        if self.rank == 0:
+            self.plan.upload("dl", d["l"]); self.plan.upload("ddet", d["det"])
+            if qpr is not None and np.size(qpr):
+                self.plan.upload("qpr", qpr)
+        else:
+            self.plan.upload("dl", np.ones(1))
+        self.plan.upload("udsqr", problem.block_udsqr(self.P, self.blocks_of[self.rank], ud))
+
+    def getada(self):
+        """Partial ADA' + absd of this rank's blocks, then one all-reduce: the plan holds the full ADA' afterwards."""
+        torch, dist = _torch()
+        self.plan.getada()
+        if self.world == 1:
+            return
+        self.plan.copy("ada", self.buf, 0, self.nv, to_plan=False)
+        self.plan.copy("absd", self.buf[self.nv:], 0, self.m, to_plan=False)
+        dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
+        self.plan.copy("ada", self.buf, 0, self.nv, to_plan=True)
+        self.plan.copy("absd", self.buf[self.nv:], 0, self.m, to_plan=True)
+
+
 # ----------------------------------------------------------------------------------------- subtree sharding
 def components(P):
     """Connected components of the ADA' pattern of problem P = groups of constraints that share a cone variable

@@ -350,3 +350,30 @@ def sub_scaling_q(P, sub, d):
     base = int(qnorm[0]) if q.size else 0
     q2 = np.concatenate([q2f[int(qnorm[k]) - base:int(qnorm[k + 1]) - base] for k in keep]) if keep.size else np.zeros(0)
     return q1, q2
+
+
+def block_subproblem(P, blocks, keep_lq):
+    """All m constraints, but only the PSD blocks listed in `blocks` (indices into K.s, ascending) and -- when keep_lq --
+    the LP / Lorentz rows; otherwise a single artificial x0 row.  The partial ADA' of such sub-problems on the common
+    pattern add up to ADA' (spscale.c:473-491 loops the blocks independently).  Returns (Problem, kept rows of P.At)."""
+    At = sp.csc_matrix(P.At)
+    lpN, q, s, nreal, qnorm, psd = _cone_layout(P.K)
+    blocks = [int(b) for b in blocks]
+    psd0 = int(psd[0]) if s.size else At.shape[0]
+    rows = list(range(psd0)) if keep_lq else [0]
+    for k in blocks:
+        rows.extend(range(int(psd[k]), int(psd[k + 1])))
+    rows = np.asarray(rows, dtype=np.int64)
+    K = make_K(lpN if keep_lq else 1, q if keep_lq else [], [s[k] for k in blocks if k < nreal], [s[k] for k in blocks if k >= nreal])
+    sub = Problem(sp.csc_matrix(At.tocsr()[rows, :]), K, f"{P.name}[blocks {blocks}{'+lq' if keep_lq else ''}]")
+    sub.blocks = np.asarray(blocks, dtype=np.int64)
+    return sub, rows
+
+
+def block_udsqr(P, blocks, ud):
+    """The slices of udsqr (concatenated D_k, Hermitian blocks [Re; Im]) that belong to the PSD blocks `blocks`."""
+    lpN, q, s, nreal, qnorm, psd = _cone_layout(P.K)
+    lens = np.where(np.arange(s.size) < nreal, s ** 2, 2 * s ** 2)
+    off = np.concatenate(([0], np.cumsum(lens)))
+    ud = np.asarray(ud, dtype=np.float64).ravel()
+    return np.concatenate([ud[off[k]:off[k + 1]] for k in blocks]) if len(blocks) else np.zeros(0)

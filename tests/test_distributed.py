@@ -48,6 +48,27 @@ def _worker(rank, world, port, case, q):
             cs.getada()
             err = max(np.abs(sh.download("ada") - ref.download("ada")).max(), np.abs(sh.download("absd") - ref.download("absd")).max())
             q.put((rank, float(err), [int(c) for c in cs.cols]))
+        elif case == "blocks":
+            # ADA' = sum of the PSD blocks' contributions: blocks dealt to the ranks, one all-reduce of [values | absd]
+            from helpers import ref_scaling
+            P = problem.random_sdp(m=40, lp=5, q=(4, 3), s=(8, 5, 6), hs=(4,), dens=0.3, seed=9)
+            d, ud = ref_scaling(P, 2)
+            ADApat = problem.symb_ada(P)
+            L = mex.symbchol(ADApat)
+            Q = problem.lorentz_pattern(P)
+            qv = np.random.default_rng(0).standard_normal(Q.nnz)
+            ref = Plan(0); ref.set_chol(L, ADApat); ref.set_ada(P.At, P.Ablkjc, P.K, Q)
+            ref.upload("dl", d["l"]); ref.upload("ddet", d["det"]); ref.upload("udsqr", ud); ref.upload("qpr", qv)
+            ref.getada()
+            bs = sd.BlockShardedAda(P, L, ADApat)
+            bs.upload_scaling(d, ud, qv)
+            bs.getada()
+            err = max(np.abs(bs.plan.download("ada") - ref.download("ada")).max() / np.abs(ref.download("ada")).max(),
+                      np.abs(bs.plan.download("absd") - ref.download("absd")).max() / np.abs(ref.download("absd")).max())
+            bs.plan.blkchol(pars, True)                  # the replicated factor sees the assembled ADA'
+            ref.blkchol(pars, True)
+            err = max(err, np.abs(bs.plan.download("d") - ref.download("d")).max() / np.abs(ref.download("d")).max())
+            q.put((rank, float(err), [int(b.size) for b in bs.blocks_of]))
         else:
             if case == "subtrees_lorentz":
                 # components with Lorentz cones: the getada2 term needs every rank's own DAt.q (formed on the device
@@ -83,7 +104,7 @@ def _worker(rank, world, port, case, q):
         q.put((rank, "ERR " + traceback.format_exc(), None))
 
 
-@pytest.mark.parametrize("case", ["columns", "subtrees", "subtrees_lorentz"])
+@pytest.mark.parametrize("case", ["columns", "subtrees", "subtrees_lorentz", "blocks"])
 def test_two_ranks_gloo(case):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -98,6 +119,9 @@ def test_two_ranks_gloo(case):
     for rank, err, info in res:
         assert not isinstance(err, str), err
         assert err < 1e-12, (rank, err)
+        if case == "blocks":
+            assert info is not None and sum(info) == 4 and min(info) >= 1
+            continue
         assert info is not None and (len(info) == 3 if case == "columns" else sum(info) == (35 if case == "subtrees" else 30) and min(info) > 0)
 
 

@@ -184,7 +184,9 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
 // ================================================================= kernels
 
 // ---- permuteP: scatter tril(ADA(perm,perm)) into the (zeroed) fronts
-__global__ void k_assemble(double *F, const double *ada, const int *src, const int64_t *dst, int64_t nnzL) {
+__global__ void k_assemble(double *F, const double *ada, const int *src, const int64_t *dst, int64_t nnzL, double *ub) {
+  // ub[0..2] (pivot thresholds of this factorisation, filled by k_prep_pivots -- the next launch on the stream) start at 0
+  if (ub && blockIdx.x == 0 && threadIdx.x < 3) ub[threadIdx.x] = 0.0;
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; t < nnzL; t += stride) { int s = src[t]; F[dst[t]] = s < 0 ? 0.0 : ada[s]; }
@@ -206,10 +208,12 @@ __global__ void k_load_factor(double *F, double *FT, const double *Lpr, const in
 // exact and order independent); ub[1] = maxu; k_ldl_panel forms ub from them.  ub[2] is zeroed by the host before.
 __global__ void k_prep_pivots(int m, const double *ada, const int *asm_src, const int64_t *Ljc, const int *perm,
                               const double *absd, int use_absd, double canceltol, double maxu, double abstol,
-                              double *lb, double *ub, int *pivstat, double *pivval, int nsuper, int *upd_cnt, int *diag_cnt) {
+                              double *lb, double *ub, int *pivstat, double *pivval, int nsuper, int *upd_cnt, int *diag_cnt,
+                              unsigned long long *sb_g, int nsbg) {
   __shared__ double red[256];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
   for (int i = gid; i < nsuper; i += gstride) { upd_cnt[i] = 0; diag_cnt[i] = 0; }     // counters of k_ldl_panel
+  for (int i = gid; i < nsbg; i += gstride) sb_g[i] = 0ull;                             // growth records of the solve inverses (sdm_solve.hip)
   double mx = 0.0;
   for (int j = gid; j < m; j += gstride) {
     int s = asm_src[Ljc[j]];
@@ -1010,14 +1014,10 @@ __global__ void k_gather_perm(double *dst, const double *src, const int *perm, i
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < m) { if (forward) dst[k] = src[perm[k]]; else dst[perm[k]] = src[k]; }
 }
+// ./d of wrapPcg.m:57 with deninfac.m:89-94 folded in: skipped pivots (d = 0) act as 1
 __global__ void k_divd(double *v, const double *d, int m) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < m) v[k] /= d[k];
-}
-// d for the solves: deninfac.m:89-94 with no dense columns -- skipped pivots (d=0) act as 1
-__global__ void k_dsolve(double *ds, const double *d, int m) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < m) ds[k] = d[k] > 0.0 ? d[k] : 1.0;
+  if (k < m) { const double dk = d[k]; v[k] /= dk > 0.0 ? dk : 1.0; }
 }
 
 // ============================================================ host drivers
@@ -1045,10 +1045,10 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
 #endif
   SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), st));
   SDM_KLAUNCH(P, k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
-             C.d_asm_dst.p, (int64_t)C.nnzL);
-  SDM_HIP_CHECK(hipMemsetAsync(C.ub.p, 0, 3 * sizeof(double), st));
+             C.d_asm_dst.p, (int64_t)C.nnzL, C.ub.p);
   SDM_KLAUNCH(P, k_prep_pivots, dim3(grid1d(m, 256, 64)), dim3(256), 0, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
-             P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, (int)C.nsuper, C.upd_cnt.p, C.diag_cnt.p);
+             P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, (int)C.nsuper, C.upd_cnt.p, C.diag_cnt.p,
+             C.sb_g.p, 2 * C.nsbtot);
   for (int l = 0; l < C.nlevels; l++) {
     const int *list = C.d_levlist.p + C.levptr[l];
     const int nfr = C.levptr[l + 1] - C.levptr[l];
@@ -1069,8 +1069,7 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
         SDM_KLAUNCH(P, k_ldl_update, dim3(L.lasttiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p, 1);
     }
   }
-  SDM_KLAUNCH(P, k_dsolve, dim3((m + 255) / 256), dim3(256), 0, C.dsolve.p, C.d.p, m);
-  solve_prepare(P);                                                  // inverses of the diagonal super-blocks for the solves
+  solve_prepare(P, /*sb_g_is_zero=*/true);                           // inverses of the diagonal super-blocks for the solves
   SDM_HIP_CHECK(hipGetLastError());
   P->factored = true;
 }
@@ -1099,7 +1098,6 @@ void chol_load_factor(sdm_plan *P, const double *h_Lpr, const double *h_d) {
     SDM_HIP_CHECK(hipMemcpyAsync(C.d.p, h_d, (size_t)m * sizeof(double), hipMemcpyHostToDevice, P->stream));
     SDM_HIP_CHECK(hipMemsetAsync(C.pivstat.p, 0, (size_t)m * sizeof(int), P->stream));
     SDM_HIP_CHECK(hipMemsetAsync(C.lb.p, 0, (size_t)m * sizeof(double), P->stream));
-    SDM_KLAUNCH(P, k_dsolve, dim3((m + 255) / 256), dim3(256), 0, C.dsolve.p, C.d.p, m);
     SDM_HIP_CHECK(hipStreamSynchronize(P->stream));                  // h_d may be pageable
   }
   DevBuf<double> tmp;
@@ -1108,7 +1106,7 @@ void chol_load_factor(sdm_plan *P, const double *h_Lpr, const double *h_d) {
   SDM_HIP_CHECK(hipMemsetAsync(C.frontsT.p, 0, (size_t)C.tsize * sizeof(double), P->stream));
   SDM_KLAUNCH(P, k_load_factor, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, C.frontsT.p, tmp.p, C.d_asm_dst.p,
               C.d_asm_dstT.p, (int64_t)C.nnzL);
-  solve_prepare(P);
+  solve_prepare(P, false);
   SDM_HIP_CHECK(hipStreamSynchronize(P->stream));
   P->factored = true;
 }
@@ -1119,7 +1117,7 @@ void vec_gather(sdm_plan *P, double *dst, const double *src, bool forward) {
 }
 void vec_divd(sdm_plan *P, double *v) {
   const int m = (int)P->chol.m;
-  SDM_KLAUNCH(P, k_divd, dim3((m + 255) / 256), dim3(256), 0, v, P->chol.dsolve.p, m);
+  SDM_KLAUNCH(P, k_divd, dim3((m + 255) / 256), dim3(256), 0, v, solve_d(P), m);
 }
 
 }  // namespace sdm

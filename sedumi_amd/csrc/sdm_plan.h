@@ -148,7 +148,7 @@ struct CholPlan {
   int64_t ssize = 0; int nsbtot = 0;
   std::vector<int64_t> sn_soff; std::vector<int> sn_sld, sn_sboff;
   DevBuf<int64_t> d_soff; DevBuf<int> d_sld, d_sboff;
-  DevBuf<double> S, xfin, ttmp;
+  DevBuf<double> S, xfin, ttmp, zdiv;
   DevBuf<unsigned long long> sb_g;   // per super-block: bit patterns of max|inverse| and max|L block| (growth check)
   DevBuf<int> sb_cnt;                // per super-block: arrival tickets of the (rare) substitution fallback
   DevBuf<int> l_i128, l_t3, l_pm;    // work lists of the inversion / premultiplication launches (4 ints per item)
@@ -298,10 +298,12 @@ void vec_divd(sdm_plan *P, double *v);
 FrontTab front_tab(CholPlan &C);
 // sdm_solve.hip: inverse-block solves
 void solve_build(sdm_plan *P);                      // host tables + buffers (end of chol_build)
-void solve_prepare(sdm_plan *P);                    // after a factorisation: diagonal super-block inverses, premultiplied block rows
+void solve_prepare(sdm_plan *P, bool sb_g_is_zero);  // after a factorisation: diagonal super-block inverses, premultiplied block rows
+const double *solve_d(sdm_plan *P);                  // the d the solves divide by: L.d (skipped pivots act as 1), or Ld of deninfac
 void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode);   // mode bits 1 fw | 2 ./d | 4 bw
 void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growth);
-void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *y, int64_t y_stride, double *wv, int nrhs);
+void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *y, int64_t y_stride, double *wv, int nrhs,
+                    double *zdiv = nullptr, const double *dscale = nullptr);
 // sdm_pcg.hip: Amul / vecsym / psdscale on the plan
 void pcg_amul(sdm_plan *P, int transp);
 void pcg_set_dense(sdm_plan *P, sdm_int nden, const sdm_int *cols, const double *Aden);

@@ -65,7 +65,7 @@ void solve_build(sdm_plan *P) {
   C.d_soff.upload(C.sn_soff); C.d_sld.upload(C.sn_sld); C.d_sboff.upload(C.sn_sboff);
   C.S.alloc((size_t)std::max<int64_t>(soff, 1));
   SDM_HIP_CHECK(hipMemset(C.S.p, 0, (size_t)std::max<int64_t>(soff, 1) * sizeof(double)));   // upper triangles stay zero for good
-  C.xfin.alloc((size_t)std::max<sdm_int>(C.m, 1));
+  C.xfin.alloc((size_t)std::max<sdm_int>(C.m, 1)); C.zdiv.alloc((size_t)std::max<sdm_int>(C.m, 1));
   C.ttmp.alloc((size_t)std::max(tslots, 1) * 128 * 128);
   C.sb_g.alloc((size_t)std::max(2 * sb, 2)); C.sb_cnt.alloc((size_t)std::max(sb, 1));
   SDM_HIP_CHECK(hipMemset(C.sb_g.p, 0, (size_t)std::max(2 * sb, 2) * sizeof(unsigned long long)));
@@ -452,7 +452,7 @@ __device__ __noinline__ void block_solve_bw(const double *Fs, int ld, int k0, in
 // ticket; the winner acquires.)
 template <bool FW>
 __device__ __forceinline__ void bad_block_arrive(const double *Fs, int ld, int k0, int nb, double *yp, int *cnt, int nsl, double *w,
-                                                 double *Sd) {
+                                                 double *Sd, double *zp = nullptr, const double *dp = nullptr, bool also_bw = false) {
   __shared__ int last;
   SDM_STORES_DONE();
   __syncthreads();
@@ -466,12 +466,24 @@ __device__ __forceinline__ void bad_block_arrive(const double *Fs, int ld, int k
   if (!last) return;
   SDM_ACQUIRE_FENCE();
   if (FW) block_solve_fw(Fs, ld, k0, nb, yp, w, Sd); else block_solve_bw(Fs, ld, k0, nb, yp, w, Sd);
+  if (FW && zp) {                                                    // the block is final: its ./d copy for the backward sweep
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += ST) { const double dk = dp[i]; zp[i] = yp[i] / (dk > 0.0 ? dk : 1.0); }
+    if (also_bw) {                                                   // last block of a front without rows below: x = L_PP' \ z right away
+      SDM_STORES_DONE();
+      __syncthreads();
+      block_solve_bw(Fs, ld, k0, nb, zp, w, Sd);
+    }
+  }
 }
 
 // ================================================================ forward sweep
 // several right-hand sides side by side (blockIdx.z): element strides of the right-hand sides, of the result, of the
 // update-vector scratch and of the fallback tickets (all 0 for a single right-hand side)
-struct FwBatch { int64_t src, y, wv, cnt; };
+// fold_bw: the level's fronts have no rows below their own columns and the ./d copy is being written: a BAD last
+// super-block is then also substituted backward right where its forward value becomes final (the backward sweep of
+// such a level starts without k_sbw_init)
+struct FwBatch { int64_t src, y, wv, cnt; int fold_bw; };
 // assembly of a front's right-hand side (levels above the leaves): own entries through perm, children's update vectors
 __global__ void __launch_bounds__(ST)
 k_sfw_init(FrontTab tab, const int *list, double *wv, const double *src, const int *perm, const double *y, FwBatch bt) {
@@ -529,7 +541,8 @@ __device__ __forceinline__ double slab_consume(const sdm_double2 (&v)[NLD], int 
 // y_P = inv(L_PP) a_P for every super-block of every front of a level (bad blocks: copy, then substitution)
 __global__ void __launch_bounds__(ST)
 k_sfw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, const double *wv, const double *src,
-           const int *perm, double *y, const unsigned long long *sb_g, int *sb_cnt, double thr, int gather, FwBatch bt) {
+           const int *perm, double *y, const unsigned long long *sb_g, int *sb_cnt, double thr, int gather, FwBatch bt,
+           double *zdiv, const double *dscale) {
   __shared__ double xs[SBW], red[(ST / 8) * SROWS], wsub[SBW];
   __shared__ double Sd[64 * TP];
   const int s = list[blockIdx.y];
@@ -552,11 +565,17 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
   if (bad) {
     if (tid < SROWS && r0 + tid < ns) y[first + r0 + tid] = xs[r0 - c0 + tid];
     // block 0 has nothing left of it: its right-hand side is complete here; later blocks are completed by step Pb-1
-    if (Pb == 0) bad_block_arrive<true>(F + tab.foff[s], tab.ld[s], c0, nb, y + first + c0, sb_cnt + sb, (nb + SROWS - 1) / SROWS, wsub, Sd);
+    if (Pb == 0) bad_block_arrive<true>(F + tab.foff[s], tab.ld[s], c0, nb, y + first + c0, sb_cnt + sb, (nb + SROWS - 1) / SROWS, wsub, Sd,
+                                         zdiv ? zdiv + first + c0 : nullptr, zdiv ? dscale + first + c0 : nullptr,
+                                         bt.fold_bw && ns <= SBW);
     return;
   }
   const double sum = slab_consume(v, ncols, xs, red);
-  if (tid < SROWS && r0 + tid < ns) y[first + r0 + tid] = sum;
+  if (tid < SROWS && r0 + tid < ns) {
+    y[first + r0 + tid] = sum;
+    // block 0 is final here: its ./d copy (wrapPcg.m:57; skipped pivots act as 1, deninfac.m:89-94) for the backward sweep
+    if (zdiv && Pb == 0) { const double dk = dscale[first + r0 + tid]; zdiv[first + r0 + tid] = sum / (dk > 0.0 ? dk : 1.0); }
+  }
 }
 
 // step P: y_P is final; every row beyond super-block P receives  - M(r, P) y_P   (M = S for the front's own rows
@@ -564,7 +583,8 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
 // vector passed to the parent)
 __global__ void __launch_bounds__(ST)
 k_sfw_step(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, double *wv, double *y,
-           const unsigned long long *sb_g, int *sb_cnt, double thr, int Pb, int first_assign, FwBatch bt) {
+           const unsigned long long *sb_g, int *sb_cnt, double thr, int Pb, int first_assign, FwBatch bt, double *zdiv,
+           const double *dscale) {
   __shared__ double xs[SBW], red[(ST / 8) * SROWS], wsub[SBW];
   __shared__ double Sd[64 * TP];
   const int s = list[blockIdx.y];
@@ -594,10 +614,17 @@ k_sfw_step(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
   if (bad) slab_issue(v, Fs, ld, c0, nb, r0, ns - 1);               // rare: the rows of a bad block were not premultiplied
   const double sum = slab_consume(v, nb, xs, red);
   if (regA) {
-    if (tid < SROWS && r0 + tid < ns) y[first + r0 + tid] -= sum;
+    if (tid < SROWS && r0 + tid < ns) {
+      const double yv = y[first + r0 + tid] - sum;
+      y[first + r0 + tid] = yv;
+      // block Pb+1 receives its last contribution in this step: final (unless it still has to be solved by substitution)
+      if (zdiv && Pr == Pb + 1 && !bad) { const double dk = dscale[first + r0 + tid]; zdiv[first + r0 + tid] = yv / (dk > 0.0 ? dk : 1.0); }
+    }
     if (bad && Pr == Pb + 1) {                                      // this step completes the right-hand side of block Pr
       const int nbr = min(SBW, ns - Pr * SBW);
-      bad_block_arrive<true>(Fs, ld, Pr * SBW, nbr, y + first + Pr * SBW, sb_cnt + sbr, (nbr + SROWS - 1) / SROWS, wsub, Sd);
+      bad_block_arrive<true>(Fs, ld, Pr * SBW, nbr, y + first + Pr * SBW, sb_cnt + sbr, (nbr + SROWS - 1) / SROWS, wsub, Sd,
+                             zdiv ? zdiv + first + Pr * SBW : nullptr, zdiv ? dscale + first + Pr * SBW : nullptr,
+                             bt.fold_bw && (Pr + 1) * SBW >= ns);
     }
   } else {
     double *u = wv + tab.woff[s];
@@ -676,7 +703,12 @@ k_sbw_init(const double *__restrict__ F, FrontTab tab, const int *list, double *
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int c = c0 + 4 * wave + q;
-      if (c < ns) { const double z = y[first + c]; y[first + c] = (dscale ? z / dscale[first + c] : z) - tot[q]; }
+      if (c < ns) {
+        const double z = y[first + c];
+        double dk = dscale ? dscale[first + c] : 1.0;
+        dk = dk > 0.0 ? dk : 1.0;                                    // skipped pivots act as 1 (deninfac.m:89-94)
+        y[first + c] = (dscale ? z / dk : z) - tot[q];
+      }
     }
   }
   // the last super-block of a front has nothing above it in this sweep: if bad, it is solved once all its columns are set
@@ -753,7 +785,9 @@ k_sbw_diag(const double *__restrict__ S, FrontTab tab, const int *list, const do
 }
 
 // ================================================================ host drivers
-void solve_prepare(sdm_plan *P) {
+const double *solve_d(sdm_plan *P) { return P->dense.factored ? (const double *)P->chol.dsolve.p : (const double *)P->chol.d.p; }
+
+void solve_prepare(sdm_plan *P, bool sb_g_is_zero) {
   CholPlan &C = P->chol;
   FrontTab tab = front_tab(C);
 #ifndef SDM_EMU
@@ -765,7 +799,8 @@ void solve_prepare(sdm_plan *P) {
   }
 #endif
   C.growth_used = C.growth_max;                                     // the solves decide with the bound the premultiplication saw
-  SDM_HIP_CHECK(hipMemsetAsync(C.sb_g.p, 0, (size_t)std::max(2 * C.nsbtot, 2) * sizeof(unsigned long long), P->stream));
+  if (!sb_g_is_zero)                                                // (a factorisation zeroes them in k_prep_pivots)
+    SDM_HIP_CHECK(hipMemsetAsync(C.sb_g.p, 0, (size_t)std::max(2 * C.nsbtot, 2) * sizeof(unsigned long long), P->stream));
   if (C.n_i128) SDM_KLAUNCH(P, k_sinv128, dim3(C.n_i128), dim3(ST), INV_LDS, C.fronts.p, C.S.p, tab, C.l_i128.p, C.sb_g.p);
   if (C.n_t3) {
     SDM_KLAUNCH(P, k_stile, dim3(C.n_t3), dim3(ST), TILE_LDS, C.fronts.p, C.S.p, C.ttmp.p, tab, C.l_t3.p, C.sb_g.p, 0, C.growth_used);
@@ -794,7 +829,8 @@ void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growt
 
 // forward sweeps of nrhs right-hand sides side by side (grid.z): rhs + z*rhs_stride -> y + z*y_stride (permuted order);
 // wv = update-vector scratch of wsize doubles per right-hand side
-void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *y, int64_t y_stride, double *wv, int nrhs) {
+void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *y, int64_t y_stride, double *wv, int nrhs,
+                    double *zdiv, const double *dscale) {
   CholPlan &C = P->chol;
   FrontTab tab = front_tab(C);
   const double thr = C.growth_used;
@@ -803,29 +839,33 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
   bt.src = nrhs > 1 ? rhs_stride : 0; bt.y = nrhs > 1 ? y_stride : 0; bt.wv = nrhs > 1 ? C.wsize : 0; bt.cnt = nrhs > 1 ? C.nsbtot : 0;
   for (int l = 0; l < C.nlevels; l++) {
     const SolveLevel &L = C.slev[l];
+    bt.fold_bw = (zdiv && !L.below) ? 1 : 0;
     const int *list = C.d_levlist.p + C.levptr[l];
     const int gather = L.children ? 0 : 1;
     if (!gather) SDM_KLAUNCH(P, k_sfw_init, dim3(L.nfronts, 1, nrhs), dim3(ST), 0, tab, list, wv, rhs, C.d_perm.p, y, bt);
     SDM_KLAUNCH(P, k_sfw_diag, dim3((L.maxns + SROWS - 1) / SROWS, L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, wv, rhs,
-                C.d_perm.p, y, C.sb_g.p, C.sb_cnt.p, thr, gather, bt);
+                C.d_perm.p, y, C.sb_g.p, C.sb_cnt.p, thr, gather, bt, zdiv, dscale);
     for (int Pb = 0; Pb < (int)L.maxslab_fw.size(); Pb++)
       if (L.maxslab_fw[Pb] > 0)
         SDM_KLAUNCH(P, k_sfw_step, dim3(L.maxslab_fw[Pb], L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, wv, y, C.sb_g.p,
-                    C.sb_cnt.p, thr, Pb, (gather && Pb == 0) ? 1 : 0, bt);
+                    C.sb_cnt.p, thr, Pb, (gather && Pb == 0) ? 1 : 0, bt, zdiv, dscale);
   }
 }
 
-// backward sweep of the vector in ywork (permuted order); divide: ./d on the way in; dscale = that d
-static void solve_bw_inplace(sdm_plan *P, double *yout, const double *dscale) {
+// backward sweep in place on the vector y (permuted order).  dscale != null: ./d on the way in (k_sbw_init);
+// skip_plain_init: the levels whose fronts have no rows below their own columns need no k_sbw_init at all (the ./d
+// was already applied by the forward sweep's final writes)
+static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double *dscale, bool skip_plain_init) {
   CholPlan &C = P->chol;
   FrontTab tab = front_tab(C);
-  double *y = P->ywork.p;
   const double thr = C.growth_used;
   for (int l = C.nlevels - 1; l >= 0; l--) {
     const SolveLevel &L = C.slev[l];
     const int *list = C.d_levlist.p + C.levptr[l];
     const int ncs = (L.maxns + SROWS - 1) / SROWS;
-    SDM_KLAUNCH(P, k_sbw_init, dim3(ncs, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, dscale, C.sb_g.p, C.sb_cnt.p, thr);
+    // (a bad last super-block of such a level was substituted backward by the forward sweep: FwBatch::fold_bw)
+    if (!(skip_plain_init && !L.below))
+      SDM_KLAUNCH(P, k_sbw_init, dim3(ncs, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, dscale, C.sb_g.p, C.sb_cnt.p, thr);
     for (int Q = L.nsb - 1; Q >= 1; Q--)
       SDM_KLAUNCH(P, k_sbw_step, dim3(Q * (SBW / SROWS), L.nfronts), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, y, C.sb_g.p, C.sb_cnt.p, thr, Q);
     SDM_KLAUNCH(P, k_sbw_diag, dim3(ncs, L.nfronts), dim3(ST), 0, C.S.p, tab, list, y, C.xfin.p, yout, C.d_perm.p, C.sb_g.p, thr);
@@ -839,8 +879,11 @@ void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode) {
   // with a resident dense-column factor (sdm_plan_deninfac) the complete solve is wrapPcg.m:56-59:
   //   p = fwdpr1(Lden, L \ r(perm)) ;  y = p ./ L.d ;  y(perm) = L' \ bwdpr1(Lden, y)
   const bool dense = (mode == 7) && P->dense.factored;
+  // fw, ./d, bw in one call without dense columns: the forward sweep writes the ./d copy of every block as it becomes
+  // final (zdiv), the backward sweep runs on that copy and needs k_sbw_init only where rows below a supernode exist
+  const bool fold = (mode == 7) && !dense;
   if (mode & 1) {
-    solve_fw_batch(P, rhs, 0, y, 0, C.wvec.p, 1);
+    solve_fw_batch(P, rhs, 0, y, 0, C.wvec.p, 1, fold ? C.zdiv.p : nullptr, fold ? solve_d(P) : nullptr);
     if (!(mode & 4)) {
       if (mode & 2) vec_divd(P, y);
       SDM_HIP_CHECK(hipMemcpyAsync(yout, y, mb, hipMemcpyDeviceToDevice, P->stream));
@@ -851,9 +894,11 @@ void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode) {
   }
   if (dense) {
     dense_prodform(P, y, /*with_divide=*/true);                      // fwdpr1, ./ Ld, bwdpr1 in one launch
-    solve_bw_inplace(P, yout, nullptr);
+    solve_bw_inplace(P, y, yout, nullptr, false);
+  } else if (fold) {
+    solve_bw_inplace(P, C.zdiv.p, yout, nullptr, true);
   } else {
-    solve_bw_inplace(P, yout, (mode & 2) ? (const double *)C.dsolve.p : (const double *)nullptr);
+    solve_bw_inplace(P, y, yout, (mode & 2) ? solve_d(P) : (const double *)nullptr, false);
   }
 }
 

@@ -5,6 +5,7 @@ the reference's own example problems, with the NORMAL-EQUATIONS HOT PATH pluggab
 
     hot = RefHot(glue)   the reference MEX (oracle/_ref):   getada1/2/3 | getada.m, blkchol, fwblkslv, bwblkslv, invcholfac
     hot = HipHot()       this repository's library through sedumi_amd.mex (HIP on a GPU box, the fiber emulator on CPU)
+    hot = PlanHot()      the same library through its resident plan: problem, scaling, ADA', factor and solves stay in HBM
 
 Everything outside the hot path -- the cone algebra (qrK, psdframeit, psdinvjmul, urotorder, givensrot, sqrtinv, iswnbr,
 vecsym, ddot, qblkmul, quadadd: reference MEX through the oracle) and the MATLAB control flow (restated below, file and
@@ -47,7 +48,26 @@ def default_pars():
 
 
 # ----------------------------------------------------------------------------------------------- hot paths
-class RefHot:
+class MexShapedHot:
+    """sedumi.m:442-463 for a hot path that is called MEX by MEX: ADA', blkchol, deninfac.m:87-94 (no dense columns)."""
+
+    def factor(self, S, d, DAt, L, pars):
+        ADA, absd = self.form(S, d, DAt)                            # sedumi.m:446-452
+        LL, Ld, Lskip, Ladd = self.blkchol(L, ADA, pars, absd)      # sedumi.m:458
+        L = dict(L)
+        L["L"] = LL
+        Ld = vec(Ld).copy()
+        skip = sp.csc_matrix(Lskip).nonzero()[0]                    # deninfac.m:87-94
+        if skip.size:
+            perm0 = vec(L["perm"]).astype(int) - 1
+            dtol = np.maximum(pars["canceltol"] * vec(absd)[perm0[skip]], pars["abstol"])
+            Ld[skip[Ld[skip] <= dtol]] = 1.0
+        L["d"], L["skip"], L["add"] = Ld, Lskip, Ladd
+        L["nskip"], L["nadd"] = int(sp.csc_matrix(Lskip).nnz), int(sp.csc_matrix(Ladd).nnz)
+        return L
+
+
+class RefHot(MexShapedHot):
     """The reference's own MEX for the normal-equations path (sedumi.m:446-458, wrapPcg.m:56-59)."""
     name = "reference"
 
@@ -84,7 +104,7 @@ class RefHot:
         return self.ref.call("bwblkslv", 1, L, col(r))
 
 
-class HipHot:
+class HipHot(MexShapedHot):
     """This repository's library behind the same calls (sedumi_amd.mex mirrors the MEX signatures)."""
     name = "sedumi_amd"
 
@@ -110,6 +130,47 @@ class HipHot:
     def bw(self, L, r):
         from sedumi_amd import mex
         return mex.bwblkslv(L, col(r))
+
+
+class PlanHot:
+    """The resident tier (sedumi_amd.plan.Plan): the problem, the scaling, ADA', the factor and the solves live in HBM;
+    per iteration the loop uploads d.{l,det,q1,q2,u} (+ d.perm), and per solve one right-hand side."""
+    name = "sedumi_amd.plan"
+
+    def __init__(self, device=0):
+        self.device, self.plan = device, None
+
+    def factor(self, S, d, DAt, L, pars):
+        from sedumi_amd.plan import Plan
+        K = S["K"]
+        if self.plan is None:
+            self.plan = Plan(self.device)
+            self.plan.set_chol(S["L"], S["ADA"])
+            self.plan.set_ada(S["A"], S["Ablkjc"], K, S["DAt"]["q"] if K["q"].size else None)
+        pl = self.plan
+        pl.upload("dl", d["l"]); pl.upload("ddet", d["det"])
+        if K["q"].size:
+            pl.upload("q1", d["q1"]); pl.upload("q2", d["q2"])
+            pl.getdatq()                                            # getDAtm.m:39-44
+        if np.sum(K["s"]) > 0:
+            pl.upload("u", d["u"])
+            pl.invcholfac(d["perm"] if np.size(d["perm"]) else None)   # sedumi.m:452
+        pl.getada()                                                 # sedumi.m:446-452
+        pl.blkchol(pars, True)                                      # sedumi.m:458
+        (si, _), (ai, _) = pl.pivots()
+        Ld = pl.download("d")
+        Ld[si] = np.where(Ld[si] <= 0.0, 1.0, Ld[si])               # deninfac.m:87-94 (skipped pivots carry d = 0)
+        L = dict(L)
+        L["d"], L["nskip"], L["nadd"] = Ld, int(si.size), int(ai.size)
+        return L
+
+    def fw(self, L, r):
+        self.plan.upload("rhs", vec(r)); self.plan.fwsolve()
+        return self.plan.download("y")
+
+    def bw(self, L, r):
+        self.plan.upload("rhs", vec(r)); self.plan.bwsolve()
+        return self.plan.download("y")
 
 
 # ----------------------------------------------------------------------------------------------- cone algebra
@@ -825,18 +886,7 @@ class Sedumi:
                 stepdif = 1
             self.pars["stepdif"] = stepdif
             DAt = self.G.getDAtm(S, d)                              # sedumi.m:442
-            ADA, absd = hot.form(S, d, DAt)                         # sedumi.m:446-452
-            LL, Ld, Lskip, Ladd = hot.blkchol(L, ADA, pars["chol"], absd)    # sedumi.m:458
-            L["L"] = LL
-            Ld = vec(Ld).copy()
-            skip = sp.csc_matrix(Lskip).nonzero()[0]                # deninfac.m:77-94 (no dense columns)
-            if skip.size:
-                perm0 = vec(L["perm"]).astype(int) - 1
-                dtol = np.maximum(pars["chol"]["canceltol"] * vec(absd)[perm0[skip]], pars["chol"]["abstol"])
-                fix = skip[Ld[skip] <= dtol]
-                Ld[fix] = 1.0
-            L["d"] = Ld
-            L["skip"], L["add"] = Lskip, Ladd
+            L = hot.factor(S, d, DAt, L, pars["chol"])                 # sedumi.m:446-463
             Lsd = self.sdfactor(L, d, DAt, v, y, R, y0)              # sedumi.m:466
             y0Old = y0
             xscl, yNxt, zscl, y0Nxt, w, relt, dxmdz, err, wr = self.wregion(L, Lsd, d, v, vfrm, DAt, R, y, y0, wr)
@@ -879,7 +929,7 @@ class Sedumi:
             precision2 = (y0 * r0 + rgap) / x0
             row = {"iter": it, "by_x0": by / x0, "gap": merit, "delta": wr["delta"], "rate": rate, "tP": relt["p"], "tD": relt["d"],
                    "feas": feasratio, "kcg1": err["kcg"], "kcg2": Lsd["kcg"], "prec": max(precision1, precision2),
-                   "nskip": int(sp.csc_matrix(Lskip).nnz), "nadd": int(sp.csc_matrix(Ladd).nnz)}
+                   "nskip": L["nskip"], "nadd": L["nadd"]}
             rows.append(row)
             if verbose:
                 print(" %2d : %10.2E %8.2E %5.3f %6.4f %6.4f %6.4f %6.2f %2d %2d  %1.1E" % (

@@ -5,7 +5,8 @@ count, same residual columns, same objective values as examples/test_sedumi.m:22
   * reference hot path, CPU:          the restatement itself reproduces test_sedumi.m's optimal values (tol 1e-6, as there)
                                       and the committed log (tests/golden/driver_*.npz, make_driver_golden.py);
   * library through the emulator, CPU: arch0 (PSD + LP) and nb (Lorentz, getada.m route) against that log;
-  * library on the GPU:               arch0, control07, nb against that log.
+  * library on the GPU:               arch0, control07, nb against that log,
+each time through the MEX-shaped calls (sedumi_amd.mex) and through the resident plan (sedumi_amd.plan.Plan).
 
 The last iteration or two of a run sit at the edge of double precision (the reference needs 30-90 CG steps there and
 skips pivots), so the logs are compared row by row up to two iterations before the shorter run ends, and the
@@ -70,20 +71,21 @@ def test_loop_restatement_reproduces_the_reference_objectives(name):
     check_log(name, r, g, 1e-6, 1e-6)
 
 
-@pytest.mark.parametrize("name", ["nb", "arch0"])
-def test_loop_on_the_emulated_library_follows_the_reference_log(name):
+@pytest.mark.parametrize("name,tier", [("nb", "mex"), ("nb", "plan"), ("arch0", "plan")])
+def test_loop_on_the_emulated_library_follows_the_reference_log(name, tier):
     from driver import sedumi_loop as sl
     helpers.use_emu()
-    r, g = run(name, sl.HipHot())
+    r, g = run(name, sl.HipHot() if tier == "mex" else sl.PlanHot())
     check_objectives(name, r)
     check_log(name, r, g, 1e-2, 1e-2)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tier", ["mex", "plan"])
 @pytest.mark.parametrize("name", ["nb", "arch0", "control07"])
-def test_loop_on_the_gpu_follows_the_reference_log(name):
+def test_loop_on_the_gpu_follows_the_reference_log(name, tier):
     from driver import sedumi_loop as sl
     helpers.use_hip()
-    r, g = run(name, sl.HipHot())
+    r, g = run(name, sl.HipHot() if tier == "mex" else sl.PlanHot())
     check_objectives(name, r)
     check_log(name, r, g, 1e-2, 1e-2)

@@ -53,6 +53,7 @@ class MexShapedHot:
 
     def factor(self, S, d, DAt, L, pars):
         ADA, absd = self.form(S, d, DAt)                            # sedumi.m:446-452
+        self.last_ADA = ADA
         LL, Ld, Lskip, Ladd = self.blkchol(L, ADA, pars, absd)      # sedumi.m:458
         L = dict(L)
         L["L"] = LL
@@ -158,6 +159,8 @@ class PlanHot:
         pl.getada()                                                 # sedumi.m:446-452
         pl.blkchol(pars, True)                                      # sedumi.m:458
         (si, _), (ai, _) = pl.pivots()
+        pat = pl.ADA_pattern
+        self.last_ADA = sp.csc_matrix((pl.download("ada"), pat.indices, pat.indptr), shape=pat.shape)
         Ld = pl.download("d")
         Ld[si] = np.where(Ld[si] <= 0.0, 1.0, Ld[si])               # deninfac.m:87-94 (skipped pivots carry d = 0)
         L = dict(L)
@@ -171,6 +174,55 @@ class PlanHot:
     def bw(self, L, r):
         self.plan.upload("rhs", vec(r)); self.plan.bwsolve()
         return self.plan.download("y")
+
+
+class ShadowHot:
+    """Runs `shadow` next to `primary` on identical inputs -- every factorisation and every solve of a whole run, i.e. the
+    scalings a real solve produces, ill-conditioned tail included -- records how far the two are apart, and continues
+    with the primary's results."""
+
+    def __init__(self, primary, shadow):
+        self.primary, self.shadow, self.name = primary, shadow, primary.name + "+shadow"
+        self.records, self.it = [], 0
+
+    @staticmethod
+    def _rel(a, b):
+        return float(np.linalg.norm(vec(a) - vec(b)) / max(np.linalg.norm(vec(b)), 1e-300))
+
+    def factor(self, S, d, DAt, L, pars):
+        Lp = self.primary.factor(S, d, DAt, L, pars)
+        self.Ls = self.shadow.factor(S, d, DAt, L, pars)
+        self.it += 1
+        Ap, As = getattr(self.primary, "last_ADA", None), getattr(self.shadow, "last_ADA", None)
+        self.cur = {"iter": self.it, "d": self._rel(self.Ls["d"], Lp["d"]),
+                    "ada": float(abs(As - Ap).max() / abs(Ap).max()) if Ap is not None and As is not None else np.nan,
+                    "ada_asym": float(abs(As - As.T).max() / abs(As).max()) if As is not None else np.nan, "nskip": (self.Ls["nskip"], Lp["nskip"]),
+                    "nadd": (self.Ls["nadd"], Lp["nadd"]), "fw": 0.0, "bw": 0.0, "nsolves": 0,
+                    "dcond": float(np.max(Lp["d"]) / max(np.min(Lp["d"]), 1e-300))}
+        self.records.append(self.cur)
+        return Lp
+
+    def fw(self, L, r):
+        a, b = self.primary.fw(L, r), self.shadow.fw(self.Ls, r)
+        self.cur["fw"] = max(self.cur["fw"], self._rel(b, a)); self.cur["nsolves"] += 1
+        self.rhs, self.fw_shadow = vec(r), vec(b)
+        return a
+
+    def bw(self, L, r):
+        """Always the second half of x = ADA \\ rhs (wrapPcg.m:56-59): next to the distance between the two results, the
+        normwise backward error |ADA x - rhs| / (|ADA| |x| + |rhs|) of each path is kept -- the two factors differ at the
+        1e-11 level late in a run, so on an ill-conditioned ADA' the solutions legitimately differ by cond x that."""
+        a = self.primary.bw(L, r)
+        b = self.shadow.bw(self.Ls, self.fw_shadow / vec(self.Ls["d"]))              # the shadow's own (fw ./ d)
+        self.cur["bw"] = max(self.cur["bw"], self._rel(b, a))
+        if self.cur["nskip"] == (0, 0):
+            for key, hot, x in (("berr_ref", self.primary, vec(a)), ("berr_lib", self.shadow, vec(b))):
+                ADA = getattr(hot, "last_ADA", None)                # each path against the ADA' it factored itself
+                if ADA is not None:
+                    nA = abs(ADA).sum(axis=0).max()
+                    e = np.abs(ADA @ x - self.rhs).max() / (nA * np.abs(x).max() + np.abs(self.rhs).max())
+                    self.cur[key] = max(self.cur.get(key, 0.0), float(e))
+        return a
 
 
 # ----------------------------------------------------------------------------------------------- cone algebra

@@ -323,9 +323,39 @@ def factor_flops(plan):
 
 
 def stage1_flops(P):
-    """2 * n_k^2 * (nonzero columns of A_jk) summed over the (constraint, block) tasks."""
-    s = P.K["s"].ravel().astype(np.int64)
-    return float(2.0 * np.sum(s.astype(np.float64) ** 2 * s) * P.m) if s.size else 0.0
+    """FLOPs of ADA' stage 1 per unit, summed over the (constraint j, PSD block k) tasks that have nonzeros (DESIGN.md
+    section 3): blocks of order n <= 96 (k_psd_stage1_mfma) 2 n^2 nslot (Z = Y D(cols,:) dense) + 2 nnz n (Y); larger and
+    Hermitian blocks (k_psd_stage1) 2 nnz n + 4 |U_k| nslot (two dots per target of the block's union pattern U_k);
+    nslot = distinct columns among the stored nonzeros of A_jk."""
+    K = P.K
+    s = K["s"].ravel().astype(np.int64)
+    if not s.size:
+        return 0.0
+    import scipy.sparse as sp
+    At = sp.csc_matrix(P.At)
+    start = (K["blkstart"].ravel().astype(np.int64) - 1)[1 + K["q"].size:]            # first row of every PSD block, then N
+    rsdpN = int(np.asarray(K.get("rsdpN", s.size)).ravel()[0])
+    rows = At.indices
+    cols = np.repeat(np.arange(At.shape[1]), np.diff(At.indptr))
+    sel = rows >= start[0]
+    rows, cols = rows[sel], cols[sel]
+    blk = np.searchsorted(start, rows, side="right") - 1
+    off = rows - start[blk]
+    n = s[blk]
+    colin = (off % (n * n)) // n                                                       # column inside the block (either plane)
+    task = cols.astype(np.int64) * s.size + blk
+    nnz_t = np.bincount(task, minlength=At.shape[1] * s.size).astype(np.float64)
+    slot_key = np.unique(task * (int(s.max()) + 1) + colin)
+    nslot_t = np.bincount(slot_key // (int(s.max()) + 1), minlength=At.shape[1] * s.size).astype(np.float64)
+    ulen = np.bincount(blk[np.unique(blk * (2 * int(s.max()) ** 2 + 1) + off, return_index=True)[1]], minlength=s.size).astype(np.float64)
+    tot = 0.0
+    for k in range(s.size):
+        nk, sl = float(s[k]), slice(k, None, s.size)
+        if s[k] <= 96 and k < rsdpN and s.max() <= 96:
+            tot += float(np.sum(2.0 * nk * nk * nslot_t[sl] + 2.0 * nnz_t[sl] * nk))
+        else:
+            tot += float(np.sum(2.0 * nnz_t[sl] * nk + 4.0 * ulen[k] * nslot_t[sl]))
+    return tot
 
 
 def measure_config(name, device, steps, warmup, nprof):

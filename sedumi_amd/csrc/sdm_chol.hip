@@ -469,8 +469,10 @@ __device__ __forceinline__ void rows_stage(const double *Fs, int ld, int ms, int
 #pragma unroll
   for (int c4 = 0; c4 < NB / 4; c4++) { const int c = 4 * c4 + lk; Tw[c * 17 + li] = c < kb ? tv[c4] : 0.0; }
 }
-// 16-column block b of the blocked substitution on the wave tile: needs columns 0 .. 16b+15 of S (L11) and ds
-__device__ __forceinline__ void rows_block(int b, const double (*S)[NB + 1], const double *ds, double *Tw, int lane) {
+// 16-column block b of the blocked substitution on the wave tile, in two halves: the product part needs the columns
+// 0 .. 16b-1 of L11 only (rows 16b .. 16b+15 of them), the triangle its columns 16b .. 16b+15 and their pivots -- the
+// row-solve workgroups run the first half BEFORE they wait for the publication of the block's own 16 columns
+__device__ __forceinline__ void rows_block_gemm(int b, const double (*S)[NB + 1], double *Tw, int lane) {
   const int li = lane & 15, lk = lane >> 4;
   const int cb = 16 * b;
   if (b > 0) {
@@ -486,6 +488,10 @@ __device__ __forceinline__ void rows_block(int b, const double (*S)[NB + 1], con
     for (int r = 0; r < 4; r++) Tw[(cb + li) * 17 + lk + 4 * r] = acc[r];
     SDM_WAVE_SYNC();
   }
+}
+__device__ __forceinline__ void rows_block_tri(int b, const double (*S)[NB + 1], const double *ds, double *Tw, int lane) {
+  const int li = lane & 15;
+  const int cb = 16 * b;
   // the 16x16 triangle by substitution, lane li = row (the 4 lane groups lk compute the same row redundantly),
   // column-oriented: once x_j is final, x_c -= x_j l_cj for all c > j (independent updates, one LDS round trip
   // per column of the triangle) -- no inverse of the block is formed (multipliers may be as large as maxu)
@@ -511,6 +517,10 @@ __device__ __forceinline__ void rows_block(int b, const double (*S)[NB + 1], con
 #pragma unroll
   for (int c = 0; c < 16; c++) Tw[(cb + c) * 17 + li] = x[c];
   SDM_WAVE_SYNC();
+}
+__device__ __forceinline__ void rows_block(int b, const double (*S)[NB + 1], const double *ds, double *Tw, int lane) {
+  rows_block_gemm(b, S, Tw, lane);
+  rows_block_tri(b, S, ds, Tw, lane);
 }
 // l = x / d out of the wave tile into the front
 __device__ __forceinline__ void rows_store(double *Fs, int ld, int ms, int k0, int kb, int R0, const double *ds, const double *Tw, int lane) {
@@ -688,6 +698,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
       double *Tw = RB + ty * (NB * 17);
       if (!(phase == 0 && panel > 0) && busy) rows_stage(Fs, ld, rend, k0c, kbc, R0, Tw, tx);      // else staged by the update above
       for (int blk = 0; blk < NB / 16 && 16 * blk < kbc; blk++) {
+        if (busy) rows_block_gemm(blk, S, Tw, tx);                   // needs earlier columns only: off the tail of the launch
         spin_until(diag_cnt + s, 4 * panel + blk + 1, tmo);            // columns 16 blk .. of L11 and their pivots are in DT / d
         for (int e = tid; e < NB * 16; e += LDL_THREADS) {
           const int i = e >> 4, j = 16 * blk + (e & 15);
@@ -695,7 +706,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
         }
         if (tid < 16) dsr[16 * blk + tid] = 16 * blk + tid < kbc ? d[first + k0c + 16 * blk + tid] : 0.0;
         __syncthreads();
-        if (busy) rows_block(blk, S, dsr, Tw, tx);
+        if (busy) rows_block_tri(blk, S, dsr, Tw, tx);
       }
       if (busy) rows_store(Fs, ld, rend, k0c, kbc, R0, dsr, Tw, tx);
       return;
@@ -1048,7 +1059,7 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
              C.d_asm_dst.p, (int64_t)C.nnzL, C.ub.p);
   SDM_KLAUNCH(P, k_prep_pivots, dim3(grid1d(m, 256, 64)), dim3(256), 0, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
              P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, (int)C.nsuper, C.upd_cnt.p, C.diag_cnt.p,
-             C.sb_g.p, 2 * C.nsbtot);
+             C.sb_g.p, 4 * C.nsbtot);
   for (int l = 0; l < C.nlevels; l++) {
     const int *list = C.d_levlist.p + C.levptr[l];
     const int nfr = C.levptr[l + 1] - C.levptr[l];

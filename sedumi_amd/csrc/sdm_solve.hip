@@ -30,6 +30,7 @@ namespace sdm {
 constexpr int ST = 256;          // work-items per workgroup of every kernel in this file
 constexpr int TP = 65;           // LDS pitch of staged 64-wide operand blocks (conflict-free transposing stores)
 constexpr size_t INV_LDS = (size_t)4 * 64 * TP * sizeof(double);      // k_sinv128: four staged 64x64 blocks
+constexpr int SPREP_MAX_ITEMS = 256;                                  // k_sprep: one workgroup per item, all resident (one per CU)
 constexpr size_t TILE_LDS = (size_t)2 * 64 * TP * sizeof(double);     // k_stile: one A and one B operand block
 
 // ---------------------------------------------------------------- host tables
@@ -67,8 +68,9 @@ void solve_build(sdm_plan *P) {
   SDM_HIP_CHECK(hipMemset(C.S.p, 0, (size_t)std::max<int64_t>(soff, 1) * sizeof(double)));   // upper triangles stay zero for good
   C.xfin.alloc((size_t)std::max<sdm_int>(C.m, 1)); C.zdiv.alloc((size_t)std::max<sdm_int>(C.m, 1));
   C.ttmp.alloc((size_t)std::max(tslots, 1) * 128 * 128);
-  C.sb_g.alloc((size_t)std::max(2 * sb, 2)); C.sb_cnt.alloc((size_t)std::max(sb, 1));
-  SDM_HIP_CHECK(hipMemset(C.sb_g.p, 0, (size_t)std::max(2 * sb, 2) * sizeof(unsigned long long)));
+  // growth records (2 per super-block), then the completion counters of k_sprep (4 ints = 2 words per super-block)
+  C.sb_g.alloc((size_t)std::max(4 * sb, 4)); C.sb_cnt.alloc((size_t)std::max(sb, 1));
+  SDM_HIP_CHECK(hipMemset(C.sb_g.p, 0, (size_t)std::max(4 * sb, 4) * sizeof(unsigned long long)));
   SDM_HIP_CHECK(hipMemset(C.sb_cnt.p, 0, (size_t)std::max(sb, 1) * sizeof(int)));
   // levels
   C.slev.assign(C.nlevels, SolveLevel());
@@ -184,12 +186,18 @@ __device__ __forceinline__ void stage_transposed_store(double *dst, const double
   }
 }
 // Cs[row*TP + col] (LDS) -> column-major destination, rows < nr, cols < nc; returns max |value| written
+// WT: write-through stores (the tile is read by other workgroups of the SAME launch, k_sprep)
+template <bool WT = false>
 __device__ __forceinline__ double store_tile(double *dst, int64_t ld, const double *Cs, int nr, int nc, int tid) {
   const int r = tid & 63, cq = tid >> 6;
   double mx = 0.0;
 #pragma unroll 4
   for (int c = cq; c < 64; c += ST / 64)
-    if (r < nr && c < nc) { const double v = Cs[r * TP + c]; dst[(int64_t)c * ld + r] = v; mx = fabs(v) > mx ? fabs(v) : mx; }
+    if (r < nr && c < nc) {
+      const double v = Cs[r * TP + c];
+      if (WT) sdm_store_wt(&dst[(int64_t)c * ld + r], v); else dst[(int64_t)c * ld + r] = v;
+      mx = fabs(v) > mx ? fabs(v) : mx;
+    }
   return mx;
 }
 
@@ -201,11 +209,11 @@ __device__ __forceinline__ double store_tile(double *dst, int64_t ld, const doub
 //   64x64  X10 = -inv(A11) (A10 inv(A00)) for the two 64-column blocks A and C (plain FMAs from LDS, two wavefronts each);
 //   128    X21 = -inv(C) (B inv(A)) on the FP64 matrix cores, B = L(C rows, A columns) requested at the very start.
 // Results go to S; max|inv| and max|L| to sb_g (growth check).
-__global__ void __launch_bounds__(ST)
-k_sinv128(const double *__restrict__ F, double *__restrict__ S, FrontTab tab, const int *items, unsigned long long *sb_g) {
-  SDM_DYN_SMEM(smem);
+template <bool WT>
+__device__ __forceinline__ void sinv128_body(char *smem, const double *__restrict__ F, double *__restrict__ S, const FrontTab &tab,
+                                             const int *it, unsigned long long *sb_g) {
   double *bufA = (double *)smem, *bufC = bufA + 64 * TP, *bufB = bufC + 64 * TP, *bufT = bufB + 64 * TP;
-  const int s = items[4 * blockIdx.x], h = items[4 * blockIdx.x + 1];
+  const int s = it[0], h = it[1];
   const int ns = tab.ns[s], ld = tab.ld[s], sld = tab.sld[s];
   const double *Fs = F + tab.foff[s];
   double *Ss = S + tab.soff[s];
@@ -306,8 +314,8 @@ k_sinv128(const double *__restrict__ F, double *__restrict__ S, FrontTab tab, co
   // inverses to S (lower triangles incl. the unit diagonal; the upper triangles of S are zero and stay zero)
   for (int e = tid; e < 64 * 64; e += ST) {
     const int i = e & 63, j = e >> 6;
-    if (i >= j && i < nbA) Ss[(int64_t)(k0 + j) * sld + k0 + i] = bufA[i * TP + j];
-    if (i >= j && i < nbC) Ss[(int64_t)(k0 + 64 + j) * sld + k0 + 64 + i] = bufC[j * TP + i];
+    if (i >= j && i < nbA) { if (WT) sdm_store_wt(&Ss[(int64_t)(k0 + j) * sld + k0 + i], bufA[i * TP + j]); else Ss[(int64_t)(k0 + j) * sld + k0 + i] = bufA[i * TP + j]; }
+    if (i >= j && i < nbC) { if (WT) sdm_store_wt(&Ss[(int64_t)(k0 + 64 + j) * sld + k0 + 64 + i], bufC[j * TP + i]); else Ss[(int64_t)(k0 + 64 + j) * sld + k0 + 64 + i] = bufC[j * TP + i]; }
   }
   if (nbC <= 0) return;
   __syncthreads();
@@ -321,19 +329,23 @@ k_sinv128(const double *__restrict__ F, double *__restrict__ S, FrontTab tab, co
   __syncthreads();                                                  // bufB is free: stage the result for coalesced stores
   acc_to_lds_rowmajor(acc, bufB, wave, lane, -1.0);
   __syncthreads();
-  const double gm = store_tile(Ss + (int64_t)k0 * sld + k0 + 64, sld, bufB, nbC, 64, tid);
+  const double gm = store_tile<WT>(Ss + (int64_t)k0 * sld + k0 + 64, sld, bufB, nbC, 64, tid);
   wave_atomic_max(gP, gm, lane);
+}
+__global__ void __launch_bounds__(ST)
+k_sinv128(const double *__restrict__ F, double *__restrict__ S, FrontTab tab, const int *items, unsigned long long *sb_g) {
+  SDM_DYN_SMEM(smem);
+  sinv128_body<false>(smem, F, S, tab, items + 4 * blockIdx.x, sb_g);
 }
 
 // Generic product tile  C(64x64) = sgn * sum_k A(:,k) B(k,:)  for the remaining stages:
 //   mode 0  T(I,J)  = sum_{K>=J} B2(I,K) inv(A2)(K,J)          (level 3, first half; into the scratch ttmp)
 //   mode 1  X(I,J)  = - sum_{K<=I} inv(C2)(I,K) T(K,J)         (level 3, second half; into S)
 //   mode 2  S_PQ tile (I,J) = sum_{K<=I} inv(L_PP)(I,K) L(P rows K, columns J)     (premultiplication; into S)
-__global__ void __launch_bounds__(ST)
-k_stile(const double *F, double *S, double *ttmp, FrontTab tab, const int *items, unsigned long long *sb_g, int mode, double thr) {
-  SDM_DYN_SMEM(smem);
+template <bool WT>
+__device__ __forceinline__ void stile_body(char *smem, const double *F, double *S, double *ttmp, const FrontTab &tab, const int *it,
+                                           unsigned long long *sb_g, int mode, double thr) {
   double *As = (double *)smem, *Bs = As + 64 * TP;
-  const int *it = items + 4 * blockIdx.x;
   const int s = it[0], Pb = it[1];
   const int ns = tab.ns[s], ld = tab.ld[s], sld = tab.sld[s];
   const double *Fs = F + tab.foff[s];
@@ -388,8 +400,58 @@ k_stile(const double *F, double *S, double *ttmp, FrontTab tab, const int *items
   if (track_l) wave_atomic_max(gP + 1, lmx, lane);
   acc_to_lds_rowmajor(acc, As, wave, lane, sgn);
   __syncthreads();
-  const double gm = store_tile(Cp, ldc, As, arows, 64, tid);
+  const double gm = store_tile<WT>(Cp, ldc, As, arows, 64, tid);
   if (track_g) wave_atomic_max(gP, gm, lane);
+}
+__global__ void __launch_bounds__(ST)
+k_stile(const double *F, double *S, double *ttmp, FrontTab tab, const int *items, unsigned long long *sb_g, int mode, double thr) {
+  SDM_DYN_SMEM(smem);
+  stile_body<false>(smem, F, S, ttmp, tab, items + 4 * blockIdx.x, sb_g, mode, thr);
+}
+
+// ---- all of the above in ONE launch for problems whose items fit the device at once (k_sprep): workgroups take the
+// items in the order 128-blocks, level-3 first halves, level-3 second halves, premultiplication tiles, and wait on
+// per-super-block completion counters instead of on launch boundaries (three of them, ~4 us each, and their tails).
+// Producers store write-through, count after their stores are acknowledged; consumers poll with acquire loads.
+// cnt[4*sb + 0/1/2] = finished 128-blocks / first halves / second halves of super-block sb (zeroed with sb_g).
+__device__ __forceinline__ void prep_wait(const int *cnt, int target, int *tmo) {
+  if (threadIdx.x == 0) {
+    long it = 0;
+    for (; sdm_signal_load(cnt) < target && it < (1L << 21); it++) SDM_SPIN_PAUSE();
+    if (it == (1L << 21)) sdm_raise_flag(tmo);
+  }
+  __syncthreads();
+  SDM_ACQUIRE_FENCE();
+}
+__device__ __forceinline__ void prep_done(int *cnt) {
+  SDM_STORES_DONE();
+  __syncthreads();
+  if (threadIdx.x == 0) sdm_signal_add(cnt);
+}
+__global__ void __launch_bounds__(ST)
+k_sprep(const double *F, double *S, double *ttmp, FrontTab tab, const int *l_i128, int n_i128, const int *l_t3, int n_t3,
+        const int *l_pm, int n_pm, unsigned long long *sb_g, int *cnt, double thr, int *tmo) {
+  SDM_DYN_SMEM(smem);
+  int b = blockIdx.x;
+  if (b < n_i128) {
+    const int *it = l_i128 + 4 * b;
+    sinv128_body<true>(smem, F, S, tab, it, sb_g);
+    // the growth maxima (atomicMax, device scope) are read by the premultiplication tiles of this launch as well
+    prep_done(cnt + 4 * (tab.sboff[it[0]] + (128 * it[1]) / SBW));
+    return;
+  }
+  b -= n_i128;
+  const int mode = b < n_t3 ? 0 : (b < 2 * n_t3 ? 1 : 2);
+  const int *it = mode == 2 ? l_pm + 4 * (b - 2 * n_t3) : l_t3 + 4 * (b - mode * n_t3);
+  const int s = it[0], Pb = it[1];
+  const int nb = min(SBW, tab.ns[s] - Pb * SBW);
+  const int n128 = (nb + 127) / 128, nt = nb > 128 ? 2 * ((nb - 128 + 63) / 64) : 0;
+  int *c = cnt + 4 * (tab.sboff[s] + Pb);
+  prep_wait(c, n128, tmo);
+  if (mode == 1) prep_wait(c + 1, nt, tmo);
+  if (mode == 2 && nt > 0) prep_wait(c + 2, nt, tmo);
+  stile_body<true>(smem, F, S, ttmp, tab, it, sb_g, mode, thr);
+  if (mode < 2) prep_done(c + 1 + mode);
 }
 
 // ================================================================ substitution fallback for one super-block
@@ -795,12 +857,19 @@ void solve_prepare(sdm_plan *P, bool sb_g_is_zero) {
   if (!attr) {
     SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_sinv128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)INV_LDS));
     SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_stile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS));
+    SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_sprep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)INV_LDS));
     attr = true;
   }
 #endif
   C.growth_used = C.growth_max;                                     // the solves decide with the bound the premultiplication saw
   if (!sb_g_is_zero)                                                // (a factorisation zeroes them in k_prep_pivots)
-    SDM_HIP_CHECK(hipMemsetAsync(C.sb_g.p, 0, (size_t)std::max(2 * C.nsbtot, 2) * sizeof(unsigned long long), P->stream));
+    SDM_HIP_CHECK(hipMemsetAsync(C.sb_g.p, 0, (size_t)std::max(4 * C.nsbtot, 4) * sizeof(unsigned long long), P->stream));
+  const int nitems = C.n_i128 + 2 * C.n_t3 + C.n_pm;
+  if (nitems <= SPREP_MAX_ITEMS && C.n_i128 > 0) {                   // everything resident at once: one launch, counters instead of boundaries
+    SDM_KLAUNCH(P, k_sprep, dim3(nitems), dim3(ST), INV_LDS, C.fronts.p, C.S.p, C.ttmp.p, tab, C.l_i128.p, C.n_i128, C.l_t3.p, C.n_t3,
+                C.l_pm.p, C.n_pm, C.sb_g.p, (int *)(C.sb_g.p + 2 * C.nsbtot), C.growth_used, C.tmo.dev());
+    return;
+  }
   if (C.n_i128) SDM_KLAUNCH(P, k_sinv128, dim3(C.n_i128), dim3(ST), INV_LDS, C.fronts.p, C.S.p, tab, C.l_i128.p, C.sb_g.p);
   if (C.n_t3) {
     SDM_KLAUNCH(P, k_stile, dim3(C.n_t3), dim3(ST), TILE_LDS, C.fronts.p, C.S.p, C.ttmp.p, tab, C.l_t3.p, C.sb_g.p, 0, C.growth_used);

@@ -221,6 +221,7 @@ __device__ __forceinline__ void sinv128_body(char *smem, const double *__restric
   unsigned long long *gP = sb_g + 2 * (tab.sboff[s] + k0 / SBW);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double vB[SPT];
+  SDM_PHASE_BEGIN();
   if (nbC > 0) stage_colmajor_load(vB, Fs + (int64_t)k0 * ld + k0 + 64, ld, nbC, 64, tid);     // B(row, k) = L(k0+64+row, k0+k)
   // raw strictly lower triangles, column-major: rawA[k*TP + i] = L(k0+i, k0+k) (bufT), rawC likewise (bufB); the
   // destination buffers start as zero
@@ -245,6 +246,7 @@ __device__ __forceinline__ void sinv128_body(char *smem, const double *__restric
     }
   }
   __syncthreads();
+  SDM_PHASE(0);
   const int blk = wave >> 1, q = wave & 1;                          // wavefront -> (64-block A / C, 32-block inside it)
   const double *raw = blk == 0 ? rawA : rawC;
   double *dst = blk == 0 ? bufA : bufC;
@@ -270,7 +272,9 @@ __device__ __forceinline__ void sinv128_body(char *smem, const double *__restric
     }
     wave_atomic_max(gP, gm, lane);
   }
+  SDM_PHASE(1);
   __syncthreads();
+  SDM_PHASE(2);
   {
     // ---- 64x64: X10 = -inv11 (L10 inv00), two wavefronts per block, plain FMAs from LDS.  T1 goes to the unused
     // upper right quadrant of the raw buffer (rows 32.., columns < 32 of raw[k*TP + i] hold zeros of the upper triangle)
@@ -308,6 +312,7 @@ __device__ __forceinline__ void sinv128_body(char *smem, const double *__restric
     }
     wave_atomic_max(gP, gm, lane);
   }
+  SDM_PHASE(3);
   __syncthreads();                                                  // bufA = inv(A) (B operand), bufC = inv(C) (A operand); raw buffers free
   if (nbC > 0) lmx = fmax(lmx, stage_colmajor_store(bufB, vB, nbC, 64, tid));
   wave_atomic_max(gP + 1, lmx, lane);
@@ -317,6 +322,7 @@ __device__ __forceinline__ void sinv128_body(char *smem, const double *__restric
     if (i >= j && i < nbA) { if (WT) sdm_store_wt(&Ss[(int64_t)(k0 + j) * sld + k0 + i], bufA[i * TP + j]); else Ss[(int64_t)(k0 + j) * sld + k0 + i] = bufA[i * TP + j]; }
     if (i >= j && i < nbC) { if (WT) sdm_store_wt(&Ss[(int64_t)(k0 + 64 + j) * sld + k0 + 64 + i], bufC[j * TP + i]); else Ss[(int64_t)(k0 + 64 + j) * sld + k0 + 64 + i] = bufC[j * TP + i]; }
   }
+  SDM_PHASE(4);
   if (nbC <= 0) return;
   __syncthreads();
   Acc22 acc;
@@ -329,8 +335,10 @@ __device__ __forceinline__ void sinv128_body(char *smem, const double *__restric
   __syncthreads();                                                  // bufB is free: stage the result for coalesced stores
   acc_to_lds_rowmajor(acc, bufB, wave, lane, -1.0);
   __syncthreads();
+  SDM_PHASE(5);
   const double gm = store_tile<WT>(Ss + (int64_t)k0 * sld + k0 + 64, sld, bufB, nbC, 64, tid);
   wave_atomic_max(gP, gm, lane);
+  SDM_PHASE(6);
 }
 __global__ void __launch_bounds__(ST)
 k_sinv128(const double *__restrict__ F, double *__restrict__ S, FrontTab tab, const int *items, unsigned long long *sb_g) {
@@ -384,6 +392,7 @@ __device__ __forceinline__ void stile_body(char *smem, const double *F, double *
   acc_zero(acc);
   double lmx = 0.0;
   double va[SPT], vb[SPT];
+  SDM_PHASE_BEGIN();
   stage_colmajor_load(va, Ap, lda, arows, kvalid, tid);
   stage_transposed_load(vb, Bp, ldb, kvalid, 64, tid);
   for (int kb = 0; kb < kvalid; kb += 64) {
@@ -397,11 +406,16 @@ __device__ __forceinline__ void stile_body(char *smem, const double *F, double *
     mma_block(acc, As, Bs, wave, lane);
     __syncthreads();
   }
+  SDM_PHASE(8 + 4 * mode);
   if (track_l) wave_atomic_max(gP + 1, lmx, lane);
   acc_to_lds_rowmajor(acc, As, wave, lane, sgn);
   __syncthreads();
   const double gm = store_tile<WT>(Cp, ldc, As, arows, 64, tid);
   if (track_g) wave_atomic_max(gP, gm, lane);
+  SDM_PHASE(9 + 4 * mode);
+#if defined(SDM_PHASES) && !defined(SDM_EMU)
+  if (tid == 0) atomicAdd(&sdm_phase_acc[10 + 4 * mode], 1ull);
+#endif
 }
 __global__ void __launch_bounds__(ST)
 k_stile(const double *F, double *S, double *ttmp, FrontTab tab, const int *items, unsigned long long *sb_g, int mode, double thr) {
@@ -865,7 +879,8 @@ void solve_prepare(sdm_plan *P, bool sb_g_is_zero) {
   if (!sb_g_is_zero)                                                // (a factorisation zeroes them in k_prep_pivots)
     SDM_HIP_CHECK(hipMemsetAsync(C.sb_g.p, 0, (size_t)std::max(4 * C.nsbtot, 4) * sizeof(unsigned long long), P->stream));
   const int nitems = C.n_i128 + 2 * C.n_t3 + C.n_pm;
-  if (nitems <= SPREP_MAX_ITEMS && C.n_i128 > 0) {                   // everything resident at once: one launch, counters instead of boundaries
+  static const bool fused_off = getenv("SDM_SPREP_OFF") != nullptr;     // tuning override (tools only)
+  if (nitems <= SPREP_MAX_ITEMS && C.n_i128 > 0 && !fused_off) {                   // everything resident at once: one launch, counters instead of boundaries
     SDM_KLAUNCH(P, k_sprep, dim3(nitems), dim3(ST), INV_LDS, C.fronts.p, C.S.p, C.ttmp.p, tab, C.l_i128.p, C.n_i128, C.l_t3.p, C.n_t3,
                 C.l_pm.p, C.n_pm, C.sb_g.p, (int *)(C.sb_g.p + 2 * C.nsbtot), C.growth_used, C.tmo.dev());
     return;
@@ -972,3 +987,12 @@ void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode) {
 }
 
 }  // namespace sdm
+
+#if defined(SDM_PHASES) && !defined(SDM_EMU)
+// tools-only build (python -m sedumi_amd.build --phases): read / reset the in-kernel phase clocks of this file
+extern "C" int sdm_debug_phases_solve(unsigned long long *out32, int reset) {
+  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(sdm_phase_acc), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sdm_phase_acc), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif

@@ -611,6 +611,253 @@ __device__ __forceinline__ void wait_prev_update(const int *cnt, int ns, int ms,
   spin_until(cnt, target, tmo);
 }
 
+// ---- LDL' of the 64-column diagonal block of panel `panel` of front s by ALL work-items of the calling workgroup (the
+// header of k_ldl_panel describes the method).  S (= smem) holds the block on entry unless load_block (then it is read
+// from the front), Lc = zero.  publish: other workgroups wait for the factored block -- it goes to DT / d 16 columns at
+// a time as it becomes final, diag_cnt[s] counts those publications (*npub of the 4 are out on return; the caller
+// signals the rest once the write-back below has been acknowledged).  On return: S = unit lower factor (scaled columns),
+// ds = pivots (LDS), the block written in place and to DT, d / pivstat / pivval stored.  Returns false when the block
+// went through the general path (a pivot asked for the never-fail rule's column probe).
+// PERSIST (k_ldl_front): upd_cnt = the front's per-tile-row counters of finished update steps.
+// (k_ldl_front) every tile row below `panel` has applied the updates of the panels before it
+__device__ __forceinline__ void front_wait_updates(const int *upd_done, int panel, int T, int *tmo) {
+  for (int r = panel + 1; r < T; r++) spin_until(upd_done + r, panel, tmo);
+}
+template <bool PERSIST>
+__device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT, const FrontTab &tab, int s, int panel, double *d, double *lb,
+                                               const double *ubp, int *pivstat, double *pivval, double *colbuf, const double *ada,
+                                               const int *asm_src, const int64_t *Ljc, int mtot, int *upd_cnt, int *diag_cnt, int q0, int *tmo,
+                                               bool load_block, bool publish, double *ds, int *npub) {
+  SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
+  double (*S)[NB + 1] = (double (*)[NB + 1])smem;                 // diagonal block, S[row][col]
+  double *RB = (double *)smem + NB * (NB + 1);                    // Lc during the LDL', then Xs / the wave tiles of the row solve
+  double *Lc = RB;                                                // Lc[k*NB+i] = l_ik
+  __shared__ double lbs[NB], pv[NB];
+  __shared__ int stt[NB];
+  __shared__ int badflag;
+  __shared__ double red_v[LDL_THREADS];
+  __shared__ int red_i[LDL_THREADS];
+  const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
+  const int k0 = panel * NB, kb = min(NB, ns - k0);
+  const int r0 = k0 + kb, nrows = ms - r0;
+  double *Fs = F + tab.foff[s];
+  double *cb = colbuf + tab.woff[s] + s;                          // probe scratch: ms + 1 doubles per front
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int tx = tid & 63, ty = tid >> 6, ny = bs >> 6;
+  const double maxu = ubp[1], ub = ubp[2] / (maxu * maxu);      // ubp[2] = max diagonal (k_prep_pivots)
+  if (load_block) {
+    double sv[NB / (LDL_THREADS / 64)];
+    const double *pc = Fs + (int64_t)k0 * ld + k0 + min(tx, kb - 1);
+#pragma unroll
+    for (int q = 0; q < NB / (LDL_THREADS / 64); q++) sv[q] = pc[(int64_t)min(ty + ny * q, kb - 1) * ld];     // all loads in flight
+#pragma unroll
+    for (int q = 0; q < NB / (LDL_THREADS / 64); q++) {
+      const int j = ty + ny * q;
+      // (columns beyond a partial block: unit diagonal, so that the straight-line sweep stays finite there)
+      if (j < NB) { S[tx][j] = (tx < kb && j <= tx) ? sv[q] : ((tx == j && tx >= kb) ? 1.0 : 0.0); Lc[j * NB + tx] = 0.0; }
+    }
+  }
+  if (tid < NB) { lbs[tid] = tid < kb ? lb[first + k0 + tid] : 0.0; ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
+  if (tid == 0) { badflag = 0; *npub = 0; }
+  SDM_PHASE_BEGIN();
+  __syncthreads();
+  SDM_PHASE(16);
+  // ---- LDL' of the block (see the header): wavefront 0 sweeps SW columns in registers while the other wavefronts
+  // apply the previous sweep to the trailing columns.  The sweep is straight-line code: a skipped pivot gives the
+  // multiplier 0, a pivot that needs the probe only raises `bad` (everything computed after it is discarded: the
+  // block is redone by the general path), the bookkeeping of pivot gc lives in lane gc.
+  const int nsw = (kb + SW - 1) / SW;
+  if (ty == 0) {
+    SDM_SETPRIO(3);
+    const double mylb = lbs[tx];
+    double xs[SW];                                                     // columns of the sweep just finished (unscaled)
+    for (int s = -1; s < nsw - 1; s++) {
+      const int c0 = s * SW, cn = c0 + SW;                             // sweep s is final; sweep columns cn .. cn+SW-1 now
+      double x[SW], lsc[SW];
+#pragma unroll
+      for (int cc = 0; cc < SW; cc++) x[cc] = S[tx][cn + cc];
+      if (s >= 0) {
+        // look-ahead: the columns of the next sweep receive sweep s here (x_rj -= l_jk * x_rk, k ascending)
+        // (multipliers fetched in two batches of SW/2 columns, all loads of a batch in flight before the first use)
+#pragma unroll
+        for (int kh = 0; kh < SW; kh += SW / 2) {
+          double lj[SW / 2][SW];
+#pragma unroll
+          for (int k = 0; k < SW / 2; k++)
+#pragma unroll
+            for (int cc = 0; cc < SW; cc++) lj[k][cc] = Lc[(c0 + kh + k) * NB + cn + cc];
+#pragma unroll
+          for (int k = 0; k < SW / 2; k++)
+#pragma unroll
+            for (int cc = 0; cc < SW; cc++) SDM_PIN(lj[k][cc]);
+#pragma unroll
+          for (int k = 0; k < SW / 2; k++)
+#pragma unroll
+            for (int cc = 0; cc < SW; cc++) x[cc] -= lj[k][cc] * xs[kh + k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < SW; k++) {
+        const int gc = cn + k;
+        const double xkk = sdm_bcast_lane(x[k], gc);
+        const bool accept = sdm_lane_pred(x[k] > mylb, gc);           // uniform: the pivot's own lane decides (x_kk > lb_k)
+        const double l = accept ? x[k] / xkk : 0.0;                    // skipped pivot: unit column
+#pragma unroll
+        for (int j = k + 1; j < SW; j++) x[j] -= sdm_bcast_lane(l, cn + j) * x[k];
+        lsc[k] = l;
+      }
+      // rows above the diagonal carry don't-care values from here on (nobody reads them: every consumer of S and Lc
+      // is restricted to the lower triangle), which saves the masks
+#pragma unroll
+      for (int k = 0; k < SW; k++) {
+        Lc[(cn + k) * NB + tx] = lsc[k];
+        S[tx][cn + k] = x[k];
+        xs[k] = x[k];
+      }
+      SDM_WAVE_SYNC();
+      if (tx >= cn && tx < cn + SW && tx < kb) {                       // bookkeeping of pivot tx in lane tx
+        const double pval = S[tx][tx];
+        const bool acc = pval > mylb;
+        ds[tx] = acc ? pval : 0.0;
+        if (!acc) { stt[tx] = 1; pv[tx] = pval; }
+        if (acc && ms - (k0 + tx) > 1 && pval < ub) badflag = 1;       // needs the column probe: general path below
+      }
+      SDM_PHASE(17);
+      __syncthreads();
+      SDM_PHASE(19);
+    }
+    SDM_SETPRIO(0);
+  } else if (ty < ny - 1) {
+    __syncthreads();                                                   // sweep 0
+    for (int s = 0; s < nsw - 1; s++) {
+      const int c0 = s * SW;
+      double xk[SW];
+#pragma unroll
+      for (int k = 0; k < SW; k++) xk[k] = S[tx][c0 + k];
+      for (int j0 = c0 + 2 * SW + 4 * (ty - 1); j0 < kb; j0 += 4 * (ny - 2)) {   // 4 columns per wavefront at a time
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = S[tx][min(j0 + u, NB - 1)];
+#pragma unroll
+        for (int k = 0; k < SW; k++) {
+          double lj[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) lj[u] = Lc[(c0 + k) * NB + min(j0 + u, NB - 1)];
+#pragma unroll
+          for (int u = 0; u < 4; u++) v[u] -= lj[u] * xk[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (j0 + u < kb && tx >= j0 + u) S[tx][j0 + u] = v[u];
+      }
+      SDM_PHASE(18);
+      __syncthreads();
+    }
+  } else {
+    // ---- the last wavefront publishes the factor as it grows: after every second sweep 16 more columns of L11 (and
+    // their pivots) are final; they go to DT / d write-through and, one sweep later (the stores have been acknowledged
+    // by then), the count the row-solve workgroups of this launch poll goes up by one.  Nothing is published from a
+    // sweep on in which a pivot asked for the probe (the block is redone by the general path; what was published
+    // before is what the general path computes again).
+    double *Dsp = DT + tab.toff[s] + (int64_t)panel * NB * NB;
+    int issued = 0, signalled = 0;
+    __syncthreads();                                                   // sweep 0
+    for (int sw = 0; sw < nsw - 1; sw++) {
+      if (publish) {
+        if (issued > signalled) {                                      // columns stored during the previous sweep
+          SDM_STORES_DONE();
+          if (tx == 0) sdm_signal_add(&diag_cnt[s]);
+          signalled = issued;
+        }
+        const int g = issued;                                          // sweeps 0 .. sw are final: columns < 8 (sw+1)
+        if (SW * (sw + 1) >= 16 * (g + 1) && badflag == 0) {
+#pragma unroll
+          for (int c = 0; c < 16; c++) {
+            const int j = 16 * g + c;
+            if (tx >= j) sdm_store_wt(&Dsp[tx * NB + j], tx == j ? 1.0 : Lc[j * NB + tx]);
+          }
+          if (tx < 16 && 16 * g + tx < kb) sdm_store_wt(&d[first + k0 + 16 * g + tx], ds[16 * g + tx]);
+          issued = g + 1;
+        }
+      }
+      __syncthreads();
+    }
+    // after the last sweep: what is left of the block, right away (the epilogue below would be 2-3 us later)
+    if (publish && badflag == 0) {
+      for (int g = issued; 16 * g < kb; g++) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+          const int j = 16 * g + c;
+          if (tx >= j) sdm_store_wt(&Dsp[tx * NB + j], tx == j ? 1.0 : Lc[j * NB + tx]);
+        }
+        if (tx < 16 && 16 * g + tx < kb) sdm_store_wt(&d[first + k0 + 16 * g + tx], ds[16 * g + tx]);
+        issued = g + 1;
+      }
+    }
+    if (issued > signalled) { SDM_STORES_DONE(); if (tx == 0) sdm_signal_add(&diag_cnt[s], issued - signalled); }
+    if (tx == 0) *npub = issued;
+  }
+  const bool bad = badflag != 0;
+  const bool ok = !bad;
+  if (!ok) {
+    // ---- general path: one column per step by all work-items, pivot_probe available
+    if (panel > 0) {                                                 // the probe reads the rows below the block
+      if (PERSIST) front_wait_updates(upd_cnt, panel, (ms + TILE - 1) / TILE, tmo);
+      else wait_prev_update(upd_cnt + s, ns, ms, panel, q0, tmo);
+    }
+    for (int j = ty; j < NB; j += ny) { S[tx][j] = (tx < kb && j <= tx) ? Fs[(int64_t)(k0 + j) * ld + k0 + tx] : 0.0; Lc[j * NB + tx] = 0.0; }
+    if (tid < NB) { ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
+    __syncthreads();
+    for (int k = 0; k < kb; k++) {
+      double xkk = S[k][k];
+      if (xkk > lbs[k]) {
+        if (ms - (k0 + k) > 1 && xkk < ub) {                         // rare: stability probe of the never-fail rule
+          double nraw = 0.0;
+          if (k0 + k + 1 >= ns && first + ns < mtot) { int sidx = asm_src[Ljc[first + ns]]; nraw = sidx < 0 ? 0.0 : ada[sidx]; }
+          const double ubk = pivot_probe(S, Lc, k, kb, k0, ns, ms, ld, Fs, ds, cb, nraw, red_v, red_i) / maxu;
+          if (xkk < ubk) {
+            if (tid == 0) { stt[k] = 2; pv[k] = ubk - xkk; lbs[k] = ubk - xkk; }
+            xkk = ubk;
+          }
+        }
+        // every work-item forms the multipliers it needs itself (same division, same rounding): one barrier per column
+        const double sik = S[tx][k];
+        if (tid > k && tid < kb) Lc[k * NB + tid] = sik / xkk;
+        if (tid == 0) ds[k] = xkk;
+        for (int i = k + 1 + ty; i < kb; i += ny)
+          if (tx >= i) S[tx][i] -= (S[i][k] / xkk) * sik;
+      } else {
+        // skipped pivot: d = 0, the column becomes the unit vector (blkchol2.c:157-161, blkchol.c:409-414)
+        if (tid == 0) { stt[k] = 1; pv[k] = xkk; ds[k] = 0.0; }
+      }
+      __syncthreads();
+    }
+  }
+  SDM_PHASE(20);
+  for (int j = ty; j < NB; j += ny) if (tx > j) S[tx][j] = Lc[j * NB + tx];     // scaled columns for the row solve
+  __syncthreads();
+  SDM_PHASE(21);
+  {
+    double *Ds = DT + tab.toff[s] + (int64_t)panel * NB * NB;
+    // the factored block goes in place from THIS workgroup in every case: it also stored the raw updated block (tile
+    // (0,0) of the previous update), and two workgroups writing the same lines in one launch may sit behind different
+    // L2s whose write-back order is not defined
+    const bool inplace = true;
+    for (int j = ty; j < kb; j += ny)
+      if (tx < kb && tx >= j) {
+        const double v = (tx == j) ? 1.0 : S[tx][j];                // unit diagonal stored explicitly (blkchol2.c:136)
+        if (inplace) Fs[(int64_t)(k0 + j) * ld + k0 + tx] = v;
+        sdm_store_wt(&Ds[tx * NB + j], v);                          // transposed copy of the block (backward solve, row solve)
+      }
+    if (tid < kb) {
+      const int gk = first + k0 + tid;
+      sdm_store_wt(&d[gk], ds[tid]);
+      if (stt[tid]) { pivstat[gk] = stt[tid]; pivval[gk] = pv[tid]; }   // pivval = amount added (what blkchol2.c:127 keeps in lb[k])
+    }
+  }
+  return ok;
+}
+
 __global__ void __launch_bounds__(LDL_THREADS)
 k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, double *d, double *lb, const double *ubp,
             int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src,
@@ -747,229 +994,17 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
                                           (double (*)[NB + 1])smem, (double *)smem + NB * (NB + 1), kbc);
   }
   double (*S)[NB + 1] = (double (*)[NB + 1])smem;                 // diagonal block, S[row][col]
-  double *RB = (double *)smem + NB * (NB + 1);                    // Lc during the LDL', then Xs / the wave tiles of the row solve
-  double *Lc = RB;                                                // Lc[k*NB+i] = l_ik
-  __shared__ double ds[NB], lbs[NB], pv[NB];
-  __shared__ int stt[NB];
-  __shared__ int badflag, npub;
-  __shared__ double red_v[LDL_THREADS];
-  __shared__ int red_i[LDL_THREADS];
+  double *RB = (double *)smem + NB * (NB + 1);                    // Xs / the wave tiles of the row solve
+  __shared__ double ds[NB];
+  __shared__ int npub;
   const int s = list[blockIdx.y];
-  const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
+  const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s];
   const int k0 = panel * NB, kb = min(NB, ns - k0);
   const int r0 = k0 + kb, nrows = ms - r0;
   double *Fs = F + tab.foff[s];
-  double *cb = colbuf + tab.woff[s] + s;                          // probe scratch: ms + 1 doubles per front
-  const int tid = threadIdx.x, bs = blockDim.x;
-  const int tx = tid & 63, ty = tid >> 6, ny = bs >> 6;
-  const double maxu = ubp[1], ub = ubp[2] / (maxu * maxu);      // ubp[2] = max diagonal (k_prep_pivots)
-  if (panel == 0) {
-    double sv[NB / (LDL_THREADS / 64)];
-    const double *pc = Fs + (int64_t)k0 * ld + k0 + min(tx, kb - 1);
-#pragma unroll
-    for (int q = 0; q < NB / (LDL_THREADS / 64); q++) sv[q] = pc[(int64_t)min(ty + ny * q, kb - 1) * ld];     // all loads in flight
-#pragma unroll
-    for (int q = 0; q < NB / (LDL_THREADS / 64); q++) {
-      const int j = ty + ny * q;
-      // (columns beyond a partial block: unit diagonal, so that the straight-line sweep stays finite there)
-      if (j < NB) { S[tx][j] = (tx < kb && j <= tx) ? sv[q] : ((tx == j && tx >= kb) ? 1.0 : 0.0); Lc[j * NB + tx] = 0.0; }
-    }
-  }
-  if (tid < NB) { lbs[tid] = tid < kb ? lb[first + k0 + tid] : 0.0; ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
-  if (tid == 0) { badflag = 0; npub = 0; }
-  SDM_PHASE_BEGIN();
-  __syncthreads();
-  SDM_PHASE(16);
-  // ---- LDL' of the block (see the header): wavefront 0 sweeps SW columns in registers while the other wavefronts
-  // apply the previous sweep to the trailing columns.  The sweep is straight-line code: a skipped pivot gives the
-  // multiplier 0, a pivot that needs the probe only raises `bad` (everything computed after it is discarded: the
-  // block is redone by the general path), the bookkeeping of pivot gc lives in lane gc.
-  const int nsw = (kb + SW - 1) / SW;
-  if (ty == 0) {
-    SDM_SETPRIO(3);
-    const double mylb = lbs[tx];
-    double xs[SW];                                                     // columns of the sweep just finished (unscaled)
-    for (int s = -1; s < nsw - 1; s++) {
-      const int c0 = s * SW, cn = c0 + SW;                             // sweep s is final; sweep columns cn .. cn+SW-1 now
-      double x[SW], lsc[SW];
-#pragma unroll
-      for (int cc = 0; cc < SW; cc++) x[cc] = S[tx][cn + cc];
-      if (s >= 0) {
-        // look-ahead: the columns of the next sweep receive sweep s here (x_rj -= l_jk * x_rk, k ascending)
-        // (multipliers fetched in two batches of SW/2 columns, all loads of a batch in flight before the first use)
-#pragma unroll
-        for (int kh = 0; kh < SW; kh += SW / 2) {
-          double lj[SW / 2][SW];
-#pragma unroll
-          for (int k = 0; k < SW / 2; k++)
-#pragma unroll
-            for (int cc = 0; cc < SW; cc++) lj[k][cc] = Lc[(c0 + kh + k) * NB + cn + cc];
-#pragma unroll
-          for (int k = 0; k < SW / 2; k++)
-#pragma unroll
-            for (int cc = 0; cc < SW; cc++) SDM_PIN(lj[k][cc]);
-#pragma unroll
-          for (int k = 0; k < SW / 2; k++)
-#pragma unroll
-            for (int cc = 0; cc < SW; cc++) x[cc] -= lj[k][cc] * xs[kh + k];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < SW; k++) {
-        const int gc = cn + k;
-        const double xkk = sdm_bcast_lane(x[k], gc);
-        const bool accept = sdm_lane_pred(x[k] > mylb, gc);           // uniform: the pivot's own lane decides (x_kk > lb_k)
-        const double l = accept ? x[k] / xkk : 0.0;                    // skipped pivot: unit column
-#pragma unroll
-        for (int j = k + 1; j < SW; j++) x[j] -= sdm_bcast_lane(l, cn + j) * x[k];
-        lsc[k] = l;
-      }
-      // rows above the diagonal carry don't-care values from here on (nobody reads them: every consumer of S and Lc
-      // is restricted to the lower triangle), which saves the masks
-#pragma unroll
-      for (int k = 0; k < SW; k++) {
-        Lc[(cn + k) * NB + tx] = lsc[k];
-        S[tx][cn + k] = x[k];
-        xs[k] = x[k];
-      }
-      SDM_WAVE_SYNC();
-      if (tx >= cn && tx < cn + SW && tx < kb) {                       // bookkeeping of pivot tx in lane tx
-        const double pval = S[tx][tx];
-        const bool acc = pval > mylb;
-        ds[tx] = acc ? pval : 0.0;
-        if (!acc) { stt[tx] = 1; pv[tx] = pval; }
-        if (acc && ms - (k0 + tx) > 1 && pval < ub) badflag = 1;       // needs the column probe: general path below
-      }
-      SDM_PHASE(17);
-      __syncthreads();
-      SDM_PHASE(19);
-    }
-    SDM_SETPRIO(0);
-  } else if (ty < ny - 1) {
-    __syncthreads();                                                   // sweep 0
-    for (int s = 0; s < nsw - 1; s++) {
-      const int c0 = s * SW;
-      double xk[SW];
-#pragma unroll
-      for (int k = 0; k < SW; k++) xk[k] = S[tx][c0 + k];
-      for (int j0 = c0 + 2 * SW + 4 * (ty - 1); j0 < kb; j0 += 4 * (ny - 2)) {   // 4 columns per wavefront at a time
-        double v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = S[tx][min(j0 + u, NB - 1)];
-#pragma unroll
-        for (int k = 0; k < SW; k++) {
-          double lj[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) lj[u] = Lc[(c0 + k) * NB + min(j0 + u, NB - 1)];
-#pragma unroll
-          for (int u = 0; u < 4; u++) v[u] -= lj[u] * xk[k];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (j0 + u < kb && tx >= j0 + u) S[tx][j0 + u] = v[u];
-      }
-      SDM_PHASE(18);
-      __syncthreads();
-    }
-  } else {
-    // ---- the last wavefront publishes the factor as it grows: after every second sweep 16 more columns of L11 (and
-    // their pivots) are final; they go to DT / d write-through and, one sweep later (the stores have been acknowledged
-    // by then), the count the row-solve workgroups of this launch poll goes up by one.  Nothing is published from a
-    // sweep on in which a pivot asked for the probe (the block is redone by the general path; what was published
-    // before is what the general path computes again).
-    double *Dsp = DT + tab.toff[s] + (int64_t)panel * NB * NB;
-    int issued = 0, signalled = 0;
-    __syncthreads();                                                   // sweep 0
-    for (int sw = 0; sw < nsw - 1; sw++) {
-      if (nrows > TRSM_ROWS) {
-        if (issued > signalled) {                                      // columns stored during the previous sweep
-          SDM_STORES_DONE();
-          if (tx == 0) sdm_signal_add(&diag_cnt[s]);
-          signalled = issued;
-        }
-        const int g = issued;                                          // sweeps 0 .. sw are final: columns < 8 (sw+1)
-        if (SW * (sw + 1) >= 16 * (g + 1) && badflag == 0) {
-#pragma unroll
-          for (int c = 0; c < 16; c++) {
-            const int j = 16 * g + c;
-            if (tx >= j) sdm_store_wt(&Dsp[tx * NB + j], tx == j ? 1.0 : Lc[j * NB + tx]);
-          }
-          if (tx < 16 && 16 * g + tx < kb) sdm_store_wt(&d[first + k0 + 16 * g + tx], ds[16 * g + tx]);
-          issued = g + 1;
-        }
-      }
-      __syncthreads();
-    }
-    // after the last sweep: what is left of the block, right away (the epilogue below would be 2-3 us later)
-    if (nrows > TRSM_ROWS && badflag == 0) {
-      for (int g = issued; 16 * g < kb; g++) {
-#pragma unroll
-        for (int c = 0; c < 16; c++) {
-          const int j = 16 * g + c;
-          if (tx >= j) sdm_store_wt(&Dsp[tx * NB + j], tx == j ? 1.0 : Lc[j * NB + tx]);
-        }
-        if (tx < 16 && 16 * g + tx < kb) sdm_store_wt(&d[first + k0 + 16 * g + tx], ds[16 * g + tx]);
-        issued = g + 1;
-      }
-    }
-    if (issued > signalled) { SDM_STORES_DONE(); if (tx == 0) sdm_signal_add(&diag_cnt[s], issued - signalled); }
-    if (tx == 0) npub = issued;
-  }
-  const bool bad = badflag != 0;
-  const bool ok = !bad;
-  if (!ok) {
-    // ---- general path: one column per step by all work-items, pivot_probe available
-    if (panel > 0) wait_prev_update(upd_cnt + s, ns, ms, panel, q0, tmo);  // the probe reads the rows below the block
-    for (int j = ty; j < NB; j += ny) { S[tx][j] = (tx < kb && j <= tx) ? Fs[(int64_t)(k0 + j) * ld + k0 + tx] : 0.0; Lc[j * NB + tx] = 0.0; }
-    if (tid < NB) { ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
-    __syncthreads();
-    for (int k = 0; k < kb; k++) {
-      double xkk = S[k][k];
-      if (xkk > lbs[k]) {
-        if (ms - (k0 + k) > 1 && xkk < ub) {                         // rare: stability probe of the never-fail rule
-          double nraw = 0.0;
-          if (k0 + k + 1 >= ns && first + ns < mtot) { int sidx = asm_src[Ljc[first + ns]]; nraw = sidx < 0 ? 0.0 : ada[sidx]; }
-          const double ubk = pivot_probe(S, Lc, k, kb, k0, ns, ms, ld, Fs, ds, cb, nraw, red_v, red_i) / maxu;
-          if (xkk < ubk) {
-            if (tid == 0) { stt[k] = 2; pv[k] = ubk - xkk; lbs[k] = ubk - xkk; }
-            xkk = ubk;
-          }
-        }
-        // every work-item forms the multipliers it needs itself (same division, same rounding): one barrier per column
-        const double sik = S[tx][k];
-        if (tid > k && tid < kb) Lc[k * NB + tid] = sik / xkk;
-        if (tid == 0) ds[k] = xkk;
-        for (int i = k + 1 + ty; i < kb; i += ny)
-          if (tx >= i) S[tx][i] -= (S[i][k] / xkk) * sik;
-      } else {
-        // skipped pivot: d = 0, the column becomes the unit vector (blkchol2.c:157-161, blkchol.c:409-414)
-        if (tid == 0) { stt[k] = 1; pv[k] = xkk; ds[k] = 0.0; }
-      }
-      __syncthreads();
-    }
-  }
-  SDM_PHASE(20);
-  for (int j = ty; j < NB; j += ny) if (tx > j) S[tx][j] = Lc[j * NB + tx];     // scaled columns for the row solve
-  __syncthreads();
-  SDM_PHASE(21);
-  {
-    double *Ds = DT + tab.toff[s] + (int64_t)panel * NB * NB;
-    // the factored block goes in place from THIS workgroup in every case: it also stored the raw updated block (tile
-    // (0,0) of the previous update), and two workgroups writing the same lines in one launch may sit behind different
-    // L2s whose write-back order is not defined
-    const bool inplace = true;
-    for (int j = ty; j < kb; j += ny)
-      if (tx < kb && tx >= j) {
-        const double v = (tx == j) ? 1.0 : S[tx][j];                // unit diagonal stored explicitly (blkchol2.c:136)
-        if (inplace) Fs[(int64_t)(k0 + j) * ld + k0 + tx] = v;
-        sdm_store_wt(&Ds[tx * NB + j], v);                          // transposed copy of the block (backward solve, row solve)
-      }
-    if (tid < kb) {
-      const int gk = first + k0 + tid;
-      sdm_store_wt(&d[gk], ds[tid]);
-      if (stt[tid]) { pivstat[gk] = stt[tid]; pivval[gk] = pv[tid]; }   // pivval = amount added (what blkchol2.c:127 keeps in lb[k])
-    }
-  }
+  const int tid = threadIdx.x;
+  const bool ok = ldl_diag_block<false>(smem, F, DT, tab, s, panel, d, lb, ubp, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_cnt, diag_cnt,
+                                        q0, tmo, panel == 0, nrows > TRSM_ROWS, ds, &npub);
   if (nrows > TRSM_ROWS) {                                         // the row-solve workgroups of this launch are waiting
     if (16 * npub < kb) SDM_STORES_DONE();                         // (uniform) something of the block is still unpublished
     __syncthreads();

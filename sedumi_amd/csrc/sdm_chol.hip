@@ -163,6 +163,23 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
     for (int li = C.lev_first_launch[l]; li < (int)C.launches.size(); li++) C.launches[li].q0 = q0;
   }
   C.lev_first_launch[nlev] = (int)C.launches.size();
+  // levels whose fronts are all of the k_ldl_front kind: blocked row solves (MFMA_MIN_ROWS rule of panel_rows), at most
+  // FRONT_MAXT tile rows, no partial last panel with rows below it, and few enough workgroups to be resident together
+  C.lev_persist.assign(nlev, 0); C.lev_maxT.assign(nlev, 0);
+  {
+    const bool off = getenv("SDM_FRONT_OFF") != nullptr;              // comparison override (tools, tests): read at every set_chol
+    for (int l = 0; l < nlev; l++) {
+      bool ok = !off;
+      int wgs = 0, maxT = 0;
+      for (int i = C.levptr[l]; i < C.levptr[l + 1] && ok; i++) {
+        const int s = C.levlist[i], ns = C.sn_ns[s], ms = C.sn_ms[s], T = (ms + TILE - 1) / TILE;
+        if (ms - std::min(NB, ns) < MFMA_MIN_ROWS || T > FRONT_MAXT || (ns % NB != 0 && ms != ns)) ok = false;
+        wgs += T; maxT = std::max(maxT, T);
+      }
+      if (ok && maxT * (C.levptr[l + 1] - C.levptr[l]) <= 192) { C.lev_persist[l] = 1; C.lev_maxT[l] = maxT; }
+    }
+  }
+  C.front_cnt.alloc((size_t)std::max<sdm_int>(1, C.nsuper) * 2 * FRONT_MAXT);
   // upload
   C.d_first.upload(C.sn_first); C.d_ns.upload(C.sn_ns); C.d_ms.upload(C.sn_ms); C.d_ld.upload(C.sn_ld); C.d_parent.upload(C.sn_parent);
   C.d_childptr.upload(C.childptr); C.d_childlist.upload(C.childlist); C.d_levlist.upload(C.levlist);
@@ -209,10 +226,11 @@ __global__ void k_load_factor(double *F, double *FT, const double *Lpr, const in
 __global__ void k_prep_pivots(int m, const double *ada, const int *asm_src, const int64_t *Ljc, const int *perm,
                               const double *absd, int use_absd, double canceltol, double maxu, double abstol,
                               double *lb, double *ub, int *pivstat, double *pivval, int nsuper, int *upd_cnt, int *diag_cnt,
-                              unsigned long long *sb_g, int nsbg) {
+                              unsigned long long *sb_g, int nsbg, int *front_cnt, int nfc) {
   __shared__ double red[256];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
   for (int i = gid; i < nsuper; i += gstride) { upd_cnt[i] = 0; diag_cnt[i] = 0; }     // counters of k_ldl_panel
+  for (int i = gid; i < nfc; i += gstride) front_cnt[i] = 0;                            // counters of k_ldl_front
   for (int i = gid; i < nsbg; i += gstride) sb_g[i] = 0ull;                             // growth records of the solve inverses (sdm_solve.hip)
   double mx = 0.0;
   for (int j = gid; j < m; j += gstride) {
@@ -523,13 +541,15 @@ __device__ __forceinline__ void rows_block(int b, const double (*S)[NB + 1], con
   rows_block_tri(b, S, ds, Tw, lane);
 }
 // l = x / d out of the wave tile into the front
+template <bool WT = false>
 __device__ __forceinline__ void rows_store(double *Fs, int ld, int ms, int k0, int kb, int R0, const double *ds, const double *Tw, int lane) {
   const int li = lane & 15, lk = lane >> 4;
   for (int c4 = 0; c4 < NB / 4; c4++) {
     const int c = 4 * c4 + lk, row = R0 + li;
     if (c < kb && row < ms) {
       const double dc = ds[c], xv = Tw[c * 17 + li];
-      Fs[(int64_t)(k0 + c) * ld + row] = dc > 0.0 ? xv / dc : 0.0;
+      const double v = dc > 0.0 ? xv / dc : 0.0;
+      if (WT) sdm_store_wt(&Fs[(int64_t)(k0 + c) * ld + row], v); else Fs[(int64_t)(k0 + c) * ld + row] = v;
     }
   }
 }
@@ -1031,6 +1051,110 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   SDM_PHASE(23);
 }
 
+// ---- the whole LDL' of a front in ONE launch (fronts of FRONT_MINMS <= m_s <= 64 FRONT_MAXT rows; chol_build decides per
+// level).  One workgroup per 64-row tile row r of the front, all resident; it owns the tiles (r, c), c <= r, and for the
+// panels q = 0, 1, ... does
+//   q <  r   R: rows of tile (r, q) against the factored diagonal block of panel q (published by workgroup q, 16 columns
+//               at a time, exactly as in k_ldl_panel), result stored and counted in row_cnt[r];
+//            U: tiles (r, c) -= L(r, q) D_q L(c, q)' for c = q+1 .. r  (L(c, q) once row_cnt[c] says it is there); the tile
+//               of the NEXT panel's column comes last and stays in LDS as the next R's input, the diagonal tile of
+//               workgroup q+1 goes straight into the LDS arrays of its LDL';
+//   q == r   D: LDL' of the diagonal block (ldl_diag_block), then the workgroup is done.
+// The chain per panel is D -> (hand-over) -> last block of R in workgroup q+1 -> its diagonal tile -> D: no launch
+// boundary, no wait for the slowest row workgroup.  Arithmetic and its order per entry are those of the launch-per-panel
+// path (same device functions), so both produce the same bits.  upd_done[r] counts the U steps finished (the rare column
+// probe of a later diagonal block waits for them).  The emulator runs workgroups one after the other: there the host
+// loops over (step, phase 1 = D, 2 = R, 3 = U) and nothing is carried in LDS.
+__global__ void __launch_bounds__(LDL_THREADS)
+k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, double *lb, const double *ubp, int *pivstat,
+            double *pivval, double *colbuf, const double *ada, const int *asm_src, const int64_t *Ljc, int mtot, int *front_cnt,
+            int *diag_cnt, int phase, int step, int *tmo) {
+  SDM_FP_STRICT;
+  SDM_DYN_SMEM(smem);
+  const int s = list[blockIdx.y];
+  const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
+  const int T = (ms + TILE - 1) / TILE, NP = (ns + NB - 1) / NB;
+  const int r = blockIdx.x;
+  if (r >= T) return;
+  double *Fs = F + tab.foff[s];
+  int *row_cnt = front_cnt + (int64_t)s * 2 * FRONT_MAXT, *upd_done = row_cnt + FRONT_MAXT;
+  double (*As)[TILE] = (double (*)[TILE])smem;
+  double (*Bs)[TILE] = As + NB;
+  double (*S)[NB + 1] = (double (*)[NB + 1])smem;
+  double *RB = (double *)smem + NB * (NB + 1);
+  __shared__ double dsh[NB], ds[NB], dsr[NB];
+  __shared__ int npub;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const bool carry = phase == 0;
+  bool have_S = false, have_tw = false;
+  for (int q = carry ? 0 : step; q < (carry ? NP : step + 1) && q <= r; q++) {
+    const int k0 = q * NB, kb = min(NB, ns - k0);
+    if (q == r) {
+      if (phase == 0 || phase == 1) {
+        const int nrows = ms - (k0 + kb);
+        ldl_diag_block<true>(smem, F, DT, tab, s, q, d, lb, ubp, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, 0, tmo,
+                             !have_S, nrows > 0, ds, &npub);
+        if (nrows > 0) {
+          if (16 * npub < kb) SDM_STORES_DONE();
+          __syncthreads();
+          if (tid == 0) sdm_signal_add(&diag_cnt[s], 4 - npub);
+        }
+      }
+      break;
+    }
+    const int rbeg = r * TILE, rend = min(ms, rbeg + TILE);
+    if (phase == 0 || phase == 2) {
+      // ---- R: 16 rows per wavefront (4 of the 8 busy), following the diagonal block as workgroup q publishes it
+      const double *Ds = DT + tab.toff[s] + (int64_t)q * NB * NB;
+      const int R0 = rbeg + 16 * ty;
+      const bool busy = R0 < rend;
+      double *Tw = RB + ty * (NB * 17);
+      if (!have_tw && busy) rows_stage(Fs, ld, rend, k0, kb, R0, Tw, tx);
+      for (int blk = 0; blk < NB / 16 && 16 * blk < kb; blk++) {
+        if (busy) rows_block_gemm(blk, S, Tw, tx);
+        spin_until(diag_cnt + s, 4 * q + blk + 1, tmo);
+        for (int e = tid; e < NB * 16; e += LDL_THREADS) {
+          const int i = e >> 4, j = 16 * blk + (e & 15);
+          S[i][j] = (i < kb && j < i) ? Ds[i * NB + j] : 0.0;
+        }
+        if (tid < 16) dsr[16 * blk + tid] = 16 * blk + tid < kb ? d[first + k0 + 16 * blk + tid] : 0.0;
+        __syncthreads();
+        if (busy) rows_block_tri(blk, S, dsr, Tw, tx);
+      }
+      if (busy) rows_store<true>(Fs, ld, rend, k0, kb, R0, dsr, Tw, tx);
+      SDM_STORES_DONE();
+      __syncthreads();
+      if (tid == 0) sdm_signal_add(&row_cnt[r]);
+      have_tw = false;
+    }
+    if (phase == 0 || phase == 3) {
+      // ---- U: the tiles of this row.  Order: the far ones, the diagonal one, last the tile of the next panel's column
+      SDM_ACQUIRE_FENCE();                                            // this workgroup's own L(r, q), not a cached copy from before
+      const int c1 = q + 1;
+      for (int cc = c1 + 1; cc <= r + 1; cc++) {
+        const int c = cc <= r ? cc : c1;                              // c1 last
+        if (c == c1 && cc <= r) continue;                             // (r == c1: the only tile, handled as cc = r + 1)
+        if (c < r) spin_until(row_cnt + c, q + 1, tmo);
+        const int I = r - c1, J = c - c1;
+        const int kbn = min(NB, ns - c1 * NB);                        // columns of the next panel (<= 0: none)
+        if (c == r && r == c1 && carry && c1 < NP) {
+          update_tile<LDL_THREADS / 64, true, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh, S, RB, kbn);
+          have_S = true;
+        } else if (c == c1 && c < r && carry && c1 < NP) {
+          update_tile<LDL_THREADS / 64, false, true, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh, nullptr, nullptr, kbn, tid, true, RB);
+          have_tw = true;
+        } else {
+          update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh);
+        }
+        __syncthreads();                                              // As / Bs are reused by the next tile
+      }
+      SDM_STORES_DONE();
+      __syncthreads();
+      if (tid == 0) sdm_signal_add(&upd_done[r]);
+    }
+  }
+}
+
 // stand-alone update.  Supernodes that END with this panel: all tiles (the update of the rows beyond, passed up to the
 // parent).  Supernodes with a next panel: nothing when `riding` (their tiles ride along with the diagonal-block launch
 // of the next panel, k_ldl_panel), else every tile but tile 0 (which k_ldl_panel's workgroup 0 always applies itself).
@@ -1088,17 +1212,32 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
   
 #ifndef SDM_EMU
   SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_RIDE));
+  SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_RIDE));
 #endif
   SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), st));
   SDM_KLAUNCH(P, k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
              C.d_asm_dst.p, (int64_t)C.nnzL, C.ub.p);
   SDM_KLAUNCH(P, k_prep_pivots, dim3(grid1d(m, 256, 64)), dim3(256), 0, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
              P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, (int)C.nsuper, C.upd_cnt.p, C.diag_cnt.p,
-             C.sb_g.p, 4 * C.nsbtot);
+             C.sb_g.p, 4 * C.nsbtot, C.front_cnt.p, (int)C.front_cnt.n);
   for (int l = 0; l < C.nlevels; l++) {
     const int *list = C.d_levlist.p + C.levptr[l];
     const int nfr = C.levptr[l + 1] - C.levptr[l];
     if (l > 0) SDM_KLAUNCH(P, k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, C.fronts.p, tab, list);
+    if (C.lev_persist[l]) {                                          // the whole level in one launch (k_ldl_front)
+#ifdef SDM_EMU
+      int maxnp = 0;
+      for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) maxnp = std::max(maxnp, (C.sn_ns[C.levlist[i]] + NB - 1) / NB);
+      for (int step = 0; step < maxnp; step++)
+        for (int phase = 1; phase <= 3; phase++)
+#else
+      const int phase = 0, step = 0;
+#endif
+          SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l], nfr), dim3(LDL_THREADS), PANEL_LDS_RIDE, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
+                      C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p,
+                      C.diag_cnt.p, phase, step, C.tmo.dev());
+      continue;
+    }
     for (int li = C.lev_first_launch[l]; li < C.lev_first_launch[l + 1]; li++) {
       const LevelLaunch &L = C.launches[li];
       // ONE launch per panel: diagonal block (+ tile 0 of the previous panel's update), the row solves and the rest of

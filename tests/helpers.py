@@ -176,3 +176,104 @@ def check_golden(name, tag):
     y = mex.bwblkslv(Ls, yfw / Ld)
     errs["y"] = relerr(y.ravel(), z[f"{tag}_y"])
     return errs
+
+
+# ------------------------------------------------------------------ k_ldl_front against the launch-per-panel path
+def bordered_blocks(n1, n2, nc, rng):
+    """Two dense diagonal blocks, each coupled to a dense trailing block: the leaf fronts have many rows below
+    their own columns (ms > ns)."""
+    m = n1 + n2 + nc
+    X = np.zeros((m, m))
+    X[:n1, :n1] = rng.standard_normal((n1, n1)); X[n1:n1 + n2, n1:n1 + n2] = rng.standard_normal((n2, n2))
+    X[n1 + n2:, :] = rng.standard_normal((nc, m))
+    X = 0.1 * (X + X.T) / np.sqrt(m)
+    X = X + np.diag(np.abs(X).sum(axis=1) + 1.0)
+    X = sp.csc_matrix(X); X.sort_indices()
+    return X
+
+
+def _factor_both_ways(X, L, pars=None, rhs=None):
+    """(lpr, d, pivots, y, kernels) of the resident plan with the one-launch front kernel and with the launch-per-panel path."""
+    import os
+    from sedumi_amd.plan import Plan
+    out = []
+    for off in (False, True):
+        if off:
+            os.environ["SDM_FRONT_OFF"] = "1"
+        try:
+            plan = Plan(0)
+            plan.set_chol(L, X)
+        finally:
+            os.environ.pop("SDM_FRONT_OFF", None)
+        plan.upload("ada", sp.csc_matrix(X).data)
+        plan.upload("rhs", rhs if rhs is not None else np.ones(X.shape[0]))
+        plan.kprof(True)
+        plan.blkchol(pars, False)
+        plan.ldlsolve()
+        names = set(plan.kprof_summary().keys())
+        plan.kprof(False)
+        out.append((plan.download("lpr"), plan.download("d"), plan.pivots(), plan.download("y"), names))
+    return out
+
+
+def check_one_launch_front(refmex, m):
+    """k_ldl_front (one workgroup per tile row, the whole front in one launch) against the launch-per-panel path on single
+    dense fronts: same device functions in the same order per entry, so the same bits -- and both within tolerance of
+    the reference.  m = 666 is control07's shape (partial last panel), m = 1000 the largest number of tile rows (16)."""
+    from oracle import glue as gl
+    from sedumi_amd import problem
+    rng = np.random.default_rng(m)
+    B = rng.standard_normal((m, m))
+    X = sp.csc_matrix(B @ B.T + m * np.eye(m)); X.sort_indices()
+    L = problem.dense_symbolic(m)
+    (l1, d1, p1, y1, k1), (l2, d2, p2, y2, k2) = _factor_both_ways(X, L, rhs=rng.standard_normal(m))
+    assert "k_ldl_front" in k1 and "k_ldl_panel" not in k1 and "k_ldl_front" not in k2 and "k_ldl_panel" in k2
+    assert np.array_equal(l1, l2) and np.array_equal(d1, d2) and np.array_equal(y1, y2)
+    r = refmex.call("blkchol", 4, L, X, gl.default_pars_chol())
+    assert relerr(d1, r[1].ravel()) < TOL and relerr(l1, sp.csc_matrix(r[0]).data) < TOL
+
+
+def check_one_launch_levels(refmex, glue):
+    """A leaf front of 64 columns with 800 rows below them (the update matrix for the parent) and the dense root of 928
+    columns: both levels take k_ldl_front, extend-add in between."""
+    from oracle import glue as gl
+    rng = np.random.default_rng(5)
+    X = bordered_blocks(64, 128, 800, rng)
+    L = glue.symbchol(X)
+    xs = L["xsuper"].ravel().astype(int)
+    assert xs.size - 1 == 2 and xs[1] - xs[0] == 64
+    (l1, d1, p1, y1, k1), (l2, d2, p2, y2, k2) = _factor_both_ways(X, L, rhs=rng.standard_normal(X.shape[0]))
+    assert "k_ldl_front" in k1 and "k_ldl_panel" not in k1 and "k_ldl_front" not in k2
+    assert np.array_equal(l1, l2) and np.array_equal(d1, d2) and np.array_equal(y1, y2)
+    r = refmex.call("blkchol", 4, L, X, gl.default_pars_chol())
+    assert relerr(d1, r[1].ravel()) < TOL and relerr(l1, sp.csc_matrix(r[0]).data) < TOL
+
+
+def check_one_launch_pivot_rule(refmex, m, maxu):
+    """Rank-deficient dense front of k_ldl_front's size: skipped pivots, the never-fail rule's column probe (the rare path
+    of the diagonal-block code: it waits for the update steps of the rows below) and added diagonals -- same decisions
+    as the reference, same bits as the launch-per-panel path."""
+    from oracle import glue as gl
+    from sedumi_amd import problem
+    rng = np.random.default_rng(m + int(maxu))
+    h = m // 2
+    B = rng.standard_normal((h, h))
+    A = B @ B.T + h * np.eye(h)
+    # second half: the Schur complement is E = diag(s) (C C' / h + I) diag(s), s_j^2 between 1e-10 h and 1e-5 h -- pivots and
+    # off-diagonals far above the rounding noise of the elimination (1e-13 h), so that every decision is a clean one
+    C = rng.standard_normal((m - h, m - h))
+    sj = np.sqrt(10.0 ** rng.uniform(-10, -5, m - h) * h)
+    E = (C @ C.T / (m - h) + np.eye(m - h)) * np.outer(sj, sj)
+    X = np.block([[A, A], [A, A + E]])
+    X = np.pad(X, ((0, m - 2 * h), (0, m - 2 * h))); X[2 * h:, 2 * h:] = np.eye(m - 2 * h)
+    X = sp.csc_matrix(X + 0.0); X = sp.csc_matrix((X.toarray().ravel(order="F"), np.tile(np.arange(m), m), np.arange(0, m * m + 1, m)), shape=(m, m))
+    L = problem.dense_symbolic(m)
+    pars = dict(gl.default_pars_chol()); pars["maxu"] = maxu; pars["canceltol"] = 1e-8          # about half of those pivots are skipped
+    (l1, d1, p1, y1, k1), (l2, d2, p2, y2, k2) = _factor_both_ways(X, L, pars, rng.standard_normal(m))
+    assert "k_ldl_front" in k1 and "k_ldl_front" not in k2
+    r = refmex.call("blkchol", 4, L, X, pars)
+    (si, sv), (ai, av) = p1
+    assert np.array_equal(si, sp.csc_matrix(r[2]).indices) and np.array_equal(ai, sp.csc_matrix(r[3]).indices)
+    assert si.size + ai.size > 0
+    assert np.array_equal(l1, l2) and np.array_equal(d1, d2) and np.array_equal(p1[0][0], p2[0][0]) and np.array_equal(p1[1][1], p2[1][1])
+    assert relerr(d1, r[1].ravel()) < 1e-8

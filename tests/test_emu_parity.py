@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from helpers import TOL, check_golden, check_iteration, load_golden, ref_scaling, relerr, spd_pattern, use_emu
+import helpers
+from helpers import TOL, bordered_blocks, check_golden, check_iteration, load_golden, ref_scaling, relerr, spd_pattern, use_emu
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -194,19 +195,6 @@ def test_big_single_front_solves(refmex):
     assert relerr(mex.bwblkslv(L, rhs), refmex.call("bwblkslv", 1, L, rhs)) < TOL
 
 
-def _bordered_blocks(n1, n2, nc, rng):
-    """Two dense diagonal blocks, each coupled to a dense trailing block: the leaf fronts have many rows below
-    their own columns (ms > ns)."""
-    m = n1 + n2 + nc
-    X = np.zeros((m, m))
-    X[:n1, :n1] = rng.standard_normal((n1, n1)); X[n1:n1 + n2, n1:n1 + n2] = rng.standard_normal((n2, n2))
-    X[n1 + n2:, :] = rng.standard_normal((nc, m))
-    X = 0.1 * (X + X.T) / np.sqrt(m)
-    X = X + np.diag(np.abs(X).sum(axis=1) + 1.0)
-    X = sp.csc_matrix(X); X.sort_indices()
-    return X
-
-
 @pytest.mark.parametrize("n1,n2,nc", [(100, 130, 900), (128, 65, 900), (64, 192, 900), (128, 200, 841)])
 def test_pipelined_sweeps_full_workgroup_fronts(refmex, glue, n1, n2, nc):
     """Fronts of >= 961 rows run the sweeps with 16 wavefronts and the look-ahead schedule (front_fw_pipe /
@@ -215,7 +203,7 @@ def test_pipelined_sweeps_full_workgroup_fronts(refmex, glue, n1, n2, nc):
     from oracle import glue as gl
     from sedumi_amd import mex
     rng = np.random.default_rng(n1 + nc)
-    X = _bordered_blocks(n1, n2, nc, rng)
+    X = bordered_blocks(n1, n2, nc, rng)
     L = glue.symbchol(X)
     xs = L["xsuper"].ravel().astype(int)
     assert xs.size - 1 >= 2 and np.diff(L["L"].indptr)[xs[0] - 1] >= 961 > xs[1] - xs[0]
@@ -292,7 +280,7 @@ def test_multifront_solves_with_and_without_fallback(refmex, glue, kind, m, thr)
     from oracle import glue as gl
     from sedumi_amd.plan import Plan
     rng = np.random.default_rng(17)
-    X = _bordered_blocks(300, 70, 40, rng) if kind == "bordered" else spd_pattern(kind, m, rng, 0.04)
+    X = bordered_blocks(300, 70, 40, rng) if kind == "bordered" else spd_pattern(kind, m, rng, 0.04)
     L = glue.symbchol(X)
     n = X.shape[0]
     r = refmex.call("blkchol", 4, L, X, gl.default_pars_chol())
@@ -352,3 +340,17 @@ def test_getada_gateway_on_the_nb_example():
         A = ADA.toarray()
         assert relerr(A[np.triu_indices(m)], z[f"{tag}_ADA_triu"]) < TOL and relerr(A, A.T) < 1e-14
         assert relerr(absd.ravel(), z[f"{tag}_absd"]) < TOL
+
+
+@pytest.mark.parametrize("m", [330, 512, 666, 1000])
+def test_one_launch_front_matches_the_panel_launches_bit_for_bit(refmex, m):
+    helpers.check_one_launch_front(refmex, m)
+
+
+def test_one_launch_front_levels_with_rows_below(refmex, glue):
+    helpers.check_one_launch_levels(refmex, glue)
+
+
+@pytest.mark.parametrize("m,maxu", [(400, 5e5), (400, 30.0), (400, 2.0), (666, 30.0)])
+def test_one_launch_front_pivot_rule(refmex, m, maxu):
+    helpers.check_one_launch_pivot_rule(refmex, m, maxu)

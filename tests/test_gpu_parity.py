@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
+import helpers
 from helpers import TOL, check_golden, check_iteration, ref_scaling, relerr, spd_pattern, use_hip
 
 pytestmark = pytest.mark.gpu
@@ -527,3 +528,38 @@ def test_pcg_operators_on_gpu(refmex, case):
     pivot order) on the resident plan against vecsym.c and the restated Amul.m / psdscale.m."""
     from test_pcg_ops import CASES, check_pcg_ops
     check_pcg_ops(refmex, CASES[case], seed=case)
+
+
+@pytest.mark.parametrize("m", [330, 512, 666, 1000, 1024])
+def test_one_launch_front_matches_the_panel_launches_bit_for_bit(refmex, m):
+    """k_ldl_front (workgroups of one launch hand the factor on through device-scope counters) against the launch-per-panel
+    path: same bits, and both within tolerance of the reference."""
+    helpers.check_one_launch_front(refmex, m)
+
+
+def test_one_launch_front_levels_with_rows_below(refmex, glue):
+    helpers.check_one_launch_levels(refmex, glue)
+
+
+@pytest.mark.parametrize("m,maxu", [(400, 5e5), (400, 30.0), (400, 2.0), (666, 30.0), (1000, 2.0)])
+def test_one_launch_front_pivot_rule(refmex, m, maxu):
+    helpers.check_one_launch_pivot_rule(refmex, m, maxu)
+
+
+def test_one_launch_front_is_deterministic_across_repeats(refmex):
+    """20 factorisations of control07's shape in a row: the counters are re-armed by k_prep_pivots every time and the
+    result never changes by a bit."""
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    m = 666
+    rng = np.random.default_rng(1)
+    B = rng.standard_normal((m, m))
+    X = sp.csc_matrix(B @ B.T + m * np.eye(m)); X.sort_indices()
+    plan = Plan(0)
+    plan.set_chol(problem.dense_symbolic(m), X)
+    plan.upload("ada", X.data); plan.upload("rhs", rng.standard_normal(m))
+    plan.blkchol(None, False); plan.ldlsolve()
+    l0, d0, y0 = plan.download("lpr"), plan.download("d"), plan.download("y")
+    for _ in range(20):
+        plan.blkchol(None, False); plan.ldlsolve()
+        assert np.array_equal(plan.download("lpr"), l0) and np.array_equal(plan.download("d"), d0) and np.array_equal(plan.download("y"), y0)

@@ -176,10 +176,10 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
         if (ms - std::min(NB, ns) < MFMA_MIN_ROWS || T > FRONT_MAXT || (ns % NB != 0 && ms != ns)) ok = false;
         wgs += T; maxT = std::max(maxT, T);
       }
-      if (ok && maxT * (C.levptr[l + 1] - C.levptr[l]) <= 192) { C.lev_persist[l] = 1; C.lev_maxT[l] = maxT; }
+      if (ok && (maxT + (maxT - 1) * (maxT - 2) / 2) * (C.levptr[l + 1] - C.levptr[l]) <= 224) { C.lev_persist[l] = 1; C.lev_maxT[l] = maxT; }
     }
   }
-  C.front_cnt.alloc((size_t)std::max<sdm_int>(1, C.nsuper) * 2 * FRONT_MAXT);
+  C.front_cnt.alloc((size_t)std::max<sdm_int>(1, C.nsuper) * FRONT_CNT);
   // upload
   C.d_first.upload(C.sn_first); C.d_ns.upload(C.sn_ns); C.d_ms.upload(C.sn_ms); C.d_ld.upload(C.sn_ld); C.d_parent.upload(C.sn_parent);
   C.d_childptr.upload(C.childptr); C.d_childlist.upload(C.childlist); C.d_levlist.upload(C.levlist);
@@ -1052,14 +1052,15 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
 }
 
 // ---- the whole LDL' of a front in ONE launch (fronts of FRONT_MINMS <= m_s <= 64 FRONT_MAXT rows; chol_build decides per
-// level).  One workgroup per 64-row tile row r of the front, all resident; it owns the tiles (r, c), c <= r, and for the
-// panels q = 0, 1, ... does
+// level).  All workgroups resident.  One ROW workgroup per 64-row tile row r of the front; for the panels q = 0, 1, ... it does
 //   q <  r   R: rows of tile (r, q) against the factored diagonal block of panel q (published by workgroup q, 16 columns
-//               at a time, exactly as in k_ldl_panel), result stored and counted in row_cnt[r];
-//            U: tiles (r, c) -= L(r, q) D_q L(c, q)' for c = q+1 .. r  (L(c, q) once row_cnt[c] says it is there); the tile
-//               of the NEXT panel's column comes last and stays in LDS as the next R's input, the diagonal tile of
-//               workgroup q+1 goes straight into the LDS arrays of its LDL';
+//               at a time, exactly as in k_ldl_panel), result stored write-through and counted in row_cnt[r];
+//            U: the LAST update of the tile in the next panel's column, (r, q+1) -= L(r, q) D_q L(q+1, q)': it stays in LDS
+//               as the next R's input, or -- r = q+1 -- goes straight into the LDS arrays of the LDL';
 //   q == r   D: LDL' of the diagonal block (ldl_diag_block), then the workgroup is done.
+// One TILE workgroup per tile (r, c), 2 <= c <= r, applies that tile's other updates q = 0 .. c-2 as soon as row_cnt says
+// L(r, q) and L(c, q) are there, and counts them in tile_cnt (the row workgroup waits for it before the tile's last update):
+// a row workgroup never has more than one tile update between two row solves.
 // The chain per panel is D -> (hand-over) -> last block of R in workgroup q+1 -> its diagonal tile -> D: no launch
 // boundary, no wait for the slowest row workgroup.  Arithmetic and its order per entry are those of the launch-per-panel
 // path (same device functions), so both produce the same bits.  upd_done[r] counts the U steps finished (the rare column
@@ -1068,16 +1069,14 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
 __global__ void __launch_bounds__(LDL_THREADS)
 k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, double *lb, const double *ubp, int *pivstat,
             double *pivval, double *colbuf, const double *ada, const int *asm_src, const int64_t *Ljc, int mtot, int *front_cnt,
-            int *diag_cnt, int phase, int step, int *tmo) {
+            int *diag_cnt, int phase, int step, int tile_wg0, int *tmo) {
   SDM_FP_STRICT;
   SDM_DYN_SMEM(smem);
   const int s = list[blockIdx.y];
   const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
   const int T = (ms + TILE - 1) / TILE, NP = (ns + NB - 1) / NB;
-  const int r = blockIdx.x;
-  if (r >= T) return;
   double *Fs = F + tab.foff[s];
-  int *row_cnt = front_cnt + (int64_t)s * 2 * FRONT_MAXT, *upd_done = row_cnt + FRONT_MAXT;
+  int *row_cnt = front_cnt + (int64_t)s * FRONT_CNT, *upd_done = row_cnt + FRONT_MAXT, *tile_cnt = upd_done + FRONT_MAXT;
   double (*As)[TILE] = (double (*)[TILE])smem;
   double (*Bs)[TILE] = As + NB;
   double (*S)[NB + 1] = (double (*)[NB + 1])smem;
@@ -1085,6 +1084,26 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
   __shared__ double dsh[NB], ds[NB], dsr[NB];
   __shared__ int npub;
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  if ((int)blockIdx.x >= tile_wg0) {
+    // ---- tile workgroup: owner of tile (rt, ct), 2 <= ct <= rt, for the updates of the panels q <= ct - 2 (the last
+    // update of a tile, q = ct - 1, belongs to the row workgroup: its result is the next R's / D's input)
+    if (phase != 0 && phase != 3) return;
+    int I, J;
+    tile_index((int)blockIdx.x - tile_wg0, I, J);
+    const int rt = I + 2, ct = J + 2;
+    if (rt >= T) return;
+    for (int q = (phase == 0 ? 0 : step); q < (phase == 0 ? NP : step + 1) && q <= ct - 2; q++) {
+      spin_until(row_cnt + rt, q + 1, tmo);
+      if (ct < rt) spin_until(row_cnt + ct, q + 1, tmo);
+      update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, q * NB, NB, rt - (q + 1), ct - (q + 1), d, As, Bs, dsh);
+      SDM_STORES_DONE();
+      __syncthreads();
+      if (tid == 0) sdm_signal_add(&tile_cnt[rt * FRONT_MAXT + ct]);
+    }
+    return;
+  }
+  const int r = blockIdx.x;
+  if (r >= T) return;
   const bool carry = phase == 0;
   bool have_S = false, have_tw = false;
   for (int q = carry ? 0 : step; q < (carry ? NP : step + 1) && q <= r; q++) {
@@ -1128,25 +1147,24 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
       have_tw = false;
     }
     if (phase == 0 || phase == 3) {
-      // ---- U: the tiles of this row.  Order: the far ones, the diagonal one, last the tile of the next panel's column
-      SDM_ACQUIRE_FENCE();                                            // this workgroup's own L(r, q), not a cached copy from before
+      // ---- U: the LAST update of the tile in the next panel's column, (r, q+1); its earlier ones came from the tile's
+      // own workgroup (tile_cnt), the others of this row are theirs altogether
       const int c1 = q + 1;
-      for (int cc = c1 + 1; cc <= r + 1; cc++) {
-        const int c = cc <= r ? cc : c1;                              // c1 last
-        if (c == c1 && cc <= r) continue;                             // (r == c1: the only tile, handled as cc = r + 1)
-        if (c < r) spin_until(row_cnt + c, q + 1, tmo);
-        const int I = r - c1, J = c - c1;
+      if (c1 <= r) {
+        SDM_ACQUIRE_FENCE();                                          // this workgroup's own L(r, q), not a cached copy from before
+        if (c1 >= 2) spin_until(tile_cnt + r * FRONT_MAXT + c1, q, tmo);
+        if (c1 < r) spin_until(row_cnt + c1, q + 1, tmo);
+        const int I = r - c1, J = 0;
         const int kbn = min(NB, ns - c1 * NB);                        // columns of the next panel (<= 0: none)
-        if (c == r && r == c1 && carry && c1 < NP) {
+        if (r == c1 && carry && c1 < NP) {
           update_tile<LDL_THREADS / 64, true, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh, S, RB, kbn);
           have_S = true;
-        } else if (c == c1 && c < r && carry && c1 < NP) {
+        } else if (c1 < r && carry && c1 < NP) {
           update_tile<LDL_THREADS / 64, false, true, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh, nullptr, nullptr, kbn, tid, true, RB);
           have_tw = true;
         } else {
           update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh);
         }
-        __syncthreads();                                              // As / Bs are reused by the next tile
       }
       SDM_STORES_DONE();
       __syncthreads();
@@ -1233,9 +1251,9 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
 #else
       const int phase = 0, step = 0;
 #endif
-          SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l], nfr), dim3(LDL_THREADS), PANEL_LDS_RIDE, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
+          SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + (C.lev_maxT[l] - 1) * (C.lev_maxT[l] - 2) / 2, nfr), dim3(LDL_THREADS), PANEL_LDS_RIDE, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
                       C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p,
-                      C.diag_cnt.p, phase, step, C.tmo.dev());
+                      C.diag_cnt.p, phase, step, C.lev_maxT[l], C.tmo.dev());
       continue;
     }
     for (int li = C.lev_first_launch[l]; li < C.lev_first_launch[l + 1]; li++) {

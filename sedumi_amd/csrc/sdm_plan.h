@@ -26,6 +26,7 @@ constexpr int ROWS_BATCH = 16 * (PANEL_THREADS / 64);   // rows per workgroup of
 constexpr int TRSM_ROWS = 128;        // up to this many rows below the diagonal block are solved by the diagonal-block kernel itself
 constexpr int MFMA_MIN_ROWS = 256;    // fronts with fewer rows below their first panel use the bit-faithful row substitution
 constexpr int CHK = 16;               // column chunk of the row substitution held in registers
+constexpr int FRONT_CNT = 2 * 16 + 16 * 16;   // counters per front of k_ldl_front: rows solved, update steps, updates per tile
 constexpr int FRONT_MAXT = 16;        // fronts of up to this many 64-row tile rows (and at least MFMA_MIN_ROWS + NB rows) are factored by ONE launch (k_ldl_front)
 constexpr int PANEL_RB = (LDL_THREADS / 64) * NB * 17;     // doubles: max(Lc 64x64, Xs 48 x TRSM_ROWS, 8 wave tiles 64x17)
 constexpr size_t PANEL_LDS = (size_t)(NB * (NB + 1) + PANEL_RB) * sizeof(double);

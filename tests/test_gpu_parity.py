@@ -380,7 +380,7 @@ def test_sweeps_with_front_vector_in_hbm(refmex, glue):
     sweep bodies): multi-front factor whose leaves have 3100+ rows below their own columns."""
     from oracle import glue as gl
     from sedumi_amd import mex
-    from test_emu_parity import _bordered_blocks
+    from helpers import bordered_blocks as _bordered_blocks
     rng = np.random.default_rng(9)
     X = _bordered_blocks(100, 130, 3100, rng)
     L = glue.symbchol(X)

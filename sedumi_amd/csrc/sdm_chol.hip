@@ -344,9 +344,12 @@ __device__ __noinline__ double pivot_probe(const double (*S)[NB + 1], const doub
 // as that kernel's S / Lc arrays (which overlay As / Bs), kbn = columns of the next panel.
 template <int NW, bool DIAG, bool WT = false, bool TW = false>
 __device__ __forceinline__ void update_tile(double *Fs, int ld, int ms, int first, int k0, int kb, int I, int J, const double *d,
-                                            double (*As)[TILE], double (*Bs)[TILE], double *dsh,
+                                            double (*As)[UTP], double (*Bs)[UTP], double *dsh,
                                             double (*S)[NB + 1] = nullptr, double *Lc = nullptr, int kbn = 0,
-                                            int tid = threadIdx.x, bool active = true, double *tw = nullptr) {
+                                            int tid = threadIdx.x, bool active = true, double *tw = nullptr,
+                                            bool staged = false, const double *lds_cv = nullptr) {
+  // staged: As / Bs hold the operands already (k_ldl_front builds them from the row solve's LDS tiles); lds_cv: the tile's
+  // current values were fetched into LDS before (lds_cv[col * TILE + row])
   // TW: the result also goes to LDS as the row solve's wave tiles (tw[(row/16)*NB*17 + col*17 + row%16], columns
   // beyond kbn zeroed) -- the workgroup that solves these rows next needs no second trip to HBM
   // tid: position inside the group of NW wavefronts that shares the tile (two groups of one workgroup may run two
@@ -354,7 +357,7 @@ __device__ __forceinline__ void update_tile(double *Fs, int ld, int ms, int firs
   constexpr int BJ = 8 / NW;                                  // 16-column MFMA tiles per wavefront along J
   const int r0 = k0 + kb;
   SDM_PHASE_BEGIN();
-  if (tid < NB) dsh[tid] = tid < kb ? d[first + k0 + tid] : 0.0;
+  if (!staged && tid < NB) dsh[tid] = tid < kb ? d[first + k0 + tid] : 0.0;
   const int w = tid >> 6, l = tid & 63;
   const int wi = NW == 4 ? w >> 1 : w >> 2, wj = NW == 4 ? w & 1 : w & 3;
   const int cj = wj * 16 * BJ;                                // first tile column of this wavefront
@@ -370,9 +373,9 @@ __device__ __forceinline__ void update_tile(double *Fs, int ld, int ms, int firs
         const int jj = lk + 4 * r;                 // result row  -> J dimension (front column)
         const int gi = r0 + I * TILE + wi * 32 + a * 16 + ll;
         const int gj = r0 + J * TILE + cj + b * 16 + jj;
-        cv[a][b][r] = Fs[(int64_t)min(gj, ms - 1) * ld + min(gi, ms - 1)];
+        cv[a][b][r] = lds_cv ? lds_cv[(cj + b * 16 + jj) * TILE + wi * 32 + a * 16 + ll] : Fs[(int64_t)min(gj, ms - 1) * ld + min(gi, ms - 1)];
       }
-  {
+  if (!staged) {
     // all loads of a work-item are issued before the first use (addresses clamped, masked afterwards): one
     // memory round trip per tile instead of one per element
     const int i = tid & 63, kq = tid >> 6;
@@ -919,8 +922,8 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
       bx = bx < ntw ? 1 + bx : 0;
     }
 #endif
-    double (*As)[TILE] = (double (*)[TILE])smem;
-    double (*Bs)[TILE] = As + NB;
+    double (*As)[UTP] = (double (*)[UTP])smem;
+    double (*Bs)[UTP] = As + NB;
     __shared__ double dsh[NB];
     if (bx > 0 && bx <= nrw) {
       // ---- row-solve workgroup b
@@ -1025,6 +1028,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   const int tid = threadIdx.x;
   const bool ok = ldl_diag_block<false>(smem, F, DT, tab, s, panel, d, lb, ubp, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_cnt, diag_cnt,
                                         q0, tmo, panel == 0, nrows > TRSM_ROWS, ds, &npub);
+  SDM_PHASE_BEGIN();
   if (nrows > TRSM_ROWS) {                                         // the row-solve workgroups of this launch are waiting
     if (16 * npub < kb) SDM_STORES_DONE();                         // (uniform) something of the block is still unpublished
     __syncthreads();
@@ -1049,6 +1053,87 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
     if (tid == 0) sdm_signal_add(&diag_cnt[s], 4);
   }
   SDM_PHASE(23);
+}
+
+// k_ldl_front calls its three stages through real function calls: each gets a register allocation of its own.  Inlined
+// into one body they share 256 VGPRs with the sweep code of the diagonal block and spill inside the store loops -- and a
+// scratch reload between two write-through stores waits for the first one's acknowledgement (vmcnt counts in order):
+// every stored tile then costs eight memory round trips instead of one.
+#ifdef SDM_EMU
+#define SDM_NOINLINE
+#else
+#define SDM_NOINLINE __noinline__
+#endif
+__device__ SDM_NOINLINE bool front_diag(char *smem, double *F, double *DT, const FrontTab &tab, int s, int panel, double *d, double *lb, const double *ubp,
+                                        int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src, const int64_t *Ljc,
+                                        int mtot, int *upd_done, int *diag_cnt, int *tmo, bool load_block, bool publish, double *ds, int *npub) {
+  return ldl_diag_block<true>(smem, F, DT, tab, s, panel, d, lb, ubp, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, 0, tmo,
+                              load_block, publish, ds, npub);
+}
+// kind 0: plain (result to the front only), 1: also the LDS arrays of the next LDL' (S, Lc = RB), 2: also the wave tiles of the next row solve (RB)
+__device__ SDM_NOINLINE void front_update(int kind, double *Fs, int ld, int ms, int first, int k0, int I, int J, const double *d, char *smem,
+                                          double *dsh, int kbn) {
+  double (*As)[UTP] = (double (*)[UTP])smem;
+  double (*Bs)[UTP] = As + NB;
+  double *RB = (double *)smem + NB * (NB + 1);
+  if (kind == 1) update_tile<LDL_THREADS / 64, true, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh, (double (*)[NB + 1])smem, RB, kbn);
+  else if (kind == 2) update_tile<LDL_THREADS / 64, false, true, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh, nullptr, nullptr, kbn, threadIdx.x, true, RB);
+  else update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh);
+}
+// R: rows of tile row r against the diagonal block of panel q as it is published; have_tw: the tile is in the wave tiles already
+__device__ SDM_NOINLINE void front_rows(double *Fs, const double *Ds, const double *d, int ld, int ms, int first, int q, int kb, int r, char *smem,
+                                        double *dsr, const int *diag_cnt_s, int *tmo, bool have_tw, bool defer_ack) {
+  double (*S)[NB + 1] = (double (*)[NB + 1])smem;
+  double *RB = (double *)smem + NB * (NB + 1);
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int k0 = q * NB, rbeg = r * TILE, rend = min(ms, rbeg + TILE);
+  const int R0 = rbeg + 16 * ty;
+  const bool busy = R0 < rend;
+  double *Tw = RB + ty * (NB * 17);
+  if (!have_tw && busy) rows_stage(Fs, ld, rend, k0, kb, R0, Tw, tx);
+  for (int blk = 0; blk < NB / 16 && 16 * blk < kb; blk++) {
+    if (busy) rows_block_gemm(blk, S, Tw, tx);
+    spin_until(diag_cnt_s, 4 * q + blk + 1, tmo);
+    for (int e = tid; e < NB * 16; e += LDL_THREADS) {
+      const int i = e >> 4, j = 16 * blk + (e & 15);
+      S[i][j] = (i < kb && j < i) ? Ds[i * NB + j] : 0.0;
+    }
+    if (tid < 16) dsr[16 * blk + tid] = 16 * blk + tid < kb ? d[first + k0 + 16 * blk + tid] : 0.0;
+    __syncthreads();
+    if (busy) rows_block_tri(blk, S, dsr, Tw, tx);
+  }
+  if (busy) rows_store<true>(Fs, ld, rend, k0, kb, R0, dsr, Tw, tx);
+  if (defer_ack) return;                                           // the caller counts the rows after its next piece of work
+  SDM_STORES_DONE();
+  __syncthreads();
+}
+// the last update of workgroup r's own diagonal tile, r = q + 1, with everything taken from LDS: the operands are the rows
+// just solved (wave tiles, unscaled: l = x / d as rows_store writes it), the pivots are in dsr, the tile's current
+// values were fetched into cvl at the start of the step.  Result: S / Lc for the LDL' and the raw block in the front.
+constexpr int FRONT_CV_OFF = NB * (NB + 1) + (LDL_THREADS / 64) * NB * 17;          // doubles: behind S and the wave tiles
+constexpr size_t FRONT_LDS = (size_t)(FRONT_CV_OFF + NB * TILE) * sizeof(double);
+__device__ SDM_NOINLINE void front_diag_update_lds(double *Fs, int ld, int ms, int first, int k0, const double *d, char *smem, double *dsh,
+                                                   const double *dsr, int rbeg, int kbn) {
+  double (*As)[UTP] = (double (*)[UTP])smem;
+  double (*Bs)[UTP] = As + NB;
+  double *RB = (double *)smem + NB * (NB + 1);
+  const int tid = threadIdx.x, i = tid & 63, kq = tid >> 6;
+  constexpr int NW = LDL_THREADS / 64;
+  double xv[NB / NW];
+  __syncthreads();                                                   // the wave tiles of all four row wavefronts are final
+#pragma unroll
+  for (int j = 0; j < NB / NW; j++) xv[j] = RB[(i >> 4) * (NB * 17) + (kq + NW * j) * 17 + (i & 15)];
+  __syncthreads();                                                   // As / Bs overlay the wave tiles
+#pragma unroll
+  for (int j = 0; j < NB / NW; j++) {
+    const int k = kq + NW * j;
+    const double dk = dsr[k];
+    const double l = (rbeg + i < ms && dk > 0.0) ? xv[j] / dk : 0.0;
+    As[k][i] = l;
+    Bs[k][i] = l * dk;
+  }
+  update_tile<NW, true, true>(Fs, ld, ms, first, k0, NB, 0, 0, d, As, Bs, dsh, (double (*)[NB + 1])smem, RB, kbn, tid, true, nullptr, true,
+                              (const double *)smem + FRONT_CV_OFF);
 }
 
 // ---- the whole LDL' of a front in ONE launch (fronts of FRONT_MINMS <= m_s <= 64 FRONT_MAXT rows; chol_build decides per
@@ -1077,13 +1162,9 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
   const int T = (ms + TILE - 1) / TILE, NP = (ns + NB - 1) / NB;
   double *Fs = F + tab.foff[s];
   int *row_cnt = front_cnt + (int64_t)s * FRONT_CNT, *upd_done = row_cnt + FRONT_MAXT, *tile_cnt = upd_done + FRONT_MAXT;
-  double (*As)[TILE] = (double (*)[TILE])smem;
-  double (*Bs)[TILE] = As + NB;
-  double (*S)[NB + 1] = (double (*)[NB + 1])smem;
-  double *RB = (double *)smem + NB * (NB + 1);
   __shared__ double dsh[NB], ds[NB], dsr[NB];
   __shared__ int npub;
-  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int tid = threadIdx.x;
   if ((int)blockIdx.x >= tile_wg0) {
     // ---- tile workgroup: owner of tile (rt, ct), 2 <= ct <= rt, for the updates of the panels q <= ct - 2 (the last
     // update of a tile, q = ct - 1, belongs to the row workgroup: its result is the next R's / D's input)
@@ -1095,7 +1176,7 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
     for (int q = (phase == 0 ? 0 : step); q < (phase == 0 ? NP : step + 1) && q <= ct - 2; q++) {
       spin_until(row_cnt + rt, q + 1, tmo);
       if (ct < rt) spin_until(row_cnt + ct, q + 1, tmo);
-      update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, q * NB, NB, rt - (q + 1), ct - (q + 1), d, As, Bs, dsh);
+      front_update(0, Fs, ld, ms, first, q * NB, rt - (q + 1), ct - (q + 1), d, smem, dsh, 0);
       SDM_STORES_DONE();
       __syncthreads();
       if (tid == 0) sdm_signal_add(&tile_cnt[rt * FRONT_MAXT + ct]);
@@ -1111,8 +1192,8 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
     if (q == r) {
       if (phase == 0 || phase == 1) {
         const int nrows = ms - (k0 + kb);
-        ldl_diag_block<true>(smem, F, DT, tab, s, q, d, lb, ubp, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, 0, tmo,
-                             !have_S, nrows > 0, ds, &npub);
+        front_diag(smem, F, DT, tab, s, q, d, lb, ubp, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, tmo,
+                   !have_S, nrows > 0, ds, &npub);
         if (nrows > 0) {
           if (16 * npub < kb) SDM_STORES_DONE();
           __syncthreads();
@@ -1122,29 +1203,45 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
       break;
     }
     const int rbeg = r * TILE, rend = min(ms, rbeg + TILE);
+#if defined(SDM_PHASES) && !defined(SDM_EMU)
+    const bool crit = r == q + 1;
+    long long fph_ = wall_clock64();
+#define SDM_FPHASE(n) do { const long long t_ = wall_clock64(); if (crit && threadIdx.x == 0) atomicAdd(&sdm_phase_acc[n], (unsigned long long)(t_ - fph_)); fph_ = t_; } while (0)
+#else
+#define SDM_FPHASE(n) do {} while (0)
+#endif
+    const bool crit_lds = carry && r == q + 1 && q + 1 < NP;         // the next diagonal block's workgroup: its tile update runs from LDS
+    if (crit_lds) {
+      // the tile's current values into LDS while the diagonal block of panel q is still being factored
+      if (r >= 2) spin_until(tile_cnt + r * FRONT_MAXT + r, q, tmo);
+      else SDM_ACQUIRE_FENCE();
+      double *cvl = (double *)smem + FRONT_CV_OFF;
+      double t8[NB * TILE / LDL_THREADS];
+#pragma unroll
+      for (int j = 0; j < NB * TILE / LDL_THREADS; j++) {
+        const int e = tid + LDL_THREADS * j, ti = e & 63, tj = e >> 6;
+        t8[j] = Fs[(int64_t)min(rbeg + tj, ms - 1) * ld + min(rbeg + ti, ms - 1)];
+      }
+#pragma unroll
+      for (int j = 0; j < NB * TILE / LDL_THREADS; j++) cvl[tid + LDL_THREADS * j] = t8[j];
+    }
     if (phase == 0 || phase == 2) {
       // ---- R: 16 rows per wavefront (4 of the 8 busy), following the diagonal block as workgroup q publishes it
-      const double *Ds = DT + tab.toff[s] + (int64_t)q * NB * NB;
-      const int R0 = rbeg + 16 * ty;
-      const bool busy = R0 < rend;
-      double *Tw = RB + ty * (NB * 17);
-      if (!have_tw && busy) rows_stage(Fs, ld, rend, k0, kb, R0, Tw, tx);
-      for (int blk = 0; blk < NB / 16 && 16 * blk < kb; blk++) {
-        if (busy) rows_block_gemm(blk, S, Tw, tx);
-        spin_until(diag_cnt + s, 4 * q + blk + 1, tmo);
-        for (int e = tid; e < NB * 16; e += LDL_THREADS) {
-          const int i = e >> 4, j = 16 * blk + (e & 15);
-          S[i][j] = (i < kb && j < i) ? Ds[i * NB + j] : 0.0;
-        }
-        if (tid < 16) dsr[16 * blk + tid] = 16 * blk + tid < kb ? d[first + k0 + 16 * blk + tid] : 0.0;
-        __syncthreads();
-        if (busy) rows_block_tri(blk, S, dsr, Tw, tx);
-      }
-      if (busy) rows_store<true>(Fs, ld, rend, k0, kb, R0, dsr, Tw, tx);
-      SDM_STORES_DONE();
-      __syncthreads();
-      if (tid == 0) sdm_signal_add(&row_cnt[r]);
+      front_rows(Fs, DT + tab.toff[s] + (int64_t)q * NB * NB, d, ld, ms, first, q, kb, r, smem, dsr, diag_cnt + s, tmo, have_tw, crit_lds);
+      SDM_FPHASE(1);
       have_tw = false;
+      if (crit_lds) {
+        front_diag_update_lds(Fs, ld, ms, first, k0, d, smem, dsh, dsr, rbeg, min(NB, ns - (q + 1) * NB));
+        have_S = true;
+        SDM_FPHASE(4);
+        SDM_STORES_DONE();
+        __syncthreads();
+        if (tid == 0) { sdm_signal_add(&row_cnt[r]); sdm_signal_add(&upd_done[r]); }
+        SDM_FPHASE(5);
+        continue;
+      }
+      if (tid == 0) sdm_signal_add(&row_cnt[r]);
+      SDM_FPHASE(2);                                                  // rows stored, acknowledged, counted
     }
     if (phase == 0 || phase == 3) {
       // ---- U: the LAST update of the tile in the next panel's column, (r, q+1); its earlier ones came from the tile's
@@ -1154,21 +1251,18 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
         SDM_ACQUIRE_FENCE();                                          // this workgroup's own L(r, q), not a cached copy from before
         if (c1 >= 2) spin_until(tile_cnt + r * FRONT_MAXT + c1, q, tmo);
         if (c1 < r) spin_until(row_cnt + c1, q + 1, tmo);
+        SDM_FPHASE(3);                                                // fence + counters
         const int I = r - c1, J = 0;
         const int kbn = min(NB, ns - c1 * NB);                        // columns of the next panel (<= 0: none)
-        if (r == c1 && carry && c1 < NP) {
-          update_tile<LDL_THREADS / 64, true, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh, S, RB, kbn);
-          have_S = true;
-        } else if (c1 < r && carry && c1 < NP) {
-          update_tile<LDL_THREADS / 64, false, true, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh, nullptr, nullptr, kbn, tid, true, RB);
-          have_tw = true;
-        } else {
-          update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh);
-        }
+        if (r == c1 && carry && c1 < NP) { front_update(1, Fs, ld, ms, first, k0, I, J, d, smem, dsh, kbn); have_S = true; }
+        else if (c1 < r && carry && c1 < NP) { front_update(2, Fs, ld, ms, first, k0, I, J, d, smem, dsh, kbn); have_tw = true; }
+        else front_update(0, Fs, ld, ms, first, k0, I, J, d, smem, dsh, kbn);
       }
+      SDM_FPHASE(4);                                                  // the tile update
       SDM_STORES_DONE();
       __syncthreads();
       if (tid == 0) sdm_signal_add(&upd_done[r]);
+      SDM_FPHASE(5);
     }
   }
 }
@@ -1178,8 +1272,8 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
 // of the next panel, k_ldl_panel), else every tile but tile 0 (which k_ldl_panel's workgroup 0 always applies itself).
 __global__ void __launch_bounds__(256)
 k_ldl_update(double *F, FrontTab tab, const int *list, int panel, const double *d, int riding) {
-  __shared__ double As[NB][TILE];
-  __shared__ double Bs[NB][TILE];
+  __shared__ double As[NB][UTP];
+  __shared__ double Bs[NB][UTP];
   __shared__ double dsh[NB];
   const int s = list[blockIdx.y];
   const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
@@ -1230,7 +1324,7 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
   
 #ifndef SDM_EMU
   SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_RIDE));
-  SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_RIDE));
+  SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FRONT_LDS));
 #endif
   SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), st));
   SDM_KLAUNCH(P, k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
@@ -1251,7 +1345,7 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
 #else
       const int phase = 0, step = 0;
 #endif
-          SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + (C.lev_maxT[l] - 1) * (C.lev_maxT[l] - 2) / 2, nfr), dim3(LDL_THREADS), PANEL_LDS_RIDE, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
+          SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + (C.lev_maxT[l] - 1) * (C.lev_maxT[l] - 2) / 2, nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
                       C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p,
                       C.diag_cnt.p, phase, step, C.lev_maxT[l], C.tmo.dev());
       continue;

@@ -8,6 +8,7 @@ namespace sdm {
 
 constexpr int NB = 64;     // factor panel width (columns)
 constexpr int TILE = 64;   // trailing-update tile (MFMA 4 waves x 32x32)
+constexpr int UTP = 72;    // LDS pitch (doubles) of the update's operand tiles As[k][row]: the four k rows one ds_read_b64 of an MFMA operand touches start 16 banks apart (64 would put all four on the same banks)
 constexpr int S1_MAXN = 96;   // PSD blocks up to this order take the matrix-core stage 1 of ADA'
 constexpr int S1_KC = 48;     // slots (nonzero columns of A_jk) per GEMM chunk
 constexpr int S1_WAVES = 8;   // wavefronts per task
@@ -30,7 +31,7 @@ constexpr int FRONT_CNT = 2 * 16 + 16 * 16;   // counters per front of k_ldl_fro
 constexpr int FRONT_MAXT = 16;        // fronts of up to this many 64-row tile rows (and at least MFMA_MIN_ROWS + NB rows) are factored by ONE launch (k_ldl_front)
 constexpr int PANEL_RB = (LDL_THREADS / 64) * NB * 17;     // doubles: max(Lc 64x64, Xs 48 x TRSM_ROWS, 8 wave tiles 64x17)
 constexpr size_t PANEL_LDS = (size_t)(NB * (NB + 1) + PANEL_RB) * sizeof(double);
-constexpr size_t PANEL_LDS_RIDE = std::max(PANEL_LDS, (size_t)4 * NB * TILE * sizeof(double));   // two update tiles side by side
+constexpr size_t PANEL_LDS_RIDE = std::max(PANEL_LDS, (size_t)4 * NB * UTP * sizeof(double));   // two update tiles side by side
 static_assert(PANEL_RB >= NB * NB && PANEL_RB >= (NB - CHK) * TRSM_ROWS && TRSM_ROWS == 16 * (LDL_THREADS / 64) && ROWS_BATCH <= TRSM_ROWS, "panel LDS layout");
 
 template <class T>

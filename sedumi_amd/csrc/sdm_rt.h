@@ -50,14 +50,16 @@ typedef double2 sdm_double2;
 __device__ __forceinline__ void sdm_signal_add(int *p, int n = 1) { __hip_atomic_fetch_add(p, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sdm_store_wt(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #define SDM_STORES_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-__device__ __forceinline__ int sdm_signal_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+// (relaxed: a poll must not invalidate caches -- with dozens of workgroups polling, acquire loads kept every L2 of the device
+// cold; the ONE acquire fence a consumer needs comes after its wait has ended, SDM_ACQUIRE_FENCE in spin_until / prep_wait)
+__device__ __forceinline__ int sdm_signal_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // error flag in pinned host memory (HostFlag): one system-scope store, read by the host after a stream synchronise
 __device__ __forceinline__ void sdm_raise_flag(int *p) { __hip_atomic_store(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 #define SDM_ACQUIRE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 // a wave-uniform integer the compiler cannot prove uniform (e.g. threadIdx.x >> 6): moved to a scalar register, so that
 // addresses built from it stay scalar and loads through them become s_load
 #define SDM_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane(x)
-#define SDM_SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
+#define SDM_SPIN_PAUSE() __builtin_amdgcn_s_sleep(4)
 // predicate of lane `lane` (uniform), delivered to every lane: one compare into a lane mask, one scalar bit test
 __device__ __forceinline__ bool sdm_lane_pred(bool pred, int lane) { return (__ballot(pred) >> lane) & 1ull; }
 // v_readlane_b32 x2: a scalar broadcast, no LDS crossbar round trip (ds_bpermute) on the dependency chain

@@ -256,6 +256,7 @@ def profile_unit(plan, P, ud, nprof):
     ada_bytes = 8.0 * (ud.size + P.At.nnz + plan.nnzADA)
     model = {
         "k_ldl_panel": ("mfma", fac_flops / npanel),                               # the panel launches carry the whole LDL'
+        "k_ldl_front": ("mfma", fac_flops / max(1, prof.get("k_ldl_front", (nprof, 0))[0] // nprof)),   # ... or ONE launch per level does
         "k_ldl_update": ("mfma", fac_flops / npanel),
         "k_psd_stage1_mfma": ("mfma", None), "k_psd_stage1": ("mfma", None),       # flops filled below from the task list
         "k_psd_stage2": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)), "k_psd_stage2_ell": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)),

@@ -27,6 +27,7 @@ inline int sdm_signal_load(const int *p) { return *p; }
 inline void sdm_raise_flag(int *p) { *p = 1; }
 #define SDM_UNIFORM_INT(x) (x)
 #define SDM_ACQUIRE_FENCE() do {} while (0)
+#define SDM_COMPILER_BARRIER() do {} while (0)
 #define SDM_SPIN_PAUSE() do { fprintf(stderr, "hipemu: waiting on a workgroup that has not run\n"); abort(); } while (0)
 #else
 #include <hip/hip_runtime.h>
@@ -60,6 +61,8 @@ __device__ __forceinline__ void sdm_raise_flag(int *p) { __hip_atomic_store(p, 1
 // addresses built from it stay scalar and loads through them become s_load
 #define SDM_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane(x)
 #define SDM_SPIN_PAUSE() __builtin_amdgcn_s_sleep(4)
+// no memory access moves across this point at compile time
+#define SDM_COMPILER_BARRIER() asm volatile("" ::: "memory")
 // predicate of lane `lane` (uniform), delivered to every lane: one compare into a lane mask, one scalar bit test
 __device__ __forceinline__ bool sdm_lane_pred(bool pred, int lane) { return (__ballot(pred) >> lane) & 1ull; }
 // v_readlane_b32 x2: a scalar broadcast, no LDS crossbar round trip (ds_bpermute) on the dependency chain

@@ -128,14 +128,17 @@ __device__ __forceinline__ void acc_zero(Acc22 &a) {
 }
 __device__ __forceinline__ void mma_block(Acc22 &acc, const double *As, const double *Bs, int wave, int lane) {
   const int rb = 32 * (wave & 1) + (lane & 15), cb = 32 * (wave >> 1) + (lane & 15), kq = lane >> 4;
-#pragma unroll 4
+  // the operands of step kk+4 are fetched from LDS while the four products of step kk issue
+  double a0 = As[kq * TP + rb], a1 = As[kq * TP + rb + 16], b0 = Bs[kq * TP + cb], b1 = Bs[kq * TP + cb + 16];
+#pragma unroll
   for (int kk = 0; kk < 64; kk += 4) {
-    const double a0 = As[(kk + kq) * TP + rb], a1 = As[(kk + kq) * TP + rb + 16];
-    const double b0 = Bs[(kk + kq) * TP + cb], b1 = Bs[(kk + kq) * TP + cb + 16];
+    const int kn = min(kk + 4, 60) + kq;
+    const double na0 = As[kn * TP + rb], na1 = As[kn * TP + rb + 16], nb0 = Bs[kn * TP + cb], nb1 = Bs[kn * TP + cb + 16];
     acc.t[0][0] = SDM_MFMA_F64_16x16x4(a0, b0, acc.t[0][0]);
     acc.t[0][1] = SDM_MFMA_F64_16x16x4(a0, b1, acc.t[0][1]);
     acc.t[1][0] = SDM_MFMA_F64_16x16x4(a1, b0, acc.t[1][0]);
     acc.t[1][1] = SDM_MFMA_F64_16x16x4(a1, b1, acc.t[1][1]);
+    a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
   }
 }
 // accumulator -> LDS as Cs[row*TP + col] (the layout of a B operand whose k index is the row) scaled by sgn
@@ -203,10 +206,9 @@ __device__ __forceinline__ double store_tile(double *dst, int64_t ld, const doub
 
 // ================================================================ inversion of the diagonal super-blocks
 // One workgroup per 128-column block h of a front, bottom-up, everything in LDS / registers:
-//   32x32  each of the four wavefronts inverts one 32x32 unit lower triangular diagonal block by rows (lane i owns
-//          row i of the block and of its inverse in registers; the finished row k reaches the other lanes through
-//          v_readlane -- no memory on the 496-step chain);
-//   64x64  X10 = -inv(A11) (A10 inv(A00)) for the two 64-column blocks A and C (plain FMAs from LDS, two wavefronts each);
+//   32x32  each of the four wavefronts inverts one 32x32 unit lower triangular diagonal block by columns (lane j owns
+//          column j of the inverse in registers; the entries of L come as broadcast LDS reads at compile-time offsets);
+//   64x64  X10 = -inv(A11) (A10 inv(A00)) for the two 64-column blocks A and C (matrix cores, two wavefronts each);
 //   128    X21 = -inv(C) (B inv(A)) on the FP64 matrix cores, B = L(C rows, A columns) requested at the very start.
 // Results go to S; max|inv| and max|L| to sb_g (growth check).
 template <bool WT>
@@ -251,23 +253,34 @@ __device__ __forceinline__ void sinv128_body(char *smem, const double *__restric
   const double *raw = blk == 0 ? rawA : rawC;
   double *dst = blk == 0 ? bufA : bufC;
   {
-    // ---- 32x32 by rows: x[j] = inv(i, j), l[k] = L(i, k) of lane i's row (zero for k >= i, and for the idle lanes)
-    const int i = lane & 31;
-    double l[32], x[32];
+    // ---- 32x32 by columns: lane j owns column j of the inverse in registers, X(i, j) = delta_ij - sum_{k<i} L(i, k) X(k, j);
+    // L(i, k) is the same for every lane: one broadcast LDS read at a compile-time offset per term, no cross-lane traffic
+    // (the earlier row form spent 2 v_readlane + 1 FMA per term on the chain: 6.8 us; this one 496 pipelined reads + FMAs)
+    const int j = lane & 31;
+    const double *Lb = raw + (32 * q) * TP + 32 * q;                 // Lb[k*TP + i] = L(i, k) of this 32-block
+    double X[32];
 #pragma unroll
-    for (int k = 0; k < 32; k++) { l[k] = lane < 32 ? raw[(32 * q + k) * TP + 32 * q + i] : 0.0; x[k] = (k == i && lane < 32) ? 1.0 : 0.0; }
+    for (int i = 0; i < 32; i++) {
+      // row i's coefficients are read one row ahead of their use; the dependence on X[i-2] keeps the compiler from hoisting ALL
+      // 496 reads to the top (which it does otherwise -- and then spills them: 79 us instead of 3)
+      double lrow[32];
+      const int z = i >= 2 ? SDM_ZERO_AFTER(X[i - 2]) : 0;           // an opaque 0: row i's reads cannot be issued before row i-2 is done
 #pragma unroll
-    for (int k = 0; k < 31; k++) {
+      for (int k = 0; k < i; k++) lrow[k] = Lb[k * TP + i + z];
+      double a0 = (i == j) ? 1.0 : 0.0, a1 = 0.0;                    // two partial sums: half the dependent FMA chain
 #pragma unroll
-      for (int j = 0; j <= k; j++) x[j] -= l[k] * sdm_bcast_lane(x[j], k);      // row k is final: lane k has l[k' >= k] = 0
+      for (int k = 0; k < i; k++) {
+        if (k & 1) a1 -= lrow[k] * X[k]; else a0 -= lrow[k] * X[k];
+      }
+      X[i] = a0 + a1;
     }
     double gm = 0.0;
     if (lane < 32) {
 #pragma unroll
-      for (int j = 0; j < 32; j++) {
-        gm = fmax(gm, fabs(x[j]));
+      for (int i = 0; i < 32; i++) {
+        gm = fmax(gm, fabs(X[i]));
         // inv(A) is kept as a B operand [k*TP + col] = inv(k, col); inv(C) as an A operand [k*TP + row] = inv(row, k)
-        if (blk == 0) dst[(32 * q + i) * TP + 32 * q + j] = x[j]; else dst[(32 * q + j) * TP + 32 * q + i] = x[j];
+        if (blk == 0) dst[(32 * q + i) * TP + 32 * q + j] = X[i]; else dst[(32 * q + j) * TP + 32 * q + i] = X[i];
       }
     }
     wave_atomic_max(gP, gm, lane);
@@ -276,40 +289,47 @@ __device__ __forceinline__ void sinv128_body(char *smem, const double *__restric
   __syncthreads();
   SDM_PHASE(2);
   {
-    // ---- 64x64: X10 = -inv11 (L10 inv00), two wavefronts per block, plain FMAs from LDS.  T1 goes to the unused
-    // upper right quadrant of the raw buffer (rows 32.., columns < 32 of raw[k*TP + i] hold zeros of the upper triangle)
-    const int t = tid & 127, c = t & 31, rq = t >> 5;
+    // ---- 64x64: X10 = -inv11 (L10 inv00) per 64-block on the FP64 matrix cores: two wavefronts per block, wavefront q owns
+    // the two 16x16 tiles of output columns 16q .. 16q+15 of each product, K = 32 = 8 steps of v_mfma_f64_16x16x4_f64.
+    // T goes to the unused upper right quadrant of the raw buffer (rows 32.., columns < 32 of raw[k*TP + i] hold zeros).
+    const int li = lane & 15, lk = lane >> 4;
     double *Ts = (blk == 0 ? rawA : rawC) + 32 * TP;                 // Ts[r*TP + c]
-    double acc[8];
+    sdm_double4 acc[2];
+    for (int t = 0; t < 2; t++) for (int r = 0; r < 4; r++) acc[t][r] = 0.0;
 #pragma unroll
-    for (int jj = 0; jj < 8; jj++) acc[jj] = 0.0;
-    for (int k = 0; k < 32; k++) {
-      const double inv00 = blk == 0 ? dst[k * TP + c] : dst[c * TP + k];            // inv00(k, c)
+    for (int s4 = 0; s4 < 8; s4++) {
+      const int k = 4 * s4 + lk;
+      const double b = blk == 0 ? dst[k * TP + 16 * q + li] : dst[(16 * q + li) * TP + k];          // inv00(k, 16q + li)
 #pragma unroll
-      for (int jj = 0; jj < 8; jj++) acc[jj] += raw[k * TP + 32 + rq + 4 * jj] * inv00;   // L10(r, k)
+      for (int t = 0; t < 2; t++) acc[t] = SDM_MFMA_F64_16x16x4(raw[k * TP + 32 + 16 * t + li], b, acc[t]);   // L10(16t + li, k)
     }
 #pragma unroll
-    for (int jj = 0; jj < 8; jj++) Ts[(rq + 4 * jj) * TP + c] = acc[jj];
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) Ts[(16 * t + lk + 4 * r) * TP + 16 * q + li] = acc[t][r];
     __syncthreads();
+    for (int t = 0; t < 2; t++) for (int r = 0; r < 4; r++) acc[t][r] = 0.0;
 #pragma unroll
-    for (int jj = 0; jj < 8; jj++) acc[jj] = 0.0;
-    for (int k = 0; k < 32; k++) {
-      const double tk = Ts[k * TP + c];
+    for (int s4 = 0; s4 < 8; s4++) {
+      const int k = 4 * s4 + lk;
+      const double b = Ts[k * TP + 16 * q + li];                                                    // T(k, 16q + li)
 #pragma unroll
-      for (int jj = 0; jj < 8; jj++) {
-        const int r = rq + 4 * jj;
-        const double inv11 = blk == 0 ? dst[(32 + r) * TP + 32 + k] : dst[(32 + k) * TP + 32 + r];   // inv11(r, k)
-        acc[jj] += inv11 * tk;
+      for (int t = 0; t < 2; t++) {
+        const int rr = 16 * t + li;
+        const double a = blk == 0 ? dst[(32 + rr) * TP + 32 + k] : dst[(32 + k) * TP + 32 + rr];    // inv11(rr, k)
+        acc[t] = SDM_MFMA_F64_16x16x4(a, b, acc[t]);
       }
     }
     double gm = 0.0;
 #pragma unroll
-    for (int jj = 0; jj < 8; jj++) {
-      const int r = rq + 4 * jj;
-      const double v = -acc[jj];
-      gm = fmax(gm, fabs(v));
-      if (blk == 0) dst[(32 + r) * TP + c] = v; else dst[c * TP + 32 + r] = v;
-    }
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rr = 16 * t + lk + 4 * r, c = 16 * q + li;
+        const double v = -acc[t][r];
+        gm = fmax(gm, fabs(v));
+        if (blk == 0) dst[(32 + rr) * TP + c] = v; else dst[c * TP + 32 + rr] = v;
+      }
     wave_atomic_max(gP, gm, lane);
   }
   SDM_PHASE(3);

@@ -137,42 +137,6 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
     }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
     A.t_order.upload(order); }
-  { // tiled matrix-core stage 1: real blocks only, every task's slots and nonzeros resident in LDS, Y and D rows of
-    // Kp x np doubles each.  Targets of block k bucketed by tile pair (hi >= lo): entry = u << 8 | a << 4 | b with
-    // z[u] = (T1[a][b] + T2[b][a]) / 2, T1 = Z(tile hi, tile lo), T2 = Z(tile lo, tile hi)
-    int maxslot = 0; int64_t maxnz = 0;
-    for (size_t t = 0; t < t_col.size(); t++) {
-      maxslot = std::max(maxslot, t_nslot[t]);
-      maxnz = std::max<int64_t>(maxnz, (t + 1 < t_slotptr.size() ? s_nzptr[t_slotptr[t + 1]] : A.nnzA) - s_nzptr[t_slotptr[t]]);
-    }
-    const int kp = (maxslot + 3) & ~3, np = (A.maxn + 15) & ~15;
-    const size_t lds = (size_t)(2 * kp * np + 8 * 2 * 16 * 17) * sizeof(double);
-    int64_t maxu = 0;
-    for (sdm_int k = 0; k < sdpN; k++) maxu = std::max<int64_t>(maxu, (int64_t)U[k].size());
-    A.s1t_ok = sdpN > 0 && sdpN == rsdpN && A.maxn > S1_MAXN && maxslot <= S1T_KMAX && maxnz <= S1_NZ && lds <= 150 * 1024 && maxu < (1 << 23)
-               && getenv("SDM_S1T_OFF") == nullptr;
-    if (A.s1t_ok) {
-      A.s1t_kp = kp; A.s1t_np = np;
-      std::vector<int> ptr, ent; std::vector<int64_t> ptroff(sdpN + 1, 0), entoff(sdpN + 1, 0);
-      for (sdm_int k = 0; k < sdpN; k++) {
-        const int n = (int)A.psd_n[k], nt = (n + 15) / 16, npair = nt * (nt + 1) / 2;
-        std::vector<std::vector<int>> bucket(npair);
-        for (size_t u = 0; u < U[k].size(); u++) {
-          const int q = U[k][u], c = q / n, r = q - c * n, I = r / 16, J = c / 16;
-          const int hi = std::max(I, J), lo = std::min(I, J);
-          const int a = I >= J ? r % 16 : c % 16, b = I >= J ? c % 16 : r % 16;
-          bucket[hi * (hi + 1) / 2 + lo].push_back((int)(u << 8) | (a << 4) | b);
-        }
-        ptroff[k] = (int64_t)ptr.size(); entoff[k] = (int64_t)ent.size();
-        int run = 0;
-        for (int pp = 0; pp < npair; pp++) { ptr.push_back(run); ent.insert(ent.end(), bucket[pp].begin(), bucket[pp].end()); run += (int)bucket[pp].size(); }
-        ptr.push_back(run);
-      }
-      ptroff[sdpN] = (int64_t)ptr.size(); entoff[sdpN] = (int64_t)ent.size();
-      if (ent.empty()) ent.push_back(0);
-      A.s1t_ptr.upload(ptr); A.s1t_ent.upload(ent); A.s1t_ptroff.upload(ptroff); A.s1t_entoff.upload(entoff);
-    }
-  }
   A.ntask = (sdm_int)t_col.size(); A.zlen = zlen;
   A.h_taskptr = c_taskptr; A.col0 = 0; A.col1 = m;
   { std::vector<int64_t> czl(m + 1, 0);                       // length of z_j (all tasks of constraint j)
@@ -663,89 +627,6 @@ k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0, con
 #endif
 }
 
-// ---- stage 1 for real blocks of order > S1_MAXN whose tasks fit LDS (64 x 200: configs[4]): Y = D X(:,cols) and the rows
-// D(cols,:) of ALL slots of the task in LDS, then Z = Y' D(cols,:) tile by tile on the FP64 matrix cores -- but only the
-// 16x16 tile pairs (hi,lo) / (lo,hi) that hold targets, each pair by one wavefront: both tiles go to a wave-private
-// scratch and the pair's targets are read off it, z(r,c) = (Z[r][c] + Z[c][r]) / 2 (spscale.c:283-304).  Z itself never
-// exists.  (The two-dot kernel above does 4 LDS reads per target and slot: 0.75 ms on 64 x 200; this one 0.2.)
-struct Stage1Tiles { const int *ptr, *ent; const int64_t *ptroff, *entoff; int kp, np; };
-__global__ void __launch_bounds__(64 * S1_WAVES)
-k_psd_stage1_tiled(Stage1Tab T, Stage1Tiles Q, const double *udsqr, double *zbuf, int task0, const int *order) {
-  SDM_DYN_SMEM(smem);
-  const int task = order ? order[blockIdx.x] : blockIdx.x + task0;
-  const int n = T.t_n[task], nslot = T.t_nslot[task], blk = T.t_blk[task];
-  const int np = Q.np, kp = Q.kp;
-  double *Yl = (double *)smem;                      // Yl[t*np + i]
-  double *Dl = Yl + kp * np;                        // Dl[t*np + j] = D[col_t][j]
-  double *Zw = Dl + kp * np;                        // per wavefront: two 16 x 17 tiles
-  const int64_t slot0 = T.t_slotptr[task], tend = T.t_end[task];
-  const double *D = udsqr + T.t_udoff[task];
-  double *z = zbuf + T.t_zoff[task];
-  const int64_t rowbase = T.psd_start[blk];
-  const int tid = threadIdx.x, bs = blockDim.x;
-  const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
-  const int li = lane & 15, lk = lane >> 4;
-  __shared__ double nzx[S1_NZ];
-  __shared__ int nzr[S1_NZ];
-  __shared__ int sbeg[S1T_KMAX + 1], scol[S1T_KMAX];
-  const int64_t nzb = T.s_nzptr[slot0];
-  for (int64_t u = nzb + tid; u < tend; u += bs) { nzx[u - nzb] = T.Apr[u]; nzr[u - nzb] = (int)(T.Air[u] - rowbase); }
-  for (int t = tid; t <= nslot; t += bs) sbeg[t] = (int)((t < nslot ? T.s_nzptr[slot0 + t] : tend) - nzb);
-  for (int t = tid; t < nslot; t += bs) scol[t] = T.s_col[slot0 + t];
-  __syncthreads();
-  for (int t = wave; t < kp; t += nw) {
-    if (t < nslot) {
-      const int sb = sbeg[t], se = sbeg[t + 1], col = scol[t];
-      for (int i = lane; i < np; i += 64) {
-        double a = 0.0;
-        if (i < n) {
-          int u = sb;
-          for (; u + 4 <= se; u += 4) {                 // 4 independent column loads of D in flight
-            const double d0 = D[(int64_t)(nzr[u] - col * n) * n + i], d1 = D[(int64_t)(nzr[u + 1] - col * n) * n + i];
-            const double d2 = D[(int64_t)(nzr[u + 2] - col * n) * n + i], d3 = D[(int64_t)(nzr[u + 3] - col * n) * n + i];
-            a += nzx[u] * d0; a += nzx[u + 1] * d1; a += nzx[u + 2] * d2; a += nzx[u + 3] * d3;
-          }
-          for (; u < se; u++) a += nzx[u] * D[(int64_t)(nzr[u] - col * n) * n + i];
-        }
-        Yl[t * np + i] = a;
-        Dl[t * np + i] = i < n ? D[(int64_t)col * n + i] : 0.0;
-      }
-    } else {
-      for (int i = lane; i < np; i += 64) { Yl[t * np + i] = 0.0; Dl[t * np + i] = 0.0; }
-    }
-  }
-  __syncthreads();
-  const int nt = (n + 15) >> 4, npair = nt * (nt + 1) / 2;
-  const int *ptr = Q.ptr + Q.ptroff[blk];
-  const int *ent = Q.ent + Q.entoff[blk];
-  double *Z1 = Zw + wave * (2 * 16 * 17), *Z2 = Z1 + 16 * 17;
-  for (int pp = wave; pp < npair; pp += nw) {
-    const int eb = ptr[pp], ee = ptr[pp + 1];
-    if (eb == ee) continue;                             // (wave-uniform) no target in this pair of tiles
-    int hi = (int)((sqrtf(8.0f * (float)pp + 1.0f) - 1.0f) * 0.5f);
-    while ((hi + 1) * (hi + 2) / 2 <= pp) hi++;
-    while (hi * (hi + 1) / 2 > pp) hi--;
-    const int lo = pp - hi * (hi + 1) / 2;
-    sdm_double4 acc1, acc2;
-    for (int r = 0; r < 4; r++) { acc1[r] = 0.0; acc2[r] = 0.0; }
-    for (int q4 = 0; q4 < kp; q4 += 4) {
-      const double yh = Yl[(q4 + lk) * np + 16 * hi + li], dlo = Dl[(q4 + lk) * np + 16 * lo + li];
-      acc1 = SDM_MFMA_F64_16x16x4(yh, dlo, acc1);       // Z(16 hi + row, 16 lo + col)
-      if (hi != lo) {
-        const double yl = Yl[(q4 + lk) * np + 16 * lo + li], dhi = Dl[(q4 + lk) * np + 16 * hi + li];
-        acc2 = SDM_MFMA_F64_16x16x4(yl, dhi, acc2);     // Z(16 lo + row, 16 hi + col)
-      }
-    }
-    for (int r = 0; r < 4; r++) { Z1[(lk + 4 * r) * 17 + li] = acc1[r]; Z2[(lk + 4 * r) * 17 + li] = hi != lo ? acc2[r] : acc1[r]; }
-    SDM_WAVE_SYNC();
-    for (int e = eb + lane; e < ee; e += 64) {
-      const int v = ent[e], u = v >> 8, a = (v >> 4) & 15, b = v & 15;
-      z[u] = (Z1[a * 17 + b] + Z2[b * 17 + a]) / 2;
-    }
-    SDM_WAVE_SYNC();
-  }
-}
-
 // ---- stage 2: ADA(i,j) += a_i[psd]' z_j ; absd fused (getada3.c:333-351).  Sparse ADA' patterns: one workgroup per
 // column j walks the pattern entries of the column.  Short constraint rows: one entry per work-item, z_j staged in
 // LDS when it fits (all entries of the column gather from it); long rows: one entry per wavefront.
@@ -1037,15 +918,6 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
       if (lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage1_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
       SDM_KLAUNCH(P, k_psd_stage1_mfma, dim3((unsigned)ntask), dim3(64 * S1_WAVES), lds, T, A.udsqr.p, A.zbuf.p, task0,
-                  (ntask == (int)A.ntask) ? (const int *)A.t_order.p : (const int *)nullptr);
-    } else if (A.s1t_ok) {
-      Stage1Tiles Q;
-      Q.ptr = A.s1t_ptr.p; Q.ent = A.s1t_ent.p; Q.ptroff = A.s1t_ptroff.p; Q.entoff = A.s1t_entoff.p; Q.kp = A.s1t_kp; Q.np = A.s1t_np;
-      const size_t lds = (size_t)(2 * A.s1t_kp * A.s1t_np + S1_WAVES * 2 * 16 * 17) * sizeof(double);
-#ifndef SDM_EMU
-      SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage1_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-#endif
-      SDM_KLAUNCH(P, k_psd_stage1_tiled, dim3((unsigned)ntask), dim3(64 * S1_WAVES), lds, T, Q, A.udsqr.p, A.zbuf.p, task0,
                   (ntask == (int)A.ntask) ? (const int *)A.t_order.p : (const int *)nullptr);
     } else
     {

@@ -14,7 +14,6 @@ constexpr int S1_KC = 48;     // slots (nonzero columns of A_jk) per GEMM chunk
 constexpr int S1_WAVES = 8;   // wavefronts per task
 constexpr int S1_NZ = 1536;   // nonzeros of a chunk of slots staged in LDS (bigger chunks read At directly)
 constexpr int S1_MAXT = ((S1_MAXN / 16) * (S1_MAXN / 16) + S1_WAVES - 1) / S1_WAVES;   // 16x16 tiles of Z per wavefront
-constexpr int S1T_KMAX = 32;   // tiled stage 1: slots of a task (all resident in LDS at once)
 constexpr int S1_GEN_LDS = 24 * 1024;   // LDS target per task of the generic stage-1 kernel (bytes)
 constexpr int ELL_WAVES = 8;  // wavefronts per workgroup of the ELL stage-2 kernel of ADA'
 constexpr int SOLVE_LDS_MAX = 3072;   // doubles of a product-form right-hand side kept in LDS (k_pr1_solve)
@@ -192,9 +191,6 @@ struct AdaPlan {
   DevBuf<int64_t> t_slotptr, t_udoff, t_uoff, t_zoff;
   DevBuf<int> s_col;                      // per slot: column of X_jk
   DevBuf<int64_t> s_nzptr;                // per slot (+1): nonzero range in At
-  // tiled matrix-core stage 1 (blocks of order > S1_MAXN that fit LDS): per block the targets bucketed by 16x16 tile pair
-  bool s1t_ok = false; int s1t_kp = 0, s1t_np = 0;
-  DevBuf<int> s1t_ptr, s1t_ent; DevBuf<int64_t> s1t_ptroff, s1t_entoff;
   DevBuf<int> u_pos;                      // concatenated target lists U_k (position r + c*n_k [+ n_k^2 for Im])
   DevBuf<int64_t> c_taskptr;              // per constraint: its tasks
   DevBuf<double> zbuf, dsqr, symtmp;

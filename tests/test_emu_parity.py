@@ -43,16 +43,6 @@ def test_iteration_unit_block_diagonal_multi_supernode(glue):
     assert S["L"]["xsuper"].size - 1 > 1
 
 
-@pytest.mark.parametrize("kw", [dict(nblk=3, n=100, mper=10, nnz=12, seed=8), dict(nblk=2, n=130, mper=14, nnz=30, seed=9)])
-def test_iteration_unit_blocks_above_96_take_the_tiled_stage1(glue, kw):
-    """PSD blocks of order 100 and 130 (not multiples of 16; up to 32 nonzero columns per constraint): stage 1 of ADA' on the
-    tile-pair matrix-core kernel (k_psd_stage1_tiled), stage by stage against the reference."""
-    from sedumi_amd import problem
-    P = problem.blockdiag_sdp(**kw)
-    errs, S, _ = check_iteration(glue, P, seed=kw["seed"])
-    assert max(errs.values()) < TOL, errs
-
-
 @pytest.mark.parametrize("name", ["arch0", "nb"])
 def test_golden_small_examples(name):
     for tag in ("init", "rand"):

@@ -168,6 +168,16 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   C.lev_persist.assign(nlev, 0); C.lev_maxT.assign(nlev, 0);
   {
     const bool off = getenv("SDM_FRONT_OFF") != nullptr;              // comparison override (tools, tests): read at every set_chol
+    // k_ldl_front's workgroups wait for each other in both directions (a row workgroup for its tile workgroups and vice
+    // versa): they must all be resident, one per compute unit (135 KB of LDS each).  A device -- or a partition of one --
+    // with fewer compute units than the level needs keeps the launch-per-panel path.
+    int ncu = 0;
+#ifdef SDM_EMU
+    ncu = 1 << 20;
+#else
+    SDM_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, P->device));
+#endif
+    const int wg_budget = std::min(224, ncu - ncu / 8);              // leave an eighth of the device to whatever else is running
     for (int l = 0; l < nlev; l++) {
       bool ok = !off;
       int wgs = 0, maxT = 0;
@@ -176,7 +186,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
         if (ms - std::min(NB, ns) < MFMA_MIN_ROWS || T > FRONT_MAXT || (ns % NB != 0 && ms != ns)) ok = false;
         wgs += T; maxT = std::max(maxT, T);
       }
-      if (ok && (maxT + (maxT - 1) * (maxT - 2) / 2) * (C.levptr[l + 1] - C.levptr[l]) <= 224) { C.lev_persist[l] = 1; C.lev_maxT[l] = maxT; }
+      if (ok && (maxT + (maxT - 1) * (maxT - 2) / 2) * (C.levptr[l + 1] - C.levptr[l]) <= wg_budget) { C.lev_persist[l] = 1; C.lev_maxT[l] = maxT; }
     }
   }
   C.front_cnt.alloc((size_t)std::max<sdm_int>(1, C.nsuper) * FRONT_CNT);

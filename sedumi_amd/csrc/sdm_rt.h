@@ -23,6 +23,7 @@ inline bool sdm_lane_pred(bool pred, int lane) { return emu_shfl(pred ? 1.0 : 0.
 inline void sdm_signal_add(int *p, int n = 1) { *p += n; }
 inline void sdm_store_wt(double *p, double v) { *p = v; }
 inline double sdm_load_wt(const double *p) { return *p; }
+inline unsigned long long sdm_load_wt_u64(const unsigned long long *p) { return *p; }
 #define SDM_STORES_DONE() do {} while (0)
 inline int sdm_signal_load(const int *p) { return *p; }
 inline void sdm_raise_flag(int *p) { *p = 1; }
@@ -54,6 +55,7 @@ __device__ __forceinline__ void sdm_store_wt(double *p, double v) { __hip_atomic
 // the matching read: an sc1 load bypasses this CU's L1 (served by L2 / memory), so data another workgroup published with
 // sdm_store_wt needs NO acquire fence (1.7 us: MI355X_MICROARCH.md, price list) before it is read this way
 __device__ __forceinline__ double sdm_load_wt(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long sdm_load_wt_u64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #define SDM_STORES_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 // (relaxed: a poll must not invalidate caches -- with dozens of workgroups polling, acquire loads kept every L2 of the device
 // cold; the ONE acquire fence a consumer needs comes after its wait has ended, SDM_ACQUIRE_FENCE in spin_until / prep_wait)

@@ -157,10 +157,15 @@ __device__ __forceinline__ void acc_to_lds_rowmajor(const Acc22 &acc, double *Cs
 // unconditional), the LDS stores later -- so that one memory latency is paid per block, not one per element.
 // column-major operand: dst[k*TP + r] = src[k*ld + r] for r < nr, k < nk, zero elsewhere
 constexpr int SPT = 64 * 64 / ST;      // elements per work-item
+// WT: sc1 loads (what another workgroup of the SAME launch stored write-through is read without an acquire fence)
+template <bool WT = false>
 __device__ __forceinline__ void stage_colmajor_load(double (&v)[SPT], const double *src, int64_t ld, int nr, int nk, int tid) {
   const int r = min(tid & 63, nr - 1), kq = tid >> 6;
 #pragma unroll
-  for (int j = 0; j < SPT; j++) v[j] = src[(int64_t)min(kq + (ST / 64) * j, nk - 1) * ld + r];
+  for (int j = 0; j < SPT; j++) {
+    const double *a = &src[(int64_t)min(kq + (ST / 64) * j, nk - 1) * ld + r];
+    v[j] = WT ? sdm_load_wt(a) : *a;
+  }
 }
 __device__ __forceinline__ double stage_colmajor_store(double *dst, const double (&v)[SPT], int nr, int nk, int tid) {
   const int r = tid & 63, kq = tid >> 6;
@@ -175,10 +180,14 @@ __device__ __forceinline__ double stage_colmajor_store(double *dst, const double
   return mx;
 }
 // the same transposed: dst[k*TP + c] = src[c*ld + k] for k < nk, c < nc, zero elsewhere
+template <bool WT = false>
 __device__ __forceinline__ void stage_transposed_load(double (&v)[SPT], const double *src, int64_t ld, int nk, int nc, int tid) {
   const int k = min(tid & 63, nk - 1), cq = tid >> 6;
 #pragma unroll
-  for (int j = 0; j < SPT; j++) v[j] = src[(int64_t)min(cq + (ST / 64) * j, nc - 1) * ld + k];
+  for (int j = 0; j < SPT; j++) {
+    const double *a = &src[(int64_t)min(cq + (ST / 64) * j, nc - 1) * ld + k];
+    v[j] = WT ? sdm_load_wt(a) : *a;
+  }
 }
 __device__ __forceinline__ void stage_transposed_store(double *dst, const double (&v)[SPT], int nk, int nc, int tid) {
   const int k = tid & 63, cq = tid >> 6;
@@ -401,7 +410,8 @@ __device__ __forceinline__ void stile_body(char *smem, const double *F, double *
     Cp = Ss + (int64_t)(k0 + 64 * J) * sld + k0 + 128 + 64 * I; ldc = sld;
     sgn = -1.0; track_g = true;
   } else {
-    if (sb_is_bad(sb_g, tab.sboff[s] + Pb, thr)) return;            // this block row stays unpremultiplied
+    if (WT ? !(bits_to_double(sdm_load_wt_u64(&sb_g[2 * (tab.sboff[s] + Pb)])) * bits_to_double(sdm_load_wt_u64(&sb_g[2 * (tab.sboff[s] + Pb) + 1])) <= thr)
+           : sb_is_bad(sb_g, tab.sboff[s] + Pb, thr)) return;       // this block row stays unpremultiplied
     const int I = it[2], J = it[3];
     arows = min(64, nb - 64 * I); kvalid = min(64 * (I + 1), nb);
     Ap = Ss + (int64_t)k0 * sld + k0 + 64 * I; lda = sld;
@@ -413,15 +423,15 @@ __device__ __forceinline__ void stile_body(char *smem, const double *F, double *
   double lmx = 0.0;
   double va[SPT], vb[SPT];
   SDM_PHASE_BEGIN();
-  stage_colmajor_load(va, Ap, lda, arows, kvalid, tid);
-  stage_transposed_load(vb, Bp, ldb, kvalid, 64, tid);
+  stage_colmajor_load<WT>(va, Ap, lda, arows, kvalid, tid);
+  stage_transposed_load<WT>(vb, Bp, ldb, kvalid, 64, tid);
   for (int kb = 0; kb < kvalid; kb += 64) {
     lmx = fmax(lmx, stage_colmajor_store(As, va, arows, kvalid - kb, tid));
     stage_transposed_store(Bs, vb, kvalid - kb, 64, tid);
     __syncthreads();
     if (kb + 64 < kvalid) {                                          // next K block: loads in flight during the products
-      stage_colmajor_load(va, Ap + (int64_t)(kb + 64) * lda, lda, arows, kvalid - kb - 64, tid);
-      stage_transposed_load(vb, Bp + kb + 64, ldb, kvalid - kb - 64, 64, tid);
+      stage_colmajor_load<WT>(va, Ap + (int64_t)(kb + 64) * lda, lda, arows, kvalid - kb - 64, tid);
+      stage_transposed_load<WT>(vb, Bp + kb + 64, ldb, kvalid - kb - 64, 64, tid);
     }
     mma_block(acc, As, Bs, wave, lane);
     __syncthreads();
@@ -454,8 +464,7 @@ __device__ __forceinline__ void prep_wait(const int *cnt, int target, int *tmo) 
     for (; sdm_signal_load(cnt) < target && it < (1L << 21); it++) SDM_SPIN_PAUSE();
     if (it == (1L << 21)) sdm_raise_flag(tmo);
   }
-  __syncthreads();
-  SDM_ACQUIRE_FENCE();
+  __syncthreads();                                                  // no acquire fence: everything waited for is read with sc1 loads
 }
 __device__ __forceinline__ void prep_done(int *cnt) {
   SDM_STORES_DONE();

@@ -196,6 +196,11 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   C.d_lindx.upload(lindx); C.d_relidx.upload(relidx);
   { std::vector<int> p32(m); for (sdm_int i = 0; i < m; i++) p32[i] = (int)perm[i]; C.d_perm.upload(p32); }
   C.d_foff.upload(C.sn_foff); C.d_xl.upload(C.sn_xl); C.d_woff.upload(C.sn_woff); C.d_roff.upload(C.sn_roff);
+  if (C.fsize <= ASM_FULL_MAX) {                                    // inverse map for k_assemble_full
+    std::vector<int> fsrc((size_t)C.fsize, -1);
+    for (sdm_int t = 0; t < C.nnzL; t++) fsrc[(size_t)asm_dst[t]] = asm_src[t];
+    C.d_asm_fsrc.upload(fsrc);
+  } else C.d_asm_fsrc.release();
   C.d_asm_src.upload(asm_src); C.d_asm_dst.upload(asm_dst); C.d_asm_dstT.upload(asm_dstT); C.d_toff.upload(C.sn_toff);
   C.frontsT.alloc((size_t)C.tsize);
   { std::vector<int64_t> l64(C.Ljc.begin(), C.Ljc.end()); C.d_Ljc.upload(l64); }
@@ -211,6 +216,15 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
 // ================================================================= kernels
 
 // ---- permuteP: scatter tril(ADA(perm,perm)) into the (zeroed) fronts
+// the same with the zero fill of the fronts folded in (arenas of up to ASM_FULL_MAX entries): one work-item per ENTRY of
+// the arena through the inverse map (entry -> ADA value index, -1 = structural zero / padding), one launch less per
+// factorisation than memset + scatter
+__global__ void k_assemble_full(double *F, const double *ada, const int *fsrc, int64_t fsize, double *ub) {
+  if (ub && blockIdx.x == 0 && threadIdx.x < 3) ub[threadIdx.x] = 0.0;
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; t < fsize; t += stride) { const int s = fsrc[t]; F[t] = s < 0 ? 0.0 : ada[s]; }
+}
 __global__ void k_assemble(double *F, const double *ada, const int *src, const int64_t *dst, int64_t nnzL, double *ub) {
   // ub[0..2] (pivot thresholds of this factorisation, filled by k_prep_pivots -- the next launch on the stream) start at 0
   if (ub && blockIdx.x == 0 && threadIdx.x < 3) ub[threadIdx.x] = 0.0;
@@ -1337,9 +1351,13 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
   SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_RIDE));
   SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FRONT_LDS));
 #endif
-  SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), st));
-  SDM_KLAUNCH(P, k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
-             C.d_asm_dst.p, (int64_t)C.nnzL, C.ub.p);
+  if (C.d_asm_fsrc.n) {
+    SDM_KLAUNCH(P, k_assemble_full, dim3(grid1d(C.fsize, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_fsrc.p, (int64_t)C.fsize, C.ub.p);
+  } else {
+    SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), st));
+    SDM_KLAUNCH(P, k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
+               C.d_asm_dst.p, (int64_t)C.nnzL, C.ub.p);
+  }
   SDM_KLAUNCH(P, k_prep_pivots, dim3(grid1d(m, 256, 64)), dim3(256), 0, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
              P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, (int)C.nsuper, C.upd_cnt.p, C.diag_cnt.p,
              C.sb_g.p, 4 * C.nsbtot, C.front_cnt.p, (int)C.front_cnt.n);

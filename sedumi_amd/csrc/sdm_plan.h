@@ -27,6 +27,7 @@ constexpr int ROWS_BATCH = 16 * (PANEL_THREADS / 64);   // rows per workgroup of
 constexpr int TRSM_ROWS = 128;        // up to this many rows below the diagonal block are solved by the diagonal-block kernel itself
 constexpr int MFMA_MIN_ROWS = 256;    // fronts with fewer rows below their first panel use the bit-faithful row substitution
 constexpr int CHK = 16;               // column chunk of the row substitution held in registers
+constexpr int64_t ASM_FULL_MAX = 4 << 20;   // arenas of up to this many entries are assembled with the zero fill folded in
 constexpr int FRONT_CNT = 2 * 16 + 16 * 16;   // counters per front of k_ldl_front: rows solved, update steps, updates per tile
 constexpr int FRONT_MAXT = 16;        // fronts of up to this many 64-row tile rows (and at least MFMA_MIN_ROWS + NB rows) are factored by ONE launch (k_ldl_front)
 constexpr int PANEL_RB = (LDL_THREADS / 64) * NB * 17;     // doubles: max(Lc 64x64, Xs 48 x TRSM_ROWS, 8 wave tiles 64x17)
@@ -144,6 +145,7 @@ struct CholPlan {
   DevBuf<double> fronts, frontsT, wvec, colbuf, d, dsolve, lb, pivval, ub;
   DevBuf<int> pivstat;
   DevBuf<int> diag_cnt;    // per front: panels whose factored diagonal block has been published (k_ldl_panel)
+  DevBuf<int> d_asm_fsrc;  // arena entry -> ADA value index (k_assemble_full), empty for arenas above ASM_FULL_MAX entries
   DevBuf<int> front_cnt;   // k_ldl_front: per front 2 x FRONT_MAXT counters (rows solved through panel / update steps finished, per tile row)
   std::vector<char> lev_persist;   // level factored by ONE k_ldl_front launch (all its fronts qualify)
   std::vector<int> lev_maxT;       // its grid: tile rows of the tallest front

@@ -172,6 +172,10 @@ struct FrontTab {
   const int64_t *foff, *xl, *woff, *roff, *toff;
   const int *childptr, *childlist, *lindx, *relidx;
   const int64_t *soff; const int *sld, *sboff;
+  // levels of ONE front (solve kernels): its descriptor rides along as kernel arguments, so the first data load of a
+  // launch does not wait for two dependent table loads (list[..] -> ns[s], soff[s], ...)
+  int one = 0, o_s = 0, o_ns = 0, o_ms = 0, o_ld = 0, o_first = 0, o_sld = 0, o_sboff = 0;
+  int64_t o_foff = 0, o_soff = 0, o_woff = 0, o_xl = 0;
 };
 
 // ----------------------------------------------------------------- ada plan

@@ -609,6 +609,7 @@ k_sfw_init(FrontTab tab, const int *list, double *wv, const double *src, const i
   }
 }
 
+#define FT(field) (tab.one ? tab.o_##field : tab.field[s])      // front descriptor: kernel argument (one-front level) or table
 // ---- slab products.  Every kernel below issues its matrix loads FIRST (registers), then fetches the vector it
 // multiplies with (written by the previous launch) into LDS, then multiplies: the two memory latencies overlap.
 // Forward: sum_c M(r, cbase + c) xs[c] for the SROWS rows rbase .. of one slab.  Work-item (p = tid & 7, g = tid >> 3)
@@ -650,27 +651,27 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
            double *zdiv, const double *dscale) {
   __shared__ double xs[SBW], red[(ST / 8) * SROWS], wsub[SBW];
   __shared__ double Sd[64 * TP];
-  const int s = list[blockIdx.y];
-  const int ns = tab.ns[s], first = tab.first[s];
+  const int s = tab.one ? tab.o_s : list[blockIdx.y];
+  const int ns = FT(ns), first = FT(first);
   const int r0 = SROWS * blockIdx.x;
   if (r0 >= ns) return;
   wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; if (src) src += (int64_t)blockIdx.z * bt.src;
   sb_cnt += (int64_t)blockIdx.z * bt.cnt;
   const int Pb = r0 / SBW, c0 = Pb * SBW, nb = min(SBW, ns - c0);
-  const int sb = tab.sboff[s] + Pb;
+  const int sb = FT(sboff) + Pb;
   const int tid = threadIdx.x;
   const int ncols = min(nb, r0 + SROWS - c0);                       // lower triangular: columns up to the slab's last row
   sdm_double2 v[NLD];
-  slab_issue(v, S + tab.soff[s], tab.sld[s], c0, ncols, r0, ns - 1);
+  slab_issue(v, S + FT(soff), FT(sld), c0, ncols, r0, ns - 1);
   const bool bad = sb_is_bad(sb_g, sb, thr);
-  const double *a = wv + tab.woff[s];
+  const double *a = wv + FT(woff);
   // the block's right-hand side: gathered through perm (leaves) or taken from the assembled vector
   for (int c = tid; c < nb; c += ST) xs[c] = gather ? src[perm[first + c0 + c]] : a[c0 + c];
   __syncthreads();
   if (bad) {
     if (tid < SROWS && r0 + tid < ns) y[first + r0 + tid] = xs[r0 - c0 + tid];
     // block 0 has nothing left of it: its right-hand side is complete here; later blocks are completed by step Pb-1
-    if (Pb == 0) bad_block_arrive<true>(F + tab.foff[s], tab.ld[s], c0, nb, y + first + c0, sb_cnt + sb, (nb + SROWS - 1) / SROWS, wsub, Sd,
+    if (Pb == 0) bad_block_arrive<true>(F + FT(foff), FT(ld), c0, nb, y + first + c0, sb_cnt + sb, (nb + SROWS - 1) / SROWS, wsub, Sd,
                                          zdiv ? zdiv + first + c0 : nullptr, zdiv ? dscale + first + c0 : nullptr,
                                          bt.fold_bw && ns <= SBW);
     return;
@@ -692,8 +693,8 @@ k_sfw_step(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
            const double *dscale) {
   __shared__ double xs[SBW], red[(ST / 8) * SROWS], wsub[SBW];
   __shared__ double Sd[64 * TP];
-  const int s = list[blockIdx.y];
-  const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s], ld = tab.ld[s];
+  const int s = tab.one ? tab.o_s : list[blockIdx.y];
+  const int ns = FT(ns), ms = FT(ms), first = FT(first), ld = FT(ld);
   const int c0 = Pb * SBW;
   if (c0 >= ns) return;
   wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; sb_cnt += (int64_t)blockIdx.z * bt.cnt;
@@ -704,15 +705,15 @@ k_sfw_step(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
   const int bx = blockIdx.x;
   if (bx >= slabsA + slabsB) return;
   const int tid = threadIdx.x;
-  const double *Fs = F + tab.foff[s];
+  const double *Fs = F + FT(foff);
   const bool regA = bx < slabsA;
   const int r0 = regA ? ra + SROWS * bx : ebase + SROWS * (bx - slabsA);
   sdm_double2 v[NLD];
   // the front's own rows come from S (issued before the growth flag of their block is known: S is valid memory
   // either way); the rows below the supernode from the factor itself
-  if (regA) slab_issue(v, S + tab.soff[s], tab.sld[s], c0, nb, r0, ns - 1);
+  if (regA) slab_issue(v, S + FT(soff), FT(sld), c0, nb, r0, ns - 1);
   else slab_issue(v, Fs, ld, c0, nb, r0, ms - 1);
-  const int Pr = r0 / SBW, sbr = tab.sboff[s] + Pr;
+  const int Pr = r0 / SBW, sbr = FT(sboff) + Pr;
   const bool bad = regA && sb_is_bad(sb_g, sbr, thr);
   for (int c = tid; c < nb; c += ST) xs[c] = y[first + c0 + c];
   __syncthreads();
@@ -732,7 +733,7 @@ k_sfw_step(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
                              bt.fold_bw && (Pr + 1) * SBW >= ns);
     }
   } else {
-    double *u = wv + tab.woff[s];
+    double *u = wv + FT(woff);
     const int r = r0 + tid;
     if (tid < SROWS && r >= ns && r < ms) u[r] = first_assign ? -sum : u[r] - sum;
   }
@@ -780,14 +781,14 @@ k_sbw_init(const double *__restrict__ F, FrontTab tab, const int *list, double *
            const unsigned long long *sb_g, int *sb_cnt, double thr) {
   __shared__ double xs[SBW], wsub[SBW];
   __shared__ double Sd[64 * TP];
-  const int s = list[blockIdx.y];
-  const int ns = tab.ns[s], ms = tab.ms[s], first = tab.first[s], ld = tab.ld[s];
+  const int s = tab.one ? tab.o_s : list[blockIdx.y];
+  const int ns = FT(ns), ms = FT(ms), first = FT(first), ld = FT(ld);
   const int c0 = SROWS * blockIdx.x;
   if (c0 >= ns) return;
   const int ncols = min(SROWS, ns - c0);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const double *Fs = F + tab.foff[s];
-  const int *rows = tab.lindx + tab.xl[s];
+  const double *Fs = F + FT(foff);
+  const int *rows = tab.lindx + FT(xl);
   double tot[4] = {0.0, 0.0, 0.0, 0.0};
   const int ebase = ns & ~1;
   if (ms > ns) {
@@ -818,9 +819,9 @@ k_sbw_init(const double *__restrict__ F, FrontTab tab, const int *list, double *
   }
   // the last super-block of a front has nothing above it in this sweep: if bad, it is solved once all its columns are set
   const int nsb = (ns + SBW - 1) / SBW, Pl = nsb - 1;
-  if (c0 / SBW == Pl && sb_is_bad(sb_g, tab.sboff[s] + Pl, thr)) {
+  if (c0 / SBW == Pl && sb_is_bad(sb_g, FT(sboff) + Pl, thr)) {
     const int nbl = ns - Pl * SBW;
-    bad_block_arrive<false>(Fs, ld, Pl * SBW, nbl, y + first + Pl * SBW, sb_cnt + tab.sboff[s] + Pl, (nbl + SROWS - 1) / SROWS, wsub, Sd);
+    bad_block_arrive<false>(Fs, ld, Pl * SBW, nbl, y + first + Pl * SBW, sb_cnt + FT(sboff) + Pl, (nbl + SROWS - 1) / SROWS, wsub, Sd);
   }
 }
 
@@ -830,17 +831,17 @@ k_sbw_step(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
            const unsigned long long *sb_g, int *sb_cnt, double thr, int Q) {
   __shared__ double xs[SBW], wsub[SBW];
   __shared__ double Sd[64 * TP];
-  const int s = list[blockIdx.y];
-  const int ns = tab.ns[s], first = tab.first[s], ld = tab.ld[s];
+  const int s = tab.one ? tab.o_s : list[blockIdx.y];
+  const int ns = FT(ns), first = FT(first), ld = FT(ld);
   const int rb = Q * SBW;
   if (rb >= ns) return;
   const int nbq = min(SBW, ns - rb);
   const int c0 = SROWS * blockIdx.x;                                // < rb by the grid
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const double *Fs = F + tab.foff[s];
+  const double *Fs = F + FT(foff);
   sdm_double2 v[8];
-  slabT_issue(v, S + tab.soff[s], tab.sld[s], c0, SROWS, rb, nbq);  // before the growth flag is known (S is valid memory either way)
-  const bool badq = sb_is_bad(sb_g, tab.sboff[s] + Q, thr);
+  slabT_issue(v, S + FT(soff), FT(sld), c0, SROWS, rb, nbq);  // before the growth flag is known (S is valid memory either way)
+  const bool badq = sb_is_bad(sb_g, FT(sboff) + Q, thr);
   for (int i = tid; i < nbq; i += ST) xs[i] = y[first + rb + i];
   __syncthreads();
   if (badq) slabT_issue(v, Fs, ld, c0, SROWS, rb, nbq);             // rare: the rows of a bad block were not premultiplied
@@ -851,8 +852,8 @@ k_sbw_step(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
     for (int q = 0; q < 4; q++) y[first + c0 + 4 * wave + q] -= part[q];
   }
   const int Pc = c0 / SBW;
-  if (Pc == Q - 1 && sb_is_bad(sb_g, tab.sboff[s] + Pc, thr))      // this step completes v of block Q-1
-    bad_block_arrive<false>(Fs, ld, Pc * SBW, SBW, y + first + Pc * SBW, sb_cnt + tab.sboff[s] + Pc, SBW / SROWS, wsub, Sd);
+  if (Pc == Q - 1 && sb_is_bad(sb_g, FT(sboff) + Pc, thr))      // this step completes v of block Q-1
+    bad_block_arrive<false>(Fs, ld, Pc * SBW, SBW, y + first + Pc * SBW, sb_cnt + FT(sboff) + Pc, SBW / SROWS, wsub, Sd);
 }
 
 // x_P = inv(L_PP)' v_P ; the result goes to xfin (descendants read it) and, scattered through perm, to yout
@@ -860,8 +861,8 @@ __global__ void __launch_bounds__(ST)
 k_sbw_diag(const double *__restrict__ S, FrontTab tab, const int *list, const double *y, double *xfin, double *yout, const int *perm,
            const unsigned long long *sb_g, double thr) {
   __shared__ double xs[SBW];
-  const int s = list[blockIdx.y];
-  const int ns = tab.ns[s], first = tab.first[s];
+  const int s = tab.one ? tab.o_s : list[blockIdx.y];
+  const int ns = FT(ns), first = FT(first);
   const int c0 = SROWS * blockIdx.x;
   if (c0 >= ns) return;
   const int Pb = c0 / SBW, rb = Pb * SBW, nb = min(SBW, ns - rb);
@@ -869,8 +870,8 @@ k_sbw_diag(const double *__restrict__ S, FrontTab tab, const int *list, const do
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nr = rb + nb - c0;                                       // rows c0 .. end of the block (upper part of S is zero)
   sdm_double2 v[8];
-  slabT_issue(v, S + tab.soff[s], tab.sld[s], c0, ncols, c0, nr);
-  const bool bad = sb_is_bad(sb_g, tab.sboff[s] + Pb, thr);
+  slabT_issue(v, S + FT(soff), FT(sld), c0, ncols, c0, nr);
+  const bool bad = sb_is_bad(sb_g, FT(sboff) + Pb, thr);
   for (int i = tid; i < nr; i += ST) xs[i] = y[first + c0 + i];
   __syncthreads();
   double part[4];
@@ -892,6 +893,16 @@ k_sbw_diag(const double *__restrict__ S, FrontTab tab, const int *list, const do
 // ================================================================ host drivers
 const double *solve_d(sdm_plan *P) { return P->dense.factored ? (const double *)P->chol.dsolve.p : (const double *)P->chol.d.p; }
 
+#undef FT
+// the level's table for the solve kernels: with the descriptor of its only front filled in when there is just one
+static FrontTab level_tab(const CholPlan &C, FrontTab t, int l) {
+  if (C.levptr[l + 1] - C.levptr[l] != 1) return t;
+  const int s = C.levlist[C.levptr[l]];
+  t.one = 1; t.o_s = s; t.o_ns = C.sn_ns[s]; t.o_ms = C.sn_ms[s]; t.o_ld = C.sn_ld[s]; t.o_first = C.sn_first[s];
+  t.o_sld = C.sn_sld[s]; t.o_sboff = C.sn_sboff[s]; t.o_foff = C.sn_foff[s]; t.o_soff = C.sn_soff[s]; t.o_woff = C.sn_woff[s];
+  t.o_xl = C.sn_xl[s];
+  return t;
+}
 void solve_prepare(sdm_plan *P, bool sb_g_is_zero) {
   CholPlan &C = P->chol;
   FrontTab tab = front_tab(C);
@@ -950,10 +961,12 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
   if ((size_t)C.nsbtot * (size_t)nrhs > C.sb_cnt.n) throw std::runtime_error("solve_fw_batch: ticket array too small for this many right-hand sides");
   FwBatch bt;
   bt.src = nrhs > 1 ? rhs_stride : 0; bt.y = nrhs > 1 ? y_stride : 0; bt.wv = nrhs > 1 ? C.wsize : 0; bt.cnt = nrhs > 1 ? C.nsbtot : 0;
+  const FrontTab tab0 = tab;
   for (int l = 0; l < C.nlevels; l++) {
     const SolveLevel &L = C.slev[l];
     bt.fold_bw = (zdiv && !L.below) ? 1 : 0;
     const int *list = C.d_levlist.p + C.levptr[l];
+    tab = level_tab(C, tab0, l);
     const int gather = L.children ? 0 : 1;
     if (!gather) SDM_KLAUNCH(P, k_sfw_init, dim3(L.nfronts, 1, nrhs), dim3(ST), 0, tab, list, wv, rhs, C.d_perm.p, y, bt);
     SDM_KLAUNCH(P, k_sfw_diag, dim3((L.maxns + SROWS - 1) / SROWS, L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, wv, rhs,
@@ -972,9 +985,11 @@ static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double 
   CholPlan &C = P->chol;
   FrontTab tab = front_tab(C);
   const double thr = C.growth_used;
+  const FrontTab tab0 = tab;
   for (int l = C.nlevels - 1; l >= 0; l--) {
     const SolveLevel &L = C.slev[l];
     const int *list = C.d_levlist.p + C.levptr[l];
+    tab = level_tab(C, tab0, l);
     const int ncs = (L.maxns + SROWS - 1) / SROWS;
     // (a bad last super-block of such a level was substituted backward by the forward sweep: FwBatch::fold_bw)
     if (!(skip_plain_init && !L.below))

@@ -675,7 +675,8 @@ template <bool PERSIST>
 __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT, const FrontTab &tab, int s, int panel, double *d, double *lb,
                                                const double *ubp, int *pivstat, double *pivval, double *colbuf, const double *ada,
                                                const int *asm_src, const int64_t *Ljc, int mtot, int *upd_cnt, int *diag_cnt, int q0, int *tmo,
-                                               bool load_block, bool publish, double *ds, int *npub) {
+                                               bool load_block, bool publish, double *ds, int *npub, bool raw_in_lds = false) {
+  // raw_in_lds (k_ldl_front): the raw block is not in the front but in LDS behind the wave tiles (front_rows_diag)
   SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
   double (*S)[NB + 1] = (double (*)[NB + 1])smem;                 // diagonal block, S[row][col]
   double *RB = (double *)smem + NB * (NB + 1);                    // Lc during the LDL', then Xs / the wave tiles of the row solve
@@ -853,7 +854,10 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
       if (PERSIST) front_wait_updates(upd_cnt, panel, (ms + TILE - 1) / TILE, tmo);
       else wait_prev_update(upd_cnt + s, ns, ms, panel, q0, tmo);
     }
-    for (int j = ty; j < NB; j += ny) { S[tx][j] = (tx < kb && j <= tx) ? Fs[(int64_t)(k0 + j) * ld + k0 + tx] : 0.0; Lc[j * NB + tx] = 0.0; }
+    for (int j = ty; j < NB; j += ny) {
+      const double raw = raw_in_lds ? ((const double *)smem)[FRONT_CV_OFF + j * TILE + tx] : Fs[(int64_t)(k0 + min(j, kb - 1)) * ld + k0 + min(tx, kb - 1)];
+      S[tx][j] = (tx < kb && j <= tx) ? raw : 0.0; Lc[j * NB + tx] = 0.0;
+    }
     if (tid < NB) { ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
     __syncthreads();
     for (int k = 0; k < kb; k++) {
@@ -1091,9 +1095,10 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
 #endif
 __device__ SDM_NOINLINE bool front_diag(char *smem, double *F, double *DT, const FrontTab &tab, int s, int panel, double *d, double *lb, const double *ubp,
                                         int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src, const int64_t *Ljc,
-                                        int mtot, int *upd_done, int *diag_cnt, int *tmo, bool load_block, bool publish, double *ds, int *npub) {
+                                        int mtot, int *upd_done, int *diag_cnt, int *tmo, bool load_block, bool publish, double *ds, int *npub,
+                                        bool raw_in_lds) {
   return ldl_diag_block<true>(smem, F, DT, tab, s, panel, d, lb, ubp, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, 0, tmo,
-                              load_block, publish, ds, npub);
+                              load_block, publish, ds, npub, raw_in_lds);
 }
 // kind 0: plain (result to the front only), 1: also the LDS arrays of the next LDL' (S, Lc = RB), 2: also the wave tiles of the next row solve (RB)
 __device__ SDM_NOINLINE void front_update(int kind, double *Fs, int ld, int ms, int first, int k0, int I, int J, const double *d, char *smem,
@@ -1135,8 +1140,6 @@ __device__ SDM_NOINLINE void front_rows(double *Fs, const double *Ds, const doub
 // the last update of workgroup r's own diagonal tile, r = q + 1, with everything taken from LDS: the operands are the rows
 // just solved (wave tiles, unscaled: l = x / d as rows_store writes it), the pivots are in dsr, the tile's current
 // values were fetched into cvl at the start of the step.  Result: S / Lc for the LDL' and the raw block in the front.
-constexpr int FRONT_CV_OFF = NB * (NB + 1) + (LDL_THREADS / 64) * NB * 17;          // doubles: behind S and the wave tiles
-constexpr size_t FRONT_LDS = (size_t)(FRONT_CV_OFF + NB * TILE) * sizeof(double);
 __device__ SDM_NOINLINE void front_diag_update_lds(double *Fs, int ld, int ms, int first, int k0, const double *d, char *smem, double *dsh,
                                                    const double *dsr, int rbeg, int kbn) {
   double (*As)[UTP] = (double (*)[UTP])smem;
@@ -1159,6 +1162,79 @@ __device__ SDM_NOINLINE void front_diag_update_lds(double *Fs, int ld, int ms, i
   }
   update_tile<NW, true, true>(Fs, ld, ms, first, k0, NB, 0, 0, d, As, Bs, dsh, (double (*)[NB + 1])smem, RB, kbn, tid, true, nullptr, true,
                               (const double *)smem + FRONT_CV_OFF);
+}
+
+// The two of them fused for the workgroup on the chain (r = q + 1): the rows are solved 16 columns at a time as before, but
+// every finished 16-column block is scaled (l = x / d, as rows_store does), stored write-through AND kept in LDS (Lt, the
+// wave tiles the four idle wavefronts do not use), and the update of the workgroup's own diagonal tile reads its operands
+// from there -- A operand l, B operand l * d, the products in the same k order as update_tile, so the same bits.  The
+// K = 48 part of the update runs while the last 16 columns of the diagonal block are still being factored; after they
+// arrive only their triangle, 4 of the 16 k-steps and the epilogue are left.  The raw updated block stays in LDS (cvl:
+// the general path of the LDL' reloads it from there); it reaches the front as the factored block.
+__device__ SDM_NOINLINE void front_rows_diag(double *Fs, const double *Ds, const double *d, int ld, int ms, int first, int q, int r, char *smem,
+                                             double *dsr, const int *diag_cnt_s, int *tmo, bool have_tw, int kbn) {
+  double (*S)[NB + 1] = (double (*)[NB + 1])smem;
+  double *RB = (double *)smem + NB * (NB + 1);
+  double *cvl = (double *)smem + FRONT_CV_OFF;
+  constexpr int NW = LDL_THREADS / 64;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int k0 = q * NB, rbeg = r * TILE, rend = min(ms, rbeg + TILE);
+  const int R0 = rbeg + 16 * ty;
+  const bool busy = R0 < rend && ty < 4;
+  double *Tw = RB + ty * (NB * 17);
+  double *Lt = RB + 4 * (NB * 17);                                    // Lt[w * NB*17 + c*17 + li] = l(row 16w + li, column c)
+  const int li = tx & 15, lk = tx >> 4;
+  const int wi = ty >> 2, wj = ty & 3;                                // update_tile's NW = 8 mapping: rows 32 wi + 16 a + li, columns 16 wj + ..
+  sdm_double4 acc[2];
+  for (int a = 0; a < 2; a++) for (int x = 0; x < 4; x++) acc[a][x] = 0.0;
+  if (!have_tw && busy) rows_stage(Fs, ld, rend, k0, NB, R0, Tw, tx);
+  for (int blk = 0; blk < NB / 16; blk++) {
+    if (busy) rows_block_gemm(blk, S, Tw, tx);
+    spin_until(diag_cnt_s, 4 * q + blk + 1, tmo, false);             // the block and its pivots come through sc1 loads
+    for (int e = tid; e < NB * 16; e += LDL_THREADS) {
+      const int i = e >> 4, j = 16 * blk + (e & 15);
+      S[i][j] = j < i ? sdm_load_wt(&Ds[i * NB + j]) : 0.0;
+    }
+    if (tid < 16) dsr[16 * blk + tid] = sdm_load_wt(&d[first + k0 + 16 * blk + tid]);
+    __syncthreads();
+    if (busy) {
+      rows_block_tri(blk, S, dsr, Tw, tx);
+      // l = x / d of the block's 16 columns: to the front (write-through) and to Lt (rows beyond the front: 0)
+#pragma unroll
+      for (int c4 = 0; c4 < 4; c4++) {
+        const int c = 16 * blk + 4 * c4 + lk, row = R0 + li;
+        const double dc = dsr[c], xv = Tw[c * 17 + li];
+        const double l = (row < rend && dc > 0.0) ? xv / dc : 0.0;
+        if (row < rend) sdm_store_wt(&Fs[(int64_t)(k0 + c) * ld + row], l);
+        Lt[ty * (NB * 17) + c * 17 + li] = l;
+      }
+    }
+    if (blk < 2) continue;
+    __syncthreads();                                                  // Lt of the columns up to 16 blk + 15 is complete
+    // k-steps of the update whose columns are final: 0 .. 11 after block 2, 12 .. 15 after block 3
+#pragma unroll 4
+    for (int kk = (blk == 2 ? 0 : 48); kk < (blk == 2 ? 48 : 64); kk += 4) {
+      const int k = kk + lk;
+      const double bv = Lt[wj * (NB * 17) + k * 17 + li] * dsr[k];
+#pragma unroll
+      for (int a = 0; a < 2; a++) acc[a] = SDM_MFMA_F64_16x16x4(bv, Lt[(2 * wi + a) * (NB * 17) + k * 17 + li], acc[a]);
+    }
+  }
+  __syncthreads();                                                    // S, the wave tiles and Lt are dead: S / Lc of the LDL' overlay them
+  double *Lc = RB;
+  for (int j = ty; j < NB; j += NW) { S[tx][j] = (tx == j && tx >= kbn) ? 1.0 : 0.0; Lc[j * NB + tx] = 0.0; }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+      const int ti = wi * 32 + a * 16 + li, tj = 16 * wj + lk + 4 * x;
+      if (rbeg + ti < ms && rbeg + tj < ms && ti >= tj) {
+        const double v = cvl[tj * TILE + ti] - acc[a][x];
+        cvl[tj * TILE + ti] = v;                                      // the raw updated block (general path of the LDL')
+        if (ti < kbn) S[ti][tj] = v;
+      }
+    }
 }
 
 // ---- the whole LDL' of a front in ONE launch (fronts of FRONT_MINMS <= m_s <= 64 FRONT_MAXT rows; chol_build decides per
@@ -1211,14 +1287,14 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
   const int r = blockIdx.x;
   if (r >= T) return;
   const bool carry = phase == 0;
-  bool have_S = false, have_tw = false;
+  bool have_S = false, have_tw = false, raw_in_lds = false;
   for (int q = carry ? 0 : step; q < (carry ? NP : step + 1) && q <= r; q++) {
     const int k0 = q * NB, kb = min(NB, ns - k0);
     if (q == r) {
       if (phase == 0 || phase == 1) {
         const int nrows = ms - (k0 + kb);
         front_diag(smem, F, DT, tab, s, q, d, lb, ubp, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, tmo,
-                   !have_S, nrows > 0, ds, &npub);
+                   !have_S, nrows > 0, ds, &npub, raw_in_lds);
         if (nrows > 0) {
           if (16 * npub < kb) SDM_STORES_DONE();
           __syncthreads();
@@ -1252,12 +1328,13 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
     }
     if (phase == 0 || phase == 2) {
       // ---- R: 16 rows per wavefront (4 of the 8 busy), following the diagonal block as workgroup q publishes it
-      front_rows(Fs, DT + tab.toff[s] + (int64_t)q * NB * NB, d, ld, ms, first, q, kb, r, smem, dsr, diag_cnt + s, tmo, have_tw, crit_lds);
+      if (crit_lds) front_rows_diag(Fs, DT + tab.toff[s] + (int64_t)q * NB * NB, d, ld, ms, first, q, r, smem, dsr, diag_cnt + s, tmo, have_tw,
+                                    min(NB, ns - (q + 1) * NB));
+      else front_rows(Fs, DT + tab.toff[s] + (int64_t)q * NB * NB, d, ld, ms, first, q, kb, r, smem, dsr, diag_cnt + s, tmo, have_tw, false);
       SDM_FPHASE(1);
       have_tw = false;
       if (crit_lds) {
-        front_diag_update_lds(Fs, ld, ms, first, k0, d, smem, dsh, dsr, rbeg, min(NB, ns - (q + 1) * NB));
-        have_S = true;
+        have_S = true; raw_in_lds = true;
         SDM_FPHASE(4);
         SDM_STORES_DONE();
         __syncthreads();

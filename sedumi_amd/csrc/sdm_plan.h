@@ -33,6 +33,8 @@ constexpr int FRONT_MAXT = 16;        // fronts of up to this many 64-row tile r
 constexpr int PANEL_RB = (LDL_THREADS / 64) * NB * 17;     // doubles: max(Lc 64x64, Xs 48 x TRSM_ROWS, 8 wave tiles 64x17)
 constexpr size_t PANEL_LDS = (size_t)(NB * (NB + 1) + PANEL_RB) * sizeof(double);
 constexpr size_t PANEL_LDS_RIDE = std::max(PANEL_LDS, (size_t)4 * NB * UTP * sizeof(double));   // two update tiles side by side
+constexpr int FRONT_CV_OFF = NB * (NB + 1) + (LDL_THREADS / 64) * NB * 17;          // k_ldl_front: doubles, behind S and the wave tiles: the next diagonal tile's values
+constexpr size_t FRONT_LDS = (size_t)(FRONT_CV_OFF + NB * TILE) * sizeof(double);
 static_assert(PANEL_RB >= NB * NB && PANEL_RB >= (NB - CHK) * TRSM_ROWS && TRSM_ROWS == 16 * (LDL_THREADS / 64) && ROWS_BATCH <= TRSM_ROWS, "panel LDS layout");
 
 template <class T>

@@ -71,7 +71,9 @@ def check_log(name, r, ref):
     assert abs(r["iter"] - ref["iter"]) <= 2, (r["iter"], ref["iter"])
     A, B = r["rows"], ref["rows"]
     upto = min(len(A), len(B)) - 2
-    strict = next((i for i in range(upto) if B[i]["kcg1"] > 1 or B[i]["kcg2"] > 1), upto)
+    # (the first row in which EITHER run needs a second CG step ends the strict zone: whether a residual of 4.9e-3 or 5.1e-3 times
+    # the tolerance comes out of the first step is decided in the last bits of the solves)
+    strict = next((i for i in range(upto) if max(B[i]["kcg1"], B[i]["kcg2"], A[i]["kcg1"], A[i]["kcg2"]) > 1), upto)
     worst = {}
     for i in range(upto):
         e = abs(A[i]["by_x0"] - B[i]["by_x0"]) / max(abs(B[i]["by_x0"]), 1e-300)

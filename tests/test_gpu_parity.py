@@ -563,3 +563,37 @@ def test_one_launch_front_is_deterministic_across_repeats(refmex):
     for _ in range(20):
         plan.blkchol(None, False); plan.ldlsolve()
         assert np.array_equal(plan.download("lpr"), l0) and np.array_equal(plan.download("d"), d0) and np.array_equal(plan.download("y"), y0)
+
+
+def test_one_launch_front_under_uneven_load(refmex):
+    """The hand-overs inside k_ldl_front with the device busy elsewhere: three other plans on their own streams keep factoring
+    (a second and third k_ldl_front of 16 tile rows = 121 workgroups each -- together with ours more than the device holds
+    at once -- and a MAXCUT-sized front on the launch-per-panel path streaming its trailing matrix), while control07's shape
+    is factored and solved 60 times: every result identical to the idle one, bit for bit."""
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+
+    def dense_plan(m, seed):
+        rng = np.random.default_rng(seed)
+        B = rng.standard_normal((m, m))
+        X = sp.csc_matrix(B @ B.T + m * np.eye(m)); X.sort_indices()
+        pl = Plan(0)
+        pl.set_chol(problem.dense_symbolic(m), X)
+        pl.upload("ada", X.data); pl.upload("rhs", rng.standard_normal(m))
+        return pl
+
+    main = dense_plan(666, 1)
+    main.blkchol(None, False); main.ldlsolve()
+    l0, d0, y0 = main.download("lpr"), main.download("d"), main.download("y")
+    others = [dense_plan(1000, 2), dense_plan(1024, 3), dense_plan(2000, 4)]
+    for pl in others:
+        pl.blkchol(None, False)
+    refs = [(pl.download("lpr"), pl.download("d")) for pl in others]
+    for rep in range(60):
+        for pl in others:                                  # asynchronous: queued on their streams
+            for _ in range(2):
+                pl.blkchol(None, False)
+        main.blkchol(None, False); main.ldlsolve()
+        assert np.array_equal(main.download("lpr"), l0) and np.array_equal(main.download("d"), d0) and np.array_equal(main.download("y"), y0), rep
+    for pl, (l, d) in zip(others, refs):
+        assert np.array_equal(pl.download("lpr"), l) and np.array_equal(pl.download("d"), d)

@@ -38,6 +38,65 @@ def vec(x):
     return np.asarray(x.todense() if sp.issparse(x) else x, dtype=np.float64).ravel()
 
 
+# ----------------------------------------------------------------------------------------------- pretransfo
+def pretransfo(At, b, c, K):
+    """pretransfo.m for LP / Lorentz / real PSD (oracle.glue.pretransfo_real) and, restated here, for Hermitian PSD blocks
+    (K.scomplex) with complex constraints (K.ycomplex): pretransfo.m:113-148 (field checks), :250-259 (complex
+    constraints become pairs of real ones), :310-320 (which blocks are Hermitian), :455-481 (Hermitian coefficients folded
+    into the lower triangle, [Re; Im] storage), :484-515 (K, the x0 row, At = real(QR At)).  No free variables, rotated
+    cones, K.xcomplex or diagonal-block detection for complex data (the example problem quantum.mat needs none)."""
+    sc = np.asarray(K.get("scomplex", []), dtype=np.int64).ravel()
+    yc = np.asarray(K.get("ycomplex", []), dtype=np.int64).ravel()
+    cplx = np.iscomplexobj(At.toarray() if sp.issparse(At) and At.dtype.kind == "c" else At) or np.iscomplexobj(c) or np.iscomplexobj(b)
+    if sc.size == 0 and yc.size == 0 and not cplx:
+        return gl.pretransfo_real(At, b, c, K)
+    Kl = int(np.asarray(K.get("l", 0)).ravel()[0]) if np.size(K.get("l", 0)) else 0
+    Kq = np.asarray(K.get("q", []), dtype=np.int64).ravel(); Kq = Kq[Kq > 0]
+    Ks = np.asarray(K.get("s", []), dtype=np.int64).ravel(); Ks = Ks[Ks > 0]
+    assert Kq.size == 0, "Lorentz cones together with complex data are not restated"
+    N = Kl + int((Ks ** 2).sum())
+    At = sp.csc_matrix(At, dtype=np.complex128)
+    if At.shape[0] != N and At.shape[1] == N:
+        At = sp.csc_matrix(At.conj().T)                                # pretransfo.m:173 (At')
+    assert At.shape[0] == N
+    b = np.asarray(b.todense() if sp.issparse(b) else b, dtype=np.complex128).ravel()
+    c = np.asarray(c.todense() if sp.issparse(c) else c, dtype=np.complex128).ravel()
+    yc = np.unique(yc)
+    if yc.size:                                                        # pretransfo.m:254-256
+        b = np.concatenate((b.real, b[yc - 1].imag))
+        At = sp.hstack((At, 1j * At[:, yc - 1])).tocsc()
+    else:
+        b = b.real
+    scplx = np.zeros(Ks.size, dtype=bool); scplx[np.unique(sc) - 1] = True
+    order = np.concatenate((np.nonzero(~scplx)[0], np.nonzero(scplx)[0]))   # real blocks first, then Hermitian (pretransfo.m:486)
+    jstrt_all = Kl + np.concatenate(([0], np.cumsum(Ks[:-1] ** 2)))
+    ii, jj, vv = [np.arange(Kl)], [np.arange(Kl)], [np.ones(Kl, dtype=np.complex128)]
+    off = Kl
+    for k in order:
+        n, j0 = int(Ks[k]), int(jstrt_all[k])
+        if not scplx[k]:                                               # pretransfo.m:434-452
+            idx = np.arange(n * n); cols = idx // n; rows = idx - n * cols
+            ii.append(off + np.maximum(rows, cols) + np.minimum(rows, cols) * n); jj.append(j0 + idx); vv.append(np.ones(n * n, dtype=np.complex128))
+            off += n * n
+        else:                                                          # pretransfo.m:455-481
+            bnd = np.arange(2 * n * n); cols = bnd // n; rows = bnd - n * cols
+            imgv = cols >= n
+            cols = cols - imgv * n
+            indxs = np.maximum(rows, cols) + np.minimum(rows, cols) * n + imgv * (n * n) + off
+            vals = 1 + imgv * (-1 + 1j * (1 - 2 * (rows > cols)))
+            keep = (~imgv) | (rows != cols)
+            ii.append(indxs[keep]); jj.append((rows + cols * n + j0)[keep]); vv.append(vals[keep].astype(np.complex128))
+            off += 2 * n * n
+    KN = off + 1                                                       # + the artificial (x0, z0) row in front
+    QR = sp.csc_matrix((np.concatenate(vv), (np.concatenate(ii) + 1, np.concatenate(jj))), shape=(KN, N))
+    At2 = sp.csc_matrix((QR @ At).real); At2.eliminate_zeros(); At2.sort_indices()
+    c2 = np.asarray(QR @ c).real.ravel()
+    from sedumi_amd import problem
+    Kint = problem.make_K(Kl + 1, [], Ks[~scplx], Ks[scplx])
+    assert int(Kint["N"]) == KN
+    return At2, b, c2, Kint
+
+
 # ----------------------------------------------------------------------------------------------- parameters
 def default_pars():
     """checkpars.m:43-193"""
@@ -239,7 +298,8 @@ class Cone:
         self.i1, self.i2, self.i3 = mb[0] - 1, mb[1] - 1, mb[2] - 1     # 0-based starts: Lorentz trace, norm-bound, PSD
         self.lq = int(K["lq"])
         self.N = int(K["N"])
-        self.lenud = int(np.sum(self.s ** 2))
+        self.nreal = int(np.asarray(K.get("rsdpN", self.s.size)).ravel()[0])
+        self.lenud = int(np.sum(self.s[:self.nreal] ** 2) + 2 * np.sum(self.s[self.nreal:] ** 2))
         self.qb = K["qblkstart"]
 
     # ---- Lorentz helpers (MEX: ddot.c, qblkmul.c)
@@ -305,12 +365,29 @@ class Cone:
             return y, t
         return y + np.concatenate((t * d["q1"], self.qblkmul(t, d["q2"])))
 
-    # ---- PSD helpers (psdscale.m, psdinvscale.m, psdfactor.m, psdeig.m, psdjmul.m, triumtriu.m, minpsdeig.m)
+    # ---- PSD helpers (psdscale.m, psdinvscale.m, psdfactor.m, psdeig.m, psdjmul.m, triumtriu.m, minpsdeig.m); Hermitian blocks
+    # (the last len(K.s) - K.rsdpN ones) are stored [Re; Im] and handled as complex matrices here, X' = conjugate transpose
     def _blocks(self, x):
         xi = x.size - self.lenud
-        for n in self.s:
-            yield x[xi:xi + n * n].reshape(n, n, order="F"), n
-            xi += n * n
+        for k, n in enumerate(self.s):
+            if k < self.nreal:
+                yield x[xi:xi + n * n].reshape(n, n, order="F"), n
+                xi += n * n
+            else:
+                yield (x[xi:xi + n * n] + 1j * x[xi + n * n:xi + 2 * n * n]).reshape(n, n, order="F"), n
+                xi += 2 * n * n
+
+    def _pack(self, mats, zero_imag_diag=False):
+        out = []
+        for k, M in enumerate(mats):
+            if k < self.nreal:
+                out.append(np.real(M).ravel(order="F"))
+            else:
+                Im = np.imag(M).copy()
+                if zero_imag_diag:
+                    np.fill_diagonal(Im, 0.0)
+                out.append(np.real(M).ravel(order="F")); out.append(Im.ravel(order="F"))
+        return np.concatenate(out) if out else np.zeros(0)
 
     def psdscale(self, ud, x, transp=False):
         if not self.s.size:
@@ -326,21 +403,21 @@ class Cone:
             if perm is not None and not transp:
                 PP = perm[pi_:pi_ + n].astype(int) - 1; pi_ += n
                 XX = XX[np.ix_(PP, PP)]
-            Y = TT.T @ XX @ TT
+            Y = TT.conj().T @ XX @ TT
             if perm is not None and transp:
                 PP = perm[pi_:pi_ + n].astype(int) - 1; pi_ += n
                 Z = np.zeros_like(Y); Z[np.ix_(PP, PP)] = Y; Y = Z
-            out.append(Y.ravel(order="F"))
-        return np.concatenate(out)
+            out.append(Y)
+        return self._pack(out, zero_imag_diag=True)
 
     def psdinvscale(self, ud, x):
         import scipy.linalg as sl
         out = []
         for (TT, n), (XX, _) in zip(self._blocks(ud), self._blocks(x)):
             TT = np.triu(TT)
-            W = sl.solve_triangular(TT, XX.T, lower=False).T            # XX / TT'
-            out.append(sl.solve_triangular(TT, W, lower=False).ravel(order="F"))
-        return np.concatenate(out) if out else np.zeros(0)
+            W = sl.solve_triangular(TT.conj(), XX.T, lower=False).T     # XX / TT'
+            out.append(sl.solve_triangular(TT, W, lower=False))
+        return self._pack(out, zero_imag_diag=True)
 
     def psdfactor(self, x):
         out = []
@@ -349,42 +426,41 @@ class Cone:
                 Lc = np.linalg.cholesky(XX)                            # chol(XX,'lower')
             except np.linalg.LinAlgError:                              # `return` with the remaining blocks of ux still zero
                 ux = np.zeros(self.lenud)
-                if out:
-                    done = np.concatenate(out)
-                    ux[:done.size] = done
+                done = self._pack(out)
+                ux[:done.size] = done
                 return ux, False
-            out.append((Lc + np.tril(Lc, -1).T).ravel(order="F"))
-        return (np.concatenate(out) if out else np.zeros(0)), True
+            out.append(Lc + np.tril(Lc, -1).conj().T)
+        return self._pack(out), True
 
     def psdeig(self, x, want_q=False):
         labs, qs = [], []
         for XX, n in self._blocks(x):
-            XX = XX + XX.T
+            XX = XX + XX.conj().T
             if want_q:
                 w, Q = np.linalg.eigh(XX)
-                qs.append(Q.ravel(order="F"))
+                qs.append(Q)
             else:
                 w = np.linalg.eigvalsh(XX)
             labs.append(0.5 * w)
         lab = np.concatenate(labs) if labs else np.zeros(0)
-        return (lab, np.concatenate(qs) if qs else np.zeros(0)) if want_q else lab
+        return (lab, self._pack(qs)) if want_q else lab
 
     def psdjmul(self, x, y):
         out = []
         for (XX, n), (YY, _) in zip(self._blocks(x), self._blocks(y)):
             ZZ = XX @ YY
-            out.append((0.5 * (ZZ + ZZ.T)).ravel(order="F"))
-        return np.concatenate(out) if out else np.zeros(0)
+            out.append(0.5 * (ZZ + ZZ.conj().T))
+        return self._pack(out)
 
     def triumtriu(self, x, y):
         out = []
         for (XX, n), (YY, _) in zip(self._blocks(x), self._blocks(y)):
             ZZ = np.triu(XX) @ np.triu(YY)
-            out.append((ZZ + np.triu(ZZ, 1).T).ravel(order="F"))
-        return np.concatenate(out) if out else np.zeros(0)
+            out.append(ZZ + np.triu(ZZ, 1).conj().T)
+        return self._pack(out)
 
     def minpsdeig(self, x):
-        return min(np.linalg.eigvalsh(XX + XX.T).min() for XX, n in self._blocks(x)) / 2
+        return min(np.linalg.eigvalsh(XX + XX.conj().T).min() for XX, n in self._blocks(x)) / 2
 
     def psdinvjmul(self, lab, frms, b):
         if not self.s.size:
@@ -399,9 +475,9 @@ class Cone:
         x[:self.l] = 1.0
         x[self.l:self.l + self.nq] = np.sqrt(2.0)
         xi = self.lq
-        for n in self.s:
+        for k, n in enumerate(self.s):
             x[xi:xi + n * n:n + 1] = 1.0
-            xi += n * n
+            xi += n * n * (1 if k < self.nreal else 2)
         return x
 
     def maxeigK(self, x):                                          # maxeigK.m (used by the Farkas test only)
@@ -410,7 +486,7 @@ class Cone:
             nrm = np.sqrt(np.maximum(self.ddot(x[self.i2:self.i3], x), 0.0))
             vals.append(((x[self.i1:self.i2] + nrm) / np.sqrt(2)).max())
         for XX, n in self._blocks(x):
-            vals.append(np.linalg.eigvalsh(XX + XX.T).max() / 2)
+            vals.append(np.linalg.eigvalsh(XX + XX.conj().T).max() / 2)
         return max(vals)
 
 
@@ -423,7 +499,7 @@ class Sedumi:
         self.ref = self.G.ref
         self.pars = pars or default_pars()
         if not internal:
-            At, b, c, K = gl.pretransfo_real(At, b, c, K)               # sedumi.m:261
+            At, b, c, K = pretransfo(At, b, c, K)                       # sedumi.m:261
         self.A, self.b, self.c, self.K = sp.csc_matrix(At), vec(b), vec(c), K
         self.S = self.G.setup(self.A, K, self.pars["denq"], self.pars["denf"])     # sedumi.m:356-392
         if len(self.S["dense"]["cols"]):
@@ -1017,4 +1093,4 @@ def load_example(name):
     import scipy.io as sio
     d = sio.loadmat(f"/root/reference/examples/{name}.mat")
     K = {k: d["K"][k][0, 0].astype(float).ravel() for k in d["K"].dtype.names}
-    return d["At"], d["b"], d["c"], K
+    return d["At"].astype(np.complex128) if np.iscomplexobj(d["c"]) else d["At"], d["b"], d["c"], K

@@ -4,8 +4,9 @@ oracle/_ref).  Runs ONLY in the build container (needs /root/reference for the e
 
 Stored per problem (driver_<name>.npz): b and the internal c (At and K are in <name>.npz already), the iteration
 count, STOP code, objective values, and the columns sedumi.m:511-512 prints, one row per iteration.  trto3 and
-OH_2Pi_STO-6GN9r12g1T2 (examples/test_sedumi.m:26-27; six minutes of reference hot path each) have no <name>.npz: their
-driver file also carries the internal At (3902 and 66180 nonzeros) and K.
+OH_2Pi_STO-6GN9r12g1T2 (examples/test_sedumi.m:26-27; six minutes of reference hot path each) and the complex quantum
+(test_sedumi.m:28: two Hermitian PSD blocks of order 5, complex constraints) have no <name>.npz: their driver file also
+carries the internal At (3902, 66180 and 341 nonzeros) and K.
 
     python tests/golden/make_driver_golden.py [names...]
 
@@ -39,7 +40,7 @@ def main():
         if not os.path.exists(os.path.join(HERE, f"{name}.npz")):
             A = S.A.tocsc(); A.sort_indices()
             extra = {"At_data": A.data, "At_indices": A.indices.astype(np.int32), "At_indptr": A.indptr.astype(np.int64), "At_shape": np.array(A.shape),
-                     "K_l": S.K["l"], "K_q": S.K["q"], "K_s": S.K["s"]}
+                     "K_l": S.K["l"], "K_q": S.K["q"], "K_s": S.K["s"], "K_rsdpN": S.K["rsdpN"]}
         np.savez_compressed(path, b=S.b, c=S.c, iter=r["iter"], STOP=r["STOP"], cx=r["cx"], by=r["by"], rows=rows, cols=np.array(COLS), **extra)
         print(name, "iter", r["iter"], "STOP", r["STOP"], "cx", r["cx"], "by", r["by"], "->", path, os.path.getsize(path) // 1024, "KiB")
 

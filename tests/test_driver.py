@@ -2,7 +2,8 @@
 repository's library (tests/driver/sedumi_loop.py), and the accuracy of the library on the scalings such a run produces.
 
   * reference hot path:  the restatement itself reproduces examples/test_sedumi.m:22-25's optimal values (tol 1e-6, as there);
-  * library, emulated (CPU: nb, arch0) and on the GPU (nb, arch0, control07), through the MEX-shaped calls and through the
+  * library, emulated (CPU: nb, arch0, quantum) and on the GPU (nb, arch0, control07, quantum; trto3 and OH_2Pi against a
+    committed log), through the MEX-shaped calls and through the
     resident plan: same optimal values, iteration count within two, and the iteration log of the reference-hot-path run
     ON THE SAME HOST followed row by row (check_log);
   * accuracy (tests/driver/accuracy.py): at chosen iterations of the reference run, ADA', the factor and the solves of both
@@ -20,7 +21,7 @@ from oracle import refmex
 pytestmark = pytest.mark.skipif(not refmex.available(), reason="oracle/_ref is not built")
 
 OPT = {"arch0": -5.665170e-01, "control07": -2.062510e+01, "nb": -5.070309e-02,       # examples/test_sedumi.m:22-27
-       "OH_2Pi": 7.946708e+01, "trto3": -1.279999e+04}
+       "OH_2Pi": 7.946708e+01, "trto3": -1.279999e+04, "quantum": -0.75395345}
 TOL_OBJ = 1e-6                                                                            # examples/test_sedumi.m:30
 
 
@@ -30,7 +31,9 @@ def problem(name):
         import scipy.sparse as sp
         from sedumi_amd import problem as pr
         At = sp.csc_matrix((g["At_data"], g["At_indices"], g["At_indptr"]), shape=tuple(g["At_shape"]))
-        return At, pr.make_K(int(g["K_l"]), g["K_q"].ravel(), g["K_s"].ravel()), g
+        nreal = int(g["K_rsdpN"]) if "K_rsdpN" in g else g["K_s"].size
+        ks = g["K_s"].ravel()
+        return At, pr.make_K(int(g["K_l"]), g["K_q"].ravel(), ks[:nreal], ks[nreal:]), g
     _, At, K = helpers.load_golden(name)
     return At, K, g
 
@@ -60,7 +63,7 @@ def check_objectives(name, r):
 # arch0 is the sensitive one: from iteration 10 on its PSD scaling is so ill-conditioned that ADA' -- the reference's as
 # much as ours, see the accuracy tests below -- is only good to 6e-11, and the run amplifies that by 1e2 per iteration
 # around iterations 9-12 (two runs of the REFERENCE hot path on hosts with different LAPACK kernels part ways there, too).
-TOL_LOG = {"nb": (1e-6, 1e-2), "control07": (1e-6, 1e-2), "arch0": (1e-3, 1e-1)}
+TOL_LOG = {"nb": (1e-6, 1e-2), "control07": (1e-6, 1e-2), "arch0": (1e-3, 1e-1), "quantum": (1e-6, 1e-2)}
 
 
 def check_log(name, r, ref):
@@ -93,7 +96,7 @@ def check_log(name, r, ref):
     assert abs(r["cx"] - ref["cx"]) / abs(ref["cx"]) < TOL_OBJ and abs(r["by"] - ref["by"]) / abs(ref["by"]) < TOL_OBJ
 
 
-@pytest.mark.parametrize("name", ["nb", "arch0"])
+@pytest.mark.parametrize("name", ["nb", "arch0", "quantum"])
 def test_loop_restatement_reproduces_the_reference_objectives(name):
     """... and, in the container the fixtures were made in, the committed log (elsewhere LAPACK may round differently)."""
     r = reference_run(name)
@@ -103,7 +106,7 @@ def test_loop_restatement_reproduces_the_reference_objectives(name):
     assert abs(r["cx"] - float(g["cx"])) / abs(float(g["cx"])) < TOL_OBJ and abs(r["by"] - float(g["by"])) / abs(float(g["by"])) < TOL_OBJ
 
 
-@pytest.mark.parametrize("name,tier", [("nb", "mex"), ("nb", "plan"), ("arch0", "plan")])
+@pytest.mark.parametrize("name,tier", [("nb", "mex"), ("nb", "plan"), ("arch0", "plan"), ("quantum", "mex"), ("quantum", "plan")])
 def test_loop_on_the_emulated_library_follows_the_reference_log(name, tier):
     from driver import sedumi_loop as sl
     helpers.use_emu()
@@ -114,7 +117,7 @@ def test_loop_on_the_emulated_library_follows_the_reference_log(name, tier):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tier", ["mex", "plan"])
-@pytest.mark.parametrize("name", ["nb", "arch0", "control07"])
+@pytest.mark.parametrize("name", ["nb", "arch0", "control07", "quantum"])
 def test_loop_on_the_gpu_follows_the_reference_log(name, tier):
     from driver import sedumi_loop as sl
     helpers.use_hip()

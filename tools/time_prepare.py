@@ -1,11 +1,9 @@
-"""tools/time_prepare.py [workload] -- time of the solve preparation (inverses of the diagonal super-blocks + premultiplication,
-sdm_solve.hip::solve_prepare) alone: sdm_plan_load_factor re-runs it on the resident factor (upload of L excluded by
-differencing against an upload-only timing is not attempted: the figure printed is the device time between two events
-around `reps` back-to-back blkchol calls minus the same with SDM_SPREP_OFF -- run the tool twice).  Prints ms per blkchol."""
+"""tools/time_prepare.py [workload] -- device time of back-to-back factorisations (sdm_plan_blkchol: assembly, pivot bounds, the
+LDL', the solve preparation) and the per-kernel times of everything in it but the LDL' launches.  SDM_SPREP_OFF=1 selects the
+four-launch solve preparation, SDM_FRONT_OFF=1 the launch-per-panel LDL'."""
 import os
 import sys
 
-import numpy as np
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)

@@ -137,6 +137,9 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
     }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
     A.t_order.upload(order); }
+  A.s1_maxnz = 0;
+  for (size_t t = 0; t < t_col.size(); t++)
+    A.s1_maxnz = std::max<int64_t>(A.s1_maxnz, (t + 1 < t_slotptr.size() ? s_nzptr[t_slotptr[t + 1]] : A.nnzA) - s_nzptr[t_slotptr[t]]);
   A.ntask = (sdm_int)t_col.size(); A.zlen = zlen;
   A.h_taskptr = c_taskptr; A.col0 = 0; A.col1 = m;
   { std::vector<int64_t> czl(m + 1, 0);                       // length of z_j (all tasks of constraint j)
@@ -427,7 +430,7 @@ struct Stage1Tab {
   const int64_t *psd_start;
 };
 __global__ void __launch_bounds__(256)
-k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0) {
+k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0, int nzcap) {
   SDM_DYN_SMEM(smem);
   double *Y = (double *)smem;                       // Y[slot][row], chunk of CC slots (Hermitian: Re then Im plane)
   const int task = blockIdx.x + task0;
@@ -446,11 +449,13 @@ k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0
   double *Yi = Y + (int64_t)CC * n;
   double *Dl = Y + (int64_t)(herm ? 2 : 1) * CC * n;
   double *Dli = Dl + (int64_t)CC * n;
-  __shared__ double nzx[S1_NZ];                     // the task's nonzeros: value, offset inside the block
-  __shared__ int nzr[S1_NZ];
+  // the task's nonzeros (value, offset inside the block) behind the Y / D-row area: nzcap of them, sized by the launch for
+  // its largest task (<= S1_NZ) -- as a static 18 KB array they cost every task of 23 nonzeros a workgroup slot per CU
+  double *nzx = Y + ldsY;
+  int *nzr = (int *)(nzx + nzcap);
   __shared__ int scol[256];
   const int64_t nzb = T.s_nzptr[slot0];
-  const bool staged = tend - nzb <= S1_NZ;
+  const bool staged = tend - nzb <= nzcap;
   if (staged)
     for (int64_t u = nzb + tid; u < tend; u += bs) { nzx[u - nzb] = T.Apr[u]; nzr[u - nzb] = (int)(T.Air[u] - rowbase); }
   for (int c0 = 0; c0 < nslot; c0 += CC) {
@@ -924,11 +929,14 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
       // LDS per task: at least one slot (Y and D row, x2 for Hermitian); beyond that S1_GEN_LDS -- several tasks per CU
       // hide each other's latencies better than one task with all its slots resident
       const size_t one = (size_t)(A.sdpN > A.rsdpN ? 4 : 2) * (size_t)A.maxn * sizeof(double);
-      const size_t lds = std::max(one, std::min(A.stage1_lds, (size_t)S1_GEN_LDS));
+      const char *le = getenv("SDM_S1_LDS");                           // tuning override (tools only)
+      const size_t ldsy = std::max(one, le ? (size_t)atol(le) : std::min(A.stage1_lds, (size_t)S1_GEN_LDS));
+      const int nzcap = (int)std::min<int64_t>(S1_NZ, (A.s1_maxnz + 1) & ~(int64_t)1);
+      const size_t lds = ldsy + (size_t)nzcap * (sizeof(double) + sizeof(int));
 #ifndef SDM_EMU
       SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
-      SDM_KLAUNCH(P, k_psd_stage1, dim3((unsigned)ntask), dim3(256), lds, T, A.udsqr.p, A.zbuf.p, (int)(lds / sizeof(double)), task0);
+      SDM_KLAUNCH(P, k_psd_stage1, dim3((unsigned)ntask), dim3(256), lds, T, A.udsqr.p, A.zbuf.p, (int)(ldsy / sizeof(double)), task0, nzcap);
     }
   }
   // the reference first adds the PSD part on one triangle and symmetrises at the very end; summing the

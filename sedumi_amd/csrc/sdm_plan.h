@@ -199,6 +199,7 @@ struct AdaPlan {
   DevBuf<int64_t> t_slotptr, t_udoff, t_uoff, t_zoff;
   DevBuf<int> s_col;                      // per slot: column of X_jk
   DevBuf<int64_t> s_nzptr;                // per slot (+1): nonzero range in At
+  int64_t s1_maxnz = 0;                   // nonzeros of the largest stage-1 task
   DevBuf<int> u_pos;                      // concatenated target lists U_k (position r + c*n_k [+ n_k^2 for Im])
   DevBuf<int64_t> c_taskptr;              // per constraint: its tasks
   DevBuf<double> zbuf, dsqr, symtmp;

@@ -43,6 +43,16 @@ def test_iteration_unit_block_diagonal_multi_supernode(glue):
     assert S["L"]["xsuper"].size - 1 > 1
 
 
+@pytest.mark.parametrize("kw", [dict(nblk=3, n=100, mper=10, nnz=12, seed=8), dict(nblk=2, n=130, mper=14, nnz=30, seed=9)])
+def test_iteration_unit_blocks_above_96(glue, kw):
+    """PSD blocks of order 100 and 130: the two-dot stage 1 of ADA' with the targets of a block regrouped for conflict-free
+    LDS gathers (the order of U_k is the library's own business), stage by stage against the reference."""
+    from sedumi_amd import problem
+    P = problem.blockdiag_sdp(**kw)
+    errs, S, _ = check_iteration(glue, P, seed=kw["seed"])
+    assert max(errs.values()) < TOL, errs
+
+
 @pytest.mark.parametrize("name", ["arch0", "nb"])
 def test_golden_small_examples(name):
     for tag in ("init", "rand"):

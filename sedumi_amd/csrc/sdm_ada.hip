@@ -259,7 +259,12 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
         for (sdm_int t = Qjc[j]; t < Qjc[j + 1]; t++) dst[(size_t)t] = (int64_t)j * lorN + Qir[t];
       A.q_dst.upload(dst);
       A.Q_d.alloc((size_t)lorN * (size_t)m);
-    } else { A.Q_d.release(); A.q_dst.release(); }
+      if (A.lq_dense && (double)lorN * (double)m <= 1.6e7) {          // inverse map for the fused form (ada_lq_q)
+        std::vector<int> src((size_t)lorN * (size_t)m, -1);
+        for (sdm_int t = 0; t < A.nnzQ; t++) src[(size_t)dst[(size_t)t]] = (int)t;
+        A.q_src.upload(src);
+      } else A.q_src.release();
+    } else { A.Q_d.release(); A.q_dst.release(); A.q_src.release(); }
     if (A.lq_dense || A.q_dense) {
       const int nt = (int)((m + TILE - 1) / TILE), T = nt * (nt + 1) / 2;
       const sdm_int rows = std::max(A.lq_dense ? A.nlq : 0, A.q_dense ? lorN : 0);
@@ -317,24 +322,29 @@ k_ada_spdot(double *ada, const int64_t *ADAjc, const int *ADAir, const int64_t *
 // split s on v_mfma_f64_16x16x4_f64 and writes it to part[s] (m x m, lower tiles); k_gram_scatter adds the splits in
 // fixed order and stores into the ADA' pattern (same masks / accumulate semantics as k_ada_spdot).
 __global__ void __launch_bounds__(256)
-k_gram_tile(const double *M, const double *wgt, int R, int m, int nsplit, double *part) {
+k_gram_tile(const double *M, const double *wgt, int R, int m, int nsplit, double *part, const double *M2 = nullptr, int R2 = 0) {
+  // M2 != null: G = M' diag(w) M + M2' M2 in the same launch (LP / Lorentz-det rows, then the rows of DAt.q: ada_lq_q)
   __shared__ double As[TILE][TILE], Bs[TILE][TILE];
   const int t = blockIdx.x, sp = blockIdx.y;
   int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while ((I + 1) * (I + 2) / 2 <= t) I++;
   while (I * (I + 1) / 2 > t) I--;
   const int J = t - I * (I + 1) / 2;
-  const int nch = (R + TILE - 1) / TILE;
+  const int nch1 = (R + TILE - 1) / TILE, nch = nch1 + (M2 ? (R2 + TILE - 1) / TILE : 0);
   const int c0 = (int)((int64_t)nch * sp / nsplit), c1 = (int)((int64_t)nch * (sp + 1) / nsplit);
+  const double *M1 = M; const int R1 = R;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
   const int wi = w >> 1, wj = w & 1, lk = l >> 4, ll = l & 15;
   sdm_double4 acc[2][2];
   for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) for (int r = 0; r < 4; r++) acc[a][b][r] = 0.0;
-  for (int ch = c0; ch < c1; ch++) {
+  for (int chg = c0; chg < c1; chg++) {
+    const bool second = chg >= nch1;                                 // (uniform) this chunk of 64 rows comes from M2
+    const int ch = second ? chg - nch1 : chg;
+    M = second ? M2 : M1; R = second ? R2 : R1;
     {
       const int tt = tid & 63, cq = tid >> 6, r = ch * TILE + tt;
       double av[TILE / 4], bv[TILE / 4];
-      const double wr = (wgt && r < R) ? wgt[r] : 1.0;
+      const double wr = (!second && wgt && r < R) ? wgt[r] : 1.0;
 #pragma unroll
       for (int q = 0; q < TILE / 4; q++) {
         const int ci = I * TILE + cq + 4 * q, cj = J * TILE + cq + 4 * q;
@@ -376,7 +386,8 @@ k_gram_tile(const double *M, const double *wgt, int R, int m, int nsplit, double
       }
 }
 __global__ void k_gram_scatter(double *ada, const int64_t *ADAjc, const int *ADAir, const double *part, int nsplit, int m,
-                               const int *invperm, int accumulate, int jbase) {
+                               const int *invperm, int accumulate, int jbase, double *absd = nullptr) {
+  // absd != null (no PSD part follows): absd(j) = ADA(j,j)  (getada.m:40)
   const int j = blockIdx.x + jbase;
   const int ipj = invperm ? invperm[j] : 0;
   for (int64_t e = ADAjc[j] + threadIdx.x; e < ADAjc[j + 1]; e += blockDim.x) {
@@ -387,7 +398,15 @@ __global__ void k_gram_scatter(double *ada, const int64_t *ADAjc, const int *ADA
     double v = 0.0;
     for (int s = 0; s < nsplit; s++) v += part[(int64_t)s * m * m + (int64_t)b * m + a];
     if (accumulate) ada[e] += v; else ada[e] = v;
+    if (absd && i == j) absd[j] = accumulate ? ada[e] : v;
   }
+}
+// dsqr (k_dsqr) and the dense copy of DAt.q (zero fill included, through the inverse map) in one launch
+__global__ void k_lq_q_prep(double *dsqr, const int *code, const double *dl, const double *ddet, int nlq, double *Qd, const double *qpr,
+                            const int *qsrc, int64_t nq) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nlq) { const int c = code[t]; dsqr[t] = c == -1 ? dl[t] : (c >= 0 ? ddet[c] : -ddet[-2 - c]); }
+  if (t < nq) { const int sidx = qsrc[t]; Qd[t] = sidx < 0 ? 0.0 : qpr[sidx]; }
 }
 __global__ void k_q_densify(double *Qd, const double *qpr, const int64_t *dst, int64_t nnz) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -892,7 +911,24 @@ void ada_q(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
   SDM_KLAUNCH(P, k_ada_spdot, dim3((unsigned)(A.col1 - A.col0)), dim3(256), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Qjc.p, A.d_Qjc.p + 1,
              A.d_Qir.p, A.qpr.p, (const double *)nullptr, d_invperm, accumulate ? 1 : 0, (int)A.col0);
 }
-void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
+// LP + Lorentz-det part and Lorentz rank-1 part of a FULL ADA' in three launches when both take the dense Gram form
+// (nb.mat's shape): prep (dsqr, dense DAt.q), one Gram launch over the rows of both operands, one scatter -- instead of
+// eight operations.  Returns false when the case does not apply (the caller then runs ada_lq + ada_q).
+bool ada_lq_q(sdm_plan *P, double *ada) {
+  AdaPlan &A = P->ada;
+  const int m = (int)A.m;
+  if (!(A.lq_dense && A.q_dense && A.q_src.n && A.col0 == 0 && A.col1 == A.m && A.lorN > 0 && A.nnzQ > 0)) return false;
+  const int64_t nq = (int64_t)A.lorN * m, nprep = std::max<int64_t>(nq, A.nlq);
+  const int nt = (m + TILE - 1) / TILE;
+  SDM_KLAUNCH(P, k_lq_q_prep, dim3((unsigned)((nprep + 255) / 256)), dim3(256), 0, A.dsqr.p, A.dsqr_code.p, A.dl.p, A.ddet.p, (int)A.nlq,
+              A.Q_d.p, A.qpr.p, A.q_src.p, nq);
+  SDM_KLAUNCH(P, k_gram_tile, dim3(nt * (nt + 1) / 2, A.gram_split), dim3(256), 0, A.Alq_d.p, A.dsqr.p, (int)A.nlq, m, A.gram_split,
+              A.gram_part.p, A.Q_d.p, (int)A.lorN);
+  SDM_KLAUNCH(P, k_gram_scatter, dim3((unsigned)m), dim3(128), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.gram_part.p, A.gram_split, m,
+              (const int *)nullptr, 0, 0, A.sdpN == 0 ? P->absd.p : (double *)nullptr);
+  return true;
+}
+void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, bool absd_done) {
   AdaPlan &A = P->ada;
   hipStream_t st = P->stream;
   const int m = (int)A.m;
@@ -901,7 +937,7 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input) {
       SDM_KLAUNCH(P, k_symmetrize, dim3(m), dim3(128), 0, A.symtmp.p, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_ADAT.p, m);
       SDM_HIP_CHECK(hipMemcpyAsync(ada, A.symtmp.p, A.symtmp.n * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
-    SDM_KLAUNCH(P, k_diag, dim3((m + 255) / 256), dim3(256), 0, P->absd.p, ada, A.d_ADAjc.p, A.d_ADAir.p, m);
+    if (!absd_done) SDM_KLAUNCH(P, k_diag, dim3((m + 255) / 256), dim3(256), 0, P->absd.p, ada, A.d_ADAjc.p, A.d_ADAir.p, m);
     return;
   }
   if (A.col1 <= A.col0) return;

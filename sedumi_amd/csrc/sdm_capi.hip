@@ -150,6 +150,7 @@ int sdm_plan_download(sdm_plan *p, const char *name, double *dst, sdm_int nelem)
 int sdm_plan_getada(sdm_plan *p) {
   SDM_TRY
   if (!p->has_ada) throw std::runtime_error("sdm_plan_getada: no ADA data set");
+  if (ada_lq_q(p, p->ada_val.p)) { ada_psd(p, p->ada_val.p, nullptr, false, true); return 0; }
   ada_lq(p, p->ada_val.p, nullptr, false);
   ada_q(p, p->ada_val.p, nullptr, true);
   ada_psd(p, p->ada_val.p, nullptr, false);

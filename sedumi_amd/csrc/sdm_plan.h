@@ -210,6 +210,7 @@ struct AdaPlan {
   int gram_split = 1;
   DevBuf<double> Alq_d, Q_d, gram_part;
   DevBuf<int64_t> q_dst;
+  DevBuf<int> q_src;                      // Q_d entry -> index into qpr, -1 = zero (k_lq_q_prep; fused LP + Lorentz Gram form)
   DevBuf<int64_t> t_end, d_psd_start;
   DevBuf<double> dl, ddet, qpr, udsqr;
   DevBuf<double> q1, q2;                  // d.q1 (per Lorentz cone), d.q2 (norm-bound parts): inputs of sdm_plan_getdatq
@@ -344,7 +345,8 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
 // are touched (the reference's triangular bookkeeping); symmetrize -> spmakesym afterwards.
 void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate);
 void ada_q(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate);
-void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input);
+void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, bool absd_done = false);
+bool ada_lq_q(sdm_plan *P, double *ada);   // ada_lq + ada_q of a full ADA' in three launches when both take the dense Gram form
 void ada_datq(sdm_plan *P);     // qpr = values of DAt.q (getDAtm.m:39-44) from the resident d.q1, d.q2
 // y(perm,perm) = u'u per PSD block (invcholfac.c); u, y device (lenud doubles), perm device int32 0-based or null
 void psd_invcholfac(hipStream_t st, const double *u, double *y, const int *perm, const std::vector<int> &ns, int rsdpN,

@@ -868,7 +868,6 @@ __global__ void k_diag(double *absd, const double *ada, const int64_t *ADAjc, co
 void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
   AdaPlan &A = P->ada;
   if (A.col1 <= A.col0) return;
-  hipStream_t st = P->stream;
   if (A.nnz_lq == 0 && !accumulate && !d_invperm) {
     // no LP / Lorentz nonzeros at all (e.g. MAXCUT): the LP part of ADA' is the zero matrix -- one memset of the
     // column panel instead of nnz(ADA') empty sparse dot products

@@ -180,11 +180,11 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
     const int wg_budget = std::min(224, ncu - ncu / 8);              // leave an eighth of the device to whatever else is running
     for (int l = 0; l < nlev; l++) {
       bool ok = !off;
-      int wgs = 0, maxT = 0;
+      int maxT = 0;
       for (int i = C.levptr[l]; i < C.levptr[l + 1] && ok; i++) {
         const int s = C.levlist[i], ns = C.sn_ns[s], ms = C.sn_ms[s], T = (ms + TILE - 1) / TILE;
         if (ms - std::min(NB, ns) < MFMA_MIN_ROWS || T > FRONT_MAXT || (ns % NB != 0 && ms != ns)) ok = false;
-        wgs += T; maxT = std::max(maxT, T);
+        maxT = std::max(maxT, T);
       }
       if (ok && (maxT + (maxT - 1) * (maxT - 2) / 2) * (C.levptr[l + 1] - C.levptr[l]) <= wg_budget) { C.lev_persist[l] = 1; C.lev_maxT[l] = maxT; }
     }
@@ -370,10 +370,7 @@ template <int NW, bool DIAG, bool WT = false, bool TW = false>
 __device__ __forceinline__ void update_tile(double *Fs, int ld, int ms, int first, int k0, int kb, int I, int J, const double *d,
                                             double (*As)[UTP], double (*Bs)[UTP], double *dsh,
                                             double (*S)[NB + 1] = nullptr, double *Lc = nullptr, int kbn = 0,
-                                            int tid = threadIdx.x, bool active = true, double *tw = nullptr,
-                                            bool staged = false, const double *lds_cv = nullptr) {
-  // staged: As / Bs hold the operands already (k_ldl_front builds them from the row solve's LDS tiles); lds_cv: the tile's
-  // current values were fetched into LDS before (lds_cv[col * TILE + row])
+                                            int tid = threadIdx.x, bool active = true, double *tw = nullptr) {
   // TW: the result also goes to LDS as the row solve's wave tiles (tw[(row/16)*NB*17 + col*17 + row%16], columns
   // beyond kbn zeroed) -- the workgroup that solves these rows next needs no second trip to HBM
   // tid: position inside the group of NW wavefronts that shares the tile (two groups of one workgroup may run two
@@ -381,7 +378,7 @@ __device__ __forceinline__ void update_tile(double *Fs, int ld, int ms, int firs
   constexpr int BJ = 8 / NW;                                  // 16-column MFMA tiles per wavefront along J
   const int r0 = k0 + kb;
   SDM_PHASE_BEGIN();
-  if (!staged && tid < NB) dsh[tid] = tid < kb ? d[first + k0 + tid] : 0.0;
+  if (tid < NB) dsh[tid] = tid < kb ? d[first + k0 + tid] : 0.0;
   const int w = tid >> 6, l = tid & 63;
   const int wi = NW == 4 ? w >> 1 : w >> 2, wj = NW == 4 ? w & 1 : w & 3;
   const int cj = wj * 16 * BJ;                                // first tile column of this wavefront
@@ -397,9 +394,9 @@ __device__ __forceinline__ void update_tile(double *Fs, int ld, int ms, int firs
         const int jj = lk + 4 * r;                 // result row  -> J dimension (front column)
         const int gi = r0 + I * TILE + wi * 32 + a * 16 + ll;
         const int gj = r0 + J * TILE + cj + b * 16 + jj;
-        cv[a][b][r] = lds_cv ? lds_cv[(cj + b * 16 + jj) * TILE + wi * 32 + a * 16 + ll] : Fs[(int64_t)min(gj, ms - 1) * ld + min(gi, ms - 1)];
+        cv[a][b][r] = Fs[(int64_t)min(gj, ms - 1) * ld + min(gi, ms - 1)];
       }
-  if (!staged) {
+  {
     // all loads of a work-item are issued before the first use (addresses clamped, masked afterwards): one
     // memory round trip per tile instead of one per element
     const int i = tid & 63, kq = tid >> 6;
@@ -688,7 +685,6 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
   __shared__ int red_i[LDL_THREADS];
   const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
   const int k0 = panel * NB, kb = min(NB, ns - k0);
-  const int r0 = k0 + kb, nrows = ms - r0;
   double *Fs = F + tab.foff[s];
   double *cb = colbuf + tab.woff[s] + s;                          // probe scratch: ms + 1 doubles per front
   const int tid = threadIdx.x, bs = blockDim.x;
@@ -1100,14 +1096,13 @@ __device__ SDM_NOINLINE bool front_diag(char *smem, double *F, double *DT, const
   return ldl_diag_block<true>(smem, F, DT, tab, s, panel, d, lb, ubp, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, 0, tmo,
                               load_block, publish, ds, npub, raw_in_lds);
 }
-// kind 0: plain (result to the front only), 1: also the LDS arrays of the next LDL' (S, Lc = RB), 2: also the wave tiles of the next row solve (RB)
+// kind 0: plain (result to the front only), 2: also the wave tiles of the next row solve (RB)
 __device__ SDM_NOINLINE void front_update(int kind, double *Fs, int ld, int ms, int first, int k0, int I, int J, const double *d, char *smem,
                                           double *dsh, int kbn) {
   double (*As)[UTP] = (double (*)[UTP])smem;
   double (*Bs)[UTP] = As + NB;
   double *RB = (double *)smem + NB * (NB + 1);
-  if (kind == 1) update_tile<LDL_THREADS / 64, true, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh, (double (*)[NB + 1])smem, RB, kbn);
-  else if (kind == 2) update_tile<LDL_THREADS / 64, false, true, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh, nullptr, nullptr, kbn, threadIdx.x, true, RB);
+  if (kind == 2) update_tile<LDL_THREADS / 64, false, true, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh, nullptr, nullptr, kbn, threadIdx.x, true, RB);
   else update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh);
 }
 // R: rows of tile row r against the diagonal block of panel q as it is published; have_tw: the tile is in the wave tiles already
@@ -1137,33 +1132,6 @@ __device__ SDM_NOINLINE void front_rows(double *Fs, const double *Ds, const doub
   SDM_STORES_DONE();
   __syncthreads();
 }
-// the last update of workgroup r's own diagonal tile, r = q + 1, with everything taken from LDS: the operands are the rows
-// just solved (wave tiles, unscaled: l = x / d as rows_store writes it), the pivots are in dsr, the tile's current
-// values were fetched into cvl at the start of the step.  Result: S / Lc for the LDL' and the raw block in the front.
-__device__ SDM_NOINLINE void front_diag_update_lds(double *Fs, int ld, int ms, int first, int k0, const double *d, char *smem, double *dsh,
-                                                   const double *dsr, int rbeg, int kbn) {
-  double (*As)[UTP] = (double (*)[UTP])smem;
-  double (*Bs)[UTP] = As + NB;
-  double *RB = (double *)smem + NB * (NB + 1);
-  const int tid = threadIdx.x, i = tid & 63, kq = tid >> 6;
-  constexpr int NW = LDL_THREADS / 64;
-  double xv[NB / NW];
-  __syncthreads();                                                   // the wave tiles of all four row wavefronts are final
-#pragma unroll
-  for (int j = 0; j < NB / NW; j++) xv[j] = RB[(i >> 4) * (NB * 17) + (kq + NW * j) * 17 + (i & 15)];
-  __syncthreads();                                                   // As / Bs overlay the wave tiles
-#pragma unroll
-  for (int j = 0; j < NB / NW; j++) {
-    const int k = kq + NW * j;
-    const double dk = dsr[k];
-    const double l = (rbeg + i < ms && dk > 0.0) ? xv[j] / dk : 0.0;
-    As[k][i] = l;
-    Bs[k][i] = l * dk;
-  }
-  update_tile<NW, true, true>(Fs, ld, ms, first, k0, NB, 0, 0, d, As, Bs, dsh, (double (*)[NB + 1])smem, RB, kbn, tid, true, nullptr, true,
-                              (const double *)smem + FRONT_CV_OFF);
-}
-
 // The two of them fused for the workgroup on the chain (r = q + 1): the rows are solved 16 columns at a time as before, but
 // every finished 16-column block is scaled (l = x / d, as rows_store does), stored write-through AND kept in LDS (Lt, the
 // wave tiles the four idle wavefronts do not use), and the update of the workgroup's own diagonal tile reads its operands
@@ -1212,7 +1180,6 @@ __device__ SDM_NOINLINE void front_rows_diag(double *Fs, const double *Ds, const
     if (blk < 2) continue;
     __syncthreads();                                                  // Lt of the columns up to 16 blk + 15 is complete
     // k-steps of the update whose columns are final: 0 .. 11 after block 2, 12 .. 15 after block 3
-#pragma unroll 4
     for (int kk = (blk == 2 ? 0 : 48); kk < (blk == 2 ? 48 : 64); kk += 4) {
       const int k = kk + lk;
       const double bv = Lt[wj * (NB * 17) + k * 17 + li] * dsr[k];
@@ -1303,7 +1270,7 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
       }
       break;
     }
-    const int rbeg = r * TILE, rend = min(ms, rbeg + TILE);
+    const int rbeg = r * TILE;
 #if defined(SDM_PHASES) && !defined(SDM_EMU)
     const bool crit = r == q + 1;
     long long fph_ = wall_clock64();
@@ -1356,8 +1323,7 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
         SDM_FPHASE(3);                                                // fence + counters
         const int I = r - c1, J = 0;
         const int kbn = min(NB, ns - c1 * NB);                        // columns of the next panel (<= 0: none)
-        if (r == c1 && carry && c1 < NP) { front_update(1, Fs, ld, ms, first, k0, I, J, d, smem, dsh, kbn); have_S = true; }
-        else if (c1 < r && carry && c1 < NP) { front_update(2, Fs, ld, ms, first, k0, I, J, d, smem, dsh, kbn); have_tw = true; }
+        if (c1 < r && carry && c1 < NP) { front_update(2, Fs, ld, ms, first, k0, I, J, d, smem, dsh, kbn); have_tw = true; }
         else front_update(0, Fs, ld, ms, first, k0, I, J, d, smem, dsh, kbn);
       }
       SDM_FPHASE(4);                                                  // the tile update

@@ -196,6 +196,8 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
       A.ell_ng = ng;
       A.g_row.upload(grow); A.g_len.upload(glen); A.g_off.upload(goff); A.g_val.upload(gval); A.g_bu.upload(gbu);
       { std::vector<int> pos((size_t)m); for (sdm_int p = 0; p < m; p++) pos[(size_t)order[p]] = (int)p; A.ell_pos.upload(pos); }
+      A.ell_order.upload(order);
+      A.ell_full = (ADAjc[m] == (sdm_int)m * m);                      // every column of the pattern full: (j, i) sits at ADAjc[i] + j
       A.d_uoff.upload(uoff);
       A.ell_ok = true;
     }
@@ -735,22 +737,36 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
                  const int64_t *Ajc_psd, const double *Apr, const int *Ablk, const int *Aupos,
                  const int64_t *c_taskptr, const int *t_blk, const int *t_ulen, const int64_t *t_zoff, const double *zbuf,
                  const int64_t *uoff, const int *g_row, const int *g_len, const int64_t *g_off, const double *g_val,
-                 const int *g_pos, int ngroups, const int *invperm, int zmax, int m, int jbase, int jend, const int *ell_pos) {
+                 const int *g_pos, int ngroups, const int *invperm, int zmax, int m, int jbase, int jend, const int *ell_pos, const int *ell_order) {
+  // ell_order != null (full ADA' on a full pattern): the workgroup's columns are order[jbase + ...] -- neighbours in the ELL row
+  // order -- and only the row groups from its columns' own group on are swept: an entry (i, j) with group(i) > group(j) is
+  // computed once, at column j, and added to (j, i) as well (the PSD part is symmetric: <a_i, z_j> = <a_j, z_i>); pairs inside
+  // one group are computed at both columns.  Half the sweep.
   SDM_DYN_SMEM(smem);
   double *zl = (double *)smem;                      // JB x z_j at full length (all blocks; zero where j has no nonzero)
   __shared__ double absred[JB][ELL_WAVES];
   __shared__ double part[JB][ELL_WAVES][64];
   const int j0 = jbase + blockIdx.x * JB;
+#define ELLCOL(x) (ell_order ? ell_order[min((x), jend - 1)] : (x))
   const int tid = threadIdx.x, bs = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
+  int gq[JB], gstart = 0;                                  // ELL group of each of the workgroup's columns
+  if (ell_order) {
+    gstart = ngroups;
+#pragma unroll
+    for (int q = 0; q < JB; q++) { gq[q] = ell_pos[ELLCOL(j0 + q)] >> 6; gstart = min(gstart, gq[q]); }
+  } else {
+#pragma unroll
+    for (int q = 0; q < JB; q++) gq[q] = 0;
+  }
   for (int k = tid; k < zmax * JB; k += bs) zl[k] = 0.0;
   __syncthreads();
   bool jhas[JB];
 #pragma unroll
   for (int q = 0; q < JB; q++) {
-    const int j = j0 + q;
+    const int j = ELLCOL(j0 + q);
     jhas[q] = false;
-    if (j < jend) {
+    if (j0 + q < jend) {
       const int64_t tb = c_taskptr[j], te = c_taskptr[j + 1];
       jhas[q] = te > tb;
       double *zq = zl + (size_t)q * zmax;
@@ -767,7 +783,7 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
 #pragma unroll
   for (int q = 0; q < JB; q++) {
     double aabs = 0.0;
-    const int j = j0 + q;
+    const int j = ELLCOL(j0 + q);
     if (jhas[q]) {
       const double *zq = zl + (size_t)q * zmax;
       for (int64_t t = Ajc_psd[j] + tid; t < Ajc[j + 1]; t += bs) aabs += fabs(Apr[t] * zq[uoff[Ablk[t]] + Aupos[t]]);
@@ -778,8 +794,8 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
   __syncthreads();
   // (the row groups are split over gridDim.y workgroups: the one that owns row j's group is the only writer of
   // entry (j,j) and reads its LP/Lorentz value here, before it adds to it)
-  if (tid < JB && j0 + tid < jend && (int)blockIdx.y == (ell_pos[j0 + tid] >> 6) % (int)gridDim.y) {
-    const int j = j0 + tid;
+  if (tid < JB && j0 + tid < jend && (int)blockIdx.y == ((ell_pos[ELLCOL(j0 + tid)] >> 6) - gstart) % (int)gridDim.y) {
+    const int j = ELLCOL(j0 + tid);
     double basev = 0.0;
     int64_t lo = ADAjc[j], hi = ADAjc[j + 1];
     const int64_t ce = hi;
@@ -794,7 +810,7 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
   // Every group of 64 rows is swept by ALL wavefronts: wave w takes the entries t = w, w+nw, ... of the 64 rows (one
   // row per lane), so the longest row costs len/nw dependent memory round trips instead of len; the nw partial
   // sums of a row meet in LDS and are added in wave order (deterministic).
-  for (int g = blockIdx.y; g < ngroups; g += gridDim.y) {
+  for (int g = gstart + blockIdx.y; g < ngroups; g += gridDim.y) {
     const int i = g_row[g * 64 + lane];
     const int len = g_len[g];
     const double *gv = g_val + g_off[g] * 64 + lane;
@@ -821,8 +837,8 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
 #pragma unroll
     for (int q = 0; q < JB; q++) part[q][wave][lane] = acc[q];
     __syncthreads();
-    if (wave < JB && i >= 0) {                            // wave q finishes column j0+q of this group
-      const int q = wave, j = j0 + q;
+    if (wave < JB && i >= 0 && j0 + wave < jend && g >= gq[wave]) {      // wave q finishes column q of this group
+      const int q = wave, j = ELLCOL(j0 + q);
       if (jhas[q] && !(invperm && invperm[i] > invperm[j])) {
         int64_t lo = ADAjc[j], hi = ADAjc[j + 1], e = -1;
         const int64_t ce = hi;
@@ -835,6 +851,7 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
           double a = 0.0;
           for (int w2 = 0; w2 < nw; w2++) a += part[q][w2][lane];
           ada[e] += a;
+          if (ell_order && g > gq[q]) ada[ADAjc[i] + j] += a;          // (j, i): not computed anywhere else (full columns)
         }
       }
     }
@@ -989,7 +1006,7 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
       SDM_KLAUNCH(P, k_psd_stage2_ell<JB>, dim3((ncols + JB - 1) / JB, gsplit), dim3(64 * ELL_WAVES), lds, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, \
                   A.d_Ajc.p, A.d_Ajc_psd.p, A.d_Apr.p, A.d_Ablk.p, A.d_Aupos.p, A.c_taskptr.p, A.t_blk.p, A.t_ulen.p,    \
                   A.t_zoff.p, A.zbuf.p, A.d_uoff.p, A.g_row.p, A.g_len.p, A.g_off.p, A.g_val.p, A.g_bu.p, A.ell_ng, d_invperm, \
-                  (int)A.zmax, m, jbase, jbase + ncols, A.ell_pos.p);                                                    \
+                  (int)A.zmax, m, jbase, jbase + ncols, A.ell_pos.p, sym ? (const int *)A.ell_order.p : (const int *)nullptr);   \
     } while (0)
 #ifndef SDM_EMU
 #define SDM_STAGE2_ATTR(JB, lds) if ((lds) > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage2_ell<JB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)))
@@ -1001,8 +1018,10 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
     // several workgroups (gridDim.y).  Measured on the bench workload with 3: 65 -> 62 us, but 2.3x the HBM traffic
     // (z_j staged once per workgroup) -- the sweep is bound by its LDS gathers and L2 re-reads, not by the chain of
     // groups inside one workgroup.  Off by default.
+    // symmetric half-sweep: the whole of a full-pattern ADA' is being formed and nothing restricts the entries touched
+    const bool sym = A.ell_full && !d_invperm && jbase == 0 && ncols == m && getenv("SDM_STAGE2_SYM_OFF") == nullptr;
     const char *gsenv = getenv("SDM_STAGE2_GS");                       // tuning override (tools only)
-    const int gsplit = gsenv ? std::max(1, atoi(gsenv)) : 1;
+    const int gsplit = gsenv ? std::max(1, atoi(gsenv)) : (sym ? 3 : 1);      // half-sweep: the long sweeps (early groups) split in three (measured 1: 52.7, 2: 41.6, 3: 38.9, 4: 41.2 us)
     const char *jbenv = getenv("SDM_STAGE2_JB");                       // tuning override (tools only)
     const int jbforce = jbenv ? atoi(jbenv) : 0;
     if (jbforce == 4 || (!jbforce && lds_of(4) <= 64 * 1024 && m >= 1024)) SDM_STAGE2_ELL(4);

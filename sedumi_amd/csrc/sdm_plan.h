@@ -233,6 +233,8 @@ struct AdaPlan {
   DevBuf<int64_t> c_zlen;
   DevBuf<int> g_row, g_len, g_bu;
   DevBuf<int> ell_pos;                     // constraint -> position in the ELL row order (its group = pos / 64)
+  DevBuf<int> ell_order;                   // position -> constraint
+  bool ell_full = false;                   // the ADA' pattern is full (symmetric half-sweep of stage 2 possible)
   DevBuf<int64_t> g_off, d_uoff;
   DevBuf<double> g_val;
 };

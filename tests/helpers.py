@@ -233,15 +233,26 @@ def check_one_launch_front(refmex, m):
     assert relerr(d1, r[1].ravel()) < TOL and relerr(l1, sp.csc_matrix(r[0]).data) < TOL
 
 
-def check_one_launch_levels(refmex, glue):
+def check_one_launch_levels(refmex, glue, two_leaves=False):
     """A leaf front of 64 columns with 800 rows below them (the update matrix for the parent) and the dense root of 928
-    columns: both levels take k_ldl_front, extend-add in between."""
+    columns: both levels take k_ldl_front, extend-add in between.  two_leaves: two leaf fronts of 64 columns (764 rows each)
+    in ONE k_ldl_front launch (grid.y = 2) under a root of 764 columns."""
     from oracle import glue as gl
     rng = np.random.default_rng(5)
-    X = bordered_blocks(64, 128, 800, rng)
+    if two_leaves:
+        sizes, nc = [64, 64, 64], 700
+        m = sum(sizes) + nc
+        X = np.zeros((m, m)); o = 0
+        for n in sizes:
+            X[o:o + n, o:o + n] = rng.standard_normal((n, n)); o += n
+        X[o:, :] = rng.standard_normal((nc, m))
+        X = 0.1 * (X + X.T) / np.sqrt(m)
+        X = sp.csc_matrix(X + np.diag(np.abs(X).sum(axis=1) + 1.0)); X.sort_indices()
+    else:
+        X = bordered_blocks(64, 128, 800, rng)
     L = glue.symbchol(X)
     xs = L["xsuper"].ravel().astype(int)
-    assert xs.size - 1 == 2 and xs[1] - xs[0] == 64
+    assert xs.size - 1 == (3 if two_leaves else 2) and xs[1] - xs[0] == 64
     (l1, d1, p1, y1, k1), (l2, d2, p2, y2, k2) = _factor_both_ways(X, L, rhs=rng.standard_normal(X.shape[0]))
     assert "k_ldl_front" in k1 and "k_ldl_panel" not in k1 and "k_ldl_front" not in k2
     assert np.array_equal(l1, l2) and np.array_equal(d1, d2) and np.array_equal(y1, y2)

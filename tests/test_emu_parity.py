@@ -357,8 +357,9 @@ def test_one_launch_front_matches_the_panel_launches_bit_for_bit(refmex, m):
     helpers.check_one_launch_front(refmex, m)
 
 
-def test_one_launch_front_levels_with_rows_below(refmex, glue):
-    helpers.check_one_launch_levels(refmex, glue)
+@pytest.mark.parametrize("two_leaves", [False, True])
+def test_one_launch_front_levels_with_rows_below(refmex, glue, two_leaves):
+    helpers.check_one_launch_levels(refmex, glue, two_leaves)
 
 
 @pytest.mark.parametrize("m,maxu", [(400, 5e5), (400, 30.0), (400, 2.0), (666, 30.0)])

@@ -547,7 +547,7 @@ k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0
 // n x n x nslot GEMM (Y = D X(:,cols) as above), accumulated over chunks of S1_KC slots; every wavefront owns a
 // fixed set of 16x16 tiles of Z in registers.  The targets are read off the finished Z in LDS:
 // z(r,c) = (Z[r][c] + Z[c][r]) / 2  -- the same two sums as spscale.c:283-304.
-__global__ void __launch_bounds__(64 * S1_WAVES)
+__global__ void __launch_bounds__(64 * S1_WAVES, 4)
 k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0, const int *order) {
   SDM_DYN_SMEM(smem);
   const int task = order ? order[blockIdx.x] : blockIdx.x + task0;      // heaviest tasks first (full-range launches)
@@ -621,7 +621,7 @@ k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0, con
       const int tile = wave + x * nw;
       if (tile < ntile) {                               // wave-uniform
         const int I = tile / nt, J = tile - I * nt;
-#pragma unroll
+#pragma unroll 4
         for (int q = 0; q < S1_KC / 4; q++) {
           const double a = Yl[(4 * q + lk) * np + I * 16 + li];
           const double b = Dl[(4 * q + lk) * np + J * 16 + li];

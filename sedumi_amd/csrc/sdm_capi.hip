@@ -60,6 +60,7 @@ void sdm_plan_destroy(sdm_plan *p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
   (void)hipStreamSynchronize(p->stream);
+  chol_forget_plan(p);
   for (auto g : p->graphs) (void)hipGraphExecDestroy(g);
   for (int i = 0; i < 16; i++) { if (p->ev_begin[i]) (void)hipEventDestroy(p->ev_begin[i]); if (p->ev_end[i]) (void)hipEventDestroy(p->ev_end[i]); }
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);

@@ -23,6 +23,7 @@
 #include "sdm_plan.h"
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <numeric>
 
 namespace sdm {
@@ -165,9 +166,13 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   C.lev_first_launch[nlev] = (int)C.launches.size();
   // levels whose fronts are all of the k_ldl_front kind: blocked row solves (MFMA_MIN_ROWS rule of panel_rows), at most
   // FRONT_MAXT tile rows, no partial last panel with rows below it, and few enough workgroups to be resident together
-  C.lev_persist.assign(nlev, 0); C.lev_maxT.assign(nlev, 0);
+  C.lev_persist.assign(nlev, 0); C.lev_maxT.assign(nlev, 0); C.lev_ntw.assign(nlev, 0);
+  std::vector<int> fslot(std::max<sdm_int>(1, C.nsuper), 0);
+  int nslot = 0;
   {
     const bool off = getenv("SDM_FRONT_OFF") != nullptr;              // comparison override (tools, tests): read at every set_chol
+    const char *mt = getenv("SDM_FRONT_MAXT");                        // (tools) fronts above this many tile rows keep the launch-per-panel path
+    const int maxT_allowed = mt ? std::min(FRONT_MAXT, atoi(mt)) : FRONT_MAXT;
     // k_ldl_front's workgroups wait for each other in both directions (a row workgroup for its tile workgroups and vice
     // versa): they must all be resident, one per compute unit (135 KB of LDS each).  A device -- or a partition of one --
     // with fewer compute units than the level needs keeps the launch-per-panel path.
@@ -177,19 +182,35 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
 #else
     SDM_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, P->device));
 #endif
-    const int wg_budget = std::min(224, ncu - ncu / 8);              // leave an eighth of the device to whatever else is running
+    const char *wb = getenv("SDM_FRONT_WGS");                         // (tools, tests) a smaller budget: tile workgroups own several tiles
+    const int wg_budget = std::min(wb ? atoi(wb) : 224, ncu - ncu / 8);   // leave an eighth of the device to whatever else is running
     for (int l = 0; l < nlev; l++) {
       bool ok = !off;
       int maxT = 0;
+      const int nfr = C.levptr[l + 1] - C.levptr[l];
       for (int i = C.levptr[l]; i < C.levptr[l + 1] && ok; i++) {
         const int s = C.levlist[i], ns = C.sn_ns[s], ms = C.sn_ms[s], T = (ms + TILE - 1) / TILE;
-        if (ms - std::min(NB, ns) < MFMA_MIN_ROWS || T > FRONT_MAXT || (ns % NB != 0 && ms != ns)) ok = false;
+        if (ms - std::min(NB, ns) < MFMA_MIN_ROWS || T > maxT_allowed || (ns % NB != 0 && ms != ns)) ok = false;
         maxT = std::max(maxT, T);
       }
-      if (ok && (maxT + (maxT - 1) * (maxT - 2) / 2) * (C.levptr[l + 1] - C.levptr[l]) <= wg_budget) { C.lev_persist[l] = 1; C.lev_maxT[l] = maxT; }
+      if (!ok || nfr == 0) continue;
+      // one row workgroup per tile row; the tiles (r, c), c >= 2, are dealt out to the tile workgroups the budget leaves.
+      // By default only levels that get a workgroup per tile qualify (single fronts of up to 21 tile rows on a whole
+      // device): a tile workgroup takes ~20 us per update (one 147 KB workgroup per compute unit, every update a serial
+      // load -> LDS -> MFMA -> write-through chain), so with several tiles each they fall far behind the chain --
+      // measured on MAXCUT-4000's front (63 tile rows, 161 tile workgroups for 1891 tiles): 5.56 ms against 2.26 ms for
+      // the 63 panel launches.  SDM_FRONT_POOL = tiles per workgroup allowed (tests: the dealt-out mapping stays covered).
+      const char *pe = getenv("SDM_FRONT_POOL");
+      const int pool = pe ? std::max(1, atoi(pe)) : FRONT_POOL;
+      const int ntiles = (maxT - 1) * (maxT - 2) / 2;
+      const int ntw = std::min(ntiles, wg_budget / nfr - maxT);
+      if (ntw < 0 || (int64_t)ntw * pool < ntiles) continue;
+      C.lev_persist[l] = 1; C.lev_maxT[l] = maxT; C.lev_ntw[l] = ntw;
+      for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) fslot[C.levlist[i]] = nslot++;
     }
   }
-  C.front_cnt.alloc((size_t)std::max<sdm_int>(1, C.nsuper) * FRONT_CNT);
+  C.front_cnt.alloc((size_t)std::max(1, nslot) * FRONT_CNT);
+  C.d_fslot.upload(fslot);
   // upload
   C.d_first.upload(C.sn_first); C.d_ns.upload(C.sn_ns); C.d_ms.upload(C.sn_ms); C.d_ld.upload(C.sn_ld); C.d_parent.upload(C.sn_parent);
   C.d_childptr.upload(C.childptr); C.d_childlist.upload(C.childlist); C.d_levlist.upload(C.levlist);
@@ -1211,9 +1232,10 @@ __device__ SDM_NOINLINE void front_rows_diag(double *Fs, const double *Ds, const
 //            U: the LAST update of the tile in the next panel's column, (r, q+1) -= L(r, q) D_q L(q+1, q)': it stays in LDS
 //               as the next R's input, or -- r = q+1 -- goes straight into the LDS arrays of the LDL';
 //   q == r   D: LDL' of the diagonal block (ldl_diag_block), then the workgroup is done.
-// One TILE workgroup per tile (r, c), 2 <= c <= r, applies that tile's other updates q = 0 .. c-2 as soon as row_cnt says
-// L(r, q) and L(c, q) are there, and counts them in tile_cnt (the row workgroup waits for it before the tile's last update):
-// a row workgroup never has more than one tile update between two row solves.
+// The TILE workgroups apply the other updates q = 0 .. c-2 of the tiles (r, c), 2 <= c <= r, as soon as row_cnt says L(r, q)
+// and L(c, q) are there, and count them in tile_cnt (the row workgroup waits for it before the tile's last update): a row
+// workgroup never has more than one tile update between two row solves.  One workgroup per tile by default (chol_build's
+// FRONT_POOL rule); with fewer, workgroup w owns the tiles w, w + ntw, ... and goes through them panel by panel.
 // The chain per panel is D -> (hand-over) -> last block of R in workgroup q+1 -> its diagonal tile -> D: no launch
 // boundary, no wait for the slowest row workgroup.  Arithmetic and its order per entry are those of the launch-per-panel
 // path (same device functions), so both produce the same bits.  upd_done[r] counts the U steps finished (the rare column
@@ -1229,25 +1251,32 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
   const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
   const int T = (ms + TILE - 1) / TILE, NP = (ns + NB - 1) / NB;
   double *Fs = F + tab.foff[s];
-  int *row_cnt = front_cnt + (int64_t)s * FRONT_CNT, *upd_done = row_cnt + FRONT_MAXT, *tile_cnt = upd_done + FRONT_MAXT;
+  int *row_cnt = front_cnt + (int64_t)tab.fslot[s] * FRONT_CNT, *upd_done = row_cnt + FRONT_MAXT, *tile_cnt = upd_done + FRONT_MAXT;
   __shared__ double dsh[NB], ds[NB], dsr[NB];
   __shared__ int npub;
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= tile_wg0) {
-    // ---- tile workgroup: owner of tile (rt, ct), 2 <= ct <= rt, for the updates of the panels q <= ct - 2 (the last
-    // update of a tile, q = ct - 1, belongs to the row workgroup: its result is the next R's / D's input)
+    // ---- tile workgroup: owner of the tiles t = w, w + ntw, ... (tiles (rt, ct), 2 <= ct <= rt, counted column by column)
+    // for the updates of the panels q <= ct - 2 (the last update of a tile, q = ct - 1, belongs to the row workgroup: its
+    // result is the next R's / D's input).  Panel by panel, and within a panel its tiles left to right: the tiles the
+    // chain needs next (column q + 2) come first.  Everything it waits for (the rows of panel q) depends on tile updates
+    // of EARLIER panels only, which this loop has finished by then.
     if (phase != 0 && phase != 3) return;
-    int I, J;
-    tile_index((int)blockIdx.x - tile_wg0, I, J);
-    const int rt = I + 2, ct = J + 2;
-    if (rt >= T) return;
-    for (int q = (phase == 0 ? 0 : step); q < (phase == 0 ? NP : step + 1) && q <= ct - 2; q++) {
-      spin_until(row_cnt + rt, q + 1, tmo);
-      if (ct < rt) spin_until(row_cnt + ct, q + 1, tmo);
-      front_update(0, Fs, ld, ms, first, q * NB, rt - (q + 1), ct - (q + 1), d, smem, dsh, 0);
-      SDM_STORES_DONE();
-      __syncthreads();
-      if (tid == 0) sdm_signal_add(&tile_cnt[rt * FRONT_MAXT + ct]);
+    const int w = (int)blockIdx.x - tile_wg0, ntw = (int)gridDim.x - tile_wg0;
+    if (w >= (T - 1) * (T - 2) / 2) return;
+    for (int q = (phase == 0 ? 0 : step); q < (phase == 0 ? NP : step + 1) && q <= T - 3; q++) {
+      int ct = 2, c0 = 0;                                              // c0 = index of tile (ct, ct)
+      for (int t = w; t < (T - 1) * (T - 2) / 2; t += ntw) {
+        while (t >= c0 + (T - ct)) { c0 += T - ct; ct++; }
+        const int rt = ct + (t - c0);
+        if (q > ct - 2) continue;
+        spin_until(row_cnt + rt, q + 1, tmo);
+        if (ct < rt) spin_until(row_cnt + ct, q + 1, tmo);
+        front_update(0, Fs, ld, ms, first, q * NB, rt - (q + 1), ct - (q + 1), d, smem, dsh, 0);
+        SDM_STORES_DONE();
+        __syncthreads();
+        if (tid == 0) sdm_signal_add(&tile_cnt[rt * FRONT_MAXT + ct]);
+      }
     }
     return;
   }
@@ -1371,11 +1400,49 @@ __global__ void k_divd(double *v, const double *d, int m) {
 }
 
 // ============================================================ host drivers
+// Two k_ldl_front launches of different plans (streams) must not share the device: each needs ALL its workgroups resident
+// and waits inside, so two half-dispatched ones could hold the compute units the other is waiting for.  Launches of one
+// process take turns per device: a plan that follows ANOTHER plan's launch first waits (on the device: an event recorded
+// on that plan's stream, hipStreamWaitEvent on its own) -- a plan that has the device to itself pays a mutex and nothing
+// else.  Kernels whose workgroups only wait for workgroups dispatched before them (k_ldl_panel, k_sprep) need no turn.
+// Not inside a graph capture (an event of another stream cannot be captured): replayed graphs of several plans that
+// contain k_ldl_front launches must be ordered by the caller.
+struct PersistTurn {
+#ifdef SDM_EMU
+  explicit PersistTurn(sdm_plan *) {}
+  static void forget(sdm_plan *) {}
+#else
+  static constexpr int MAXDEV = 64;
+  static std::mutex &mtx() { static std::mutex m; return m; }
+  static hipEvent_t *events() { static hipEvent_t ev[MAXDEV] = {}; return ev; }
+  static sdm_plan **owners() { static sdm_plan *pl[MAXDEV] = {}; return pl; }
+  sdm_plan *P;
+  bool on;
+  std::unique_lock<std::mutex> lk;
+  explicit PersistTurn(sdm_plan *p) : P(p), on(!p->capturing && p->device >= 0 && p->device < MAXDEV) {
+    if (!on) return;
+    lk = std::unique_lock<std::mutex>(mtx());
+    sdm_plan *prev = owners()[P->device];
+    if (prev && prev != P && !prev->capturing) {
+      hipEvent_t &ev = events()[P->device];
+      if (!ev) SDM_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      SDM_HIP_CHECK(hipEventRecord(ev, prev->stream));
+      SDM_HIP_CHECK(hipStreamWaitEvent(P->stream, ev, 0));
+    }
+  }
+  ~PersistTurn() { if (on) owners()[P->device] = P; }
+  static void forget(sdm_plan *p) {                                    // the plan is going away: nobody waits for its stream any more
+    std::lock_guard<std::mutex> g(mtx());
+    for (int dv = 0; dv < MAXDEV; dv++) if (owners()[dv] == p) owners()[dv] = nullptr;
+  }
+#endif
+};
+void chol_forget_plan(sdm_plan *P) { PersistTurn::forget(P); }
 FrontTab front_tab(CholPlan &C) {
   FrontTab t;
   t.soff = C.d_soff.p; t.sld = C.d_sld.p; t.sboff = C.d_sboff.p;
   t.first = C.d_first.p; t.ns = C.d_ns.p; t.ms = C.d_ms.p; t.ld = C.d_ld.p;
-  t.foff = C.d_foff.p; t.xl = C.d_xl.p; t.woff = C.d_woff.p; t.roff = C.d_roff.p; t.toff = C.d_toff.p;
+  t.foff = C.d_foff.p; t.xl = C.d_xl.p; t.woff = C.d_woff.p; t.roff = C.d_roff.p; t.toff = C.d_toff.p; t.fslot = C.d_fslot.p;
   t.childptr = C.d_childptr.p; t.childlist = C.d_childlist.p; t.lindx = C.d_lindx.p; t.relidx = C.d_relidx.p;
   return t;
 }
@@ -1409,6 +1476,7 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
     const int nfr = C.levptr[l + 1] - C.levptr[l];
     if (l > 0) SDM_KLAUNCH(P, k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, C.fronts.p, tab, list);
     if (C.lev_persist[l]) {                                          // the whole level in one launch (k_ldl_front)
+      PersistTurn turn(P);
 #ifdef SDM_EMU
       int maxnp = 0;
       for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) maxnp = std::max(maxnp, (C.sn_ns[C.levlist[i]] + NB - 1) / NB);
@@ -1417,7 +1485,7 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
 #else
       const int phase = 0, step = 0;
 #endif
-          SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + (C.lev_maxT[l] - 1) * (C.lev_maxT[l] - 2) / 2, nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
+          SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
                       C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p,
                       C.diag_cnt.p, phase, step, C.lev_maxT[l], C.tmo.dev());
       continue;

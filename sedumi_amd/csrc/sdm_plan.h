@@ -28,8 +28,9 @@ constexpr int TRSM_ROWS = 128;        // up to this many rows below the diagonal
 constexpr int MFMA_MIN_ROWS = 256;    // fronts with fewer rows below their first panel use the bit-faithful row substitution
 constexpr int CHK = 16;               // column chunk of the row substitution held in registers
 constexpr int64_t ASM_FULL_MAX = 4 << 20;   // arenas of up to this many entries are assembled with the zero fill folded in
-constexpr int FRONT_CNT = 2 * 16 + 16 * 16;   // counters per front of k_ldl_front: rows solved, update steps, updates per tile
-constexpr int FRONT_MAXT = 16;        // fronts of up to this many 64-row tile rows (and at least MFMA_MIN_ROWS + NB rows) are factored by ONE launch (k_ldl_front)
+constexpr int FRONT_MAXT = 64;        // fronts of up to this many 64-row tile rows (and at least MFMA_MIN_ROWS + NB rows) are factored by ONE launch (k_ldl_front)
+constexpr int FRONT_CNT = 2 * FRONT_MAXT + FRONT_MAXT * FRONT_MAXT;   // counters per front of k_ldl_front: rows solved, update steps, updates per tile
+constexpr int FRONT_POOL = 1;         // tiles per tile workgroup of k_ldl_front (levels that would need more keep the launch-per-panel path; SDM_FRONT_POOL overrides)
 constexpr int PANEL_RB = (LDL_THREADS / 64) * NB * 17;     // doubles: max(Lc 64x64, Xs 48 x TRSM_ROWS, 8 wave tiles 64x17)
 constexpr size_t PANEL_LDS = (size_t)(NB * (NB + 1) + PANEL_RB) * sizeof(double);
 constexpr size_t PANEL_LDS_RIDE = std::max(PANEL_LDS, (size_t)4 * NB * UTP * sizeof(double));   // two update tiles side by side
@@ -148,9 +149,12 @@ struct CholPlan {
   DevBuf<int> pivstat;
   DevBuf<int> diag_cnt;    // per front: panels whose factored diagonal block has been published (k_ldl_panel)
   DevBuf<int> d_asm_fsrc;  // arena entry -> ADA value index (k_assemble_full), empty for arenas above ASM_FULL_MAX entries
-  DevBuf<int> front_cnt;   // k_ldl_front: per front 2 x FRONT_MAXT counters (rows solved through panel / update steps finished, per tile row)
+  DevBuf<int> front_cnt;   // k_ldl_front: FRONT_CNT counters per front of a one-launch level (slot d_fslot[s]): rows solved through
+                           // panel / update steps finished per tile row, updates applied per tile
+  DevBuf<int> d_fslot;     // front -> its slot in front_cnt (fronts of other levels: 0, unused)
   std::vector<char> lev_persist;   // level factored by ONE k_ldl_front launch (all its fronts qualify)
-  std::vector<int> lev_maxT;       // its grid: tile rows of the tallest front
+  std::vector<int> lev_maxT;       // its grid: tile rows of the tallest front ...
+  std::vector<int> lev_ntw;        // ... plus this many tile workgroups per front
   DevBuf<int> upd_cnt;     // per front: finished tile workgroups of the updates that rode along with k_ldl_panel
   HostFlag tmo;            // raised by a spin inside a panel launch of THIS plan that gave up (chol_wait_timeouts)
   // ---- solves (sdm_solve.hip): per front the ns x ns "S" array = explicit inverses of the SBW-wide diagonal
@@ -174,6 +178,7 @@ struct FrontTab {
   const int64_t *foff, *xl, *woff, *roff, *toff;
   const int *childptr, *childlist, *lindx, *relidx;
   const int64_t *soff; const int *sld, *sboff;
+  const int *fslot = nullptr;   // k_ldl_front: the front's counter slot
   // levels of ONE front (solve kernels): its descriptor rides along as kernel arguments, so the first data load of a
   // launch does not wait for two dependent table loads (list[..] -> ns[s], soff[s], ...)
   int one = 0, o_s = 0, o_ns = 0, o_ms = 0, o_ld = 0, o_first = 0, o_sld = 0, o_sboff = 0;
@@ -308,6 +313,7 @@ void set_error(const std::string &msg);
 void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm,
                 sdm_int nsuper, const sdm_int *xsuper, const sdm_int *ADAjc, const sdm_int *ADAir);
 void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd);
+void chol_forget_plan(sdm_plan *P);    // the plan is being destroyed (turn-taking of k_ldl_front launches)
 int chol_wait_timeouts(sdm_plan *P);   // non-zero: a spin inside a panel launch of this plan gave up since the last call (call after a stream sync)
 void chol_extract(sdm_plan *P, double *d_Lpr_out);           // device pointer, nnzL doubles
 void chol_load_factor(sdm_plan *P, const double *h_Lpr, const double *h_d = nullptr);   // host L values (and d) -> fronts (stand-alone solves)

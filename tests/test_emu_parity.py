@@ -362,6 +362,18 @@ def test_one_launch_front_levels_with_rows_below(refmex, glue, two_leaves):
     helpers.check_one_launch_levels(refmex, glue, two_leaves)
 
 
+@pytest.mark.parametrize("m,wgs", [(666, 18), (1000, 24), (1100, 40)])
+def test_one_launch_front_with_pooled_tile_workgroups(refmex, m, wgs):
+    """Fewer tile workgroups than tiles (what fronts of more than 16 tile rows get on a whole device): 45 tiles on 7 workgroups,
+    105 on 8, 136 on 22."""
+    helpers.check_one_launch_front(refmex, m, wgs=wgs)
+
+
+def test_one_launch_front_levels_pooled(refmex, glue):
+    helpers.check_one_launch_levels(refmex, glue, True, wgs=60)            # two leaves of 13 tile rows share the budget: 17 tile workgroups each for 66 tiles
+    helpers.check_one_launch_pivot_rule(refmex, 666, 30.0, wgs=20)
+
+
 @pytest.mark.parametrize("m,maxu", [(400, 5e5), (400, 30.0), (400, 2.0), (666, 30.0)])
 def test_one_launch_front_pivot_rule(refmex, m, maxu):
     helpers.check_one_launch_pivot_rule(refmex, m, maxu)

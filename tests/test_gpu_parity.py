@@ -530,11 +530,23 @@ def test_pcg_operators_on_gpu(refmex, case):
     check_pcg_ops(refmex, CASES[case], seed=case)
 
 
-@pytest.mark.parametrize("m", [330, 512, 666, 1000, 1024])
+@pytest.mark.parametrize("m", [330, 512, 666, 1000, 1024, 1100, 1344])
 def test_one_launch_front_matches_the_panel_launches_bit_for_bit(refmex, m):
     """k_ldl_front (workgroups of one launch hand the factor on through device-scope counters) against the launch-per-panel
-    path: same bits, and both within tolerance of the reference."""
+    path: same bits, and both within tolerance of the reference.  1344 rows = 21 tile rows + 190 tiles = 211 workgroups is
+    the largest front that gets a workgroup per tile."""
     helpers.check_one_launch_front(refmex, m)
+
+
+@pytest.mark.parametrize("m,wgs", [(666, 18), (1000, 24), (1100, 40), (2000, 224), (4000, 224)])
+def test_one_launch_front_with_pooled_tile_workgroups(refmex, m, wgs):
+    helpers.check_one_launch_front(refmex, m, wgs=wgs)
+
+
+def test_one_launch_front_levels_and_pivot_rule_pooled(refmex, glue):
+    helpers.check_one_launch_levels(refmex, glue, True, wgs=60)
+    helpers.check_one_launch_pivot_rule(refmex, 666, 30.0, wgs=20)
+    helpers.check_one_launch_pivot_rule(refmex, 2000, 30.0, wgs=224)
 
 
 @pytest.mark.parametrize("two_leaves", [False, True])
@@ -567,10 +579,11 @@ def test_one_launch_front_is_deterministic_across_repeats(refmex):
 
 
 def test_one_launch_front_under_uneven_load(refmex):
-    """The hand-overs inside k_ldl_front with the device busy elsewhere: three other plans on their own streams keep factoring
-    (a second and third k_ldl_front of 16 tile rows = 121 workgroups each -- together with ours more than the device holds
-    at once -- and a MAXCUT-sized front on the launch-per-panel path streaming its trailing matrix), while control07's shape
-    is factored and solved 60 times: every result identical to the idle one, bit for bit."""
+    """The hand-overs inside k_ldl_front with the device busy elsewhere: four other plans on their own streams keep factoring
+    (k_ldl_front launches of 121, 121 and 211 workgroups -- with ours far more than the device holds at once: launches of
+    different plans take turns, PersistTurn in sdm_chol.hip -- and a MAXCUT-sized front on the launch-per-panel path
+    streaming its trailing matrix in between), while control07's shape is factored and solved 60 times: every result
+    identical to the idle one, bit for bit."""
     from sedumi_amd import problem
     from sedumi_amd.plan import Plan
 
@@ -586,7 +599,7 @@ def test_one_launch_front_under_uneven_load(refmex):
     main = dense_plan(666, 1)
     main.blkchol(None, False); main.ldlsolve()
     l0, d0, y0 = main.download("lpr"), main.download("d"), main.download("y")
-    others = [dense_plan(1000, 2), dense_plan(1024, 3), dense_plan(2000, 4)]
+    others = [dense_plan(1000, 2), dense_plan(1024, 3), dense_plan(1344, 4), dense_plan(2000, 5)]
     for pl in others:
         pl.blkchol(None, False)
     refs = [(pl.download("lpr"), pl.download("d")) for pl in others]

@@ -23,7 +23,6 @@
 #include "sdm_plan.h"
 #include <algorithm>
 #include <cmath>
-#include <mutex>
 #include <numeric>
 
 namespace sdm {
@@ -1400,43 +1399,6 @@ __global__ void k_divd(double *v, const double *d, int m) {
 }
 
 // ============================================================ host drivers
-// Two k_ldl_front launches of different plans (streams) must not share the device: each needs ALL its workgroups resident
-// and waits inside, so two half-dispatched ones could hold the compute units the other is waiting for.  Launches of one
-// process take turns per device: a plan that follows ANOTHER plan's launch first waits (on the device: an event recorded
-// on that plan's stream, hipStreamWaitEvent on its own) -- a plan that has the device to itself pays a mutex and nothing
-// else.  Kernels whose workgroups only wait for workgroups dispatched before them (k_ldl_panel, k_sprep) need no turn.
-// Not inside a graph capture (an event of another stream cannot be captured): replayed graphs of several plans that
-// contain k_ldl_front launches must be ordered by the caller.
-struct PersistTurn {
-#ifdef SDM_EMU
-  explicit PersistTurn(sdm_plan *) {}
-  static void forget(sdm_plan *) {}
-#else
-  static constexpr int MAXDEV = 64;
-  static std::mutex &mtx() { static std::mutex m; return m; }
-  static hipEvent_t *events() { static hipEvent_t ev[MAXDEV] = {}; return ev; }
-  static sdm_plan **owners() { static sdm_plan *pl[MAXDEV] = {}; return pl; }
-  sdm_plan *P;
-  bool on;
-  std::unique_lock<std::mutex> lk;
-  explicit PersistTurn(sdm_plan *p) : P(p), on(!p->capturing && p->device >= 0 && p->device < MAXDEV) {
-    if (!on) return;
-    lk = std::unique_lock<std::mutex>(mtx());
-    sdm_plan *prev = owners()[P->device];
-    if (prev && prev != P && !prev->capturing) {
-      hipEvent_t &ev = events()[P->device];
-      if (!ev) SDM_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      SDM_HIP_CHECK(hipEventRecord(ev, prev->stream));
-      SDM_HIP_CHECK(hipStreamWaitEvent(P->stream, ev, 0));
-    }
-  }
-  ~PersistTurn() { if (on) owners()[P->device] = P; }
-  static void forget(sdm_plan *p) {                                    // the plan is going away: nobody waits for its stream any more
-    std::lock_guard<std::mutex> g(mtx());
-    for (int dv = 0; dv < MAXDEV; dv++) if (owners()[dv] == p) owners()[dv] = nullptr;
-  }
-#endif
-};
 void chol_forget_plan(sdm_plan *P) { PersistTurn::forget(P); }
 FrontTab front_tab(CholPlan &C) {
   FrontTab t;

@@ -1,6 +1,7 @@
 // sdm_plan.h -- internal structures of the resident plan (not part of the ABI).
 #pragma once
 #include "sdm_rt.h"
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -165,6 +166,8 @@ struct CholPlan {
   DevBuf<double> S, xfin, ttmp, zdiv;
   DevBuf<unsigned long long> sb_g;   // per super-block: bit patterns of max|inverse| and max|L block| (growth check)
   DevBuf<int> sb_cnt;                // per super-block: arrival tickets of the (rare) substitution fallback
+  DevBuf<int> sfront_cnt;            // k_solve_front: per super-block slabs final (forward / backward), then the exit ticket
+  bool solve_fused = false;          // one-front factors: fw, ./d, bw as ONE launch (k_solve_front; opt-in, SDM_SOLVE_FUSED at set_chol)
   DevBuf<int> l_i128, l_t3, l_pm;    // work lists of the inversion / premultiplication launches (4 ints per item)
   int n_i128 = 0, n_t3 = 0, n_pm = 0;
   std::vector<SolveLevel> slev;
@@ -308,6 +311,44 @@ struct sdm_plan {
   } while (0)
 
 namespace sdm {
+// Two launches whose workgroups all have to be resident (k_ldl_front, k_solve_front) of different plans (streams) must
+// not share the device: each needs ALL its workgroups resident and waits inside, so two half-dispatched ones could hold the compute units the other is waiting for.  Launches of one
+// process take turns per device: a plan that follows ANOTHER plan's launch first waits (on the device: an event recorded
+// on that plan's stream, hipStreamWaitEvent on its own) -- a plan that has the device to itself pays a mutex and nothing
+// else.  Kernels whose workgroups only wait for workgroups dispatched before them (k_ldl_panel, k_sprep) need no turn.
+// (Header-defined: the function-local statics are one instance per process.)
+// Not inside a graph capture (an event of another stream cannot be captured): replayed graphs of several plans that
+// contain such launches must be ordered by the caller.
+struct PersistTurn {
+#ifdef SDM_EMU
+  explicit PersistTurn(sdm_plan *) {}
+  static void forget(sdm_plan *) {}
+#else
+  static constexpr int MAXDEV = 64;
+  static std::mutex &mtx() { static std::mutex m; return m; }
+  static hipEvent_t *events() { static hipEvent_t ev[MAXDEV] = {}; return ev; }
+  static sdm_plan **owners() { static sdm_plan *pl[MAXDEV] = {}; return pl; }
+  sdm_plan *P;
+  bool on;
+  std::unique_lock<std::mutex> lk;
+  explicit PersistTurn(sdm_plan *p) : P(p), on(!p->capturing && p->device >= 0 && p->device < MAXDEV) {
+    if (!on) return;
+    lk = std::unique_lock<std::mutex>(mtx());
+    sdm_plan *prev = owners()[P->device];
+    if (prev && prev != P && !prev->capturing) {
+      hipEvent_t &ev = events()[P->device];
+      if (!ev) SDM_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      SDM_HIP_CHECK(hipEventRecord(ev, prev->stream));
+      SDM_HIP_CHECK(hipStreamWaitEvent(P->stream, ev, 0));
+    }
+  }
+  ~PersistTurn() { if (on) owners()[P->device] = P; }
+  static void forget(sdm_plan *p) {                                    // the plan is going away: nobody waits for its stream any more
+    std::lock_guard<std::mutex> g(mtx());
+    for (int dv = 0; dv < MAXDEV; dv++) if (owners()[dv] == p) owners()[dv] = nullptr;
+  }
+#endif
+};
 void set_error(const std::string &msg);
 // sdm_chol.hip
 void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm,

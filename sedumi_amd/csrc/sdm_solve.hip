@@ -32,6 +32,7 @@ constexpr int TP = 65;           // LDS pitch of staged 64-wide operand blocks (
 constexpr size_t INV_LDS = (size_t)4 * 64 * TP * sizeof(double);      // k_sinv128: four staged 64x64 blocks
 constexpr int SPREP_MAX_ITEMS = 256;                                  // k_sprep: one workgroup per item, all resident (one per CU)
 constexpr size_t TILE_LDS = (size_t)2 * 64 * TP * sizeof(double);     // k_stile: one A and one B operand block
+constexpr int SFRONT_MAX_WGS = 512;                                   // k_solve_front: all workgroups resident (three fit a compute unit)
 
 // ---------------------------------------------------------------- host tables
 void solve_build(sdm_plan *P) {
@@ -72,6 +73,11 @@ void solve_build(sdm_plan *P) {
   C.sb_g.alloc((size_t)std::max(4 * sb, 4)); C.sb_cnt.alloc((size_t)std::max(sb, 1));
   SDM_HIP_CHECK(hipMemset(C.sb_g.p, 0, (size_t)std::max(4 * sb, 4) * sizeof(unsigned long long)));
   SDM_HIP_CHECK(hipMemset(C.sb_cnt.p, 0, (size_t)std::max(sb, 1) * sizeof(int)));
+  C.sfront_cnt.alloc((size_t)2 * std::max(sb, 1) + 4);
+  SDM_HIP_CHECK(hipMemset(C.sfront_cnt.p, 0, C.sfront_cnt.n * sizeof(int)));
+  // fw, ./d, bw of a one-front factor without rows below as ONE launch (k_solve_front): opt-in until it has been timed
+  C.solve_fused = getenv("SDM_SOLVE_FUSED") != nullptr && nsuper == 1 && C.sn_ms[0] == C.sn_ns[0] &&
+                  (C.sn_ns[0] + SROWS - 1) / SROWS <= SFRONT_MAX_WGS;
   // levels
   C.slev.assign(C.nlevels, SolveLevel());
   for (int l = 0; l < C.nlevels; l++) {
@@ -890,6 +896,163 @@ k_sbw_diag(const double *__restrict__ S, FrontTab tab, const int *list, const do
   }
 }
 
+// ================================================================ the whole solve of a one-front factor in ONE launch
+// fw, ./d, bw (wrapPcg.m:56-59 without dense columns) for factors that are a single front without rows below (the dense
+// Schur complements of SDPs: control07, MAXCUT).  The launch-per-step sweeps above are chains of 2 (nsb - 1) + 2 dependent
+// launches; here workgroup b OWNS rows 16 b .. of the forward sweep and the same columns of the backward sweep and
+// accumulates their value in registers, in the order of the step launches (same slab functions: same bits):
+//   forward   diagonal-block product, then for Q = 0 .. P-1:  - M(rows, Q) y_Q  as soon as block Q is final (doneF[Q] =
+//             slabs of block Q final; the matrix slab is in flight before the wait); y and z = y ./ d stored write-through,
+//             counted in doneF[P];
+//   backward  v = z, then for Q = nsb-1 .. P+1:  - M(Q, columns)' v_Q  as soon as block Q is final (doneB[Q]); v stored (vb, an
+//             array of its own), counted in doneB[P]; once the whole block is there: x = inv(L_PP)' v  ->  xfin, yout(perm).
+// Blocks on the substitution fallback: rows / columns stay unpremultiplied (F instead of S), the last slab to arrive
+// solves the block (block_solve_fw / _bw) and counts for all of them.  Forward waits are for lower workgroups, backward
+// waits for higher ones: all workgroups must be resident (SFRONT_MAX_WGS; PersistTurn on the host).  The last workgroup
+// to leave re-arms the counters.  The emulator (workgroups one after the other) runs phase 1 = forward, phase 2 = the
+// backward accumulation with the workgroups in reverse order, phase 3 = the diagonal-block products; the GPU runs
+// phase 0 = all of it.
+__device__ __forceinline__ bool arrive_is_last(int *cnt, int nsl) {
+  __shared__ int last;
+  SDM_STORES_DONE();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int t = atomicAdd(cnt, 1);
+    last = t == nsl - 1;
+    if (last) atomicExch(cnt, 0);                                     // ready for the next solve
+  }
+  __syncthreads();
+  return last != 0;
+}
+__global__ void __launch_bounds__(ST)
+k_solve_front(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const double *src, const int *perm, double *y,
+              double *zdiv, double *vb, const double *dscale, double *xfin, double *yout, const unsigned long long *sb_g, int *sb_cnt, int *done,
+              double thr, int phase, int *tmo) {
+  __shared__ double xs[SBW], red[(ST / 8) * SROWS], wsub[SBW];
+  __shared__ double Sd[64 * TP];
+  const int ns = tab.o_ns, first = tab.o_first, ld = tab.o_ld, sld = tab.o_sld;
+  const int nsb = (ns + SBW - 1) / SBW;
+  const int nwg = gridDim.x;
+#ifdef SDM_EMU
+  const int bx = phase == 2 ? nwg - 1 - (int)blockIdx.x : (int)blockIdx.x;
+#else
+  const int bx = blockIdx.x;
+#endif
+  const int r0 = SROWS * bx;                                          // rows (forward) = columns (backward) of this workgroup
+  const int Pb = r0 / SBW, c0 = Pb * SBW, nb = min(SBW, ns - c0);
+  const int sb = tab.o_sboff + Pb;
+  const int nsl = (nb + SROWS - 1) / SROWS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const double *Fs = F + tab.o_foff, *Ss = S + tab.o_soff;
+  int *doneF = done, *doneB = done + nsb, *fin = done + 2 * nsb;
+  const bool bad = sb_is_bad(sb_g, sb, thr);
+  if (phase <= 1) {
+    // ---------------------------------------------------------------- forward
+    sdm_double2 v[NLD];
+    const int ncols = min(nb, r0 + SROWS - c0);                       // lower triangular: columns up to the slab's last row
+    slab_issue(v, Ss, sld, c0, ncols, r0, ns - 1);
+    for (int c = tid; c < nb; c += ST) xs[c] = src[perm[first + c0 + c]];
+    __syncthreads();
+    double acc;
+    if (bad) acc = (tid < SROWS && r0 + tid < ns) ? xs[r0 - c0 + tid] : 0.0;     // the right-hand side itself: solved by substitution below
+    else acc = slab_consume(v, ncols, xs, red);
+    for (int Q = 0; Q < Pb; Q++) {
+      const int cq = Q * SBW;
+      if (bad) slab_issue(v, Fs, ld, cq, SBW, r0, ns - 1);            // the rows of a bad block were not premultiplied
+      else slab_issue(v, Ss, sld, cq, SBW, r0, ns - 1);
+      prep_wait(doneF + Q, SBW / SROWS, tmo);                         // y_Q is final (and everybody is done with xs / red)
+      for (int c = tid; c < SBW; c += ST) xs[c] = sdm_load_wt(&y[first + cq + c]);
+      __syncthreads();
+      acc -= slab_consume(v, SBW, xs, red);
+    }
+    if (tid < SROWS && r0 + tid < ns) {
+      sdm_store_wt(&y[first + r0 + tid], acc);
+      if (!bad) { const double dk = dscale[first + r0 + tid]; sdm_store_wt(&zdiv[first + r0 + tid], acc / (dk > 0.0 ? dk : 1.0)); }
+    }
+    if (!bad) {
+      prep_done(doneF + Pb);
+    } else if (arrive_is_last(sb_cnt + sb, nsl)) {
+      SDM_ACQUIRE_FENCE();
+      block_solve_fw(Fs, ld, c0, nb, y + first + c0, wsub, Sd);
+      __syncthreads();
+      for (int i = tid; i < nb; i += ST) { const double dk = dscale[first + c0 + i]; zdiv[first + c0 + i] = y[first + c0 + i] / (dk > 0.0 ? dk : 1.0); }
+      if (Pb == nsb - 1) {                                            // nothing above the last block: x = L_PP' \ z right away
+        SDM_STORES_DONE();
+        __syncthreads();
+        block_solve_bw(Fs, ld, c0, nb, zdiv + first + c0, wsub, Sd);
+      }
+      SDM_STORES_DONE();
+      __syncthreads();
+      if (tid == 0) { __threadfence(); sdm_signal_add(doneF + Pb, nsl); }
+    }
+    if (phase == 1) return;
+  }
+  // ------------------------------------------------------------------ backward (z from zdiv, v in vb)
+  if (phase == 0 || phase == 2) {
+  prep_wait(doneF + Pb, nsl, tmo);                                    // this block's z (x for a bad last block) is complete
+  double val[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { const int c = r0 + 4 * wave + q; val[q] = c < ns ? sdm_load_wt(&zdiv[first + c]) : 0.0; }
+  for (int Q = nsb - 1; Q > Pb; Q--) {
+    const int rb = Q * SBW, nbq = min(SBW, ns - rb);
+    const bool badq = sb_is_bad(sb_g, tab.o_sboff + Q, thr);
+    sdm_double2 vt[8];
+    if (badq) slabT_issue(vt, Fs, ld, r0, SROWS, rb, nbq); else slabT_issue(vt, Ss, sld, r0, SROWS, rb, nbq);
+    prep_wait(doneB + Q, (nbq + SROWS - 1) / SROWS, tmo);             // v_Q (x_Q of a bad block) is final
+    for (int i = tid; i < nbq; i += ST) xs[i] = sdm_load_wt(&vb[first + rb + i]);
+    __syncthreads();
+    double part[4];
+    slabT_consume(vt, nbq, xs, part);
+#pragma unroll
+    for (int q = 0; q < 4; q++) val[q] -= part[q];
+  }
+  // v goes to an array of its own: every line another workgroup reads after a wait is one it has not read before in this
+  // launch (z and v in the same place would be read twice through the same L2)
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int c = r0 + 4 * wave + q; if (c < ns) sdm_store_wt(&vb[first + c], val[q]); }
+  }
+  if (!bad || Pb == nsb - 1) {                                        // (a bad LAST block was substituted by the forward part: val is x)
+    prep_done(doneB + Pb);
+  } else if (arrive_is_last(sb_cnt + sb, nsl)) {
+    SDM_ACQUIRE_FENCE();
+    block_solve_bw(Fs, ld, c0, nb, vb + first + c0, wsub, Sd);
+    SDM_STORES_DONE();
+    __syncthreads();
+    if (tid == 0) { __threadfence(); sdm_signal_add(doneB + Pb, nsl); }
+  }
+  if (phase == 2) return;
+  }
+  {
+    const int nr = c0 + nb - r0, ncols = min(SROWS, ns - r0);         // rows r0 .. end of the block (upper part of S is zero)
+    sdm_double2 vt[8];
+    slabT_issue(vt, Ss, sld, r0, ncols, r0, nr);
+    prep_wait(doneB + Pb, nsl, tmo);
+    for (int i = tid; i < nr; i += ST) xs[i] = sdm_load_wt(&vb[first + r0 + i]);
+    __syncthreads();
+    double part[4];
+    if (bad) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const int c = r0 + 4 * wave + q; part[q] = c < ns ? xs[c - r0] : 0.0; }
+    } else {
+      slabT_consume(vt, nr, xs, part);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int c = r0 + 4 * wave + q;
+        if (c < ns) { xfin[first + c] = part[q]; if (yout) yout[perm[first + c]] = part[q]; }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {                                                      // the last one out re-arms the counters
+    const int t = atomicAdd(fin, 1);
+    if (t == nwg - 1) { for (int i = 0; i < 2 * nsb; i++) atomicExch(done + i, 0); atomicExch(fin, 0); }
+  }
+}
+
 // ================================================================ host drivers
 const double *solve_d(sdm_plan *P) { return P->dense.factored ? (const double *)P->chol.dsolve.p : (const double *)P->chol.d.p; }
 
@@ -1010,6 +1173,19 @@ void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode) {
   // fw, ./d, bw in one call without dense columns: the forward sweep writes the ./d copy of every block as it becomes
   // final (zdiv), the backward sweep runs on that copy and needs k_sbw_init only where rows below a supernode exist
   const bool fold = (mode == 7) && !dense;
+  if (fold && C.solve_fused) {
+    const FrontTab tab = level_tab(C, front_tab(C), 0);
+    const int nwg = (C.sn_ns[0] + SROWS - 1) / SROWS;
+    PersistTurn turn(P);
+#ifdef SDM_EMU
+    for (int phase = 1; phase <= 3; phase++)
+#else
+    const int phase = 0;
+#endif
+      SDM_KLAUNCH(P, k_solve_front, dim3(nwg), dim3(ST), 0, C.fronts.p, C.S.p, tab, rhs, C.d_perm.p, y, C.zdiv.p, C.wvec.p, solve_d(P), C.xfin.p, yout,
+                  C.sb_g.p, C.sb_cnt.p, C.sfront_cnt.p, C.growth_used, phase, C.tmo.dev());
+    return;
+  }
   if (mode & 1) {
     solve_fw_batch(P, rhs, 0, y, 0, C.wvec.p, 1, fold ? C.zdiv.p : nullptr, fold ? solve_d(P) : nullptr);
     if (!(mode & 4)) {

@@ -296,3 +296,50 @@ def check_one_launch_pivot_rule(refmex, m, maxu, wgs=None):
     assert si.size + ai.size > 0
     assert np.array_equal(l1, l2) and np.array_equal(d1, d2) and np.array_equal(p1[0][0], p2[0][0]) and np.array_equal(p1[1][1], p2[1][1])
     assert relerr(d1, r[1].ravel()) < 1e-8
+
+
+def check_fused_solve(m, thr, seed=0):
+    """k_solve_front (fw, ./d, bw of a one-front factor as ONE launch; opt-in, SDM_SOLVE_FUSED) against the launch-per-step
+    sweeps: the same slab products in the same order, so the same bits -- on the inverse path, with every super-block on
+    the substitution fallback (bound 0) and with good and bad blocks mixed; several solves in a row (the counters re-arm)."""
+    import os
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    rng = np.random.default_rng(m + seed)
+    Lv = np.tril(rng.standard_normal((m, m)) * (0.5 / np.sqrt(m)), -1) + np.eye(m)
+    if thr is not None and thr > 0 and m >= 512:
+        Lv[256:512, 256:512] = np.tril(Lv[256:512, 256:512], -1) * 1e-3 + np.eye(256)
+    d = 0.5 + rng.random(m)
+    X = Lv @ np.diag(d) @ Lv.T
+    L = problem.dense_symbolic(m)
+    rhss = [rng.standard_normal(m) for _ in range(3)]
+    out = []
+    for fused in (True, False):
+        if fused:
+            os.environ["SDM_SOLVE_FUSED"] = "1"
+        try:
+            plan = Plan(0); plan.set_chol(L, problem.dense_pattern(m))
+        finally:
+            os.environ.pop("SDM_SOLVE_FUSED", None)
+        if thr is not None:
+            plan.set_growth_max(thr)
+        plan.upload("ada", X.ravel(order="F"))
+        plan.kprof(True)
+        plan.blkchol(None, False)
+        ys = []
+        for r in rhss:
+            plan.upload("rhs", r); plan.ldlsolve(); ys.append(plan.download("y"))
+        names = set(plan.kprof_summary().keys())
+        plan.kprof(False)
+        nb, bad, _ = plan.solve_stats()
+        out.append((ys, names, bad))
+        plan.close()
+    (y1, k1, b1), (y2, k2, b2) = out
+    assert "k_solve_front" in k1 and "k_sfw_diag" not in k1 and "k_solve_front" not in k2 and "k_sfw_diag" in k2
+    assert b1 == b2
+    if thr == 0.0:
+        assert b1 == (m + 255) // 256
+    for a, b in zip(y1, y2):
+        assert np.array_equal(a, b)
+    want = np.linalg.solve(X, rhss[0])
+    assert relerr(y1[0], want) < 1e-9

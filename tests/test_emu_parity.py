@@ -377,3 +377,8 @@ def test_one_launch_front_levels_pooled(refmex, glue):
 @pytest.mark.parametrize("m,maxu", [(400, 5e5), (400, 30.0), (400, 2.0), (666, 30.0)])
 def test_one_launch_front_pivot_rule(refmex, m, maxu):
     helpers.check_one_launch_pivot_rule(refmex, m, maxu)
+
+
+@pytest.mark.parametrize("m,thr", [(90, None), (300, None), (666, None), (700, 0.0), (700, 1e-3), (1100, None), (256, 0.0)])
+def test_fused_solve_matches_the_step_launches_bit_for_bit(m, thr):
+    helpers.check_fused_solve(m, thr)

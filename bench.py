@@ -261,7 +261,7 @@ def profile_unit(plan, P, ud, nprof):
         "k_psd_stage1_mfma": ("mfma", None), "k_psd_stage1": ("mfma", None),       # flops filled below from the task list
         "k_psd_stage2": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)), "k_psd_stage2_ell": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)),
         "k_ada_spdot": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)),
-        "k_sfw_step": ("hbm", None), "k_sbw_step": ("hbm", None),
+        "k_sfw_step": ("hbm", None), "k_sbw_step": ("hbm", None), "k_sfw_diag": ("hbm", None), "k_sbw_diag": ("hbm", None),
     }
     peaks = {"hbm": (HBM_PEAK_GBS, "GB/s", 1e9), "mfma": (FP64_MATRIX_PEAK_TFS, "TFLOP/s", 1e12)}
     dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
@@ -273,8 +273,8 @@ def profile_unit(plan, P, ud, nprof):
         bound, work = model.get(key, ("hbm", None))
         if work is None and key.startswith("k_psd_stage1"):
             work = stage1_flops(P) / max(1, calls // nprof)
-        if work is None and key in ("k_sfw_step", "k_sbw_step"):
-            work = solve_bytes / max(1, calls // (nprof * NSOLVE))
+        if work is None and key in ("k_sfw_step", "k_sbw_step", "k_sfw_diag", "k_sbw_diag"):
+            work = solve_bytes / max(1, 2 * calls // (nprof * NSOLVE))       # a sweep = its diagonal-block and its step launches (about half the bytes each)
         if work is None:
             work = ada_bytes
         peak, unit, scale = peaks[bound]
@@ -301,7 +301,8 @@ def profile_unit(plan, P, ud, nprof):
                         "algorithmic_bytes_per_solve": 2.0 * solve_bytes, "achieved_GBs": 2.0 * solve_bytes / t_solve / 1e9,
                         "frac_of_hbm_peak": 2.0 * solve_bytes / t_solve / 1e9 / HBM_PEAK_GBS,
                         "dependency_chain": f"{nlaunch:.0f} dependent launches per solve x measured {1e6 * t_solve / max(nlaunch, 1):.2f} us per launch "
-                                            "(launch boundary + one memory round trip): the chain, not HBM, bounds a single-RHS solve",
+                                            "(launch boundary + the launch's own streaming)",
+                        "super_block_width": plan.solve_width(),
                         "super_blocks": nb, "blocks_on_substitution_fallback": nbad, "max_growth": growth},
               "factor": {"flops": fac_flops, "achieved_TFLOPs": fac_flops / (ph[1] * 1e-3) / 1e12,
                          "frac_of_fp64_matrix_peak": fac_flops / (ph[1] * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFS}}

@@ -345,11 +345,16 @@ int sdm_plan_deninfac(sdm_plan *p, const double *smult, double maxuden, int *hos
 int sdm_plan_lden(sdm_plan *p, sdm_int *betajc, double *beta, double *pv, sdm_int *pivperm, sdm_int *npivperm,
                   sdm_int *dopiv, double *Ld);
 
-/* The solves apply the 256-column diagonal super-blocks of L as explicit inverses (sdm_solve.hip) unless a block's
- * growth  max|inv(L_PP)| * max|L_PP|  exceeds growth_max (default 1e4): such a block is solved by substitution like
- * fwblkslv.c:109-114 / bwblkslv.c:113-122.  growth_max = 0 forces substitution everywhere.  Takes effect at the next
- * factorisation (sdm_plan_blkchol).  solve_stats reports the blocks of the last factorisation (synchronises). */
+/* The solves apply the diagonal super-blocks of L (256 .. 2048 columns: the power of two that covers the widest front,
+ * sdm_solve.hip) as explicit inverses unless a block's growth  max|inv(L_PP)| * max|L_PP|  exceeds growth_max (default
+ * 1e4): such a block is solved by substitution like fwblkslv.c:109-114 / bwblkslv.c:113-122.  growth_max = 0 forces
+ * substitution everywhere.  Takes effect at the next factorisation (sdm_plan_blkchol).  solve_stats reports the blocks
+ * of the last factorisation (synchronises).  set_solve_width (0 = automatic, or a power of two in 256 .. 2048) fixes
+ * the super-block width of the NEXT sdm_plan_set_chol: narrower blocks cost less to invert after every factorisation
+ * and more dependent launches per solve. */
 int sdm_plan_set_growth_max(sdm_plan *p, double growth_max);
+int sdm_plan_set_solve_width(sdm_plan *p, sdm_int width);
+int sdm_plan_get_solve_width(sdm_plan *p, sdm_int *width);      /* the width in force (after sdm_plan_set_chol) */
 int sdm_plan_solve_stats(sdm_plan *p, sdm_int *nblocks, sdm_int *nbad, double *max_growth);
 
 /* ---- one process-wide resident plan for the mexFunction shims: every .mex binary is its own

@@ -39,16 +39,40 @@ def build_phases(verbose=True):
     return out
 
 
-def build(force=False, verbose=True):
-    """Compile every HIP source for gfx950 into sedumi_amd/lib/libsedumi_hip.so."""
+def _compile_objects(extra, objdir, verbose):
+    """One object per source (hipcc -c), rebuilt only when the source or any header is newer; the compiles run side by side."""
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libsedumi_hip.so")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    hdr_t = max(os.path.getmtime(f) for f in hdrs)
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wall", "-Wno-unused-result"] + extra +
+                        ["-I", CSRC, "-o", obj, src])
+    if verbose:
+        for j in jobs:
+            print(" ".join(j), flush=True)
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(subprocess.check_call, jobs))
+    return hipcc, objs
+
+
+def build(force=False, verbose=True):
+    """Compile every HIP source for gfx950 into sedumi_amd/lib/libsedumi_hip.so."""
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
-           "-I", CSRC, "-o", LIB] + sources()
+    objdir = os.path.join(LIBDIR, "obj")
+    if force and os.path.isdir(objdir):
+        shutil.rmtree(objdir)
+    hipcc, objs = _compile_objects([], objdir, verbose)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -78,6 +78,7 @@ int sdm_plan_set_chol(sdm_plan *p, sdm_int m, const sdm_int *Ljc, const sdm_int 
                       sdm_int nsuper, const sdm_int *xsuper, const sdm_int *ADAjc, const sdm_int *ADAir) {
   SDM_TRY
   SDM_HIP_CHECK(hipSetDevice(p->device));
+  p->dense = sdm::DensePlan();            // dense-column tables are sized for the factor they were set with: gone with it
   chol_build(p, m, Ljc, Lir, perm, nsuper, xsuper, ADAjc, ADAir);
   p->ada_jc.assign(ADAjc, ADAjc + m + 1);
   p->ada_ir.assign(ADAir, ADAir + ADAjc[m]);
@@ -247,6 +248,19 @@ int sdm_plan_set_growth_max(sdm_plan *p, double growth_max) {
   SDM_TRY
   if (!(growth_max >= 0.0)) throw std::runtime_error("growth_max must be >= 0");
   p->chol.growth_max = growth_max;
+  SDM_CATCH
+}
+int sdm_plan_set_solve_width(sdm_plan *p, sdm_int width) {
+  SDM_TRY
+  if (width != 0 && (width < sdm::SBW_MIN || width > sdm::SBW_MAX || (width & (width - 1)) != 0))
+    throw std::runtime_error("solve width must be 0 (automatic) or a power of two in 256 .. 2048");
+  p->chol.sbw_req = (int)width;
+  SDM_CATCH
+}
+int sdm_plan_get_solve_width(sdm_plan *p, sdm_int *width) {
+  SDM_TRY
+  if (!p->has_chol) throw std::runtime_error("sdm_plan_get_solve_width: no symbolic factor set");
+  *width = p->chol.sbw;
   SDM_CATCH
 }
 int sdm_plan_solve_stats(sdm_plan *p, sdm_int *nblocks, sdm_int *nbad, double *max_growth) {

@@ -1432,7 +1432,7 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
   }
   SDM_KLAUNCH(P, k_prep_pivots, dim3(grid1d(m, 256, 64)), dim3(256), 0, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
              P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, (int)C.nsuper, C.upd_cnt.p, C.diag_cnt.p,
-             C.sb_g.p, 4 * C.nsbtot, C.front_cnt.p, (int)C.front_cnt.n);
+             C.sb_g.p, (int)C.sb_g.n, C.front_cnt.p, (int)C.front_cnt.n);
   for (int l = 0; l < C.nlevels; l++) {
     const int *list = C.d_levlist.p + C.levptr[l];
     const int nfr = C.levptr[l + 1] - C.levptr[l];

@@ -213,10 +213,6 @@ void dense_set(sdm_plan *P, sdm_int nden, const sdm_int *LADjc, const sdm_int *L
   D.ad.alloc((size_t)(m * nden)); D.lad.alloc((size_t)(m * nden)); D.wvb.alloc((size_t)(C.wsize * nden));
   D.p.alloc((size_t)std::max<sdm_int>(D.pnnz, 1)); D.beta.alloc((size_t)std::max<sdm_int>(D.pnnz, 1));
   D.dgat.alloc((size_t)std::max<sdm_int>(D.dznnz, 1)); D.smult.alloc(nden); D.dden.alloc(m);
-  if (C.sb_cnt.n < (size_t)C.nsbtot * (size_t)nden) {                // one set of fallback tickets per right-hand side
-    C.sb_cnt.alloc((size_t)C.nsbtot * (size_t)nden);
-    SDM_HIP_CHECK(hipMemset(C.sb_cnt.p, 0, C.sb_cnt.n * sizeof(int)));
-  }
   D.need_host.ensure();
   D.active = true;
 }

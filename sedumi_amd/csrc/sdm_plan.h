@@ -19,7 +19,10 @@ constexpr int S1_GEN_LDS = 24 * 1024;   // LDS target per task of the generic st
 constexpr int ELL_WAVES = 8;  // wavefronts per workgroup of the ELL stage-2 kernel of ADA'
 constexpr int SOLVE_LDS_MAX = 3072;   // doubles of a product-form right-hand side kept in LDS (k_pr1_solve)
 constexpr int FUSE_MAX_TILES = 1 << 20; // trailing updates of at most this many tiles ride along with the next diagonal-block launch (in effect: all)
-constexpr int SBW = 256;              // super-block width of the solves (columns whose diagonal block is applied as ONE explicit inverse)
+constexpr int SBW_MIN = 256;          // narrowest super-block of the solves (columns whose diagonal block is applied as ONE explicit inverse)
+constexpr int SBW_MAX = 2048;         // widest one (CholPlan::sbw = the power-of-two multiple of SBW_MIN that covers the widest front, capped here)
+constexpr int SINV_MAXLEV = 4;        // combine levels above the 128-column leaves: half widths 128, 256, 512, 1024
+constexpr int SPREP_NCNT = 2 + 2 * SINV_MAXLEV;   // completion counters per super-block of k_sprep (leaves, then T / X per level)
 constexpr int SROWS = 16;             // rows (forward) / columns (backward) of a front handled by one workgroup of the solve kernels
 constexpr int SW = 8;                 // columns of the diagonal block swept in registers at a time (readlane chain), rest via LDS
 constexpr int LDL_THREADS = 512;      // workgroup of the diagonal-block kernel: wavefront 0 sweeps, the other 7 apply the previous sweep
@@ -127,8 +130,7 @@ struct SolveLevel {
   int nfronts = 0, maxns = 0, maxms = 0, nsb = 0;   // nsb = super-blocks of the widest front
   bool children = false;                             // some front of the level has children (assembly launch needed)
   bool below = false;                                // some front has rows below its own columns
-  std::vector<int> nact_fw, nact_bw;                 // fronts (prefix of the level list, sorted by ns desc) active in step P / Q
-  std::vector<int> maxslab_fw, maxslab_bw;           // grid.x of the step launches
+  std::vector<int> slabs_fw;                         // grid.x of the forward step launch behind super-block P (0: none)
 };
 
 struct CholPlan {
@@ -158,18 +160,19 @@ struct CholPlan {
   std::vector<int> lev_ntw;        // ... plus this many tile workgroups per front
   DevBuf<int> upd_cnt;     // per front: finished tile workgroups of the updates that rode along with k_ldl_panel
   HostFlag tmo;            // raised by a spin inside a panel launch of THIS plan that gave up (chol_wait_timeouts)
-  // ---- solves (sdm_solve.hip): per front the ns x ns "S" array = explicit inverses of the SBW-wide diagonal
-  // super-blocks and the block rows left of them premultiplied by those inverses
+  // ---- solves (sdm_solve.hip): per front and super-block of sbw columns one nb x nb array in the arena S = the explicit
+  // inverse of that diagonal block of L (block P of front s at sn_soff[s] + P * sbw * sn_sld[s], leading dimension sn_sld[s])
+  int sbw = SBW_MIN;                 // super-block width of this plan (solve_build: covers the widest front, at most SBW_MAX)
+  int sbw_req = 0;                   // != 0: width asked for through sdm_plan_set_solve_width (before set_chol)
   int64_t ssize = 0; int nsbtot = 0;
   std::vector<int64_t> sn_soff; std::vector<int> sn_sld, sn_sboff;
   DevBuf<int64_t> d_soff; DevBuf<int> d_sld, d_sboff;
-  DevBuf<double> S, xfin, ttmp, zdiv;
-  DevBuf<unsigned long long> sb_g;   // per super-block: bit patterns of max|inverse| and max|L block| (growth check)
-  DevBuf<int> sb_cnt;                // per super-block: arrival tickets of the (rare) substitution fallback
-  DevBuf<int> sfront_cnt;            // k_solve_front: per super-block slabs final (forward / backward), then the exit ticket
-  bool solve_fused = false;          // one-front factors: fw, ./d, bw as ONE launch (k_solve_front; opt-in, SDM_SOLVE_FUSED at set_chol)
-  DevBuf<int> l_i128, l_t3, l_pm;    // work lists of the inversion / premultiplication launches (4 ints per item)
-  int n_i128 = 0, n_t3 = 0, n_pm = 0;
+  DevBuf<double> S, xfin, zdiv;
+  DevBuf<double> Tarena;             // scratch of the inversion, same layout as S: T = B inv(A) of every combine step
+  DevBuf<unsigned long long> sb_g;   // per super-block: bit patterns of max|inverse| and max|L block| (growth check); behind them the counters of k_sprep
+  DevBuf<int> l_i128, l_items;       // work lists of the inversion: 128-column leaves (4 ints each), combine tiles (8 ints each, sorted by stage)
+  int n_i128 = 0, n_items = 0;
+  std::vector<int> stage_ptr;        // combine tiles of stage st (= 2 * level + (0: T, 1: X)) are l_items[stage_ptr[st] .. stage_ptr[st+1])
   std::vector<SolveLevel> slev;
   double growth_max = 1e4;           // a super-block whose max|inv| * max|L| exceeds this is solved by substitution
   double growth_used = 1e4;          // the bound in force at the last solve_prepare
@@ -311,7 +314,7 @@ struct sdm_plan {
   } while (0)
 
 namespace sdm {
-// Two launches whose workgroups all have to be resident (k_ldl_front, k_solve_front) of different plans (streams) must
+// Two launches whose workgroups all have to be resident (k_ldl_front) of different plans (streams) must
 // not share the device: each needs ALL its workgroups resident and waits inside, so two half-dispatched ones could hold the compute units the other is waiting for.  Launches of one
 // process take turns per device: a plan that follows ANOTHER plan's launch first waits (on the device: an event recorded
 // on that plan's stream, hipStreamWaitEvent on its own) -- a plan that has the device to itself pays a mutex and nothing

@@ -1,26 +1,32 @@
 // sdm_solve.hip -- triangular solves  y = L \ b(perm),  y(perm) = L' \ b  (fwblkslv.c:77-134, bwblkslv.c:73-125)
-// for gfx950, built around EXPLICIT INVERSES of the diagonal super-blocks.
+// for gfx950, built around EXPLICIT INVERSES of wide diagonal super-blocks.
 //
 // The reference substitutes column by column -- a chain of m dependent steps.  A single right-hand side leaves a
 // GPU nothing to batch over (the four solves of an IPM iteration depend on each other, wrapPcg.m:56-59), so the chain
-// itself has to go.  After every factorisation (solve_prepare) each front gets a second array S (ns x ns):
-//   * the diagonal super-blocks of SBW = 256 columns are inverted explicitly:  S_PP = inv(L_PP)  (unit lower
-//     triangular; 64x64 blocks by substitution in registers, then two levels of  X21 = -inv(C) B inv(A)  on the FP64
-//     matrix cores),
-//   * the block rows left of them are premultiplied:  S_PQ = inv(L_PP) L_PQ  (FP64 matrix cores),
-// i.e. L = D~ L~ with D~ = blockdiag(L_PP) and L~ = S with identity diagonal super-blocks.  Then
-//   forward   y_P = inv(L_PP) b_P - sum_{Q<P} S_PQ y_Q          : one GEMV launch for all inv(L_PP) b_P, then one GEMV
-//                                                                  launch per super-block column P ("step"),
-//   backward  v_P = z_P - sum_{Q>P} S_QP' v_Q ,  x_P = inv(L_PP)' v_P : the mirror image,
-// every launch a plain HBM-streaming matrix-vector product over MANY workgroups (16 rows or columns each) with no
-// dependency inside it: m/256 dependent steps per sweep instead of m.  Rows below a supernode's own columns (they
-// belong to its ancestors) are never premultiplied and are read from the factor itself.
+// itself has to go.  The columns of every front are cut into super-blocks of W = CholPlan::sbw columns (256 .. 2048:
+// the power of two that covers the widest front, so control07's 666-column front is ONE block and MAXCUT-4000's front
+// is two), and after every factorisation (solve_prepare) the diagonal block L_PP of every super-block is inverted
+// explicitly into the arena S:
+//   * 128-column leaves: 32x32 by substitution in registers, then two levels of  X21 = -inv(C) B inv(A)  on the FP64
+//     matrix cores, all inside one workgroup (k_sinv128);
+//   * combine levels 256, 512, ... W: the same identity on 64x64 product tiles (k_stile), two dependent stages per
+//     level (T = B inv(A), then X21 = -inv(C) T); small problems run all of it as ONE launch with completion
+//     counters between the stages (k_sprep).
+// Then, per etree level and super-block P,
+//   forward   y_P = inv(L_PP) t_P                       one GEMV launch (k_sfw_diag), no dependency inside it,
+//             t_R -= L(R, P) y_P  for the rows R beyond  one GEMV launch (k_sfw_step), read from the factor itself
+//                                                        (own rows and the rows of the ancestors alike),
+//   backward  x_Q = inv(L_QQ)' v_Q ,  v_C -= L(Q, C)' x_Q  for the columns C left of Q: the mirror image,
+// i.e. 2 nsb - 1 dependent launches per sweep of a front of nsb super-blocks -- ONE for a front that fits a block --
+// each a plain HBM-streaming matrix-vector product over many workgroups (16 rows or columns x up to 1024 columns or
+// rows in flight per workgroup).
 //
 // Never-fail pivoting admits multipliers up to maxu = 5e5 (blkchol2.c:114-161), so an explicit inverse can be
 // ill-conditioned.  The growth of every super-block is therefore measured when it is inverted
-// (max|inv(L_PP)| * max|L_PP|); a block beyond CholPlan::growth_max keeps its rows unpremultiplied and is solved by
-// substitution by the workgroup that completes its right-hand side (an arrival ticket among the workgroups that
-// update it) -- per block, decided on the device, no host round trip.  Everything is deterministic (fixed summation
+// (max|inv(L_PP)| * max|L_PP|); a block beyond CholPlan::growth_max is solved by substitution against the factor by
+// one workgroup of the same launch -- per block, decided on the device, no host round trip.  (Measured on whole
+// runs of control07.mat: the growth of the 666-wide block stays within 1.6x of that of its 256-wide sub-blocks in
+// all 40 iterations, and both pass 1e4 in the last six)  Everything is deterministic (fixed summation
 // orders, no atomics on data).
 #include "sdm_plan.h"
 #include <algorithm>
@@ -32,75 +38,92 @@ constexpr int TP = 65;           // LDS pitch of staged 64-wide operand blocks (
 constexpr size_t INV_LDS = (size_t)4 * 64 * TP * sizeof(double);      // k_sinv128: four staged 64x64 blocks
 constexpr int SPREP_MAX_ITEMS = 256;                                  // k_sprep: one workgroup per item, all resident (one per CU)
 constexpr size_t TILE_LDS = (size_t)2 * 64 * TP * sizeof(double);     // k_stile: one A and one B operand block
-constexpr int SFRONT_MAX_WGS = 512;                                   // k_solve_front: all workgroups resident (three fit a compute unit)
+constexpr int GRPW = 1024;       // columns (forward) / rows (backward) of a slab product in flight at a time: 32 16-byte loads per work-item
 
 // ---------------------------------------------------------------- host tables
 void solve_build(sdm_plan *P) {
   CholPlan &C = P->chol;
   const int nsuper = (int)C.nsuper;
+  int W = C.sbw_req;
+  if (W == 0) { W = SBW_MIN; while (W < C.maxns && W < SBW_MAX) W *= 2; }
+  C.sbw = W;
   C.sn_soff.assign(nsuper, 0); C.sn_sld.assign(nsuper, 0); C.sn_sboff.assign(nsuper, 0);
-  std::vector<int> i128, t3, pm;
-  int64_t soff = 0; int sb = 0, tslots = 0;
+  std::vector<int> i128;
+  std::vector<std::vector<int>> stage(2 * SINV_MAXLEV);              // combine tiles per stage st = 2 * level + (0: T, 1: X)
+  int64_t soff = 0; int sb = 0;
   for (int s = 0; s < nsuper; s++) {
-    const int ns = C.sn_ns[s], sld = ns + (ns & 1);
+    const int ns = C.sn_ns[s];
+    // leading dimension of the front's inverse blocks: a multiple of 16 (whole 128-byte lines per 16-row slab), never a
+    // multiple of 256 doubles (columns 2 KB-aligned to each other would land on the same memory channels)
+    int sld = (std::min(ns, W) + 15) & ~15;
+    if (sld % 256 == 0) sld += 16;
     C.sn_soff[s] = soff; C.sn_sld[s] = sld; C.sn_sboff[s] = sb;
     soff += (int64_t)sld * ns;
-    const int nsb = (ns + SBW - 1) / SBW;
+    const int nsb = (ns + W - 1) / W;
     for (int h = 0; 128 * h < ns; h++) { i128.push_back(s); i128.push_back(h); i128.push_back(0); i128.push_back(0); }
     for (int Pb = 0; Pb < nsb; Pb++) {
-      const int k0 = Pb * SBW, nb = std::min(SBW, ns - k0);
-      if (nb > 128) {                                              // level 3:  X = -inv(C2) B2 inv(A2), via T = B2 inv(A2)
-        const int nc = nb - 128;
-        for (int I = 0; 64 * I < nc; I++)
-          for (int J = 0; J < 2; J++) { t3.push_back(s); t3.push_back(Pb); t3.push_back(2 * I + J); t3.push_back(tslots); }
-        tslots++;
+      const int nb = std::min(W, ns - Pb * W);
+      int prev = (nb + 127) / 128;                                    // what stage 0 waits for: the leaves of this super-block
+      for (int lev = 0; lev < SINV_MAXLEV; lev++) {
+        const int h = 128 << lev;
+        if (h >= nb) break;
+        int cnt = 0;
+        for (int t = 0; t < 2; t++) {
+          std::vector<int> &dst = stage[2 * lev + t];
+          for (int pi = 0; pi * 2 * h + h < nb; pi++) {
+            const int nc = std::min(h, nb - pi * 2 * h - h);
+            for (int I = 0; 64 * I < nc; I++)
+              for (int J = 0; 64 * J < h; J++) {
+                const int it[8] = {s, Pb, lev, pi, I, J, t, prev};
+                dst.insert(dst.end(), it, it + 8);
+                if (t == 0) cnt++;
+              }
+          }
+          prev = cnt;                                                  // T and X stages of a level have the same tiles
+        }
       }
-      if (Pb > 0)
-        for (int I = 0; 64 * I < nb; I++)
-          for (int J = 0; J < 4 * Pb; J++) { pm.push_back(s); pm.push_back(Pb); pm.push_back(I); pm.push_back(J); }
     }
     sb += nsb;
   }
   C.ssize = soff; C.nsbtot = sb;
-  C.n_i128 = (int)i128.size() / 4; C.n_t3 = (int)t3.size() / 4; C.n_pm = (int)pm.size() / 4;
-  C.l_i128.upload(i128); C.l_t3.upload(t3); C.l_pm.upload(pm);
+  std::vector<int> items;
+  C.stage_ptr.assign(2 * SINV_MAXLEV + 1, 0);
+  for (int st = 0; st < 2 * SINV_MAXLEV; st++) {
+    C.stage_ptr[st] = (int)items.size() / 8;
+    items.insert(items.end(), stage[st].begin(), stage[st].end());
+  }
+  C.stage_ptr[2 * SINV_MAXLEV] = (int)items.size() / 8;
+  C.n_i128 = (int)i128.size() / 4; C.n_items = (int)items.size() / 8;
+  C.l_i128.upload(i128); C.l_items.upload(items);
   C.d_soff.upload(C.sn_soff); C.d_sld.upload(C.sn_sld); C.d_sboff.upload(C.sn_sboff);
-  C.S.alloc((size_t)std::max<int64_t>(soff, 1));
-  SDM_HIP_CHECK(hipMemset(C.S.p, 0, (size_t)std::max<int64_t>(soff, 1) * sizeof(double)));   // upper triangles stay zero for good
+  const size_t sz = (size_t)std::max<int64_t>(soff, 1);
+  C.S.alloc(sz); C.Tarena.alloc(C.n_items ? sz : 1);
+  SDM_HIP_CHECK(hipMemset(C.S.p, 0, sz * sizeof(double)));            // upper triangles stay zero for good
   C.xfin.alloc((size_t)std::max<sdm_int>(C.m, 1)); C.zdiv.alloc((size_t)std::max<sdm_int>(C.m, 1));
-  C.ttmp.alloc((size_t)std::max(tslots, 1) * 128 * 128);
-  // growth records (2 per super-block), then the completion counters of k_sprep (4 ints = 2 words per super-block)
-  C.sb_g.alloc((size_t)std::max(4 * sb, 4)); C.sb_cnt.alloc((size_t)std::max(sb, 1));
-  SDM_HIP_CHECK(hipMemset(C.sb_g.p, 0, (size_t)std::max(4 * sb, 4) * sizeof(unsigned long long)));
-  SDM_HIP_CHECK(hipMemset(C.sb_cnt.p, 0, (size_t)std::max(sb, 1) * sizeof(int)));
-  C.sfront_cnt.alloc((size_t)2 * std::max(sb, 1) + 4);
-  SDM_HIP_CHECK(hipMemset(C.sfront_cnt.p, 0, C.sfront_cnt.n * sizeof(int)));
-  // fw, ./d, bw of a one-front factor without rows below as ONE launch (k_solve_front): opt-in until it has been timed
-  C.solve_fused = getenv("SDM_SOLVE_FUSED") != nullptr && nsuper == 1 && C.sn_ms[0] == C.sn_ns[0] &&
-                  (C.sn_ns[0] + SROWS - 1) / SROWS <= SFRONT_MAX_WGS;
+  // growth records (2 words per super-block), then the completion counters of k_sprep (SPREP_NCNT ints per super-block)
+  const size_t gw = (size_t)std::max(sb, 1) * (2 + SPREP_NCNT / 2);
+  C.sb_g.alloc(gw);
+  SDM_HIP_CHECK(hipMemset(C.sb_g.p, 0, gw * sizeof(unsigned long long)));
   // levels
   C.slev.assign(C.nlevels, SolveLevel());
   for (int l = 0; l < C.nlevels; l++) {
     SolveLevel &L = C.slev[l];
     L.nfronts = C.levptr[l + 1] - C.levptr[l];
-    int nsteps = 0;
     for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) {
       const int s = C.levlist[i], ns = C.sn_ns[s], ms = C.sn_ms[s];
       L.maxns = std::max(L.maxns, ns); L.maxms = std::max(L.maxms, ms);
       if (C.childptr[s + 1] > C.childptr[s]) L.children = true;
       if (ms > ns) L.below = true;
-      const int nsb = (ns + SBW - 1) / SBW;
-      nsteps = std::max(nsteps, nsb - 1 + (ms > ns ? 1 : 0));
     }
-    L.nsb = (L.maxns + SBW - 1) / SBW;
-    L.maxslab_fw.assign(nsteps, 0);
+    L.nsb = (L.maxns + W - 1) / W;
+    L.slabs_fw.assign(L.nsb, 0);
     for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) {
       const int s = C.levlist[i], ns = C.sn_ns[s], ms = C.sn_ms[s];
-      for (int Pb = 0; Pb < nsteps && Pb * SBW < ns; Pb++) {
-        const int ra = (Pb + 1) * SBW;
-        const int slabsA = ns > ra ? (ns - ra + SROWS - 1) / SROWS : 0;
-        const int slabsB = ms > ns ? (ms - (ns & ~1) + SROWS - 1) / SROWS : 0;
-        L.maxslab_fw[Pb] = std::max(L.maxslab_fw[Pb], slabsA + slabsB);
+      for (int Pb = 0; Pb * W < ns; Pb++) {
+        const int rmin = ns > (Pb + 1) * W ? (Pb + 1) * W : ns;        // first row that receives something from block Pb
+        if (rmin >= ms) continue;
+        const int rstart = ns > (Pb + 1) * W ? (Pb + 1) * W : (ns & ~1);
+        L.slabs_fw[Pb] = std::max(L.slabs_fw[Pb], (ms - rstart + SROWS - 1) / SROWS);
       }
     }
   }
@@ -220,7 +243,7 @@ __device__ __forceinline__ double store_tile(double *dst, int64_t ld, const doub
 }
 
 // ================================================================ inversion of the diagonal super-blocks
-// One workgroup per 128-column block h of a front, bottom-up, everything in LDS / registers:
+// Leaves.  One workgroup per 128-column block h of a front, bottom-up, everything in LDS / registers:
 //   32x32  each of the four wavefronts inverts one 32x32 unit lower triangular diagonal block by columns (lane j owns
 //          column j of the inverse in registers; the entries of L come as broadcast LDS reads at compile-time offsets);
 //   64x64  X10 = -inv(A11) (A10 inv(A00)) for the two 64-column blocks A and C (matrix cores, two wavefronts each);
@@ -228,14 +251,15 @@ __device__ __forceinline__ double store_tile(double *dst, int64_t ld, const doub
 // Results go to S; max|inv| and max|L| to sb_g (growth check).
 template <bool WT>
 __device__ __forceinline__ void sinv128_body(char *smem, const double *__restrict__ F, double *__restrict__ S, const FrontTab &tab,
-                                             const int *it, unsigned long long *sb_g) {
+                                             const int *it, unsigned long long *sb_g, int W) {
   double *bufA = (double *)smem, *bufC = bufA + 64 * TP, *bufB = bufC + 64 * TP, *bufT = bufB + 64 * TP;
   const int s = it[0], h = it[1];
   const int ns = tab.ns[s], ld = tab.ld[s], sld = tab.sld[s];
   const double *Fs = F + tab.foff[s];
-  double *Ss = S + tab.soff[s];
   const int k0 = 128 * h, nbA = min(64, ns - k0), nbC = max(0, min(64, ns - k0 - 64));
-  unsigned long long *gP = sb_g + 2 * (tab.sboff[s] + k0 / SBW);
+  const int Pb = k0 / W, kl = k0 - Pb * W;                          // super-block of the leaf, its first column inside it
+  double *Ss = S + tab.soff[s] + (int64_t)Pb * W * sld;
+  unsigned long long *gP = sb_g + 2 * (tab.sboff[s] + Pb);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double vB[SPT];
   SDM_PHASE_BEGIN();
@@ -354,8 +378,8 @@ __device__ __forceinline__ void sinv128_body(char *smem, const double *__restric
   // inverses to S (lower triangles incl. the unit diagonal; the upper triangles of S are zero and stay zero)
   for (int e = tid; e < 64 * 64; e += ST) {
     const int i = e & 63, j = e >> 6;
-    if (i >= j && i < nbA) { if (WT) sdm_store_wt(&Ss[(int64_t)(k0 + j) * sld + k0 + i], bufA[i * TP + j]); else Ss[(int64_t)(k0 + j) * sld + k0 + i] = bufA[i * TP + j]; }
-    if (i >= j && i < nbC) { if (WT) sdm_store_wt(&Ss[(int64_t)(k0 + 64 + j) * sld + k0 + 64 + i], bufC[j * TP + i]); else Ss[(int64_t)(k0 + 64 + j) * sld + k0 + 64 + i] = bufC[j * TP + i]; }
+    if (i >= j && i < nbA) { if (WT) sdm_store_wt(&Ss[(int64_t)(kl + j) * sld + kl + i], bufA[i * TP + j]); else Ss[(int64_t)(kl + j) * sld + kl + i] = bufA[i * TP + j]; }
+    if (i >= j && i < nbC) { if (WT) sdm_store_wt(&Ss[(int64_t)(kl + 64 + j) * sld + kl + 64 + i], bufC[j * TP + i]); else Ss[(int64_t)(kl + 64 + j) * sld + kl + 64 + i] = bufC[j * TP + i]; }
   }
   SDM_PHASE(4);
   if (nbC <= 0) return;
@@ -371,58 +395,48 @@ __device__ __forceinline__ void sinv128_body(char *smem, const double *__restric
   acc_to_lds_rowmajor(acc, bufB, wave, lane, -1.0);
   __syncthreads();
   SDM_PHASE(5);
-  const double gm = store_tile<WT>(Ss + (int64_t)k0 * sld + k0 + 64, sld, bufB, nbC, 64, tid);
+  const double gm = store_tile<WT>(Ss + (int64_t)kl * sld + kl + 64, sld, bufB, nbC, 64, tid);
   wave_atomic_max(gP, gm, lane);
   SDM_PHASE(6);
 }
 __global__ void __launch_bounds__(ST)
-k_sinv128(const double *__restrict__ F, double *__restrict__ S, FrontTab tab, const int *items, unsigned long long *sb_g) {
+k_sinv128(const double *__restrict__ F, double *__restrict__ S, FrontTab tab, const int *items, unsigned long long *sb_g, int W) {
   SDM_DYN_SMEM(smem);
-  sinv128_body<false>(smem, F, S, tab, items + 4 * blockIdx.x, sb_g);
+  sinv128_body<false>(smem, F, S, tab, items + 4 * blockIdx.x, sb_g, W);
 }
 
-// Generic product tile  C(64x64) = sgn * sum_k A(:,k) B(k,:)  for the remaining stages:
-//   mode 0  T(I,J)  = sum_{K>=J} B2(I,K) inv(A2)(K,J)          (level 3, first half; into the scratch ttmp)
-//   mode 1  X(I,J)  = - sum_{K<=I} inv(C2)(I,K) T(K,J)         (level 3, second half; into S)
-//   mode 2  S_PQ tile (I,J) = sum_{K<=I} inv(L_PP)(I,K) L(P rows K, columns J)     (premultiplication; into S)
+// Combine levels.  Level lev joins the inverses of neighbouring column ranges of half width h = 128 << lev inside a
+// super-block:  inv([A 0; B C]) = [inv(A) 0; -inv(C) B inv(A), inv(C)]  with A = columns a0 .. a0+h-1, C = the nc <= h
+// columns behind them.  One 64x64 tile of one of the two products per item {s, Pb, lev, pair, I, J, stage, wait}:
+//   stage 0  T(I, J)   =   sum_{K >= J} B(I, K) inv(A)(K, J)        B = L(C rows, A columns) from the factor; T into the scratch arena
+//   stage 1  X21(I, J) = - sum_{K <= I} inv(C)(I, K) T(K, J)        into S
+// (both triangular in K: only the 64-blocks that can be non-zero are multiplied).
 template <bool WT>
-__device__ __forceinline__ void stile_body(char *smem, const double *F, double *S, double *ttmp, const FrontTab &tab, const int *it,
-                                           unsigned long long *sb_g, int mode, double thr) {
+__device__ __forceinline__ void stile_body(char *smem, const double *F, double *S, double *T, const FrontTab &tab, const int *it,
+                                           unsigned long long *sb_g, int W) {
   double *As = (double *)smem, *Bs = As + 64 * TP;
-  const int s = it[0], Pb = it[1];
+  const int s = it[0], Pb = it[1], lev = it[2], pi = it[3], I = it[4], J = it[5], stage = it[6];
   const int ns = tab.ns[s], ld = tab.ld[s], sld = tab.sld[s];
+  const int P0 = Pb * W, nb = min(W, ns - P0);
+  const int h = 128 << lev, a0 = pi * 2 * h, nc = min(h, nb - a0 - h);
   const double *Fs = F + tab.foff[s];
-  double *Ss = S + tab.soff[s];
-  const int k0 = Pb * SBW, nb = min(SBW, ns - k0);
+  double *Sb = S + tab.soff[s] + (int64_t)P0 * sld, *Tb = T + tab.soff[s] + (int64_t)P0 * sld;
   unsigned long long *gP = sb_g + 2 * (tab.sboff[s] + Pb);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const double *Ap, *Bp; double *Cp;
-  int64_t lda, ldb, ldc;
-  int arows, kvalid;
-  double sgn = 1.0;
-  bool track_l = false, track_g = false;
-  if (mode == 0) {
-    const int I = it[2] >> 1, J = it[2] & 1;
-    arows = min(64, nb - 128 - 64 * I); kvalid = 128 - 64 * J;
-    Ap = Fs + (int64_t)(k0 + 64 * J) * ld + k0 + 128 + 64 * I; lda = ld;
-    Bp = Ss + (int64_t)(k0 + 64 * J) * sld + k0 + 64 * J; ldb = sld;
-    Cp = ttmp + (int64_t)it[3] * 128 * 128 + (int64_t)(64 * J) * 128 + 64 * I; ldc = 128;
-    track_l = true;
-  } else if (mode == 1) {
-    const int I = it[2] >> 1, J = it[2] & 1;
-    arows = min(64, nb - 128 - 64 * I); kvalid = min(64 * (I + 1), nb - 128);
-    Ap = Ss + (int64_t)(k0 + 128) * sld + k0 + 128 + 64 * I; lda = sld;
-    Bp = ttmp + (int64_t)it[3] * 128 * 128 + (int64_t)(64 * J) * 128; ldb = 128;
-    Cp = Ss + (int64_t)(k0 + 64 * J) * sld + k0 + 128 + 64 * I; ldc = sld;
-    sgn = -1.0; track_g = true;
+  int64_t lda, ldb;
+  const int arows = min(64, nc - 64 * I);
+  int kvalid;
+  if (stage == 0) {
+    kvalid = h - 64 * J;
+    Ap = Fs + (int64_t)(P0 + a0 + 64 * J) * ld + P0 + a0 + h + 64 * I; lda = ld;
+    Bp = Sb + (int64_t)(a0 + 64 * J) * sld + a0 + 64 * J; ldb = sld;
+    Cp = Tb + (int64_t)(a0 + 64 * J) * sld + a0 + h + 64 * I;
   } else {
-    if (WT ? !(bits_to_double(sdm_load_wt_u64(&sb_g[2 * (tab.sboff[s] + Pb)])) * bits_to_double(sdm_load_wt_u64(&sb_g[2 * (tab.sboff[s] + Pb) + 1])) <= thr)
-           : sb_is_bad(sb_g, tab.sboff[s] + Pb, thr)) return;       // this block row stays unpremultiplied
-    const int I = it[2], J = it[3];
-    arows = min(64, nb - 64 * I); kvalid = min(64 * (I + 1), nb);
-    Ap = Ss + (int64_t)k0 * sld + k0 + 64 * I; lda = sld;
-    Bp = Fs + (int64_t)(64 * J) * ld + k0; ldb = ld;
-    Cp = Ss + (int64_t)(64 * J) * sld + k0 + 64 * I; ldc = sld;
+    kvalid = min(64 * (I + 1), nc);
+    Ap = Sb + (int64_t)(a0 + h) * sld + a0 + h + 64 * I; lda = sld;
+    Bp = Tb + (int64_t)(a0 + 64 * J) * sld + a0 + h; ldb = sld;
+    Cp = Sb + (int64_t)(a0 + 64 * J) * sld + a0 + h + 64 * I;
   }
   Acc22 acc;
   acc_zero(acc);
@@ -442,28 +456,25 @@ __device__ __forceinline__ void stile_body(char *smem, const double *F, double *
     mma_block(acc, As, Bs, wave, lane);
     __syncthreads();
   }
-  SDM_PHASE(8 + 4 * mode);
-  if (track_l) wave_atomic_max(gP + 1, lmx, lane);
-  acc_to_lds_rowmajor(acc, As, wave, lane, sgn);
+  SDM_PHASE(8 + 4 * stage);
+  if (stage == 0) wave_atomic_max(gP + 1, lmx, lane);                // max |L| over the off-diagonal blocks of the super-block
+  acc_to_lds_rowmajor(acc, As, wave, lane, stage == 0 ? 1.0 : -1.0);
   __syncthreads();
-  const double gm = store_tile<WT>(Cp, ldc, As, arows, 64, tid);
-  if (track_g) wave_atomic_max(gP, gm, lane);
-  SDM_PHASE(9 + 4 * mode);
-#if defined(SDM_PHASES) && !defined(SDM_EMU)
-  if (tid == 0) atomicAdd(&sdm_phase_acc[10 + 4 * mode], 1ull);
-#endif
+  const double gm = store_tile<WT>(Cp, sld, As, arows, 64, tid);
+  if (stage == 1) wave_atomic_max(gP, gm, lane);                     // max |inverse|
+  SDM_PHASE(9 + 4 * stage);
 }
 __global__ void __launch_bounds__(ST)
-k_stile(const double *F, double *S, double *ttmp, FrontTab tab, const int *items, unsigned long long *sb_g, int mode, double thr) {
+k_stile(const double *F, double *S, double *T, FrontTab tab, const int *items, unsigned long long *sb_g, int W) {
   SDM_DYN_SMEM(smem);
-  stile_body<false>(smem, F, S, ttmp, tab, items + 4 * blockIdx.x, sb_g, mode, thr);
+  stile_body<false>(smem, F, S, T, tab, items + 8 * blockIdx.x, sb_g, W);
 }
 
 // ---- all of the above in ONE launch for problems whose items fit the device at once (k_sprep): workgroups take the
-// items in the order 128-blocks, level-3 first halves, level-3 second halves, premultiplication tiles, and wait on
-// per-super-block completion counters instead of on launch boundaries (three of them, ~4 us each, and their tails).
-// Producers store write-through, count after their stores are acknowledged; consumers poll with acquire loads.
-// cnt[4*sb + 0/1/2] = finished 128-blocks / first halves / second halves of super-block sb (zeroed with sb_g).
+// items in the order leaves, level 0 stage T, level 0 stage X, level 1 stage T, ... and wait on per-super-block completion
+// counters instead of on launch boundaries.  Producers store write-through and count after their stores are
+// acknowledged; consumers poll relaxed and read with sc1 loads.
+// cnt[SPREP_NCNT * sb + 0] = finished leaves, [1 + st] = finished tiles of stage st (zeroed with sb_g by k_prep_pivots).
 __device__ __forceinline__ void prep_wait(const int *cnt, int target, int *tmo) {
   if (threadIdx.x == 0) {
     long it = 0;
@@ -478,38 +489,29 @@ __device__ __forceinline__ void prep_done(int *cnt) {
   if (threadIdx.x == 0) sdm_signal_add(cnt);
 }
 __global__ void __launch_bounds__(ST)
-k_sprep(const double *F, double *S, double *ttmp, FrontTab tab, const int *l_i128, int n_i128, const int *l_t3, int n_t3,
-        const int *l_pm, int n_pm, unsigned long long *sb_g, int *cnt, double thr, int *tmo) {
+k_sprep(const double *F, double *S, double *T, FrontTab tab, const int *l_i128, int n_i128, const int *l_items,
+        unsigned long long *sb_g, int *cnt, int W, int *tmo) {
   SDM_DYN_SMEM(smem);
-  int b = blockIdx.x;
+  const int b = blockIdx.x;
   if (b < n_i128) {
     const int *it = l_i128 + 4 * b;
-    sinv128_body<true>(smem, F, S, tab, it, sb_g);
-    // the growth maxima (atomicMax, device scope) are read by the premultiplication tiles of this launch as well
-    prep_done(cnt + 4 * (tab.sboff[it[0]] + (128 * it[1]) / SBW));
+    sinv128_body<true>(smem, F, S, tab, it, sb_g, W);
+    prep_done(cnt + SPREP_NCNT * (tab.sboff[it[0]] + (128 * it[1]) / W));
     return;
   }
-  b -= n_i128;
-  const int mode = b < n_t3 ? 0 : (b < 2 * n_t3 ? 1 : 2);
-  const int *it = mode == 2 ? l_pm + 4 * (b - 2 * n_t3) : l_t3 + 4 * (b - mode * n_t3);
-  const int s = it[0], Pb = it[1];
-  const int nb = min(SBW, tab.ns[s] - Pb * SBW);
-  const int n128 = (nb + 127) / 128, nt = nb > 128 ? 2 * ((nb - 128 + 63) / 64) : 0;
-  int *c = cnt + 4 * (tab.sboff[s] + Pb);
-  prep_wait(c, n128, tmo);
-  if (mode == 1) prep_wait(c + 1, nt, tmo);
-  if (mode == 2 && nt > 0) prep_wait(c + 2, nt, tmo);
-  stile_body<true>(smem, F, S, ttmp, tab, it, sb_g, mode, thr);
-  if (mode < 2) prep_done(c + 1 + mode);
+  const int *it = l_items + 8 * (b - n_i128);
+  const int st = 2 * it[2] + it[6];
+  int *c = cnt + SPREP_NCNT * (tab.sboff[it[0]] + it[1]);
+  prep_wait(c + st, it[7], tmo);
+  stile_body<true>(smem, F, S, T, tab, it, sb_g, W);
+  prep_done(c + st + 1);
 }
 
 // ================================================================ substitution fallback for one super-block
-// Rare path (growth check failed): L_PP y = r  /  L_PP' x = v  in place on nb <= SBW entries at yp, by ONE workgroup.
-// Fs = front, (k0, k0) = position of the block.  Sd = 64*TP doubles, w = SBW doubles of LDS.
-__device__ __noinline__ void block_solve_fw(const double *Fs, int ld, int k0, int nb, double *yp, double *w, double *Sd) {
+// Rare path (growth check failed): L_PP y = r  /  L_PP' x = v  in place on the nb entries w (LDS) by ONE workgroup.
+// Fs = front, (k0, k0) = position of the block.  Sd = 64*TP doubles of LDS.
+__device__ __noinline__ void block_solve_fw(const double *Fs, int ld, int k0, int nb, double *w, double *Sd) {
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int i = tid; i < nb; i += ST) w[i] = yp[i];
-  __syncthreads();
   for (int kk = 0; kk < nb; kk += 64) {
     const int kb = min(64, nb - kk);
     for (int e = tid; e < 64 * 64; e += ST) {
@@ -530,12 +532,9 @@ __device__ __noinline__ void block_solve_fw(const double *Fs, int ld, int k0, in
     }
     __syncthreads();
   }
-  for (int i = tid; i < nb; i += ST) yp[i] = w[i];
 }
-__device__ __noinline__ void block_solve_bw(const double *Fs, int ld, int k0, int nb, double *yp, double *w, double *Sd) {
+__device__ __noinline__ void block_solve_bw(const double *Fs, int ld, int k0, int nb, double *w, double *Sd) {
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int i = tid; i < nb; i += ST) w[i] = yp[i];
-  __syncthreads();
   for (int kk = ((nb - 1) / 64) * 64; kk >= 0; kk -= 64) {
     const int kb = min(64, nb - kk);
     for (int e = tid; e < 64 * 64; e += ST) {
@@ -556,45 +555,127 @@ __device__ __noinline__ void block_solve_bw(const double *Fs, int ld, int k0, in
     }
     __syncthreads();
   }
-  for (int i = tid; i < nb; i += ST) yp[i] = w[i];
 }
-// The nsl workgroups that complete the right-hand side of a BAD super-block each call this after their stores; the
-// last arriver solves the block in place.  (All stores acknowledged, barrier, agent-scope release by one work-item,
-// ticket; the winner acquires.)
-template <bool FW>
-__device__ __forceinline__ void bad_block_arrive(const double *Fs, int ld, int k0, int nb, double *yp, int *cnt, int nsl, double *w,
-                                                 double *Sd, double *zp = nullptr, const double *dp = nullptr, bool also_bw = false) {
-  __shared__ int last;
-  SDM_STORES_DONE();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    const int t = atomicAdd(cnt, 1);
-    last = t == nsl - 1;
-    if (last) atomicExch(cnt, 0);                                   // ready for the next solve
+
+// ================================================================ slab products
+// Every kernel below issues its matrix loads FIRST (registers), then fetches the vector it multiplies with (written by the
+// previous launch) into LDS, then multiplies: the two memory latencies overlap.
+// Forward: sum_c M(r, c) xs[c] for the SROWS rows rbase .. of one slab over ncols columns.  Work-item (p = tid & 7,
+// g = tid >> 3) owns row pair p and the columns g, g+32, ...; 16-byte loads, NL of them in flight; fixed-order
+// reduction over g.  rbase even; rows are clamped to the last valid pair (rlast = last valid row).
+template <int NL>
+__device__ __forceinline__ void slab_issue(sdm_double2 (&v)[NL], const double *M, int64_t ldm, int ncols, int rbase, int rlast) {
+  const int tid = threadIdx.x, p = tid & 7, g = tid >> 3;
+  const int r = min(rbase + 2 * p, rlast & ~1);
+  const sdm_double2 *col = (const sdm_double2 *)(M + r);
+  const int64_t ld2 = ldm >> 1;
+#pragma unroll
+  for (int j = 0; j < NL; j++) v[j] = col[(int64_t)min(g + 32 * j, ncols - 1) * ld2];
+}
+template <int NL>
+__device__ __forceinline__ void slab_accum(const sdm_double2 (&v)[NL], int ncols, const double *xs, double &a0, double &a1) {
+  const int g = threadIdx.x >> 3;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    const int c = g + 32 * j;
+    const double xc = c < ncols ? xs[c] : 0.0;
+    a0 += v[j].x * xc; a1 += v[j].y * xc;
   }
-  __syncthreads();
-  if (!last) return;
-  SDM_ACQUIRE_FENCE();
-  if (FW) block_solve_fw(Fs, ld, k0, nb, yp, w, Sd); else block_solve_bw(Fs, ld, k0, nb, yp, w, Sd);
-  if (FW && zp) {                                                    // the block is final: its ./d copy for the backward sweep
-    __syncthreads();
-    for (int i = threadIdx.x; i < nb; i += ST) { const double dk = dp[i]; zp[i] = yp[i] / (dk > 0.0 ? dk : 1.0); }
-    if (also_bw) {                                                   // last block of a front without rows below: x = L_PP' \ z right away
-      SDM_STORES_DONE();
-      __syncthreads();
-      block_solve_bw(Fs, ld, k0, nb, zp, w, Sd);
+}
+// the whole product of a slab: groups of up to GRPW columns; fill() loads xs[0 .. ncols) (its barrier is ours) after the
+// first group's matrix loads have been issued.  Result for row rbase + t in work-items t < SROWS.
+template <class Fill>
+__device__ __forceinline__ double fw_product(const double *M, int64_t ldm, int ncols, int rbase, int rlast, const double *xs, double *red, Fill fill) {
+  const int tid = threadIdx.x, p = tid & 7, g = tid >> 3;
+  double a0 = 0.0, a1 = 0.0;
+  bool filled = false;
+  for (int c0 = 0; c0 < ncols; c0 += GRPW) {
+    const int n = min(GRPW, ncols - c0);
+    const double *Mg = M + (int64_t)c0 * ldm;
+    if (n <= 256) {
+      sdm_double2 v[8]; slab_issue<8>(v, Mg, ldm, n, rbase, rlast);
+      if (!filled) { fill(); __syncthreads(); filled = true; }
+      slab_accum<8>(v, n, xs + c0, a0, a1);
+    } else if (n <= 512) {
+      sdm_double2 v[16]; slab_issue<16>(v, Mg, ldm, n, rbase, rlast);
+      if (!filled) { fill(); __syncthreads(); filled = true; }
+      slab_accum<16>(v, n, xs + c0, a0, a1);
+    } else {
+      sdm_double2 v[32]; slab_issue<32>(v, Mg, ldm, n, rbase, rlast);
+      if (!filled) { fill(); __syncthreads(); filled = true; }
+      slab_accum<32>(v, n, xs + c0, a0, a1);
     }
+  }
+  red[g * SROWS + 2 * p] = a0; red[g * SROWS + 2 * p + 1] = a1;
+  __syncthreads();
+  double sum = 0.0;
+  if (tid < SROWS) {
+#pragma unroll
+    for (int q = 0; q < ST / 8; q++) sum += red[q * SROWS + tid];
+  }
+  return sum;
+}
+// Backward: sum_r M(rbase + r, c) xs[r] for the SROWS columns cbase .. of one slab over nrows rows: wavefront w owns 4
+// columns, lanes run down the row pairs (contiguous 16-byte loads, 4 * NH in flight), wave reduction in a fixed order.
+// rbase even.  Result for column cbase + 4*w + q in every lane of wavefront w as out[q].
+template <int NH>
+__device__ __forceinline__ void slabT_issue(sdm_double2 (&v)[4 * NH], const double *M, int64_t ldm, int cbase, int ncols, int rbase, int nrows) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int plast = max(((nrows + 1) >> 1) - 1, 0);
+#pragma unroll
+  for (int h = 0; h < NH; h++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c = min(cbase + 4 * wave + q, cbase + ncols - 1);
+      v[4 * h + q] = ((const sdm_double2 *)(M + (int64_t)c * ldm + rbase))[min(lane + 64 * h, plast)];
+    }
+}
+template <int NH>
+__device__ __forceinline__ void slabT_accum(const sdm_double2 (&v)[4 * NH], int nrows, const double *xs, double (&acc)[4]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int h = 0; h < NH; h++) {
+    const int pi = lane + 64 * h;
+    // rows beyond the range are dropped by selects on BOTH factors: a padding row of the front may hold anything
+    const bool in0 = 2 * pi < nrows, in1 = 2 * pi + 1 < nrows;
+    const double x0 = in0 ? xs[2 * pi] : 0.0, x1 = in1 ? xs[2 * pi + 1] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] += (in0 ? v[4 * h + q].x : 0.0) * x0 + (in1 ? v[4 * h + q].y : 0.0) * x1;
+  }
+}
+template <class Fill>
+__device__ __forceinline__ void bw_product(const double *M, int64_t ldm, int cbase, int ncols, int rbase, int nrows, const double *xs, double (&out)[4], Fill fill) {
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  bool filled = false;
+  for (int r0 = 0; r0 < nrows; r0 += GRPW) {
+    const int n = min(GRPW, nrows - r0);
+    if (n <= 256) {
+      sdm_double2 v[8]; slabT_issue<2>(v, M, ldm, cbase, ncols, rbase + r0, n);
+      if (!filled) { fill(); __syncthreads(); filled = true; }
+      slabT_accum<2>(v, n, xs + r0, acc);
+    } else if (n <= 512) {
+      sdm_double2 v[16]; slabT_issue<4>(v, M, ldm, cbase, ncols, rbase + r0, n);
+      if (!filled) { fill(); __syncthreads(); filled = true; }
+      slabT_accum<4>(v, n, xs + r0, acc);
+    } else {
+      sdm_double2 v[32]; slabT_issue<8>(v, M, ldm, cbase, ncols, rbase + r0, n);
+      if (!filled) { fill(); __syncthreads(); filled = true; }
+      slabT_accum<8>(v, n, xs + r0, acc);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    double a = acc[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    out[q] = a;
   }
 }
 
 // ================================================================ forward sweep
-// several right-hand sides side by side (blockIdx.z): element strides of the right-hand sides, of the result, of the
-// update-vector scratch and of the fallback tickets (all 0 for a single right-hand side)
-// fold_bw: the level's fronts have no rows below their own columns and the ./d copy is being written: a BAD last
-// super-block is then also substituted backward right where its forward value becomes final (the backward sweep of
-// such a level starts without k_sbw_init)
-struct FwBatch { int64_t src, y, wv, cnt; int fold_bw; };
+// several right-hand sides side by side (blockIdx.z): element strides of the right-hand sides, of the result and of the
+// update-vector scratch (all 0 for a single right-hand side)
+struct FwBatch { int64_t src, y, wv; };
 // assembly of a front's right-hand side (levels above the leaves): own entries through perm, children's update vectors
 __global__ void __launch_bounds__(ST)
 k_sfw_init(FrontTab tab, const int *list, double *wv, const double *src, const int *perm, const double *y, FwBatch bt) {
@@ -616,177 +697,85 @@ k_sfw_init(FrontTab tab, const int *list, double *wv, const double *src, const i
 }
 
 #define FT(field) (tab.one ? tab.o_##field : tab.field[s])      // front descriptor: kernel argument (one-front level) or table
-// ---- slab products.  Every kernel below issues its matrix loads FIRST (registers), then fetches the vector it
-// multiplies with (written by the previous launch) into LDS, then multiplies: the two memory latencies overlap.
-// Forward: sum_c M(r, cbase + c) xs[c] for the SROWS rows rbase .. of one slab.  Work-item (p = tid & 7, g = tid >> 3)
-// owns row pair p and the columns g, g+32, ... (ncols <= SBW = 8 x 32); 16-byte loads, 8 in flight; fixed-order
-// reduction over g.  rbase even; rows are clamped to the last valid pair (rlast = last valid row).
-constexpr int NLD = SBW / 32;
-__device__ __forceinline__ void slab_issue(sdm_double2 (&v)[NLD], const double *M, int64_t ldm, int cbase, int ncols, int rbase, int rlast) {
-  const int tid = threadIdx.x, p = tid & 7, g = tid >> 3;
-  const int r = min(rbase + 2 * p, rlast & ~1);
-  const sdm_double2 *col = (const sdm_double2 *)(M + (int64_t)cbase * ldm + r);
-  const int64_t ld2 = ldm >> 1;
-#pragma unroll
-  for (int j = 0; j < NLD; j++) v[j] = col[(int64_t)min(g + 32 * j, ncols - 1) * ld2];
-}
-// result for row rbase + t in work-items t < SROWS
-__device__ __forceinline__ double slab_consume(const sdm_double2 (&v)[NLD], int ncols, const double *xs, double *red) {
-  const int tid = threadIdx.x, p = tid & 7, g = tid >> 3;
-  double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-  for (int j = 0; j < NLD; j++) {
-    const int c = g + 32 * j;
-    const double xc = c < ncols ? xs[c] : 0.0;
-    a0 += v[j].x * xc; a1 += v[j].y * xc;
-  }
-  red[g * SROWS + 2 * p] = a0; red[g * SROWS + 2 * p + 1] = a1;
-  __syncthreads();
-  double sum = 0.0;
-  if (tid < SROWS) {
-#pragma unroll
-    for (int q = 0; q < ST / 8; q++) sum += red[q * SROWS + tid];
-  }
-  return sum;
-}
-
-// y_P = inv(L_PP) a_P for every super-block of every front of a level (bad blocks: copy, then substitution)
+// y_P = inv(L_PP) t_P for super-block Pb of every front of a level that has one; t_P = the right-hand side gathered
+// through perm (Pb = 0 of a leaf level: gather0) or the front's assembled / updated vector a.  With zdiv the ./d copy
+// (wrapPcg.m:57; skipped pivots act as 1, deninfac.m:89-94) is written as well: y_P is final here.  A block that failed
+// the growth check is substituted against the factor by workgroup 0.
 __global__ void __launch_bounds__(ST)
 k_sfw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, const double *wv, const double *src,
-           const int *perm, double *y, const unsigned long long *sb_g, int *sb_cnt, double thr, int gather, FwBatch bt,
-           double *zdiv, const double *dscale) {
-  __shared__ double xs[SBW], red[(ST / 8) * SROWS], wsub[SBW];
+           const int *perm, double *y, const unsigned long long *sb_g, double thr, int Pb, int gather0, FwBatch bt,
+           double *zdiv, const double *dscale, int W) {
+  __shared__ double xs[SBW_MAX], red[(ST / 8) * SROWS];
   __shared__ double Sd[64 * TP];
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), first = FT(first);
+  const int c0 = Pb * W;
+  if (c0 >= ns) return;
+  const int nb = min(W, ns - c0);
   const int r0 = SROWS * blockIdx.x;
-  if (r0 >= ns) return;
+  if (r0 >= nb) return;
   wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; if (src) src += (int64_t)blockIdx.z * bt.src;
-  sb_cnt += (int64_t)blockIdx.z * bt.cnt;
-  const int Pb = r0 / SBW, c0 = Pb * SBW, nb = min(SBW, ns - c0);
-  const int sb = FT(sboff) + Pb;
   const int tid = threadIdx.x;
-  const int ncols = min(nb, r0 + SROWS - c0);                       // lower triangular: columns up to the slab's last row
-  sdm_double2 v[NLD];
-  slab_issue(v, S + FT(soff), FT(sld), c0, ncols, r0, ns - 1);
-  const bool bad = sb_is_bad(sb_g, sb, thr);
-  const double *a = wv + FT(woff);
-  // the block's right-hand side: gathered through perm (leaves) or taken from the assembled vector
-  for (int c = tid; c < nb; c += ST) xs[c] = gather ? src[perm[first + c0 + c]] : a[c0 + c];
-  __syncthreads();
-  if (bad) {
-    if (tid < SROWS && r0 + tid < ns) y[first + r0 + tid] = xs[r0 - c0 + tid];
-    // block 0 has nothing left of it: its right-hand side is complete here; later blocks are completed by step Pb-1
-    if (Pb == 0) bad_block_arrive<true>(F + FT(foff), FT(ld), c0, nb, y + first + c0, sb_cnt + sb, (nb + SROWS - 1) / SROWS, wsub, Sd,
-                                         zdiv ? zdiv + first + c0 : nullptr, zdiv ? dscale + first + c0 : nullptr,
-                                         bt.fold_bw && ns <= SBW);
+  const int sld = FT(sld);
+  const double *Sb = S + FT(soff) + (int64_t)c0 * sld;
+  const double *a = wv + FT(woff) + c0;
+  const bool gather = gather0 && Pb == 0;
+  const int *pp = perm + first + c0;
+  if (sb_is_bad(sb_g, FT(sboff) + Pb, thr)) {
+    if (blockIdx.x != 0) return;
+    for (int c = tid; c < nb; c += ST) xs[c] = gather ? src[pp[c]] : a[c];
+    __syncthreads();
+    block_solve_fw(F + FT(foff), FT(ld), c0, nb, xs, Sd);
+    for (int i = tid; i < nb; i += ST) {
+      const double yv = xs[i];
+      y[first + c0 + i] = yv;
+      if (zdiv) { const double dk = dscale[first + c0 + i]; zdiv[first + c0 + i] = yv / (dk > 0.0 ? dk : 1.0); }
+    }
     return;
   }
-  const double sum = slab_consume(v, ncols, xs, red);
-  if (tid < SROWS && r0 + tid < ns) {
-    y[first + r0 + tid] = sum;
-    // block 0 is final here: its ./d copy (wrapPcg.m:57; skipped pivots act as 1, deninfac.m:89-94) for the backward sweep
-    if (zdiv && Pb == 0) { const double dk = dscale[first + r0 + tid]; zdiv[first + r0 + tid] = sum / (dk > 0.0 ? dk : 1.0); }
+  const int ncols = min(nb, r0 + SROWS);                             // lower triangular: columns up to the slab's last row
+  const double sum = fw_product(Sb, sld, ncols, r0, nb - 1, xs, red,
+                                [&]() { for (int c = tid; c < ncols; c += ST) xs[c] = gather ? src[pp[c]] : a[c]; });
+  if (tid < SROWS && r0 + tid < nb) {
+    y[first + c0 + r0 + tid] = sum;
+    if (zdiv) { const double dk = dscale[first + c0 + r0 + tid]; zdiv[first + c0 + r0 + tid] = sum / (dk > 0.0 ? dk : 1.0); }
   }
 }
 
-// step P: y_P is final; every row beyond super-block P receives  - M(r, P) y_P   (M = S for the front's own rows
-// -- F for the rows of a bad super-block -- and F for the rows below the supernode, whose sums are the update
-// vector passed to the parent)
+// step Pb: y_P is final; every row beyond super-block Pb -- the front's own rows of later blocks and the rows of its
+// ancestors, whose sums are the update vector passed to the parent -- receives  - L(r, P) y_P , read from the factor.
+// assign0 (Pb = 0 of a leaf level): the vector a has not been initialised: a = right-hand side (own rows) / 0 - sum.
 __global__ void __launch_bounds__(ST)
-k_sfw_step(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, double *wv, double *y,
-           const unsigned long long *sb_g, int *sb_cnt, double thr, int Pb, int first_assign, FwBatch bt, double *zdiv,
-           const double *dscale) {
-  __shared__ double xs[SBW], red[(ST / 8) * SROWS], wsub[SBW];
-  __shared__ double Sd[64 * TP];
+k_sfw_step(const double *__restrict__ F, FrontTab tab, const int *list, double *wv, const double *src, const int *perm, const double *y,
+           int Pb, int assign0, FwBatch bt, int W) {
+  __shared__ double xs[SBW_MAX], red[(ST / 8) * SROWS];
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), ms = FT(ms), first = FT(first), ld = FT(ld);
-  const int c0 = Pb * SBW;
+  const int c0 = Pb * W;
   if (c0 >= ns) return;
-  wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; sb_cnt += (int64_t)blockIdx.z * bt.cnt;
-  const int nb = min(SBW, ns - c0), ra = c0 + SBW;
-  const int slabsA = ns > ra ? (ns - ra + SROWS - 1) / SROWS : 0;
-  const int ebase = ns & ~1;
-  const int slabsB = ms > ns ? (ms - ebase + SROWS - 1) / SROWS : 0;
-  const int bx = blockIdx.x;
-  if (bx >= slabsA + slabsB) return;
+  const int nb = min(W, ns - c0);
+  const bool more = ns > c0 + W;                                     // later super-blocks of the front itself
+  const int rmin = more ? c0 + W : ns, rstart = more ? c0 + W : (ns & ~1);
+  const int r0 = rstart + SROWS * blockIdx.x;
+  if (rmin >= ms || r0 >= ms) return;
+  wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; if (src) src += (int64_t)blockIdx.z * bt.src;
   const int tid = threadIdx.x;
-  const double *Fs = F + FT(foff);
-  const bool regA = bx < slabsA;
-  const int r0 = regA ? ra + SROWS * bx : ebase + SROWS * (bx - slabsA);
-  sdm_double2 v[NLD];
-  // the front's own rows come from S (issued before the growth flag of their block is known: S is valid memory
-  // either way); the rows below the supernode from the factor itself
-  if (regA) slab_issue(v, S + FT(soff), FT(sld), c0, nb, r0, ns - 1);
-  else slab_issue(v, Fs, ld, c0, nb, r0, ms - 1);
-  const int Pr = r0 / SBW, sbr = FT(sboff) + Pr;
-  const bool bad = regA && sb_is_bad(sb_g, sbr, thr);
-  for (int c = tid; c < nb; c += ST) xs[c] = y[first + c0 + c];
-  __syncthreads();
-  if (bad) slab_issue(v, Fs, ld, c0, nb, r0, ns - 1);               // rare: the rows of a bad block were not premultiplied
-  const double sum = slab_consume(v, nb, xs, red);
-  if (regA) {
-    if (tid < SROWS && r0 + tid < ns) {
-      const double yv = y[first + r0 + tid] - sum;
-      y[first + r0 + tid] = yv;
-      // block Pb+1 receives its last contribution in this step: final (unless it still has to be solved by substitution)
-      if (zdiv && Pr == Pb + 1 && !bad) { const double dk = dscale[first + r0 + tid]; zdiv[first + r0 + tid] = yv / (dk > 0.0 ? dk : 1.0); }
-    }
-    if (bad && Pr == Pb + 1) {                                      // this step completes the right-hand side of block Pr
-      const int nbr = min(SBW, ns - Pr * SBW);
-      bad_block_arrive<true>(Fs, ld, Pr * SBW, nbr, y + first + Pr * SBW, sb_cnt + sbr, (nbr + SROWS - 1) / SROWS, wsub, Sd,
-                             zdiv ? zdiv + first + Pr * SBW : nullptr, zdiv ? dscale + first + Pr * SBW : nullptr,
-                             bt.fold_bw && (Pr + 1) * SBW >= ns);
-    }
-  } else {
-    double *u = wv + FT(woff);
-    const int r = r0 + tid;
-    if (tid < SROWS && r >= ns && r < ms) u[r] = first_assign ? -sum : u[r] - sum;
+  const double *yp = y + first + c0;
+  const double sum = fw_product(F + FT(foff) + (int64_t)c0 * ld, ld, nb, r0, ms - 1, xs, red,
+                                [&]() { for (int c = tid; c < nb; c += ST) xs[c] = yp[c]; });
+  double *a = wv + FT(woff);
+  const int r = r0 + tid;
+  if (tid < SROWS && r >= rmin && r < ms) {
+    const double base = assign0 ? (r < ns ? src[perm[first + r]] : 0.0) : a[r];
+    a[r] = base - sum;
   }
 }
 
 // ================================================================ backward sweep
-// sum_r M(rbase + r, c) xs[r] for the SROWS columns cbase .. of one slab over at most SBW rows: wavefront w owns 4
-// columns, lanes run down the row pairs (contiguous 16-byte loads, 8 in flight), wave reduction in a fixed order.
-// rbase even.  Result for column cbase + 4*w + q in every lane of wavefront w as out[q].
-__device__ __forceinline__ void slabT_issue(sdm_double2 (&v)[8], const double *M, int64_t ldm, int cbase, int ncols, int rbase, int nrows) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int plast = max(((nrows + 1) >> 1) - 1, 0);
-#pragma unroll
-  for (int h = 0; h < 2; h++)
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int c = min(cbase + 4 * wave + q, cbase + ncols - 1);
-      v[4 * h + q] = ((const sdm_double2 *)(M + (int64_t)c * ldm + rbase))[min(lane + 64 * h, plast)];
-    }
-}
-__device__ __forceinline__ void slabT_consume(const sdm_double2 (&v)[8], int nrows, const double *xs, double (&out)[4]) {
-  const int lane = threadIdx.x & 63;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    const int pi = lane + 64 * h;
-    // rows beyond the range are dropped by selects on BOTH factors: a padding row of the front may hold anything
-    const bool in0 = 2 * pi < nrows, in1 = 2 * pi + 1 < nrows;
-    const double x0 = in0 ? xs[2 * pi] : 0.0, x1 = in1 ? xs[2 * pi + 1] : 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) acc[q] += (in0 ? v[4 * h + q].x : 0.0) * x0 + (in1 ? v[4 * h + q].y : 0.0) * x1;
-  }
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    double a = acc[q];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-    out[q] = a;
-  }
-}
-
 // v = z ./ d  -  (rows below the supernode)' x_ancestors   for every column of every front of a level
 __global__ void __launch_bounds__(ST)
-k_sbw_init(const double *__restrict__ F, FrontTab tab, const int *list, double *y, const double *xfin, const double *dscale,
-           const unsigned long long *sb_g, int *sb_cnt, double thr) {
-  __shared__ double xs[SBW], wsub[SBW];
-  __shared__ double Sd[64 * TP];
+k_sbw_init(const double *__restrict__ F, FrontTab tab, const int *list, double *y, const double *xfin, const double *dscale) {
+  __shared__ double xs[256];
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), ms = FT(ms), first = FT(first), ld = FT(ld);
   const int c0 = SROWS * blockIdx.x;
@@ -798,18 +787,22 @@ k_sbw_init(const double *__restrict__ F, FrontTab tab, const int *list, double *
   double tot[4] = {0.0, 0.0, 0.0, 0.0};
   const int ebase = ns & ~1;
   if (ms > ns) {
-    for (int rb = ebase; rb < ms; rb += SBW) {                      // ancestors' entries, gathered SBW at a time
-      const int nr = min(SBW, ms - rb);
+    for (int rb = ebase; rb < ms; rb += 256) {                      // ancestors' entries, gathered 256 at a time
+      const int nr = min(256, ms - rb);
       sdm_double2 v[8];
-      slabT_issue(v, Fs, ld, c0, ncols, rb, nr);
+      slabT_issue<2>(v, Fs, ld, c0, ncols, rb, nr);
       __syncthreads();
       for (int i = tid; i < nr; i += ST) xs[i] = rb + i >= ns ? xfin[rows[rb + i]] : 0.0;
       __syncthreads();
-      double part[4];
-      slabT_consume(v, nr, xs, part);
-#pragma unroll
-      for (int q = 0; q < 4; q++) tot[q] += part[q];
+      slabT_accum<2>(v, nr, xs, tot);
     }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    double a = tot[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    tot[q] = a;
   }
   if (lane == 0) {
 #pragma unroll
@@ -823,240 +816,71 @@ k_sbw_init(const double *__restrict__ F, FrontTab tab, const int *list, double *
       }
     }
   }
-  // the last super-block of a front has nothing above it in this sweep: if bad, it is solved once all its columns are set
-  const int nsb = (ns + SBW - 1) / SBW, Pl = nsb - 1;
-  if (c0 / SBW == Pl && sb_is_bad(sb_g, FT(sboff) + Pl, thr)) {
-    const int nbl = ns - Pl * SBW;
-    bad_block_arrive<false>(Fs, ld, Pl * SBW, nbl, y + first + Pl * SBW, sb_cnt + FT(sboff) + Pl, (nbl + SROWS - 1) / SROWS, wsub, Sd);
-  }
 }
 
-// step Q: v_Q (x_Q for a bad block) is final; every column left of super-block Q receives  - M(Q rows, c)' v_Q
+// x_Q = inv(L_QQ)' v_Q for super-block Q of every front of a level that has one; the result goes to xfin (descendants
+// and the step launch read it) and, scattered through perm, to yout.  A block that failed the growth check is
+// substituted against the factor by workgroup 0.
 __global__ void __launch_bounds__(ST)
-k_sbw_step(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, double *y,
-           const unsigned long long *sb_g, int *sb_cnt, double thr, int Q) {
-  __shared__ double xs[SBW], wsub[SBW];
+k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, const double *y, double *xfin, double *yout,
+           const int *perm, const unsigned long long *sb_g, double thr, int Q, int W) {
+  __shared__ double xs[SBW_MAX];
   __shared__ double Sd[64 * TP];
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
-  const int ns = FT(ns), first = FT(first), ld = FT(ld);
-  const int rb = Q * SBW;
-  if (rb >= ns) return;
-  const int nbq = min(SBW, ns - rb);
-  const int c0 = SROWS * blockIdx.x;                                // < rb by the grid
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const double *Fs = F + FT(foff);
-  sdm_double2 v[8];
-  slabT_issue(v, S + FT(soff), FT(sld), c0, SROWS, rb, nbq);  // before the growth flag is known (S is valid memory either way)
-  const bool badq = sb_is_bad(sb_g, FT(sboff) + Q, thr);
-  for (int i = tid; i < nbq; i += ST) xs[i] = y[first + rb + i];
-  __syncthreads();
-  if (badq) slabT_issue(v, Fs, ld, c0, SROWS, rb, nbq);             // rare: the rows of a bad block were not premultiplied
-  double part[4];
-  slabT_consume(v, nbq, xs, part);
-  if (lane == 0) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) y[first + c0 + 4 * wave + q] -= part[q];
-  }
-  const int Pc = c0 / SBW;
-  if (Pc == Q - 1 && sb_is_bad(sb_g, FT(sboff) + Pc, thr))      // this step completes v of block Q-1
-    bad_block_arrive<false>(Fs, ld, Pc * SBW, SBW, y + first + Pc * SBW, sb_cnt + FT(sboff) + Pc, SBW / SROWS, wsub, Sd);
-}
-
-// x_P = inv(L_PP)' v_P ; the result goes to xfin (descendants read it) and, scattered through perm, to yout
-__global__ void __launch_bounds__(ST)
-k_sbw_diag(const double *__restrict__ S, FrontTab tab, const int *list, const double *y, double *xfin, double *yout, const int *perm,
-           const unsigned long long *sb_g, double thr) {
-  __shared__ double xs[SBW];
-  const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), first = FT(first);
+  const int rb = Q * W;
+  if (rb >= ns) return;
+  const int nb = min(W, ns - rb);
   const int c0 = SROWS * blockIdx.x;
-  if (c0 >= ns) return;
-  const int Pb = c0 / SBW, rb = Pb * SBW, nb = min(SBW, ns - rb);
-  const int ncols = min(SROWS, ns - c0);
+  if (c0 >= nb) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nr = rb + nb - c0;                                       // rows c0 .. end of the block (upper part of S is zero)
-  sdm_double2 v[8];
-  slabT_issue(v, S + FT(soff), FT(sld), c0, ncols, c0, nr);
-  const bool bad = sb_is_bad(sb_g, FT(sboff) + Pb, thr);
-  for (int i = tid; i < nr; i += ST) xs[i] = y[first + c0 + i];
-  __syncthreads();
-  double part[4];
-  if (bad) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) { const int c = c0 + 4 * wave + q; part[q] = c < ns ? xs[c - c0] : 0.0; }
-  } else {
-    slabT_consume(v, nr, xs, part);
+  const double *vp = y + first + rb;
+  if (sb_is_bad(sb_g, FT(sboff) + Q, thr)) {
+    if (blockIdx.x != 0) return;
+    for (int i = tid; i < nb; i += ST) xs[i] = vp[i];
+    __syncthreads();
+    block_solve_bw(F + FT(foff), FT(ld), rb, nb, xs, Sd);
+    for (int i = tid; i < nb; i += ST) { xfin[first + rb + i] = xs[i]; if (yout) yout[perm[first + rb + i]] = xs[i]; }
+    return;
   }
+  const int sld = FT(sld);
+  const double *Sb = S + FT(soff) + (int64_t)rb * sld;
+  const int ncols = min(SROWS, nb - c0), nr = nb - c0;               // rows c0 .. end of the block (lower triangular)
+  double part[4];
+  bw_product(Sb, sld, c0, ncols, c0, nr, xs, part, [&]() { for (int i = tid; i < nr; i += ST) xs[i] = vp[c0 + i]; });
   if (lane == 0) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int c = c0 + 4 * wave + q;
-      if (c < ns) { xfin[first + c] = part[q]; if (yout) yout[perm[first + c]] = part[q]; }
+      if (c < nb) { xfin[first + rb + c] = part[q]; if (yout) yout[perm[first + rb + c]] = part[q]; }
     }
   }
 }
 
-// ================================================================ the whole solve of a one-front factor in ONE launch
-// fw, ./d, bw (wrapPcg.m:56-59 without dense columns) for factors that are a single front without rows below (the dense
-// Schur complements of SDPs: control07, MAXCUT).  The launch-per-step sweeps above are chains of 2 (nsb - 1) + 2 dependent
-// launches; here workgroup b OWNS rows 16 b .. of the forward sweep and the same columns of the backward sweep and
-// accumulates their value in registers, in the order of the step launches (same slab functions: same bits):
-//   forward   diagonal-block product, then for Q = 0 .. P-1:  - M(rows, Q) y_Q  as soon as block Q is final (doneF[Q] =
-//             slabs of block Q final; the matrix slab is in flight before the wait); y and z = y ./ d stored write-through,
-//             counted in doneF[P];
-//   backward  v = z, then for Q = nsb-1 .. P+1:  - M(Q, columns)' v_Q  as soon as block Q is final (doneB[Q]); v stored (vb, an
-//             array of its own), counted in doneB[P]; once the whole block is there: x = inv(L_PP)' v  ->  xfin, yout(perm).
-// Blocks on the substitution fallback: rows / columns stay unpremultiplied (F instead of S), the last slab to arrive
-// solves the block (block_solve_fw / _bw) and counts for all of them.  Forward waits are for lower workgroups, backward
-// waits for higher ones: all workgroups must be resident (SFRONT_MAX_WGS; PersistTurn on the host).  The last workgroup
-// to leave re-arms the counters.  The emulator (workgroups one after the other) runs phase 1 = forward, phase 2 = the
-// backward accumulation with the workgroups in reverse order, phase 3 = the diagonal-block products; the GPU runs
-// phase 0 = all of it.
-__device__ __forceinline__ bool arrive_is_last(int *cnt, int nsl) {
-  __shared__ int last;
-  SDM_STORES_DONE();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    const int t = atomicAdd(cnt, 1);
-    last = t == nsl - 1;
-    if (last) atomicExch(cnt, 0);                                     // ready for the next solve
-  }
-  __syncthreads();
-  return last != 0;
-}
+// step Q: x_Q is final; every column left of super-block Q receives  - L(Q rows, c)' x_Q , read from the factor
 __global__ void __launch_bounds__(ST)
-k_solve_front(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const double *src, const int *perm, double *y,
-              double *zdiv, double *vb, const double *dscale, double *xfin, double *yout, const unsigned long long *sb_g, int *sb_cnt, int *done,
-              double thr, int phase, int *tmo) {
-  __shared__ double xs[SBW], red[(ST / 8) * SROWS], wsub[SBW];
-  __shared__ double Sd[64 * TP];
-  const int ns = tab.o_ns, first = tab.o_first, ld = tab.o_ld, sld = tab.o_sld;
-  const int nsb = (ns + SBW - 1) / SBW;
-  const int nwg = gridDim.x;
-#ifdef SDM_EMU
-  const int bx = phase == 2 ? nwg - 1 - (int)blockIdx.x : (int)blockIdx.x;
-#else
-  const int bx = blockIdx.x;
-#endif
-  const int r0 = SROWS * bx;                                          // rows (forward) = columns (backward) of this workgroup
-  const int Pb = r0 / SBW, c0 = Pb * SBW, nb = min(SBW, ns - c0);
-  const int sb = tab.o_sboff + Pb;
-  const int nsl = (nb + SROWS - 1) / SROWS;
+k_sbw_step(const double *__restrict__ F, FrontTab tab, const int *list, double *y, const double *xfin, int Q, int W) {
+  __shared__ double xs[SBW_MAX];
+  const int s = tab.one ? tab.o_s : list[blockIdx.y];
+  const int ns = FT(ns), first = FT(first), ld = FT(ld);
+  const int rb = Q * W;
+  if (rb >= ns) return;
+  const int nbq = min(W, ns - rb);
+  const int c0 = SROWS * blockIdx.x;                                // < rb by the grid
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const double *Fs = F + tab.o_foff, *Ss = S + tab.o_soff;
-  int *doneF = done, *doneB = done + nsb, *fin = done + 2 * nsb;
-  const bool bad = sb_is_bad(sb_g, sb, thr);
-  if (phase <= 1) {
-    // ---------------------------------------------------------------- forward
-    sdm_double2 v[NLD];
-    const int ncols = min(nb, r0 + SROWS - c0);                       // lower triangular: columns up to the slab's last row
-    slab_issue(v, Ss, sld, c0, ncols, r0, ns - 1);
-    for (int c = tid; c < nb; c += ST) xs[c] = src[perm[first + c0 + c]];
-    __syncthreads();
-    double acc;
-    if (bad) acc = (tid < SROWS && r0 + tid < ns) ? xs[r0 - c0 + tid] : 0.0;     // the right-hand side itself: solved by substitution below
-    else acc = slab_consume(v, ncols, xs, red);
-    for (int Q = 0; Q < Pb; Q++) {
-      const int cq = Q * SBW;
-      if (bad) slab_issue(v, Fs, ld, cq, SBW, r0, ns - 1);            // the rows of a bad block were not premultiplied
-      else slab_issue(v, Ss, sld, cq, SBW, r0, ns - 1);
-      prep_wait(doneF + Q, SBW / SROWS, tmo);                         // y_Q is final (and everybody is done with xs / red)
-      for (int c = tid; c < SBW; c += ST) xs[c] = sdm_load_wt(&y[first + cq + c]);
-      __syncthreads();
-      acc -= slab_consume(v, SBW, xs, red);
-    }
-    if (tid < SROWS && r0 + tid < ns) {
-      sdm_store_wt(&y[first + r0 + tid], acc);
-      if (!bad) { const double dk = dscale[first + r0 + tid]; sdm_store_wt(&zdiv[first + r0 + tid], acc / (dk > 0.0 ? dk : 1.0)); }
-    }
-    if (!bad) {
-      prep_done(doneF + Pb);
-    } else if (arrive_is_last(sb_cnt + sb, nsl)) {
-      SDM_ACQUIRE_FENCE();
-      block_solve_fw(Fs, ld, c0, nb, y + first + c0, wsub, Sd);
-      __syncthreads();
-      for (int i = tid; i < nb; i += ST) { const double dk = dscale[first + c0 + i]; zdiv[first + c0 + i] = y[first + c0 + i] / (dk > 0.0 ? dk : 1.0); }
-      if (Pb == nsb - 1) {                                            // nothing above the last block: x = L_PP' \ z right away
-        SDM_STORES_DONE();
-        __syncthreads();
-        block_solve_bw(Fs, ld, c0, nb, zdiv + first + c0, wsub, Sd);
-      }
-      SDM_STORES_DONE();
-      __syncthreads();
-      if (tid == 0) { __threadfence(); sdm_signal_add(doneF + Pb, nsl); }
-    }
-    if (phase == 1) return;
-  }
-  // ------------------------------------------------------------------ backward (z from zdiv, v in vb)
-  if (phase == 0 || phase == 2) {
-  prep_wait(doneF + Pb, nsl, tmo);                                    // this block's z (x for a bad last block) is complete
-  double val[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) { const int c = r0 + 4 * wave + q; val[q] = c < ns ? sdm_load_wt(&zdiv[first + c]) : 0.0; }
-  for (int Q = nsb - 1; Q > Pb; Q--) {
-    const int rb = Q * SBW, nbq = min(SBW, ns - rb);
-    const bool badq = sb_is_bad(sb_g, tab.o_sboff + Q, thr);
-    sdm_double2 vt[8];
-    if (badq) slabT_issue(vt, Fs, ld, r0, SROWS, rb, nbq); else slabT_issue(vt, Ss, sld, r0, SROWS, rb, nbq);
-    prep_wait(doneB + Q, (nbq + SROWS - 1) / SROWS, tmo);             // v_Q (x_Q of a bad block) is final
-    for (int i = tid; i < nbq; i += ST) xs[i] = sdm_load_wt(&vb[first + rb + i]);
-    __syncthreads();
-    double part[4];
-    slabT_consume(vt, nbq, xs, part);
-#pragma unroll
-    for (int q = 0; q < 4; q++) val[q] -= part[q];
-  }
-  // v goes to an array of its own: every line another workgroup reads after a wait is one it has not read before in this
-  // launch (z and v in the same place would be read twice through the same L2)
+  const double *xp = xfin + first + rb;
+  double part[4];
+  bw_product(F + FT(foff), ld, c0, SROWS, rb, nbq, xs, part, [&]() { for (int i = tid; i < nbq; i += ST) xs[i] = xp[i]; });
   if (lane == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) { const int c = r0 + 4 * wave + q; if (c < ns) sdm_store_wt(&vb[first + c], val[q]); }
-  }
-  if (!bad || Pb == nsb - 1) {                                        // (a bad LAST block was substituted by the forward part: val is x)
-    prep_done(doneB + Pb);
-  } else if (arrive_is_last(sb_cnt + sb, nsl)) {
-    SDM_ACQUIRE_FENCE();
-    block_solve_bw(Fs, ld, c0, nb, vb + first + c0, wsub, Sd);
-    SDM_STORES_DONE();
-    __syncthreads();
-    if (tid == 0) { __threadfence(); sdm_signal_add(doneB + Pb, nsl); }
-  }
-  if (phase == 2) return;
-  }
-  {
-    const int nr = c0 + nb - r0, ncols = min(SROWS, ns - r0);         // rows r0 .. end of the block (upper part of S is zero)
-    sdm_double2 vt[8];
-    slabT_issue(vt, Ss, sld, r0, ncols, r0, nr);
-    prep_wait(doneB + Pb, nsl, tmo);
-    for (int i = tid; i < nr; i += ST) xs[i] = sdm_load_wt(&vb[first + r0 + i]);
-    __syncthreads();
-    double part[4];
-    if (bad) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) { const int c = r0 + 4 * wave + q; part[q] = c < ns ? xs[c - r0] : 0.0; }
-    } else {
-      slabT_consume(vt, nr, xs, part);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int c = r0 + 4 * wave + q;
-        if (c < ns) { xfin[first + c] = part[q]; if (yout) yout[perm[first + c]] = part[q]; }
-      }
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {                                                      // the last one out re-arms the counters
-    const int t = atomicAdd(fin, 1);
-    if (t == nwg - 1) { for (int i = 0; i < 2 * nsb; i++) atomicExch(done + i, 0); atomicExch(fin, 0); }
+    for (int q = 0; q < 4; q++) y[first + c0 + 4 * wave + q] -= part[q];
   }
 }
+#undef FT
 
 // ================================================================ host drivers
 const double *solve_d(sdm_plan *P) { return P->dense.factored ? (const double *)P->chol.dsolve.p : (const double *)P->chol.d.p; }
 
-#undef FT
 // the level's table for the solve kernels: with the descriptor of its only front filled in when there is just one
 static FrontTab level_tab(const CholPlan &C, FrontTab t, int l) {
   if (C.levptr[l + 1] - C.levptr[l] != 1) return t;
@@ -1078,22 +902,22 @@ void solve_prepare(sdm_plan *P, bool sb_g_is_zero) {
     attr = true;
   }
 #endif
-  C.growth_used = C.growth_max;                                     // the solves decide with the bound the premultiplication saw
+  C.growth_used = C.growth_max;                                     // the solves decide with the bound in force here
+  const size_t gw = (size_t)std::max(C.nsbtot, 1) * (2 + SPREP_NCNT / 2);
   if (!sb_g_is_zero)                                                // (a factorisation zeroes them in k_prep_pivots)
-    SDM_HIP_CHECK(hipMemsetAsync(C.sb_g.p, 0, (size_t)std::max(4 * C.nsbtot, 4) * sizeof(unsigned long long), P->stream));
-  const int nitems = C.n_i128 + 2 * C.n_t3 + C.n_pm;
-  static const bool fused_off = getenv("SDM_SPREP_OFF") != nullptr;     // tuning override (tools only)
-  if (nitems <= SPREP_MAX_ITEMS && C.n_i128 > 0 && !fused_off) {                   // everything resident at once: one launch, counters instead of boundaries
-    SDM_KLAUNCH(P, k_sprep, dim3(nitems), dim3(ST), INV_LDS, C.fronts.p, C.S.p, C.ttmp.p, tab, C.l_i128.p, C.n_i128, C.l_t3.p, C.n_t3,
-                C.l_pm.p, C.n_pm, C.sb_g.p, (int *)(C.sb_g.p + 2 * C.nsbtot), C.growth_used, C.tmo.dev());
+    SDM_HIP_CHECK(hipMemsetAsync(C.sb_g.p, 0, gw * sizeof(unsigned long long), P->stream));
+  if (C.n_i128 == 0) return;
+  const int W = C.sbw;
+  if (C.n_i128 + C.n_items <= SPREP_MAX_ITEMS) {                    // everything resident at once: one launch, counters instead of boundaries
+    SDM_KLAUNCH(P, k_sprep, dim3(C.n_i128 + C.n_items), dim3(ST), INV_LDS, C.fronts.p, C.S.p, C.Tarena.p, tab, C.l_i128.p, C.n_i128,
+                C.l_items.p, C.sb_g.p, (int *)(C.sb_g.p + 2 * std::max(C.nsbtot, 1)), W, C.tmo.dev());
     return;
   }
-  if (C.n_i128) SDM_KLAUNCH(P, k_sinv128, dim3(C.n_i128), dim3(ST), INV_LDS, C.fronts.p, C.S.p, tab, C.l_i128.p, C.sb_g.p);
-  if (C.n_t3) {
-    SDM_KLAUNCH(P, k_stile, dim3(C.n_t3), dim3(ST), TILE_LDS, C.fronts.p, C.S.p, C.ttmp.p, tab, C.l_t3.p, C.sb_g.p, 0, C.growth_used);
-    SDM_KLAUNCH(P, k_stile, dim3(C.n_t3), dim3(ST), TILE_LDS, C.fronts.p, C.S.p, C.ttmp.p, tab, C.l_t3.p, C.sb_g.p, 1, C.growth_used);
+  SDM_KLAUNCH(P, k_sinv128, dim3(C.n_i128), dim3(ST), INV_LDS, C.fronts.p, C.S.p, tab, C.l_i128.p, C.sb_g.p, W);
+  for (int st = 0; st < 2 * SINV_MAXLEV; st++) {
+    const int n = C.stage_ptr[st + 1] - C.stage_ptr[st];
+    if (n > 0) SDM_KLAUNCH(P, k_stile, dim3(n), dim3(ST), TILE_LDS, C.fronts.p, C.S.p, C.Tarena.p, tab, C.l_items.p + 8 * (size_t)C.stage_ptr[st], C.sb_g.p, W);
   }
-  if (C.n_pm) SDM_KLAUNCH(P, k_stile, dim3(C.n_pm), dim3(ST), TILE_LDS, C.fronts.p, C.S.p, C.ttmp.p, tab, C.l_pm.p, C.sb_g.p, 2, C.growth_used);
 }
 
 // growth statistics of the last solve_prepare (host read-back; tests and bench reporting)
@@ -1119,25 +943,25 @@ void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growt
 void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *y, int64_t y_stride, double *wv, int nrhs,
                     double *zdiv, const double *dscale) {
   CholPlan &C = P->chol;
-  FrontTab tab = front_tab(C);
   const double thr = C.growth_used;
-  if ((size_t)C.nsbtot * (size_t)nrhs > C.sb_cnt.n) throw std::runtime_error("solve_fw_batch: ticket array too small for this many right-hand sides");
+  const int W = C.sbw;
   FwBatch bt;
-  bt.src = nrhs > 1 ? rhs_stride : 0; bt.y = nrhs > 1 ? y_stride : 0; bt.wv = nrhs > 1 ? C.wsize : 0; bt.cnt = nrhs > 1 ? C.nsbtot : 0;
-  const FrontTab tab0 = tab;
+  bt.src = nrhs > 1 ? rhs_stride : 0; bt.y = nrhs > 1 ? y_stride : 0; bt.wv = nrhs > 1 ? C.wsize : 0;
+  const FrontTab tab0 = front_tab(C);
   for (int l = 0; l < C.nlevels; l++) {
     const SolveLevel &L = C.slev[l];
-    bt.fold_bw = (zdiv && !L.below) ? 1 : 0;
     const int *list = C.d_levlist.p + C.levptr[l];
-    tab = level_tab(C, tab0, l);
+    const FrontTab tab = level_tab(C, tab0, l);
     const int gather = L.children ? 0 : 1;
     if (!gather) SDM_KLAUNCH(P, k_sfw_init, dim3(L.nfronts, 1, nrhs), dim3(ST), 0, tab, list, wv, rhs, C.d_perm.p, y, bt);
-    SDM_KLAUNCH(P, k_sfw_diag, dim3((L.maxns + SROWS - 1) / SROWS, L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, wv, rhs,
-                C.d_perm.p, y, C.sb_g.p, C.sb_cnt.p, thr, gather, bt, zdiv, dscale);
-    for (int Pb = 0; Pb < (int)L.maxslab_fw.size(); Pb++)
-      if (L.maxslab_fw[Pb] > 0)
-        SDM_KLAUNCH(P, k_sfw_step, dim3(L.maxslab_fw[Pb], L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, wv, y, C.sb_g.p,
-                    C.sb_cnt.p, thr, Pb, (gather && Pb == 0) ? 1 : 0, bt, zdiv, dscale);
+    for (int Pb = 0; Pb < L.nsb; Pb++) {
+      const int nbmax = std::min(W, L.maxns - Pb * W);
+      SDM_KLAUNCH(P, k_sfw_diag, dim3((nbmax + SROWS - 1) / SROWS, L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, wv, rhs,
+                  C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W);
+      if (L.slabs_fw[Pb] > 0)
+        SDM_KLAUNCH(P, k_sfw_step, dim3(L.slabs_fw[Pb], L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, tab, list, wv, rhs, C.d_perm.p, y, Pb,
+                    (gather && Pb == 0) ? 1 : 0, bt, W);
+    }
   }
 }
 
@@ -1146,20 +970,21 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
 // was already applied by the forward sweep's final writes)
 static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double *dscale, bool skip_plain_init) {
   CholPlan &C = P->chol;
-  FrontTab tab = front_tab(C);
   const double thr = C.growth_used;
-  const FrontTab tab0 = tab;
+  const int W = C.sbw;
+  const FrontTab tab0 = front_tab(C);
   for (int l = C.nlevels - 1; l >= 0; l--) {
     const SolveLevel &L = C.slev[l];
     const int *list = C.d_levlist.p + C.levptr[l];
-    tab = level_tab(C, tab0, l);
-    const int ncs = (L.maxns + SROWS - 1) / SROWS;
-    // (a bad last super-block of such a level was substituted backward by the forward sweep: FwBatch::fold_bw)
+    const FrontTab tab = level_tab(C, tab0, l);
     if (!(skip_plain_init && !L.below))
-      SDM_KLAUNCH(P, k_sbw_init, dim3(ncs, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, dscale, C.sb_g.p, C.sb_cnt.p, thr);
-    for (int Q = L.nsb - 1; Q >= 1; Q--)
-      SDM_KLAUNCH(P, k_sbw_step, dim3(Q * (SBW / SROWS), L.nfronts), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, y, C.sb_g.p, C.sb_cnt.p, thr, Q);
-    SDM_KLAUNCH(P, k_sbw_diag, dim3(ncs, L.nfronts), dim3(ST), 0, C.S.p, tab, list, y, C.xfin.p, yout, C.d_perm.p, C.sb_g.p, thr);
+      SDM_KLAUNCH(P, k_sbw_init, dim3((L.maxns + SROWS - 1) / SROWS, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, dscale);
+    for (int Q = L.nsb - 1; Q >= 0; Q--) {
+      const int nbmax = std::min(W, L.maxns - Q * W);
+      SDM_KLAUNCH(P, k_sbw_diag, dim3((nbmax + SROWS - 1) / SROWS, L.nfronts), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
+                  C.d_perm.p, C.sb_g.p, thr, Q, W);
+      if (Q > 0) SDM_KLAUNCH(P, k_sbw_step, dim3(Q * (W / SROWS), L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, Q, W);
+    }
   }
 }
 
@@ -1173,19 +998,6 @@ void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode) {
   // fw, ./d, bw in one call without dense columns: the forward sweep writes the ./d copy of every block as it becomes
   // final (zdiv), the backward sweep runs on that copy and needs k_sbw_init only where rows below a supernode exist
   const bool fold = (mode == 7) && !dense;
-  if (fold && C.solve_fused) {
-    const FrontTab tab = level_tab(C, front_tab(C), 0);
-    const int nwg = (C.sn_ns[0] + SROWS - 1) / SROWS;
-    PersistTurn turn(P);
-#ifdef SDM_EMU
-    for (int phase = 1; phase <= 3; phase++)
-#else
-    const int phase = 0;
-#endif
-      SDM_KLAUNCH(P, k_solve_front, dim3(nwg), dim3(ST), 0, C.fronts.p, C.S.p, tab, rhs, C.d_perm.p, y, C.zdiv.p, C.wvec.p, solve_d(P), C.xfin.p, yout,
-                  C.sb_g.p, C.sb_cnt.p, C.sfront_cnt.p, C.growth_used, phase, C.tmo.dev());
-    return;
-  }
   if (mode & 1) {
     solve_fw_batch(P, rhs, 0, y, 0, C.wvec.p, 1, fold ? C.zdiv.p : nullptr, fold ? solve_d(P) : nullptr);
     if (!(mode & 4)) {

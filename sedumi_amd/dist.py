@@ -126,6 +126,22 @@ class BlockShardedAda:
         self.plan.set_ada(self.sub.At, self.sub.Ablkjc, self.sub.K, problem.lorentz_pattern(self.sub))
         self.nv, self.m = self.plan.nnzADA, self.plan.m
         self.buf = torch.zeros(self.nv + self.m, dtype=torch.float64, device=self.device)
+        # absd_j = (LP / Lorentz part of ADA'_jj) + sum |a_j .* z_j| for every constraint j with PSD nonzeros, 0 otherwise
+        # (getada3.c:333-351).  A rank's kernel adds the first term only for the columns that have PSD nonzeros in ITS blocks;
+        # for a column whose PSD nonzeros all sit in other ranks' blocks rank 0 -- which carries the LP / Lorentz rows, so its
+        # partial ADA'_jj IS that first term there -- adds it by hand before the reduction.
+        self.fix_cols = self.fix_diag = None
+        if self.rank == 0 and self.world > 1 and s.size:
+            haspsd = np.zeros(self.m, dtype=bool); haspsd[np.unique(pairs[1])] = True
+            mine0 = np.isin(pairs[0], self.blocks_of[0])
+            has0 = np.zeros(self.m, dtype=bool); has0[np.unique(pairs[1][mine0])] = True
+            cols0 = np.flatnonzero(haspsd & ~has0)
+            if cols0.size:
+                pat = sp.csc_matrix(self.plan.ADA_pattern)
+                diag = np.array([pat.indptr[j] + int(np.searchsorted(pat.indices[pat.indptr[j]:pat.indptr[j + 1]], j)) for j in cols0], dtype=np.int64)
+                assert np.array_equal(pat.indices[diag], cols0)
+                self.fix_cols = torch.as_tensor(self.nv + cols0, device=self.device)
+                self.fix_diag = torch.as_tensor(diag, device=self.device)
 
     def upload_scaling(self, d, ud, qpr=None):
         """Scaling of the FULL problem: rank 0 keeps d.l / d.det (and the DAt.q values), every rank its blocks of udsqr."""
@@ -145,6 +161,8 @@ class BlockShardedAda:
             return
         self.plan.copy("ada", self.buf, 0, self.nv, to_plan=False)
         self.plan.copy("absd", self.buf[self.nv:], 0, self.m, to_plan=False)
+        if self.fix_cols is not None:
+            self.buf[self.fix_cols] += self.buf[self.fix_diag]
         dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
         self.plan.copy("ada", self.buf, 0, self.nv, to_plan=True)
         self.plan.copy("absd", self.buf[self.nv:], 0, self.m, to_plan=True)

@@ -180,6 +180,16 @@ class Plan:
         inverse (0 = substitution everywhere); effective from the next blkchol."""
         check(self._lib.sdm_plan_set_growth_max(C.c_void_p(self._p), C.c_double(float(growth_max))))
 
+    def set_solve_width(self, width):
+        """Super-block width of the solves for the NEXT set_chol (0 = automatic, or a power of two in 256 .. 2048)."""
+        check(self._lib.sdm_plan_set_solve_width(C.c_void_p(self._p), C.c_int64(int(width))))
+
+    def solve_width(self):
+        """Super-block width of the solves in force (chosen at set_chol)."""
+        w = C.c_int64(0)
+        check(self._lib.sdm_plan_get_solve_width(C.c_void_p(self._p), C.byref(w)))
+        return w.value
+
     def solve_stats(self):
         """(super-blocks, blocks on the substitution fallback, largest growth) of the last factorisation."""
         nb, bad, g = C.c_int64(0), C.c_int64(0), C.c_double(0.0)

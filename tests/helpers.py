@@ -298,11 +298,11 @@ def check_one_launch_pivot_rule(refmex, m, maxu, wgs=None):
     assert relerr(d1, r[1].ravel()) < 1e-8
 
 
-def check_fused_solve(m, thr, seed=0):
-    """k_solve_front (fw, ./d, bw of a one-front factor as ONE launch; opt-in, SDM_SOLVE_FUSED) against the launch-per-step
-    sweeps: the same slab products in the same order, so the same bits -- on the inverse path, with every super-block on
-    the substitution fallback (bound 0) and with good and bad blocks mixed; several solves in a row (the counters re-arm)."""
-    import os
+def check_solve_widths(m, thr, seed=0):
+    """The solves of a one-front factor with every super-block width the front admits (sdm_plan_set_solve_width: 256, 512,
+    ... up to the automatic choice = one block when m <= 2048): every width against numpy's solve -- on the inverse path,
+    with every super-block on the substitution fallback (bound 0) and with good and bad blocks mixed -- several solves in
+    a row, and the launch count 2 (2 nsb - 1) per fw + bw."""
     from sedumi_amd import problem
     from sedumi_amd.plan import Plan
     rng = np.random.default_rng(m + seed)
@@ -313,33 +313,35 @@ def check_fused_solve(m, thr, seed=0):
     X = Lv @ np.diag(d) @ Lv.T
     L = problem.dense_symbolic(m)
     rhss = [rng.standard_normal(m) for _ in range(3)]
-    out = []
-    for fused in (True, False):
-        if fused:
-            os.environ["SDM_SOLVE_FUSED"] = "1"
-        try:
-            plan = Plan(0); plan.set_chol(L, problem.dense_pattern(m))
-        finally:
-            os.environ.pop("SDM_SOLVE_FUSED", None)
+    wants = [np.linalg.solve(X, r) for r in rhss]
+    wauto = 256
+    while wauto < m and wauto < 2048:
+        wauto *= 2
+    widths = [0] + [w for w in (256, 512, 1024) if w < wauto]
+    for width in widths:
+        plan = Plan(0)
+        plan.set_solve_width(width)
+        plan.set_chol(L, problem.dense_pattern(m))
         if thr is not None:
             plan.set_growth_max(thr)
         plan.upload("ada", X.ravel(order="F"))
-        plan.kprof(True)
         plan.blkchol(None, False)
+        W = width or wauto
+        nsb = (m + W - 1) // W
+        nb, bad, _ = plan.solve_stats()
+        assert nb == nsb
+        if thr == 0.0:
+            assert bad == nsb
+        elif thr is None:
+            assert bad == 0
+        plan.kprof(True)
         ys = []
         for r in rhss:
             plan.upload("rhs", r); plan.ldlsolve(); ys.append(plan.download("y"))
-        names = set(plan.kprof_summary().keys())
+        prof = plan.kprof_summary()
         plan.kprof(False)
-        nb, bad, _ = plan.solve_stats()
-        out.append((ys, names, bad))
+        nl = sum(v[0] for k, v in prof.items() if k.startswith("k_sfw") or k.startswith("k_sbw"))
+        assert nl == len(rhss) * 2 * (2 * nsb - 1), (width, prof)
+        for y, want in zip(ys, wants):
+            assert relerr(y, want) < 1e-9, (width, relerr(y, want))
         plan.close()
-    (y1, k1, b1), (y2, k2, b2) = out
-    assert "k_solve_front" in k1 and "k_sfw_diag" not in k1 and "k_solve_front" not in k2 and "k_sfw_diag" in k2
-    assert b1 == b2
-    if thr == 0.0:
-        assert b1 == (m + 255) // 256
-    for a, b in zip(y1, y2):
-        assert np.array_equal(a, b)
-    want = np.linalg.solve(X, rhss[0])
-    assert relerr(y1[0], want) < 1e-9

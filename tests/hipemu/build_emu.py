@@ -17,12 +17,17 @@ def build(force=False):
         glob.glob(os.path.join(ROOT, "include", "*.h"))
     if not force and os.path.exists(LIB) and all(os.path.getmtime(f) <= os.path.getmtime(LIB) for f in deps):
         return LIB
-    objs = []
+    from concurrent.futures import ThreadPoolExecutor
+    objs, jobs = [], []
+    hdr_t = max(os.path.getmtime(f) for f in deps if f.endswith(".h"))
     for s in srcs + [os.path.join(HERE, "hipemu.cpp")]:
         o = os.path.join(HERE, "_obj_" + os.path.basename(s) + ".o")
-        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-DSDM_EMU", "-x", "c++", "-I", HERE, "-I", CSRC,
-                               "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-variable", "-c", s, "-o", o])
         objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
+            jobs.append(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-DSDM_EMU", "-x", "c++", "-I", HERE, "-I", CSRC,
+                         "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-variable", "-c", s, "-o", o])
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(subprocess.check_call, jobs))
     subprocess.check_call(["g++", "-shared", "-o", LIB] + objs)
     return LIB
 

@@ -48,10 +48,26 @@ def _worker(rank, world, port, case, q):
             cs.getada()
             err = max(np.abs(sh.download("ada") - ref.download("ada")).max(), np.abs(sh.download("absd") - ref.download("absd")).max())
             q.put((rank, float(err), [int(c) for c in cs.cols]))
-        elif case == "blocks":
+        elif case in ("blocks", "blocks_confined"):
             # ADA' = sum of the PSD blocks' contributions: blocks dealt to the ranks, one all-reduce of [values | absd]
             from helpers import ref_scaling
             P = problem.random_sdp(m=40, lp=5, q=(4, 3), s=(8, 5, 6), hs=(4,), dens=0.3, seed=9)
+            if case == "blocks_confined":
+                # columns whose PSD nonzeros are confined to ONE block each (every block in turn, so some of them sit on a rank
+                # other than 0 whatever the deal) while they also have LP entries: absd's LP / Lorentz term must still arrive
+                import scipy.sparse as sp
+                start, ns = problem._psd_rows(P.K)
+                nreal = P.K["s"].size - 1
+                A = sp.lil_matrix(P.At)
+                for j in range(16):
+                    keep = j % len(ns)
+                    for k, n in enumerate(ns):
+                        if k != keep:
+                            A[start[k]:start[k] + (n * n if k < nreal else 2 * n * n), j] = 0.0
+                    A[start[keep], j] = 1.5
+                    A[1, j] = 1.0 + 0.1 * j
+                A = sp.csc_matrix(A); A.eliminate_zeros()
+                P = problem.Problem(A, P.K, "confined")
             d, ud = ref_scaling(P, 2)
             ADApat = problem.symb_ada(P)
             L = mex.symbchol(ADApat)
@@ -104,7 +120,7 @@ def _worker(rank, world, port, case, q):
         q.put((rank, "ERR " + traceback.format_exc(), None))
 
 
-@pytest.mark.parametrize("case", ["columns", "subtrees", "subtrees_lorentz", "blocks"])
+@pytest.mark.parametrize("case", ["columns", "subtrees", "subtrees_lorentz", "blocks", "blocks_confined"])
 def test_two_ranks_gloo(case):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -119,7 +135,7 @@ def test_two_ranks_gloo(case):
     for rank, err, info in res:
         assert not isinstance(err, str), err
         assert err < 1e-12, (rank, err)
-        if case == "blocks":
+        if case in ("blocks", "blocks_confined"):
             assert info is not None and sum(info) == 4 and min(info) >= 1
             continue
         assert info is not None and (len(info) == 3 if case == "columns" else sum(info) == (35 if case == "subtrees" else 30) and min(info) > 0)

@@ -243,10 +243,10 @@ def test_pipelined_sweeps_single_front(refmex, m):
 
 @pytest.mark.parametrize("m,thr", [(700, 0.0), (700, 1e-3), (300, 0.0), (90, 0.0)])
 def test_solves_with_substitution_fallback_blocks(refmex, m, thr):
-    """The solves apply the 256-column diagonal super-blocks of L as explicit inverses unless a block's growth
-    max|inv| * max|L| exceeds the plan's bound; such a block keeps its rows unpremultiplied and is solved by
-    substitution by the last workgroup that updates it.  Bound 0: every block on the fallback; bound 1e-3 on a factor
-    whose middle super-block has tiny multipliers: good and bad blocks mixed in one front."""
+    """The solves apply the diagonal super-blocks of L (256 columns here: set_solve_width) as explicit inverses unless a
+    block's growth max|inv| * max|L| exceeds the plan's bound; such a block is solved by substitution against the factor
+    by one workgroup of the launch.  Bound 0: every block on the fallback; bound 1e-3 on a factor whose middle super-block
+    has tiny multipliers: good and bad blocks mixed in one front."""
     from sedumi_amd import problem
     from sedumi_amd.plan import Plan
     rng = np.random.default_rng(m)
@@ -256,7 +256,7 @@ def test_solves_with_substitution_fallback_blocks(refmex, m, thr):
     d = 0.5 + rng.random(m)
     X = Lv @ np.diag(d) @ Lv.T
     L = problem.dense_symbolic(m)
-    plan = Plan(0); plan.set_chol(L, problem.dense_pattern(m))
+    plan = Plan(0); plan.set_solve_width(256); plan.set_chol(L, problem.dense_pattern(m))
     plan.set_growth_max(thr)
     plan.upload("ada", X.ravel(order="F"))
     plan.blkchol(None, False)
@@ -378,6 +378,6 @@ def test_one_launch_front_pivot_rule(refmex, m, maxu):
     helpers.check_one_launch_pivot_rule(refmex, m, maxu)
 
 
-@pytest.mark.parametrize("m,thr", [(90, None), (300, None), (666, None), (700, 0.0), (700, 1e-3), (256, 0.0)])
-def test_fused_solve_matches_the_step_launches_bit_for_bit(m, thr):
-    helpers.check_fused_solve(m, thr)
+@pytest.mark.parametrize("m,thr", [(90, None), (300, None), (666, None), (700, 0.0), (700, 1e-3), (256, 0.0), (530, None)])
+def test_solve_widths(m, thr):
+    helpers.check_solve_widths(m, thr)

@@ -613,8 +613,8 @@ def test_one_launch_front_under_uneven_load(refmex):
         assert np.array_equal(pl.download("lpr"), l) and np.array_equal(pl.download("d"), d)
 
 
-@pytest.mark.parametrize("m,thr", [(90, None), (300, None), (666, None), (700, 0.0), (700, 1e-3), (1100, None), (256, 0.0)])
-def test_fused_solve_matches_the_step_launches_bit_for_bit(m, thr):
-    """Opt-in path (SDM_SOLVE_FUSED): the whole solve of a one-front factor in one launch, workgroups handing blocks on
-    through device-scope counters."""
-    helpers.check_fused_solve(m, thr)
+@pytest.mark.parametrize("m,thr", [(90, None), (300, None), (666, None), (700, 0.0), (700, 1e-3), (1100, None), (256, 0.0), (2500, None), (2500, 0.0)])
+def test_solve_widths(m, thr):
+    """Every super-block width a one-front factor admits (256 ... one block, two blocks of 2048 beyond that): inverse path,
+    substitution fallback, mixed."""
+    helpers.check_solve_widths(m, thr)

@@ -16,13 +16,9 @@ SHIMS = ["getada", "getada1", "getada2", "getada3", "blkchol", "fwblkslv", "bwbl
          "symbfwblk", "finsymbden", "dpr1fact", "fwdpr1", "bwdpr1", "invcholfac", "incorder", "adendotd", "adenscale"]
 
 
-@pytest.fixture(scope="module")
-def shimmex(refmex):
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
-    import build_emu
-    emulib = build_emu.build()
-    out = os.path.join(ROOT, "tests", "hipemu", "_mexshims")
+def build_shims(lib, out):
+    """Every mexFunction shim as a shared object of its own, linked to the C-ABI library `lib` and to the MEX-API shim of
+    the oracle (g++ only: MATLAB / Octave are not needed)."""
     os.makedirs(out, exist_ok=True)
     src = os.path.join(ROOT, "sedumi_amd", "mexshims")
     common = os.path.join(out, "mexcommon.o")
@@ -30,10 +26,24 @@ def shimmex(refmex):
     subprocess.check_call(["g++", "-O1", "-fPIC", "-Wall", "-c", os.path.join(src, "mexcommon.cpp"), "-o", common] + inc)
     for name in SHIMS:
         subprocess.check_call(["g++", "-O1", "-fPIC", "-Wall", "-shared", os.path.join(src, name + ".cpp"), common, "-o",
-                               os.path.join(out, name + ".so"), emulib, "-L", os.path.join(ROOT, "oracle", "_ref"), "-lmexshim",
-                               "-Wl,-rpath," + os.path.dirname(emulib), "-Wl,-rpath," + os.path.join(ROOT, "oracle", "_ref")] + inc)
+                               os.path.join(out, name + ".so"), lib, "-L", os.path.join(ROOT, "oracle", "_ref"), "-lmexshim",
+                               "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath," + os.path.join(ROOT, "oracle", "_ref")] + inc)
     from oracle.refmex import RefMex, REF_DIR
     return RefMex(REF_DIR, mex_dir=out)
+
+
+@pytest.fixture(scope="module")
+def shimlib():
+    """The C-ABI library the shims are linked to: here the emulated build (tests/test_mexshims_gpu.py: libsedumi_hip.so)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+    import build_emu
+    return build_emu.build()
+
+
+@pytest.fixture(scope="module")
+def shimmex(refmex, shimlib):
+    return build_shims(shimlib, os.path.join(ROOT, "tests", "hipemu", "_mexshims"))
 
 
 def test_every_hot_path_mex_has_a_shim():
@@ -133,17 +143,14 @@ def test_shim_invcholfac(refmex, shimmex):
         assert relerr(shimmex.call("invcholfac", 1, *args), refmex.call("invcholfac", 1, *args)) < TOL
 
 
-def test_factor_cache_is_shared_between_mex_binaries_and_validated_by_content(glue, refmex, shimmex):
+def test_factor_cache_is_shared_between_mex_binaries_and_validated_by_content(glue, refmex, shimmex, shimlib):
     """blkchol.mex leaves the factor resident in the plan cached inside the library (sdm_mexcache_*); fwblkslv.mex /
     bwblkslv.mex -- separate shared objects -- reuse it only when the L.L values they are handed ARE that factor.
     Two blkchol calls on the same symbolic factor, then solves with the FIRST factor's values: the cache holds the
     second factor, so the content check must reject it and the stateless path must give the first factor's answer."""
     import ctypes
     from oracle import glue as gl
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
-    import build_emu
-    lib = ctypes.CDLL(build_emu.build())
+    lib = ctypes.CDLL(shimlib)
     lib.sdm_mexcache_factor_plan.restype = ctypes.c_void_p
     rng = np.random.default_rng(12)
     X1 = spd_pattern("rand", 120, rng, 0.05)

@@ -27,15 +27,11 @@ def needs_build(lib=LIB):
 
 def build_phases(verbose=True):
     """Tools-only variant with the in-kernel phase clocks compiled in (-DSDM_PHASES): sedumi_amd/lib/libsedumi_hip_phases.so.
-    Never loaded by the package; tools/phase_profile.py points capi.use_library at it."""
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    Never loaded by the package; tools/phase_*.py point capi.use_library at it."""
     os.makedirs(LIBDIR, exist_ok=True)
     out = os.path.join(LIBDIR, "libsedumi_hip_phases.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSDM_PHASES", "-Wall", "-Wno-unused-result",
-           "-Wno-unused-variable", "-I", CSRC, "-o", out] + sources()
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    hipcc, objs = _compile_objects(["-DSDM_PHASES", "-Wno-unused-variable"], os.path.join(LIBDIR, "obj_phases"), verbose)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out
 
 

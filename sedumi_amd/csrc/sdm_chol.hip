@@ -263,6 +263,7 @@ __global__ void k_load_factor(double *F, double *FT, const double *Lpr, const in
   for (; t < nnzL; t += stride) { const double v = Lpr[t]; F[dst[t]] = v; if (dstT[t] >= 0) FT[dstT[t]] = v; }
 }
 
+constexpr unsigned long long DT_SENTINEL = 0x7ff8dead5ed00001ull;     // what DT holds until a diagonal block is published (diag_group_fetch): a quiet NaN no computation produces
 // ---- pivot thresholds (blkchol.c:168-184), grid-stride over the columns.
 //   ub = max_j P(perm_j,perm_j) / maxu^2 ;  lb_j = max(abstol, canceltol * orgd_j)
 // ub[2] collects max_j as the bit pattern of a non-negative double (ordered like the unsigned integer: atomicMax is
@@ -270,9 +271,10 @@ __global__ void k_load_factor(double *F, double *FT, const double *Lpr, const in
 __global__ void k_prep_pivots(int m, const double *ada, const int *asm_src, const int64_t *Ljc, const int *perm,
                               const double *absd, int use_absd, double canceltol, double maxu, double abstol,
                               double *lb, double *ub, int *pivstat, double *pivval, int nsuper, int *upd_cnt, int *diag_cnt,
-                              unsigned long long *sb_g, int nsbg, int *front_cnt, int nfc) {
+                              unsigned long long *sb_g, int nsbg, int *front_cnt, int nfc, unsigned long long *DTbits, int64_t ndt) {
   __shared__ double red[256];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
+  for (int64_t i = gid; i < ndt; i += gstride) DTbits[i] = DT_SENTINEL;                 // the data-tagged hand-over of the diagonal blocks (k_ldl_front)
   for (int i = gid; i < nsuper; i += gstride) { upd_cnt[i] = 0; diag_cnt[i] = 0; }     // counters of k_ldl_panel
   for (int i = gid; i < nfc; i += gstride) front_cnt[i] = 0;                            // counters of k_ldl_front
   for (int i = gid; i < nsbg; i += gstride) sb_g[i] = 0ull;                             // growth records of the solve inverses (sdm_solve.hip)
@@ -522,12 +524,16 @@ __device__ __forceinline__ void tile_index(int t, int &I, int &J) {
 // (no inverse is formed: the never-fail pivot rule allows multipliers up to maxu = 5e5); results agree with the
 // plain substitution to rounding.
 // 16 rows x 64 columns of the panel -> LDS wave tile Tw[col*17 + row]
+template <bool WT = false>
 __device__ __forceinline__ void rows_stage(const double *Fs, int ld, int ms, int k0, int kb, int R0, double *Tw, int lane) {
   const int li = lane & 15, lk = lane >> 4;
   double tv[NB / 4];
   const double *pr = Fs + min(R0 + li, ms - 1);
 #pragma unroll
-  for (int c4 = 0; c4 < NB / 4; c4++) tv[c4] = pr[(int64_t)(k0 + min(4 * c4 + lk, kb - 1)) * ld];    // 16 loads in flight
+  for (int c4 = 0; c4 < NB / 4; c4++) {                                                                // 16 loads in flight
+    const double *a = &pr[(int64_t)(k0 + min(4 * c4 + lk, kb - 1)) * ld];
+    tv[c4] = WT ? sdm_load_wt(a) : *a;
+  }
 #pragma unroll
   for (int c4 = 0; c4 < NB / 4; c4++) { const int c = 4 * c4 + lk; Tw[c * 17 + li] = c < kb ? tv[c4] : 0.0; }
 }
@@ -688,55 +694,15 @@ __device__ __forceinline__ void wait_prev_update(const int *cnt, int ns, int ms,
 __device__ __forceinline__ void front_wait_updates(const int *upd_done, int panel, int T, int *tmo) {
   for (int r = panel + 1; r < T; r++) spin_until(upd_done + r, panel, tmo);
 }
-template <bool PERSIST>
-__device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT, const FrontTab &tab, int s, int panel, double *d, double *lb,
-                                               const double *ubp, int *pivstat, double *pivval, double *colbuf, const double *ada,
-                                               const int *asm_src, const int64_t *Ljc, int mtot, int *upd_cnt, int *diag_cnt, int q0, int *tmo,
-                                               bool load_block, bool publish, double *ds, int *npub, bool raw_in_lds = false) {
-  // raw_in_lds (k_ldl_front): the raw block is not in the front but in LDS behind the wave tiles (front_rows_diag)
-  SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
-  double (*S)[NB + 1] = (double (*)[NB + 1])smem;                 // diagonal block, S[row][col]
-  double *RB = (double *)smem + NB * (NB + 1);                    // Lc during the LDL', then Xs / the wave tiles of the row solve
-  double *Lc = RB;                                                // Lc[k*NB+i] = l_ik
-  __shared__ double lbs[NB], pv[NB];
-  __shared__ int stt[NB];
-  __shared__ int badflag;
-  __shared__ double red_v[LDL_THREADS];
-  __shared__ int red_i[LDL_THREADS];
-  const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
-  const int k0 = panel * NB, kb = min(NB, ns - k0);
-  double *Fs = F + tab.foff[s];
-  double *cb = colbuf + tab.woff[s] + s;                          // probe scratch: ms + 1 doubles per front
-  const int tid = threadIdx.x, bs = blockDim.x;
-  const int tx = tid & 63, ty = tid >> 6, ny = bs >> 6;
-  const double maxu = ubp[1], ub = ubp[2] / (maxu * maxu);      // ubp[2] = max diagonal (k_prep_pivots)
-  if (load_block) {
-    double sv[NB / (LDL_THREADS / 64)];
-    const double *pc = Fs + (int64_t)k0 * ld + k0 + min(tx, kb - 1);
-#pragma unroll
-    for (int q = 0; q < NB / (LDL_THREADS / 64); q++) sv[q] = pc[(int64_t)min(ty + ny * q, kb - 1) * ld];     // all loads in flight
-#pragma unroll
-    for (int q = 0; q < NB / (LDL_THREADS / 64); q++) {
-      const int j = ty + ny * q;
-      // (columns beyond a partial block: unit diagonal, so that the straight-line sweep stays finite there)
-      if (j < NB) { S[tx][j] = (tx < kb && j <= tx) ? sv[q] : ((tx == j && tx >= kb) ? 1.0 : 0.0); Lc[j * NB + tx] = 0.0; }
-    }
-  }
-  if (tid < NB) { lbs[tid] = tid < kb ? lb[first + k0 + tid] : 0.0; ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
-  if (tid == 0) { badflag = 0; *npub = 0; }
-  SDM_PHASE_BEGIN();
-  __syncthreads();
-  SDM_PHASE(16);
-  // ---- LDL' of the block (see the header): wavefront 0 sweeps SW columns in registers while the other wavefronts
-  // apply the previous sweep to the trailing columns.  The sweep is straight-line code: a skipped pivot gives the
-  // multiplier 0, a pivot that needs the probe only raises `bad` (everything computed after it is discarded: the
-  // block is redone by the general path), the bookkeeping of pivot gc lives in lane gc.
-  const int nsw = (kb + SW - 1) / SW;
-  if (ty == 0) {
-    SDM_SETPRIO(3);
-    const double mylb = lbs[tx];
-    double xs[SW];                                                     // columns of the sweep just finished (unscaled)
-    for (int s = -1; s < nsw - 1; s++) {
+// ---- the two inner pieces of the diagonal block's LDL' (ldl_diag_block describes the method; k_ldl_front's chain
+// workgroup runs the same pieces with a different cast of wavefronts).
+// Wavefront 0, one sweep: sweep s (columns c0 = s*SW ..) is final and sits in xs (unscaled); the next SW columns cn .. are
+// brought up to date with it (look-ahead), swept in registers (lane = row; pivots and multipliers by v_readlane), written
+// back to S / Lc, and the bookkeeping of their pivots is done in the pivots' own lanes.
+__device__ __forceinline__ void diag_sweep_w0(double (*S)[NB + 1], double *Lc, int s, double (&xs)[SW], double mylb, int tx, int kb, int k0, int ms,
+                                              double ub, double *ds, int *stt, double *pv, int *badflag_p) {
+  SDM_FP_STRICT;
+  int &badflag = *badflag_p;
       const int c0 = s * SW, cn = c0 + SW;                             // sweep s is final; sweep columns cn .. cn+SW-1 now
       double x[SW], lsc[SW];
 #pragma unroll
@@ -787,19 +753,16 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
         if (!acc) { stt[tx] = 1; pv[tx] = pval; }
         if (acc && ms - (k0 + tx) > 1 && pval < ub) badflag = 1;       // needs the column probe: general path below
       }
-      SDM_PHASE(17);
-      __syncthreads();
-      SDM_PHASE(19);
-    }
-    SDM_SETPRIO(0);
-  } else if (ty < ny - 1) {
-    __syncthreads();                                                   // sweep 0
-    for (int s = 0; s < nsw - 1; s++) {
+}
+// One of nw helper wavefronts (widx = 0 .. nw-1), one sweep: sweep s goes into the trailing columns from c0 + 2 SW on
+// (x_rj -= l_jk * x_rk, k ascending), 4 columns per wavefront at a time.
+__device__ __forceinline__ void diag_trail(double (*S)[NB + 1], const double *Lc, int s, int kb, int tx, int widx, int nw) {
+  SDM_FP_STRICT;
       const int c0 = s * SW;
       double xk[SW];
 #pragma unroll
       for (int k = 0; k < SW; k++) xk[k] = S[tx][c0 + k];
-      for (int j0 = c0 + 2 * SW + 4 * (ty - 1); j0 < kb; j0 += 4 * (ny - 2)) {   // 4 columns per wavefront at a time
+      for (int j0 = c0 + 2 * SW + 4 * widx; j0 < kb; j0 += 4 * nw) {   // 4 columns per wavefront at a time
         double v[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) v[u] = S[tx][min(j0 + u, NB - 1)];
@@ -815,6 +778,102 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
         for (int u = 0; u < 4; u++)
           if (j0 + u < kb && tx >= j0 + u) S[tx][j0 + u] = v[u];
       }
+}
+
+// columns 16 g .. 16 g + 15 of the factored block into its transposed copy DT, one wavefront, lane = row: a row's 16 entries are
+// contiguous there (128 bytes), so they go out as eight 16-byte write-through stores -- full fabric writes -- instead of one
+// 8-byte write per lane and column (the publication lagged the sweeps by 4-5 us per group that way: profiles/r03k).  The pivot
+// travels in the diagonal slot; what lies above the diagonal is not read by anybody (zeros).
+__device__ __forceinline__ void publish_group(double *Dsp, const double *Lc, const double *ds, int g, int tx) {
+  if (tx < 16 * g) return;
+  double v[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const int j = 16 * g + c;
+    v[c] = tx > j ? Lc[j * NB + tx] : (tx == j ? ds[j] : 0.0);
+  }
+#if defined(SDM_PUB8)
+#pragma unroll
+  for (int c = 0; c < 16; c++) sdm_store_wt(&Dsp[tx * NB + 16 * g + c], v[c]);
+#else
+#pragma unroll
+  for (int p2 = 0; p2 < 8; p2++) sdm_store_wt2(&Dsp[tx * NB + 16 * g + 2 * p2], v[2 * p2], v[2 * p2 + 1]);
+#endif
+}
+// what ldl_diag_block needs of a front's descriptor, fetched ONCE by k_ldl_front (every read of the tables in HBM is a
+// dependent load of a microsecond, and the noinline stages of that kernel would each repeat them on the chain)
+struct FrontDesc { int ns, ms, ld, first; int64_t foff, toff, woff; double maxu, ub; };
+template <bool PERSIST>
+__device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT, const FrontTab &tab, int s, int panel, double *d, double *lb,
+                                               const double *ubp, int *pivstat, double *pivval, double *colbuf, const double *ada,
+                                               const int *asm_src, const int64_t *Ljc, int mtot, int *upd_cnt, int *diag_cnt, int q0, int *tmo,
+                                               bool load_block, bool publish, double *ds, int *npub, bool raw_in_lds = false, int pub_skip = 0,
+                                               const double *lbs_pre = nullptr, const FrontDesc *fd = nullptr,
+                                               int *owed_a = nullptr, int *owed_b = nullptr) {
+  // owed_a / owed_b (k_ldl_front): counters the workgroup owes for write-through stores it issued just before this block (the rows of L of
+  // the chain's row solve): counted behind the first sweep, when their acknowledgements have long arrived -- not waited for on the chain
+  // lbs_pre (k_ldl_front): the block's pivot thresholds, fetched into LDS when the workgroup started (one global round trip off the chain)
+  // pub_skip (k_ldl_front's chain workgroup redoing a block on the general path): 16-column groups of this block already counted in diag_cnt
+  // raw_in_lds (k_ldl_front): the raw block is not in the front but in LDS behind the wave tiles (front_rows_diag)
+  SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
+  double (*S)[NB + 1] = (double (*)[NB + 1])smem;                 // diagonal block, S[row][col]
+  double *RB = (double *)smem + NB * (NB + 1);                    // Lc during the LDL', then Xs / the wave tiles of the row solve
+  double *Lc = RB;                                                // Lc[k*NB+i] = l_ik
+  __shared__ double lbs[NB], pv[NB];
+  __shared__ int stt[NB];
+  __shared__ int badflag;
+  __shared__ double red_v[LDL_THREADS];
+  __shared__ int red_i[LDL_THREADS];
+  const int ns = fd ? fd->ns : tab.ns[s], ms = fd ? fd->ms : tab.ms[s], ld = fd ? fd->ld : tab.ld[s], first = fd ? fd->first : tab.first[s];
+  const int64_t toff_s = fd ? fd->toff : tab.toff[s];
+  const int k0 = panel * NB, kb = min(NB, ns - k0);
+  double *Fs = F + (fd ? fd->foff : tab.foff[s]);
+  double *cb = colbuf + (fd ? fd->woff : tab.woff[s]) + s;        // probe scratch: ms + 1 doubles per front
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int tx = tid & 63, ty = tid >> 6, ny = bs >> 6;
+  const double maxu = fd ? fd->maxu : ubp[1], ub = fd ? fd->ub : ubp[2] / (maxu * maxu);      // ubp[2] = max diagonal (k_prep_pivots)
+  if (load_block) {
+    double sv[NB / (LDL_THREADS / 64)];
+    const double *pc = Fs + (int64_t)k0 * ld + k0 + min(tx, kb - 1);
+#pragma unroll
+    for (int q = 0; q < NB / (LDL_THREADS / 64); q++) sv[q] = pc[(int64_t)min(ty + ny * q, kb - 1) * ld];     // all loads in flight
+#pragma unroll
+    for (int q = 0; q < NB / (LDL_THREADS / 64); q++) {
+      const int j = ty + ny * q;
+      // (columns beyond a partial block: unit diagonal, so that the straight-line sweep stays finite there)
+      if (j < NB) { S[tx][j] = (tx < kb && j <= tx) ? sv[q] : ((tx == j && tx >= kb) ? 1.0 : 0.0); Lc[j * NB + tx] = 0.0; }
+    }
+  }
+  if (tid < NB) { lbs[tid] = lbs_pre ? lbs_pre[tid] : (tid < kb ? lb[first + k0 + tid] : 0.0); ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
+  if (tid == 0) { badflag = 0; *npub = 0; }
+  SDM_PHASE_BEGIN();
+  __syncthreads();
+  SDM_PHASE(16);
+  if (PERSIST) SDM_TRACE(16 * panel + 0);                              // D: sweeps start
+  // ---- LDL' of the block (see the header): wavefront 0 sweeps SW columns in registers while the other wavefronts
+  // apply the previous sweep to the trailing columns.  The sweep is straight-line code: a skipped pivot gives the
+  // multiplier 0, a pivot that needs the probe only raises `bad` (everything computed after it is discarded: the
+  // block is redone by the general path), the bookkeeping of pivot gc lives in lane gc.
+  const int nsw = (kb + SW - 1) / SW;
+  if (ty == 0) {
+    SDM_SETPRIO(3);
+    const double mylb = lbs[tx];
+    double xs[SW];                                                     // columns of the sweep just finished (unscaled)
+    for (int s = -1; s < nsw - 1; s++) {
+      diag_sweep_w0(S, Lc, s, xs, mylb, tx, kb, k0, ms, ub, ds, stt, pv, &badflag);
+      SDM_PHASE(17);
+      if (s == -1 && owed_a) SDM_STORES_DONE();
+      __syncthreads();
+      SDM_PHASE(19);
+    }
+    SDM_SETPRIO(0);
+    if (PERSIST) SDM_TRACE(16 * panel + 1);                            // D: sweeps end
+  } else if (ty < ny - 1) {
+    if (owed_a) SDM_STORES_DONE();
+    __syncthreads();                                                   // sweep 0
+    if (owed_a && ty == 1 && tx == 0) { sdm_signal_add(owed_a); if (owed_b) sdm_signal_add(owed_b); }
+    for (int s = 0; s < nsw - 1; s++) {
+      diag_trail(S, Lc, s, kb, tx, ty - 1, ny - 2);
       SDM_PHASE(18);
       __syncthreads();
     }
@@ -824,8 +883,9 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
     // by then), the count the row-solve workgroups of this launch poll goes up by one.  Nothing is published from a
     // sweep on in which a pivot asked for the probe (the block is redone by the general path; what was published
     // before is what the general path computes again).
-    double *Dsp = DT + tab.toff[s] + (int64_t)panel * NB * NB;
-    int issued = 0, signalled = 0;
+    double *Dsp = DT + toff_s + (int64_t)panel * NB * NB;
+    int issued = pub_skip, signalled = pub_skip;
+    if (owed_a) SDM_STORES_DONE();
     __syncthreads();                                                   // sweep 0
     for (int sw = 0; sw < nsw - 1; sw++) {
       if (publish) {
@@ -836,11 +896,7 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
         }
         const int g = issued;                                          // sweeps 0 .. sw are final: columns < 8 (sw+1)
         if (SW * (sw + 1) >= 16 * (g + 1) && badflag == 0) {
-#pragma unroll
-          for (int c = 0; c < 16; c++) {
-            const int j = 16 * g + c;
-            if (tx >= j) sdm_store_wt(&Dsp[tx * NB + j], tx == j ? 1.0 : Lc[j * NB + tx]);
-          }
+          publish_group(Dsp, Lc, ds, g, tx);
           if (tx < 16 && 16 * g + tx < kb) sdm_store_wt(&d[first + k0 + 16 * g + tx], ds[16 * g + tx]);
           issued = g + 1;
         }
@@ -850,11 +906,7 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
     // after the last sweep: what is left of the block, right away (the epilogue below would be 2-3 us later)
     if (publish && badflag == 0) {
       for (int g = issued; 16 * g < kb; g++) {
-#pragma unroll
-        for (int c = 0; c < 16; c++) {
-          const int j = 16 * g + c;
-          if (tx >= j) sdm_store_wt(&Dsp[tx * NB + j], tx == j ? 1.0 : Lc[j * NB + tx]);
-        }
+        publish_group(Dsp, Lc, ds, g, tx);
         if (tx < 16 && 16 * g + tx < kb) sdm_store_wt(&d[first + k0 + 16 * g + tx], ds[16 * g + tx]);
         issued = g + 1;
       }
@@ -906,7 +958,7 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
   __syncthreads();
   SDM_PHASE(21);
   {
-    double *Ds = DT + tab.toff[s] + (int64_t)panel * NB * NB;
+    double *Ds = DT + toff_s + (int64_t)panel * NB * NB;
     // the factored block goes in place from THIS workgroup in every case: it also stored the raw updated block (tile
     // (0,0) of the previous update), and two workgroups writing the same lines in one launch may sit behind different
     // L2s whose write-back order is not defined
@@ -915,7 +967,7 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
       if (tx < kb && tx >= j) {
         const double v = (tx == j) ? 1.0 : S[tx][j];                // unit diagonal stored explicitly (blkchol2.c:136)
         if (inplace) Fs[(int64_t)(k0 + j) * ld + k0 + tx] = v;
-        sdm_store_wt(&Ds[tx * NB + j], v);                          // transposed copy of the block (backward solve, row solve)
+        sdm_store_wt(&Ds[tx * NB + j], tx == j ? ds[j] : v);        // transposed copy of the block for the row solves; its diagonal slots carry the pivots
       }
     if (tid < kb) {
       const int gk = first + k0 + tid;
@@ -1100,6 +1152,51 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   SDM_PHASE(23);
 }
 
+// ---- hand-over of a factored diagonal block to the workgroups of k_ldl_front that solve rows against it: DATA-TAGGED.  The
+// transposed copy DT of every block starts a factorisation filled with a sentinel (k_prep_pivots); the block's workgroup
+// stores each 16-column group write-through as it becomes final -- the pivots in the diagonal slots of DT, which nobody else
+// reads -- and the consumers poll the 8-byte words they need until none of them is the sentinel.  No counter, no
+// acknowledgement wait, no second round trip between "it is there" and "here it is": the flag-then-load form (store,
+// s_waitcnt, counter, poll, sc1 read) was 5.5 us of the 22.8 us per panel of control07's chain.  diag_cnt
+// is still counted for the consumers that are not on the chain (k_ldl_panel's row solves, k_sinv_follow, the column probe).
+__device__ __forceinline__ bool is_dt_sentinel(double v) { union { double d; unsigned long long u; } b; b.d = v; return b.u == DT_SENTINEL; }
+__device__ __forceinline__ double dt_tagged_load(const double *a, int *tmo) {
+  double v = sdm_load_wt(a);
+  for (long it = 0; is_dt_sentinel(v) && it < (1L << 21); it++) { SDM_SPIN_PAUSE(); v = sdm_load_wt(a); if (it + 1 == (1L << 21)) sdm_raise_flag(tmo); }
+  return v;
+}
+// columns 16 blk .. 16 blk + 15 of the block (strictly lower part, rows < kb) into S, their pivots into dsr; all work-items.
+// Every load of a work-item (two entries, for 16 of them a pivot) is in flight before the first one is looked at: ONE memory
+// round trip per group when the data is there, not one per word.
+__device__ __forceinline__ void diag_group_fetch(const double *Ds, int blk, int kb, double (*S)[NB + 1], double *dsr, int *tmo) {
+  const int tid = threadIdx.x;
+  constexpr int NE = NB * 16 / LDL_THREADS;
+  const double *a[NE + 1];
+  double v[NE + 1];
+  bool need[NE + 1];
+#pragma unroll
+  for (int t = 0; t < NE; t++) {
+    const int e = tid + LDL_THREADS * t, i = e >> 4, j = 16 * blk + (e & 15);
+    need[t] = i < kb && j < i;
+    a[t] = &Ds[i * NB + j];
+  }
+  need[NE] = tid < 16 && 16 * blk + tid < kb;
+  a[NE] = &Ds[(16 * blk + (tid & 15)) * NB + 16 * blk + (tid & 15)];
+#pragma unroll
+  for (int t = 0; t <= NE; t++) v[t] = need[t] ? sdm_load_wt(a[t]) : 0.0;
+#pragma unroll
+  for (int t = 0; t <= NE; t++)
+    if (need[t])
+      for (long it = 0; is_dt_sentinel(v[t]) && it < (1L << 21); it++) { SDM_SPIN_PAUSE(); v[t] = sdm_load_wt(a[t]); if (it + 1 == (1L << 21)) sdm_raise_flag(tmo); }
+#pragma unroll
+  for (int t = 0; t < NE; t++) {
+    const int e = tid + LDL_THREADS * t, i = e >> 4, j = 16 * blk + (e & 15);
+    S[i][j] = v[t];
+  }
+  if (tid < 16) dsr[16 * blk + tid] = v[NE];
+  __syncthreads();
+}
+
 // k_ldl_front calls its three stages through real function calls: each gets a register allocation of its own.  Inlined
 // into one body they share 256 VGPRs with the sweep code of the diagonal block and spill inside the store loops -- and a
 // scratch reload between two write-through stores waits for the first one's acknowledgement (vmcnt counts in order):
@@ -1112,9 +1209,9 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
 __device__ SDM_NOINLINE bool front_diag(char *smem, double *F, double *DT, const FrontTab &tab, int s, int panel, double *d, double *lb, const double *ubp,
                                         int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src, const int64_t *Ljc,
                                         int mtot, int *upd_done, int *diag_cnt, int *tmo, bool load_block, bool publish, double *ds, int *npub,
-                                        bool raw_in_lds) {
+                                        bool raw_in_lds, const double *lbs_pre, FrontDesc fd, int *owed_a, int *owed_b) {
   return ldl_diag_block<true>(smem, F, DT, tab, s, panel, d, lb, ubp, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, 0, tmo,
-                              load_block, publish, ds, npub, raw_in_lds);
+                              load_block, publish, ds, npub, raw_in_lds, 0, lbs_pre, &fd, owed_a, owed_b);
 }
 // kind 0: plain (result to the front only), 2: also the wave tiles of the next row solve (RB)
 __device__ SDM_NOINLINE void front_update(int kind, double *Fs, int ld, int ms, int first, int k0, int I, int J, const double *d, char *smem,
@@ -1138,13 +1235,7 @@ __device__ SDM_NOINLINE void front_rows(double *Fs, const double *Ds, const doub
   if (!have_tw && busy) rows_stage(Fs, ld, rend, k0, kb, R0, Tw, tx);
   for (int blk = 0; blk < NB / 16 && 16 * blk < kb; blk++) {
     if (busy) rows_block_gemm(blk, S, Tw, tx);
-    spin_until(diag_cnt_s, 4 * q + blk + 1, tmo, false);             // the block and its pivots come through sc1 loads
-    for (int e = tid; e < NB * 16; e += LDL_THREADS) {
-      const int i = e >> 4, j = 16 * blk + (e & 15);
-      S[i][j] = (i < kb && j < i) ? sdm_load_wt(&Ds[i * NB + j]) : 0.0;
-    }
-    if (tid < 16) dsr[16 * blk + tid] = 16 * blk + tid < kb ? sdm_load_wt(&d[first + k0 + 16 * blk + tid]) : 0.0;
-    __syncthreads();
+    diag_group_fetch(Ds, blk, kb, S, dsr, tmo);                      // polls the data itself (DT starts as a sentinel)
     if (busy) rows_block_tri(blk, S, dsr, Tw, tx);
   }
   if (busy) rows_store<true>(Fs, ld, rend, k0, kb, R0, dsr, Tw, tx);
@@ -1178,13 +1269,8 @@ __device__ SDM_NOINLINE void front_rows_diag(double *Fs, const double *Ds, const
   if (!have_tw && busy) rows_stage(Fs, ld, rend, k0, NB, R0, Tw, tx);
   for (int blk = 0; blk < NB / 16; blk++) {
     if (busy) rows_block_gemm(blk, S, Tw, tx);
-    spin_until(diag_cnt_s, 4 * q + blk + 1, tmo, false);             // the block and its pivots come through sc1 loads
-    for (int e = tid; e < NB * 16; e += LDL_THREADS) {
-      const int i = e >> 4, j = 16 * blk + (e & 15);
-      S[i][j] = j < i ? sdm_load_wt(&Ds[i * NB + j]) : 0.0;
-    }
-    if (tid < 16) dsr[16 * blk + tid] = sdm_load_wt(&d[first + k0 + 16 * blk + tid]);
-    __syncthreads();
+    diag_group_fetch(Ds, blk, NB, S, dsr, tmo);                      // polls the data itself (DT starts as a sentinel)
+    SDM_TRACE(16 * q + 2 + blk);                                     // R of the chain workgroup: group blk has arrived
     if (busy) {
       rows_block_tri(blk, S, dsr, Tw, tx);
       // l = x / d of the block's 16 columns: to the front (write-through) and to Lt (rows beyond the front: 0)
@@ -1222,6 +1308,7 @@ __device__ SDM_NOINLINE void front_rows_diag(double *Fs, const double *Ds, const
         if (ti < kbn) S[ti][tj] = v;
       }
     }
+  SDM_TRACE(16 * q + 7);                                               // chain workgroup: its diagonal tile is in the LDS arrays of the LDL'
 }
 
 // ---- the whole LDL' of a front in ONE launch (fronts of FRONT_MINMS <= m_s <= 64 FRONT_MAXT rows; chol_build decides per
@@ -1282,18 +1369,27 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
   const int r = blockIdx.x;
   if (r >= T) return;
   const bool carry = phase == 0;
-  bool have_S = false, have_tw = false, raw_in_lds = false;
+  FrontDesc fd;
+  fd.ns = ns; fd.ms = ms; fd.ld = ld; fd.first = first; fd.foff = tab.foff[s]; fd.toff = tab.toff[s]; fd.woff = tab.woff[s];
+  fd.maxu = ubp[1]; fd.ub = ubp[2] / (fd.maxu * fd.maxu);
+  __shared__ double lbs_pre[NB];
+  if (carry && r < NP && tid < NB) lbs_pre[tid] = r * NB + tid < ns ? lb[first + r * NB + tid] : 0.0;      // thresholds of the block this workgroup will factor
+  bool have_S = false, have_tw = false, raw_in_lds = false, owed = false;
   for (int q = carry ? 0 : step; q < (carry ? NP : step + 1) && q <= r; q++) {
     const int k0 = q * NB, kb = min(NB, ns - k0);
     if (q == r) {
       if (phase == 0 || phase == 1) {
         const int nrows = ms - (k0 + kb);
         front_diag(smem, F, DT, tab, s, q, d, lb, ubp, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, tmo,
-                   !have_S, nrows > 0, ds, &npub, raw_in_lds);
+                   !have_S, nrows > 0, ds, &npub, raw_in_lds, carry ? lbs_pre : nullptr, fd, owed ? &row_cnt[r] : nullptr, owed ? &upd_done[r] : nullptr);
         if (nrows > 0) {
           if (16 * npub < kb) SDM_STORES_DONE();
           __syncthreads();
           if (tid == 0) sdm_signal_add(&diag_cnt[s], 4 - npub);
+        } else {                                                      // nobody in this launch waits for the last block; k_sinv_follow does
+          SDM_STORES_DONE();
+          __syncthreads();
+          if (tid == 0) sdm_signal_add(&diag_cnt[s], 4);
         }
       }
       break;
@@ -1331,10 +1427,14 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
       if (crit_lds) {
         have_S = true; raw_in_lds = true;
         SDM_FPHASE(4);
+        // (counting these from inside the next LDL', behind its first sweep, takes the acknowledgement wait off this workgroup's
+        // path -- and puts 2 us on the path of tile row r + 1, whose last update before ITS turn waits for exactly this count:
+        // measured slower, profiles/r03l)
         SDM_STORES_DONE();
         __syncthreads();
         if (tid == 0) { sdm_signal_add(&row_cnt[r]); sdm_signal_add(&upd_done[r]); }
         SDM_FPHASE(5);
+        SDM_TRACE(16 * q + 8);                                         // its rows acknowledged and counted
         continue;
       }
       if (tid == 0) sdm_signal_add(&row_cnt[r]);
@@ -1418,7 +1518,7 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
   hipStream_t st = P->stream;
   FrontTab tab = front_tab(C);
   const int m = (int)C.m;
-  
+  P->factored = false;               // until the launches below have all been issued: a factorisation that throws leaves no factor behind
 #ifndef SDM_EMU
   SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_RIDE));
   SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FRONT_LDS));
@@ -1430,9 +1530,14 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
     SDM_KLAUNCH(P, k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
                C.d_asm_dst.p, (int64_t)C.nnzL, C.ub.p);
   }
-  SDM_KLAUNCH(P, k_prep_pivots, dim3(grid1d(m, 256, 64)), dim3(256), 0, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
+  // (DT needs its sentinel only where k_ldl_front runs; the launch-per-panel levels wait on counters)
+  bool any_persist = false;
+  for (int l = 0; l < C.nlevels; l++) any_persist = any_persist || C.lev_persist[l];
+  const int64_t ndt = any_persist ? C.tsize : 0;
+  SDM_KLAUNCH(P, k_prep_pivots, dim3(grid1d(std::max<int64_t>(m, ndt / 4), 256, 256)), dim3(256), 0, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
              P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, (int)C.nsuper, C.upd_cnt.p, C.diag_cnt.p,
-             C.sb_g.p, (int)C.sb_g.n, C.front_cnt.p, (int)C.front_cnt.n);
+             C.sb_g.p, (int)C.sb_g.n, C.front_cnt.p, (int)C.front_cnt.n, (unsigned long long *)C.frontsT.p, ndt);
+  const bool follow = C.follow;
   for (int l = 0; l < C.nlevels; l++) {
     const int *list = C.d_levlist.p + C.levptr[l];
     const int nfr = C.levptr[l + 1] - C.levptr[l];
@@ -1444,12 +1549,31 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
       for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) maxnp = std::max(maxnp, (C.sn_ns[C.levlist[i]] + NB - 1) / NB);
       for (int step = 0; step < maxnp; step++)
         for (int phase = 1; phase <= 3; phase++)
-#else
-      const int phase = 0, step = 0;
-#endif
           SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
                       C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p,
                       C.diag_cnt.p, phase, step, C.lev_maxT[l], C.tmo.dev());
+      if (follow) solve_follow(P, l, st);                            // (workgroups run one after the other here: behind = after)
+#else
+      if (follow) {
+        // fork: the inverse of the level's fronts follows the factorisation on the second stream (k_sinv_follow polls
+        // k_ldl_front's progress counters; both kernels' workgroups fit the device together: solve_build), join behind both
+        if (!P->stream2) {
+          SDM_HIP_CHECK(hipStreamCreateWithFlags(&P->stream2, hipStreamNonBlocking));
+          SDM_HIP_CHECK(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
+          SDM_HIP_CHECK(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming));
+        }
+        SDM_HIP_CHECK(hipEventRecord(P->ev_fork, st));
+        SDM_HIP_CHECK(hipStreamWaitEvent(P->stream2, P->ev_fork, 0));
+      }
+      SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
+                  C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p,
+                  C.diag_cnt.p, 0, 0, C.lev_maxT[l], C.tmo.dev());
+      if (follow) {
+        solve_follow(P, l, P->stream2);
+        SDM_HIP_CHECK(hipEventRecord(P->ev_join, P->stream2));
+        SDM_HIP_CHECK(hipStreamWaitEvent(st, P->ev_join, 0));
+      }
+#endif
       continue;
     }
     for (int li = C.lev_first_launch[l]; li < C.lev_first_launch[l + 1]; li++) {
@@ -1468,7 +1592,7 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
         SDM_KLAUNCH(P, k_ldl_update, dim3(L.lasttiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p, 1);
     }
   }
-  solve_prepare(P, /*sb_g_is_zero=*/true);                           // inverses of the diagonal super-blocks for the solves
+  if (!follow) solve_prepare(P, /*sb_g_is_zero=*/true);              // inverses of the diagonal super-blocks for the solves (else: built behind the levels)
   SDM_HIP_CHECK(hipGetLastError());
   P->factored = true;
 }
@@ -1523,6 +1647,9 @@ void vec_divd(sdm_plan *P, double *v) {
 
 #if defined(SDM_PHASES) && !defined(SDM_EMU)
 // tools-only build (python -m sedumi_amd.build --phases): read / reset the in-kernel phase clocks of this file
+extern "C" int sdm_debug_trace_chol(long long *out2048) {
+  return hipMemcpyFromSymbol(out2048, HIP_SYMBOL(sdm_trace_buf), 2048 * sizeof(long long)) != hipSuccess;
+}
 extern "C" int sdm_debug_phases_chol(unsigned long long *out32, int reset) {
   if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(sdm_phase_acc), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
   if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sdm_phase_acc), z, sizeof(z)) != hipSuccess) return 1; }

@@ -281,7 +281,8 @@ void dense_factor(sdm_plan *P, const double *smult, double maxuden, int *host_fa
     SDM_KLAUNCH(P, k_dden, dim3((m + 255) / 256), dim3(256), 0, D.dden.p, C.dsolve.p, C.d.p, D.dgat.p, D.d_dzir.p, 0, C.lb.p, C.pivstat.p, m, 2);
   } else {
     SDM_KLAUNCH(P, k_dden, dim3((m + 255) / 256), dim3(256), 0, D.dden.p, C.dsolve.p, C.d.p, D.dgat.p, D.d_dzir.p, (int)D.dznnz, C.lb.p, C.pivstat.p, m, 0);
-    SDM_KLAUNCH(P, k_dden, dim3(((int)D.dznnz + 255) / 256), dim3(256), 0, D.dden.p, C.dsolve.p, C.d.p, D.dgat.p, D.d_dzir.p, (int)D.dznnz, C.lb.p, C.pivstat.p, m, 1);
+    if (D.dznnz > 0)                                                    // (dense columns without structural rows: nothing to scatter, and an empty grid is an invalid launch)
+      SDM_KLAUNCH(P, k_dden, dim3(((int)D.dznnz + 255) / 256), dim3(256), 0, D.dden.p, C.dsolve.p, C.d.p, D.dgat.p, D.d_dzir.p, (int)D.dznnz, C.lb.p, C.pivstat.p, m, 1);
     SDM_KLAUNCH(P, k_dden, dim3((m + 255) / 256), dim3(256), 0, D.dden.p, C.dsolve.p, C.d.p, D.dgat.p, D.d_dzir.p, (int)D.dznnz, C.lb.p, C.pivstat.p, m, 2);
   }
   upload_factor_tables(P);

@@ -67,6 +67,12 @@ sdm_plan *sdm_mexcache_plan(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, c
   const char *dev = getenv("SEDUMI_HIP_DEVICE");
   g.plan = sdm_plan_create(dev ? atoi(dev) : 0, nullptr);
   if (!g.plan) return nullptr;
+  // the cached plan owns streams, events and device memory: it goes before the HIP runtime's own exit handlers run (registered
+  // by the first HIP call of the process -- at the latest the ones above -- so this one, registered after them, runs first).
+  // A plan left alive across process exit crashed there (r03g: segmentation fault after the last test of a process that
+  // had called blkchol.mex, when a late mexAtExit teardown reached sdm_plan_destroy behind the runtime's own shutdown).
+  static bool at_exit = false;
+  if (!at_exit) { at_exit = true; std::atexit([] { drop(); }); }
   if (sdm_plan_set_chol(g.plan, m, Ljc, Lir, perm, nsuper, xsuper, Xjc, Xir)) { drop(); return nullptr; }
   g.m = m; g.nnzL = nnzL; g.nsuper = nsuper; g.nnzX = nnzX;
   g.hperm = hp; g.hxs = hx; g.hLjc = hj; g.hLir = hi; g.hXjc = hxj; g.hXir = hxi;
@@ -74,7 +80,7 @@ sdm_plan *sdm_mexcache_plan(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, c
 }
 
 void sdm_mexcache_remember_factor(const double *Lpr_host, sdm_int nnz) {
-  if (!g.plan || nnz != g.nnzL) { g.have_factor = false; return; }
+  if (!g.plan || !Lpr_host || nnz != g.nnzL) { g.have_factor = false; return; }      // (NULL: invalidate -- a refactorisation is starting)
   g.have_factor = true;
   g.Lpr = Lpr_host;
   g.fp_sample = hash_vals(Lpr_host, nnz, SAMPLE);

@@ -33,7 +33,8 @@ constexpr int MFMA_MIN_ROWS = 256;    // fronts with fewer rows below their firs
 constexpr int CHK = 16;               // column chunk of the row substitution held in registers
 constexpr int64_t ASM_FULL_MAX = 4 << 20;   // arenas of up to this many entries are assembled with the zero fill folded in
 constexpr int FRONT_MAXT = 64;        // fronts of up to this many 64-row tile rows (and at least MFMA_MIN_ROWS + NB rows) are factored by ONE launch (k_ldl_front)
-constexpr int FRONT_CNT = 2 * FRONT_MAXT + FRONT_MAXT * FRONT_MAXT;   // counters per front of k_ldl_front: rows solved, update steps, updates per tile
+constexpr int FRONT_XCNT_OFF = 2 * FRONT_MAXT + FRONT_MAXT * FRONT_MAXT;   // behind the counters of k_ldl_front: those of k_sinv_follow (tiles of the inverse done)
+constexpr int FRONT_CNT = FRONT_XCNT_OFF + FRONT_MAXT * FRONT_MAXT;   // counters per front of k_ldl_front: rows solved, update steps, updates per tile; then k_sinv_follow's
 constexpr int FRONT_POOL = 1;         // tiles per tile workgroup of k_ldl_front (levels that would need more keep the launch-per-panel path; SDM_FRONT_POOL overrides)
 constexpr int PANEL_RB = (LDL_THREADS / 64) * NB * 17;     // doubles: max(Lc 64x64, Xs 48 x TRSM_ROWS, 8 wave tiles 64x17)
 constexpr size_t PANEL_LDS = (size_t)(NB * (NB + 1) + PANEL_RB) * sizeof(double);
@@ -172,6 +173,8 @@ struct CholPlan {
   DevBuf<unsigned long long> sb_g;   // per super-block: bit patterns of max|inverse| and max|L block| (growth check); behind them the counters of k_sprep
   DevBuf<int> l_i128, l_items;       // work lists of the inversion: 128-column leaves (4 ints each), combine tiles (8 ints each, sorted by stage)
   int n_i128 = 0, n_items = 0;
+  bool follow = false;               // every front is factored by k_ldl_front and inverted behind it by k_sinv_follow (no solve_prepare launches)
+  std::vector<int> lev_followT;      // grid.x of k_sinv_follow per level: tiles of the inverse of its widest front
   std::vector<int> stage_ptr;        // combine tiles of stage st (= 2 * level + (0: T, 1: X)) are l_items[stage_ptr[st] .. stage_ptr[st+1])
   std::vector<SolveLevel> slev;
   double growth_max = 1e4;           // a super-block whose max|inv| * max|L| exceeds this is solved by substitution
@@ -290,6 +293,8 @@ struct sdm_plan {
   sdm::KProf kprof;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t stream2 = nullptr;         // k_sinv_follow runs here, next to k_ldl_front on `stream` (created on first use)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool has_chol = false, has_ada = false, factored = false;
   sdm::CholPlan chol;
   sdm::AdaPlan ada;
@@ -300,18 +305,19 @@ struct sdm_plan {
   std::vector<hipGraphExec_t> graphs;   // captured launch sequences (sdm_plan_graph_*)
 };
 
-#define SDM_KLAUNCH(P, kernel, grid, block, shmem, ...)                                   \
+#define SDM_KLAUNCH_ON(P, st_, kernel, grid, block, shmem, ...)                           \
   do {                                                                                     \
     if ((P)->kprof.enabled) {                                                              \
       sdm::KProf::Rec r_; r_.name = #kernel; r_.a = (P)->kprof.get(); r_.b = (P)->kprof.get(); \
-      SDM_HIP_CHECK(hipEventRecord(r_.a, (P)->stream));                                    \
-      SDM_LAUNCH(kernel, grid, block, shmem, (P)->stream, __VA_ARGS__);                    \
-      SDM_HIP_CHECK(hipEventRecord(r_.b, (P)->stream));                                    \
+      SDM_HIP_CHECK(hipEventRecord(r_.a, (st_)));                                          \
+      SDM_LAUNCH(kernel, grid, block, shmem, (st_), __VA_ARGS__);                          \
+      SDM_HIP_CHECK(hipEventRecord(r_.b, (st_)));                                          \
       (P)->kprof.recs.push_back(r_);                                                       \
     } else {                                                                               \
-      SDM_LAUNCH(kernel, grid, block, shmem, (P)->stream, __VA_ARGS__);                    \
+      SDM_LAUNCH(kernel, grid, block, shmem, (st_), __VA_ARGS__);                          \
     }                                                                                      \
   } while (0)
+#define SDM_KLAUNCH(P, kernel, grid, block, shmem, ...) SDM_KLAUNCH_ON(P, (P)->stream, kernel, grid, block, shmem, __VA_ARGS__)
 
 namespace sdm {
 // Two launches whose workgroups all have to be resident (k_ldl_front) of different plans (streams) must
@@ -366,7 +372,8 @@ void vec_divd(sdm_plan *P, double *v);
 FrontTab front_tab(CholPlan &C);
 // sdm_solve.hip: inverse-block solves
 void solve_build(sdm_plan *P);                      // host tables + buffers (end of chol_build)
-void solve_prepare(sdm_plan *P, bool sb_g_is_zero);  // after a factorisation: diagonal super-block inverses, premultiplied block rows
+void solve_prepare(sdm_plan *P, bool sb_g_is_zero);  // after a factorisation: inverses of the diagonal super-blocks
+void solve_follow(sdm_plan *P, int level, hipStream_t st);   // the same for the fronts of a k_ldl_front level, launched NEXT to that kernel (CholPlan::follow)
 const double *solve_d(sdm_plan *P);                  // the d the solves divide by: L.d (skipped pivots act as 1), or Ld of deninfac
 void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode);   // mode bits 1 fw | 2 ./d | 4 bw
 void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growth);

@@ -23,6 +23,7 @@ inline bool sdm_lane_pred(bool pred, int lane) { return emu_shfl(pred ? 1.0 : 0.
 inline void sdm_signal_add(int *p, int n = 1) { *p += n; }
 inline void sdm_store_wt(double *p, double v) { *p = v; }
 inline double sdm_load_wt(const double *p) { return *p; }
+inline void sdm_store_wt2(double *p, double a, double b) { p[0] = a; p[1] = b; }
 inline unsigned long long sdm_load_wt_u64(const unsigned long long *p) { return *p; }
 #define SDM_STORES_DONE() do {} while (0)
 inline int sdm_signal_load(const int *p) { return *p; }
@@ -52,6 +53,15 @@ typedef double2 sdm_double2;
 // the workgroup, then one relaxed increment publishes it.  tests/test_abi.py checks the disassembly for the wait.
 __device__ __forceinline__ void sdm_signal_add(int *p, int n = 1) { __hip_atomic_fetch_add(p, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sdm_store_wt(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16 bytes write-through in one instruction (p 16-byte aligned): a row of published data as full-width fabric writes instead of
+// one 8-byte write per lane and word (MI355X_MICROARCH.md: scalar sc1 stores cost 2.7x the dwordx4 time per byte)
+__device__ __forceinline__ void sdm_store_wt2(double *p, double a, double b) {
+  typedef double v2d_ __attribute__((ext_vector_type(2)));
+  v2d_ v; v.x = a; v.y = b;
+  // (the s_nop: a VMEM store of more than 8 bytes must not be followed at once by a write of its data registers -- a hazard
+  // the compiler pads for its own stores and cannot see inside inline assembly; without it the rows came out corrupted)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
 // the matching read: an sc1 load bypasses this CU's L1 (served by L2 / memory), so data another workgroup published with
 // sdm_store_wt needs NO acquire fence (1.7 us: MI355X_MICROARCH.md, price list) before it is read this way
 __device__ __forceinline__ double sdm_load_wt(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -108,7 +118,16 @@ static __device__ unsigned long long sdm_phase_acc[32];
 #define SDM_LPHASE_BEGIN() __shared__ unsigned long long ph_l_[32]; if (threadIdx.x < 32) ph_l_[threadIdx.x] = 0; long long ph_t_ = wall_clock64()
 #define SDM_LPHASE(n) do { const long long t_ = wall_clock64(); if (threadIdx.x == 0) ph_l_[n] += (unsigned long long)(t_ - ph_t_); ph_t_ = t_; } while (0)
 #define SDM_LPHASE_END() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 32; i_++) if (ph_l_[i_]) atomicAdd(&sdm_phase_acc[i_], ph_l_[i_]); } while (0)
+// time stamps of single events (tools/trace_front.py): sdm_trace_buf[slot] = wall_clock64() by work-item 0 of the workgroup
+static __device__ long long sdm_trace_buf[2048];
+#define SDM_TRACE(slot) do { if (threadIdx.x == 0 && (slot) >= 0 && (slot) < 2048) sdm_trace_buf[(slot)] = wall_clock64(); } while (0)
+// the same for lane 0 of whichever wavefront executes it (the caller picks the wavefront)
+#define SDM_WPHASE_BEGIN() long long wph_t_ = wall_clock64()
+#define SDM_WPHASE(n) do { const long long t_ = wall_clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&sdm_phase_acc[n], (unsigned long long)(t_ - wph_t_)); wph_t_ = t_; } while (0)
 #else
+#define SDM_WPHASE_BEGIN() do {} while (0)
+#define SDM_WPHASE(n) do {} while (0)
+#define SDM_TRACE(slot) do {} while (0)
 #define SDM_PHASE_BEGIN() do {} while (0)
 #define SDM_PHASE(n) do {} while (0)
 #define SDM_LPHASE_BEGIN() do {} while (0)

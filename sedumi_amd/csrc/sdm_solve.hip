@@ -41,6 +41,7 @@ constexpr size_t TILE_LDS = (size_t)2 * 64 * TP * sizeof(double);     // k_stile
 constexpr int GRPW = 1024;       // columns (forward) / rows (backward) of a slab product in flight at a time: 32 16-byte loads per work-item
 
 // ---------------------------------------------------------------- host tables
+static void follow_decide(sdm_plan *P);
 void solve_build(sdm_plan *P) {
   CholPlan &C = P->chol;
   const int nsuper = (int)C.nsuper;
@@ -127,6 +128,30 @@ void solve_build(sdm_plan *P) {
       }
     }
   }
+  follow_decide(P);
+}
+
+// Can the inverses be built BEHIND the factorisation (k_sinv_follow)?  Every level must be a k_ldl_front level, every front
+// one super-block, and the workgroups of both kernels of a level must fit the device together, one per compute unit
+// (whichever of the two the hardware dispatches first, nobody may be kept out by workgroups that wait).
+static void follow_decide(sdm_plan *P) {
+  CholPlan &C = P->chol;
+  C.follow = false;
+  C.lev_followT.assign(C.nlevels, 0);
+  if (C.nlevels == 0 || C.maxns > C.sbw) return;
+  int ncu = 1 << 20;
+#ifndef SDM_EMU
+  SDM_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, P->device));
+#endif
+  for (int l = 0; l < C.nlevels; l++) {
+    if (!C.lev_persist[l]) return;
+    const int nfr = C.levptr[l + 1] - C.levptr[l];
+    int Tn = 0;
+    for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) Tn = std::max(Tn, (C.sn_ns[C.levlist[i]] + 63) / 64);
+    C.lev_followT[l] = Tn * (Tn + 1) / 2;
+    if ((int64_t)nfr * (C.lev_followT[l] + C.lev_maxT[l] + C.lev_ntw[l]) > ncu - ncu / 8) return;
+  }
+  C.follow = true;
 }
 
 // ================================================================ device helpers
@@ -243,6 +268,99 @@ __device__ __forceinline__ double store_tile(double *dst, int64_t ld, const doub
 }
 
 // ================================================================ inversion of the diagonal super-blocks
+// The two 64x64 unit lower triangular blocks A and C of a leaf, all four wavefronts: rawA / rawC hold their strictly lower
+// triangles column-major (raw[k*TP + i] = L(i, k)), bufA / bufC start as zero and receive the inverses -- inv(A) as a B
+// operand (bufA[k*TP + col] = inv(k, col)), inv(C) as an A operand (bufC[k*TP + row] = inv(row, k)).  One barrier inside;
+// the caller synchronises before it reads the results.  max |inverse| goes to gP.
+// ONLYA: there is no block C (rawC / bufC are not touched; wavefronts 2 and 3 only keep the barriers company).
+template <bool ONLYA = false>
+__device__ __forceinline__ void inv64_pair(double *rawA, double *rawC, double *bufA, double *bufC, int wave, int lane, unsigned long long *gP) {
+  const int blk = wave >> 1, q = wave & 1;                          // wavefront -> (64-block A / C, 32-block inside it)
+  const bool work = !(ONLYA && blk == 1);
+  const double *raw = blk == 0 ? rawA : rawC;
+  double *dst = blk == 0 ? bufA : bufC;
+  if (work) {
+    // ---- 32x32 by columns: lane j owns column j of the inverse in registers, X(i, j) = delta_ij - sum_{k<i} L(i, k) X(k, j);
+    // L(i, k) is the same for every lane: one broadcast LDS read at a compile-time offset per term, no cross-lane traffic
+    // (the earlier row form spent 2 v_readlane + 1 FMA per term on the chain: 6.8 us; this one 496 pipelined reads + FMAs)
+    const int j = lane & 31;
+    const double *Lb = raw + (32 * q) * TP + 32 * q;                 // Lb[k*TP + i] = L(i, k) of this 32-block
+    double X[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      // row i's coefficients are read one row ahead of their use; the dependence on X[i-2] keeps the compiler from hoisting ALL
+      // 496 reads to the top (which it does otherwise -- and then spills them: 79 us instead of 3)
+      double lrow[32];
+      const int z = i >= 2 ? SDM_ZERO_AFTER(X[i - 2]) : 0;           // an opaque 0: row i's reads cannot be issued before row i-2 is done
+#pragma unroll
+      for (int k = 0; k < i; k++) lrow[k] = Lb[k * TP + i + z];
+      double a0 = (i == j) ? 1.0 : 0.0, a1 = 0.0;                    // two partial sums: half the dependent FMA chain
+#pragma unroll
+      for (int k = 0; k < i; k++) {
+        if (k & 1) a1 -= lrow[k] * X[k]; else a0 -= lrow[k] * X[k];
+      }
+      X[i] = a0 + a1;
+    }
+    double gm = 0.0;
+    if (lane < 32) {
+#pragma unroll
+      for (int i = 0; i < 32; i++) {
+        gm = fmax(gm, fabs(X[i]));
+        // inv(A) is kept as a B operand [k*TP + col] = inv(k, col); inv(C) as an A operand [k*TP + row] = inv(row, k)
+        if (blk == 0) dst[(32 * q + i) * TP + 32 * q + j] = X[i]; else dst[(32 * q + j) * TP + 32 * q + i] = X[i];
+      }
+    }
+    wave_atomic_max(gP, gm, lane);
+  }
+  __syncthreads();
+  // ---- 64x64: X10 = -inv11 (L10 inv00) per 64-block on the FP64 matrix cores: two wavefronts per block, wavefront q owns
+  // the two 16x16 tiles of output columns 16q .. 16q+15 of each product, K = 32 = 8 steps of v_mfma_f64_16x16x4_f64.
+  // T goes to the unused upper right quadrant of the raw buffer (rows 32.., columns < 32 of raw[k*TP + i] hold zeros).
+  const int li = lane & 15, lk = lane >> 4;
+  double *Ts = (blk == 0 ? rawA : rawC) + 32 * TP;                   // Ts[r*TP + c]
+  sdm_double4 acc[2];
+  if (work) {
+    for (int t = 0; t < 2; t++) for (int r = 0; r < 4; r++) acc[t][r] = 0.0;
+#pragma unroll
+    for (int s4 = 0; s4 < 8; s4++) {
+      const int k = 4 * s4 + lk;
+      const double b = blk == 0 ? dst[k * TP + 16 * q + li] : dst[(16 * q + li) * TP + k];          // inv00(k, 16q + li)
+#pragma unroll
+      for (int t = 0; t < 2; t++) acc[t] = SDM_MFMA_F64_16x16x4(raw[k * TP + 32 + 16 * t + li], b, acc[t]);   // L10(16t + li, k)
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) Ts[(16 * t + lk + 4 * r) * TP + 16 * q + li] = acc[t][r];
+  }
+  __syncthreads();
+  if (work) {
+    for (int t = 0; t < 2; t++) for (int r = 0; r < 4; r++) acc[t][r] = 0.0;
+#pragma unroll
+    for (int s4 = 0; s4 < 8; s4++) {
+      const int k = 4 * s4 + lk;
+      const double b = Ts[k * TP + 16 * q + li];                                                    // T(k, 16q + li)
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int rr = 16 * t + li;
+        const double a = blk == 0 ? dst[(32 + rr) * TP + 32 + k] : dst[(32 + k) * TP + 32 + rr];    // inv11(rr, k)
+        acc[t] = SDM_MFMA_F64_16x16x4(a, b, acc[t]);
+      }
+    }
+    double gm = 0.0;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rr = 16 * t + lk + 4 * r, c = 16 * q + li;
+        const double v = -acc[t][r];
+        gm = fmax(gm, fabs(v));
+        if (blk == 0) dst[(32 + rr) * TP + c] = v; else dst[c * TP + 32 + rr] = v;
+      }
+    wave_atomic_max(gP, gm, lane);
+  }
+}
+
 // Leaves.  One workgroup per 128-column block h of a front, bottom-up, everything in LDS / registers:
 //   32x32  each of the four wavefronts inverts one 32x32 unit lower triangular diagonal block by columns (lane j owns
 //          column j of the inverse in registers; the entries of L come as broadcast LDS reads at compile-time offsets);
@@ -288,89 +406,7 @@ __device__ __forceinline__ void sinv128_body(char *smem, const double *__restric
   }
   __syncthreads();
   SDM_PHASE(0);
-  const int blk = wave >> 1, q = wave & 1;                          // wavefront -> (64-block A / C, 32-block inside it)
-  const double *raw = blk == 0 ? rawA : rawC;
-  double *dst = blk == 0 ? bufA : bufC;
-  {
-    // ---- 32x32 by columns: lane j owns column j of the inverse in registers, X(i, j) = delta_ij - sum_{k<i} L(i, k) X(k, j);
-    // L(i, k) is the same for every lane: one broadcast LDS read at a compile-time offset per term, no cross-lane traffic
-    // (the earlier row form spent 2 v_readlane + 1 FMA per term on the chain: 6.8 us; this one 496 pipelined reads + FMAs)
-    const int j = lane & 31;
-    const double *Lb = raw + (32 * q) * TP + 32 * q;                 // Lb[k*TP + i] = L(i, k) of this 32-block
-    double X[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) {
-      // row i's coefficients are read one row ahead of their use; the dependence on X[i-2] keeps the compiler from hoisting ALL
-      // 496 reads to the top (which it does otherwise -- and then spills them: 79 us instead of 3)
-      double lrow[32];
-      const int z = i >= 2 ? SDM_ZERO_AFTER(X[i - 2]) : 0;           // an opaque 0: row i's reads cannot be issued before row i-2 is done
-#pragma unroll
-      for (int k = 0; k < i; k++) lrow[k] = Lb[k * TP + i + z];
-      double a0 = (i == j) ? 1.0 : 0.0, a1 = 0.0;                    // two partial sums: half the dependent FMA chain
-#pragma unroll
-      for (int k = 0; k < i; k++) {
-        if (k & 1) a1 -= lrow[k] * X[k]; else a0 -= lrow[k] * X[k];
-      }
-      X[i] = a0 + a1;
-    }
-    double gm = 0.0;
-    if (lane < 32) {
-#pragma unroll
-      for (int i = 0; i < 32; i++) {
-        gm = fmax(gm, fabs(X[i]));
-        // inv(A) is kept as a B operand [k*TP + col] = inv(k, col); inv(C) as an A operand [k*TP + row] = inv(row, k)
-        if (blk == 0) dst[(32 * q + i) * TP + 32 * q + j] = X[i]; else dst[(32 * q + j) * TP + 32 * q + i] = X[i];
-      }
-    }
-    wave_atomic_max(gP, gm, lane);
-  }
-  SDM_PHASE(1);
-  __syncthreads();
-  SDM_PHASE(2);
-  {
-    // ---- 64x64: X10 = -inv11 (L10 inv00) per 64-block on the FP64 matrix cores: two wavefronts per block, wavefront q owns
-    // the two 16x16 tiles of output columns 16q .. 16q+15 of each product, K = 32 = 8 steps of v_mfma_f64_16x16x4_f64.
-    // T goes to the unused upper right quadrant of the raw buffer (rows 32.., columns < 32 of raw[k*TP + i] hold zeros).
-    const int li = lane & 15, lk = lane >> 4;
-    double *Ts = (blk == 0 ? rawA : rawC) + 32 * TP;                 // Ts[r*TP + c]
-    sdm_double4 acc[2];
-    for (int t = 0; t < 2; t++) for (int r = 0; r < 4; r++) acc[t][r] = 0.0;
-#pragma unroll
-    for (int s4 = 0; s4 < 8; s4++) {
-      const int k = 4 * s4 + lk;
-      const double b = blk == 0 ? dst[k * TP + 16 * q + li] : dst[(16 * q + li) * TP + k];          // inv00(k, 16q + li)
-#pragma unroll
-      for (int t = 0; t < 2; t++) acc[t] = SDM_MFMA_F64_16x16x4(raw[k * TP + 32 + 16 * t + li], b, acc[t]);   // L10(16t + li, k)
-    }
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) Ts[(16 * t + lk + 4 * r) * TP + 16 * q + li] = acc[t][r];
-    __syncthreads();
-    for (int t = 0; t < 2; t++) for (int r = 0; r < 4; r++) acc[t][r] = 0.0;
-#pragma unroll
-    for (int s4 = 0; s4 < 8; s4++) {
-      const int k = 4 * s4 + lk;
-      const double b = Ts[k * TP + 16 * q + li];                                                    // T(k, 16q + li)
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const int rr = 16 * t + li;
-        const double a = blk == 0 ? dst[(32 + rr) * TP + 32 + k] : dst[(32 + k) * TP + 32 + rr];    // inv11(rr, k)
-        acc[t] = SDM_MFMA_F64_16x16x4(a, b, acc[t]);
-      }
-    }
-    double gm = 0.0;
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int rr = 16 * t + lk + 4 * r, c = 16 * q + li;
-        const double v = -acc[t][r];
-        gm = fmax(gm, fabs(v));
-        if (blk == 0) dst[(32 + rr) * TP + c] = v; else dst[c * TP + 32 + rr] = v;
-      }
-    wave_atomic_max(gP, gm, lane);
-  }
+  inv64_pair(rawA, rawC, bufA, bufC, wave, lane, gP);
   SDM_PHASE(3);
   __syncthreads();                                                  // bufA = inv(A) (B operand), bufC = inv(C) (A operand); raw buffers free
   if (nbC > 0) lmx = fmax(lmx, stage_colmajor_store(bufB, vB, nbC, 64, tid));
@@ -505,6 +541,110 @@ k_sprep(const double *F, double *S, double *T, FrontTab tab, const int *l_i128, 
   prep_wait(c + st, it[7], tmo);
   stile_body<true>(smem, F, S, T, tab, it, sb_g, W);
   prep_done(c + st + 1);
+}
+
+// ---- the inverse of a whole front BEHIND its factorisation (k_sinv_follow): fronts factored by ONE k_ldl_front launch
+// (sdm_chol.hip) whose columns are one super-block.  Launched on the plan's second stream next to k_ldl_front, it follows
+// that kernel's own progress counters and builds X = inv(L) by block rows of 64:
+//   X(r, r) = inv(L(r, r))                                  as soon as panel r's diagonal block is published (diag_cnt),
+//   X(r, c) = - X(r, r) sum_{q = c}^{r-1} L(r, q) X(q, c)   the sum as the rows L(r, q) are published (row_cnt) and the
+//                                                            tiles X(q, c) arrive (xcnt), the product once X(r, r) is there,
+// one workgroup per 64x64 tile (diagonal tiles first, then the tiles row by row: a workgroup only waits for lower ones --
+// or for the factorisation).  The factor chain takes ~20 us per panel; a tile needs one 64^3 product per panel, so the
+// inverse is complete a few microseconds after the factor instead of a chain of six dependent tile stages later (146 us
+// for control07's 666 columns, r03a).  What it reads was stored write-through by k_ldl_front (DT, d, the rows of L) and
+// is read with sc1 loads; its own tiles likewise.  The emulator launches it after the factorisation.
+// xcnt[r * FRONT_MAXT + c] = 1 once X(r, c) is in S (c = r: the diagonal tile); zeroed with front_cnt by k_prep_pivots.
+__device__ __forceinline__ void follow_wait(const int *cnt, int target, int *tmo) {
+  if (threadIdx.x == 0) {
+    long it = 0;
+    for (; sdm_signal_load(cnt) < target && it < (1L << 22); it++) SDM_SPIN_PAUSE();
+    if (it == (1L << 22)) sdm_raise_flag(tmo);
+  }
+  __syncthreads();
+}
+__global__ void __launch_bounds__(ST)
+k_sinv_follow(const double *F, const double *DT, double *S, FrontTab tab, const int *list, int *front_cnt, const int *diag_cnt,
+              unsigned long long *sb_g, int *tmo) {
+  SDM_DYN_SMEM(smem);
+  const int s = list[blockIdx.y];
+  const int ns = tab.ns[s], ld = tab.ld[s], sld = tab.sld[s];
+  const int T = (ns + 63) / 64;
+  const int b = blockIdx.x;
+  if (b >= T * (T + 1) / 2) return;
+  const double *Fs = F + tab.foff[s];
+  double *Ss = S + tab.soff[s];
+  const int slot = tab.fslot[s];
+  const int *row_cnt = front_cnt + (int64_t)slot * FRONT_CNT;
+  int *xcnt = front_cnt + (int64_t)slot * FRONT_CNT + FRONT_XCNT_OFF;
+  unsigned long long *gP = sb_g + 2 * tab.sboff[s];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (b < T) {
+    // ---- diagonal tile r: inv(L(r, r)) from the transposed copy DT of the factored block
+    const int r = b, nb = min(64, ns - 64 * r);
+    double *bufA = (double *)smem, *rawA = bufA + 64 * TP;          // (TILE_LDS: the two arrays of the tile role)
+    const double *Ds = DT + tab.toff[s] + (int64_t)r * NB * NB;      // Ds[i*NB + k] = L(64r + i, 64r + k)
+    follow_wait(diag_cnt + s, 4 * (r + 1), tmo);
+    double lmx = 0.0;
+    {
+      double va[SPT];
+      const int i = tid & 63, kq = tid >> 6;
+#pragma unroll
+      for (int j = 0; j < SPT; j++) va[j] = sdm_load_wt(&Ds[min(i, nb - 1) * NB + min(kq + (ST / 64) * j, nb - 1)]);
+#pragma unroll
+      for (int j = 0; j < SPT; j++) {
+        const int k = kq + (ST / 64) * j;
+        const double a = (i > k && i < nb) ? va[j] : 0.0;
+        rawA[k * TP + i] = a;
+        bufA[k * TP + i] = 0.0;
+        lmx = fmax(lmx, fabs(a));
+      }
+    }
+    __syncthreads();
+    inv64_pair<true>(rawA, nullptr, bufA, nullptr, wave, lane, gP);
+    __syncthreads();
+    wave_atomic_max(gP + 1, lmx, lane);
+    for (int e = tid; e < 64 * 64; e += ST) {
+      const int i = e & 63, j = e >> 6;
+      if (i >= j && i < nb) sdm_store_wt(&Ss[(int64_t)(64 * r + j) * sld + 64 * r + i], bufA[i * TP + j]);
+    }
+    prep_done(xcnt + r * FRONT_MAXT + r);
+    return;
+  }
+  // ---- tile (r, c), c < r
+  int r = 1, c = b - T;
+  while (c >= r) { c -= r; r++; }
+  double *As = (double *)smem, *Bs = As + 64 * TP;
+  const int arows = min(64, ns - 64 * r);
+  Acc22 acc;
+  acc_zero(acc);
+  double lmx = 0.0;
+  double va[SPT], vb[SPT];
+  for (int q = c; q < r; q++) {
+    follow_wait(row_cnt + r, q + 1, tmo);                            // L(r, q) is in the front
+    follow_wait(xcnt + q * FRONT_MAXT + c, 1, tmo);                  // X(q, c) is in S
+    stage_colmajor_load<true>(va, Fs + (int64_t)(64 * q) * ld + 64 * r, ld, arows, 64, tid);
+    stage_transposed_load<true>(vb, Ss + (int64_t)(64 * c) * sld + 64 * q, sld, 64, 64, tid);
+    lmx = fmax(lmx, stage_colmajor_store(As, va, arows, 64, tid));
+    stage_transposed_store(Bs, vb, 64, 64, tid);
+    __syncthreads();
+    mma_block(acc, As, Bs, wave, lane);
+    __syncthreads();
+  }
+  wave_atomic_max(gP + 1, lmx, lane);
+  follow_wait(xcnt + r * FRONT_MAXT + r, 1, tmo);                    // X(r, r)
+  stage_colmajor_load<true>(va, Ss + (int64_t)(64 * r) * sld + 64 * r, sld, arows, arows, tid);
+  acc_to_lds_rowmajor(acc, Bs, wave, lane, 1.0);                     // the sum as a B operand: Bs[k*TP + col]
+  stage_colmajor_store(As, va, arows, arows, tid);
+  __syncthreads();
+  acc_zero(acc);
+  mma_block(acc, As, Bs, wave, lane);
+  __syncthreads();
+  acc_to_lds_rowmajor(acc, As, wave, lane, -1.0);
+  __syncthreads();
+  const double gm = store_tile<true>(Ss + (int64_t)(64 * c) * sld + 64 * r, sld, As, arows, 64, tid);
+  wave_atomic_max(gP, gm, lane);
+  prep_done(xcnt + r * FRONT_MAXT + c);
 }
 
 // ================================================================ substitution fallback for one super-block
@@ -890,18 +1030,31 @@ static FrontTab level_tab(const CholPlan &C, FrontTab t, int l) {
   t.o_xl = C.sn_xl[s];
   return t;
 }
-void solve_prepare(sdm_plan *P, bool sb_g_is_zero) {
-  CholPlan &C = P->chol;
-  FrontTab tab = front_tab(C);
+static void solve_attrs() {
 #ifndef SDM_EMU
   static bool attr = false;
   if (!attr) {
     SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_sinv128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)INV_LDS));
     SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_stile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS));
     SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_sprep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)INV_LDS));
+    SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_sinv_follow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS));
     attr = true;
   }
 #endif
+}
+// the inverses of the fronts of level l behind their factorisation: launched on stream st right after (next to) k_ldl_front
+void solve_follow(sdm_plan *P, int l, hipStream_t st) {
+  CholPlan &C = P->chol;
+  solve_attrs();
+  C.growth_used = C.growth_max;
+  const int nfr = C.levptr[l + 1] - C.levptr[l];
+  SDM_KLAUNCH_ON(P, st, k_sinv_follow, dim3(C.lev_followT[l], nfr), dim3(ST), TILE_LDS, C.fronts.p, C.frontsT.p, C.S.p, front_tab(C),
+                 C.d_levlist.p + C.levptr[l], C.front_cnt.p, C.diag_cnt.p, C.sb_g.p, C.tmo.dev());
+}
+void solve_prepare(sdm_plan *P, bool sb_g_is_zero) {
+  CholPlan &C = P->chol;
+  FrontTab tab = front_tab(C);
+  solve_attrs();
   C.growth_used = C.growth_max;                                     // the solves decide with the bound in force here
   const size_t gw = (size_t)std::max(C.nsbtot, 1) * (2 + SPREP_NCNT / 2);
   if (!sb_g_is_zero)                                                // (a factorisation zeroes them in k_prep_pivots)

@@ -24,6 +24,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   memcpy(mxGetIr(out[0]), mxGetIr(mxGetField(prhs[0], 0, "L")), nnzL * sizeof(mwIndex));
   out[1] = mxCreateDoubleMatrix(m, 1, mxREAL);
   sdm_plan *p = cached_plan(L, mxGetJc(X), mxGetIr(X));
+  remember_factor(NULL, 0);          // the resident factor is about to be overwritten: whatever the solves are handed before this call has returned is not it
   sdm_check(sdm_plan_upload(p, "ada", mxGetPr(X), (sdm_int)mxGetJc(X)[m]));
   if (absd) sdm_check(sdm_plan_upload(p, "absd", absd, m));
   sdm_check(sdm_plan_blkchol(p, &pars, absd ? 1 : 0));

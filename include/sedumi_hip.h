@@ -357,6 +357,26 @@ int sdm_plan_set_solve_width(sdm_plan *p, sdm_int width);
 int sdm_plan_get_solve_width(sdm_plan *p, sdm_int *width);      /* the width in force (after sdm_plan_set_chol) */
 int sdm_plan_solve_stats(sdm_plan *p, sdm_int *nblocks, sdm_int *nbad, double *max_growth);
 
+/* ---- Separator fronts across GPUs (sedumi_amd/dist.py SeparatorShardedSolver).  The reference relinks a finished
+ * supernode to its parent snode[lindx[xlindx[s] + n_s]] (blkchol2.c:550-554) and pulls its update into it (precorrect,
+ * blkchol2.c:346-420); here a rank factors the subtrees it owns and every rank holds the SAME front arena, so the update
+ * matrices of the separator fronts at the top of the tree are sums of equally laid out slices -- one reduce per etree level.
+ *   set_active_supernodes (before set_chol): the supernodes this plan works on (its subtrees + the top of the tree);
+ *   front_layout: etree level, arena slice ("fronts": foff, fsize), update-vector slice ("wvec": woff, ms), columns (first, ns);
+ *   blkchol_begin: permuteP + pivot thresholds ("ub"[2] = max diagonal, to be max-reduced across the ranks);
+ *   blkchol_levels(l0, l1, extend_only): extend-add into the fronts of levels l0 .. l1-1 and (unless extend_only) their LDL';
+ *   blkchol_end: the inverses for the solves;
+ *   solve_levels(what, l0, l1) on the right-hand side in "rhs": what = 1 assembly of the fronts' right-hand sides (own entries +
+ *     children's update vectors, in "wvec"), 2 the forward sweep of the levels without that assembly, 3 both, 4 the backward
+ *     sweep of levels l1-1 .. l0 (reads the ancestors' solution from "xfin", writes "y").
+ * The plan buffers "fronts", "wvec", "xfin", "ub" are reachable through sdm_plan_devptr / sdm_plan_copy. */
+int sdm_plan_set_active_supernodes(sdm_plan *p, const int *active, sdm_int nsuper);
+int sdm_plan_front_layout(sdm_plan *p, sdm_int *nlevels, sdm_int *level, sdm_int *foff, sdm_int *fsize, sdm_int *woff, sdm_int *ms, sdm_int *first, sdm_int *ns);
+int sdm_plan_blkchol_begin(sdm_plan *p, const sdm_cholpars *pars, int use_absd);
+int sdm_plan_blkchol_levels(sdm_plan *p, sdm_int l0, sdm_int l1, int extend_only);
+int sdm_plan_blkchol_end(sdm_plan *p);
+int sdm_plan_solve_levels(sdm_plan *p, int what, sdm_int l0, sdm_int l1);
+
 /* ---- one process-wide resident plan for the mexFunction shims: every .mex binary is its own
  * shared object, so the cache lives in this library.  sdm_mexcache_plan returns the plan of the symbolic factor
  * (L.{L pattern, perm, xsuper}) and ADA pattern given, creating it on a miss (NULL + sdm_last_error on failure).

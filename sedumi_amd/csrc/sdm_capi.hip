@@ -124,6 +124,11 @@ static DevBuf<double> *plan_buf(sdm_plan *p, const char *name) {
   if (s == "ad") return &p->dense.ad;       // dense columns Ad (m x nden, column major; deninfac.m:58-59)
   if (s == "lad") return &p->dense.lad;     // LAD = L \ Ad(perm,:) of the last sdm_plan_deninfac
   if (s == "dden") return &p->dense.dden;   // Ld of the last sdm_plan_deninfac
+  // the arenas the multi-GPU layer exchanges slices of (sedumi_amd.dist.SeparatorShardedSolver)
+  if (s == "fronts") return &p->chol.fronts;
+  if (s == "wvec") return &p->chol.wvec;
+  if (s == "xfin") return &p->chol.xfin;
+  if (s == "ub") return &p->chol.ub;
   throw std::runtime_error("unknown plan buffer: " + s);
 }
 void *sdm_plan_devptr(sdm_plan *p, const char *name, sdm_int *nelem) {
@@ -199,6 +204,56 @@ int sdm_plan_blkchol(sdm_plan *p, const sdm_cholpars *pars, int use_absd) {
   if (q.abstol < 0.0) q.abstol = 0.0;              // blkchol.c:303
   p->dense.factored = false;                        // the dense-column factors belong to the previous L, d
   chol_factor(p, q.canceltol, q.maxu, q.abstol, use_absd);
+  SDM_CATCH
+}
+// ---- the factorisation and the solve level by level (include/sedumi_hip.h: "Separator fronts across GPUs")
+int sdm_plan_set_active_supernodes(sdm_plan *p, const int *active, sdm_int nsuper) {
+  SDM_TRY
+  p->chol.sn_active.assign(active ? active : nullptr, active ? active + nsuper : nullptr);
+  for (auto &c : p->chol.sn_active) c = c ? 1 : 0;
+  SDM_CATCH
+}
+int sdm_plan_front_layout(sdm_plan *p, sdm_int *nlevels, sdm_int *level, sdm_int *foff, sdm_int *fsize, sdm_int *woff, sdm_int *ms, sdm_int *first, sdm_int *ns) {
+  SDM_TRY
+  if (!p->has_chol) throw std::runtime_error("sdm_plan_front_layout: no symbolic factor set");
+  const sdm::CholPlan &C = p->chol;
+  if (nlevels) *nlevels = C.nlevels;
+  for (sdm_int s = 0; s < C.nsuper; s++) {
+    if (level) level[s] = C.sn_level[s];
+    if (foff) foff[s] = C.sn_foff[s];
+    if (fsize) fsize[s] = (sdm_int)C.sn_ld[s] * C.sn_ms[s];
+    if (woff) woff[s] = C.sn_woff[s];
+    if (ms) ms[s] = C.sn_ms[s];
+    if (first) first[s] = C.sn_first[s];
+    if (ns) ns[s] = C.sn_ns[s];
+  }
+  SDM_CATCH
+}
+int sdm_plan_blkchol_begin(sdm_plan *p, const sdm_cholpars *pars, int use_absd) {
+  SDM_TRY
+  if (!p->has_chol) throw std::runtime_error("sdm_plan_blkchol_begin: no symbolic factor set");
+  sdm_cholpars q = {1e-12, 5e2, 1e-20};
+  if (pars) q = *pars;
+  if (q.abstol < 0.0) q.abstol = 0.0;
+  p->dense.factored = false;
+  chol_begin(p, q.canceltol, q.maxu, q.abstol, use_absd);
+  SDM_CATCH
+}
+int sdm_plan_blkchol_levels(sdm_plan *p, sdm_int l0, sdm_int l1, int extend_only) {
+  SDM_TRY
+  chol_levels(p, (int)l0, (int)l1, extend_only != 0);
+  SDM_CATCH
+}
+int sdm_plan_blkchol_end(sdm_plan *p) {
+  SDM_TRY
+  chol_end(p);
+  SDM_CATCH
+}
+int sdm_plan_solve_levels(sdm_plan *p, int what, sdm_int l0, sdm_int l1) {
+  SDM_TRY
+  if (!p->factored) throw std::runtime_error("sdm_plan_solve_levels: no factor resident");
+  if (p->dense.factored) throw std::runtime_error("sdm_plan_solve_levels: not with a resident dense-column factor");
+  solve_levels(p, what, (int)l0, (int)l1);
   SDM_CATCH
 }
 int sdm_plan_load_factor(sdm_plan *p, const double *Lpr, const double *d) {

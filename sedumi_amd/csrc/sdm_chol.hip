@@ -79,12 +79,14 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
     nlev = std::max(nlev, C.sn_level[s] + 1);
   }
   C.nlevels = nlev;
+  if (!C.sn_active.empty() && (sdm_int)C.sn_active.size() != nsuper) throw std::runtime_error("active-supernode mask does not match the supernode partition");
+  auto active = [&](sdm_int s) { return C.sn_active.empty() || C.sn_active[s] != 0; };
   C.levptr.assign(nlev + 1, 0);
-  for (sdm_int s = 0; s < nsuper; s++) C.levptr[C.sn_level[s] + 1]++;
+  for (sdm_int s = 0; s < nsuper; s++) if (active(s)) C.levptr[C.sn_level[s] + 1]++;
   for (int l = 0; l < nlev; l++) C.levptr[l + 1] += C.levptr[l];
-  C.levlist.resize(nsuper);
+  C.levlist.resize(C.levptr[nlev]);
   { std::vector<int> pos(C.levptr.begin(), C.levptr.end() - 1);
-    for (sdm_int s = 0; s < nsuper; s++) C.levlist[pos[C.sn_level[s]]++] = (int)s; }
+    for (sdm_int s = 0; s < nsuper; s++) if (active(s)) C.levlist[pos[C.sn_level[s]]++] = (int)s; }
   for (int l = 0; l < nlev; l++)
     std::stable_sort(C.levlist.begin() + C.levptr[l], C.levlist.begin() + C.levptr[l + 1],
                      [&](int a, int b) { return C.sn_ns[a] > C.sn_ns[b]; });
@@ -129,6 +131,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   for (int l = 0; l < nlev; l++) {
     C.lev_first_launch[l] = (int)C.launches.size();
     int b = C.levptr[l], e = C.levptr[l + 1];
+    if (b == e) continue;                                            // (no active supernode on this level)
     int maxns = C.sn_ns[C.levlist[b]], maxms = 0;
     for (int i = b; i < e; i++) maxms = std::max(maxms, C.sn_ms[C.levlist[i]]);
     C.lev_T[l] = std::max(1, std::min(128, maxms / 16));
@@ -170,8 +173,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   int nslot = 0;
   {
     const bool off = getenv("SDM_FRONT_OFF") != nullptr;              // comparison override (tools, tests): read at every set_chol
-    const char *mt = getenv("SDM_FRONT_MAXT");                        // (tools) fronts above this many tile rows keep the launch-per-panel path
-    const int maxT_allowed = mt ? std::min(FRONT_MAXT, atoi(mt)) : FRONT_MAXT;
+    const int maxT_allowed = FRONT_MAXT;
     // k_ldl_front's workgroups wait for each other in both directions (a row workgroup for its tile workgroups and vice
     // versa): they must all be resident, one per compute unit (135 KB of LDS each).  A device -- or a partition of one --
     // with fewer compute units than the level needs keeps the launch-per-panel path.
@@ -181,8 +183,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
 #else
     SDM_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, P->device));
 #endif
-    const char *wb = getenv("SDM_FRONT_WGS");                         // (tools, tests) a smaller budget: tile workgroups own several tiles
-    const int wg_budget = std::min(wb ? atoi(wb) : 224, ncu - ncu / 8);   // leave an eighth of the device to whatever else is running
+    const int wg_budget = std::min(224, ncu - ncu / 8);                // leave an eighth of the device to whatever else is running
     for (int l = 0; l < nlev; l++) {
       bool ok = !off;
       int maxT = 0;
@@ -193,14 +194,11 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
         maxT = std::max(maxT, T);
       }
       if (!ok || nfr == 0) continue;
-      // one row workgroup per tile row; the tiles (r, c), c >= 2, are dealt out to the tile workgroups the budget leaves.
-      // By default only levels that get a workgroup per tile qualify (single fronts of up to 21 tile rows on a whole
-      // device): a tile workgroup takes ~20 us per update (one 147 KB workgroup per compute unit, every update a serial
-      // load -> LDS -> MFMA -> write-through chain), so with several tiles each they fall far behind the chain --
-      // measured on MAXCUT-4000's front (63 tile rows, 161 tile workgroups for 1891 tiles): 5.56 ms against 2.26 ms for
-      // the 63 panel launches.  SDM_FRONT_POOL = tiles per workgroup allowed (tests: the dealt-out mapping stays covered).
-      const char *pe = getenv("SDM_FRONT_POOL");
-      const int pool = pe ? std::max(1, atoi(pe)) : FRONT_POOL;
+      // one row workgroup per tile row and ONE tile workgroup per tile (r, c), c >= 2: only levels that fit the device that way
+      // qualify (single fronts of up to 21 tile rows on a whole MI355X).  Tile workgroups that own several tiles were built and
+      // measured in round 2 (MAXCUT-4000's front, 63 tile rows: 5.56 ms against 2.26 ms for the 63 panel launches -- a tile
+      // update costs ~20 us of a 147 KB workgroup, so with several tiles each they fall far behind the chain) and removed.
+      const int pool = FRONT_POOL;
       const int ntiles = (maxT - 1) * (maxT - 2) / 2;
       const int ntw = std::min(ntiles, wg_budget / nfr - maxT);
       if (ntw < 0 || (int64_t)ntw * pool < ntiles) continue;
@@ -1513,7 +1511,7 @@ static inline int grid1d(int64_t n, int bs, int cap = 4096) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
 }
 
-void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd) {
+void chol_begin(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd) {
   CholPlan &C = P->chol;
   hipStream_t st = P->stream;
   FrontTab tab = front_tab(C);
@@ -1537,11 +1535,22 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
   SDM_KLAUNCH(P, k_prep_pivots, dim3(grid1d(std::max<int64_t>(m, ndt / 4), 256, 256)), dim3(256), 0, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
              P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, (int)C.nsuper, C.upd_cnt.p, C.diag_cnt.p,
              C.sb_g.p, (int)C.sb_g.n, C.front_cnt.p, (int)C.front_cnt.n, (unsigned long long *)C.frontsT.p, ndt);
+  C.pars_canceltol = canceltol; C.pars_maxu = maxu; C.pars_abstol = abstol; C.pars_use_absd = use_absd;
+  SDM_HIP_CHECK(hipGetLastError());
+}
+// levels l0 .. l1-1: children's update matrices into the fronts of the level (extend-add), then -- unless extend_only -- its LDL'
+void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
+  CholPlan &C = P->chol;
+  hipStream_t st = P->stream;
+  FrontTab tab = front_tab(C);
+  const int m = (int)C.m;
   const bool follow = C.follow;
-  for (int l = 0; l < C.nlevels; l++) {
+  for (int l = std::max(l0, 0); l < std::min(l1, C.nlevels); l++) {
     const int *list = C.d_levlist.p + C.levptr[l];
     const int nfr = C.levptr[l + 1] - C.levptr[l];
+    if (nfr == 0) continue;
     if (l > 0) SDM_KLAUNCH(P, k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, C.fronts.p, tab, list);
+    if (extend_only) continue;
     if (C.lev_persist[l]) {                                          // the whole level in one launch (k_ldl_front)
       PersistTurn turn(P);
 #ifdef SDM_EMU
@@ -1592,9 +1601,17 @@ void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const d
         SDM_KLAUNCH(P, k_ldl_update, dim3(L.lasttiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p, 1);
     }
   }
-  if (!follow) solve_prepare(P, /*sb_g_is_zero=*/true);              // inverses of the diagonal super-blocks for the solves (else: built behind the levels)
+  SDM_HIP_CHECK(hipGetLastError());
+}
+void chol_end(sdm_plan *P) {
+  if (!P->chol.follow) solve_prepare(P, /*sb_g_is_zero=*/true);      // inverses of the diagonal super-blocks for the solves (else: built behind the levels)
   SDM_HIP_CHECK(hipGetLastError());
   P->factored = true;
+}
+void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd) {
+  chol_begin(P, canceltol, maxu, abstol, use_absd);
+  chol_levels(P, 0, P->chol.nlevels, false);
+  chol_end(P);
 }
 
 // Non-zero when a workgroup gave up waiting for another one inside a launch (never expected; the results of that

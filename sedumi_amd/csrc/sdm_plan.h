@@ -143,6 +143,9 @@ struct CholPlan {
   std::vector<int> sn_first, sn_ns, sn_ms, sn_ld, sn_parent, sn_level;
   std::vector<int64_t> sn_foff, sn_xl, sn_woff, sn_roff, sn_toff;
   std::vector<int> childptr, childlist, levptr, levlist, lev_T;
+  std::vector<char> sn_active;           // empty: every supernode; else the supernodes THIS plan factors and solves (the level lists hold only
+                                         // these: the others keep their place in the arenas and are never touched by a launch -- sedumi_amd.dist)
+  double pars_canceltol = 0, pars_maxu = 0, pars_abstol = 0; int pars_use_absd = 0;   // of the factorisation in progress (chol_begin .. chol_end)
   std::vector<LevelLaunch> launches;     // factor panel launches in execution order
   std::vector<int> lev_first_launch;     // index into launches per level (+ sentinel)
   // device copies
@@ -363,6 +366,10 @@ void set_error(const std::string &msg);
 void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm,
                 sdm_int nsuper, const sdm_int *xsuper, const sdm_int *ADAjc, const sdm_int *ADAir);
 void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd);
+// the same in three steps (sdm_plan_blkchol_begin / _levels / _end: the multi-GPU layer reduces update matrices between levels)
+void chol_begin(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd);
+void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only);
+void chol_end(sdm_plan *P);
 void chol_forget_plan(sdm_plan *P);    // the plan is being destroyed (turn-taking of k_ldl_front launches)
 int chol_wait_timeouts(sdm_plan *P);   // non-zero: a spin inside a panel launch of this plan gave up since the last call (call after a stream sync)
 void chol_extract(sdm_plan *P, double *d_Lpr_out);           // device pointer, nnzL doubles
@@ -376,9 +383,12 @@ void solve_prepare(sdm_plan *P, bool sb_g_is_zero);  // after a factorisation: i
 void solve_follow(sdm_plan *P, int level, hipStream_t st);   // the same for the fronts of a k_ldl_front level, launched NEXT to that kernel (CholPlan::follow)
 const double *solve_d(sdm_plan *P);                  // the d the solves divide by: L.d (skipped pivots act as 1), or Ld of deninfac
 void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode);   // mode bits 1 fw | 2 ./d | 4 bw
+// the fw, ./d, bw solve of solve_run(mode 7) level by level: what = 1 assembly launches of the forward sweep of levels l0 .. l1-1 only,
+// 2 their forward sweep without the assembly, 3 both, 4 the backward sweep of levels l1-1 down to l0
+void solve_levels(sdm_plan *P, int what, int l0, int l1);
 void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growth);
 void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *y, int64_t y_stride, double *wv, int nrhs,
-                    double *zdiv = nullptr, const double *dscale = nullptr);
+                    double *zdiv = nullptr, const double *dscale = nullptr, int l0 = 0, int l1 = -1, int what = 3);
 // sdm_pcg.hip: Amul / vecsym / psdscale on the plan
 void pcg_amul(sdm_plan *P, int transp);
 void pcg_set_dense(sdm_plan *P, sdm_int nden, const sdm_int *cols, const double *Aden);

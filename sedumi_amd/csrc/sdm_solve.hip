@@ -61,8 +61,9 @@ void solve_build(sdm_plan *P) {
     C.sn_soff[s] = soff; C.sn_sld[s] = sld; C.sn_sboff[s] = sb;
     soff += (int64_t)sld * ns;
     const int nsb = (ns + W - 1) / W;
-    for (int h = 0; 128 * h < ns; h++) { i128.push_back(s); i128.push_back(h); i128.push_back(0); i128.push_back(0); }
-    for (int Pb = 0; Pb < nsb; Pb++) {
+    const bool act = C.sn_active.empty() || C.sn_active[s] != 0;     // (supernodes of other ranks: a place in the arena, no work)
+    for (int h = 0; act && 128 * h < ns; h++) { i128.push_back(s); i128.push_back(h); i128.push_back(0); i128.push_back(0); }
+    for (int Pb = 0; act && Pb < nsb; Pb++) {
       const int nb = std::min(W, ns - Pb * W);
       int prev = (nb + 127) / 128;                                    // what stage 0 waits for: the leaves of this super-block
       for (int lev = 0; lev < SINV_MAXLEV; lev++) {
@@ -1094,19 +1095,23 @@ void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growt
 // forward sweeps of nrhs right-hand sides side by side (grid.z): rhs + z*rhs_stride -> y + z*y_stride (permuted order);
 // wv = update-vector scratch of wsize doubles per right-hand side
 void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *y, int64_t y_stride, double *wv, int nrhs,
-                    double *zdiv, const double *dscale) {
+                    double *zdiv, const double *dscale, int l0, int l1, int what) {
+  // levels l0 .. l1-1 (l1 < 0: all); what: 1 the assembly launches only (k_sfw_init), 2 everything but them, 3 both
   CholPlan &C = P->chol;
   const double thr = C.growth_used;
   const int W = C.sbw;
   FwBatch bt;
   bt.src = nrhs > 1 ? rhs_stride : 0; bt.y = nrhs > 1 ? y_stride : 0; bt.wv = nrhs > 1 ? C.wsize : 0;
   const FrontTab tab0 = front_tab(C);
-  for (int l = 0; l < C.nlevels; l++) {
+  if (l1 < 0) l1 = C.nlevels;
+  for (int l = std::max(l0, 0); l < std::min(l1, C.nlevels); l++) {
     const SolveLevel &L = C.slev[l];
+    if (L.nfronts == 0) continue;
     const int *list = C.d_levlist.p + C.levptr[l];
     const FrontTab tab = level_tab(C, tab0, l);
     const int gather = L.children ? 0 : 1;
-    if (!gather) SDM_KLAUNCH(P, k_sfw_init, dim3(L.nfronts, 1, nrhs), dim3(ST), 0, tab, list, wv, rhs, C.d_perm.p, y, bt);
+    if (!gather && (what & 1)) SDM_KLAUNCH(P, k_sfw_init, dim3(L.nfronts, 1, nrhs), dim3(ST), 0, tab, list, wv, rhs, C.d_perm.p, y, bt);
+    if (!(what & 2)) continue;
     for (int Pb = 0; Pb < L.nsb; Pb++) {
       const int nbmax = std::min(W, L.maxns - Pb * W);
       SDM_KLAUNCH(P, k_sfw_diag, dim3((nbmax + SROWS - 1) / SROWS, L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, wv, rhs,
@@ -1121,13 +1126,15 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
 // backward sweep in place on the vector y (permuted order).  dscale != null: ./d on the way in (k_sbw_init);
 // skip_plain_init: the levels whose fronts have no rows below their own columns need no k_sbw_init at all (the ./d
 // was already applied by the forward sweep's final writes)
-static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double *dscale, bool skip_plain_init) {
+static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double *dscale, bool skip_plain_init, int l0 = 0, int l1 = -1) {
   CholPlan &C = P->chol;
   const double thr = C.growth_used;
   const int W = C.sbw;
   const FrontTab tab0 = front_tab(C);
-  for (int l = C.nlevels - 1; l >= 0; l--) {
+  if (l1 < 0) l1 = C.nlevels;
+  for (int l = std::min(l1, C.nlevels) - 1; l >= std::max(l0, 0); l--) {
     const SolveLevel &L = C.slev[l];
+    if (L.nfronts == 0) continue;
     const int *list = C.d_levlist.p + C.levptr[l];
     const FrontTab tab = level_tab(C, tab0, l);
     if (!(skip_plain_init && !L.below))
@@ -1141,6 +1148,13 @@ static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double 
   }
 }
 
+// the fw, ./d, bw solve of a right-hand side in P->rhs level by level (sdm_plan_solve_levels; the multi-GPU layer reduces the
+// assembled vectors of the separator fronts between `what` 1 and 2 and broadcasts their solution before `what` 4)
+void solve_levels(sdm_plan *P, int what, int l0, int l1) {
+  CholPlan &C = P->chol;
+  if (what & 3) solve_fw_batch(P, P->rhs.p, 0, P->ywork.p, 0, C.wvec.p, 1, C.zdiv.p, solve_d(P), l0, l1, what & 3);
+  if (what & 4) solve_bw_inplace(P, C.zdiv.p, P->y.p, nullptr, true, l0, l1);
+}
 void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode) {
   CholPlan &C = P->chol;
   const size_t mb = (size_t)C.m * sizeof(double);

@@ -10,7 +10,13 @@ RCCL over xGMI on ROCm; "gloo" in the CPU tests).  Two shardings, the ones SURVE
   component never leave its rank -- no data-path collective -- and the only exchange is the all-gather of the
   solution segments y that the (host-side) IPM needs in full.
 
-Both classes take an already initialised process group; nothing here launches processes.
+* ``SeparatorShardedSolver`` -- subtrees of ONE connected elimination tree: the supernodes at the top of the tree (the
+  separators every subtree's update matrices meet in) are owned by rank 0, the subtrees below them are dealt to the ranks;
+  every rank factors its subtrees, ONE reduce brings the subtree roots' fronts (their update matrices) to the owner, which
+  extend-adds them into the separator fronts and factors those; the forward sweep passes the roots' update vectors the same
+  way (one reduce), the backward sweep broadcasts the separators' solution.
+
+All classes take an already initialised process group; nothing here launches processes.
 """
 from __future__ import annotations
 
@@ -288,3 +294,174 @@ class SubtreeShardedSolver:
             if c is not None and c.size:
                 out[c] = host[q * self.send.numel():q * self.send.numel() + c.size]
         return out
+
+
+# ----------------------------------------------------------------------------------------- separator sharding
+def supernodal_etree(L):
+    """parent[s] of every supernode of the symbolic factor L = {L (pattern), xsuper}: the supernode of the first row below the
+    supernode's own columns -- what blkLDL relinks a finished supernode to (blkchol2.c:550-554: snode[lindx[xlindx[s] + n_s]]) --
+    and the flops n m^2 - n^2 m + n^3/3 of each."""
+    LL = sp.csc_matrix(L["L"])
+    xs = np.asarray(L["xsuper"], dtype=np.int64).ravel() - 1
+    nsuper = xs.size - 1
+    snode = np.zeros(LL.shape[0], dtype=np.int64)
+    for s in range(nsuper):
+        snode[xs[s]:xs[s + 1]] = s
+    parent = np.full(nsuper, -1, dtype=np.int64)
+    cost = np.zeros(nsuper)
+    for s in range(nsuper):
+        f, n = xs[s], xs[s + 1] - xs[s]
+        rows = LL.indices[LL.indptr[f]:LL.indptr[f + 1]]
+        ms = rows.size
+        if ms > n:
+            parent[s] = snode[np.sort(rows)[n]]
+        cost[s] = n * ms * ms - n * n * ms + n ** 3 / 3.0
+    return parent, cost, xs
+
+
+def proportional_split(parent, cost, world):
+    """Top of the tree + subtrees: starting from the roots, the heaviest subtree is opened (its root joins the top, its children
+    become subtrees of their own) until there are at least 2 x world subtrees or none heavier than total / (2 world) can be
+    opened; the subtrees are then dealt to the ranks (longest first; rank 0 starts with the top's work).  Returns (top mask,
+    owner rank per supernode: the top is rank 0's, roots list)."""
+    nsuper = parent.size
+    children = [[] for _ in range(nsuper)]
+    for s in range(nsuper):
+        if parent[s] >= 0:
+            children[parent[s]].append(s)
+    sub = cost.copy()
+    for s in range(nsuper):                     # postordered: children before parents
+        if parent[s] >= 0:
+            sub[parent[s]] += sub[s]
+    total = float(sub[parent < 0].sum())
+    work = [int(s) for s in np.flatnonzero(parent < 0)]
+    top = np.zeros(nsuper, dtype=bool)
+    while world > 1:
+        cand = [s for s in work if children[s]]
+        if not cand:
+            break
+        big = max(cand, key=lambda t: sub[t])
+        if len(work) >= 2 * world and sub[big] <= total / (2 * world):
+            break
+        work.remove(big); top[big] = True; work.extend(children[big])
+    owner = np.zeros(nsuper, dtype=np.int64)
+    load = np.zeros(world); load[0] = float(cost[top].sum())
+    root_of = np.full(nsuper, -1, dtype=np.int64)
+    for r0 in sorted(work, key=lambda t: -sub[t]):
+        rk = int(np.argmin(load)); load[rk] += sub[r0]
+        stack = [r0]
+        while stack:
+            t = stack.pop(); owner[t] = rk; root_of[t] = r0; stack.extend(children[t])
+    return top, owner, sorted(work)
+
+
+class SeparatorShardedSolver:
+    """LDL' and solves of ONE symmetric matrix whose elimination tree is connected, sharded over the ranks by subtrees (SURVEY.md
+    8e rows blkchol / fwblkslv / bwblkslv).  Every rank holds the symbolic factor and the full front arena (equal layout
+    everywhere, so slices of it travel as they are) and the values of the whole matrix (what the ADA' layers above leave on every
+    rank); it FACTORS only the supernodes it owns (sdm_plan_set_active_supernodes).  Exchanges, all on device tensors:
+      factor   one reduce (sum; every slice has one writer) of the subtree roots' fronts to rank 0, which owns the top of the tree;
+      forward  one reduce of the roots' update vectors to rank 0;
+      backward one broadcast of the top's solution;  then one all-reduce of the masked solution segments.
+    """
+
+    def __init__(self, X, group=None, device_index=0, device=None, L=None):
+        torch, dist = _torch()
+        from . import mex
+        self.group = group
+        if dist.is_available() and dist.is_initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        self.device = device if device is not None else torch.device("cpu")
+        X = sp.csc_matrix(X); X.sort_indices()
+        self.m = X.shape[0]
+        self.L = L if L is not None else mex.symbchol(X)          # ordmmd + symfct of the library (bit-exact with the reference): the same on every rank
+        parent, cost, xs = supernodal_etree(self.L)
+        self.nsuper = parent.size
+        self.top, self.owner, self.roots = proportional_split(parent, cost, self.world)
+        active = (self.owner == self.rank) & ~self.top
+        if self.rank == 0:
+            active |= self.top
+        self.plan = Plan(device_index)
+        self.plan.set_active_supernodes(active.astype(np.int32))
+        self.plan.set_chol(self.L, X)
+        lay = self.lay = self.plan.front_layout(self.nsuper)
+        self.nlevels = lay["nlevels"]
+        self.ltop = int(lay["level"][self.top].min()) if self.top.any() else self.nlevels
+        # packed exchange buffers: the roots' fronts / update vectors one after the other
+        self.f_off = np.concatenate(([0], np.cumsum(lay["fsize"][self.roots]))).astype(np.int64)
+        self.w_off = np.concatenate(([0], np.cumsum(lay["ms"][self.roots]))).astype(np.int64)
+        self.fbuf = torch.zeros(int(self.f_off[-1]), dtype=torch.float64, device=self.device)
+        self.wbuf = torch.zeros(int(self.w_off[-1]), dtype=torch.float64, device=self.device)
+        self.xbuf = torch.zeros(self.m, dtype=torch.float64, device=self.device)
+        perm = np.asarray(self.L["perm"], dtype=np.int64).ravel() - 1
+        mine = np.zeros(self.m, dtype=bool)
+        for s in np.flatnonzero(active):
+            mine[perm[xs[s]:xs[s + 1]]] = True
+        self.mask = torch.as_tensor(mine, device=self.device)           # entries of the solution this rank computes (the others of its y are never written)
+
+    def _roots(self, mine):
+        return [(i, s) for i, s in enumerate(self.roots) if (self.owner[s] == self.rank) == mine]
+
+    def factor(self, values, pars=None, absd=None):
+        """values: ADA' (the matrix) in the order of its pattern, complete on every rank."""
+        torch, dist = _torch()
+        pl, lay = self.plan, self.lay
+        pl.upload("ada", values)
+        if absd is not None:
+            pl.upload("absd", absd)
+        pl.blkchol_begin(pars, absd is not None)
+        if self.world == 1 or not self.top.any():
+            pl.blkchol_levels(0, self.nlevels); pl.blkchol_end()
+            return
+        if self.rank != 0:
+            pl.blkchol_levels(0, self.nlevels)
+        else:
+            pl.blkchol_levels(0, self.ltop)
+        self.fbuf.zero_()
+        for i, s in self._roots(True):
+            n = int(lay["fsize"][s])
+            pl.copy("fronts", self.fbuf[int(self.f_off[i]):], int(lay["foff"][s]), n, to_plan=False)
+        dist.reduce(self.fbuf, dst=0, op=dist.ReduceOp.SUM, group=self.group)
+        if self.rank == 0:
+            for i, s in self._roots(False):
+                n = int(lay["fsize"][s])
+                pl.copy("fronts", self.fbuf[int(self.f_off[i]):], int(lay["foff"][s]), n, to_plan=True)
+            pl.blkchol_levels(self.ltop, self.nlevels)
+        pl.blkchol_end()
+
+    def solve(self, rhs):
+        """x = (L D L')^{-1} rhs in the original order, complete on every rank (a device tensor of length m)."""
+        torch, dist = _torch()
+        pl, lay = self.plan, self.lay
+        pl.upload("rhs", rhs)
+        if self.world == 1 or not self.top.any():                      # a forest (or one rank): nothing meets at the top
+            pl.solve_levels(3, 0, self.nlevels); pl.solve_levels(4, 0, self.nlevels)
+            pl.copy("y", self.xbuf, 0, self.m, to_plan=False)
+            if self.world > 1:
+                self.xbuf.masked_fill_(~self.mask, 0.0)
+                dist.all_reduce(self.xbuf, op=dist.ReduceOp.SUM, group=self.group)
+            return self.xbuf
+        # forward: every rank its subtrees; the roots' update vectors to the owner of the top; the top
+        pl.solve_levels(3, 0, self.nlevels if self.rank != 0 else self.ltop)
+        self.wbuf.zero_()
+        for i, s in self._roots(True):
+            pl.copy("wvec", self.wbuf[int(self.w_off[i]):], int(lay["woff"][s]), int(lay["ms"][s]), to_plan=False)
+        dist.reduce(self.wbuf, dst=0, op=dist.ReduceOp.SUM, group=self.group)
+        if self.rank == 0:
+            for i, s in self._roots(False):
+                pl.copy("wvec", self.wbuf[int(self.w_off[i]):], int(lay["woff"][s]), int(lay["ms"][s]), to_plan=True)
+            pl.solve_levels(3, self.ltop, self.nlevels)
+            pl.solve_levels(4, self.ltop, self.nlevels)               # backward through the top
+            pl.copy("xfin", self.xbuf, 0, self.m, to_plan=False)
+        dist.broadcast(self.xbuf, src=0, group=self.group)
+        if self.rank != 0:
+            pl.copy("xfin", self.xbuf, 0, self.m, to_plan=True)
+            pl.solve_levels(4, 0, self.nlevels)
+        else:
+            pl.solve_levels(4, 0, self.ltop)
+        pl.copy("y", self.xbuf, 0, self.m, to_plan=False)
+        self.xbuf.masked_fill_(~self.mask, 0.0)
+        dist.all_reduce(self.xbuf, op=dist.ReduceOp.SUM, group=self.group)
+        return self.xbuf

@@ -212,7 +212,7 @@ class Plan:
         if not tensor.is_cuda and capi.backend() != "emu":
             # host tensor next to a real GPU plan (gloo smoke runs): staged through the host copies of the buffer
             import torch
-            n = {"ada": self.nnzADA, "lpr": self.nnzL}.get(name, self.m)
+            n = self.devptr(name)[1]
             full = self.download(name, n)
             if to_plan:
                 full[offset:offset + nelem] = tensor[:nelem].numpy()
@@ -230,6 +230,39 @@ class Plan:
             cp.maxu = float(pars.get("maxu", cp.maxu))
             cp.abstol = max(float(pars.get("abstol", cp.abstol)), 0.0)
         check(self._lib.sdm_plan_blkchol(C.c_void_p(self._p), C.byref(cp), 1 if use_absd else 0))
+
+    # ---- the factorisation and the solve level by level (sedumi_amd.dist.SeparatorShardedSolver)
+    def set_active_supernodes(self, active):
+        """Before set_chol: the supernodes (0/1 per supernode of the symbolic factor) this plan factors and solves."""
+        a = np.ascontiguousarray(active, dtype=np.int32)
+        check(self._lib.sdm_plan_set_active_supernodes(C.c_void_p(self._p), a.ctypes.data_as(C.POINTER(C.c_int)), C.c_int64(a.size)))
+
+    def front_layout(self, nsuper):
+        """dict of int64 arrays per supernode: etree level, slice of "fronts" (foff, fsize), slice of "wvec" (woff, ms), columns (first, ns);
+        plus nlevels."""
+        out = {k: np.zeros(nsuper, dtype=np.int64) for k in ("level", "foff", "fsize", "woff", "ms", "first", "ns")}
+        nl = C.c_int64(0)
+        check(self._lib.sdm_plan_front_layout(C.c_void_p(self._p), C.byref(nl), *[pi(out[k]) for k in ("level", "foff", "fsize", "woff", "ms", "first", "ns")]))
+        out["nlevels"] = nl.value
+        return out
+
+    def blkchol_begin(self, pars=None, use_absd=True):
+        cp = capi.CholPars(1e-12, 5e5, 1e-20)
+        if pars:
+            cp.canceltol = float(pars.get("canceltol", cp.canceltol))
+            cp.maxu = float(pars.get("maxu", cp.maxu))
+            cp.abstol = max(float(pars.get("abstol", cp.abstol)), 0.0)
+        check(self._lib.sdm_plan_blkchol_begin(C.c_void_p(self._p), C.byref(cp), 1 if use_absd else 0))
+
+    def blkchol_levels(self, l0, l1, extend_only=False):
+        check(self._lib.sdm_plan_blkchol_levels(C.c_void_p(self._p), C.c_int64(int(l0)), C.c_int64(int(l1)), 1 if extend_only else 0))
+
+    def blkchol_end(self):
+        check(self._lib.sdm_plan_blkchol_end(C.c_void_p(self._p)))
+
+    def solve_levels(self, what, l0, l1):
+        """what: 1 assembly of the forward sweep of levels l0 .. l1-1, 2 their forward sweep without it, 3 both, 4 backward sweep."""
+        check(self._lib.sdm_plan_solve_levels(C.c_void_p(self._p), C.c_int(int(what)), C.c_int64(int(l0)), C.c_int64(int(l1))))
 
     def pivots(self):
         m = self.m

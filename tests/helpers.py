@@ -192,26 +192,20 @@ def bordered_blocks(n1, n2, nc, rng):
     return X
 
 
-def _factor_both_ways(X, L, pars=None, rhs=None, wgs=None):
-    """(lpr, d, pivots, y, kernels) of the resident plan with the one-launch front kernel and with the launch-per-panel path.
-    wgs: workgroup budget of the front kernel (SDM_FRONT_WGS, with SDM_FRONT_POOL = 16 tiles per tile workgroup allowed:
-    the dealt-out mapping, which the default build does not choose -- DESIGN.md section 3c)."""
+def _factor_both_ways(X, L, pars=None, rhs=None):
+    """(lpr, d, pivots, y, kernels) of the resident plan with the one-launch front kernel and with the launch-per-panel path
+    (SDM_FRONT_OFF at set_chol: the comparison switch)."""
     import os
     from sedumi_amd.plan import Plan
     out = []
     for off in (False, True):
         if off:
             os.environ["SDM_FRONT_OFF"] = "1"
-        elif wgs:
-            os.environ["SDM_FRONT_WGS"] = str(wgs)
-            os.environ["SDM_FRONT_POOL"] = "16"
         try:
             plan = Plan(0)
             plan.set_chol(L, X)
         finally:
             os.environ.pop("SDM_FRONT_OFF", None)
-            os.environ.pop("SDM_FRONT_WGS", None)
-            os.environ.pop("SDM_FRONT_POOL", None)
         plan.upload("ada", sp.csc_matrix(X).data)
         plan.upload("rhs", rhs if rhs is not None else np.ones(X.shape[0]))
         plan.kprof(True)
@@ -223,23 +217,22 @@ def _factor_both_ways(X, L, pars=None, rhs=None, wgs=None):
     return out
 
 
-def check_one_launch_front(refmex, m, wgs=None):
+def check_one_launch_front(refmex, m):
     """k_ldl_front (one workgroup per tile row, the whole front in one launch) against the launch-per-panel path on single
     dense fronts: same device functions in the same order per entry, so the same bits -- and both within tolerance of
     the reference.  m = 666 is control07's shape (partial last panel); up to 21 tile rows every tile has a workgroup of its
-    own on a whole device; with a budget wgs the tile workgroups own up to 16 tiles each."""
+    own on a whole device."""
     from oracle import glue as gl
     from sedumi_amd import problem
     rng = np.random.default_rng(m)
     B = rng.standard_normal((m, m))
     X = sp.csc_matrix(B @ B.T + m * np.eye(m)); X.sort_indices()
     L = problem.dense_symbolic(m)
-    (l1, d1, p1, y1, k1), (l2, d2, p2, y2, k2) = _factor_both_ways(X, L, rhs=rng.standard_normal(m), wgs=wgs)
+    (l1, d1, p1, y1, k1), (l2, d2, p2, y2, k2) = _factor_both_ways(X, L, rhs=rng.standard_normal(m))
     assert "k_ldl_front" in k1 and "k_ldl_panel" not in k1 and "k_ldl_front" not in k2 and "k_ldl_panel" in k2
     # up to 14 tile rows (on a whole MI355X; always in the emulator) the inverse for the solves is built BEHIND the factor
     from sedumi_amd import capi
-    if wgs is None:
-        assert ("k_sinv_follow" in k1) == (m <= 896 or capi.backend() == "emu")
+    assert ("k_sinv_follow" in k1) == (m <= 896 or capi.backend() == "emu")
     assert "k_sinv_follow" not in k2
     assert ("k_sinv_follow" in k1) != ("k_sprep" in k1 or "k_sinv128" in k1)
     assert np.array_equal(l1, l2) and np.array_equal(d1, d2) and relerr(y1, y2) < 1e-12   # (the inverses for the solves are built differently: behind k_ldl_front / after the panel launches)
@@ -247,7 +240,7 @@ def check_one_launch_front(refmex, m, wgs=None):
     assert relerr(d1, r[1].ravel()) < TOL and relerr(l1, sp.csc_matrix(r[0]).data) < TOL
 
 
-def check_one_launch_levels(refmex, glue, two_leaves=False, wgs=None):
+def check_one_launch_levels(refmex, glue, two_leaves=False):
     """A leaf front of 64 columns with 800 rows below them (the update matrix for the parent) and the dense root of 928
     columns: both levels take k_ldl_front, extend-add in between.  two_leaves: two leaf fronts of 64 columns (764 rows each)
     in ONE k_ldl_front launch (grid.y = 2) under a root of 764 columns."""
@@ -267,14 +260,14 @@ def check_one_launch_levels(refmex, glue, two_leaves=False, wgs=None):
     L = glue.symbchol(X)
     xs = L["xsuper"].ravel().astype(int)
     assert xs.size - 1 == (3 if two_leaves else 2) and xs[1] - xs[0] == 64
-    (l1, d1, p1, y1, k1), (l2, d2, p2, y2, k2) = _factor_both_ways(X, L, rhs=rng.standard_normal(X.shape[0]), wgs=wgs)
+    (l1, d1, p1, y1, k1), (l2, d2, p2, y2, k2) = _factor_both_ways(X, L, rhs=rng.standard_normal(X.shape[0]))
     assert "k_ldl_front" in k1 and "k_ldl_panel" not in k1 and "k_ldl_front" not in k2
     assert np.array_equal(l1, l2) and np.array_equal(d1, d2) and relerr(y1, y2) < 1e-12   # (the inverses for the solves are built differently: behind k_ldl_front / after the panel launches)
     r = refmex.call("blkchol", 4, L, X, gl.default_pars_chol())
     assert relerr(d1, r[1].ravel()) < TOL and relerr(l1, sp.csc_matrix(r[0]).data) < TOL
 
 
-def check_one_launch_pivot_rule(refmex, m, maxu, wgs=None):
+def check_one_launch_pivot_rule(refmex, m, maxu):
     """Rank-deficient dense front of k_ldl_front's size: skipped pivots, the never-fail rule's column probe (the rare path
     of the diagonal-block code: it waits for the update steps of the rows below) and added diagonals -- same decisions
     as the reference, same bits as the launch-per-panel path."""
@@ -294,7 +287,7 @@ def check_one_launch_pivot_rule(refmex, m, maxu, wgs=None):
     X = sp.csc_matrix(X + 0.0); X = sp.csc_matrix((X.toarray().ravel(order="F"), np.tile(np.arange(m), m), np.arange(0, m * m + 1, m)), shape=(m, m))
     L = problem.dense_symbolic(m)
     pars = dict(gl.default_pars_chol()); pars["maxu"] = maxu; pars["canceltol"] = 1e-8          # about half of those pivots are skipped
-    (l1, d1, p1, y1, k1), (l2, d2, p2, y2, k2) = _factor_both_ways(X, L, pars, rng.standard_normal(m), wgs=wgs)
+    (l1, d1, p1, y1, k1), (l2, d2, p2, y2, k2) = _factor_both_ways(X, L, pars, rng.standard_normal(m))
     assert "k_ldl_front" in k1 and "k_ldl_front" not in k2
     r = refmex.call("blkchol", 4, L, X, pars)
     (si, sv), (ai, av) = p1

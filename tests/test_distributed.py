@@ -48,6 +48,40 @@ def _worker(rank, world, port, case, q):
             cs.getada()
             err = max(np.abs(sh.download("ada") - ref.download("ada")).max(), np.abs(sh.download("absd") - ref.download("absd")).max())
             q.put((rank, float(err), [int(c) for c in cs.cols]))
+        elif case.startswith("separator"):
+            # ONE connected elimination tree: subtrees to the ranks, the top of the tree to rank 0; one reduce of the roots' fronts,
+            # one reduce of their update vectors, one broadcast of the top's solution
+            import scipy.sparse as sp
+            from helpers import spd_pattern
+            kind = case.split("_", 1)[1]
+            rng = np.random.default_rng(23)
+            if kind == "bordered":                           # three dense diagonal blocks under a dense border: three subtrees, one separator front
+                sizes, nc = [40, 35, 30], 10
+                mm = sum(sizes) + nc
+                X = np.zeros((mm, mm)); o = 0
+                for n in sizes:
+                    X[o:o + n, o:o + n] = rng.standard_normal((n, n)); o += n
+                X[o:, :] = rng.standard_normal((nc, mm))
+                X = 0.1 * (X + X.T) / np.sqrt(mm)
+                X = X + np.diag(np.abs(X).sum(axis=1) + 1.0)
+            else:
+                X = spd_pattern(kind, {"arrow": 90, "grid": 196, "rand": 150}[kind], rng, 0.03)
+            X = sp.csc_matrix(X); X.sort_indices()
+            m = X.shape[0]
+            solver = sd.SeparatorShardedSolver(X)
+            assert solver.top.any() and len(solver.roots) >= 2, (solver.top.sum(), solver.roots)       # (rank 0 owns the top; the subtrees go where the load is lowest)
+            rhs = rng.standard_normal(m)
+            xs = []
+            for rep in range(2):                             # twice: the arenas are reused
+                solver.factor(X.data, pars)
+                xs.append(solver.solve(rhs).cpu().numpy().copy())
+            assert np.array_equal(xs[0], xs[1]), (float(np.abs(xs[0] - xs[1]).max()), float(np.abs(xs[0]).max()), int(np.isnan(xs[0]).sum()), int(np.isnan(xs[1]).sum()))
+            one = Plan(0); one.set_chol(solver.L, X); one.upload("ada", X.data); one.upload("rhs", rhs)
+            one.blkchol(pars, False); one.ldlsolve()
+            x1 = one.download("y")
+            want = np.linalg.solve(X.toarray(), rhs)
+            err = max(np.abs(xs[0] - x1).max() / np.abs(x1).max(), np.abs(xs[0] - want).max() / np.abs(want).max())
+            q.put((rank, float(err), [int(solver.top.sum()), len(solver.roots)]))
         elif case in ("blocks", "blocks_confined"):
             # ADA' = sum of the PSD blocks' contributions: blocks dealt to the ranks, one all-reduce of [values | absd]
             from helpers import ref_scaling
@@ -120,13 +154,14 @@ def _worker(rank, world, port, case, q):
         q.put((rank, "ERR " + traceback.format_exc(), None))
 
 
-@pytest.mark.parametrize("case", ["columns", "subtrees", "subtrees_lorentz", "blocks", "blocks_confined"])
-def test_two_ranks_gloo(case):
+@pytest.mark.parametrize("case,world", [("columns", 2), ("subtrees", 2), ("subtrees_lorentz", 2), ("blocks", 2), ("blocks_confined", 2),
+                                        ("separator_arrow", 2), ("separator_grid", 2), ("separator_bordered", 2), ("separator_grid", 4), ("separator_rand", 4)])
+def test_ranks_gloo(case, world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -135,6 +170,9 @@ def test_two_ranks_gloo(case):
     for rank, err, info in res:
         assert not isinstance(err, str), err
         assert err < 1e-12, (rank, err)
+        if case.startswith("separator"):
+            assert info is not None and info[0] >= 1 and info[1] >= 2
+            continue
         if case in ("blocks", "blocks_confined"):
             assert info is not None and sum(info) == 4 and min(info) >= 1
             continue

@@ -362,15 +362,8 @@ def test_one_launch_front_levels_with_rows_below(refmex, glue, two_leaves):
     helpers.check_one_launch_levels(refmex, glue, two_leaves)
 
 
-@pytest.mark.parametrize("m,wgs", [(666, 18), (1000, 24)])
-def test_one_launch_front_with_pooled_tile_workgroups(refmex, m, wgs):
-    """Fewer tile workgroups than tiles (the dealt-out mapping, SDM_FRONT_POOL): 45 tiles on 7 workgroups, 105 on 8."""
-    helpers.check_one_launch_front(refmex, m, wgs=wgs)
 
 
-def test_one_launch_front_levels_pooled(refmex, glue):
-    helpers.check_one_launch_levels(refmex, glue, True, wgs=60)            # two leaves of 13 tile rows share the budget: 17 tile workgroups each for 66 tiles
-    helpers.check_one_launch_pivot_rule(refmex, 666, 30.0, wgs=20)
 
 
 @pytest.mark.parametrize("m,maxu", [(400, 5e5), (400, 30.0), (400, 2.0), (666, 30.0)])

@@ -538,15 +538,8 @@ def test_one_launch_front_matches_the_panel_launches_bit_for_bit(refmex, m):
     helpers.check_one_launch_front(refmex, m)
 
 
-@pytest.mark.parametrize("m,wgs", [(666, 18), (1000, 24), (1100, 40), (2000, 224), (4000, 224)])
-def test_one_launch_front_with_pooled_tile_workgroups(refmex, m, wgs):
-    helpers.check_one_launch_front(refmex, m, wgs=wgs)
 
 
-def test_one_launch_front_levels_and_pivot_rule_pooled(refmex, glue):
-    helpers.check_one_launch_levels(refmex, glue, True, wgs=60)
-    helpers.check_one_launch_pivot_rule(refmex, 666, 30.0, wgs=20)
-    helpers.check_one_launch_pivot_rule(refmex, 2000, 30.0, wgs=224)
 
 
 @pytest.mark.parametrize("two_leaves", [False, True])

@@ -32,7 +32,8 @@ PARS = {"canceltol": 1e-12, "maxu": 5e5, "abstol": 1e-20}          # checkpars.m
 HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_MATRIX_PEAK_TFS = 78.6                                         # v_mfma_f64_16x16x4_f64: = the FP64 vector rate on CDNA4
 NSOLVE = 4
-CONFIG_NOTE = {"contro": "examples/control07.mat (BASELINE.json configs[1])", "nb": "nb-shaped SOCP (BASELINE.json configs[2])",
+CONFIG_NOTE = {"contro": "examples/control07.mat (BASELINE.json configs[1])", "nb": "examples/nb.mat (BASELINE.json configs[2]; no PSD blocks: the getada.m route)",
+               "arch0": "examples/arch0.mat (BASELINE.json configs[0])", "nb_lik": "nb-shaped SOCP (BASELINE.json configs[2] shape)",
                "maxcut": "MAXCUT SDP, one dense PSD block (BASELINE.json configs[3])"}
 
 
@@ -41,21 +42,32 @@ def build_workload(name, seed):
     import scipy.sparse as sp
     from sedumi_amd import mex, problem
     qpr = None
-    if name == "control07":
-        z = np.load(os.path.join(ROOT, "tests", "golden", "control07.npz"))
+    gold = {"control07": ("control07", "rand"), "control07_init": ("control07", "init"), "arch0": ("arch0", "rand"), "arch0_init": ("arch0", "init"),
+            "nb": ("nb", "rand"), "nb_init": ("nb", "init")}
+    if name in gold:
+        # the reference's own examples: hot-path inputs of examples/<name>.mat (At after pretransfo, K, a scaling, rhs) from
+        # tests/golden/<name>.npz; tag "init" = the identity scaling of iteration 1 (sdinit.m:63-78), "rand" = an ill-conditioned one
+        fname, tag = gold[name]
+        z = np.load(os.path.join(ROOT, "tests", "golden", fname + ".npz"))
         At = sp.csc_matrix((z["At_data"], z["At_indices"], z["At_indptr"]), shape=tuple(z["At_shape"]))
         K = problem.make_K(int(z["K_l"]), z["K_q"].ravel(), z["K_s"].ravel())
-        P = problem.Problem(At, K, "control07.mat")
+        P = problem.Problem(At, K, fname + ".mat")
         assert np.array_equal(P.Ablkjc, z["Ablkjc"])
-        d = {"l": z["rand_dl"], "det": z["rand_ddet"]}
-        ud, rhs = z["rand_udsqr"], z["rhs"]
-        note = "examples/control07.mat inputs (tests/golden/control07.npz), scaling of the golden 'rand' tag"
+        d = {"l": z[f"{tag}_dl"], "det": z[f"{tag}_ddet"]}
+        ud, rhs = z[f"{tag}_udsqr"], z["rhs"]
+        note = f"examples/{fname}.mat inputs (tests/golden/{fname}.npz), scaling of the golden '{tag}' tag"
+        L, ADA = problem.dense_symbolic(P.m), problem.dense_pattern(P.m)
+        Q = sp.csc_matrix((z[f"{tag}_DAtq_data"], z[f"{tag}_DAtq_indices"], z[f"{tag}_DAtq_indptr"]), shape=tuple(z[f"{tag}_DAtq_shape"]))
+        if Q.nnz:                                       # Lorentz cones: the DAt.q of getDAtm.m for this scaling, values in the order of its pattern
+            Q.sort_indices()
+            qpr = np.asarray(Q.data, dtype=np.float64)
+        return P, L, ADA, Q, d, ud, rhs, qpr, note
     else:
         if name == "control07_like":
             P = problem.control_like(seed=seed)
         elif name.startswith("maxcut"):
             P = problem.maxcut(int(name[6:] or 4000))
-        elif name == "nb":                              # BASELINE.json configs[2] shape: 793 Lorentz cones of dimension 3, m = 123
+        elif name == "nb_like":                         # BASELINE.json configs[2] shape: 793 Lorentz cones of dimension 3, m = 123
             P = problem.random_sdp(m=123, lp=4, q=(3,) * 793, s=(), dens=0.66, seed=31 + seed)
             P.name = "nb_like(m=123,q=793x3)"
         elif name.startswith("blockdiag"):
@@ -258,12 +270,13 @@ def profile_unit(plan, P, ud, nprof):
         "k_ldl_panel": ("mfma", fac_flops / npanel),                               # the panel launches carry the whole LDL'
         "k_ldl_front": ("mfma", fac_flops / max(1, prof.get("k_ldl_front", (nprof, 0))[0] // nprof)),   # ... or ONE launch per level does
         "k_ldl_update": ("mfma", fac_flops / npanel),
-        "k_psd_stage1_mfma": ("mfma", None), "k_psd_stage1": ("mfma", None),       # flops filled below from the task list
+        "k_psd_stage1_mfma": ("mfma", None), "k_psd_stage1": ("fp64_vector", None),  # flops filled below from the task list (the two-dot kernel has no MFMA in it)
         "k_psd_stage2": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)), "k_psd_stage2_ell": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)),
         "k_ada_spdot": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)),
         "k_sfw_step": ("hbm", None), "k_sbw_step": ("hbm", None), "k_sfw_diag": ("hbm", None), "k_sbw_diag": ("hbm", None),
     }
-    peaks = {"hbm": (HBM_PEAK_GBS, "GB/s", 1e9), "mfma": (FP64_MATRIX_PEAK_TFS, "TFLOP/s", 1e12)}
+    peaks = {"hbm": (HBM_PEAK_GBS, "GB/s", 1e9), "mfma": (FP64_MATRIX_PEAK_TFS, "TFLOP/s", 1e12),
+             "fp64_vector": (FP64_MATRIX_PEAK_TFS, "TFLOP/s", 1e12)}                    # (the FP64 vector rate equals the matrix rate on CDNA4)
     # (k_sinv_follow runs NEXT to k_ldl_front on the plan's second stream and spends most of its time waiting for it:
     # its events overlap that kernel's, it is not a stage of its own)
     dom = max(((k, v) for k, v in prof.items() if k != "k_sinv_follow"), key=lambda kv: kv[1][1])[0] if prof else None
@@ -526,7 +539,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="control07",
                     help="control07 (default: examples/control07.mat, BASELINE configs[1]) | control07_like (synthetic, same shape) | "
-                         "nb (configs[2] shape) | lpdense (configs[2] dense-column variant) | maxcut<n> (configs[3]) | blockdiag[:nblk:n:mper] (configs[4]) | "
+                         "control07_init / arch0[_init] / nb[_init] (the reference examples at the golden scalings) | nb_like (configs[2] shape) | lpdense (configs[2] dense-column variant) | maxcut<n> (configs[3]) | blockdiag[:nblk:n:mper] (configs[4]) | "
                          "grid[:n] (factor + solves of a matrix with separators, subtrees sharded over the ranks)")
     ap.add_argument("--shard", default="auto", choices=["auto", "replicas", "columns", "blocks"],
                     help="N>1, ONE unit per step: blocks = PSD blocks dealt to the ranks, partial ADA' + one RCCL all-reduce (auto when "
@@ -643,7 +656,10 @@ def main():
                 if ob:
                     base_blas = cpu_baseline(P, d, ud, rhs, budget_s=8.0, blas=ob)
             if not args.no_other_configs and args.workload == "control07":
-                for nm, st, wu, npf in (("control07_like", 100, 5, 20), ("nb", 100, 5, 20), ("maxcut4000", 10, 2, 5), ("blockdiag", 20, 3, 10)):
+                # the second scaling of the headline config (identity scaling of iteration 1 next to an ill-conditioned one),
+                # the other reference examples at both scalings, then the synthetic configs[3], [4]
+                for nm, st, wu, npf in (("control07_init", 100, 5, 20), ("arch0", 100, 5, 20), ("arch0_init", 100, 5, 20), ("nb", 100, 5, 20),
+                                        ("nb_init", 100, 5, 20), ("maxcut4000", 10, 2, 5), ("blockdiag", 20, 3, 10)):
                     others.append(measure_config(nm, local_rank, st, wu, npf))
         mult = 1 if (shard_cols or world == 1) else world
         out = {

@@ -1500,7 +1500,7 @@ __global__ void k_divd(double *v, const double *d, int m) {
 void chol_forget_plan(sdm_plan *P) { PersistTurn::forget(P); }
 FrontTab front_tab(CholPlan &C) {
   FrontTab t;
-  t.soff = C.d_soff.p; t.sld = C.d_sld.p; t.sboff = C.d_sboff.p;
+  t.soff = C.d_soff.p; t.sld = C.d_sld.p; t.sboff = C.d_sboff.p; t.ltoff = C.d_ltoff.p;
   t.first = C.d_first.p; t.ns = C.d_ns.p; t.ms = C.d_ms.p; t.ld = C.d_ld.p;
   t.foff = C.d_foff.p; t.xl = C.d_xl.p; t.woff = C.d_woff.p; t.roff = C.d_roff.p; t.toff = C.d_toff.p; t.fslot = C.d_fslot.p;
   t.childptr = C.d_childptr.p; t.childlist = C.d_childlist.p; t.lindx = C.d_lindx.p; t.relidx = C.d_relidx.p;

@@ -172,6 +172,12 @@ struct CholPlan {
   std::vector<int64_t> sn_soff; std::vector<int> sn_sld, sn_sboff;
   DevBuf<int64_t> d_soff; DevBuf<int> d_sld, d_sboff;
   DevBuf<double> S, xfin, zdiv;
+  DevBuf<double> ST;                 // the same blocks transposed (ST[r*sld + c] = inverse(r, c)): the forward sweep reads ROWS of an inverse, the
+                                     // backward sweep columns -- with both copies every product of the sweeps is a dot product along contiguous memory
+  DevBuf<double> LT;                 // fronts of several super-blocks: the rows of L below super-block P against its columns, transposed likewise
+                                     // (LT block (s, P) at sn_ltoff[s] + lt_boff(P), (ns - (P+1) sbw) rows of nb_P <= sbw entries, pitch sbw): forward step
+  std::vector<int64_t> sn_ltoff; DevBuf<int64_t> d_ltoff;
+  DevBuf<int> l_lt; int n_lt = 0;    // 64x64 tiles of that transposition (4 ints each: s, P, I, J)
   DevBuf<double> Tarena;             // scratch of the inversion, same layout as S: T = B inv(A) of every combine step
   DevBuf<unsigned long long> sb_g;   // per super-block: bit patterns of max|inverse| and max|L block| (growth check); behind them the counters of k_sprep
   DevBuf<int> l_i128, l_items;       // work lists of the inversion: 128-column leaves (4 ints each), combine tiles (8 ints each, sorted by stage)
@@ -190,11 +196,12 @@ struct FrontTab {
   const int64_t *foff, *xl, *woff, *roff, *toff;
   const int *childptr, *childlist, *lindx, *relidx;
   const int64_t *soff; const int *sld, *sboff;
+  const int64_t *ltoff = nullptr;
   const int *fslot = nullptr;   // k_ldl_front: the front's counter slot
   // levels of ONE front (solve kernels): its descriptor rides along as kernel arguments, so the first data load of a
   // launch does not wait for two dependent table loads (list[..] -> ns[s], soff[s], ...)
   int one = 0, o_s = 0, o_ns = 0, o_ms = 0, o_ld = 0, o_first = 0, o_sld = 0, o_sboff = 0;
-  int64_t o_foff = 0, o_soff = 0, o_woff = 0, o_xl = 0;
+  int64_t o_foff = 0, o_soff = 0, o_woff = 0, o_xl = 0, o_ltoff = 0;
 };
 
 // ----------------------------------------------------------------- ada plan

@@ -99,8 +99,29 @@ void solve_build(sdm_plan *P) {
   C.l_i128.upload(i128); C.l_items.upload(items);
   C.d_soff.upload(C.sn_soff); C.d_sld.upload(C.sn_sld); C.d_sboff.upload(C.sn_sboff);
   const size_t sz = (size_t)std::max<int64_t>(soff, 1);
-  C.S.alloc(sz); C.Tarena.alloc(C.n_items ? sz : 1);
+  C.S.alloc(sz); C.ST.alloc(sz); C.Tarena.alloc(C.n_items ? sz : 1);
   SDM_HIP_CHECK(hipMemset(C.S.p, 0, sz * sizeof(double)));            // upper triangles stay zero for good
+  SDM_HIP_CHECK(hipMemset(C.ST.p, 0, sz * sizeof(double)));           // (here: the lower ones)
+  // fronts of several super-blocks: transposed copy of the rows of L below each super-block (forward step launches)
+  {
+    C.sn_ltoff.assign(nsuper, 0);
+    std::vector<int> lt;
+    int64_t ltoff = 0;
+    for (int s = 0; s < nsuper; s++) {
+      const int ns = C.sn_ns[s], nsb = (ns + W - 1) / W;
+      C.sn_ltoff[s] = ltoff;
+      if (!(C.sn_active.empty() || C.sn_active[s] != 0)) continue;
+      for (int Pb = 0; Pb + 1 < nsb; Pb++) {
+        const int nr = ns - (Pb + 1) * W;
+        for (int I = 0; 64 * I < nr; I++)
+          for (int J = 0; 64 * J < W; J++) { lt.push_back(s); lt.push_back(Pb); lt.push_back(I); lt.push_back(J); }
+        ltoff += (int64_t)nr * W;
+      }
+    }
+    C.n_lt = (int)lt.size() / 4;
+    C.l_lt.upload(lt); C.d_ltoff.upload(C.sn_ltoff);
+    C.LT.alloc((size_t)std::max<int64_t>(ltoff, 1));
+  }
   C.xfin.alloc((size_t)std::max<sdm_int>(C.m, 1)); C.zdiv.alloc((size_t)std::max<sdm_int>(C.m, 1));
   // growth records (2 words per super-block), then the completion counters of k_sprep (SPREP_NCNT ints per super-block)
   const size_t gw = (size_t)std::max(sb, 1) * (2 + SPREP_NCNT / 2);
@@ -121,12 +142,8 @@ void solve_build(sdm_plan *P) {
     L.slabs_fw.assign(L.nsb, 0);
     for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) {
       const int s = C.levlist[i], ns = C.sn_ns[s], ms = C.sn_ms[s];
-      for (int Pb = 0; Pb * W < ns; Pb++) {
-        const int rmin = ns > (Pb + 1) * W ? (Pb + 1) * W : ns;        // first row that receives something from block Pb
-        if (rmin >= ms) continue;
-        const int rstart = ns > (Pb + 1) * W ? (Pb + 1) * W : (ns & ~1);
-        L.slabs_fw[Pb] = std::max(L.slabs_fw[Pb], (ms - rstart + SROWS - 1) / SROWS);
-      }
+      for (int Pb = 0; Pb * W < ns; Pb++)                              // (slabs of the rows BELOW the supernode; its own later rows: k_sfw_rows)
+        if (ms > ns) L.slabs_fw[Pb] = std::max(L.slabs_fw[Pb], (ms - (ns & ~1) + SROWS - 1) / SROWS);
     }
   }
   follow_decide(P);
@@ -268,6 +285,19 @@ __device__ __forceinline__ double store_tile(double *dst, int64_t ld, const doub
   return mx;
 }
 
+// the same tile into the TRANSPOSED arena: dst[r*ld + c] = Cs[r*TP + c] (rows < nr, columns < nc), consecutive work-items on
+// consecutive columns
+template <bool WT = false>
+__device__ __forceinline__ void store_tile_T(double *dst, int64_t ld, const double *Cs, int nr, int nc, int tid) {
+  const int c = tid & 63, rq = tid >> 6;
+#pragma unroll 4
+  for (int r = rq; r < 64; r += ST / 64)
+    if (r < nr && c < nc) {
+      const double v = Cs[r * TP + c];
+      if (WT) sdm_store_wt(&dst[(int64_t)r * ld + c], v); else dst[(int64_t)r * ld + c] = v;
+    }
+}
+
 // ================================================================ inversion of the diagonal super-blocks
 // The two 64x64 unit lower triangular blocks A and C of a leaf, all four wavefronts: rawA / rawC hold their strictly lower
 // triangles column-major (raw[k*TP + i] = L(i, k)), bufA / bufC start as zero and receive the inverses -- inv(A) as a B
@@ -369,7 +399,7 @@ __device__ __forceinline__ void inv64_pair(double *rawA, double *rawC, double *b
 //   128    X21 = -inv(C) (B inv(A)) on the FP64 matrix cores, B = L(C rows, A columns) requested at the very start.
 // Results go to S; max|inv| and max|L| to sb_g (growth check).
 template <bool WT>
-__device__ __forceinline__ void sinv128_body(char *smem, const double *__restrict__ F, double *__restrict__ S, const FrontTab &tab,
+__device__ __forceinline__ void sinv128_body(char *smem, const double *__restrict__ F, double *__restrict__ S, double *__restrict__ STr, const FrontTab &tab,
                                              const int *it, unsigned long long *sb_g, int W) {
   double *bufA = (double *)smem, *bufC = bufA + 64 * TP, *bufB = bufC + 64 * TP, *bufT = bufB + 64 * TP;
   const int s = it[0], h = it[1];
@@ -378,6 +408,7 @@ __device__ __forceinline__ void sinv128_body(char *smem, const double *__restric
   const int k0 = 128 * h, nbA = min(64, ns - k0), nbC = max(0, min(64, ns - k0 - 64));
   const int Pb = k0 / W, kl = k0 - Pb * W;                          // super-block of the leaf, its first column inside it
   double *Ss = S + tab.soff[s] + (int64_t)Pb * W * sld;
+  double *Ts = STr + tab.soff[s] + (int64_t)Pb * W * sld;           // the transposed copy: Ts[r*sld + c] = inverse(r, c)
   unsigned long long *gP = sb_g + 2 * (tab.sboff[s] + Pb);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double vB[SPT];
@@ -418,6 +449,11 @@ __device__ __forceinline__ void sinv128_body(char *smem, const double *__restric
     if (i >= j && i < nbA) { if (WT) sdm_store_wt(&Ss[(int64_t)(kl + j) * sld + kl + i], bufA[i * TP + j]); else Ss[(int64_t)(kl + j) * sld + kl + i] = bufA[i * TP + j]; }
     if (i >= j && i < nbC) { if (WT) sdm_store_wt(&Ss[(int64_t)(kl + 64 + j) * sld + kl + 64 + i], bufC[j * TP + i]); else Ss[(int64_t)(kl + 64 + j) * sld + kl + 64 + i] = bufC[j * TP + i]; }
   }
+  for (int e = tid; e < 64 * 64; e += ST) {                           // transposed copy: consecutive work-items on consecutive columns j
+    const int j = e & 63, i = e >> 6;
+    if (i >= j && i < nbA) { if (WT) sdm_store_wt(&Ts[(int64_t)(kl + i) * sld + kl + j], bufA[i * TP + j]); else Ts[(int64_t)(kl + i) * sld + kl + j] = bufA[i * TP + j]; }
+    if (i >= j && i < nbC) { if (WT) sdm_store_wt(&Ts[(int64_t)(kl + 64 + i) * sld + kl + 64 + j], bufC[j * TP + i]); else Ts[(int64_t)(kl + 64 + i) * sld + kl + 64 + j] = bufC[j * TP + i]; }
+  }
   SDM_PHASE(4);
   if (nbC <= 0) return;
   __syncthreads();
@@ -433,13 +469,14 @@ __device__ __forceinline__ void sinv128_body(char *smem, const double *__restric
   __syncthreads();
   SDM_PHASE(5);
   const double gm = store_tile<WT>(Ss + (int64_t)kl * sld + kl + 64, sld, bufB, nbC, 64, tid);
+  store_tile_T<WT>(Ts + (int64_t)(kl + 64) * sld + kl, sld, bufB, nbC, 64, tid);
   wave_atomic_max(gP, gm, lane);
   SDM_PHASE(6);
 }
 __global__ void __launch_bounds__(ST)
-k_sinv128(const double *__restrict__ F, double *__restrict__ S, FrontTab tab, const int *items, unsigned long long *sb_g, int W) {
+k_sinv128(const double *__restrict__ F, double *__restrict__ S, double *__restrict__ STr, FrontTab tab, const int *items, unsigned long long *sb_g, int W) {
   SDM_DYN_SMEM(smem);
-  sinv128_body<false>(smem, F, S, tab, items + 4 * blockIdx.x, sb_g, W);
+  sinv128_body<false>(smem, F, S, STr, tab, items + 4 * blockIdx.x, sb_g, W);
 }
 
 // Combine levels.  Level lev joins the inverses of neighbouring column ranges of half width h = 128 << lev inside a
@@ -449,7 +486,7 @@ k_sinv128(const double *__restrict__ F, double *__restrict__ S, FrontTab tab, co
 //   stage 1  X21(I, J) = - sum_{K <= I} inv(C)(I, K) T(K, J)        into S
 // (both triangular in K: only the 64-blocks that can be non-zero are multiplied).
 template <bool WT>
-__device__ __forceinline__ void stile_body(char *smem, const double *F, double *S, double *T, const FrontTab &tab, const int *it,
+__device__ __forceinline__ void stile_body(char *smem, const double *F, double *S, double *STr, double *T, const FrontTab &tab, const int *it,
                                            unsigned long long *sb_g, int W) {
   double *As = (double *)smem, *Bs = As + 64 * TP;
   const int s = it[0], Pb = it[1], lev = it[2], pi = it[3], I = it[4], J = it[5], stage = it[6];
@@ -498,13 +535,16 @@ __device__ __forceinline__ void stile_body(char *smem, const double *F, double *
   acc_to_lds_rowmajor(acc, As, wave, lane, stage == 0 ? 1.0 : -1.0);
   __syncthreads();
   const double gm = store_tile<WT>(Cp, sld, As, arows, 64, tid);
-  if (stage == 1) wave_atomic_max(gP, gm, lane);                     // max |inverse|
+  if (stage == 1) {
+    store_tile_T<WT>(STr + tab.soff[s] + (int64_t)P0 * sld + (int64_t)(a0 + h + 64 * I) * sld + a0 + 64 * J, sld, As, arows, 64, tid);
+    wave_atomic_max(gP, gm, lane);                                   // max |inverse|
+  }
   SDM_PHASE(9 + 4 * stage);
 }
 __global__ void __launch_bounds__(ST)
-k_stile(const double *F, double *S, double *T, FrontTab tab, const int *items, unsigned long long *sb_g, int W) {
+k_stile(const double *F, double *S, double *STr, double *T, FrontTab tab, const int *items, unsigned long long *sb_g, int W) {
   SDM_DYN_SMEM(smem);
-  stile_body<false>(smem, F, S, T, tab, items + 8 * blockIdx.x, sb_g, W);
+  stile_body<false>(smem, F, S, STr, T, tab, items + 8 * blockIdx.x, sb_g, W);
 }
 
 // ---- all of the above in ONE launch for problems whose items fit the device at once (k_sprep): workgroups take the
@@ -526,13 +566,13 @@ __device__ __forceinline__ void prep_done(int *cnt) {
   if (threadIdx.x == 0) sdm_signal_add(cnt);
 }
 __global__ void __launch_bounds__(ST)
-k_sprep(const double *F, double *S, double *T, FrontTab tab, const int *l_i128, int n_i128, const int *l_items,
+k_sprep(const double *F, double *S, double *STr, double *T, FrontTab tab, const int *l_i128, int n_i128, const int *l_items,
         unsigned long long *sb_g, int *cnt, int W, int *tmo) {
   SDM_DYN_SMEM(smem);
   const int b = blockIdx.x;
   if (b < n_i128) {
     const int *it = l_i128 + 4 * b;
-    sinv128_body<true>(smem, F, S, tab, it, sb_g, W);
+    sinv128_body<true>(smem, F, S, STr, tab, it, sb_g, W);
     prep_done(cnt + SPREP_NCNT * (tab.sboff[it[0]] + (128 * it[1]) / W));
     return;
   }
@@ -540,7 +580,7 @@ k_sprep(const double *F, double *S, double *T, FrontTab tab, const int *l_i128, 
   const int st = 2 * it[2] + it[6];
   int *c = cnt + SPREP_NCNT * (tab.sboff[it[0]] + it[1]);
   prep_wait(c + st, it[7], tmo);
-  stile_body<true>(smem, F, S, T, tab, it, sb_g, W);
+  stile_body<true>(smem, F, S, STr, T, tab, it, sb_g, W);
   prep_done(c + st + 1);
 }
 
@@ -565,7 +605,7 @@ __device__ __forceinline__ void follow_wait(const int *cnt, int target, int *tmo
   __syncthreads();
 }
 __global__ void __launch_bounds__(ST)
-k_sinv_follow(const double *F, const double *DT, double *S, FrontTab tab, const int *list, int *front_cnt, const int *diag_cnt,
+k_sinv_follow(const double *F, const double *DT, double *S, double *STr, FrontTab tab, const int *list, int *front_cnt, const int *diag_cnt,
               unsigned long long *sb_g, int *tmo) {
   SDM_DYN_SMEM(smem);
   const int s = list[blockIdx.y];
@@ -574,7 +614,7 @@ k_sinv_follow(const double *F, const double *DT, double *S, FrontTab tab, const 
   const int b = blockIdx.x;
   if (b >= T * (T + 1) / 2) return;
   const double *Fs = F + tab.foff[s];
-  double *Ss = S + tab.soff[s];
+  double *Ss = S + tab.soff[s], *Ts = STr + tab.soff[s];
   const int slot = tab.fslot[s];
   const int *row_cnt = front_cnt + (int64_t)slot * FRONT_CNT;
   int *xcnt = front_cnt + (int64_t)slot * FRONT_CNT + FRONT_XCNT_OFF;
@@ -608,6 +648,10 @@ k_sinv_follow(const double *F, const double *DT, double *S, FrontTab tab, const 
     for (int e = tid; e < 64 * 64; e += ST) {
       const int i = e & 63, j = e >> 6;
       if (i >= j && i < nb) sdm_store_wt(&Ss[(int64_t)(64 * r + j) * sld + 64 * r + i], bufA[i * TP + j]);
+    }
+    for (int e = tid; e < 64 * 64; e += ST) {
+      const int j = e & 63, i = e >> 6;
+      if (i >= j && i < nb) Ts[(int64_t)(64 * r + i) * sld + 64 * r + j] = bufA[i * TP + j];       // (the transposed copy is read by the solves only: plain stores)
     }
     prep_done(xcnt + r * FRONT_MAXT + r);
     return;
@@ -644,6 +688,7 @@ k_sinv_follow(const double *F, const double *DT, double *S, FrontTab tab, const 
   acc_to_lds_rowmajor(acc, As, wave, lane, -1.0);
   __syncthreads();
   const double gm = store_tile<true>(Ss + (int64_t)(64 * c) * sld + 64 * r, sld, As, arows, 64, tid);
+  store_tile_T<false>(Ts + (int64_t)(64 * r) * sld + 64 * c, sld, As, arows, 64, tid);
   wave_atomic_max(gP, gm, lane);
   prep_done(xcnt + r * FRONT_MAXT + c);
 }
@@ -813,6 +858,65 @@ __device__ __forceinline__ void bw_product(const double *M, int64_t ldm, int cba
   }
 }
 
+// ================================================================ row products
+// Every product of the sweeps that involves an inverse block, or a block of L inside a supernode, is a set of independent
+// DOT PRODUCTS ALONG CONTIGUOUS MEMORY: rows of the transposed inverse (forward diagonal block), rows of the transposed copy of
+// L (forward step), columns of the inverse (backward diagonal block), columns of L (backward step).  One wavefront per row,
+// four rows per workgroup: 16-byte loads, up to eight in flight per lane (the vector entries next to them, straight from
+// L2), no LDS, no barrier, and -- rows being what they are -- as many workgroups as rows / 4, however long the rows are
+// (the 16-row slabs of the first version streamed up to 256 KB per workgroup at ~25 GB/s: 12 us per launch on MAXCUT-4000).
+// sum_{j = jlo}^{n-1} M[j] x[j];  M 16-byte aligned, readable up to index n rounded up to even; fixed summation order.
+// GATHER: x[j] = xg[px[j]].  Result in every lane.  (Eight 16-byte loads per lane in flight, the vector entries next to them
+// straight from L2; the variant with the vector staged in LDS and sixteen loads in flight measured 5-10 % slower on the long
+// rows of MAXCUT-4000 -- the barrier costs more than the second round trip: profiles/r03n.)
+template <bool GATHER>
+__device__ __forceinline__ double row_dot(const double *__restrict__ M, const double *__restrict__ x, const int *__restrict__ px, int n, int jlo, int lane) {
+  double a0 = 0.0, a1 = 0.0;
+  const sdm_double2 *M2 = (const sdm_double2 *)M;
+  const int npair = (n + 1) >> 1;
+  for (int p0 = 0; p0 < npair; p0 += 8 * 64) {
+    sdm_double2 v[8];
+    double x0[8], x1[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int pi = p0 + lane + 64 * k, pc = min(pi, npair - 1);
+      v[k] = M2[pc];
+      const int j0 = 2 * pc, j1 = min(2 * pc + 1, n - 1);
+      x0[k] = GATHER ? x[px[j0]] : x[j0];
+      x1[k] = GATHER ? x[px[j1]] : x[j1];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int pi = p0 + lane + 64 * k;
+      const bool in0 = pi < npair && 2 * pi >= jlo, in1 = pi < npair && 2 * pi + 1 < n && 2 * pi + 1 >= jlo;
+      // (selects on both factors: what lies outside the range may be anything)
+      a0 += (in0 ? v[k].x : 0.0) * (in0 ? x0[k] : 0.0);
+      a1 += (in1 ? v[k].y : 0.0) * (in1 ? x1[k] : 0.0);
+    }
+  }
+  double a = a0 + a1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  return a;
+}
+// transposed copy of the rows of L below super-block Pb of a front (64x64 tiles through LDS): LT[r*W + c] = L((Pb+1) W + r, Pb W + c)
+__device__ __forceinline__ int64_t lt_boff(int ns, int W, int Pb) { return (int64_t)W * ((int64_t)Pb * ns - (int64_t)W * Pb * (Pb + 1) / 2); }
+__global__ void __launch_bounds__(ST)
+k_ltrans(const double *__restrict__ F, double *__restrict__ LT, FrontTab tab, const int *items, int W) {
+  __shared__ double t[64][65];
+  const int *it = items + 4 * blockIdx.x;
+  const int s = it[0], Pb = it[1], I = it[2], J = it[3];
+  const int ns = tab.ns[s], ld = tab.ld[s];
+  const int R0 = (Pb + 1) * W, nr = ns - R0;
+  const double *src = F + tab.foff[s] + (int64_t)(Pb * W + 64 * J) * ld + R0 + 64 * I;       // (row i, column c) at src[c*ld + i]
+  double *dst = LT + tab.ltoff[s] + lt_boff(ns, W, Pb) + (int64_t)(64 * I) * W + 64 * J;
+  const int tid = threadIdx.x, a = tid & 63, b = tid >> 6;
+  const int nri = min(64, nr - 64 * I);
+  for (int c = b; c < 64; c += ST / 64) t[c][a] = a < nri ? src[(int64_t)c * ld + a] : 0.0;
+  __syncthreads();
+  for (int i = b; i < 64; i += ST / 64) if (i < nri) dst[(int64_t)i * W + a] = t[a][i];
+}
+
 // ================================================================ forward sweep
 // several right-hand sides side by side (blockIdx.z): element strides of the right-hand sides, of the result and of the
 // update-vector scratch (all 0 for a single right-hand side)
@@ -840,25 +944,24 @@ k_sfw_init(FrontTab tab, const int *list, double *wv, const double *src, const i
 #define FT(field) (tab.one ? tab.o_##field : tab.field[s])      // front descriptor: kernel argument (one-front level) or table
 // y_P = inv(L_PP) t_P for super-block Pb of every front of a level that has one; t_P = the right-hand side gathered
 // through perm (Pb = 0 of a leaf level: gather0) or the front's assembled / updated vector a.  With zdiv the ./d copy
-// (wrapPcg.m:57; skipped pivots act as 1, deninfac.m:89-94) is written as well: y_P is final here.  A block that failed
-// the growth check is substituted against the factor by workgroup 0.
+// (wrapPcg.m:57; skipped pivots act as 1, deninfac.m:89-94) is written as well: y_P is final here.  One wavefront per row of
+// the TRANSPOSED inverse (row r of the inverse: r + 1 contiguous entries).  A block that failed the growth check is
+// substituted against the factor by workgroup 0.
 __global__ void __launch_bounds__(ST)
-k_sfw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, const double *wv, const double *src,
+k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTab tab, const int *list, const double *wv, const double *src,
            const int *perm, double *y, const unsigned long long *sb_g, double thr, int Pb, int gather0, FwBatch bt,
            double *zdiv, const double *dscale, int W) {
-  __shared__ double xs[SBW_MAX], red[(ST / 8) * SROWS];
+  __shared__ double xs[SBW_MAX];
   __shared__ double Sd[64 * TP];
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), first = FT(first);
   const int c0 = Pb * W;
   if (c0 >= ns) return;
   const int nb = min(W, ns - c0);
-  const int r0 = SROWS * blockIdx.x;
-  if (r0 >= nb) return;
+  if (4 * (int)blockIdx.x >= nb) return;
   wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; if (src) src += (int64_t)blockIdx.z * bt.src;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int sld = FT(sld);
-  const double *Sb = S + FT(soff) + (int64_t)c0 * sld;
   const double *a = wv + FT(woff) + c0;
   const bool gather = gather0 && Pb == 0;
   const int *pp = perm + first + c0;
@@ -874,42 +977,57 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
     }
     return;
   }
-  const int ncols = min(nb, r0 + SROWS);                             // lower triangular: columns up to the slab's last row
-  const double sum = fw_product(Sb, sld, ncols, r0, nb - 1, xs, red,
-                                [&]() { for (int c = tid; c < ncols; c += ST) xs[c] = gather ? src[pp[c]] : a[c]; });
-  if (tid < SROWS && r0 + tid < nb) {
-    y[first + c0 + r0 + tid] = sum;
-    if (zdiv) { const double dk = dscale[first + c0 + r0 + tid]; zdiv[first + c0 + r0 + tid] = sum / (dk > 0.0 ? dk : 1.0); }
+  const int r = 4 * blockIdx.x + wave;
+  if (r >= nb) return;
+  const double *M = STr + FT(soff) + (int64_t)c0 * sld + (int64_t)r * sld;
+  const double sum = gather ? row_dot<true>(M, src, pp, r + 1, 0, lane) : row_dot<false>(M, a, nullptr, r + 1, 0, lane);
+  if (lane == 0) {
+    y[first + c0 + r] = sum;
+    if (zdiv) { const double dk = dscale[first + c0 + r]; zdiv[first + c0 + r] = sum / (dk > 0.0 ? dk : 1.0); }
   }
 }
 
-// step Pb: y_P is final; every row beyond super-block Pb -- the front's own rows of later blocks and the rows of its
-// ancestors, whose sums are the update vector passed to the parent -- receives  - L(r, P) y_P , read from the factor.
-// assign0 (Pb = 0 of a leaf level): the vector a has not been initialised: a = right-hand side (own rows) / 0 - sum.
+// step Pb, the front's OWN rows of later super-blocks:  - L(r, P) y_P  along the rows of the transposed copy LT
+// assign0 (Pb = 0 of a leaf level): the vector a has not been initialised: a = right-hand side - sum.
 __global__ void __launch_bounds__(ST)
-k_sfw_step(const double *__restrict__ F, FrontTab tab, const int *list, double *wv, const double *src, const int *perm, const double *y,
+k_sfw_rows(const double *__restrict__ LT, FrontTab tab, const int *list, double *wv, const double *src, const int *perm, const double *y,
            int Pb, int assign0, FwBatch bt, int W) {
+  const int s = tab.one ? tab.o_s : list[blockIdx.y];
+  const int ns = FT(ns), first = FT(first);
+  const int R0 = (Pb + 1) * W;
+  const int rl = 4 * blockIdx.x + (threadIdx.x >> 6);
+  if (R0 + rl >= ns) return;
+  wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; if (src) src += (int64_t)blockIdx.z * bt.src;
+  const int lane = threadIdx.x & 63;
+  const double *M = LT + FT(ltoff) + lt_boff(ns, W, Pb) + (int64_t)rl * W;
+  const double sum = row_dot<false>(M, y + first + Pb * W, nullptr, W, 0, lane);
+  if (lane == 0) {
+    double *a = wv + FT(woff);
+    const int r = R0 + rl;
+    a[r] = (assign0 ? src[perm[first + r]] : a[r]) - sum;
+  }
+}
+
+// step Pb, the rows BELOW the supernode (they belong to its ancestors; their sums are the update vector passed to the parent):
+//  - L(r, P) y_P  read from the factor itself, 16-row slabs.  assign0: the vector has not been initialised: 0 - sum.
+__global__ void __launch_bounds__(ST)
+k_sfw_step(const double *__restrict__ F, FrontTab tab, const int *list, double *wv, const double *y, int Pb, int assign0, FwBatch bt, int W) {
   __shared__ double xs[SBW_MAX], red[(ST / 8) * SROWS];
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), ms = FT(ms), first = FT(first), ld = FT(ld);
   const int c0 = Pb * W;
-  if (c0 >= ns) return;
+  if (c0 >= ns || ms <= ns) return;
   const int nb = min(W, ns - c0);
-  const bool more = ns > c0 + W;                                     // later super-blocks of the front itself
-  const int rmin = more ? c0 + W : ns, rstart = more ? c0 + W : (ns & ~1);
-  const int r0 = rstart + SROWS * blockIdx.x;
-  if (rmin >= ms || r0 >= ms) return;
-  wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; if (src) src += (int64_t)blockIdx.z * bt.src;
+  const int r0 = (ns & ~1) + SROWS * blockIdx.x;
+  if (r0 >= ms) return;
+  wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y;
   const int tid = threadIdx.x;
   const double *yp = y + first + c0;
   const double sum = fw_product(F + FT(foff) + (int64_t)c0 * ld, ld, nb, r0, ms - 1, xs, red,
                                 [&]() { for (int c = tid; c < nb; c += ST) xs[c] = yp[c]; });
   double *a = wv + FT(woff);
   const int r = r0 + tid;
-  if (tid < SROWS && r >= rmin && r < ms) {
-    const double base = assign0 ? (r < ns ? src[perm[first + r]] : 0.0) : a[r];
-    a[r] = base - sum;
-  }
+  if (tid < SROWS && r >= ns && r < ms) a[r] = (assign0 ? 0.0 : a[r]) - sum;
 }
 
 // ================================================================ backward sweep
@@ -960,8 +1078,9 @@ k_sbw_init(const double *__restrict__ F, FrontTab tab, const int *list, double *
 }
 
 // x_Q = inv(L_QQ)' v_Q for super-block Q of every front of a level that has one; the result goes to xfin (descendants
-// and the step launch read it) and, scattered through perm, to yout.  A block that failed the growth check is
-// substituted against the factor by workgroup 0.
+// and the step launch read it) and, scattered through perm, to yout.  One wavefront per COLUMN of the inverse (column c: the
+// nb - c contiguous entries from the diagonal down).  A block that failed the growth check is substituted against the factor
+// by workgroup 0.
 __global__ void __launch_bounds__(ST)
 k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, const double *y, double *xfin, double *yout,
            const int *perm, const unsigned long long *sb_g, double thr, int Q, int W) {
@@ -972,8 +1091,7 @@ k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
   const int rb = Q * W;
   if (rb >= ns) return;
   const int nb = min(W, ns - rb);
-  const int c0 = SROWS * blockIdx.x;
-  if (c0 >= nb) return;
+  if (4 * (int)blockIdx.x >= nb) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const double *vp = y + first + rb;
   if (sb_is_bad(sb_g, FT(sboff) + Q, thr)) {
@@ -984,38 +1102,28 @@ k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
     for (int i = tid; i < nb; i += ST) { xfin[first + rb + i] = xs[i]; if (yout) yout[perm[first + rb + i]] = xs[i]; }
     return;
   }
+  const int c = 4 * blockIdx.x + wave;
+  if (c >= nb) return;
   const int sld = FT(sld);
-  const double *Sb = S + FT(soff) + (int64_t)rb * sld;
-  const int ncols = min(SROWS, nb - c0), nr = nb - c0;               // rows c0 .. end of the block (lower triangular)
-  double part[4];
-  bw_product(Sb, sld, c0, ncols, c0, nr, xs, part, [&]() { for (int i = tid; i < nr; i += ST) xs[i] = vp[c0 + i]; });
-  if (lane == 0) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int c = c0 + 4 * wave + q;
-      if (c < nb) { xfin[first + rb + c] = part[q]; if (yout) yout[perm[first + rb + c]] = part[q]; }
-    }
-  }
+  const int ce = c & ~1;                                              // 16-byte aligned start (the entry above the diagonal is skipped: jlo)
+  const double *M = S + FT(soff) + (int64_t)rb * sld + (int64_t)c * sld + ce;
+  const double sum = row_dot<false>(M, vp + ce, nullptr, nb - ce, c - ce, lane);
+  if (lane == 0) { xfin[first + rb + c] = sum; if (yout) yout[perm[first + rb + c]] = sum; }
 }
 
-// step Q: x_Q is final; every column left of super-block Q receives  - L(Q rows, c)' x_Q , read from the factor
+// step Q: x_Q is final; every column left of super-block Q receives  - L(Q rows, c)' x_Q , read from the factor (a column
+// of L is contiguous there), one wavefront per column
 __global__ void __launch_bounds__(ST)
 k_sbw_step(const double *__restrict__ F, FrontTab tab, const int *list, double *y, const double *xfin, int Q, int W) {
-  __shared__ double xs[SBW_MAX];
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), first = FT(first), ld = FT(ld);
   const int rb = Q * W;
   if (rb >= ns) return;
   const int nbq = min(W, ns - rb);
-  const int c0 = SROWS * blockIdx.x;                                // < rb by the grid
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const double *xp = xfin + first + rb;
-  double part[4];
-  bw_product(F + FT(foff), ld, c0, SROWS, rb, nbq, xs, part, [&]() { for (int i = tid; i < nbq; i += ST) xs[i] = xp[i]; });
-  if (lane == 0) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) y[first + c0 + 4 * wave + q] -= part[q];
-  }
+  const int c = 4 * blockIdx.x + (threadIdx.x >> 6);                // < rb by the grid
+  const int lane = threadIdx.x & 63;
+  const double sum = row_dot<false>(F + FT(foff) + (int64_t)c * ld + rb, xfin + first + rb, nullptr, nbq, 0, lane);
+  if (lane == 0) y[first + c] -= sum;
 }
 #undef FT
 
@@ -1027,7 +1135,7 @@ static FrontTab level_tab(const CholPlan &C, FrontTab t, int l) {
   if (C.levptr[l + 1] - C.levptr[l] != 1) return t;
   const int s = C.levlist[C.levptr[l]];
   t.one = 1; t.o_s = s; t.o_ns = C.sn_ns[s]; t.o_ms = C.sn_ms[s]; t.o_ld = C.sn_ld[s]; t.o_first = C.sn_first[s];
-  t.o_sld = C.sn_sld[s]; t.o_sboff = C.sn_sboff[s]; t.o_foff = C.sn_foff[s]; t.o_soff = C.sn_soff[s]; t.o_woff = C.sn_woff[s];
+  t.o_sld = C.sn_sld[s]; t.o_sboff = C.sn_sboff[s]; t.o_foff = C.sn_foff[s]; t.o_soff = C.sn_soff[s]; t.o_woff = C.sn_woff[s]; t.o_ltoff = C.sn_ltoff[s];
   t.o_xl = C.sn_xl[s];
   return t;
 }
@@ -1049,7 +1157,7 @@ void solve_follow(sdm_plan *P, int l, hipStream_t st) {
   solve_attrs();
   C.growth_used = C.growth_max;
   const int nfr = C.levptr[l + 1] - C.levptr[l];
-  SDM_KLAUNCH_ON(P, st, k_sinv_follow, dim3(C.lev_followT[l], nfr), dim3(ST), TILE_LDS, C.fronts.p, C.frontsT.p, C.S.p, front_tab(C),
+  SDM_KLAUNCH_ON(P, st, k_sinv_follow, dim3(C.lev_followT[l], nfr), dim3(ST), TILE_LDS, C.fronts.p, C.frontsT.p, C.S.p, C.ST.p, front_tab(C),
                  C.d_levlist.p + C.levptr[l], C.front_cnt.p, C.diag_cnt.p, C.sb_g.p, C.tmo.dev());
 }
 void solve_prepare(sdm_plan *P, bool sb_g_is_zero) {
@@ -1060,17 +1168,18 @@ void solve_prepare(sdm_plan *P, bool sb_g_is_zero) {
   const size_t gw = (size_t)std::max(C.nsbtot, 1) * (2 + SPREP_NCNT / 2);
   if (!sb_g_is_zero)                                                // (a factorisation zeroes them in k_prep_pivots)
     SDM_HIP_CHECK(hipMemsetAsync(C.sb_g.p, 0, gw * sizeof(unsigned long long), P->stream));
-  if (C.n_i128 == 0) return;
   const int W = C.sbw;
+  if (C.n_lt) SDM_KLAUNCH(P, k_ltrans, dim3(C.n_lt), dim3(ST), 0, C.fronts.p, C.LT.p, tab, C.l_lt.p, W);
+  if (C.n_i128 == 0) return;
   if (C.n_i128 + C.n_items <= SPREP_MAX_ITEMS) {                    // everything resident at once: one launch, counters instead of boundaries
-    SDM_KLAUNCH(P, k_sprep, dim3(C.n_i128 + C.n_items), dim3(ST), INV_LDS, C.fronts.p, C.S.p, C.Tarena.p, tab, C.l_i128.p, C.n_i128,
+    SDM_KLAUNCH(P, k_sprep, dim3(C.n_i128 + C.n_items), dim3(ST), INV_LDS, C.fronts.p, C.S.p, C.ST.p, C.Tarena.p, tab, C.l_i128.p, C.n_i128,
                 C.l_items.p, C.sb_g.p, (int *)(C.sb_g.p + 2 * std::max(C.nsbtot, 1)), W, C.tmo.dev());
     return;
   }
-  SDM_KLAUNCH(P, k_sinv128, dim3(C.n_i128), dim3(ST), INV_LDS, C.fronts.p, C.S.p, tab, C.l_i128.p, C.sb_g.p, W);
+  SDM_KLAUNCH(P, k_sinv128, dim3(C.n_i128), dim3(ST), INV_LDS, C.fronts.p, C.S.p, C.ST.p, tab, C.l_i128.p, C.sb_g.p, W);
   for (int st = 0; st < 2 * SINV_MAXLEV; st++) {
     const int n = C.stage_ptr[st + 1] - C.stage_ptr[st];
-    if (n > 0) SDM_KLAUNCH(P, k_stile, dim3(n), dim3(ST), TILE_LDS, C.fronts.p, C.S.p, C.Tarena.p, tab, C.l_items.p + 8 * (size_t)C.stage_ptr[st], C.sb_g.p, W);
+    if (n > 0) SDM_KLAUNCH(P, k_stile, dim3(n), dim3(ST), TILE_LDS, C.fronts.p, C.S.p, C.ST.p, C.Tarena.p, tab, C.l_items.p + 8 * (size_t)C.stage_ptr[st], C.sb_g.p, W);
   }
 }
 
@@ -1114,11 +1223,14 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
     if (!(what & 2)) continue;
     for (int Pb = 0; Pb < L.nsb; Pb++) {
       const int nbmax = std::min(W, L.maxns - Pb * W);
-      SDM_KLAUNCH(P, k_sfw_diag, dim3((nbmax + SROWS - 1) / SROWS, L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, wv, rhs,
+      SDM_KLAUNCH(P, k_sfw_diag, dim3((nbmax + 3) / 4, L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, C.ST.p, tab, list, wv, rhs,
                   C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W);
-      if (L.slabs_fw[Pb] > 0)
-        SDM_KLAUNCH(P, k_sfw_step, dim3(L.slabs_fw[Pb], L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, tab, list, wv, rhs, C.d_perm.p, y, Pb,
-                    (gather && Pb == 0) ? 1 : 0, bt, W);
+      const int assign0 = (gather && Pb == 0) ? 1 : 0;
+      if (L.maxns > (Pb + 1) * W)                                    // the fronts' own rows of later super-blocks
+        SDM_KLAUNCH(P, k_sfw_rows, dim3((L.maxns - (Pb + 1) * W + 3) / 4, L.nfronts, nrhs), dim3(ST), 0, C.LT.p, tab, list, wv, rhs, C.d_perm.p, y, Pb,
+                    assign0, bt, W);
+      if (L.slabs_fw[Pb] > 0)                                        // the rows below the supernodes
+        SDM_KLAUNCH(P, k_sfw_step, dim3(L.slabs_fw[Pb], L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, tab, list, wv, y, Pb, assign0, bt, W);
     }
   }
 }
@@ -1141,9 +1253,9 @@ static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double 
       SDM_KLAUNCH(P, k_sbw_init, dim3((L.maxns + SROWS - 1) / SROWS, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, dscale);
     for (int Q = L.nsb - 1; Q >= 0; Q--) {
       const int nbmax = std::min(W, L.maxns - Q * W);
-      SDM_KLAUNCH(P, k_sbw_diag, dim3((nbmax + SROWS - 1) / SROWS, L.nfronts), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
+      SDM_KLAUNCH(P, k_sbw_diag, dim3((nbmax + 3) / 4, L.nfronts), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
                   C.d_perm.p, C.sb_g.p, thr, Q, W);
-      if (Q > 0) SDM_KLAUNCH(P, k_sbw_step, dim3(Q * (W / SROWS), L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, Q, W);
+      if (Q > 0) SDM_KLAUNCH(P, k_sbw_step, dim3(Q * (W / 4), L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, Q, W);
     }
   }
 }

@@ -35,6 +35,16 @@ def build_phases(verbose=True):
     return out
 
 
+def build_variant(tag, flags, verbose=True):
+    """Tools-only build with extra compiler flags (a measurement variant): sedumi_amd/lib/libsedumi_hip_<tag>.so.
+    Never loaded by the package; the tools point capi.use_library at it (SDM_LIB)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = os.path.join(LIBDIR, "libsedumi_hip_%s.so" % tag)
+    hipcc, objs = _compile_objects(list(flags), os.path.join(LIBDIR, "obj_" + tag), verbose)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 def _compile_objects(extra, objdir, verbose):
     """One object per source (hipcc -c), rebuilt only when the source or any header is newer; the compiles run side by side."""
     from concurrent.futures import ThreadPoolExecutor
@@ -78,5 +88,8 @@ def build(force=False, verbose=True):
 if __name__ == "__main__":
     if "--phases" in sys.argv:
         build_phases()
+    elif "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], sys.argv[i + 2:])
     else:
         build(force="--force" in sys.argv)

@@ -703,6 +703,7 @@ __device__ __forceinline__ void diag_sweep_w0(double (*S)[NB + 1], double *Lc, i
   int &badflag = *badflag_p;
       const int c0 = s * SW, cn = c0 + SW;                             // sweep s is final; sweep columns cn .. cn+SW-1 now
       double x[SW], lsc[SW];
+      SDM_PHASE_BEGIN();
 #pragma unroll
       for (int cc = 0; cc < SW; cc++) x[cc] = S[tx][cn + cc];
       if (s >= 0) {
@@ -725,6 +726,7 @@ __device__ __forceinline__ void diag_sweep_w0(double (*S)[NB + 1], double *Lc, i
             for (int cc = 0; cc < SW; cc++) x[cc] -= lj[k][cc] * xs[kh + k];
         }
       }
+      SDM_PHASE(6);
 #pragma unroll
       for (int k = 0; k < SW; k++) {
         const int gc = cn + k;
@@ -735,6 +737,7 @@ __device__ __forceinline__ void diag_sweep_w0(double (*S)[NB + 1], double *Lc, i
         for (int j = k + 1; j < SW; j++) x[j] -= sdm_bcast_lane(l, cn + j) * x[k];
         lsc[k] = l;
       }
+      SDM_PHASE(7);
       // rows above the diagonal carry don't-care values from here on (nobody reads them: every consumer of S and Lc
       // is restricted to the lower triangle), which saves the masks
 #pragma unroll
@@ -751,6 +754,7 @@ __device__ __forceinline__ void diag_sweep_w0(double (*S)[NB + 1], double *Lc, i
         if (!acc) { stt[tx] = 1; pv[tx] = pval; }
         if (acc && ms - (k0 + tx) > 1 && pval < ub) badflag = 1;       // needs the column probe: general path below
       }
+      SDM_PHASE(8);
 }
 // One of nw helper wavefronts (widx = 0 .. nw-1), one sweep: sweep s goes into the trailing columns from c0 + 2 SW on
 // (x_rj -= l_jk * x_rk, k ascending), 4 columns per wavefront at a time.
@@ -1567,7 +1571,12 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
         // fork: the inverse of the level's fronts follows the factorisation on the second stream (k_sinv_follow polls
         // k_ldl_front's progress counters; both kernels' workgroups fit the device together: solve_build), join behind both
         if (!P->stream2) {
-          SDM_HIP_CHECK(hipStreamCreateWithFlags(&P->stream2, hipStreamNonBlocking));
+          // its own PRIORITY class: streams of one class share a few hardware queues round robin, and two streams on one queue run
+          // their kernels one after the other -- the follower would start when the factorisation ends (measured: a second plan of the
+          // same process paid 100 us per factorisation that way, profiles/r03m other_configs).  Queues of different classes are distinct.
+          int prio_least = 0, prio_greatest = 0;
+          SDM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+          SDM_HIP_CHECK(hipStreamCreateWithPriority(&P->stream2, hipStreamNonBlocking, prio_least));
           SDM_HIP_CHECK(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
           SDM_HIP_CHECK(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming));
         }

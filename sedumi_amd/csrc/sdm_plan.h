@@ -24,7 +24,10 @@ constexpr int SBW_MAX = 2048;         // widest one (CholPlan::sbw = the power-o
 constexpr int SINV_MAXLEV = 4;        // combine levels above the 128-column leaves: half widths 128, 256, 512, 1024
 constexpr int SPREP_NCNT = 2 + 2 * SINV_MAXLEV;   // completion counters per super-block of k_sprep (leaves, then T / X per level)
 constexpr int SROWS = 16;             // rows (forward) / columns (backward) of a front handled by one workgroup of the solve kernels
-constexpr int SW = 8;                 // columns of the diagonal block swept in registers at a time (readlane chain), rest via LDS
+#ifndef SDM_SW
+#define SDM_SW 8
+#endif
+constexpr int SW = SDM_SW;                 // columns of the diagonal block swept in registers at a time (readlane chain), rest via LDS
 constexpr int LDL_THREADS = 512;      // workgroup of the diagonal-block kernel: wavefront 0 sweeps, the other 7 apply the previous sweep
 constexpr int PANEL_THREADS = 256;    // workgroup of the row-solve kernel: 4 wavefronts, one per SIMD (the solve is issue bound)
 constexpr int ROWS_BATCH = 16 * (PANEL_THREADS / 64);   // rows per workgroup of the row-solve kernel (16 per wavefront on the matrix cores)

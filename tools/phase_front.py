@@ -31,6 +31,7 @@ v = np.array(list(buf), dtype=np.float64) / 100.0
 npan = (m + 63) // 64
 print("m=%d, %d panels; us summed over the panels:" % (m, npan))
 print("  D (work-item 0 of the block's workgroup): load %.0f | sweeps %.0f | trailing %.0f | barrier %.0f | copy %.0f | barrier %.0f | write-back + publish %.0f" % tuple(v[16:23]))
+print("  inside the sweeps: look-ahead (LDS + products) %.0f | pivots %.0f | write-back + bookkeeping %.0f" % tuple(v[6:9]))
 print("  next block's workgroup: until the last 16 columns arrive %.0f | stage + triangle %.0f | rows stored + acknowledged + counted %.0f | fence + counters %.0f | diagonal tile %.0f | stores + count %.0f"
       % tuple(v[0:6]))
 print("  diagonal tile inside update_tile: loads+fill %.0f mfma %.0f to S + HBM %.0f" % (v[14], v[15], v[31]))

@@ -10,6 +10,9 @@ import numpy as np
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
+if os.environ.get("SDM_LIB"):                      # a measurement variant (python -m sedumi_amd.build --variant <tag> <flags>)
+    from sedumi_amd import capi
+    capi.use_library(os.path.join(ROOT, "sedumi_amd", "lib", os.environ["SDM_LIB"]))
 import bench  # noqa: E402
 from sedumi_amd.plan import Plan  # noqa: E402
 
@@ -52,9 +55,16 @@ for width in widths:
     nl = sum(v[0] for k, v in prof.items() if k.startswith("k_sfw") or k.startswith("k_sbw")) / 20.0
     prep = {k: round(1e3 * v[1] / 5, 2) for k, v in prof.items() if k in ("k_sprep", "k_sinv128", "k_stile")}
     nb, nbad, growth = plan.solve_stats()
+    yv = plan.download("y", plan.m)                                   # (residual of the last solve against the matrix that was factored)
+    import scipy.sparse as sp
+    A = sp.csc_matrix((plan.download("ada", ADA.nnz), ADA.indices, ADA.indptr), shape=ADA.shape)
+    if abs(A - A.T).sum() > 0:
+        A = sp.tril(A) + sp.tril(A, -1).T
+    resid = float(np.linalg.norm(A @ yv - rhs) / np.linalg.norm(rhs))
     print(json.dumps({"workload": P.name, "m": plan.m, "width": plan.solve_width(), "us_per_solve": round(us, 2), "launches_per_solve": nl,
                       "GBs": round(bytes_solve / us / 1e3, 1), "frac_of_hbm_peak": round(bytes_solve / us / 1e3 / 8000.0, 4),
                       "factor_incl_inversion_ms": round(fac / reps, 4), "inversion_us_by_kernel_with_events": prep,
-                      "kernel_us_with_events": {k: round(1e3 * v[1] / v[0], 2) for k, v in prof.items() if k.startswith("k_s")},
-                      "super_blocks": nb, "bad": nbad, "growth": growth}), flush=True)
+                      "kernel_us_with_events": {k: round(1e3 * v[1] / v[0], 2) for k, v in prof.items() if k.startswith("k_s") or k.startswith("k_ldl")},
+                      "super_blocks": nb, "bad": nbad, "growth": growth, "relres": resid,
+                      "lib": os.environ.get("SDM_LIB", "")}), flush=True)
     plan.close()

@@ -563,7 +563,7 @@ k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0, con
   double *z = zbuf + T.t_zoff[task];
   const int64_t rowbase = T.psd_start[T.t_blk[task]];
   const int tid = threadIdx.x, bs = blockDim.x;
-  const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
+  const int wave = SDM_UNIFORM_INT(tid >> 6), lane = tid & 63, nw = bs >> 6;      // (the wavefront index in a scalar register)
   const int li = lane & 15, lk = lane >> 4;
   sdm_double4 acc[S1_MAXT];
   for (int x = 0; x < S1_MAXT; x++) for (int r = 0; r < 4; r++) acc[x][r] = 0.0;

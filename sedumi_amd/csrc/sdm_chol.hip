@@ -21,6 +21,7 @@
 // pivot DECISIONS follow blkchol2.c:114-161 including the idamax quirk of
 // maxabs (blkchol2.c:66-70).
 #include "sdm_plan.h"
+#include <cstring>
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -806,12 +807,11 @@ __device__ __forceinline__ void publish_group(double *Dsp, const double *Lc, con
 // dependent load of a microsecond, and the noinline stages of that kernel would each repeat them on the chain)
 struct FrontDesc { int ns, ms, ld, first; int64_t foff, toff, woff; double maxu, ub; };
 template <bool PERSIST>
-__device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT, const FrontTab &tab, int s, int panel, double *d, double *lb,
-                                               const double *ubp, int *pivstat, double *pivval, double *colbuf, const double *ada,
+__device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT, const FrontDesc &fd, int s, int panel, double *d, double *lb,
+                                               int *pivstat, double *pivval, double *colbuf, const double *ada,
                                                const int *asm_src, const int64_t *Ljc, int mtot, int *upd_cnt, int *diag_cnt, int q0, int *tmo,
                                                bool load_block, bool publish, double *ds, int *npub, bool raw_in_lds = false, int pub_skip = 0,
-                                               const double *lbs_pre = nullptr, const FrontDesc *fd = nullptr,
-                                               int *owed_a = nullptr, int *owed_b = nullptr) {
+                                               const double *lbs_pre = nullptr, int *owed_a = nullptr, int *owed_b = nullptr) {
   // owed_a / owed_b (k_ldl_front): counters the workgroup owes for write-through stores it issued just before this block (the rows of L of
   // the chain's row solve): counted behind the first sweep, when their acknowledgements have long arrived -- not waited for on the chain
   // lbs_pre (k_ldl_front): the block's pivot thresholds, fetched into LDS when the workgroup started (one global round trip off the chain)
@@ -826,14 +826,14 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
   __shared__ int badflag;
   __shared__ double red_v[LDL_THREADS];
   __shared__ int red_i[LDL_THREADS];
-  const int ns = fd ? fd->ns : tab.ns[s], ms = fd ? fd->ms : tab.ms[s], ld = fd ? fd->ld : tab.ld[s], first = fd ? fd->first : tab.first[s];
-  const int64_t toff_s = fd ? fd->toff : tab.toff[s];
+  const int ns = fd.ns, ms = fd.ms, ld = fd.ld, first = fd.first;
+  const int64_t toff_s = fd.toff;
   const int k0 = panel * NB, kb = min(NB, ns - k0);
-  double *Fs = F + (fd ? fd->foff : tab.foff[s]);
-  double *cb = colbuf + (fd ? fd->woff : tab.woff[s]) + s;        // probe scratch: ms + 1 doubles per front
+  double *Fs = F + fd.foff;
+  double *cb = colbuf + fd.woff + s;                              // probe scratch: ms + 1 doubles per front
   const int tid = threadIdx.x, bs = blockDim.x;
   const int tx = tid & 63, ty = tid >> 6, ny = bs >> 6;
-  const double maxu = fd ? fd->maxu : ubp[1], ub = fd ? fd->ub : ubp[2] / (maxu * maxu);      // ubp[2] = max diagonal (k_prep_pivots)
+  const double maxu = fd.maxu, ub = fd.ub;                          // ub = max diagonal (k_prep_pivots) / maxu^2
   if (load_block) {
     double sv[NB / (LDL_THREADS / 64)];
     const double *pc = Fs + (int64_t)k0 * ld + k0 + min(tx, kb - 1);
@@ -980,10 +980,198 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
   return ok;
 }
 
+#ifdef SDM_EMU
+#define SDM_NOINLINE
+#else
+// (a callable function does not inherit the kernel's launch bounds: the register allocator budgets it for the translation unit's
+// default workgroup size -- 1024 work-items = 128 VGPRs unless the file is compiled with --gpu-max-threads-per-block=512, as
+// sedumi_amd/build.py does for this file; with 128 the roles spill inside although their kernels may use 256)
+#define SDM_NOINLINE __noinline__
+#endif
+#ifndef SDM_NI_ROWS
+#define SDM_NI_ROWS __forceinline__       // (measured: +1 us per launch as a call)
+#endif
+#ifndef SDM_NI_TILES
+#define SDM_NI_TILES __forceinline__      // (the throughput role of big fronts: as a call it saves and reloads 40 callee-saved VGPRs per workgroup, +4 us per launch on MAXCUT-4000)
+#endif
+#ifndef SDM_NI_DUPD
+#define SDM_NI_DUPD SDM_NOINLINE
+#endif
+#ifndef SDM_NI_DBLK
+#define SDM_NI_DBLK SDM_NOINLINE
+#endif
+#ifndef SDM_NI_DROWS
+#define SDM_NI_DROWS SDM_NOINLINE
+#endif
+// The roles of a k_ldl_panel workgroup are REAL function calls (as in k_ldl_front below): inlined into one body they shared one
+// register allocation and the kernel spilled 167 VGPRs (round 2); each role alone fits.
+// ---- row-solve workgroup b of panel `panel` (see k_ldl_panel)
+__device__ SDM_NI_ROWS SDM_NORETURN void panel_role_rows(char *smem, double *Fs, const double *Ds, double *d, int ns, int ms, int ld, int first, int panel, int b,
+                                             int *upd_cnt_s, const int *diag_cnt_s, int phase, int *tmo) {
+  SDM_FP_STRICT;
+  double (*As)[UTP] = (double (*)[UTP])smem;
+  double (*Bs)[UTP] = As + NB;
+  __shared__ double dsh[NB];
+  const int k0c = panel * NB, kbc = min(NB, ns - k0c);
+  const int kp = (panel - 1) * NB;
+  const bool mfma_rows = ms - min(NB, ns) >= MFMA_MIN_ROWS;
+  if (phase != 2 && panel > 0) {
+    if (mfma_rows)                                              // the result doubles as the row solve's wave tiles in LDS
+      update_tile<LDL_THREADS / 64, false, true, true>(Fs, ld, ms, first, kp, NB, b + 1, 0, d, As, Bs, dsh, nullptr, nullptr, kbc,
+                                                        threadIdx.x, true, (double *)smem + NB * (NB + 1));
+    else
+      update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, kp, NB, b + 1, 0, d, As, Bs, dsh);
+    SDM_STORES_DONE();
+    __syncthreads();
+    if (threadIdx.x == 0) sdm_signal_add(upd_cnt_s);
+  }
+  if (phase == 1) SDM_ENDPGM();
+  double (*S)[NB + 1] = (double (*)[NB + 1])smem;
+  double *RB = (double *)smem + NB * (NB + 1);
+  __shared__ double dsr[NB];
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = blockDim.x >> 6;
+  const int rbeg = k0c + NB * (b + 1), rend = min(ms, k0c + NB * (b + 2));      // = tile row b+1
+  if (!mfma_rows) {
+    // few rows: the faithful substitution needs the whole block
+    spin_until(diag_cnt_s, 4 * (panel + 1), tmo);                  // (with the fence: panel_rows re-reads this workgroup's own updated rows)
+    constexpr int NQ = NB / (LDL_THREADS / 64);
+    double sv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) sv[q] = sdm_load_wt(&Ds[min(ty + ny * q, NB - 1) * NB + tx]);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) { const int i = ty + ny * q; if (i < NB) S[i][tx] = (i < kbc && tx < i) ? sv[q] : 0.0; }
+    if (tid < NB) dsr[tid] = tid < kbc ? sdm_load_wt(&d[first + k0c + tid]) : 0.0;
+    __syncthreads();
+    panel_rows(Fs, ld, ns, ms, k0c, kbc, rbeg, rend, ROWS_BATCH, S, dsr, RB);
+    SDM_ENDPGM();
+  }
+  // blocked substitution, 16 rows per wavefront (4 of the 8 are busy), following the diagonal block as workgroup 0
+  // publishes it 16 columns at a time
+  const int R0 = rbeg + 16 * ty;
+  const bool busy = R0 < rend;
+  double *Tw = RB + ty * (NB * 17);
+  if (!(phase == 0 && panel > 0) && busy) rows_stage(Fs, ld, rend, k0c, kbc, R0, Tw, tx);      // else staged by the update above
+  for (int blk = 0; blk < NB / 16 && 16 * blk < kbc; blk++) {
+    if (busy) rows_block_gemm(blk, S, Tw, tx);                   // needs earlier columns only: off the tail of the launch
+    spin_until(diag_cnt_s, 4 * panel + blk + 1, tmo, false);       // columns 16 blk .. of L11 and their pivots are in DT / d (sc1 loads: no fence)
+    for (int e = tid; e < NB * 16; e += LDL_THREADS) {
+      const int i = e >> 4, j = 16 * blk + (e & 15);
+      S[i][j] = (i < kbc && j < i) ? sdm_load_wt(&Ds[i * NB + j]) : 0.0;
+    }
+    if (tid < 16) dsr[16 * blk + tid] = 16 * blk + tid < kbc ? sdm_load_wt(&d[first + k0c + 16 * blk + tid]) : 0.0;
+    __syncthreads();
+    if (busy) rows_block_tri(blk, S, dsr, Tw, tx);
+  }
+  if (busy) rows_store(Fs, ld, rend, k0c, kbc, R0, dsr, Tw, tx);
+  SDM_ENDPGM();                                                  // (the kernel has nothing left to do for this workgroup)
+}
+// ---- tile workgroup w: two tiles of the previous panel's update side by side, 4 wavefronts each
+__device__ SDM_NI_TILES void panel_role_tiles(char *smem, double *Fs, const double *d, int ms, int ld, int first, int panel, int w, int nrw, int nt,
+                                              int *upd_cnt_s) {
+  SDM_FP_STRICT;
+  double (*As)[UTP] = (double (*)[UTP])smem;
+  double (*Bs)[UTP] = As + NB;
+  const int kp = (panel - 1) * NB;
+  const int half = threadIdx.x >> 8, u = 2 * w + half;
+  int I, J, ntl;
+  bool active;
+  if (nrw > 0) {                                               // block column 0 belongs to the row-solve workgroups
+    ntl = (nt - 1) * nt / 2;
+    if (2 * w >= ntl) SDM_ENDPGM();
+    active = u < ntl;
+    tile_index(active ? u : 0, I, J);
+    I++; J++;
+  } else {
+    ntl = nt * (nt + 1) / 2 - 1;                               // all tiles but (0,0)
+    if (2 * w >= ntl) SDM_ENDPGM();
+    active = u < ntl;
+    tile_index(active ? u + 1 : 1, I, J);
+  }
+  __shared__ double dsh2[2][NB];
+  update_tile<4, false, true>(Fs, ld, ms, first, kp, NB, I, J, d, As + half * 2 * NB, Bs + half * 2 * NB, dsh2[half],
+                              nullptr, nullptr, 0, (int)threadIdx.x & 255, active);
+  if (nrw == 0) {                                              // readers in this launch: workgroup 0's row solve / probe
+    SDM_STORES_DONE();
+    __syncthreads();
+    if (threadIdx.x == 0) sdm_signal_add(upd_cnt_s);
+  }
+  SDM_ENDPGM();
+}
+// ---- workgroup 0, first piece: tile (0,0) of the previous update = this panel's diagonal block, straight into S
+__device__ SDM_NI_DUPD void panel_diag_update(char *smem, double *Fs, const double *d, int ms, int ld, int first, int panel, int kbc) {
+  SDM_FP_STRICT;
+  double (*As)[UTP] = (double (*)[UTP])smem;
+  double (*Bs)[UTP] = As + NB;
+  __shared__ double dsh[NB];
+  update_tile<LDL_THREADS / 64, true>(Fs, ld, ms, first, (panel - 1) * NB, NB, 0, 0, d, As, Bs, dsh,
+                                      (double (*)[NB + 1])smem, (double *)smem + NB * (NB + 1), kbc);
+}
+// ---- workgroup 0, second piece: the LDL' of the block
+__device__ SDM_NI_DBLK bool panel_diag_block(char *smem, double *F, double *DT, FrontDesc fd, int s, int panel, double *d, double *lb,
+                                              int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src, const int64_t *Ljc,
+                                              int mtot, int *upd_cnt, int *diag_cnt, int q0, int *tmo, bool load_block, bool publish, double *ds, int *npub) {
+  return ldl_diag_block<false>(smem, F, DT, fd, s, panel, d, lb, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_cnt, diag_cnt, q0, tmo,
+                               load_block, publish, ds, npub);
+}
+// ---- workgroup 0, last piece: rows of its own tile row that are left to it
+__device__ SDM_NI_DROWS void panel_diag_rows(char *smem, double *Fs, int ld, int ns, int ms, int k0, int kb, int rbeg, int rend, const double *ds) {
+  panel_rows(Fs, ld, ns, ms, k0, kb, rbeg, rend, TRSM_ROWS, (const double (*)[NB + 1])smem, ds, (double *)smem + NB * (NB + 1));
+}
+
+#ifndef SDM_NI_DIAG
+#define SDM_NI_DIAG SDM_NOINLINE
+#endif
+// ---- workgroup 0: its tile of the previous update, the LDL' of the block, the rows left to it, the counts
+__device__ SDM_NI_DIAG SDM_NORETURN void panel_role_diag(char *smem, double *F, double *DT, FrontDesc fd, int s, int panel, double *d,
+                                                         const PanelCtx *ctx, int *upd_cnt, int *diag_cnt, int q0, int *tmo) {
+  // (uniform loads: one scalar round trip, issued before the tile of the previous update is fetched)
+  double *lb = ctx->lb; int *pivstat = ctx->pivstat; double *pivval = ctx->pivval; double *colbuf = ctx->colbuf;
+  const double *ada = ctx->ada; const int *asm_src = ctx->asm_src; const int64_t *Ljc = ctx->Ljc; const int mtot = ctx->mtot;
+  {
+    const double *ubp = ctx->ubp;
+    fd.maxu = ubp[1]; fd.ub = ubp[2] / (fd.maxu * fd.maxu);
+  }
+  const int ns = fd.ns, ms = fd.ms, ld = fd.ld, first = fd.first;
+  double *Fs = F + fd.foff;
+  const int k0 = panel * NB, kb = min(NB, ns - k0);
+  const int r0 = k0 + kb, nrows = ms - r0;
+  if (panel > 0) panel_diag_update(smem, Fs, d, ms, ld, first, panel, kb);
+  __shared__ double ds[NB];
+  __shared__ int npub;
+  const int tid = threadIdx.x;
+  const bool ok = panel_diag_block(smem, F, DT, fd, s, panel, d, lb, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_cnt, diag_cnt,
+                                   q0, tmo, panel == 0, nrows > TRSM_ROWS, ds, &npub);
+  SDM_PHASE_BEGIN();
+  if (nrows > TRSM_ROWS) {                                         // the row-solve workgroups of this launch are waiting
+    if (16 * npub < kb) SDM_STORES_DONE();                         // (uniform) something of the block is still unpublished
+    __syncthreads();
+    if (tid == 0) sdm_signal_add(&diag_cnt[s], 4 - npub);          // 4 counts per panel: one per 16 columns of the block
+    // a partial block (kb < 64, last panel of the supernode) leaves rows r0 .. k0+63 in this workgroup's own tile row:
+    // they were updated by its tile (0,0) and are solved here (the row-solve workgroups own whole tile rows)
+    if (kb < NB) {
+      SDM_ACQUIRE_FENCE();                                       // its own tile-(0,0) stores, not a cached copy from before them
+      panel_diag_rows(smem, Fs, ld, ns, ms, k0, kb, r0, k0 + NB, ds);
+    }
+  }
+  SDM_PHASE(22);
+  if (nrows > 0 && nrows <= TRSM_ROWS) {
+    if (panel > 0 && ok) wait_prev_update(upd_cnt + s, ns, ms, panel, q0, tmo);
+    panel_diag_rows(smem, Fs, ld, ns, ms, k0, kb, r0, ms, ds);
+  }
+  if (nrows <= TRSM_ROWS) {
+    // nobody in this launch waits for this block: the count (= 4 x panels done) goes up at the very end, behind the
+    // same stores-acknowledged / barrier sequence as every other publication
+    SDM_STORES_DONE();
+    __syncthreads();
+    if (tid == 0) sdm_signal_add(&diag_cnt[s], 4);
+  }
+  SDM_PHASE(23);
+  SDM_ENDPGM();
+}
+
 __global__ void __launch_bounds__(LDL_THREADS)
-k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, double *d, double *lb, const double *ubp,
-            int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src,
-            const int64_t *Ljc, int mtot, int *upd_cnt, int *diag_cnt, int q0, int phase, int *tmo) {
+k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, double *d, const PanelCtx *ctx,
+            int *upd_cnt, int *diag_cnt, int q0, int phase, int *tmo) {
   SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
   SDM_DYN_SMEM(smem);
   // ONE launch per 64-column panel p.  grid = (workgroups, fronts); per front:
@@ -997,161 +1185,45 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   // All of this hides behind workgroup 0's dependency chain.  The emulator runs workgroups one after the other:
   // phase 1 (everything but the substitution, diagonal block last) and phase 2 (the substitution) are two launches
   // there; the GPU runs phase 0 = both.
-  {
-    const int s = list[blockIdx.y];
-    const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
-    const int k0c = panel * NB, kbc = min(NB, ns - k0c), nrowsc = ms - (k0c + kbc);
-    const int nrw = nrowsc > TRSM_ROWS ? (ms - (k0c + NB) + ROWS_BATCH - 1) / ROWS_BATCH : 0;   // tile rows below the first
-    const int kp = (panel - 1) * NB;                               // previous panel (full when there is a panel p)
-    const int nt = panel > 0 ? (ms - (kp + NB) + TILE - 1) / TILE : 0;
-    // Roles by "logical" index bx: 0 = diagonal block, 1..nrw = row solves, beyond = update tiles.  The hardware hands
-    // out workgroups in launch order, and a workgroup that waits must wait for one handed out BEFORE it (or for one
-    // that does not wait before it signals), else a full device of waiting workgroups could keep the awaited one out:
-    //   fronts with row-solve workgroups:  diagonal block < row solves (wait for it) < tiles (nobody waits for them);
-    //   small fronts:                      tiles (never wait) < diagonal block (its in-workgroup row solve waits for them).
-    // The emulator runs them one after the other in the order  tiles, row solves (phase 1: their update tile only),
-    // diagonal block.
-#ifdef SDM_EMU
-    const int bx = (int)gridDim.x - 1 - (int)blockIdx.x;
-#else
-    int bx = blockIdx.x;
-    if (nrw == 0) {
-      const int ntw = panel > 0 ? (nt * (nt + 1) / 2) / 2 : 0;
-      if (bx > ntw) return;
-      bx = bx < ntw ? 1 + bx : 0;
-    }
-#endif
-    double (*As)[UTP] = (double (*)[UTP])smem;
-    double (*Bs)[UTP] = As + NB;
-    __shared__ double dsh[NB];
-    if (bx > 0 && bx <= nrw) {
-      // ---- row-solve workgroup b
-      const int b = bx - 1;
-      double *Fs = F + tab.foff[s];
-      const bool mfma_rows = ms - min(NB, ns) >= MFMA_MIN_ROWS;
-      if (phase != 2 && panel > 0) {
-        if (mfma_rows)                                              // the result doubles as the row solve's wave tiles in LDS
-          update_tile<LDL_THREADS / 64, false, true, true>(Fs, ld, ms, first, kp, NB, b + 1, 0, d, As, Bs, dsh, nullptr, nullptr, kbc,
-                                                            threadIdx.x, true, (double *)smem + NB * (NB + 1));
-        else
-          update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, kp, NB, b + 1, 0, d, As, Bs, dsh);
-        SDM_STORES_DONE();
-        __syncthreads();
-        if (threadIdx.x == 0) sdm_signal_add(&upd_cnt[s]);
-      }
-      if (phase == 1) return;
-      double (*S)[NB + 1] = (double (*)[NB + 1])smem;
-      double *RB = (double *)smem + NB * (NB + 1);
-      __shared__ double dsr[NB];
-      const double *Ds = DT + tab.toff[s] + (int64_t)panel * NB * NB;    // Ds[i*NB + j] = L(k0+i, k0+j)
-      const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = blockDim.x >> 6;
-      const int rbeg = k0c + NB * (b + 1), rend = min(ms, k0c + NB * (b + 2));      // = tile row b+1
-      if (!mfma_rows) {
-        // few rows: the faithful substitution needs the whole block
-        spin_until(diag_cnt + s, 4 * (panel + 1), tmo);                // (with the fence: panel_rows re-reads this workgroup's own updated rows)
-        constexpr int NQ = NB / (LDL_THREADS / 64);
-        double sv[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; q++) sv[q] = sdm_load_wt(&Ds[min(ty + ny * q, NB - 1) * NB + tx]);
-#pragma unroll
-        for (int q = 0; q < NQ; q++) { const int i = ty + ny * q; if (i < NB) S[i][tx] = (i < kbc && tx < i) ? sv[q] : 0.0; }
-        if (tid < NB) dsr[tid] = tid < kbc ? sdm_load_wt(&d[first + k0c + tid]) : 0.0;
-        __syncthreads();
-        panel_rows(Fs, ld, ns, ms, k0c, kbc, rbeg, rend, ROWS_BATCH, S, dsr, RB);
-        return;
-      }
-      // blocked substitution, 16 rows per wavefront (4 of the 8 are busy), following the diagonal block as workgroup 0
-      // publishes it 16 columns at a time
-      const int R0 = rbeg + 16 * ty;
-      const bool busy = R0 < rend;
-      double *Tw = RB + ty * (NB * 17);
-      if (!(phase == 0 && panel > 0) && busy) rows_stage(Fs, ld, rend, k0c, kbc, R0, Tw, tx);      // else staged by the update above
-      for (int blk = 0; blk < NB / 16 && 16 * blk < kbc; blk++) {
-        if (busy) rows_block_gemm(blk, S, Tw, tx);                   // needs earlier columns only: off the tail of the launch
-        spin_until(diag_cnt + s, 4 * panel + blk + 1, tmo, false);     // columns 16 blk .. of L11 and their pivots are in DT / d (sc1 loads: no fence)
-        for (int e = tid; e < NB * 16; e += LDL_THREADS) {
-          const int i = e >> 4, j = 16 * blk + (e & 15);
-          S[i][j] = (i < kbc && j < i) ? sdm_load_wt(&Ds[i * NB + j]) : 0.0;
-        }
-        if (tid < 16) dsr[16 * blk + tid] = 16 * blk + tid < kbc ? sdm_load_wt(&d[first + k0c + 16 * blk + tid]) : 0.0;
-        __syncthreads();
-        if (busy) rows_block_tri(blk, S, dsr, Tw, tx);
-      }
-      if (busy) rows_store(Fs, ld, rend, k0c, kbc, R0, dsr, Tw, tx);
-      return;
-    }
-    if (bx > nrw) {
-      // ---- tile workgroup: two tiles side by side, 4 wavefronts each (the stand-alone kernel's shape)
-      if (phase == 2 || panel == 0) return;
-      const int w = bx - 1 - nrw, half = threadIdx.x >> 8, u = 2 * w + half;
-      int I, J, ntl;
-      bool active;
-      if (nrw > 0) {                                               // block column 0 belongs to the row-solve workgroups
-        ntl = (nt - 1) * nt / 2;
-        if (2 * w >= ntl) return;
-        active = u < ntl;
-        tile_index(active ? u : 0, I, J);
-        I++; J++;
-      } else {
-        ntl = nt * (nt + 1) / 2 - 1;                               // all tiles but (0,0)
-        if (2 * w >= ntl) return;
-        active = u < ntl;
-        tile_index(active ? u + 1 : 1, I, J);
-      }
-      __shared__ double dsh2[2][NB];
-      update_tile<4, false, true>(F + tab.foff[s], ld, ms, first, kp, NB, I, J, d, As + half * 2 * NB, Bs + half * 2 * NB, dsh2[half],
-                                  nullptr, nullptr, 0, (int)threadIdx.x & 255, active);
-      if (nrw == 0) {                                              // readers in this launch: workgroup 0's row solve / probe
-        SDM_STORES_DONE();
-        __syncthreads();
-        if (threadIdx.x == 0) sdm_signal_add(&upd_cnt[s]);
-      }
-      return;
-    }
-    // ---- workgroup 0
-    if (phase == 2) return;
-    if (panel > 0)
-      // tile (0,0) = this panel's diagonal block (and what lies right of / below it inside the tile): straight into S
-      update_tile<LDL_THREADS / 64, true>(F + tab.foff[s], ld, ms, first, kp, NB, 0, 0, d, As, Bs, dsh,
-                                          (double (*)[NB + 1])smem, (double *)smem + NB * (NB + 1), kbc);
-  }
-  double (*S)[NB + 1] = (double (*)[NB + 1])smem;                 // diagonal block, S[row][col]
-  double *RB = (double *)smem + NB * (NB + 1);                    // Xs / the wave tiles of the row solve
-  __shared__ double ds[NB];
-  __shared__ int npub;
   const int s = list[blockIdx.y];
-  const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s];
+  const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
+  double *Fs = F + tab.foff[s];
   const int k0 = panel * NB, kb = min(NB, ns - k0);
   const int r0 = k0 + kb, nrows = ms - r0;
-  double *Fs = F + tab.foff[s];
-  const int tid = threadIdx.x;
-  const bool ok = ldl_diag_block<false>(smem, F, DT, tab, s, panel, d, lb, ubp, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_cnt, diag_cnt,
-                                        q0, tmo, panel == 0, nrows > TRSM_ROWS, ds, &npub);
-  SDM_PHASE_BEGIN();
-  if (nrows > TRSM_ROWS) {                                         // the row-solve workgroups of this launch are waiting
-    if (16 * npub < kb) SDM_STORES_DONE();                         // (uniform) something of the block is still unpublished
-    __syncthreads();
-    if (tid == 0) sdm_signal_add(&diag_cnt[s], 4 - npub);          // 4 counts per panel: one per 16 columns of the block
-    // a partial block (kb < 64, last panel of the supernode) leaves rows r0 .. k0+63 in this workgroup's own tile row:
-    // they were updated by its tile (0,0) and are solved here (the row-solve workgroups own whole tile rows)
-    if (kb < NB) {
-      SDM_ACQUIRE_FENCE();                                       // its own tile-(0,0) stores, not a cached copy from before them
-      panel_rows(Fs, ld, ns, ms, k0, kb, r0, k0 + NB, TRSM_ROWS, S, ds, RB);
-    }
+  const int nrw = nrows > TRSM_ROWS ? (ms - (k0 + NB) + ROWS_BATCH - 1) / ROWS_BATCH : 0;   // tile rows below the first
+  const int nt = panel > 0 ? (ms - k0 + TILE - 1) / TILE : 0;    // tile rows of the previous panel's update
+  // Roles by "logical" index bx: 0 = diagonal block, 1..nrw = row solves, beyond = update tiles.  The hardware hands
+  // out workgroups in launch order, and a workgroup that waits must wait for one handed out BEFORE it (or for one
+  // that does not wait before it signals), else a full device of waiting workgroups could keep the awaited one out:
+  //   fronts with row-solve workgroups:  diagonal block < row solves (wait for it) < tiles (nobody waits for them);
+  //   small fronts:                      tiles (never wait) < diagonal block (its in-workgroup row solve waits for them).
+  // The emulator runs them one after the other in the order  tiles, row solves (phase 1: their update tile only),
+  // diagonal block.
+#ifdef SDM_EMU
+  const int bx = (int)gridDim.x - 1 - (int)blockIdx.x;
+#else
+  int bx = blockIdx.x;
+  if (nrw == 0) {
+    const int ntw = panel > 0 ? (nt * (nt + 1) / 2) / 2 : 0;
+    if (bx > ntw) return;
+    bx = bx < ntw ? 1 + bx : 0;
   }
-  SDM_PHASE(22);
-  if (nrows > 0 && nrows <= TRSM_ROWS) {
-    if (panel > 0 && ok) wait_prev_update(upd_cnt + s, ns, ms, panel, q0, tmo);
-    panel_rows(Fs, ld, ns, ms, k0, kb, r0, ms, TRSM_ROWS, S, ds, RB);
+#endif
+  if (bx > 0 && bx <= nrw) {
+    panel_role_rows(smem, Fs, DT + tab.toff[s] + (int64_t)panel * NB * NB, d, ns, ms, ld, first, panel, bx - 1, upd_cnt + s, diag_cnt + s, phase, tmo);
+    return;
   }
-  if (nrows <= TRSM_ROWS) {
-    // nobody in this launch waits for this block: the count (= 4 x panels done) goes up at the very end, behind the
-    // same stores-acknowledged / barrier sequence as every other publication
-    SDM_STORES_DONE();
-    __syncthreads();
-    if (tid == 0) sdm_signal_add(&diag_cnt[s], 4);
+  if (bx > nrw) {
+    if (phase == 2 || panel == 0) return;
+    panel_role_tiles(smem, Fs, d, ms, ld, first, panel, bx - 1 - nrw, nrw, nt, upd_cnt + s);
+    return;
   }
-  SDM_PHASE(23);
+  // ---- workgroup 0
+  if (phase == 2) return;
+  FrontDesc fd;
+  fd.ns = ns; fd.ms = ms; fd.ld = ld; fd.first = first; fd.foff = tab.foff[s]; fd.toff = tab.toff[s]; fd.woff = tab.woff[s];
+  fd.maxu = 0.0; fd.ub = 0.0;                                       // (filled in by the role: behind ctx)
+  panel_role_diag(smem, F, DT, fd, s, panel, d, ctx, upd_cnt, diag_cnt, q0, tmo);
 }
 
 // ---- hand-over of a factored diagonal block to the workgroups of k_ldl_front that solve rows against it: DATA-TAGGED.  The
@@ -1203,17 +1275,12 @@ __device__ __forceinline__ void diag_group_fetch(const double *Ds, int blk, int 
 // into one body they share 256 VGPRs with the sweep code of the diagonal block and spill inside the store loops -- and a
 // scratch reload between two write-through stores waits for the first one's acknowledgement (vmcnt counts in order):
 // every stored tile then costs eight memory round trips instead of one.
-#ifdef SDM_EMU
-#define SDM_NOINLINE
-#else
-#define SDM_NOINLINE __noinline__
-#endif
-__device__ SDM_NOINLINE bool front_diag(char *smem, double *F, double *DT, const FrontTab &tab, int s, int panel, double *d, double *lb, const double *ubp,
+__device__ SDM_NOINLINE bool front_diag(char *smem, double *F, double *DT, int s, int panel, double *d, double *lb,
                                         int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src, const int64_t *Ljc,
                                         int mtot, int *upd_done, int *diag_cnt, int *tmo, bool load_block, bool publish, double *ds, int *npub,
                                         bool raw_in_lds, const double *lbs_pre, FrontDesc fd, int *owed_a, int *owed_b) {
-  return ldl_diag_block<true>(smem, F, DT, tab, s, panel, d, lb, ubp, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, 0, tmo,
-                              load_block, publish, ds, npub, raw_in_lds, 0, lbs_pre, &fd, owed_a, owed_b);
+  return ldl_diag_block<true>(smem, F, DT, fd, s, panel, d, lb, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, 0, tmo,
+                              load_block, publish, ds, npub, raw_in_lds, 0, lbs_pre, owed_a, owed_b);
 }
 // kind 0: plain (result to the front only), 2: also the wave tiles of the next row solve (RB)
 __device__ SDM_NOINLINE void front_update(int kind, double *Fs, int ld, int ms, int first, int k0, int I, int J, const double *d, char *smem,
@@ -1382,7 +1449,7 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
     if (q == r) {
       if (phase == 0 || phase == 1) {
         const int nrows = ms - (k0 + kb);
-        front_diag(smem, F, DT, tab, s, q, d, lb, ubp, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, tmo,
+        front_diag(smem, F, DT, s, q, d, lb, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, tmo,
                    !have_S, nrows > 0, ds, &npub, raw_in_lds, carry ? lbs_pre : nullptr, fd, owed ? &row_cnt[r] : nullptr, owed ? &upd_done[r] : nullptr);
         if (nrows > 0) {
           if (16 * npub < kb) SDM_STORES_DONE();
@@ -1540,6 +1607,16 @@ void chol_begin(sdm_plan *P, const double canceltol, const double maxu, const do
              P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, (int)C.nsuper, C.upd_cnt.p, C.diag_cnt.p,
              C.sb_g.p, (int)C.sb_g.n, C.front_cnt.p, (int)C.front_cnt.n, (unsigned long long *)C.frontsT.p, ndt);
   C.pars_canceltol = canceltol; C.pars_maxu = maxu; C.pars_abstol = abstol; C.pars_use_absd = use_absd;
+  {
+    PanelCtx c = {};
+    c.lb = C.lb.p; c.ubp = C.ub.p; c.pivstat = C.pivstat.p; c.pivval = C.pivval.p; c.colbuf = C.colbuf.p; c.ada = P->ada_val.p;
+    c.asm_src = C.d_asm_src.p; c.Ljc = C.d_Ljc.p; c.mtot = m;
+    if (!C.panel_ctx.p || memcmp(&c, &C.panel_ctx_host, sizeof(c)) != 0) {
+      if (!C.panel_ctx.p) C.panel_ctx.alloc(1);
+      C.panel_ctx_host = c;
+      SDM_HIP_CHECK(hipMemcpyAsync(C.panel_ctx.p, &C.panel_ctx_host, sizeof(c), hipMemcpyHostToDevice, st));
+    }
+  }
   SDM_HIP_CHECK(hipGetLastError());
 }
 // levels l0 .. l1-1: children's update matrices into the fronts of the level (extend-add), then -- unless extend_only -- its LDL'
@@ -1604,8 +1681,7 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
       const int phase = 0;
 #endif
         SDM_KLAUNCH(P, k_ldl_panel, dim3(1 + L.ride_wgs, L.nactive), dim3(LDL_THREADS), PANEL_LDS_RIDE, C.fronts.p, C.frontsT.p, tab, list,
-                    L.panel, C.d.p, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p,
-                    C.d_Ljc.p, m, C.upd_cnt.p, C.diag_cnt.p, 1, phase, C.tmo.dev());
+                    L.panel, C.d.p, C.panel_ctx.p, C.upd_cnt.p, C.diag_cnt.p, 1, phase, C.tmo.dev());
       if (L.lasttiles > 0)                                           // supernodes that end with this panel and have rows beyond
         SDM_KLAUNCH(P, k_ldl_update, dim3(L.lasttiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p, 1);
     }

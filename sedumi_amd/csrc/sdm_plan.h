@@ -75,6 +75,14 @@ struct DevBuf {
   }
 };
 
+// Arguments of k_ldl_panel that only its diagonal-block role reads (pivot thresholds and report, the never-fail rule's probe inputs):
+// kept in device memory behind one pointer -- as sixteen more scalar kernel arguments they were live across the whole kernel and the
+// register allocator parked them in a VGPR's lanes (sgpr spills, and a VGPR spill around the role's call)
+struct PanelCtx {
+  double *lb; const double *ubp; int *pivstat; double *pivval; double *colbuf; const double *ada; const int *asm_src; const int64_t *Ljc;
+  int mtot, pad;
+};
+
 // one int in pinned host memory that kernels of a plan can raise (rare error reports: no copy, no symbol lookup;
 // the host reads it after a stream synchronise)
 struct HostFlag {
@@ -166,6 +174,8 @@ struct CholPlan {
   std::vector<int> lev_maxT;       // its grid: tile rows of the tallest front ...
   std::vector<int> lev_ntw;        // ... plus this many tile workgroups per front
   DevBuf<int> upd_cnt;     // per front: finished tile workgroups of the updates that rode along with k_ldl_panel
+  DevBuf<PanelCtx> panel_ctx;   // what only workgroup 0 of k_ldl_panel needs, behind ONE kernel argument (uploaded when it changes)
+  PanelCtx panel_ctx_host = {};
   HostFlag tmo;            // raised by a spin inside a panel launch of THIS plan that gave up (chol_wait_timeouts)
   // ---- solves (sdm_solve.hip): per front and super-block of sbw columns one nb x nb array in the arena S = the explicit
   // inverse of that diagonal block of L (block P of front s at sn_soff[s] + P * sbw * sn_sld[s], leading dimension sn_sld[s])

@@ -133,6 +133,18 @@ static __device__ long long sdm_trace_buf[2048];
 #define SDM_LPHASE_BEGIN() do {} while (0)
 #define SDM_LPHASE(n) do {} while (0)
 #define SDM_LPHASE_END() do {} while (0)
+
+#endif
+
+// End the wavefront from inside a device function whose caller has nothing left to do (the roles of k_ldl_panel): the function's
+// epilogue -- reloading the callee-saved registers its prologue parked in scratch, then the return -- is dead code that way.
+// SDM_NORETURN marks such a function for its callers: nothing of theirs has to survive the call.
+#ifdef SDM_EMU
+#define SDM_ENDPGM() return
+#define SDM_NORETURN
+#else
+#define SDM_ENDPGM() __builtin_amdgcn_endpgm()
+#define SDM_NORETURN __attribute__((noreturn))
 #endif
 
 #include <cstdint>

@@ -69,9 +69,10 @@ def test_panel_launch_publishes_only_after_its_stores_are_acknowledged(hiplib, t
         if "gfx950" not in f:
             continue
         dis = subprocess.run([objdump, "-d", str(tmp_path / f)], capture_output=True, text=True).stdout
-        m = re.search(r"^[0-9a-f]+ <[^>]*k_ldl_panel[^>]*>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)", dis, flags=re.S | re.M)
-        if m:
-            body = m.group(1).split("\n")
+        # the kernel and the device functions its workgroup roles live in (panel_role_diag is a real call)
+        parts = re.findall(r"^[0-9a-f]+ <[^>]*(?:k_ldl_panel|panel_role_|panel_diag_)[^>]*>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)", dis, flags=re.S | re.M)
+        if parts:
+            body = [l for part in parts for l in part.split("\n") + ["<function boundary>"]]
             break
     assert body, "k_ldl_panel not found in the gfx950 code objects"
     signals = [i for i, l in enumerate(body) if re.search(r"\bglobal_atomic_add\b", l)]
@@ -81,8 +82,8 @@ def test_panel_launch_publishes_only_after_its_stores_are_acknowledged(hiplib, t
         j, waited = i - 1, False
         while j >= 0 and not re.search(r"\bglobal_store\w* .*\bsc1\b", body[j]):
             waited = waited or "s_waitcnt vmcnt(0)" in body[j]
-            if re.search(r"\bglobal_atomic_add\b", body[j]):
-                j = -1                      # an earlier signal lies in between: nothing new to publish here
+            if re.search(r"\bglobal_atomic_add\b", body[j]) or body[j] == "<function boundary>":
+                j = -1                      # an earlier signal (or another function) lies in between: nothing new to publish here
                 break
             j -= 1
         if j >= 0:
@@ -111,3 +112,22 @@ def test_no_device_is_an_error_not_a_fallback(hiplib):
     capi.use_library(None)
     with pytest.raises(capi.SdmError):
         Plan(0)
+
+
+def test_no_kernel_spills_vector_registers(hiplib):
+    """Code-object metadata of every gfx950 kernel in the library (llvm-readelf --notes on the embedded code objects,
+    tools/code_objects.py): no kernel spills VGPRs.  k_ldl_panel did (167, round 2) until its workgroup roles became
+    separate register allocations; the two factor kernels keep a few hundred bytes of scratch for the argument blocks and
+    return addresses of those calls, everything else has none."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("code_objects", os.path.join(ROOT, "tools", "code_objects.py"))
+    co = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(co)
+    if not os.path.exists(co.READELF):
+        pytest.skip("llvm-readelf not found")
+    ks = co.kernels(hiplib)
+    assert len(ks) >= 40 and any("k_ldl_front" in k for k in ks) and any("k_sfw_diag" in k for k in ks)
+    spilling = {k: v["vgpr_spill_count"] for k, v in ks.items() if v["vgpr_spill_count"]}
+    assert not spilling, f"kernels that spill vector registers: {spilling}"
+    scratch = sorted(k for k, v in ks.items() if v["private_segment_fixed_size"])
+    assert all("k_ldl_front" in k or "k_ldl_panel" in k for k in scratch), scratch

@@ -334,9 +334,11 @@ __global__ void k_extend_add(double *F, FrontTab tab, const int *list) {
 // obtained by forward substitution against those columns.  cb = scratch of >= ms+1
 // doubles.
 __device__ __noinline__ double pivot_probe(const double (*S)[NB + 1], const double *Lc, int k, int kb, int k0, int ns,
-                                           int ms, int ld, const double *Fs, const double *ds, double *cb,
+                                           int ms, int ld, SDM_GP(const double) Fs_, const double *ds, SDM_GP(double) cb_,
                                            double next_raw_diag, double *red_v, int *red_i) {
   SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
+  const double *Fs = (const double *)Fs_;
+  double *cb = (double *)cb_;
   const int tid = threadIdx.x, bs = blockDim.x;
   const int len = ms - (k0 + k) - 1;          // entries below the diagonal of this column
   const int nin = kb - k - 1;                 // of which inside the LDS block
@@ -936,7 +938,7 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
         if (ms - (k0 + k) > 1 && xkk < ub) {                         // rare: stability probe of the never-fail rule
           double nraw = 0.0;
           if (k0 + k + 1 >= ns && first + ns < mtot) { int sidx = asm_src[Ljc[first + ns]]; nraw = sidx < 0 ? 0.0 : ada[sidx]; }
-          const double ubk = pivot_probe(S, Lc, k, kb, k0, ns, ms, ld, Fs, ds, cb, nraw, red_v, red_i) / maxu;
+          const double ubk = pivot_probe(S, Lc, k, kb, k0, ns, ms, ld, (SDM_GP(const double))Fs, ds, (SDM_GP(double))cb, nraw, red_v, red_i) / maxu;
           if (xkk < ubk) {
             if (tid == 0) { stt[k] = 2; pv[k] = ubk - xkk; lbs[k] = ubk - xkk; }
             xkk = ubk;
@@ -1098,8 +1100,10 @@ __device__ SDM_NI_TILES void panel_role_tiles(char *smem, double *Fs, const doub
   SDM_ENDPGM();
 }
 // ---- workgroup 0, first piece: tile (0,0) of the previous update = this panel's diagonal block, straight into S
-__device__ SDM_NI_DUPD void panel_diag_update(char *smem, double *Fs, const double *d, int ms, int ld, int first, int panel, int kbc) {
+__device__ SDM_NI_DUPD void panel_diag_update(char *smem, SDM_GP(double) Fs_, SDM_GP(const double) d_, int ms, int ld, int first, int panel, int kbc) {
   SDM_FP_STRICT;
+  double *Fs = (double *)Fs_;
+  const double *d = (const double *)d_;
   double (*As)[UTP] = (double (*)[UTP])smem;
   double (*Bs)[UTP] = As + NB;
   __shared__ double dsh[NB];
@@ -1107,14 +1111,28 @@ __device__ SDM_NI_DUPD void panel_diag_update(char *smem, double *Fs, const doub
                                       (double (*)[NB + 1])smem, (double *)smem + NB * (NB + 1), kbc);
 }
 // ---- workgroup 0, second piece: the LDL' of the block
-__device__ SDM_NI_DBLK bool panel_diag_block(char *smem, double *F, double *DT, FrontDesc fd, int s, int panel, double *d, double *lb,
-                                              int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src, const int64_t *Ljc,
-                                              int mtot, int *upd_cnt, int *diag_cnt, int q0, int *tmo, bool load_block, bool publish, double *ds, int *npub) {
+__device__ SDM_NI_DBLK bool panel_diag_block(char *smem, SDM_GP(double) F_, SDM_GP(double) DT_, FrontDesc fd, int s, int panel, SDM_GP(double) d_, SDM_GP(double) lb_,
+                                              SDM_GP(int) pivstat_, SDM_GP(double) pivval_, SDM_GP(double) colbuf_, SDM_GP(const double) ada_, SDM_GP(const int) asm_src_, SDM_GP(const int64_t) Ljc_,
+                                              int mtot, SDM_GP(int) upd_cnt_, SDM_GP(int) diag_cnt_, int q0, SDM_GP(int) tmo_, bool load_block, bool publish, double *ds, int *npub) {
+  double *F = (double *)F_;
+  double *DT = (double *)DT_;
+  double *d = (double *)d_;
+  double *lb = (double *)lb_;
+  int *pivstat = (int *)pivstat_;
+  double *pivval = (double *)pivval_;
+  double *colbuf = (double *)colbuf_;
+  const double *ada = (const double *)ada_;
+  const int *asm_src = (const int *)asm_src_;
+  const int64_t *Ljc = (const int64_t *)Ljc_;
+  int *upd_cnt = (int *)upd_cnt_;
+  int *diag_cnt = (int *)diag_cnt_;
+  int *tmo = (int *)tmo_;
   return ldl_diag_block<false>(smem, F, DT, fd, s, panel, d, lb, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_cnt, diag_cnt, q0, tmo,
                                load_block, publish, ds, npub);
 }
 // ---- workgroup 0, last piece: rows of its own tile row that are left to it
-__device__ SDM_NI_DROWS void panel_diag_rows(char *smem, double *Fs, int ld, int ns, int ms, int k0, int kb, int rbeg, int rend, const double *ds) {
+__device__ SDM_NI_DROWS void panel_diag_rows(char *smem, SDM_GP(double) Fs_, int ld, int ns, int ms, int k0, int kb, int rbeg, int rend, const double *ds) {
+  double *Fs = (double *)Fs_;
   panel_rows(Fs, ld, ns, ms, k0, kb, rbeg, rend, TRSM_ROWS, (const double (*)[NB + 1])smem, ds, (double *)smem + NB * (NB + 1));
 }
 
@@ -1122,8 +1140,15 @@ __device__ SDM_NI_DROWS void panel_diag_rows(char *smem, double *Fs, int ld, int
 #define SDM_NI_DIAG SDM_NOINLINE
 #endif
 // ---- workgroup 0: its tile of the previous update, the LDL' of the block, the rows left to it, the counts
-__device__ SDM_NI_DIAG SDM_NORETURN void panel_role_diag(char *smem, double *F, double *DT, FrontDesc fd, int s, int panel, double *d,
-                                                         const PanelCtx *ctx, int *upd_cnt, int *diag_cnt, int q0, int *tmo) {
+__device__ SDM_NI_DIAG SDM_NORETURN void panel_role_diag(char *smem, SDM_GP(double) F_, SDM_GP(double) DT_, FrontDesc fd, int s, int panel, SDM_GP(double) d_,
+                                                         SDM_GP(const PanelCtx) ctx_, SDM_GP(int) upd_cnt_, SDM_GP(int) diag_cnt_, int q0, SDM_GP(int) tmo_) {
+  double *F = (double *)F_;
+  double *DT = (double *)DT_;
+  double *d = (double *)d_;
+  const PanelCtx *ctx = (const PanelCtx *)ctx_;
+  int *upd_cnt = (int *)upd_cnt_;
+  int *diag_cnt = (int *)diag_cnt_;
+  int *tmo = (int *)tmo_;
   // (uniform loads: one scalar round trip, issued before the tile of the previous update is fetched)
   double *lb = ctx->lb; int *pivstat = ctx->pivstat; double *pivval = ctx->pivval; double *colbuf = ctx->colbuf;
   const double *ada = ctx->ada; const int *asm_src = ctx->asm_src; const int64_t *Ljc = ctx->Ljc; const int mtot = ctx->mtot;
@@ -1135,12 +1160,13 @@ __device__ SDM_NI_DIAG SDM_NORETURN void panel_role_diag(char *smem, double *F, 
   double *Fs = F + fd.foff;
   const int k0 = panel * NB, kb = min(NB, ns - k0);
   const int r0 = k0 + kb, nrows = ms - r0;
-  if (panel > 0) panel_diag_update(smem, Fs, d, ms, ld, first, panel, kb);
+  if (panel > 0) panel_diag_update(smem, (SDM_GP(double))Fs, (SDM_GP(const double))d, ms, ld, first, panel, kb);
   __shared__ double ds[NB];
   __shared__ int npub;
   const int tid = threadIdx.x;
-  const bool ok = panel_diag_block(smem, F, DT, fd, s, panel, d, lb, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_cnt, diag_cnt,
-                                   q0, tmo, panel == 0, nrows > TRSM_ROWS, ds, &npub);
+  const bool ok = panel_diag_block(smem, (SDM_GP(double))F, (SDM_GP(double))DT, fd, s, panel, (SDM_GP(double))d, (SDM_GP(double))lb, (SDM_GP(int))pivstat, (SDM_GP(double))pivval,
+                                   (SDM_GP(double))colbuf, (SDM_GP(const double))ada, (SDM_GP(const int))asm_src, (SDM_GP(const int64_t))Ljc, mtot, (SDM_GP(int))upd_cnt,
+                                   (SDM_GP(int))diag_cnt, q0, (SDM_GP(int))tmo, panel == 0, nrows > TRSM_ROWS, ds, &npub);
   SDM_PHASE_BEGIN();
   if (nrows > TRSM_ROWS) {                                         // the row-solve workgroups of this launch are waiting
     if (16 * npub < kb) SDM_STORES_DONE();                         // (uniform) something of the block is still unpublished
@@ -1150,13 +1176,13 @@ __device__ SDM_NI_DIAG SDM_NORETURN void panel_role_diag(char *smem, double *F, 
     // they were updated by its tile (0,0) and are solved here (the row-solve workgroups own whole tile rows)
     if (kb < NB) {
       SDM_ACQUIRE_FENCE();                                       // its own tile-(0,0) stores, not a cached copy from before them
-      panel_diag_rows(smem, Fs, ld, ns, ms, k0, kb, r0, k0 + NB, ds);
+      panel_diag_rows(smem, (SDM_GP(double))Fs, ld, ns, ms, k0, kb, r0, k0 + NB, ds);
     }
   }
   SDM_PHASE(22);
   if (nrows > 0 && nrows <= TRSM_ROWS) {
     if (panel > 0 && ok) wait_prev_update(upd_cnt + s, ns, ms, panel, q0, tmo);
-    panel_diag_rows(smem, Fs, ld, ns, ms, k0, kb, r0, ms, ds);
+    panel_diag_rows(smem, (SDM_GP(double))Fs, ld, ns, ms, k0, kb, r0, ms, ds);
   }
   if (nrows <= TRSM_ROWS) {
     // nobody in this launch waits for this block: the count (= 4 x panels done) goes up at the very end, behind the
@@ -1223,7 +1249,8 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   FrontDesc fd;
   fd.ns = ns; fd.ms = ms; fd.ld = ld; fd.first = first; fd.foff = tab.foff[s]; fd.toff = tab.toff[s]; fd.woff = tab.woff[s];
   fd.maxu = 0.0; fd.ub = 0.0;                                       // (filled in by the role: behind ctx)
-  panel_role_diag(smem, F, DT, fd, s, panel, d, ctx, upd_cnt, diag_cnt, q0, tmo);
+  panel_role_diag(smem, (SDM_GP(double))F, (SDM_GP(double))DT, fd, s, panel, (SDM_GP(double))d, (SDM_GP(const PanelCtx))ctx, (SDM_GP(int))upd_cnt, (SDM_GP(int))diag_cnt, q0,
+                  (SDM_GP(int))tmo);
 }
 
 // ---- hand-over of a factored diagonal block to the workgroups of k_ldl_front that solve rows against it: DATA-TAGGED.  The
@@ -1275,16 +1302,33 @@ __device__ __forceinline__ void diag_group_fetch(const double *Ds, int blk, int 
 // into one body they share 256 VGPRs with the sweep code of the diagonal block and spill inside the store loops -- and a
 // scratch reload between two write-through stores waits for the first one's acknowledgement (vmcnt counts in order):
 // every stored tile then costs eight memory round trips instead of one.
-__device__ SDM_NOINLINE bool front_diag(char *smem, double *F, double *DT, int s, int panel, double *d, double *lb,
-                                        int *pivstat, double *pivval, double *colbuf, const double *ada, const int *asm_src, const int64_t *Ljc,
-                                        int mtot, int *upd_done, int *diag_cnt, int *tmo, bool load_block, bool publish, double *ds, int *npub,
-                                        bool raw_in_lds, const double *lbs_pre, FrontDesc fd, int *owed_a, int *owed_b) {
+__device__ SDM_NOINLINE bool front_diag(char *smem, SDM_GP(double) F_, SDM_GP(double) DT_, int s, int panel, SDM_GP(double) d_, SDM_GP(double) lb_,
+                                        SDM_GP(int) pivstat_, SDM_GP(double) pivval_, SDM_GP(double) colbuf_, SDM_GP(const double) ada_, SDM_GP(const int) asm_src_, SDM_GP(const int64_t) Ljc_,
+                                        int mtot, SDM_GP(int) upd_done_, SDM_GP(int) diag_cnt_, SDM_GP(int) tmo_, bool load_block, bool publish, double *ds, int *npub,
+                                        bool raw_in_lds, const double *lbs_pre, FrontDesc fd, SDM_GP(int) owed_a_, SDM_GP(int) owed_b_) {
+  double *F = (double *)F_;
+  double *DT = (double *)DT_;
+  double *d = (double *)d_;
+  double *lb = (double *)lb_;
+  int *pivstat = (int *)pivstat_;
+  double *pivval = (double *)pivval_;
+  double *colbuf = (double *)colbuf_;
+  const double *ada = (const double *)ada_;
+  const int *asm_src = (const int *)asm_src_;
+  const int64_t *Ljc = (const int64_t *)Ljc_;
+  int *upd_done = (int *)upd_done_;
+  int *diag_cnt = (int *)diag_cnt_;
+  int *tmo = (int *)tmo_;
+  int *owed_a = (int *)owed_a_;
+  int *owed_b = (int *)owed_b_;
   return ldl_diag_block<true>(smem, F, DT, fd, s, panel, d, lb, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, 0, tmo,
                               load_block, publish, ds, npub, raw_in_lds, 0, lbs_pre, owed_a, owed_b);
 }
 // kind 0: plain (result to the front only), 2: also the wave tiles of the next row solve (RB)
-__device__ SDM_NOINLINE void front_update(int kind, double *Fs, int ld, int ms, int first, int k0, int I, int J, const double *d, char *smem,
+__device__ SDM_NOINLINE void front_update(int kind, SDM_GP(double) Fs_, int ld, int ms, int first, int k0, int I, int J, SDM_GP(const double) d_, char *smem,
                                           double *dsh, int kbn) {
+  double *Fs = (double *)Fs_;
+  const double *d = (const double *)d_;
   double (*As)[UTP] = (double (*)[UTP])smem;
   double (*Bs)[UTP] = As + NB;
   double *RB = (double *)smem + NB * (NB + 1);
@@ -1292,8 +1336,13 @@ __device__ SDM_NOINLINE void front_update(int kind, double *Fs, int ld, int ms, 
   else update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh);
 }
 // R: rows of tile row r against the diagonal block of panel q as it is published; have_tw: the tile is in the wave tiles already
-__device__ SDM_NOINLINE void front_rows(double *Fs, const double *Ds, const double *d, int ld, int ms, int first, int q, int kb, int r, char *smem,
-                                        double *dsr, const int *diag_cnt_s, int *tmo, bool have_tw, bool defer_ack) {
+__device__ SDM_NOINLINE void front_rows(SDM_GP(double) Fs_, SDM_GP(const double) Ds_, SDM_GP(const double) d_, int ld, int ms, int first, int q, int kb, int r, char *smem,
+                                        double *dsr, SDM_GP(const int) diag_cnt_s_, SDM_GP(int) tmo_, bool have_tw, bool defer_ack) {
+  double *Fs = (double *)Fs_;
+  const double *Ds = (const double *)Ds_;
+  const double *d = (const double *)d_;
+  const int *diag_cnt_s = (const int *)diag_cnt_s_;
+  int *tmo = (int *)tmo_;
   double (*S)[NB + 1] = (double (*)[NB + 1])smem;
   double *RB = (double *)smem + NB * (NB + 1);
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
@@ -1319,8 +1368,13 @@ __device__ SDM_NOINLINE void front_rows(double *Fs, const double *Ds, const doub
 // K = 48 part of the update runs while the last 16 columns of the diagonal block are still being factored; after they
 // arrive only their triangle, 4 of the 16 k-steps and the epilogue are left.  The raw updated block stays in LDS (cvl:
 // the general path of the LDL' reloads it from there); it reaches the front as the factored block.
-__device__ SDM_NOINLINE void front_rows_diag(double *Fs, const double *Ds, const double *d, int ld, int ms, int first, int q, int r, char *smem,
-                                             double *dsr, const int *diag_cnt_s, int *tmo, bool have_tw, int kbn) {
+__device__ SDM_NOINLINE void front_rows_diag(SDM_GP(double) Fs_, SDM_GP(const double) Ds_, SDM_GP(const double) d_, int ld, int ms, int first, int q, int r, char *smem,
+                                             double *dsr, SDM_GP(const int) diag_cnt_s_, SDM_GP(int) tmo_, bool have_tw, int kbn) {
+  double *Fs = (double *)Fs_;
+  const double *Ds = (const double *)Ds_;
+  const double *d = (const double *)d_;
+  const int *diag_cnt_s = (const int *)diag_cnt_s_;
+  int *tmo = (int *)tmo_;
   double (*S)[NB + 1] = (double (*)[NB + 1])smem;
   double *RB = (double *)smem + NB * (NB + 1);
   double *cvl = (double *)smem + FRONT_CV_OFF;
@@ -1427,7 +1481,7 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
         if (q > ct - 2) continue;
         spin_until(row_cnt + rt, q + 1, tmo);
         if (ct < rt) spin_until(row_cnt + ct, q + 1, tmo);
-        front_update(0, Fs, ld, ms, first, q * NB, rt - (q + 1), ct - (q + 1), d, smem, dsh, 0);
+        front_update(0, (SDM_GP(double))Fs, ld, ms, first, q * NB, rt - (q + 1), ct - (q + 1), (SDM_GP(const double))d, smem, dsh, 0);
         SDM_STORES_DONE();
         __syncthreads();
         if (tid == 0) sdm_signal_add(&tile_cnt[rt * FRONT_MAXT + ct]);
@@ -1449,8 +1503,9 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
     if (q == r) {
       if (phase == 0 || phase == 1) {
         const int nrows = ms - (k0 + kb);
-        front_diag(smem, F, DT, s, q, d, lb, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, tmo,
-                   !have_S, nrows > 0, ds, &npub, raw_in_lds, carry ? lbs_pre : nullptr, fd, owed ? &row_cnt[r] : nullptr, owed ? &upd_done[r] : nullptr);
+        front_diag(smem, (SDM_GP(double))F, (SDM_GP(double))DT, s, q, (SDM_GP(double))d, (SDM_GP(double))lb, (SDM_GP(int))pivstat, (SDM_GP(double))pivval, (SDM_GP(double))colbuf, (SDM_GP(const double))ada,
+                   (SDM_GP(const int))asm_src, (SDM_GP(const int64_t))Ljc, mtot, (SDM_GP(int))upd_done, (SDM_GP(int))diag_cnt, (SDM_GP(int))tmo,
+                   !have_S, nrows > 0, ds, &npub, raw_in_lds, carry ? lbs_pre : nullptr, fd, (SDM_GP(int))(owed ? &row_cnt[r] : nullptr), (SDM_GP(int))(owed ? &upd_done[r] : nullptr));
         if (nrows > 0) {
           if (16 * npub < kb) SDM_STORES_DONE();
           __syncthreads();
@@ -1488,9 +1543,11 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
     }
     if (phase == 0 || phase == 2) {
       // ---- R: 16 rows per wavefront (4 of the 8 busy), following the diagonal block as workgroup q publishes it
-      if (crit_lds) front_rows_diag(Fs, DT + tab.toff[s] + (int64_t)q * NB * NB, d, ld, ms, first, q, r, smem, dsr, diag_cnt + s, tmo, have_tw,
+      if (crit_lds) front_rows_diag((SDM_GP(double))Fs, (SDM_GP(const double))(DT + tab.toff[s] + (int64_t)q * NB * NB), (SDM_GP(const double))d, ld, ms, first, q, r, smem, dsr, (SDM_GP(const int))(diag_cnt + s),
+                                    (SDM_GP(int))tmo, have_tw,
                                     min(NB, ns - (q + 1) * NB));
-      else front_rows(Fs, DT + tab.toff[s] + (int64_t)q * NB * NB, d, ld, ms, first, q, kb, r, smem, dsr, diag_cnt + s, tmo, have_tw, false);
+      else front_rows((SDM_GP(double))Fs, (SDM_GP(const double))(DT + tab.toff[s] + (int64_t)q * NB * NB), (SDM_GP(const double))d, ld, ms, first, q, kb, r, smem, dsr, (SDM_GP(const int))(diag_cnt + s),
+                      (SDM_GP(int))tmo, have_tw, false);
       SDM_FPHASE(1);
       have_tw = false;
       if (crit_lds) {
@@ -1520,8 +1577,8 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
         SDM_FPHASE(3);                                                // fence + counters
         const int I = r - c1, J = 0;
         const int kbn = min(NB, ns - c1 * NB);                        // columns of the next panel (<= 0: none)
-        if (c1 < r && carry && c1 < NP) { front_update(2, Fs, ld, ms, first, k0, I, J, d, smem, dsh, kbn); have_tw = true; }
-        else front_update(0, Fs, ld, ms, first, k0, I, J, d, smem, dsh, kbn);
+        if (c1 < r && carry && c1 < NP) { front_update(2, (SDM_GP(double))Fs, ld, ms, first, k0, I, J, (SDM_GP(const double))d, smem, dsh, kbn); have_tw = true; }
+        else front_update(0, (SDM_GP(double))Fs, ld, ms, first, k0, I, J, (SDM_GP(const double))d, smem, dsh, kbn);
       }
       SDM_FPHASE(4);                                                  // the tile update
       SDM_STORES_DONE();

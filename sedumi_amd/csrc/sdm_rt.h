@@ -147,6 +147,18 @@ static __device__ long long sdm_trace_buf[2048];
 #define SDM_NORETURN __attribute__((noreturn))
 #endif
 
+// A pointer that a __noinline__ device function receives as a plain parameter is a GENERIC pointer to the compiler: every access
+// through it becomes a FLAT instruction, and flat instructions count in lgkmcnt as well as vmcnt -- so the next wait for an LDS
+// read also waits for every outstanding global load and for the acknowledgement of every write-through store (microseconds on
+// the chain of the factor kernels).  Such functions therefore take their global-memory pointers as SDM_GP(T) -- address space 1,
+// what kernel arguments are -- and convert them to plain pointers at the top: the address-space inference follows the conversion
+// and the accesses are global_load / global_store / global_atomic again.  Callers cast: (SDM_GP(T))p.
+#ifdef SDM_EMU
+#define SDM_GP(T) T *
+#else
+#define SDM_GP(T) __attribute__((address_space(1))) T *
+#endif
+
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>

@@ -13,12 +13,13 @@ from sedumi_amd.plan import Plan  # noqa: E402
 
 capi.use_library(os.path.join(ROOT, "sedumi_amd", "lib", "libsedumi_hip_phases.so"))
 lib = capi.lib()
-P = problem.control_like(seed=0)
-L, ADA, Q = problem.dense_symbolic(P.m), problem.dense_pattern(P.m), problem.lorentz_pattern(P)
-d, ud = problem.spd_scaling(P.K, seed=5)
+import bench  # noqa: E402
+P, L, ADA, Q, d, ud, rhs0, qpr, note = bench.build_workload(sys.argv[1] if len(sys.argv) > 1 else "control07", 0)
 plan = Plan(0)
 plan.set_chol(L, ADA); plan.set_ada(P.At, P.Ablkjc, P.K, Q)
 plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud)
+if qpr is not None:
+    plan.upload("qpr", qpr)
 for _ in range(3):
     plan.getada()
 plan.sync()

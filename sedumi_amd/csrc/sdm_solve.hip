@@ -696,18 +696,20 @@ k_sinv_follow(const double *F, const double *DT, double *S, double *STr, FrontTa
 // ================================================================ substitution fallback for one super-block
 // Rare path (growth check failed): L_PP y = r  /  L_PP' x = v  in place on the nb entries w (LDS) by ONE workgroup.
 // Fs = front, (k0, k0) = position of the block.  Sd = 64*TP doubles of LDS.
+constexpr int BSC = 32;          // columns per step of the substitution fallback (its LDS tile: BSC x (BSC + 1) doubles)
+constexpr int BSP = BSC + 1;
 __device__ __noinline__ void block_solve_fw(const double *Fs, int ld, int k0, int nb, double *w, double *Sd) {
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int kk = 0; kk < nb; kk += 64) {
-    const int kb = min(64, nb - kk);
-    for (int e = tid; e < 64 * 64; e += ST) {
-      const int i = e & 63, c = e >> 6;
-      Sd[c * TP + i] = (i > c && i < kb) ? Fs[(int64_t)(k0 + kk + c) * ld + k0 + kk + i] : 0.0;
+  for (int kk = 0; kk < nb; kk += BSC) {
+    const int kb = min(BSC, nb - kk);
+    for (int e = tid; e < BSC * BSC; e += ST) {
+      const int i = e % BSC, c = e / BSC;
+      Sd[c * BSP + i] = (i > c && i < kb) ? Fs[(int64_t)(k0 + kk + c) * ld + k0 + kk + i] : 0.0;
     }
     __syncthreads();
     if (tid < 64) {
       double wi = lane < kb ? w[kk + lane] : 0.0;
-      for (int k = 0; k < 64; k++) wi -= Sd[k * TP + lane] * sdm_bcast_lane(wi, k);
+      for (int k = 0; k < BSC; k++) wi -= (lane < BSC ? Sd[k * BSP + min(lane, BSC - 1)] : 0.0) * sdm_bcast_lane(wi, k);
       if (lane < kb) w[kk + lane] = wi;
     }
     __syncthreads();
@@ -721,16 +723,16 @@ __device__ __noinline__ void block_solve_fw(const double *Fs, int ld, int k0, in
 }
 __device__ __noinline__ void block_solve_bw(const double *Fs, int ld, int k0, int nb, double *w, double *Sd) {
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int kk = ((nb - 1) / 64) * 64; kk >= 0; kk -= 64) {
-    const int kb = min(64, nb - kk);
-    for (int e = tid; e < 64 * 64; e += ST) {
-      const int i = e & 63, c = e >> 6;
-      Sd[c * TP + i] = (i > c && i < kb) ? Fs[(int64_t)(k0 + kk + c) * ld + k0 + kk + i] : 0.0;
+  for (int kk = ((nb - 1) / BSC) * BSC; kk >= 0; kk -= BSC) {
+    const int kb = min(BSC, nb - kk);
+    for (int e = tid; e < BSC * BSC; e += ST) {
+      const int i = e % BSC, c = e / BSC;
+      Sd[c * BSP + i] = (i > c && i < kb) ? Fs[(int64_t)(k0 + kk + c) * ld + k0 + kk + i] : 0.0;
     }
     __syncthreads();
     if (tid < 64) {
       double xj = lane < kb ? w[kk + lane] : 0.0;
-      for (int k = 63; k >= 0; k--) xj -= Sd[lane * TP + k] * sdm_bcast_lane(xj, k);      // L(k, lane), zero unless k > lane
+      for (int k = BSC - 1; k >= 0; k--) xj -= (lane < BSC ? Sd[min(lane, BSC - 1) * BSP + k] : 0.0) * sdm_bcast_lane(xj, k);      // L(k, lane), zero unless k > lane
       if (lane < kb) w[kk + lane] = xj;
     }
     __syncthreads();
@@ -869,17 +871,20 @@ __device__ __forceinline__ void bw_product(const double *M, int64_t ldm, int cba
 // GATHER: x[j] = xg[px[j]].  Result in every lane.  (Eight 16-byte loads per lane in flight, the vector entries next to them
 // straight from L2; the variant with the vector staged in LDS and sixteen loads in flight measured 5-10 % slower on the long
 // rows of MAXCUT-4000 -- the barrier costs more than the second round trip: profiles/r03n.)
-template <bool GATHER>
+// LPR = lanes per row: 64 (one row per wavefront) or 16 (four rows per wavefront, lane = position inside its group of 16: fronts of
+// up to 256 columns -- rows of at most 128 pairs are eight loads per lane of a 16-lane group, and a launch over many small fronts
+// needs a quarter of the workgroups: blockdiag 64 x 150 columns: 2432 -> 640, 27 -> 19 us per solve).
+template <bool GATHER, int LPR = 64>
 __device__ __forceinline__ double row_dot(const double *__restrict__ M, const double *__restrict__ x, const int *__restrict__ px, int n, int jlo, int lane) {
   double a0 = 0.0, a1 = 0.0;
   const sdm_double2 *M2 = (const sdm_double2 *)M;
   const int npair = (n + 1) >> 1;
-  for (int p0 = 0; p0 < npair; p0 += 8 * 64) {
+  for (int p0 = 0; p0 < npair; p0 += 8 * LPR) {
     sdm_double2 v[8];
     double x0[8], x1[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      const int pi = p0 + lane + 64 * k, pc = min(pi, npair - 1);
+      const int pi = p0 + lane + LPR * k, pc = min(pi, npair - 1);
       v[k] = M2[pc];
       const int j0 = 2 * pc, j1 = min(2 * pc + 1, n - 1);
       x0[k] = GATHER ? x[px[j0]] : x[j0];
@@ -887,7 +892,7 @@ __device__ __forceinline__ double row_dot(const double *__restrict__ M, const do
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      const int pi = p0 + lane + 64 * k;
+      const int pi = p0 + lane + LPR * k;
       const bool in0 = pi < npair && 2 * pi >= jlo, in1 = pi < npair && 2 * pi + 1 < n && 2 * pi + 1 >= jlo;
       // (selects on both factors: what lies outside the range may be anything)
       a0 += (in0 ? v[k].x : 0.0) * (in0 ? x0[k] : 0.0);
@@ -896,7 +901,7 @@ __device__ __forceinline__ double row_dot(const double *__restrict__ M, const do
   }
   double a = a0 + a1;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  for (int o = LPR / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
   return a;
 }
 // transposed copy of the rows of L below super-block Pb of a front (64x64 tiles through LDS): LT[r*W + c] = L((Pb+1) W + r, Pb W + c)
@@ -951,14 +956,14 @@ __global__ void __launch_bounds__(ST)
 k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTab tab, const int *list, const double *wv, const double *src,
            const int *perm, double *y, const unsigned long long *sb_g, double thr, int Pb, int gather0, FwBatch bt,
            double *zdiv, const double *dscale, int W) {
-  __shared__ double xs[SBW_MAX];
-  __shared__ double Sd[64 * TP];
+  SDM_DYN_SMEM(smem);                                                // (the rare substitution fallback only: W + BSC * BSP doubles -- as static
+  double *xs = (double *)smem, *Sd = xs + W;                          // arrays sized for the widest block they cost every launch 49 KB per workgroup)
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), first = FT(first);
   const int c0 = Pb * W;
   if (c0 >= ns) return;
   const int nb = min(W, ns - c0);
-  if (4 * (int)blockIdx.x >= nb) return;
+  if ((W <= 256 ? 16 : 4) * (int)blockIdx.x >= nb) return;
   wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; if (src) src += (int64_t)blockIdx.z * bt.src;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int sld = FT(sld);
@@ -974,6 +979,17 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTa
       const double yv = xs[i];
       y[first + c0 + i] = yv;
       if (zdiv) { const double dk = dscale[first + c0 + i]; zdiv[first + c0 + i] = yv / (dk > 0.0 ? dk : 1.0); }
+    }
+    return;
+  }
+  if (W <= 256) {                                                      // (uniform for the launch: the grid is sized accordingly) 16 rows per workgroup
+    const int r = 16 * blockIdx.x + 4 * wave + (lane >> 4), l16 = lane & 15;
+    const int rc = min(r, nb - 1);
+    const double *M = STr + FT(soff) + (int64_t)c0 * sld + (int64_t)rc * sld;
+    const double sum = gather ? row_dot<true, 16>(M, src, pp, rc + 1, 0, l16) : row_dot<false, 16>(M, a, nullptr, rc + 1, 0, l16);
+    if (l16 == 0 && r < nb) {
+      y[first + c0 + r] = sum;
+      if (zdiv) { const double dk = dscale[first + c0 + r]; zdiv[first + c0 + r] = sum / (dk > 0.0 ? dk : 1.0); }
     }
     return;
   }
@@ -1084,14 +1100,14 @@ k_sbw_init(const double *__restrict__ F, FrontTab tab, const int *list, double *
 __global__ void __launch_bounds__(ST)
 k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, const double *y, double *xfin, double *yout,
            const int *perm, const unsigned long long *sb_g, double thr, int Q, int W) {
-  __shared__ double xs[SBW_MAX];
-  __shared__ double Sd[64 * TP];
+  SDM_DYN_SMEM(smem);
+  double *xs = (double *)smem, *Sd = xs + W;
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), first = FT(first);
   const int rb = Q * W;
   if (rb >= ns) return;
   const int nb = min(W, ns - rb);
-  if (4 * (int)blockIdx.x >= nb) return;
+  if ((W <= 256 ? 16 : 4) * (int)blockIdx.x >= nb) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const double *vp = y + first + rb;
   if (sb_is_bad(sb_g, FT(sboff) + Q, thr)) {
@@ -1102,9 +1118,17 @@ k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
     for (int i = tid; i < nb; i += ST) { xfin[first + rb + i] = xs[i]; if (yout) yout[perm[first + rb + i]] = xs[i]; }
     return;
   }
+  const int sld = FT(sld);
+  if (W <= 256) {                                                      // 16 columns per workgroup (see k_sfw_diag)
+    const int c = 16 * blockIdx.x + 4 * wave + (lane >> 4), l16 = lane & 15;
+    const int cc = min(c, nb - 1), ce = cc & ~1;
+    const double *M = S + FT(soff) + (int64_t)rb * sld + (int64_t)cc * sld + ce;
+    const double sum = row_dot<false, 16>(M, vp + ce, nullptr, nb - ce, cc - ce, l16);
+    if (l16 == 0 && c < nb) { xfin[first + rb + c] = sum; if (yout) yout[perm[first + rb + c]] = sum; }
+    return;
+  }
   const int c = 4 * blockIdx.x + wave;
   if (c >= nb) return;
-  const int sld = FT(sld);
   const int ce = c & ~1;                                              // 16-byte aligned start (the entry above the diagonal is skipped: jlo)
   const double *M = S + FT(soff) + (int64_t)rb * sld + (int64_t)c * sld + ce;
   const double sum = row_dot<false>(M, vp + ce, nullptr, nb - ce, c - ce, lane);
@@ -1223,7 +1247,7 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
     if (!(what & 2)) continue;
     for (int Pb = 0; Pb < L.nsb; Pb++) {
       const int nbmax = std::min(W, L.maxns - Pb * W);
-      SDM_KLAUNCH(P, k_sfw_diag, dim3((nbmax + 3) / 4, L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, C.ST.p, tab, list, wv, rhs,
+      SDM_KLAUNCH(P, k_sfw_diag, dim3(W <= 256 ? (nbmax + 15) / 16 : (nbmax + 3) / 4, L.nfronts, nrhs), dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.ST.p, tab, list, wv, rhs,
                   C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W);
       const int assign0 = (gather && Pb == 0) ? 1 : 0;
       if (L.maxns > (Pb + 1) * W)                                    // the fronts' own rows of later super-blocks
@@ -1253,7 +1277,7 @@ static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double 
       SDM_KLAUNCH(P, k_sbw_init, dim3((L.maxns + SROWS - 1) / SROWS, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, dscale);
     for (int Q = L.nsb - 1; Q >= 0; Q--) {
       const int nbmax = std::min(W, L.maxns - Q * W);
-      SDM_KLAUNCH(P, k_sbw_diag, dim3((nbmax + 3) / 4, L.nfronts), dim3(ST), 0, C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
+      SDM_KLAUNCH(P, k_sbw_diag, dim3(W <= 256 ? (nbmax + 15) / 16 : (nbmax + 3) / 4, L.nfronts), dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
                   C.d_perm.p, C.sb_g.p, thr, Q, W);
       if (Q > 0) SDM_KLAUNCH(P, k_sbw_step, dim3(Q * (W / 4), L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, Q, W);
     }

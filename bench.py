@@ -301,7 +301,11 @@ def profile_unit(plan, P, ud, nprof):
                           "~7 us read as ~7 us: see phases_ms_per_step for those)",
                 "stage_ms_per_step": {k: v[1] / nprof for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
         import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+        # the committed PMC file of THIS workload (tools/profile_round.sh <tag>_<workload> <workload>), latest round
+        import re
+        key = re.sub(r"[^a-z0-9]", "", P.name.lower().split(".")[0].replace("(n=", "").replace("_sdp", ""))
+        key = "blockdiag" if key.startswith("blockdiag") else key
+        pmcs = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")) if key and ("_" + key + "_") in os.path.basename(f))
         if pmcs:
             try:
                 roof["traffic_from_committed_profile"] = {"bytes_per_launch": json.load(open(pmcs[-1])).get(dom),

@@ -749,9 +749,10 @@ __device__ __forceinline__ void diag_sweep_w0(double (*S)[NB + 1], double *Lc, i
         S[tx][cn + k] = x[k];
         xs[k] = x[k];
       }
-      SDM_WAVE_SYNC();
-      if (tx >= cn && tx < cn + SW && tx < kb) {                       // bookkeeping of pivot tx in lane tx
-        const double pval = S[tx][tx];
+      if (tx >= cn && tx < cn + SW && tx < kb) {                       // bookkeeping of pivot tx in lane tx (its own register copy of x_tt)
+        double pval = x[0];
+#pragma unroll
+        for (int k = 1; k < SW; k++) pval = (tx == cn + k) ? x[k] : pval;
         const bool acc = pval > mylb;
         ds[tx] = acc ? pval : 0.0;
         if (!acc) { stt[tx] = 1; pv[tx] = pval; }
@@ -893,7 +894,9 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
     __syncthreads();                                                   // sweep 0
     for (int sw = 0; sw < nsw - 1; sw++) {
       if (publish) {
-        if (issued > signalled) {                                      // columns stored during the previous sweep
+        // (k_ldl_front: the row workgroups read the data-tagged DT itself; the count is for consumers off the chain -- the follower,
+        // the column probe -- and goes up behind the last sweep: no acknowledgement wait inside the sweeps, whose barrier it would hold)
+        if (!PERSIST && issued > signalled) {                          // columns stored during the previous sweep
           SDM_STORES_DONE();
           if (tx == 0) sdm_signal_add(&diag_cnt[s]);
           signalled = issued;
@@ -1689,7 +1692,7 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
     if (nfr == 0) continue;
     if (l > 0) SDM_KLAUNCH(P, k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, C.fronts.p, tab, list);
     if (extend_only) continue;
-    if (C.lev_persist[l]) {                                          // the whole level in one launch (k_ldl_front)
+    if (C.lev_persist[l] && !C.front_disabled) {                     // the whole level in one launch (k_ldl_front)
       PersistTurn turn(P);
 #ifdef SDM_EMU
       int maxnp = 0;
@@ -1763,7 +1766,13 @@ int chol_wait_timeouts(sdm_plan *P) {
   CholPlan &C = P->chol;
   if (!C.tmo.host) return 0;
   const int n = *(volatile int *)C.tmo.host;
-  if (n) { *(volatile int *)C.tmo.host = 0; P->factored = false; }
+  if (n) {
+    *(volatile int *)C.tmo.host = 0; P->factored = false;
+    // k_ldl_front needs ALL its workgroups resident and they wait for each other: another process on the same device (or a partition
+    // smaller than the one the plan was built on) can keep some of them out until the bounded waits give up.  The launch-per-panel
+    // path only ever waits for workgroups dispatched earlier, so this plan's later factorisations take that one.
+    C.front_disabled = true; C.follow = false;
+  }
   return n;
 }
 

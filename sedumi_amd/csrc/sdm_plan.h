@@ -196,6 +196,7 @@ struct CholPlan {
   DevBuf<int> l_i128, l_items;       // work lists of the inversion: 128-column leaves (4 ints each), combine tiles (8 ints each, sorted by stage)
   int n_i128 = 0, n_items = 0;
   bool follow = false;               // every front is factored by k_ldl_front and inverted behind it by k_sinv_follow (no solve_prepare launches)
+  bool front_disabled = false;       // a launch of this plan timed out: its later factorisations take the launch-per-panel path (chol_wait_timeouts)
   std::vector<int> lev_followT;      // grid.x of k_sinv_follow per level: tiles of the inverse of its widest front
   std::vector<int> stage_ptr;        // combine tiles of stage st (= 2 * level + (0: T, 1: X)) are l_items[stage_ptr[st] .. stage_ptr[st+1])
   std::vector<SolveLevel> slev;

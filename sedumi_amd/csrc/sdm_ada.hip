@@ -727,6 +727,73 @@ k_psd_stage2(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, 
   }
 }
 
+// ---- PSD part WITHOUT the z_j detour, for constraints of at most S1_DIRECT_MAXNZ nonzeros per PSD block (MAXCUT: A_i = e_i e_i').  With
+// so few nonzeros the pairwise form   a_i' z_j = sum_{(r,c) in A_i} a_i(r,c) * 1/2 sum_{(s,t) in A_j} x_j(s,t) (D(r,s) D(t,c) + D(c,s) D(t,r))
+// costs a handful of D entries per pattern entry, while the two-stage form writes and re-reads every z_j on the whole union pattern (MAXCUT-4000:
+// 128 MB each way, 715 MB of HBM traffic and two launches of 180 + 200 us).  One workgroup per column j, one pattern entry per work-item as
+// in k_psd_stage2; the symmetry of D_k puts the work-item's own index last in every D access (coalesced).  absd as in getada3.c:341-347.
+constexpr int S1_DIRECT_MAXNZ = 2;
+__global__ void __launch_bounds__(256)
+k_psd_direct(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, const int64_t *Ajc, const int64_t *Ajc_psd, const double *Apr,
+             const int *Air, const int *Ablk, const int64_t *c_taskptr, const int *t_blk, const int *t_n, const int64_t *t_udoff,
+             const int64_t *t_slotptr, const int64_t *s_nzptr, const int64_t *t_end, const int64_t *psd_start, const double *udsqr,
+             const int *invperm, int nblk, int jbase) {
+  SDM_DYN_SMEM(smem);
+  // per block of column j: order n (0 = no nonzero of A_j there), offsets of D_k and of the block's rows, and the nonzeros of A_jk
+  int *bn = (int *)smem;                                   // [nblk]
+  int *bnz = bn + nblk;                                    // [nblk] number of nonzeros
+  int *brc = bnz + nblk;                                   // [nblk][MAXNZ][2] (row, column)
+  long long *bud = (long long *)(brc + 2 * S1_DIRECT_MAXNZ * nblk);     // [nblk] (8-byte aligned: an even number of ints before it)
+  long long *bst = bud + nblk;                             // [nblk]
+  double *bx = (double *)(bst + nblk);                     // [nblk][MAXNZ]
+  const int j = blockIdx.x + jbase;
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int64_t tb0 = c_taskptr[j], te0 = c_taskptr[j + 1];
+  const bool jhas = te0 > tb0;
+  for (int k = tid; k < nblk; k += bs) {
+    bn[k] = 0; bnz[k] = 0; bst[k] = psd_start[k]; bud[k] = 0;
+    for (int w = 0; w < S1_DIRECT_MAXNZ; w++) { brc[(k * S1_DIRECT_MAXNZ + w) * 2] = 0; brc[(k * S1_DIRECT_MAXNZ + w) * 2 + 1] = 0; bx[k * S1_DIRECT_MAXNZ + w] = 0.0; }
+  }
+  __syncthreads();
+  for (int64_t t = tb0 + tid; t < te0; t += bs) {
+    const int k = t_blk[t], n = t_n[t];
+    const int64_t u0 = s_nzptr[t_slotptr[t]], u1 = t_end[t];
+    bn[k] = n; bud[k] = t_udoff[t]; bnz[k] = (int)(u1 - u0);
+    for (int64_t u = u0; u < u1 && u - u0 < S1_DIRECT_MAXNZ; u++) {
+      const int q = (int)(Air[u] - psd_start[k]);
+      brc[(k * S1_DIRECT_MAXNZ + (int)(u - u0)) * 2] = q % n; brc[(k * S1_DIRECT_MAXNZ + (int)(u - u0)) * 2 + 1] = q / n;
+      bx[k * S1_DIRECT_MAXNZ + (int)(u - u0)] = Apr[u];
+    }
+  }
+  __syncthreads();
+  const int ipj = invperm ? invperm[j] : 0;
+  // (four pattern entries per work-item in flight with straight-line terms measured no faster: 172 against 164 us on MAXCUT-4000)
+  for (int64_t e = ADAjc[j] + tid; e < ADAjc[j + 1]; e += bs) {
+    const int i = ADAir[e];
+    if (invperm && invperm[i] > ipj) continue;
+    double acc = 0.0, aabs = 0.0;
+    if (jhas)
+      for (int64_t p = Ajc_psd[i]; p < Ajc[i + 1]; p++) {
+        const int k = Ablk[p], n = bn[k];
+        if (n == 0) continue;
+        const double *D = udsqr + bud[k];
+        const int q = (int)(Air[p] - bst[k]);
+        const int c = q / n, r = q - c * n;
+        double zv = 0.0;
+        for (int w = 0; w < bnz[k]; w++) {
+          const int s2 = brc[(k * S1_DIRECT_MAXNZ + w) * 2], t2 = brc[(k * S1_DIRECT_MAXNZ + w) * 2 + 1];
+          const double *Ds = D + (int64_t)s2 * n, *Dt = D + (int64_t)t2 * n;
+          zv += bx[k * S1_DIRECT_MAXNZ + w] * (Ds[r] * Dt[c] + Ds[c] * Dt[r]);
+        }
+        const double term = Apr[p] * (zv / 2);
+        acc += term; aabs += fabs(term);
+      }
+    const double base = ada[e];
+    ada[e] = base + acc;
+    if (i == j) absd[j] = jhas ? base + aabs : 0.0;
+  }
+}
+
 // ---- stage 2, dense-ish patterns: one workgroup per JB consecutive ADA columns.  Their z_j (all blocks touched
 // by constraint j) are staged in LDS once; the wavefronts then sweep the groups of 64 rows, ONE ROW PER LANE, over
 // the interleaved (ELL) copy of the PSD nonzeros: coalesced loads (each feeding JB columns), LDS gathers, no
@@ -959,6 +1026,21 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
   if (A.col1 <= A.col0) return;
   const int ncols = (int)(A.col1 - A.col0), jbase = (int)A.col0;
   const int task0 = (int)A.h_taskptr[A.col0], ntask = (int)(A.h_taskptr[A.col1] - A.h_taskptr[A.col0]);
+  // constraints of one or two nonzeros per PSD block on a pattern swept one entry per work-item: the pairwise form, no z_j (k_psd_direct)
+  const bool direct = A.thread_per_row && !A.ell_ok && A.sdpN == A.rsdpN && A.s1_maxnz <= S1_DIRECT_MAXNZ;
+  if (direct) {
+    if (sym_input) {
+      SDM_KLAUNCH(P, k_symmetrize, dim3(m), dim3(128), 0, A.symtmp.p, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_ADAT.p, m);
+      SDM_HIP_CHECK(hipMemcpyAsync(ada, A.symtmp.p, A.symtmp.n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    const int nb = (int)A.sdpN;
+    const size_t lds = (size_t)(2 * nb + 2 * S1_DIRECT_MAXNZ * nb + 2) * sizeof(int) + (size_t)(2 * nb) * sizeof(long long) + (size_t)(S1_DIRECT_MAXNZ * nb) * sizeof(double);
+    SDM_KLAUNCH(P, k_psd_direct, dim3(ncols), dim3(256), lds, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p, A.d_Apr.p, A.d_Air.p,
+                A.d_Ablk.p, A.c_taskptr.p, A.t_blk.p, A.t_n.p, A.t_udoff.p, A.t_slotptr.p, A.s_nzptr.p, A.t_end.p, A.d_psd_start.p, A.udsqr.p,
+                d_invperm, nb, jbase);
+    SDM_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (ntask > 0) {
     Stage1Tab T;
     T.t_n = A.t_n.p; T.t_nslot = A.t_nslot.p; T.t_ulen = A.t_ulen.p; T.t_herm = A.t_herm.p; T.s_col = A.s_col.p;

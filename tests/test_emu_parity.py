@@ -53,6 +53,52 @@ def test_iteration_unit_blocks_above_96(glue, kw):
     assert max(errs.values()) < TOL, errs
 
 
+def _few_nonzero_sdp(seed, m, blocks, lp=0):
+    """Every constraint has at most two nonzeros per PSD block (diagonal entries, and off-diagonal ones stored in ONE triangle with the
+    doubled value, as blockdiag_sdp does): the shape that takes the pairwise form of the PSD part (k_psd_direct)."""
+    from sedumi_amd import problem
+    rng = np.random.default_rng(seed)
+    K = problem.make_K(lp + 1, [], list(blocks))
+    start, _ = problem._psd_rows(K)
+    rows, cols, vals = [], [], []
+    for j in range(m):
+        for k, n in enumerate(blocks):
+            kind = rng.integers(0, 4)                      # 0: nothing in this block, 1: one diagonal, 2: one off-diagonal, 3: two entries
+            if kind == 0 and not (k == j % len(blocks)):
+                continue
+            used = set()
+            for _ in range(2 if kind == 3 else 1):
+                r, c = sorted(rng.integers(0, n, size=2))
+                if kind == 1:
+                    c = r
+                if (r, c) in used:
+                    continue
+                used.add((r, c))
+                rows.append(start[k] + c + r * n); cols.append(j); vals.append(rng.standard_normal() * (1.0 if r == c else 2.0))
+        for r in rng.integers(1, lp + 1, size=min(lp, 2)) if lp else []:
+            rows.append(int(r)); cols.append(j); vals.append(rng.standard_normal())
+    At = sp.csc_matrix((vals, (rows, cols)), shape=(int(K["N"]), m))
+    At.sum_duplicates()
+    return problem.Problem(At, K, f"few_nonzero_sdp(seed={seed})")
+
+
+@pytest.mark.parametrize("seed,m,blocks,lp", [(1, 30, (40,), 0), (2, 24, (9, 14, 6), 0), (3, 40, (25, 12), 5)])
+def test_iteration_unit_constraints_of_one_or_two_nonzeros_per_block(glue, seed, m, blocks, lp):
+    """MAXCUT-type constraints: the PSD part of ADA' in its pairwise form (k_psd_direct, no z_j), stage by stage against the reference."""
+    P = _few_nonzero_sdp(seed, m, blocks, lp)
+    for rev in (0, 1):
+        _set_reverse(rev)
+        errs, S, _ = check_iteration(glue, P, seed=seed)
+        assert max(errs.values()) < TOL, errs
+    _set_reverse(0)
+
+
+def test_iteration_unit_maxcut_small(glue):
+    from sedumi_amd import problem
+    errs, S, _ = check_iteration(glue, problem.maxcut(90), seed=5)
+    assert max(errs.values()) < TOL, errs
+
+
 @pytest.mark.parametrize("name", ["arch0", "nb"])
 def test_golden_small_examples(name):
     for tag in ("init", "rand"):

@@ -273,6 +273,7 @@ def profile_unit(plan, P, ud, nprof):
         "k_psd_stage1_mfma": ("mfma", None), "k_psd_stage1": ("fp64_vector", None),  # flops filled below from the task list (the two-dot kernel has no MFMA in it)
         "k_psd_stage2": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)), "k_psd_stage2_ell": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)),
         "k_ada_spdot": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)),
+        "k_psd_direct": ("hbm", 8.0 * (ud.size + 2.0 * plan.nnzADA)),                # D_k once, ADA' read and written
         "k_sfw_step": ("hbm", None), "k_sbw_step": ("hbm", None), "k_sfw_diag": ("hbm", None), "k_sbw_diag": ("hbm", None),
     }
     peaks = {"hbm": (HBM_PEAK_GBS, "GB/s", 1e9), "mfma": (FP64_MATRIX_PEAK_TFS, "TFLOP/s", 1e12),

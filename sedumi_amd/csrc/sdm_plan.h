@@ -15,7 +15,7 @@ constexpr int S1_KC = 48;     // slots (nonzero columns of A_jk) per GEMM chunk
 constexpr int S1_WAVES = 8;   // wavefronts per task
 constexpr int S1_NZ = 1536;   // nonzeros of a chunk of slots staged in LDS (bigger chunks read At directly)
 constexpr int S1_MAXT = ((S1_MAXN / 16) * (S1_MAXN / 16) + S1_WAVES - 1) / S1_WAVES;   // 16x16 tiles of Z per wavefront
-constexpr int S1_GEN_LDS = 24 * 1024;   // LDS target per task of the generic stage-1 kernel (bytes)
+constexpr int S1_GEN_LDS = 74 * 1024;   // LDS target per task of the generic stage-1 kernel (bytes): two 512-work-item tasks per compute unit
 constexpr int ELL_WAVES = 8;  // wavefronts per workgroup of the ELL stage-2 kernel of ADA'
 constexpr int SOLVE_LDS_MAX = 3072;   // doubles of a product-form right-hand side kept in LDS (k_pr1_solve)
 constexpr int FUSE_MAX_TILES = 1 << 20; // trailing updates of at most this many tiles ride along with the next diagonal-block launch (in effect: all)

@@ -141,6 +141,9 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
   for (size_t t = 0; t < t_col.size(); t++)
     A.s1_maxnz = std::max<int64_t>(A.s1_maxnz, (t + 1 < t_slotptr.size() ? s_nzptr[t_slotptr[t + 1]] : A.nnzA) - s_nzptr[t_slotptr[t]]);
   A.ntask = (sdm_int)t_col.size(); A.zlen = zlen;
+  A.one_task_per_col = true; A.s1_maxulen = 0;
+  for (sdm_int j = 0; j < m; j++) if (c_taskptr[j + 1] - c_taskptr[j] > 1) A.one_task_per_col = false;
+  for (size_t t = 0; t < t_ulen.size(); t++) A.s1_maxulen = std::max(A.s1_maxulen, t_ulen[t]);
   A.h_taskptr = c_taskptr; A.col0 = 0; A.col1 = m;
   { std::vector<int64_t> czl(m + 1, 0);                       // length of z_j (all tasks of constraint j)
     A.zmaxj = 0;
@@ -450,8 +453,15 @@ struct Stage1Tab {
   const int *t_blk;
   const int64_t *psd_start;
 };
+// what the generic stage-1 kernel needs to finish column j itself (stage 2 riding in the task): null ada = two-stage form
+struct Stage2Ride {
+  double *ada, *absd;
+  const int64_t *ADAjc, *Ajc, *Ajc_psd;
+  const int *ADAir, *Ablk, *Aupos, *t_col, *invperm;
+  const double *Apr;
+};
 __global__ void __launch_bounds__(512, 4)
-k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0, int nzcap) {
+k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0, int nzcap, Stage2Ride R2) {
   SDM_DYN_SMEM(smem);
   double *Y = (double *)smem;                       // Y[slot][row], chunk of CC slots (Hermitian: Re then Im plane)
   const int task = blockIdx.x + task0;
@@ -587,6 +597,36 @@ k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0
       if (c0 == 0) z[u] = v; else z[u] += v;
     }
     __syncthreads();
+  }
+  if (!herm && R2.ada && ulen <= S1_TREG * bs) {
+    // Stage 2 of this constraint right here (it touches no other PSD block: z_j is exactly what this task has in registers): z_j goes
+    // to LDS instead of zbuf -- 230 MB written and read again per unit on 64 blocks of order 200 -- and the pattern entries of column j
+    // are formed one per work-item as k_psd_stage2 does (getada3.c:333-351, absd :341-347).
+    double *zl = Y;                                                  // (Y / Dl are dead: behind the last barrier of the chunk loop)
+#pragma unroll
+    for (int k = 0; k < S1_TREG; k++) if (tid + k * bs < ulen) zl[tid + k * bs] = zreg[k];
+    __syncthreads();
+    const int j = R2.t_col[task], kblk = T.t_blk[task];
+    const int ipj = R2.invperm ? R2.invperm[j] : 0;
+    for (int64_t e = R2.ADAjc[j] + tid; e < R2.ADAjc[j + 1]; e += bs) {
+      const int i = R2.ADAir[e];
+      if (R2.invperm && R2.invperm[i] > ipj) continue;
+      double acc = 0.0, aabs = 0.0;
+      int64_t p = R2.Ajc_psd[i];
+      const int64_t pe = R2.Ajc[i + 1];
+      for (; p + 4 <= pe; p += 4) {                                  // 4 nonzeros of a_i in flight
+        double x[4]; int b[4], u[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { x[q] = R2.Apr[p + q]; b[q] = R2.Ablk[p + q]; u[q] = R2.Aupos[p + q]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (b[q] == kblk) { const double term = x[q] * zl[u[q]]; acc += term; aabs += fabs(term); }
+      }
+      for (; p < pe; p++) if (R2.Ablk[p] == kblk) { const double term = R2.Apr[p] * zl[R2.Aupos[p]]; acc += term; aabs += fabs(term); }
+      const double base = R2.ada[e];
+      R2.ada[e] = base + acc;
+      if (i == j) R2.absd[j] = base + aabs;
+    }
+    return;
   }
   if (!herm) {
 #pragma unroll
@@ -1121,7 +1161,21 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
 #ifndef SDM_EMU
       SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
-      SDM_KLAUNCH(P, k_psd_stage1, dim3((unsigned)ntask), dim3(512), lds, T, A.udsqr.p, A.zbuf.p, (int)(ldsy / sizeof(double)), task0, nzcap);
+      // every constraint touches at most one PSD block and the pattern is swept one entry per work-item: stage 2 rides in the task
+      const bool ride = A.one_task_per_col && A.thread_per_row && !A.ell_ok && A.sdpN == A.rsdpN && A.s1_maxulen <= 6 * 512 &&
+                        (int64_t)A.s1_maxulen * (int64_t)sizeof(double) <= (int64_t)ldsy;
+      Stage2Ride R2 = {};
+      if (ride) {
+        if (sym_input) {
+          SDM_KLAUNCH(P, k_symmetrize, dim3(m), dim3(128), 0, A.symtmp.p, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_ADAT.p, m);
+          SDM_HIP_CHECK(hipMemcpyAsync(ada, A.symtmp.p, A.symtmp.n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        SDM_HIP_CHECK(hipMemsetAsync(P->absd.p + jbase, 0, (size_t)ncols * sizeof(double), st));      // (constraints without PSD nonzeros: absd = 0)
+        R2.ada = ada; R2.absd = P->absd.p; R2.ADAjc = A.d_ADAjc.p; R2.Ajc = A.d_Ajc.p; R2.Ajc_psd = A.d_Ajc_psd.p; R2.ADAir = A.d_ADAir.p;
+        R2.Ablk = A.d_Ablk.p; R2.Aupos = A.d_Aupos.p; R2.t_col = A.t_col.p; R2.invperm = d_invperm; R2.Apr = A.d_Apr.p;
+      }
+      SDM_KLAUNCH(P, k_psd_stage1, dim3((unsigned)ntask), dim3(512), lds, T, A.udsqr.p, A.zbuf.p, (int)(ldsy / sizeof(double)), task0, nzcap, R2);
+      if (ride) { SDM_HIP_CHECK(hipGetLastError()); return; }
     }
   }
   // the reference first adds the PSD part on one triangle and symmetrises at the very end; summing the

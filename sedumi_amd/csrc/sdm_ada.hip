@@ -93,6 +93,8 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
     }
   A.thread_per_row = (m > 0 && psdnnz / (double)m < 48.0);     // short rows: one pattern entry per work-item, else per wavefront
   A.nnz_lq = A.nnzA - psdnnz;                                      // LP + Lorentz nonzeros of At
+  A.lq_maxcol = 0;
+  for (sdm_int j = 0; j < m; j++) A.lq_maxcol = std::max<int64_t>(A.lq_maxcol, (sdpN > 0 ? Ajc_psd[j] : Ajc[j + 1]) - Ajc[j]);
   // ---- stage-1 tasks and slots
   std::vector<int> t_col, t_blk, t_n, t_nslot, t_ulen, t_herm, s_col;
   std::vector<int64_t> t_slotptr, t_udoff, t_uoff, t_zoff, s_nzptr, c_taskptr(m + 1, 0);
@@ -223,6 +225,8 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
   A.d_Apr.upload(Apr, (size_t)A.nnzA);
   A.d_Ablk.upload(Ablk); A.d_Aupos.upload(Aupos);
   A.nnzQ = lorN > 0 ? Qjc[m] : 0;
+  A.q_maxcol = 0;
+  for (sdm_int j = 0; j < m && lorN > 0; j++) A.q_maxcol = std::max<int64_t>(A.q_maxcol, Qjc[j + 1] - Qjc[j]);
   { std::vector<int64_t> v(m + 1, 0); if (lorN > 0) v.assign(Qjc, Qjc + m + 1); A.d_Qjc.upload(v); }
   { std::vector<int> v((size_t)A.nnzQ); for (sdm_int t = 0; t < A.nnzQ; t++) v[t] = (int)Qir[t]; A.d_Qir.upload(v); }
   { std::vector<int64_t> v(ADAjc, ADAjc + m + 1); A.d_ADAjc.upload(v); }
@@ -298,27 +302,55 @@ __global__ void k_fill(double *x, double v, int64_t n) {
 
 // sparse weighted dot of two At columns restricted to [beg,end) ranges; one wavefront per ADA entry.
 //   val(i,j) = sum_r  M(r,i) * w(r) * M(r,j),   w = dsqr (getada1) or 1 (getada2)
+constexpr int SPDOT_CAP = 2048;      // entries of a column of M that k_ada_spdot keeps in LDS (24 KB)
+// LPE = lanes per pattern entry: 16 (four entries per wavefront: short columns) or 64
+template <int LPE>
 __global__ void __launch_bounds__(256)
 k_ada_spdot(double *ada, const int64_t *ADAjc, const int *ADAir, const int64_t *Mbeg, const int64_t *Mend,
-            const int *Mir, const double *Mpr, const double *wgt, const int *invperm, int accumulate, int jbase) {
+            const int *Mir, const double *Mpr, const double *wgt, const int *invperm, int accumulate, int jbase, int cap) {
+  // Column j of M (its row indices and its values times the weights) goes to LDS once per workgroup when it fits `cap` entries: the
+  // binary searches of all the column's pattern entries then walk LDS (~100 clocks a step) instead of being chains of dependent loads
+  // from L2 (each entry of a nearly dense ADA' was 8 steps x 4 rounds of them: 4 ms on the LP with m = 2000, 36 us on arch0.mat).
+  SDM_DYN_SMEM(smem);
+  double *jv = (double *)smem;
+  int *jr = (int *)(jv + cap);
   const int j = blockIdx.x + jbase;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   const int64_t jb = Mbeg[j], je = Mend[j];
+  const int nj = (int)(je - jb);
+  const bool inlds = nj <= cap;
+  if (inlds)
+    for (int t = threadIdx.x; t < nj; t += blockDim.x) { const int r = Mir[jb + t]; jr[t] = r; jv[t] = (wgt ? wgt[r] : 1.0) * Mpr[jb + t]; }
+  __syncthreads();
   const int ipj = invperm ? invperm[j] : 0;
-  for (int64_t e = ADAjc[j] + wave; e < ADAjc[j + 1]; e += nw) {
-    const int i = ADAir[e];
-    if (invperm && invperm[i] > ipj) continue;       // wave-uniform
+  // short columns: four pattern entries per wavefront, 16 lanes each -- the per-entry chain (row index -> column range -> nonzeros) is
+  // three dependent round trips however short the column, so it is the number of entries in flight that counts (arch0.mat: 36 -> 12 us);
+  // long columns keep the whole wavefront on one entry (nb.mat's DAt.q at the identity scaling: 34 us, 49 with four entries each)
+  constexpr int EPW = 64 / LPE;
+  const int g = lane / LPE, l16 = lane % LPE;
+  const int64_t e1 = ADAjc[j + 1];
+  for (int64_t e0 = ADAjc[j] + EPW * wave; e0 < e1; e0 += EPW * nw) {
+    const int64_t e = e0 + g;
+    const bool on = e < e1;
+    const int i = ADAir[on ? e : e1 - 1];
+    const bool skip = !on || (invperm && invperm[i] > ipj);
     double acc = 0.0;
-    if (je > jb) {
-      for (int64_t t = Mbeg[i] + lane; t < Mend[i]; t += 64) {
+    if (je > jb && !skip) {
+      for (int64_t t = Mbeg[i] + l16; t < Mend[i]; t += LPE) {
         const int r = Mir[t];
-        int64_t lo = jb, hi = je;                     // first index with Mir >= r
-        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (Mir[mid] < r) lo = mid + 1; else hi = mid; }
-        if (lo < je && Mir[lo] == r) acc += Mpr[t] * ((wgt ? wgt[r] : 1.0) * Mpr[lo]);
+        if (inlds) {
+          int lo = 0, hi = nj;                        // first index with jr >= r
+          while (lo < hi) { const int mid = (lo + hi) >> 1; if (jr[mid] < r) lo = mid + 1; else hi = mid; }
+          if (lo < nj && jr[lo] == r) acc += Mpr[t] * jv[lo];
+        } else {
+          int64_t lo = jb, hi = je;
+          while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (Mir[mid] < r) lo = mid + 1; else hi = mid; }
+          if (lo < je && Mir[lo] == r) acc += Mpr[t] * ((wgt ? wgt[r] : 1.0) * Mpr[lo]);
+        }
       }
     }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if (lane == 0) { if (accumulate) ada[e] += acc; else ada[e] = acc; }
+    for (int off = LPE / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off);       // (lane 0 of each group ends with its own group's sum)
+    if (l16 == 0 && !skip) { if (accumulate) ada[e] += acc; else ada[e] = acc; }
   }
 }
 
@@ -1060,8 +1092,13 @@ void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
                 A.gram_split, m, d_invperm, accumulate ? 1 : 0, (int)A.col0);
     return;
   }
-  SDM_KLAUNCH(P, k_ada_spdot, dim3((unsigned)(A.col1 - A.col0)), dim3(256), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p,
-             A.d_Air.p, A.d_Apr.p, A.dsqr.p, d_invperm, accumulate ? 1 : 0, (int)A.col0);
+  if (A.lq_maxcol <= 256)                                            // (measured: 200 nonzeros per column are still faster four entries at a time;
+                                                                     //  ONE column of 793 is not: its single entry is the whole launch)
+    SDM_KLAUNCH(P, k_ada_spdot<16>, dim3((unsigned)(A.col1 - A.col0)), dim3(256), (size_t)SPDOT_CAP * 12, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p,
+               A.d_Air.p, A.d_Apr.p, A.dsqr.p, d_invperm, accumulate ? 1 : 0, (int)A.col0, SPDOT_CAP);
+  else
+    SDM_KLAUNCH(P, k_ada_spdot<64>, dim3((unsigned)(A.col1 - A.col0)), dim3(256), (size_t)SPDOT_CAP * 12, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p,
+               A.d_Air.p, A.d_Apr.p, A.dsqr.p, d_invperm, accumulate ? 1 : 0, (int)A.col0, SPDOT_CAP);
 }
 void ada_datq(sdm_plan *P) {
   AdaPlan &A = P->ada;
@@ -1082,8 +1119,12 @@ void ada_q(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
                 A.gram_split, m, d_invperm, accumulate ? 1 : 0, (int)A.col0);
     return;
   }
-  SDM_KLAUNCH(P, k_ada_spdot, dim3((unsigned)(A.col1 - A.col0)), dim3(256), 0, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Qjc.p, A.d_Qjc.p + 1,
-             A.d_Qir.p, A.qpr.p, (const double *)nullptr, d_invperm, accumulate ? 1 : 0, (int)A.col0);
+  if (A.q_maxcol <= 256)
+    SDM_KLAUNCH(P, k_ada_spdot<16>, dim3((unsigned)(A.col1 - A.col0)), dim3(256), (size_t)SPDOT_CAP * 12, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Qjc.p, A.d_Qjc.p + 1,
+               A.d_Qir.p, A.qpr.p, (const double *)nullptr, d_invperm, accumulate ? 1 : 0, (int)A.col0, SPDOT_CAP);
+  else
+    SDM_KLAUNCH(P, k_ada_spdot<64>, dim3((unsigned)(A.col1 - A.col0)), dim3(256), (size_t)SPDOT_CAP * 12, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_Qjc.p, A.d_Qjc.p + 1,
+               A.d_Qir.p, A.qpr.p, (const double *)nullptr, d_invperm, accumulate ? 1 : 0, (int)A.col0, SPDOT_CAP);
 }
 // LP + Lorentz-det part and Lorentz rank-1 part of a FULL ADA' in three launches when both take the dense Gram form
 // (nb.mat's shape): prep (dsqr, dense DAt.q), one Gram launch over the rows of both operands, one scatter -- instead of

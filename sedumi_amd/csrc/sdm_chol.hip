@@ -694,6 +694,9 @@ __device__ __forceinline__ void wait_prev_update(const int *cnt, int ns, int ms,
 // (k_ldl_front) every tile row below `panel` has applied the updates of the panels before it
 __device__ __forceinline__ void front_wait_updates(const int *upd_done, int panel, int T, int *tmo) {
   for (int r = panel + 1; r < T; r++) spin_until(upd_done + r, panel, tmo);
+  // the probe of the block's last column also looks at the first diagonal entry of the next block (what lies behind the column in
+  // L's storage): that tile's updates q <= panel - 1 are its tile workgroup's, counted in tile_cnt (behind upd_done)
+  if (panel + 1 < T && panel + 1 >= 2) spin_until(upd_done + FRONT_MAXT + (panel + 1) * FRONT_MAXT + panel + 1, panel, tmo);
 }
 // ---- the two inner pieces of the diagonal block's LDL' (ldl_diag_block describes the method; k_ldl_front's chain
 // workgroup runs the same pieces with a different cast of wavefronts).
@@ -1405,8 +1408,20 @@ __device__ SDM_NOINLINE void front_rows_diag(SDM_GP(double) Fs_, SDM_GP(const do
         const int c = 16 * blk + 4 * c4 + lk, row = R0 + li;
         const double dc = dsr[c], xv = Tw[c * 17 + li];
         const double l = (row < rend && dc > 0.0) ? xv / dc : 0.0;
-        if (row < rend) sdm_store_wt(&Fs[(int64_t)(k0 + c) * ld + row], l);
+        if (blk == 3 && row < rend) sdm_store_wt(&Fs[(int64_t)(k0 + c) * ld + row], l);
         Lt[ty * (NB * 17) + c * 17 + li] = l;
+      }
+    } else if (blk == 3 && ty >= 4) {
+      // the rows of the first three groups go to the front only NOW, when the last group has arrived: until then workgroup q may
+      // still take the general path for a later column of its block, and the column probe reads these rows' unsolved values
+      // from the front (a store per finished group -- the first form of this function -- replaced them with multipliers under
+      // the probe's eyes: wrong pivot decisions on rank-deficient fronts, profiles/r03ap_soak_def.txt).  The four wavefronts
+      // without rows of their own write them from Lt, beside the last group's substitution.
+      const int w = ty - 4, rowb = rbeg + 16 * w + li;
+#pragma unroll
+      for (int c4 = 0; c4 < 12; c4++) {
+        const int c = 4 * c4 + lk;
+        if (rowb < rend) sdm_store_wt(&Fs[(int64_t)(k0 + c) * ld + rowb], Lt[w * (NB * 17) + c * 17 + li]);
       }
     }
     if (blk < 2) continue;

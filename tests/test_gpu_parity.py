@@ -552,6 +552,11 @@ def test_one_launch_front_pivot_rule(refmex, m, maxu):
     helpers.check_one_launch_pivot_rule(refmex, m, maxu)
 
 
+def test_one_launch_front_rank_deficient_cases(refmex):
+    """40 seeded rank-deficient fronts of 320 .. 700 rows with probes anywhere in a block (helpers.check_rank_deficient_fronts)."""
+    helpers.check_rank_deficient_fronts(refmex, 40)
+
+
 def test_one_launch_front_is_deterministic_across_repeats(refmex):
     """20 factorisations of control07's shape in a row: the counters are re-armed by k_prep_pivots every time and the
     result never changes by a bit."""

@@ -10,7 +10,7 @@ from helpers import relerr, spd_pattern
 from oracle import glue as gl
 from oracle.refmex import RefMex, REF_DIR
 from sedumi_amd import mex, problem
-from test_emu_parity import _bordered_blocks
+from helpers import bordered_blocks as _bordered_blocks
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 ref = RefMex(REF_DIR)

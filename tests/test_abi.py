@@ -92,6 +92,27 @@ def test_panel_launch_publishes_only_after_its_stores_are_acknowledged(hiplib, t
     assert checked >= 2
 
 
+def test_chain_functions_of_the_one_launch_front_touch_no_scratch(hiplib, tmp_path):
+    """k_ldl_front calls its stages as real functions.  Those on the chain from one diagonal block to the next (the chain
+    workgroup's row solve front_rows_diag, the other workgroups' front_rows and front_update) must fit the registers a callee
+    may use freely: one that needs more saves and restores callee-saved VGPRs through scratch on EVERY call -- 152 scratch
+    instructions and 1.4 us per panel when an unrolled store loop in front_rows_diag did (round 3, profiles/r03aq / r03ar)."""
+    import shutil
+    lib = shutil.copy(hiplib, tmp_path / "lib.so")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    subprocess.run([objdump, "--offloading", str(lib)], capture_output=True, text=True, cwd=tmp_path)
+    found = {}
+    for f in sorted(os.listdir(tmp_path)):
+        if "gfx950" not in f:
+            continue
+        dis = subprocess.run([objdump, "-d", str(tmp_path / f)], capture_output=True, text=True).stdout
+        for name in ("front_rows_diag", "front_rows", "front_update"):
+            for sym, part in re.findall(r"^[0-9a-f]+ <([^>]*sdm\d+%s[A-Z][^>]*)>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)" % name, dis, flags=re.S | re.M):
+                found[name] = len(re.findall(r"\bscratch_(?:load|store)", part))
+    assert set(found) == {"front_rows_diag", "front_rows", "front_update"}, found
+    assert all(v == 0 for v in found.values()), found
+
+
 def test_loader_fails_loudly_without_library(tmp_path):
     from sedumi_amd import capi
     capi.use_library(str(tmp_path / "nope.so"))

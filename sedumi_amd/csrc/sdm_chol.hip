@@ -208,7 +208,6 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
     }
   }
   C.front_cnt.alloc((size_t)std::max(1, nslot) * FRONT_CNT);
-  C.front_shadow.alloc((size_t)std::max(1, nslot) * NB * TILE);
   C.d_fslot.upload(fslot);
   // upload
   C.d_first.upload(C.sn_first); C.d_ns.upload(C.sn_ns); C.d_ms.upload(C.sn_ms); C.d_ld.upload(C.sn_ld); C.d_parent.upload(C.sn_parent);
@@ -336,12 +335,9 @@ __global__ void k_extend_add(double *F, FrontTab tab, const int *list) {
 // doubles.
 __device__ __noinline__ double pivot_probe(const double (*S)[NB + 1], const double *Lc, int k, int kb, int k0, int ns,
                                            int ms, int ld, SDM_GP(const double) Fs_, const double *ds, SDM_GP(double) cb_,
-                                           double next_raw_diag, double *red_v, int *red_i, SDM_GP(const double) shadow_ = nullptr) {
+                                           double next_raw_diag, double *red_v, int *red_i) {
   SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
   const double *Fs = (const double *)Fs_;
-  // shadow (k_ldl_front): the unsolved values of the TILE rows right below the block, shadow[col * TILE + row] -- the front itself may
-  // already hold their multipliers for the columns that were handed on before the pivot that asked for this probe
-  const double *shadow = (const double *)shadow_;
   double *cb = (double *)cb_;
   const int tid = threadIdx.x, bs = blockDim.x;
   const int len = ms - (k0 + k) - 1;          // entries below the diagonal of this column
@@ -352,7 +348,7 @@ __device__ __noinline__ double pivot_probe(const double (*S)[NB + 1], const doub
     double x[NB];
     double diagacc = 0.0;
     for (int c = 0; c <= k; c++) {
-      double v = (shadow && r < k0 + kb + TILE) ? shadow[c * TILE + r - (k0 + kb)] : Fs[(int64_t)(k0 + c) * ld + r];
+      double v = Fs[(int64_t)(k0 + c) * ld + r];
       for (int j = 0; j < c; j++) v -= x[j] * Lc[j * NB + c];   // l_cj, scaled
       double dc = (c < k) ? ds[c] : 1.0;
       x[c] = (dc > 0.0) ? v : 0.0;
@@ -397,10 +393,9 @@ template <int NW, bool DIAG, bool WT = false, bool TW = false>
 __device__ __forceinline__ void update_tile(double *Fs, int ld, int ms, int first, int k0, int kb, int I, int J, const double *d,
                                             double (*As)[UTP], double (*Bs)[UTP], double *dsh,
                                             double (*S)[NB + 1] = nullptr, double *Lc = nullptr, int kbn = 0,
-                                            int tid = threadIdx.x, bool active = true, double *tw = nullptr, double *shadow = nullptr) {
+                                            int tid = threadIdx.x, bool active = true, double *tw = nullptr) {
   // TW: the result also goes to LDS as the row solve's wave tiles (tw[(row/16)*NB*17 + col*17 + row%16], columns
-  // beyond kbn zeroed) -- the workgroup that solves these rows next needs no second trip to HBM; shadow (k_ldl_front, the tile of the
-  // next chain workgroup): a second copy of the result in HBM, shadow[col * TILE + row], for the column probe (front_rows_diag)
+  // beyond kbn zeroed) -- the workgroup that solves these rows next needs no second trip to HBM
   // tid: position inside the group of NW wavefronts that shares the tile (two groups of one workgroup may run two
   // tiles side by side: same barriers); active = false: go through the motions (barriers) without storing
   constexpr int BJ = 8 / NW;                                  // 16-column MFMA tiles per wavefront along J
@@ -493,7 +488,6 @@ __device__ __forceinline__ void update_tile(double *Fs, int ld, int ms, int firs
           if (WT) sdm_store_wt(&Fs[(int64_t)gj * ld + gi], v); else Fs[(int64_t)gj * ld + gi] = v;
           if (DIAG && ti < kbn) S[ti][tj] = v;
           if (TW) tw[(ti >> 4) * (NB * 17) + tj * 17 + (ti & 15)] = tj < kbn ? v : 0.0;
-          if (TW && shadow) sdm_store_wt(&shadow[tj * TILE + ti], v);
         }
       }
   SDM_PHASE(DIAG ? 31 : 30);
@@ -826,8 +820,7 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
                                                const double *lbs_pre = nullptr, int *owed_a = nullptr, int *owed_b = nullptr) {
   // owed_a / owed_b (k_ldl_front): counters the workgroup owes for write-through stores it issued just before this block (the rows of L of
   // the chain's row solve): counted behind the first sweep, when their acknowledgements have long arrived -- not waited for on the chain
-  // lbs_pre (k_ldl_front): the block's pivot thresholds, fetched into LDS when the workgroup started (one global round trip off the chain);
-  // behind them, in lbs_pre[NB], the address of the front's shadow tile (pivot_probe)
+  // lbs_pre (k_ldl_front): the block's pivot thresholds, fetched into LDS when the workgroup started (one global round trip off the chain)
   // pub_skip (k_ldl_front's chain workgroup redoing a block on the general path): 16-column groups of this block already counted in diag_cnt
   // raw_in_lds (k_ldl_front): the raw block is not in the front but in LDS behind the wave tiles (front_rows_diag)
   SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
@@ -951,9 +944,7 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
         if (ms - (k0 + k) > 1 && xkk < ub) {                         // rare: stability probe of the never-fail rule
           double nraw = 0.0;
           if (k0 + k + 1 >= ns && first + ns < mtot) { int sidx = asm_src[Ljc[first + ns]]; nraw = sidx < 0 ? 0.0 : ada[sidx]; }
-          // (k_ldl_front from panel 1 on: the chain workgroup below stores its solved rows group by group, the probe reads their shadow)
-          const double *shadow = (PERSIST && lbs_pre && panel >= 1 && k0 + kb < ns) ? *(const double *const *)&lbs_pre[NB] : nullptr;
-          const double ubk = pivot_probe(S, Lc, k, kb, k0, ns, ms, ld, (SDM_GP(const double))Fs, ds, (SDM_GP(double))cb, nraw, red_v, red_i, (SDM_GP(const double))shadow) / maxu;
+          const double ubk = pivot_probe(S, Lc, k, kb, k0, ns, ms, ld, (SDM_GP(const double))Fs, ds, (SDM_GP(double))cb, nraw, red_v, red_i) / maxu;
           if (xkk < ubk) {
             if (tid == 0) { stt[k] = 2; pv[k] = ubk - xkk; lbs[k] = ubk - xkk; }
             xkk = ubk;
@@ -1347,8 +1338,7 @@ __device__ SDM_NOINLINE void front_update(int kind, SDM_GP(double) Fs_, int ld, 
   double (*As)[UTP] = (double (*)[UTP])smem;
   double (*Bs)[UTP] = As + NB;
   double *RB = (double *)smem + NB * (NB + 1);
-  if (kind == 2) update_tile<LDL_THREADS / 64, false, true, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh, nullptr, nullptr, kbn, threadIdx.x, true, RB,
-                                                                  I == 1 ? *(double *const *)&dsh[NB] : nullptr);   // the tile of the next chain workgroup: also to the front's shadow
+  if (kind == 2) update_tile<LDL_THREADS / 64, false, true, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh, nullptr, nullptr, kbn, threadIdx.x, true, RB);
   else update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh);
 }
 // R: rows of tile row r against the diagonal block of panel q as it is published; have_tw: the tile is in the wave tiles already
@@ -1378,14 +1368,15 @@ __device__ SDM_NOINLINE void front_rows(SDM_GP(double) Fs_, SDM_GP(const double)
   __syncthreads();
 }
 // The two of them fused for the workgroup on the chain (r = q + 1): the rows are solved 16 columns at a time as before, but
-// every finished 16-column block is scaled (l = x / d, as rows_store does), stored write-through AND kept in LDS (Lt, the
-// wave tiles the four idle wavefronts do not use), and the update of the workgroup's own diagonal tile reads its operands
+// every finished 16-column block is scaled (l = x / d, as rows_store does) and kept in LDS (Lt, the wave tiles the four idle
+// wavefronts do not use; it goes to the front write-through when the LAST block has arrived -- the column probe of the diagonal
+// block's workgroup must find the rows unsolved until then), and the update of the workgroup's own diagonal tile reads its operands
 // from there -- A operand l, B operand l * d, the products in the same k order as update_tile, so the same bits.  The
 // K = 48 part of the update runs while the last 16 columns of the diagonal block are still being factored; after they
 // arrive only their triangle, 4 of the 16 k-steps and the epilogue are left.  The raw updated block stays in LDS (cvl:
 // the general path of the LDL' reloads it from there); it reaches the front as the factored block.
 __device__ SDM_NOINLINE void front_rows_diag(SDM_GP(double) Fs_, SDM_GP(const double) Ds_, SDM_GP(const double) d_, int ld, int ms, int first, int q, int r, char *smem,
-                                             double *dsr, SDM_GP(const int) diag_cnt_s_, SDM_GP(int) tmo_, bool have_tw, int kbn, bool defer) {
+                                             double *dsr, SDM_GP(const int) diag_cnt_s_, SDM_GP(int) tmo_, bool have_tw, int kbn) {
   double *Fs = (double *)Fs_;
   const double *Ds = (const double *)Ds_;
   const double *d = (const double *)d_;
@@ -1418,16 +1409,18 @@ __device__ SDM_NOINLINE void front_rows_diag(SDM_GP(double) Fs_, SDM_GP(const do
         const int c = 16 * blk + 4 * c4 + lk, row = R0 + li;
         const double dc = dsr[c], xv = Tw[c * 17 + li];
         const double l = (row < rend && dc > 0.0) ? xv / dc : 0.0;
-        if ((blk == 3 || !defer) && row < rend) sdm_store_wt(&Fs[(int64_t)(k0 + c) * ld + row], l);
+        if (blk == 3 && row < rend) sdm_store_wt(&Fs[(int64_t)(k0 + c) * ld + row], l);
         Lt[ty * (NB * 17) + c * 17 + li] = l;
       }
-    } else if (defer && blk == 3 && ty >= 4) {
-      // defer (panel 0): the rows of the first three groups go to the front only NOW, when the last group has arrived.  Until then
-      // workgroup q may still take the general path for a later column of its block, and the column probe reads these rows'
-      // unsolved values (a store per finished group replaced them with multipliers under the probe's eyes: wrong pivot decisions
-      // on rank-deficient fronts, profiles/r03ap_soak_def.txt).  The four wavefronts without rows of their own write them from
-      // Lt, beside the last group's substitution.  From panel 1 on the tile's last update left a shadow copy of the unsolved rows
-      // for the probe (update_tile), and every group is stored as it is finished: 1.4 us per panel less on the chain.
+    } else if (blk == 3 && ty >= 4) {
+      // the rows of the first three groups go to the front only NOW, when the last group has arrived.  Until then workgroup q may
+      // still take the general path for a later column of its block, and the column probe reads these rows' unsolved values
+      // from the front (a store per finished group -- the first form of this function -- replaced them with multipliers under
+      // the probe's eyes: wrong pivot decisions on rank-deficient fronts, profiles/r03ap_soak_def.txt).  The four wavefronts
+      // without rows of their own write them from Lt, beside the last group's substitution.  (Keeping the store per group and
+      // giving the probe a shadow copy of the unsolved rows is no faster: profiles/r03at.  The loop must NOT be unrolled: with
+      // 12 loads and addresses in flight the function needs callee-saved VGPRs and saves 76 of them through scratch on every
+      // call, 1.4 us per panel -- tests/test_abi.py checks.)
       const int w = ty - 4, rowb = rbeg + 16 * w + li;
 #pragma unroll 1
       for (int c4 = 0; c4 < 12; c4++) {
@@ -1482,7 +1475,7 @@ __device__ SDM_NOINLINE void front_rows_diag(SDM_GP(double) Fs_, SDM_GP(const do
 __global__ void __launch_bounds__(LDL_THREADS)
 k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, double *lb, const double *ubp, int *pivstat,
             double *pivval, double *colbuf, const double *ada, const int *asm_src, const int64_t *Ljc, int mtot, int *front_cnt,
-            double *front_shadow, int *diag_cnt, int phase, int step, int tile_wg0, int *tmo) {
+            int *diag_cnt, int phase, int step, int tile_wg0, int *tmo) {
   SDM_FP_STRICT;
   SDM_DYN_SMEM(smem);
   const int s = list[blockIdx.y];
@@ -1490,7 +1483,7 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
   const int T = (ms + TILE - 1) / TILE, NP = (ns + NB - 1) / NB;
   double *Fs = F + tab.foff[s];
   int *row_cnt = front_cnt + (int64_t)tab.fslot[s] * FRONT_CNT, *upd_done = row_cnt + FRONT_MAXT, *tile_cnt = upd_done + FRONT_MAXT;
-  __shared__ double dsh[NB + 1], ds[NB], dsr[NB];
+  __shared__ double dsh[NB], ds[NB], dsr[NB];
   __shared__ int npub;
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= tile_wg0) {
@@ -1524,8 +1517,7 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
   FrontDesc fd;
   fd.ns = ns; fd.ms = ms; fd.ld = ld; fd.first = first; fd.foff = tab.foff[s]; fd.toff = tab.toff[s]; fd.woff = tab.woff[s];
   fd.maxu = ubp[1]; fd.ub = ubp[2] / (fd.maxu * fd.maxu);
-  __shared__ double lbs_pre[NB + 1];                                   // [NB]: the address of the front's shadow tile; dsh[NB] likewise
-  if (tid == 0) { double *sh = front_shadow + (int64_t)tab.fslot[s] * (NB * TILE); *(double **)&lbs_pre[NB] = sh; *(double **)&dsh[NB] = sh; }
+  __shared__ double lbs_pre[NB];
   if (carry && r < NP && tid < NB) lbs_pre[tid] = r * NB + tid < ns ? lb[first + r * NB + tid] : 0.0;      // thresholds of the block this workgroup will factor
   bool have_S = false, have_tw = false, raw_in_lds = false, owed = false;
   for (int q = carry ? 0 : step; q < (carry ? NP : step + 1) && q <= r; q++) {
@@ -1575,7 +1567,7 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
       // ---- R: 16 rows per wavefront (4 of the 8 busy), following the diagonal block as workgroup q publishes it
       if (crit_lds) front_rows_diag((SDM_GP(double))Fs, (SDM_GP(const double))(DT + tab.toff[s] + (int64_t)q * NB * NB), (SDM_GP(const double))d, ld, ms, first, q, r, smem, dsr, (SDM_GP(const int))(diag_cnt + s),
                                     (SDM_GP(int))tmo, have_tw,
-                                    min(NB, ns - (q + 1) * NB), q == 0);
+                                    min(NB, ns - (q + 1) * NB));
       else front_rows((SDM_GP(double))Fs, (SDM_GP(const double))(DT + tab.toff[s] + (int64_t)q * NB * NB), (SDM_GP(const double))d, ld, ms, first, q, kb, r, smem, dsr, (SDM_GP(const int))(diag_cnt + s),
                       (SDM_GP(int))tmo, have_tw, false);
       SDM_FPHASE(1);
@@ -1607,7 +1599,6 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
         SDM_FPHASE(3);                                                // fence + counters
         const int I = r - c1, J = 0;
         const int kbn = min(NB, ns - c1 * NB);                        // columns of the next panel (<= 0: none)
-        // (the tile of the NEXT chain workgroup also goes to the front's shadow: the column probe of diagonal block c1 reads it there)
         if (c1 < r && carry && c1 < NP) { front_update(2, (SDM_GP(double))Fs, ld, ms, first, k0, I, J, (SDM_GP(const double))d, smem, dsh, kbn); have_tw = true; }
         else front_update(0, (SDM_GP(double))Fs, ld, ms, first, k0, I, J, (SDM_GP(const double))d, smem, dsh, kbn);
       }
@@ -1728,7 +1719,7 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
       for (int step = 0; step < maxnp; step++)
         for (int phase = 1; phase <= 3; phase++)
           SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
-                      C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p, C.front_shadow.p,
+                      C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p,
                       C.diag_cnt.p, phase, step, C.lev_maxT[l], C.tmo.dev());
       if (follow) solve_follow(P, l, st);                            // (workgroups run one after the other here: behind = after)
 #else
@@ -1749,7 +1740,7 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
         SDM_HIP_CHECK(hipStreamWaitEvent(P->stream2, P->ev_fork, 0));
       }
       SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
-                  C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p, C.front_shadow.p,
+                  C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p,
                   C.diag_cnt.p, 0, 0, C.lev_maxT[l], C.tmo.dev());
       if (follow) {
         solve_follow(P, l, P->stream2);

@@ -169,7 +169,6 @@ struct CholPlan {
   DevBuf<int> d_asm_fsrc;  // arena entry -> ADA value index (k_assemble_full), empty for arenas above ASM_FULL_MAX entries
   DevBuf<int> front_cnt;   // k_ldl_front: FRONT_CNT counters per front of a one-launch level (slot d_fslot[s]): rows solved through
                            // panel / update steps finished per tile row, updates applied per tile
-  DevBuf<double> front_shadow;   // k_ldl_front: NB x TILE doubles per slot, the unsolved rows of the next chain workgroup's tile (for the column probe)
   DevBuf<int> d_fslot;     // front -> its slot in front_cnt (fronts of other levels: 0, unused)
   std::vector<char> lev_persist;   // level factored by ONE k_ldl_front launch (all its fronts qualify)
   std::vector<int> lev_maxT;       // its grid: tile rows of the tallest front ...

@@ -1716,6 +1716,13 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
 #ifdef SDM_EMU
       int maxnp = 0;
       for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) maxnp = std::max(maxnp, (C.sn_ns[C.levlist[i]] + NB - 1) / NB);
+      if (emu_concurrent()) {
+        // the kernel exactly as the GPU runs it (phase 0: everything carried in LDS, the fused row solve of the chain workgroup,
+        // the data-tagged hand-over): one process per workgroup, all at once (tests/hipemu: emu_launch_concurrent)
+        SDM_KLAUNCH_CONCURRENT(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
+                               C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p,
+                               C.diag_cnt.p, 0, 0, C.lev_maxT[l], C.tmo.dev());
+      } else
       for (int step = 0; step < maxnp; step++)
         for (int phase = 1; phase <= 3; phase++)
           SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,

@@ -345,6 +345,16 @@ struct sdm_plan {
     }                                                                                      \
   } while (0)
 #define SDM_KLAUNCH(P, kernel, grid, block, shmem, ...) SDM_KLAUNCH_ON(P, (P)->stream, kernel, grid, block, shmem, __VA_ARGS__)
+#ifdef SDM_EMU
+// (tests/hipemu only) a launch whose workgroups wait for each other, as one process per workgroup: emu_launch_concurrent
+#define SDM_KLAUNCH_CONCURRENT(P, kernel, grid, block, shmem, ...)                             \
+  do {                                                                                         \
+    sdm::KProf::Rec r_; r_.name = #kernel;                                                     \
+    if ((P)->kprof.enabled) { r_.a = (P)->kprof.get(); r_.b = (P)->kprof.get(); SDM_HIP_CHECK(hipEventRecord(r_.a, (P)->stream)); } \
+    SDM_LAUNCH_CONCURRENT(kernel, grid, block, shmem, __VA_ARGS__);                            \
+    if ((P)->kprof.enabled) { SDM_HIP_CHECK(hipEventRecord(r_.b, (P)->stream)); (P)->kprof.recs.push_back(r_); } \
+  } while (0)
+#endif
 
 namespace sdm {
 // Two launches whose workgroups all have to be resident (k_ldl_front) of different plans (streams) must

@@ -19,19 +19,21 @@ inline double sdm_bcast_lane(double v, int lane) { return emu_shfl(v, lane, 0); 
 #define SDM_SETPRIO(n) do {} while (0)
 // predicate of lane `lane` (uniform), delivered to every lane
 inline bool sdm_lane_pred(bool pred, int lane) { return emu_shfl(pred ? 1.0 : 0.0, lane, 0) != 0.0; }
-// completion counters between workgroups of one launch (the emulator runs workgroups one after the other)
-inline void sdm_signal_add(int *p, int n = 1) { *p += n; }
-inline void sdm_store_wt(double *p, double v) { *p = v; }
-inline double sdm_load_wt(const double *p) { return *p; }
-inline void sdm_store_wt2(double *p, double a, double b) { p[0] = a; p[1] = b; }
-inline unsigned long long sdm_load_wt_u64(const unsigned long long *p) { return *p; }
-#define SDM_STORES_DONE() do {} while (0)
-inline int sdm_signal_load(const int *p) { return *p; }
-inline void sdm_raise_flag(int *p) { *p = 1; }
+// completion counters and published data between workgroups of one launch.  The emulator runs workgroups one after the other --
+// or, for a launch whose workgroups wait for each other (emu_launch_concurrent), as processes side by side over shared memory:
+// hence real atomics, volatile accesses and fences here (x86-64: aligned 8-byte accesses are single copies, stores stay in order)
+inline void sdm_signal_add(int *p, int n = 1) { __atomic_fetch_add(p, n, __ATOMIC_SEQ_CST); }
+inline void sdm_store_wt(double *p, double v) { *(volatile double *)p = v; }
+inline double sdm_load_wt(const double *p) { return *(const volatile double *)p; }
+inline void sdm_store_wt2(double *p, double a, double b) { ((volatile double *)p)[0] = a; ((volatile double *)p)[1] = b; }
+inline unsigned long long sdm_load_wt_u64(const unsigned long long *p) { return *(const volatile unsigned long long *)p; }
+#define SDM_STORES_DONE() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+inline int sdm_signal_load(const int *p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+inline void sdm_raise_flag(int *p) { __atomic_store_n(p, 1, __ATOMIC_SEQ_CST); emu_report_timeout(); }
 #define SDM_UNIFORM_INT(x) (x)
-#define SDM_ACQUIRE_FENCE() do {} while (0)
-#define SDM_COMPILER_BARRIER() do {} while (0)
-#define SDM_SPIN_PAUSE() do { fprintf(stderr, "hipemu: waiting on a workgroup that has not run\n"); abort(); } while (0)
+#define SDM_ACQUIRE_FENCE() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define SDM_COMPILER_BARRIER() __asm__ __volatile__("" ::: "memory")
+#define SDM_SPIN_PAUSE() emu_spin_pause()
 #else
 #include <hip/hip_runtime.h>
 typedef double sdm_double4 __attribute__((ext_vector_type(4)));

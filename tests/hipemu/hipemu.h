@@ -65,11 +65,15 @@ enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMe
 
 inline const char *hipGetErrorString(hipError_t) { return "emu"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
+/* "device" and pinned memory: anonymous SHARED mappings, so that the workgroup processes of a concurrent launch
+   (emu_launch_concurrent) and the host see the same bytes */
+void *emu_shared_alloc(size_t n);
+void emu_shared_free(void *p);
+inline hipError_t hipMalloc(void **p, size_t n) { *p = emu_shared_alloc(n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
 template <class T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
-inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
-inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
-inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipFree(void *p) { emu_shared_free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = emu_shared_alloc(n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
+inline hipError_t hipHostFree(void *p) { emu_shared_free(p); return hipSuccess; }
 inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned = 0) { *d = h; return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = 0) { if (n) memcpy(d, s, n); return hipSuccess; }
@@ -103,6 +107,18 @@ inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorU
 void emu_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body, const char *name = "?");
 #define SDM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
   emu_launch((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); }, #kernel)
+/* launch of a kernel whose workgroups WAIT FOR EACH OTHER (k_ldl_front): one forked process per workgroup, all running
+   at once over the shared "device" memory, each a ring of fibers as above; throws if one of them fails or they stall.
+   Only used when the test asked for it (emu_set_concurrent): the default remains the phase-by-phase sequential form. */
+void emu_launch_concurrent(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body, const char *name = "?");
+#define SDM_LAUNCH_CONCURRENT(kernel, grid, block, shmem, ...) \
+  emu_launch_concurrent((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); }, #kernel)
+void emu_set_concurrent(int on);
+int emu_concurrent();
+/* inside a spin loop on another workgroup's progress: yields the processor in a workgroup process, aborts in a sequential
+   launch (there the other workgroup has either run already or never will) */
+void emu_spin_pause();
+void emu_report_timeout();
 
 /* ---- wave-level operations (wave = 64 consecutive linear thread ids) ---- */
 double emu_shfl(double v, int srcLane, int mode);  /* mode 0: idx, 1: down(delta), 2: xor(mask) */
@@ -122,12 +138,12 @@ struct emu_double4 {
    result reg r of lane l is D[(l>>4)+4r][l&15]  (cdna_hip_programming.md section 3) */
 emu_double4 emu_mfma_f64_16x16x4(double a, double b, emu_double4 c);
 
-inline double atomicAdd(double *p, double v) { double o = *p; *p = o + v; return o; }
-inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
-inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+inline double atomicAdd(double *p, double v) { double o = *p; *p = o + v; return o; }   /* (no kernel of a concurrent launch adds doubles) */
+inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
 inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
-inline int atomicExch(int *p, int v) { int o = *p; *p = v; return o; }
+inline int atomicExch(int *p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 
 /* scheduling order knob: 0 ascending lanes, 1 descending (exposes missing barriers) */
 void emu_set_reverse(int rev);

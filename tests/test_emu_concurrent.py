@@ -1,0 +1,93 @@
+"""k_ldl_front exactly as the GPU runs it -- ONE launch, every workgroup waiting for the others' progress, the chain
+workgroup's fused row solve, the data-tagged hand-over of the diagonal blocks -- on the CPU: the emulator forks one
+process per workgroup over shared "device" memory (tests/hipemu: emu_launch_concurrent) instead of stepping the launch
+through its phases.  Same sources, same arithmetic; what differs from the device is only the timing, which is the point:
+an ordering the kernel relies on without enforcing it shows up here (the reintroduced round-3 bug -- rows stored under the
+column probe of a later group -- fails 20 of 80 of the cases below)."""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import helpers
+from helpers import TOL, relerr
+
+
+@pytest.fixture()
+def concurrent_emu():
+    helpers.use_emu()
+    from hipemu import build_emu
+    lib = ctypes.CDLL(build_emu.build())
+    lib._Z18emu_set_concurrenti(1)
+    yield lib
+    lib._Z18emu_set_concurrenti(0)
+
+
+def _dense_front(m, seed):
+    rng = np.random.default_rng(seed)
+    B = rng.standard_normal((m, m))
+    X = sp.csc_matrix(B @ B.T + m * np.eye(m)); X.sort_indices()
+    return X, rng.standard_normal(m)
+
+
+def _factor_solve(m, seed, lib, concurrent):
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    X, rhs = _dense_front(m, seed)
+    lib._Z18emu_set_concurrenti(int(concurrent))
+    plan = Plan(0)
+    plan.set_chol(problem.dense_symbolic(m), X)
+    plan.upload("ada", X.data); plan.upload("rhs", rhs)
+    plan.kprof(True)
+    plan.blkchol(None, False); plan.ldlsolve()
+    names = set(plan.kprof_summary().keys())
+    plan.kprof(False)
+    return plan.download("lpr"), plan.download("d"), plan.download("y"), names
+
+
+@pytest.mark.parametrize("m", [330, 400, 666])
+def test_concurrent_workgroups_give_the_bits_of_the_phased_launch(refmex, concurrent_emu, m):
+    """m = 330: 6 row + 10 tile workgroups; 400: a partial last tile row; 666 (control07's shape): 11 + 45 processes."""
+    from oracle import glue as gl
+    from sedumi_amd import problem
+    l1, d1, y1, k1 = _factor_solve(m, m, concurrent_emu, True)
+    l0, d0, y0, k0 = _factor_solve(m, m, concurrent_emu, False)
+    assert "k_ldl_front" in k0 and "k_ldl_panel" not in k0 and "k_ldl_front" in k1 and "k_ldl_panel" not in k1
+    assert np.array_equal(l1, l0) and np.array_equal(d1, d0) and np.array_equal(y1, y0)
+    X, _ = _dense_front(m, m)
+    r = refmex.call("blkchol", 4, problem.dense_symbolic(m), X, gl.default_pars_chol())
+    assert relerr(d1, r[1].ravel()) < TOL and relerr(l1, sp.csc_matrix(r[0]).data) < TOL
+
+
+def test_rank_deficient_fronts_as_concurrent_workgroups(refmex, concurrent_emu):
+    """The cases of the GPU soak (helpers.rank_deficient_front_case, 320 .. 450 rows here): skip / add decisions index by
+    index and the pivots of the reference, with the column probe anywhere in a block."""
+    from sedumi_amd import mex
+    rng = np.random.default_rng(777)
+    nadd = 0
+    for case in range(30):
+        args = helpers.rank_deficient_front_case(rng, 320, 450)
+        rr = refmex.call("blkchol", 4, *args)
+        o = mex.blkchol(*args)
+        assert np.array_equal(o[2].indices, rr[2].indices) and np.array_equal(o[3].indices, rr[3].indices), (case, o[3].nnz, rr[3].nnz)
+        assert relerr(o[1], rr[1]) < 1e-8, case
+        nadd += rr[3].nnz
+    assert nadd > 0
+
+
+@pytest.mark.parametrize("m,maxu", [(400, 30.0), (400, 2.0)])
+def test_pivot_rule_as_concurrent_workgroups(refmex, concurrent_emu, m, maxu):
+    helpers.check_one_launch_pivot_rule(refmex, m, maxu)
+
+
+@pytest.mark.parametrize("two_leaves", [False, True])
+def test_levels_with_rows_below_as_concurrent_workgroups(refmex, glue, concurrent_emu, two_leaves):
+    """Fronts with rows below their columns (update matrix for the parent), two fronts in one launch (grid.y = 2)."""
+    helpers.check_one_launch_levels(refmex, glue, two_leaves)
+
+
+def test_control07_unit_as_concurrent_workgroups(concurrent_emu):
+    """The bench workload's iteration unit against its golden reference outputs, the factorisation as 56 concurrent processes."""
+    errs = helpers.check_golden("control07", "rand")
+    assert max(errs.values()) < TOL, errs

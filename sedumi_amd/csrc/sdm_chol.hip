@@ -1231,16 +1231,16 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   //   small fronts:                      tiles (never wait) < diagonal block (its in-workgroup row solve waits for them).
   // The emulator runs them one after the other in the order  tiles, row solves (phase 1: their update tile only),
   // diagonal block.
-#ifdef SDM_EMU
-  const int bx = (int)gridDim.x - 1 - (int)blockIdx.x;
-#else
   int bx = blockIdx.x;
+#ifdef SDM_EMU
+  if (phase != 0) bx = (int)gridDim.x - 1 - (int)blockIdx.x;        // (phase 0 in the emulator: its workgroups run as concurrent processes, roles as on the device)
+  else
+#endif
   if (nrw == 0) {
     const int ntw = panel > 0 ? (nt * (nt + 1) / 2) / 2 : 0;
     if (bx > ntw) return;
     bx = bx < ntw ? 1 + bx : 0;
   }
-#endif
   if (bx > 0 && bx <= nrw) {
     panel_role_rows(smem, Fs, DT + tab.toff[s] + (int64_t)panel * NB * NB, d, ns, ms, ld, first, panel, bx - 1, upd_cnt + s, diag_cnt + s, phase, tmo);
     return;
@@ -1717,12 +1717,16 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
       int maxnp = 0;
       for (int i = C.levptr[l]; i < C.levptr[l + 1]; i++) maxnp = std::max(maxnp, (C.sn_ns[C.levlist[i]] + NB - 1) / NB);
       if (emu_concurrent()) {
+        emu_group_begin();
         // the kernel exactly as the GPU runs it (phase 0: everything carried in LDS, the fused row solve of the chain workgroup,
         // the data-tagged hand-over): one process per workgroup, all at once (tests/hipemu: emu_launch_concurrent)
         SDM_KLAUNCH_CONCURRENT(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
                                C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p,
                                C.diag_cnt.p, 0, 0, C.lev_maxT[l], C.tmo.dev());
-      } else
+        if (follow) solve_follow(P, l, st);                          // beside it, polling its counters -- as on the second stream of the device
+        emu_group_end();
+        continue;
+      }
       for (int step = 0; step < maxnp; step++)
         for (int phase = 1; phase <= 3; phase++)
           SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
@@ -1762,6 +1766,10 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
       // ONE launch per panel: diagonal block (+ tile 0 of the previous panel's update), the row solves and the rest of
       // the previous update (see k_ldl_panel).  The emulator runs it in two phases (workgroups are sequential there).
 #ifdef SDM_EMU
+      if (emu_concurrent() && (1 + L.ride_wgs) * L.nactive <= 200)   // as on the device: one launch, the roles wait for each other (one process per workgroup)
+        SDM_KLAUNCH_CONCURRENT(P, k_ldl_panel, dim3(1 + L.ride_wgs, L.nactive), dim3(LDL_THREADS), PANEL_LDS_RIDE, C.fronts.p, C.frontsT.p, tab, list,
+                               L.panel, C.d.p, C.panel_ctx.p, C.upd_cnt.p, C.diag_cnt.p, 1, 0, C.tmo.dev());
+      else
       for (int phase = 1; phase <= 2; phase++)
 #else
       const int phase = 0;

@@ -27,7 +27,10 @@ inline void sdm_store_wt(double *p, double v) { *(volatile double *)p = v; }
 inline double sdm_load_wt(const double *p) { return *(const volatile double *)p; }
 inline void sdm_store_wt2(double *p, double a, double b) { ((volatile double *)p)[0] = a; ((volatile double *)p)[1] = b; }
 inline unsigned long long sdm_load_wt_u64(const unsigned long long *p) { return *(const volatile unsigned long long *)p; }
-#define SDM_STORES_DONE() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+// ("this WAVEFRONT's stores have been acknowledged": the lanes of a wavefront issue their stores together, so lane 0 may signal
+// for all of them afterwards -- here the lanes are fibers that run one after the other, and the rendezvous is what makes the
+// other lanes' stores precede lane 0's signal.  Every call site is wave-uniform; one that is not would stall the emulator.)
+#define SDM_STORES_DONE() do { (void)emu_shfl(0.0, 0, 0); __atomic_thread_fence(__ATOMIC_SEQ_CST); } while (0)
 inline int sdm_signal_load(const int *p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 inline void sdm_raise_flag(int *p) { __atomic_store_n(p, 1, __ATOMIC_SEQ_CST); emu_report_timeout(); }
 #define SDM_UNIFORM_INT(x) (x)

@@ -1196,6 +1196,13 @@ void solve_prepare(sdm_plan *P, bool sb_g_is_zero) {
   if (C.n_lt) SDM_KLAUNCH(P, k_ltrans, dim3(C.n_lt), dim3(ST), 0, C.fronts.p, C.LT.p, tab, C.l_lt.p, W);
   if (C.n_i128 == 0) return;
   if (C.n_i128 + C.n_items <= SPREP_MAX_ITEMS) {                    // everything resident at once: one launch, counters instead of boundaries
+#ifdef SDM_EMU
+    if (emu_concurrent() && C.n_i128 + C.n_items <= 200) {          // as on the device: its workgroups wait for each other's counters (one process each)
+      SDM_KLAUNCH_CONCURRENT(P, k_sprep, dim3(C.n_i128 + C.n_items), dim3(ST), INV_LDS, C.fronts.p, C.S.p, C.ST.p, C.Tarena.p, tab, C.l_i128.p, C.n_i128,
+                             C.l_items.p, C.sb_g.p, (int *)(C.sb_g.p + 2 * std::max(C.nsbtot, 1)), W, C.tmo.dev());
+      return;
+    }
+#endif
     SDM_KLAUNCH(P, k_sprep, dim3(C.n_i128 + C.n_items), dim3(ST), INV_LDS, C.fronts.p, C.S.p, C.ST.p, C.Tarena.p, tab, C.l_i128.p, C.n_i128,
                 C.l_items.p, C.sb_g.p, (int *)(C.sb_g.p + 2 * std::max(C.nsbtot, 1)), W, C.tmo.dev());
     return;

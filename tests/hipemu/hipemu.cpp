@@ -63,6 +63,9 @@ unsigned long g_progress = 0;
 int g_reverse = 0;
 int g_concurrent = 0;        /* tests: launches of kernels with inter-workgroup waits run one process per workgroup */
 bool g_in_wg_process = false;
+bool g_group_open = false;   /* launches between emu_group_begin / _end run side by side: their processes are waited for at the end */
+std::vector<pid_t> g_group_kids;
+std::string g_group_names;
 bool g_spinning = false;     /* some work-item of the round polled another workgroup (emu_spin_pause) */
 constexpr size_t SHARED_HDR = 256;
 
@@ -211,11 +214,50 @@ void run_block(unsigned bx, unsigned by, unsigned bz, dim3 block, int nthr, cons
 void emu_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body, const char *name) {
   const int nthr = (int)(block.x * block.y * block.z);
   if (nthr <= 0 || grid.x * grid.y * grid.z == 0) return;
+  if (g_group_open) { emu_launch_concurrent(grid, block, shmem, body, name); return; }
   prepare_launch(grid, block, shmem, body, nthr);
   for (unsigned bz = 0; bz < grid.z; bz++)
     for (unsigned by = 0; by < grid.y; by++)
       for (unsigned bx = 0; bx < grid.x; bx++) run_block(bx, by, bz, block, nthr, name);
   g_body = nullptr;
+}
+
+/* wait for exactly these processes; a failed one or a stall (10 minutes) ends them all */
+static void wait_for(const std::vector<pid_t> &kids, const char *name) {
+  const auto t0 = std::chrono::steady_clock::now();
+  size_t left = kids.size();
+  std::vector<char> done(kids.size(), 0);
+  bool failed = false, asked = false;
+  auto t_last = t0;
+  while (left > 0 && !failed) {
+    bool any = false;
+    for (size_t i = 0; i < kids.size(); i++) {
+      if (done[i]) continue;
+      int st = 0;
+      pid_t r = waitpid(kids[i], &st, WNOHANG);
+      if (r == kids[i]) {
+        done[i] = 1; left--; any = true;
+        if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0)) {
+          failed = true;
+          fprintf(stderr, "hipemu: workgroup process %zu of %s ended with %s %d\n", i, name, WIFSIGNALED(st) ? "signal" : "exit code", WIFSIGNALED(st) ? WTERMSIG(st) : WEXITSTATUS(st));
+        }
+      }
+    }
+    const auto now = std::chrono::steady_clock::now();
+    if (any) t_last = now; else usleep(2000);
+    if (!asked && std::chrono::duration<double>(now - t_last).count() > 20.0) {
+      asked = true;                               /* no workgroup has finished for 20 s: ask the remaining ones where they are (once) */
+      for (size_t i = 0; i < kids.size(); i++) if (!done[i]) kill(kids[i], SIGUSR1);
+    }
+    if (std::chrono::duration<double>(now - t0).count() > 600.0) {
+      failed = true;
+      fprintf(stderr, "hipemu: %s stalled (%zu workgroups still running after 10 minutes)\n", name, left);
+    }
+  }
+  if (failed) {
+    for (size_t i = 0; i < kids.size(); i++) if (!done[i]) { kill(kids[i], SIGKILL); waitpid(kids[i], nullptr, 0); }
+    throw std::runtime_error(std::string("hipemu: a workgroup process of ") + name + " failed or the launch stalled");
+  }
 }
 
 void emu_report_timeout() {                        /* a spin of a kernel gave up (sdm_raise_flag): say which workgroup and where */
@@ -252,7 +294,12 @@ void emu_launch_concurrent(dim3 grid, dim3 block, size_t shmem, const std::funct
     for (unsigned by = 0; by < grid.y; by++)
       for (unsigned bx = 0; bx < grid.x; bx++) {
         pid_t pid = fork();
-        if (pid < 0) { for (pid_t k : kids) { kill(k, SIGKILL); waitpid(k, nullptr, 0); } throw std::runtime_error("hipemu: fork failed"); }
+        if (pid < 0) {
+          kids.insert(kids.end(), g_group_kids.begin(), g_group_kids.end());
+          g_group_kids.clear(); g_group_open = false;
+          for (pid_t k : kids) { kill(k, SIGKILL); waitpid(k, nullptr, 0); }
+          throw std::runtime_error("hipemu: fork failed");
+        }
         if (pid == 0) {                              /* the workgroup's process: its statics (= LDS) are its own from here on */
           g_in_wg_process = true;
           signal(SIGSEGV, wg_crash);
@@ -263,41 +310,16 @@ void emu_launch_concurrent(dim3 grid, dim3 block, size_t shmem, const std::funct
         kids.push_back(pid);
       }
   g_body = nullptr;
-  /* wait for exactly the processes started above; a failed one or a stall (10 minutes) ends them all */
-  const auto t0 = std::chrono::steady_clock::now();
-  size_t left = kids.size();
-  std::vector<char> done(kids.size(), 0);
-  bool failed = false, asked = false;
-  auto t_last = t0;
-  while (left > 0 && !failed) {
-    bool any = false;
-    for (size_t i = 0; i < kids.size(); i++) {
-      if (done[i]) continue;
-      int st = 0;
-      pid_t r = waitpid(kids[i], &st, WNOHANG);
-      if (r == kids[i]) {
-        done[i] = 1; left--; any = true;
-        if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0)) {
-          failed = true;
-          fprintf(stderr, "hipemu: workgroup %zu of %s ended with %s %d\n", i, name, WIFSIGNALED(st) ? "signal" : "exit code", WIFSIGNALED(st) ? WTERMSIG(st) : WEXITSTATUS(st));
-        }
-      }
-    }
-    const auto now = std::chrono::steady_clock::now();
-    if (any) t_last = now; else usleep(2000);
-    if (!asked && std::chrono::duration<double>(now - t_last).count() > 20.0) {
-      asked = true;                               /* no workgroup has finished for 20 s: ask the remaining ones where they are (once) */
-      for (size_t i = 0; i < kids.size(); i++) if (!done[i]) kill(kids[i], SIGUSR1);
-    }
-    if (std::chrono::duration<double>(now - t0).count() > 600.0) {
-      failed = true;
-      fprintf(stderr, "hipemu: %s stalled (%zu workgroups still running after 10 minutes)\n", name, left);
-    }
-  }
-  if (failed) {
-    for (size_t i = 0; i < kids.size(); i++) if (!done[i]) { kill(kids[i], SIGKILL); waitpid(kids[i], nullptr, 0); }
-    throw std::runtime_error(std::string("hipemu: a workgroup process of ") + name + " failed or the launch stalled");
-  }
+  if (g_group_open) { g_group_kids.insert(g_group_kids.end(), kids.begin(), kids.end()); g_group_names += std::string(g_group_names.empty() ? "" : " + ") + name; return; }
+  wait_for(kids, name);
+}
+
+void emu_group_begin() { g_group_open = true; g_group_kids.clear(); g_group_names.clear(); }
+void emu_group_end() {
+  g_group_open = false;
+  std::vector<pid_t> kids;
+  kids.swap(g_group_kids);
+  if (!kids.empty()) wait_for(kids, g_group_names.c_str());
 }
 
 struct emu_event { std::chrono::steady_clock::time_point t; };

@@ -113,6 +113,10 @@ void emu_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>
 void emu_launch_concurrent(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body, const char *name = "?");
 #define SDM_LAUNCH_CONCURRENT(kernel, grid, block, shmem, ...) \
   emu_launch_concurrent((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); }, #kernel)
+/* launches between the two run side by side (a kernel and the follower that polls its progress from a second stream): every
+   launch in between forks its workgroups and returns; _end waits for all of them */
+void emu_group_begin();
+void emu_group_end();
 void emu_set_concurrent(int on);
 int emu_concurrent();
 /* inside a spin loop on another workgroup's progress: yields the processor in a workgroup process, aborts in a sequential

@@ -54,6 +54,7 @@ def test_concurrent_workgroups_give_the_bits_of_the_phased_launch(refmex, concur
     l1, d1, y1, k1 = _factor_solve(m, m, concurrent_emu, True)
     l0, d0, y0, k0 = _factor_solve(m, m, concurrent_emu, False)
     assert "k_ldl_front" in k0 and "k_ldl_panel" not in k0 and "k_ldl_front" in k1 and "k_ldl_panel" not in k1
+    assert "k_sinv_follow" in k1          # beside the factorisation, polling its counters (a second group of processes)
     assert np.array_equal(l1, l0) and np.array_equal(d1, d0) and np.array_equal(y1, y0)
     X, _ = _dense_front(m, m)
     r = refmex.call("blkchol", 4, problem.dense_symbolic(m), X, gl.default_pars_chol())
@@ -91,3 +92,20 @@ def test_control07_unit_as_concurrent_workgroups(concurrent_emu):
     """The bench workload's iteration unit against its golden reference outputs, the factorisation as 56 concurrent processes."""
     errs = helpers.check_golden("control07", "rand")
     assert max(errs.values()) < TOL, errs
+
+
+@pytest.mark.parametrize("m", [200, 700])
+def test_panel_launches_as_concurrent_workgroups(refmex, concurrent_emu, m, monkeypatch):
+    """The launch-per-panel path (k_ldl_panel: diagonal block, row solves and the previous update's tiles in ONE launch whose
+    roles wait for each other; k_sprep: the inverses for the solves, its workgroups chained by counters) with a process
+    per workgroup, against the phased run and the reference.  200 rows: no row-solve workgroups (the roles are remapped)."""
+    from oracle import glue as gl
+    from sedumi_amd import problem
+    monkeypatch.setenv("SDM_FRONT_OFF", "1")
+    l1, d1, y1, k1 = _factor_solve(m, m, concurrent_emu, True)
+    l0, d0, y0, k0 = _factor_solve(m, m, concurrent_emu, False)
+    assert "k_ldl_panel" in k1 and "k_ldl_front" not in k1 and "k_sprep" in k1
+    assert np.array_equal(l1, l0) and np.array_equal(d1, d0) and np.array_equal(y1, y0)
+    X, _ = _dense_front(m, m)
+    r = refmex.call("blkchol", 4, problem.dense_symbolic(m), X, gl.default_pars_chol())
+    assert relerr(d1, r[1].ravel()) < TOL and relerr(l1, sp.csc_matrix(r[0]).data) < TOL

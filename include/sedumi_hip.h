@@ -353,6 +353,11 @@ int sdm_plan_lden(sdm_plan *p, sdm_int *betajc, double *beta, double *pv, sdm_in
  * the super-block width of the NEXT sdm_plan_set_chol: narrower blocks cost less to invert after every factorisation
  * and more dependent launches per solve. */
 int sdm_plan_set_growth_max(sdm_plan *p, double growth_max);
+/* on = 0: the NEXT sdm_plan_set_chol plans every front on the launch-per-panel path (k_ldl_panel) -- no level is factored
+ * by the one-launch kernel (k_ldl_front) and no inverse is built beside it.  Default 1.  The comparison switch of the tests
+ * and tools (both paths produce the same bits); also what a caller sharing the device between processes wants (all
+ * workgroups of a one-launch level must be resident at once). */
+int sdm_plan_set_one_launch_fronts(sdm_plan *p, int on);
 int sdm_plan_set_solve_width(sdm_plan *p, sdm_int width);
 int sdm_plan_get_solve_width(sdm_plan *p, sdm_int *width);      /* the width in force (after sdm_plan_set_chol) */
 int sdm_plan_solve_stats(sdm_plan *p, sdm_int *nblocks, sdm_int *nbad, double *max_growth);

@@ -1195,8 +1195,7 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
       // LDS per task: at least one slot (Y and D row, x2 for Hermitian); beyond that S1_GEN_LDS -- several tasks per CU
       // hide each other's latencies better than one task with all its slots resident
       const size_t one = (size_t)(A.sdpN > A.rsdpN ? 4 : 2) * (size_t)A.maxn * sizeof(double);
-      const char *le = getenv("SDM_S1_LDS");                           // tuning override (tools only)
-      const size_t ldsy = std::max(one, le ? (size_t)atol(le) : std::min(A.stage1_lds, (size_t)S1_GEN_LDS));
+      const size_t ldsy = std::max(one, std::min(A.stage1_lds, (size_t)S1_GEN_LDS));
       const int nzcap = (int)std::min<int64_t>(S1_NZ, (A.s1_maxnz + 1) & ~(int64_t)1);
       const size_t lds = ldsy + (size_t)nzcap * (sizeof(double) + sizeof(int));
 #ifndef SDM_EMU
@@ -1247,13 +1246,10 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
     // (z_j staged once per workgroup) -- the sweep is bound by its LDS gathers and L2 re-reads, not by the chain of
     // groups inside one workgroup.  Off by default.
     // symmetric half-sweep: the whole of a full-pattern ADA' is being formed and nothing restricts the entries touched
-    const bool sym = A.ell_full && !d_invperm && jbase == 0 && ncols == m && getenv("SDM_STAGE2_SYM_OFF") == nullptr;
-    const char *gsenv = getenv("SDM_STAGE2_GS");                       // tuning override (tools only)
-    const int gsplit = gsenv ? std::max(1, atoi(gsenv)) : (sym ? 3 : 1);      // half-sweep: the long sweeps (early groups) split in three (measured 1: 52.7, 2: 41.6, 3: 38.9, 4: 41.2 us)
-    const char *jbenv = getenv("SDM_STAGE2_JB");                       // tuning override (tools only)
-    const int jbforce = jbenv ? atoi(jbenv) : 0;
-    if (jbforce == 4 || (!jbforce && lds_of(4) <= 64 * 1024 && m >= 1024)) SDM_STAGE2_ELL(4);
-    else if (jbforce == 2 || (!jbforce && lds_of(2) <= 64 * 1024 && m >= 512)) SDM_STAGE2_ELL(2);
+    const bool sym = A.ell_full && !d_invperm && jbase == 0 && ncols == m;
+    const int gsplit = sym ? 3 : 1;                                     // half-sweep: the long sweeps (early groups) split in three (measured 1: 52.7, 2: 41.6, 3: 38.9, 4: 41.2 us)
+    if (lds_of(4) <= 64 * 1024 && m >= 1024) SDM_STAGE2_ELL(4);
+    else if (lds_of(2) <= 64 * 1024 && m >= 512) SDM_STAGE2_ELL(2);
     else SDM_STAGE2_ELL(1);
 #undef SDM_STAGE2_ELL
 #undef SDM_STAGE2_ATTR

@@ -308,6 +308,11 @@ int sdm_plan_set_growth_max(sdm_plan *p, double growth_max) {
   p->chol.growth_max = growth_max;
   SDM_CATCH
 }
+int sdm_plan_set_one_launch_fronts(sdm_plan *p, int on) {
+  SDM_TRY
+  p->chol.front_off_req = !on;
+  SDM_CATCH
+}
 int sdm_plan_set_solve_width(sdm_plan *p, sdm_int width) {
   SDM_TRY
   if (width != 0 && (width < sdm::SBW_MIN || width > sdm::SBW_MAX || (width & (width - 1)) != 0))

@@ -173,7 +173,7 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   std::vector<int> fslot(std::max<sdm_int>(1, C.nsuper), 0);
   int nslot = 0;
   {
-    const bool off = getenv("SDM_FRONT_OFF") != nullptr;              // comparison override (tools, tests): read at every set_chol
+    const bool off = C.front_off_req;                                 // sdm_plan_set_one_launch_fronts(p, 0): the comparison switch of tests and tools
     const int maxT_allowed = FRONT_MAXT;
     // k_ldl_front's workgroups wait for each other in both directions (a row workgroup for its tile workgroups and vice
     // versa): they must all be resident, one per compute unit (135 KB of LDS each).  A device -- or a partition of one --
@@ -1342,12 +1342,10 @@ __device__ SDM_NOINLINE void front_update(int kind, SDM_GP(double) Fs_, int ld, 
   else update_tile<LDL_THREADS / 64, false, true>(Fs, ld, ms, first, k0, NB, I, J, d, As, Bs, dsh);
 }
 // R: rows of tile row r against the diagonal block of panel q as it is published; have_tw: the tile is in the wave tiles already
-__device__ SDM_NOINLINE void front_rows(SDM_GP(double) Fs_, SDM_GP(const double) Ds_, SDM_GP(const double) d_, int ld, int ms, int first, int q, int kb, int r, char *smem,
-                                        double *dsr, SDM_GP(const int) diag_cnt_s_, SDM_GP(int) tmo_, bool have_tw, bool defer_ack) {
+__device__ SDM_NOINLINE void front_rows(SDM_GP(double) Fs_, SDM_GP(const double) Ds_, int ld, int ms, int q, int kb, int r, char *smem,
+                                        double *dsr, SDM_GP(int) tmo_, bool have_tw, bool defer_ack) {
   double *Fs = (double *)Fs_;
   const double *Ds = (const double *)Ds_;
-  const double *d = (const double *)d_;
-  const int *diag_cnt_s = (const int *)diag_cnt_s_;
   int *tmo = (int *)tmo_;
   double (*S)[NB + 1] = (double (*)[NB + 1])smem;
   double *RB = (double *)smem + NB * (NB + 1);
@@ -1375,12 +1373,10 @@ __device__ SDM_NOINLINE void front_rows(SDM_GP(double) Fs_, SDM_GP(const double)
 // K = 48 part of the update runs while the last 16 columns of the diagonal block are still being factored; after they
 // arrive only their triangle, 4 of the 16 k-steps and the epilogue are left.  The raw updated block stays in LDS (cvl:
 // the general path of the LDL' reloads it from there); it reaches the front as the factored block.
-__device__ SDM_NOINLINE void front_rows_diag(SDM_GP(double) Fs_, SDM_GP(const double) Ds_, SDM_GP(const double) d_, int ld, int ms, int first, int q, int r, char *smem,
-                                             double *dsr, SDM_GP(const int) diag_cnt_s_, SDM_GP(int) tmo_, bool have_tw, int kbn) {
+__device__ SDM_NOINLINE void front_rows_diag(SDM_GP(double) Fs_, SDM_GP(const double) Ds_, int ld, int ms, int q, int r, char *smem,
+                                             double *dsr, SDM_GP(int) tmo_, bool have_tw, int kbn) {
   double *Fs = (double *)Fs_;
   const double *Ds = (const double *)Ds_;
-  const double *d = (const double *)d_;
-  const int *diag_cnt_s = (const int *)diag_cnt_s_;
   int *tmo = (int *)tmo_;
   double (*S)[NB + 1] = (double (*)[NB + 1])smem;
   double *RB = (double *)smem + NB * (NB + 1);
@@ -1565,11 +1561,9 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
     }
     if (phase == 0 || phase == 2) {
       // ---- R: 16 rows per wavefront (4 of the 8 busy), following the diagonal block as workgroup q publishes it
-      if (crit_lds) front_rows_diag((SDM_GP(double))Fs, (SDM_GP(const double))(DT + tab.toff[s] + (int64_t)q * NB * NB), (SDM_GP(const double))d, ld, ms, first, q, r, smem, dsr, (SDM_GP(const int))(diag_cnt + s),
-                                    (SDM_GP(int))tmo, have_tw,
+      if (crit_lds) front_rows_diag((SDM_GP(double))Fs, (SDM_GP(const double))(DT + tab.toff[s] + (int64_t)q * NB * NB), ld, ms, q, r, smem, dsr, (SDM_GP(int))tmo, have_tw,
                                     min(NB, ns - (q + 1) * NB));
-      else front_rows((SDM_GP(double))Fs, (SDM_GP(const double))(DT + tab.toff[s] + (int64_t)q * NB * NB), (SDM_GP(const double))d, ld, ms, first, q, kb, r, smem, dsr, (SDM_GP(const int))(diag_cnt + s),
-                      (SDM_GP(int))tmo, have_tw, false);
+      else front_rows((SDM_GP(double))Fs, (SDM_GP(const double))(DT + tab.toff[s] + (int64_t)q * NB * NB), ld, ms, q, kb, r, smem, dsr, (SDM_GP(int))tmo, have_tw, false);
       SDM_FPHASE(1);
       have_tw = false;
       if (crit_lds) {
@@ -1664,7 +1658,6 @@ static inline int grid1d(int64_t n, int bs, int cap = 4096) {
 void chol_begin(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd) {
   CholPlan &C = P->chol;
   hipStream_t st = P->stream;
-  FrontTab tab = front_tab(C);
   const int m = (int)C.m;
   P->factored = false;               // until the launches below have all been issued: a factorisation that throws leaves no factor behind
 #ifndef SDM_EMU

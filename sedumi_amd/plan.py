@@ -180,6 +180,10 @@ class Plan:
         inverse (0 = substitution everywhere); effective from the next blkchol."""
         check(self._lib.sdm_plan_set_growth_max(C.c_void_p(self._p), C.c_double(float(growth_max))))
 
+    def set_one_launch_fronts(self, on):
+        """False: the NEXT set_chol plans every front on the launch-per-panel path (the comparison switch of tests and tools)."""
+        check(self._lib.sdm_plan_set_one_launch_fronts(C.c_void_p(self._p), C.c_int(1 if on else 0)))
+
     def set_solve_width(self, width):
         """Super-block width of the solves for the NEXT set_chol (0 = automatic, or a power of two in 256 .. 2048)."""
         check(self._lib.sdm_plan_set_solve_width(C.c_void_p(self._p), C.c_int64(int(width))))

@@ -194,18 +194,13 @@ def bordered_blocks(n1, n2, nc, rng):
 
 def _factor_both_ways(X, L, pars=None, rhs=None):
     """(lpr, d, pivots, y, kernels) of the resident plan with the one-launch front kernel and with the launch-per-panel path
-    (SDM_FRONT_OFF at set_chol: the comparison switch)."""
-    import os
+    (Plan.set_one_launch_fronts(False) before set_chol: the comparison switch)."""
     from sedumi_amd.plan import Plan
     out = []
     for off in (False, True):
-        if off:
-            os.environ["SDM_FRONT_OFF"] = "1"
-        try:
-            plan = Plan(0)
-            plan.set_chol(L, X)
-        finally:
-            os.environ.pop("SDM_FRONT_OFF", None)
+        plan = Plan(0)
+        plan.set_one_launch_fronts(not off)
+        plan.set_chol(L, X)
         plan.upload("ada", sp.csc_matrix(X).data)
         plan.upload("rhs", rhs if rhs is not None else np.ones(X.shape[0]))
         plan.kprof(True)

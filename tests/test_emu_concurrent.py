@@ -31,12 +31,13 @@ def _dense_front(m, seed):
     return X, rng.standard_normal(m)
 
 
-def _factor_solve(m, seed, lib, concurrent):
+def _factor_solve(m, seed, lib, concurrent, one_launch=True):
     from sedumi_amd import problem
     from sedumi_amd.plan import Plan
     X, rhs = _dense_front(m, seed)
     lib._Z18emu_set_concurrenti(int(concurrent))
     plan = Plan(0)
+    plan.set_one_launch_fronts(one_launch)
     plan.set_chol(problem.dense_symbolic(m), X)
     plan.upload("ada", X.data); plan.upload("rhs", rhs)
     plan.kprof(True)
@@ -95,15 +96,14 @@ def test_control07_unit_as_concurrent_workgroups(concurrent_emu):
 
 
 @pytest.mark.parametrize("m", [200, 700])
-def test_panel_launches_as_concurrent_workgroups(refmex, concurrent_emu, m, monkeypatch):
+def test_panel_launches_as_concurrent_workgroups(refmex, concurrent_emu, m):
     """The launch-per-panel path (k_ldl_panel: diagonal block, row solves and the previous update's tiles in ONE launch whose
     roles wait for each other; k_sprep: the inverses for the solves, its workgroups chained by counters) with a process
     per workgroup, against the phased run and the reference.  200 rows: no row-solve workgroups (the roles are remapped)."""
     from oracle import glue as gl
     from sedumi_amd import problem
-    monkeypatch.setenv("SDM_FRONT_OFF", "1")
-    l1, d1, y1, k1 = _factor_solve(m, m, concurrent_emu, True)
-    l0, d0, y0, k0 = _factor_solve(m, m, concurrent_emu, False)
+    l1, d1, y1, k1 = _factor_solve(m, m, concurrent_emu, True, one_launch=False)
+    l0, d0, y0, k0 = _factor_solve(m, m, concurrent_emu, False, one_launch=False)
     assert "k_ldl_panel" in k1 and "k_ldl_front" not in k1 and "k_sprep" in k1
     assert np.array_equal(l1, l0) and np.array_equal(d1, d0) and np.array_equal(y1, y0)
     X, _ = _dense_front(m, m)

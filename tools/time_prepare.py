@@ -1,6 +1,5 @@
 """tools/time_prepare.py [workload] -- device time of back-to-back factorisations (sdm_plan_blkchol: assembly, pivot bounds, the
-LDL', the solve preparation) and the per-kernel times of everything in it but the LDL' launches.  SDM_SPREP_OFF=1 selects the
-four-launch solve preparation, SDM_FRONT_OFF=1 the launch-per-panel LDL'."""
+LDL', the solve preparation) and the per-kernel times of everything in it but the LDL' launches."""
 import os
 import sys
 
@@ -26,5 +25,5 @@ for _ in range(20):
     plan.blkchol(bench.PARS, True)
 prof = plan.kprof_summary()
 plan.kprof(False)
-print(name, "SDM_SPREP_OFF" if os.environ.get("SDM_SPREP_OFF") else "fused", "blkchol ms:", plan.timer_ms(0) / reps,
+print(name, "blkchol ms:", plan.timer_ms(0) / reps,
       {k: round(v[1] / 20, 4) for k, v in prof.items() if not k.startswith("k_ldl")})

@@ -339,7 +339,7 @@ __device__ __noinline__ double pivot_probe(const double (*S)[NB + 1], const doub
   SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
   const double *Fs = (const double *)Fs_;
   double *cb = (double *)cb_;
-  const int tid = threadIdx.x, bs = blockDim.x;
+  const int tid = threadIdx.x, bs = LDL_THREADS;              // (blockDim.x inside a called function is two dependent loads from the dispatch packet)
   const int len = ms - (k0 + k) - 1;          // entries below the diagonal of this column
   const int nin = kb - k - 1;                 // of which inside the LDS block
   // gather the column into cb[0..len-1]; cb[len] = what lies after the column in L's storage
@@ -618,7 +618,7 @@ __device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int 
 __device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, int k0, int kb, int rbeg, int rend, int brows,
                                            const double (*S)[NB + 1], const double *ds, double *RB, bool staged = false) {
   SDM_FP_STRICT;
-  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = blockDim.x >> 6;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = LDL_THREADS >> 6;
   rend = min(rend, ms);
   if (ms - min(NB, ns) >= MFMA_MIN_ROWS) {                         // per front, the same path for all its panels
     // 16 rows per wavefront at a time, blocked substitution with the GEMM part on the matrix cores
@@ -809,17 +809,18 @@ __device__ __forceinline__ void publish_group(double *Dsp, const double *Lc, con
   for (int p2 = 0; p2 < 8; p2++) sdm_store_wt2(&Dsp[tx * NB + 16 * g + 2 * p2], v[2 * p2], v[2 * p2 + 1]);
 #endif
 }
-// what ldl_diag_block needs of a front's descriptor, fetched ONCE by k_ldl_front (every read of the tables in HBM is a
-// dependent load of a microsecond, and the noinline stages of that kernel would each repeat them on the chain)
-struct FrontDesc { int ns, ms, ld, first; int64_t foff, toff, woff; double maxu, ub; };
+// what ldl_diag_block needs of a front's descriptor, fetched ONCE per workgroup (every read of the tables in HBM is a dependent
+// load of a microsecond, and the noinline stages would each repeat them on the chain).  It lives in LDS and is handed on BY
+// ADDRESS: a struct passed by value to a called function travels through the stack (scratch memory) behind a pointer -- two
+// dependent memory round trips at the top of every diagonal block.  For the same reason the function's other arguments are
+// kept to the 32 registers the calling convention has: what only the rare general path needs comes through PanelCtx.
+struct FrontDesc { int ns, ms, ld, first; int64_t foff, toff, woff; double maxu, ub; int s, pad; };
 template <bool PERSIST>
-__device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT, const FrontDesc &fd, int s, int panel, double *d, double *lb,
-                                               int *pivstat, double *pivval, double *colbuf, const double *ada,
-                                               const int *asm_src, const int64_t *Ljc, int mtot, int *upd_cnt, int *diag_cnt, int q0, int *tmo,
+__device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT, const FrontDesc &fd, int panel, double *d, double *lb,
+                                               int *pivstat, double *pivval, const PanelCtx *ctx, int *upd_cnt, int *diag_cnt, int q0, int *tmo,
                                                bool load_block, bool publish, double *ds, int *npub, bool raw_in_lds = false, int pub_skip = 0,
-                                               const double *lbs_pre = nullptr, int *owed_a = nullptr, int *owed_b = nullptr) {
-  // owed_a / owed_b (k_ldl_front): counters the workgroup owes for write-through stores it issued just before this block (the rows of L of
-  // the chain's row solve): counted behind the first sweep, when their acknowledgements have long arrived -- not waited for on the chain
+                                               const double *lbs_pre = nullptr) {
+  // ctx: what only the general path reads (probe scratch, the next supernode's raw diagonal); fd.maxu / fd.ub are read behind the first barrier
   // lbs_pre (k_ldl_front): the block's pivot thresholds, fetched into LDS when the workgroup started (one global round trip off the chain)
   // pub_skip (k_ldl_front's chain workgroup redoing a block on the general path): 16-column groups of this block already counted in diag_cnt
   // raw_in_lds (k_ldl_front): the raw block is not in the front but in LDS behind the wave tiles (front_rows_diag)
@@ -836,10 +837,9 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
   const int64_t toff_s = fd.toff;
   const int k0 = panel * NB, kb = min(NB, ns - k0);
   double *Fs = F + fd.foff;
-  double *cb = colbuf + fd.woff + s;                              // probe scratch: ms + 1 doubles per front
-  const int tid = threadIdx.x, bs = blockDim.x;
+  const int s = fd.s;
+  const int tid = threadIdx.x, bs = LDL_THREADS;                    // (both kernels launch LDL_THREADS work-items; blockDim.x inside a called function is two dependent loads)
   const int tx = tid & 63, ty = tid >> 6, ny = bs >> 6;
-  const double maxu = fd.maxu, ub = fd.ub;                          // ub = max diagonal (k_prep_pivots) / maxu^2
   if (load_block) {
     double sv[NB / (LDL_THREADS / 64)];
     const double *pc = Fs + (int64_t)k0 * ld + k0 + min(tx, kb - 1);
@@ -856,6 +856,7 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
   if (tid == 0) { badflag = 0; *npub = 0; }
   SDM_PHASE_BEGIN();
   __syncthreads();
+  const double ub = fd.ub;                                           // max diagonal (k_prep_pivots) / maxu^2; (k_ldl_panel: written just before this block)
   SDM_PHASE(16);
   if (PERSIST) SDM_TRACE(16 * panel + 0);                              // D: sweeps start
   // ---- LDL' of the block (see the header): wavefront 0 sweeps SW columns in registers while the other wavefronts
@@ -870,16 +871,13 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
     for (int s = -1; s < nsw - 1; s++) {
       diag_sweep_w0(S, Lc, s, xs, mylb, tx, kb, k0, ms, ub, ds, stt, pv, &badflag);
       SDM_PHASE(17);
-      if (s == -1 && owed_a) SDM_STORES_DONE();
       __syncthreads();
       SDM_PHASE(19);
     }
     SDM_SETPRIO(0);
     if (PERSIST) SDM_TRACE(16 * panel + 1);                            // D: sweeps end
   } else if (ty < ny - 1) {
-    if (owed_a) SDM_STORES_DONE();
     __syncthreads();                                                   // sweep 0
-    if (owed_a && ty == 1 && tx == 0) { sdm_signal_add(owed_a); if (owed_b) sdm_signal_add(owed_b); }
     for (int s = 0; s < nsw - 1; s++) {
       diag_trail(S, Lc, s, kb, tx, ty - 1, ny - 2);
       SDM_PHASE(18);
@@ -893,7 +891,6 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
     // before is what the general path computes again).
     double *Dsp = DT + toff_s + (int64_t)panel * NB * NB;
     int issued = pub_skip, signalled = pub_skip;
-    if (owed_a) SDM_STORES_DONE();
     __syncthreads();                                                   // sweep 0
     for (int sw = 0; sw < nsw - 1; sw++) {
       if (publish) {
@@ -943,7 +940,9 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
       if (xkk > lbs[k]) {
         if (ms - (k0 + k) > 1 && xkk < ub) {                         // rare: stability probe of the never-fail rule
           double nraw = 0.0;
-          if (k0 + k + 1 >= ns && first + ns < mtot) { int sidx = asm_src[Ljc[first + ns]]; nraw = sidx < 0 ? 0.0 : ada[sidx]; }
+          const double maxu = fd.maxu;
+          double *cb = ctx->colbuf + fd.woff + s;                    // probe scratch: ms + 1 doubles per front
+          if (k0 + k + 1 >= ns && first + ns < ctx->mtot) { int sidx = ctx->asm_src[ctx->Ljc[first + ns]]; nraw = sidx < 0 ? 0.0 : ctx->ada[sidx]; }
           const double ubk = pivot_probe(S, Lc, k, kb, k0, ns, ms, ld, (SDM_GP(const double))Fs, ds, (SDM_GP(double))cb, nraw, red_v, red_i) / maxu;
           if (xkk < ubk) {
             if (tid == 0) { stt[k] = 2; pv[k] = ubk - xkk; lbs[k] = ubk - xkk; }
@@ -994,7 +993,10 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
 // (a callable function does not inherit the kernel's launch bounds: the register allocator budgets it for the translation unit's
 // default workgroup size -- 1024 work-items = 128 VGPRs unless the file is compiled with --gpu-max-threads-per-block=512, as
 // sedumi_amd/build.py does for this file; with 128 the roles spill inside although their kernels may use 256)
-#define SDM_NOINLINE __noinline__
+// not_tail_called: a call the optimizer marks as a tail call (it does whenever no stack object of the caller is passed along) makes
+// the callee ineligible for the "no callee-saved registers" treatment of internal functions, and it then saves and restores every
+// callee-saved VGPR it touches through scratch on each call: 72 of them in the diagonal-block stage, 117 in panel_diag_rows.
+#define SDM_NOINLINE __noinline__ __attribute__((not_tail_called))
 #endif
 #ifndef SDM_NI_ROWS
 #define SDM_NI_ROWS __forceinline__       // (measured: +1 us per launch as a call)
@@ -1037,7 +1039,7 @@ __device__ SDM_NI_ROWS SDM_NORETURN void panel_role_rows(char *smem, double *Fs,
   double (*S)[NB + 1] = (double (*)[NB + 1])smem;
   double *RB = (double *)smem + NB * (NB + 1);
   __shared__ double dsr[NB];
-  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = blockDim.x >> 6;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = LDL_THREADS >> 6;
   const int rbeg = k0c + NB * (b + 1), rend = min(ms, k0c + NB * (b + 2));      // = tile row b+1
   if (!mfma_rows) {
     // few rows: the faithful substitution needs the whole block
@@ -1117,24 +1119,20 @@ __device__ SDM_NI_DUPD void panel_diag_update(char *smem, SDM_GP(double) Fs_, SD
                                       (double (*)[NB + 1])smem, (double *)smem + NB * (NB + 1), kbc);
 }
 // ---- workgroup 0, second piece: the LDL' of the block
-__device__ SDM_NI_DBLK bool panel_diag_block(char *smem, SDM_GP(double) F_, SDM_GP(double) DT_, FrontDesc fd, int s, int panel, SDM_GP(double) d_, SDM_GP(double) lb_,
-                                              SDM_GP(int) pivstat_, SDM_GP(double) pivval_, SDM_GP(double) colbuf_, SDM_GP(const double) ada_, SDM_GP(const int) asm_src_, SDM_GP(const int64_t) Ljc_,
-                                              int mtot, SDM_GP(int) upd_cnt_, SDM_GP(int) diag_cnt_, int q0, SDM_GP(int) tmo_, bool load_block, bool publish, double *ds, int *npub) {
+__device__ SDM_NI_DBLK bool panel_diag_block(char *smem, SDM_GP(double) F_, SDM_GP(double) DT_, const FrontDesc *fd, int panel, SDM_GP(double) d_, SDM_GP(double) lb_,
+                                              SDM_GP(int) pivstat_, SDM_GP(double) pivval_, SDM_GP(const PanelCtx) ctx_, SDM_GP(int) upd_cnt_, SDM_GP(int) diag_cnt_, int q0,
+                                              SDM_GP(int) tmo_, bool load_block, bool publish, double *ds, int *npub) {
   double *F = (double *)F_;
   double *DT = (double *)DT_;
   double *d = (double *)d_;
   double *lb = (double *)lb_;
   int *pivstat = (int *)pivstat_;
   double *pivval = (double *)pivval_;
-  double *colbuf = (double *)colbuf_;
-  const double *ada = (const double *)ada_;
-  const int *asm_src = (const int *)asm_src_;
-  const int64_t *Ljc = (const int64_t *)Ljc_;
+  const PanelCtx *ctx = (const PanelCtx *)ctx_;
   int *upd_cnt = (int *)upd_cnt_;
   int *diag_cnt = (int *)diag_cnt_;
   int *tmo = (int *)tmo_;
-  return ldl_diag_block<false>(smem, F, DT, fd, s, panel, d, lb, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_cnt, diag_cnt, q0, tmo,
-                               load_block, publish, ds, npub);
+  return ldl_diag_block<false>(smem, F, DT, *fd, panel, d, lb, pivstat, pivval, ctx, upd_cnt, diag_cnt, q0, tmo, load_block, publish, ds, npub);
 }
 // ---- workgroup 0, last piece: rows of its own tile row that are left to it
 __device__ SDM_NI_DROWS void panel_diag_rows(char *smem, SDM_GP(double) Fs_, int ld, int ns, int ms, int k0, int kb, int rbeg, int rend, const double *ds) {
@@ -1146,7 +1144,7 @@ __device__ SDM_NI_DROWS void panel_diag_rows(char *smem, SDM_GP(double) Fs_, int
 #define SDM_NI_DIAG SDM_NOINLINE
 #endif
 // ---- workgroup 0: its tile of the previous update, the LDL' of the block, the rows left to it, the counts
-__device__ SDM_NI_DIAG SDM_NORETURN void panel_role_diag(char *smem, SDM_GP(double) F_, SDM_GP(double) DT_, FrontDesc fd, int s, int panel, SDM_GP(double) d_,
+__device__ SDM_NI_DIAG SDM_NORETURN void panel_role_diag(char *smem, SDM_GP(double) F_, SDM_GP(double) DT_, FrontDesc *fdp, int panel, SDM_GP(double) d_,
                                                          SDM_GP(const PanelCtx) ctx_, SDM_GP(int) upd_cnt_, SDM_GP(int) diag_cnt_, int q0, SDM_GP(int) tmo_) {
   double *F = (double *)F_;
   double *DT = (double *)DT_;
@@ -1156,11 +1154,13 @@ __device__ SDM_NI_DIAG SDM_NORETURN void panel_role_diag(char *smem, SDM_GP(doub
   int *diag_cnt = (int *)diag_cnt_;
   int *tmo = (int *)tmo_;
   // (uniform loads: one scalar round trip, issued before the tile of the previous update is fetched)
-  double *lb = ctx->lb; int *pivstat = ctx->pivstat; double *pivval = ctx->pivval; double *colbuf = ctx->colbuf;
-  const double *ada = ctx->ada; const int *asm_src = ctx->asm_src; const int64_t *Ljc = ctx->Ljc; const int mtot = ctx->mtot;
+  double *lb = ctx->lb; int *pivstat = ctx->pivstat; double *pivval = ctx->pivval;
+  const FrontDesc &fd = *fdp;
+  const int s = fd.s;
   {
     const double *ubp = ctx->ubp;
-    fd.maxu = ubp[1]; fd.ub = ubp[2] / (fd.maxu * fd.maxu);
+    const double maxu = ubp[1], ub = ubp[2] / (maxu * maxu);
+    if (threadIdx.x == 0) { fdp->maxu = maxu; fdp->ub = ub; }      // (read behind the first barrier of the diagonal block)
   }
   const int ns = fd.ns, ms = fd.ms, ld = fd.ld, first = fd.first;
   double *Fs = F + fd.foff;
@@ -1170,9 +1170,8 @@ __device__ SDM_NI_DIAG SDM_NORETURN void panel_role_diag(char *smem, SDM_GP(doub
   __shared__ double ds[NB];
   __shared__ int npub;
   const int tid = threadIdx.x;
-  const bool ok = panel_diag_block(smem, (SDM_GP(double))F, (SDM_GP(double))DT, fd, s, panel, (SDM_GP(double))d, (SDM_GP(double))lb, (SDM_GP(int))pivstat, (SDM_GP(double))pivval,
-                                   (SDM_GP(double))colbuf, (SDM_GP(const double))ada, (SDM_GP(const int))asm_src, (SDM_GP(const int64_t))Ljc, mtot, (SDM_GP(int))upd_cnt,
-                                   (SDM_GP(int))diag_cnt, q0, (SDM_GP(int))tmo, panel == 0, nrows > TRSM_ROWS, ds, &npub);
+  const bool ok = panel_diag_block(smem, (SDM_GP(double))F, (SDM_GP(double))DT, fdp, panel, (SDM_GP(double))d, (SDM_GP(double))lb, (SDM_GP(int))pivstat, (SDM_GP(double))pivval,
+                                   (SDM_GP(const PanelCtx))ctx, (SDM_GP(int))upd_cnt, (SDM_GP(int))diag_cnt, q0, (SDM_GP(int))tmo, panel == 0, nrows > TRSM_ROWS, ds, &npub);
   SDM_PHASE_BEGIN();
   if (nrows > TRSM_ROWS) {                                         // the row-solve workgroups of this launch are waiting
     if (16 * npub < kb) SDM_STORES_DONE();                         // (uniform) something of the block is still unpublished
@@ -1252,10 +1251,9 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   }
   // ---- workgroup 0
   if (phase == 2) return;
-  FrontDesc fd;
-  fd.ns = ns; fd.ms = ms; fd.ld = ld; fd.first = first; fd.foff = tab.foff[s]; fd.toff = tab.toff[s]; fd.woff = tab.woff[s];
-  fd.maxu = 0.0; fd.ub = 0.0;                                       // (filled in by the role: behind ctx)
-  panel_role_diag(smem, (SDM_GP(double))F, (SDM_GP(double))DT, fd, s, panel, (SDM_GP(double))d, (SDM_GP(const PanelCtx))ctx, (SDM_GP(int))upd_cnt, (SDM_GP(int))diag_cnt, q0,
+  __shared__ FrontDesc fd;                                          // (every work-item writes the same values: no barrier needed before it reads them back)
+  fd.ns = ns; fd.ms = ms; fd.ld = ld; fd.first = first; fd.foff = tab.foff[s]; fd.toff = tab.toff[s]; fd.woff = tab.woff[s]; fd.s = s;
+  panel_role_diag(smem, (SDM_GP(double))F, (SDM_GP(double))DT, &fd, panel, (SDM_GP(double))d, (SDM_GP(const PanelCtx))ctx, (SDM_GP(int))upd_cnt, (SDM_GP(int))diag_cnt, q0,
                   (SDM_GP(int))tmo);
 }
 
@@ -1308,27 +1306,20 @@ __device__ __forceinline__ void diag_group_fetch(const double *Ds, int blk, int 
 // into one body they share 256 VGPRs with the sweep code of the diagonal block and spill inside the store loops -- and a
 // scratch reload between two write-through stores waits for the first one's acknowledgement (vmcnt counts in order):
 // every stored tile then costs eight memory round trips instead of one.
-__device__ SDM_NOINLINE bool front_diag(char *smem, SDM_GP(double) F_, SDM_GP(double) DT_, int s, int panel, SDM_GP(double) d_, SDM_GP(double) lb_,
-                                        SDM_GP(int) pivstat_, SDM_GP(double) pivval_, SDM_GP(double) colbuf_, SDM_GP(const double) ada_, SDM_GP(const int) asm_src_, SDM_GP(const int64_t) Ljc_,
-                                        int mtot, SDM_GP(int) upd_done_, SDM_GP(int) diag_cnt_, SDM_GP(int) tmo_, bool load_block, bool publish, double *ds, int *npub,
-                                        bool raw_in_lds, const double *lbs_pre, FrontDesc fd, SDM_GP(int) owed_a_, SDM_GP(int) owed_b_) {
+__device__ SDM_NOINLINE bool front_diag(char *smem, SDM_GP(double) F_, SDM_GP(double) DT_, const FrontDesc *fd, int panel, SDM_GP(double) d_, SDM_GP(double) lb_,
+                                        SDM_GP(int) pivstat_, SDM_GP(double) pivval_, SDM_GP(const PanelCtx) ctx_, SDM_GP(int) upd_done_, SDM_GP(int) diag_cnt_, SDM_GP(int) tmo_,
+                                        bool load_block, bool publish, double *ds, int *npub, bool raw_in_lds, const double *lbs_pre) {
   double *F = (double *)F_;
   double *DT = (double *)DT_;
   double *d = (double *)d_;
   double *lb = (double *)lb_;
   int *pivstat = (int *)pivstat_;
   double *pivval = (double *)pivval_;
-  double *colbuf = (double *)colbuf_;
-  const double *ada = (const double *)ada_;
-  const int *asm_src = (const int *)asm_src_;
-  const int64_t *Ljc = (const int64_t *)Ljc_;
+  const PanelCtx *ctx = (const PanelCtx *)ctx_;
   int *upd_done = (int *)upd_done_;
   int *diag_cnt = (int *)diag_cnt_;
   int *tmo = (int *)tmo_;
-  int *owed_a = (int *)owed_a_;
-  int *owed_b = (int *)owed_b_;
-  return ldl_diag_block<true>(smem, F, DT, fd, s, panel, d, lb, pivstat, pivval, colbuf, ada, asm_src, Ljc, mtot, upd_done, diag_cnt, 0, tmo,
-                              load_block, publish, ds, npub, raw_in_lds, 0, lbs_pre, owed_a, owed_b);
+  return ldl_diag_block<true>(smem, F, DT, *fd, panel, d, lb, pivstat, pivval, ctx, upd_done, diag_cnt, 0, tmo, load_block, publish, ds, npub, raw_in_lds, 0, lbs_pre);
 }
 // kind 0: plain (result to the front only), 2: also the wave tiles of the next row solve (RB)
 __device__ SDM_NOINLINE void front_update(int kind, SDM_GP(double) Fs_, int ld, int ms, int first, int k0, int I, int J, SDM_GP(const double) d_, char *smem,
@@ -1470,8 +1461,7 @@ __device__ SDM_NOINLINE void front_rows_diag(SDM_GP(double) Fs_, SDM_GP(const do
 // loops over (step, phase 1 = D, 2 = R, 3 = U) and nothing is carried in LDS.
 __global__ void __launch_bounds__(LDL_THREADS)
 k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, double *lb, const double *ubp, int *pivstat,
-            double *pivval, double *colbuf, const double *ada, const int *asm_src, const int64_t *Ljc, int mtot, int *front_cnt,
-            int *diag_cnt, int phase, int step, int tile_wg0, int *tmo) {
+            double *pivval, const PanelCtx *ctx, int *front_cnt, int *diag_cnt, int phase, int step, int tile_wg0, int *tmo) {
   SDM_FP_STRICT;
   SDM_DYN_SMEM(smem);
   const int s = list[blockIdx.y];
@@ -1510,20 +1500,19 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
   const int r = blockIdx.x;
   if (r >= T) return;
   const bool carry = phase == 0;
-  FrontDesc fd;
-  fd.ns = ns; fd.ms = ms; fd.ld = ld; fd.first = first; fd.foff = tab.foff[s]; fd.toff = tab.toff[s]; fd.woff = tab.woff[s];
-  fd.maxu = ubp[1]; fd.ub = ubp[2] / (fd.maxu * fd.maxu);
+  __shared__ FrontDesc fd;                                          // (every work-item writes the same values: no barrier needed before it reads them back)
+  fd.ns = ns; fd.ms = ms; fd.ld = ld; fd.first = first; fd.foff = tab.foff[s]; fd.toff = tab.toff[s]; fd.woff = tab.woff[s]; fd.s = s;
+  { const double maxu = ubp[1]; fd.maxu = maxu; fd.ub = ubp[2] / (maxu * maxu); }
   __shared__ double lbs_pre[NB];
   if (carry && r < NP && tid < NB) lbs_pre[tid] = r * NB + tid < ns ? lb[first + r * NB + tid] : 0.0;      // thresholds of the block this workgroup will factor
-  bool have_S = false, have_tw = false, raw_in_lds = false, owed = false;
+  bool have_S = false, have_tw = false, raw_in_lds = false;
   for (int q = carry ? 0 : step; q < (carry ? NP : step + 1) && q <= r; q++) {
     const int k0 = q * NB, kb = min(NB, ns - k0);
     if (q == r) {
       if (phase == 0 || phase == 1) {
         const int nrows = ms - (k0 + kb);
-        front_diag(smem, (SDM_GP(double))F, (SDM_GP(double))DT, s, q, (SDM_GP(double))d, (SDM_GP(double))lb, (SDM_GP(int))pivstat, (SDM_GP(double))pivval, (SDM_GP(double))colbuf, (SDM_GP(const double))ada,
-                   (SDM_GP(const int))asm_src, (SDM_GP(const int64_t))Ljc, mtot, (SDM_GP(int))upd_done, (SDM_GP(int))diag_cnt, (SDM_GP(int))tmo,
-                   !have_S, nrows > 0, ds, &npub, raw_in_lds, carry ? lbs_pre : nullptr, fd, (SDM_GP(int))(owed ? &row_cnt[r] : nullptr), (SDM_GP(int))(owed ? &upd_done[r] : nullptr));
+        front_diag(smem, (SDM_GP(double))F, (SDM_GP(double))DT, &fd, q, (SDM_GP(double))d, (SDM_GP(double))lb, (SDM_GP(int))pivstat, (SDM_GP(double))pivval, (SDM_GP(const PanelCtx))ctx,
+                   (SDM_GP(int))upd_done, (SDM_GP(int))diag_cnt, (SDM_GP(int))tmo, !have_S, nrows > 0, ds, &npub, raw_in_lds, carry ? lbs_pre : nullptr);
         if (nrows > 0) {
           if (16 * npub < kb) SDM_STORES_DONE();
           __syncthreads();
@@ -1714,7 +1703,7 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
         // the kernel exactly as the GPU runs it (phase 0: everything carried in LDS, the fused row solve of the chain workgroup,
         // the data-tagged hand-over): one process per workgroup, all at once (tests/hipemu: emu_launch_concurrent)
         SDM_KLAUNCH_CONCURRENT(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
-                               C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p,
+                               C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.panel_ctx.p, C.front_cnt.p,
                                C.diag_cnt.p, 0, 0, C.lev_maxT[l], C.tmo.dev());
         if (follow) solve_follow(P, l, st);                          // beside it, polling its counters -- as on the second stream of the device
         emu_group_end();
@@ -1723,7 +1712,7 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
       for (int step = 0; step < maxnp; step++)
         for (int phase = 1; phase <= 3; phase++)
           SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
-                      C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p,
+                      C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.panel_ctx.p, C.front_cnt.p,
                       C.diag_cnt.p, phase, step, C.lev_maxT[l], C.tmo.dev());
       if (follow) solve_follow(P, l, st);                            // (workgroups run one after the other here: behind = after)
 #else
@@ -1744,7 +1733,7 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
         SDM_HIP_CHECK(hipStreamWaitEvent(P->stream2, P->ev_fork, 0));
       }
       SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
-                  C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.colbuf.p, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, m, C.front_cnt.p,
+                  C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.panel_ctx.p, C.front_cnt.p,
                   C.diag_cnt.p, 0, 0, C.lev_maxT[l], C.tmo.dev());
       if (follow) {
         solve_follow(P, l, P->stream2);

@@ -92,27 +92,6 @@ def test_panel_launch_publishes_only_after_its_stores_are_acknowledged(hiplib, t
     assert checked >= 2
 
 
-def test_chain_functions_of_the_one_launch_front_touch_no_scratch(hiplib, tmp_path):
-    """k_ldl_front calls its stages as real functions.  Those on the chain from one diagonal block to the next (the chain
-    workgroup's row solve front_rows_diag, the other workgroups' front_rows and front_update) must fit the registers a callee
-    may use freely: one that needs more saves and restores callee-saved VGPRs through scratch on EVERY call -- 152 scratch
-    instructions and 1.4 us per panel when an unrolled store loop in front_rows_diag did (round 3, profiles/r03aq / r03ar)."""
-    import shutil
-    lib = shutil.copy(hiplib, tmp_path / "lib.so")
-    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    subprocess.run([objdump, "--offloading", str(lib)], capture_output=True, text=True, cwd=tmp_path)
-    found = {}
-    for f in sorted(os.listdir(tmp_path)):
-        if "gfx950" not in f:
-            continue
-        dis = subprocess.run([objdump, "-d", str(tmp_path / f)], capture_output=True, text=True).stdout
-        for name in ("front_rows_diag", "front_rows", "front_update"):
-            for sym, part in re.findall(r"^[0-9a-f]+ <([^>]*sdm\d+%s[A-Z][^>]*)>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)" % name, dis, flags=re.S | re.M):
-                found[name] = len(re.findall(r"\bscratch_(?:load|store)", part))
-    assert set(found) == {"front_rows_diag", "front_rows", "front_update"}, found
-    assert all(v == 0 for v in found.values()), found
-
-
 def test_loader_fails_loudly_without_library(tmp_path):
     from sedumi_amd import capi
     capi.use_library(str(tmp_path / "nope.so"))
@@ -135,11 +114,23 @@ def test_no_device_is_an_error_not_a_fallback(hiplib):
         Plan(0)
 
 
-def test_no_kernel_spills_vector_registers(hiplib):
+def _disassemble_gfx950(hiplib, tmp_path):
+    import shutil
+    lib = shutil.copy(hiplib, tmp_path / "lib.so")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    subprocess.run([objdump, "--offloading", str(lib)], capture_output=True, text=True, cwd=tmp_path)
+    return "\n".join(subprocess.run([objdump, "-d", str(tmp_path / f)], capture_output=True, text=True).stdout
+                     for f in sorted(os.listdir(tmp_path)) if "gfx950" in f)       # one code object per source file
+
+
+def test_no_kernel_spills_vector_registers(hiplib, tmp_path):
     """Code-object metadata of every gfx950 kernel in the library (llvm-readelf --notes on the embedded code objects,
-    tools/code_objects.py): no kernel spills VGPRs.  k_ldl_panel did (167, round 2) until its workgroup roles became
-    separate register allocations; the two factor kernels keep a few hundred bytes of scratch for the argument blocks and
-    return addresses of those calls, everything else has none."""
+    tools/code_objects.py): no kernel spills VGPRs inside its code.  k_ldl_panel did (167, round 2) until its workgroup roles
+    became separate register allocations.  ONE exception, checked instruction by instruction: the diagonal-block role of
+    k_ldl_panel calls three stages that use the whole register file and save nothing for their caller (the cheap form of
+    a call: tests below), so the role parks what it needs after a call -- the work-item id, a dozen addresses -- in scratch
+    right before the call and fetches it right after.  The metadata counts those as 3 spilled VGPRs; every scratch
+    instruction of the role must sit within a few instructions of a call, the function's entry or its end."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("code_objects", os.path.join(ROOT, "tools", "code_objects.py"))
     co = importlib.util.module_from_spec(spec)
@@ -149,6 +140,35 @@ def test_no_kernel_spills_vector_registers(hiplib):
     ks = co.kernels(hiplib)
     assert len(ks) >= 40 and any("k_ldl_front" in k for k in ks) and any("k_sfw_diag" in k for k in ks)
     spilling = {k: v["vgpr_spill_count"] for k, v in ks.items() if v["vgpr_spill_count"]}
-    assert not spilling, f"kernels that spill vector registers: {spilling}"
+    assert all("k_ldl_panel" in k and n <= 4 for k, n in spilling.items()), f"kernels that spill vector registers: {spilling}"
     scratch = sorted(k for k, v in ks.items() if v["private_segment_fixed_size"])
     assert all("k_ldl_front" in k or "k_ldl_panel" in k for k in scratch), scratch
+    # where the scratch instructions of k_ldl_panel and of its diagonal-block role are
+    dis = _disassemble_gfx950(hiplib, tmp_path)
+    checked = 0
+    for name in ("k_ldl_panel", "panel_role_diag"):
+        for sym, part in re.findall(r"^[0-9a-f]+ <([^>]*sdm\d+%s[A-Z][^>]*)>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)" % name, dis, flags=re.S | re.M):
+            lines = [l for l in part.split("\n") if l.strip()]
+            anchors = [i for i, l in enumerate(lines) if "s_swappc_b64" in l or "s_endpgm" in l or "s_setpc_b64" in l] + [0, len(lines) - 1]
+            for i, l in enumerate(lines):
+                if re.search(r"\bscratch_(?:load|store)", l):
+                    assert min(abs(i - a) for a in anchors) <= 24, (sym, i, l)
+                    checked += 1
+    assert checked > 0
+
+
+def test_called_stages_save_no_registers_for_their_callers(hiplib, tmp_path):
+    """The stages of the two factor kernels are called functions that use most of the register file.  Under the default
+    convention such a function saves and restores every callee-saved VGPR it touches through scratch on each call -- 72 in the
+    diagonal-block stage, 117 in panel_diag_rows (round 3: 2 us per panel of MAXCUT-4000's factor, 0.7 us per panel of
+    control07's).  Internal functions whose calls are not marked as tail calls are exempt (the caller keeps what it needs in
+    registers the callee leaves alone): SDM_NOINLINE carries not_tail_called for that.  Checked here: none of them has more
+    than a handful of scratch instructions."""
+    dis = _disassemble_gfx950(hiplib, tmp_path)
+    found = {}
+    for name in ("front_diag", "front_rows_diag", "front_rows", "front_update", "panel_diag_block", "panel_diag_rows", "panel_diag_update"):
+        for sym, part in re.findall(r"^[0-9a-f]+ <([^>]*sdm\d+%s[A-Z][^>]*)>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)" % name, dis, flags=re.S | re.M):
+            found[name] = len(re.findall(r"\bscratch_(?:load|store)", part))
+    assert len(found) == 7, found
+    assert all(v <= 16 for v in found.values()), found
+    assert found["front_rows_diag"] == 0 and found["front_rows"] == 0 and found["front_update"] == 0, found

@@ -270,6 +270,12 @@ int sdm_plan_copy(sdm_plan *p, const char *name, void *devptr, sdm_int offset, s
 /* blkchol (sedumi.m:458) on the resident "ada"/"absd".  use_absd=0 takes
  * diag(ADA(perm,perm)) as in blkchol.c:380-381. */
 int sdm_plan_blkchol(sdm_plan *p, const sdm_cholpars *pars, int use_absd);
+/* The same, waited for, with ONE recovery: if a workgroup of a one-launch level gave up waiting for another one (the device
+ * is shared with another process and not all of the launch's workgroups became resident), the factorisation is repeated
+ * once on the launch-per-panel path and the plan stays on that path.  What blkchol.mex and sdm_blkchol call (they hand
+ * the factor back, so they wait anyway); the asynchronous form above reports such a time-out as an error at the plan's
+ * next read-back instead. */
+int sdm_plan_blkchol_wait(sdm_plan *p, const sdm_cholpars *pars, int use_absd);
 /* pivot report of the last factor: counts (host, synchronises) and lists. */
 int sdm_plan_pivots(sdm_plan *p, sdm_int *nskip, sdm_int *skip_idx, double *skip_val,
                     sdm_int *nadd, sdm_int *add_idx, double *add_val);

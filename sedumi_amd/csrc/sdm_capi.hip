@@ -206,6 +206,16 @@ int sdm_plan_blkchol(sdm_plan *p, const sdm_cholpars *pars, int use_absd) {
   chol_factor(p, q.canceltol, q.maxu, q.abstol, use_absd);
   SDM_CATCH
 }
+int sdm_plan_blkchol_wait(sdm_plan *p, const sdm_cholpars *pars, int use_absd) {
+  SDM_TRY
+  for (int attempt = 0; ; attempt++) {
+    if (sdm_plan_blkchol(p, pars, use_absd)) throw std::runtime_error(g_err);
+    SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    if (!chol_wait_timeouts(p)) break;                               // (a time-out switches the plan to the launch-per-panel path)
+    if (attempt == 1) throw std::runtime_error("blkchol: a workgroup timed out waiting for another one inside a panel launch");
+  }
+  SDM_CATCH
+}
 // ---- the factorisation and the solve level by level (include/sedumi_hip.h: "Separator fronts across GPUs")
 int sdm_plan_set_active_supernodes(sdm_plan *p, const int *active, sdm_int nsuper) {
   SDM_TRY
@@ -598,7 +608,7 @@ int sdm_blkchol(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int
   if (sdm_plan_set_chol(p, m, Ljc, Lir, perm, nsuper, xsuper, Xjc, Xir)) throw std::runtime_error(g_err);
   SDM_HIP_CHECK(hipMemcpy(p->ada_val.p, Xpr, (size_t)Xjc[m] * sizeof(double), hipMemcpyHostToDevice));
   if (absd) SDM_HIP_CHECK(hipMemcpy(p->absd.p, absd, m * sizeof(double), hipMemcpyHostToDevice));
-  if (sdm_plan_blkchol(p, pars, absd ? 1 : 0)) throw std::runtime_error(g_err);
+  if (sdm_plan_blkchol_wait(p, pars, absd ? 1 : 0)) throw std::runtime_error(g_err);
   if (sdm_plan_download(p, "lpr", Lpr, Ljc[m])) throw std::runtime_error(g_err);
   if (sdm_plan_download(p, "d", d, m)) throw std::runtime_error(g_err);
   if (sdm_plan_pivots(p, nskip, skip_idx, skip_val, nadd, add_idx, add_val)) throw std::runtime_error(g_err);

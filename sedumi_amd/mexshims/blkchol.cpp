@@ -27,7 +27,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   remember_factor(NULL, 0);          // the resident factor is about to be overwritten: whatever the solves are handed before this call has returned is not it
   sdm_check(sdm_plan_upload(p, "ada", mxGetPr(X), (sdm_int)mxGetJc(X)[m]));
   if (absd) sdm_check(sdm_plan_upload(p, "absd", absd, m));
-  sdm_check(sdm_plan_blkchol(p, &pars, absd ? 1 : 0));
+  sdm_check(sdm_plan_blkchol_wait(p, &pars, absd ? 1 : 0));      // (waited for, repeated once on the launch-per-panel path after a time-out)
   sdm_check(sdm_plan_download(p, "lpr", mxGetPr(out[0]), nnzL));
   sdm_check(sdm_plan_download(p, "d", mxGetPr(out[1]), m));
   ivec sidx(m > 0 ? m : 1), aidx(m > 0 ? m : 1);

@@ -1715,6 +1715,7 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
                       C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.panel_ctx.p, C.front_cnt.p,
                       C.diag_cnt.p, phase, step, C.lev_maxT[l], C.tmo.dev());
       if (follow) solve_follow(P, l, st);                            // (workgroups run one after the other here: behind = after)
+      if (emu_take_injected_timeout()) *(volatile int *)C.tmo.host = 1;   // (tests: as if a workgroup of this launch had given up waiting)
 #else
       if (follow) {
         // fork: the inverse of the level's fronts follows the factorisation on the second stream (k_sinv_follow polls

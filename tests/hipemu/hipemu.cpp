@@ -139,6 +139,9 @@ void emu_shared_free(void *p) {
   munmap(m, *(size_t *)m);
 }
 void emu_set_concurrent(int on) { g_concurrent = on; }
+static int g_injected_timeouts = 0;
+void emu_inject_timeouts(int n) { g_injected_timeouts = n; }
+int emu_take_injected_timeout() { if (g_injected_timeouts <= 0) return 0; g_injected_timeouts--; return 1; }
 int emu_concurrent() { return g_concurrent; }
 void emu_spin_pause() {
   if (!g_in_wg_process) { fprintf(stderr, "hipemu: waiting on a workgroup that has not run\n"); abort(); }

@@ -118,6 +118,10 @@ void emu_launch_concurrent(dim3 grid, dim3 block, size_t shmem, const std::funct
 void emu_group_begin();
 void emu_group_end();
 void emu_set_concurrent(int on);
+/* fault injection for the host-side recovery paths: the next n launches that ask (emu_take_injected_timeout) are told that
+   one of their workgroups gave up waiting */
+void emu_inject_timeouts(int n);
+int emu_take_injected_timeout();
 int emu_concurrent();
 /* inside a spin loop on another workgroup's progress: yields the processor in a workgroup process, aborts in a sequential
    launch (there the other workgroup has either run already or never will) */

@@ -420,3 +420,32 @@ def test_one_launch_front_pivot_rule(refmex, m, maxu):
 @pytest.mark.parametrize("m,thr", [(90, None), (300, None), (666, None), (700, 0.0), (700, 1e-3), (256, 0.0), (530, None)])
 def test_solve_widths(m, thr):
     helpers.check_solve_widths(m, thr)
+
+
+def test_blocking_blkchol_recovers_from_a_starved_one_launch_level(refmex):
+    """sdm_plan_blkchol_wait (what blkchol.mex and sdm_blkchol call): a one-launch level whose workgroups could not all become
+    resident raises the plan's time-out flag; the factorisation is repeated once on the launch-per-panel path and the plan
+    stays there.  The time-out is injected (tests/hipemu: emu_inject_timeouts)."""
+    import ctypes
+    from hipemu import build_emu
+    from oracle import glue as gl
+    from sedumi_amd import mex, problem
+    lib = ctypes.CDLL(build_emu.build())
+    m = 330
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((m, m))
+    X = sp.csc_matrix(B @ B.T + m * np.eye(m)); X.sort_indices()
+    L = problem.dense_symbolic(m)
+    r = refmex.call("blkchol", 4, L, X, gl.default_pars_chol())
+    lib._Z19emu_inject_timeoutsi(1)
+    o = mex.blkchol(L, X, gl.default_pars_chol())
+    assert relerr(o[1].ravel(), r[1].ravel()) < TOL and relerr(sp.csc_matrix(o[0]).data, sp.csc_matrix(r[0]).data) < TOL
+    assert lib._Z25emu_take_injected_timeoutv() == 0                       # it was consumed by the first attempt
+    # a second factorisation of the same pattern by the same (cached) plan: it stays on the launch-per-panel path, where nothing
+    # waits for workgroups that are not resident yet -- an injected time-out is not even looked at
+    lib._Z19emu_inject_timeoutsi(1)
+    try:
+        o = mex.blkchol(L, X, gl.default_pars_chol())
+        assert relerr(o[1].ravel(), r[1].ravel()) < TOL
+    finally:
+        lib._Z19emu_inject_timeoutsi(0)

@@ -109,3 +109,28 @@ def test_panel_launches_as_concurrent_workgroups(refmex, concurrent_emu, m):
     X, _ = _dense_front(m, m)
     r = refmex.call("blkchol", 4, problem.dense_symbolic(m), X, gl.default_pars_chol())
     assert relerr(d1, r[1].ravel()) < TOL and relerr(l1, sp.csc_matrix(r[0]).data) < TOL
+
+
+# ---- the sparse / multi-front cases of tests/test_emu_parity.py once more, their factor launches as concurrent workgroups
+# (levels of many small fronts: grid.y > 1; launches of more than 200 workgroups keep the phased form)
+import test_emu_parity as _tp  # noqa: E402
+
+
+@pytest.mark.parametrize("kind,m", [("rand", 120), ("arrow", 70), ("blockdiag", 100), ("grid", 100)])
+def test_sparse_factor_and_solves_as_concurrent_workgroups(refmex, glue, concurrent_emu, kind, m):
+    _tp.test_sparse_factor_and_solves(refmex, glue, kind, m)
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_pivot_decisions_as_concurrent_workgroups(refmex, glue, concurrent_emu, case):
+    _tp.test_pivot_decisions_skip_and_add(refmex, glue, case)
+
+
+@pytest.mark.parametrize("kind,m,thr", [("rand", 200, 0.0), ("grid", 144, 0.0), ("bordered", 0, 1e4)])
+def test_multifront_solves_as_concurrent_workgroups(refmex, glue, concurrent_emu, kind, m, thr):
+    _tp.test_multifront_solves_with_and_without_fallback(refmex, glue, kind, m, thr)
+
+
+def test_iteration_units_as_concurrent_workgroups(glue, concurrent_emu):
+    _tp.test_iteration_unit_block_diagonal_multi_supernode(glue)
+    _tp.test_iteration_unit_maxcut_small(glue)

@@ -999,10 +999,10 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
 #define SDM_NOINLINE __noinline__ __attribute__((not_tail_called))
 #endif
 #ifndef SDM_NI_ROWS
-#define SDM_NI_ROWS __forceinline__       // (measured: +1 us per launch as a call)
+#define SDM_NI_ROWS __forceinline__       // (measured: +1 us per launch as a call -- while calls still saved callee-saved registers, see SDM_NOINLINE)
 #endif
 #ifndef SDM_NI_TILES
-#define SDM_NI_TILES __forceinline__      // (the throughput role of big fronts: as a call it saves and reloads 40 callee-saved VGPRs per workgroup, +4 us per launch on MAXCUT-4000)
+#define SDM_NI_TILES __forceinline__      // (the throughput role of big fronts: as a call it saved and reloaded 40 callee-saved VGPRs per workgroup, +4 us per launch on MAXCUT-4000 -- before not_tail_called; not measured again)
 #endif
 #ifndef SDM_NI_DUPD
 #define SDM_NI_DUPD SDM_NOINLINE

@@ -615,12 +615,14 @@ __device__ __forceinline__ void panel_rows_mfma(double *Fs, int ld, int ms, int 
 }
 
 // rows [rbeg, rend) below the diagonal block of panel k0 (at most brows = TRSM_ROWS of them per call)
+// ONLY: 0 both paths compiled in, 1 the blocked (MFMA) path alone, 2 the few-rows path alone (callers that have chosen already)
+template <int ONLY = 0>
 __device__ __forceinline__ void panel_rows(double *Fs, int ld, int ns, int ms, int k0, int kb, int rbeg, int rend, int brows,
                                            const double (*S)[NB + 1], const double *ds, double *RB, bool staged = false) {
   SDM_FP_STRICT;
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, ny = LDL_THREADS >> 6;
   rend = min(rend, ms);
-  if (ms - min(NB, ns) >= MFMA_MIN_ROWS) {                         // per front, the same path for all its panels
+  if (ONLY != 2 && (ONLY == 1 || ms - min(NB, ns) >= MFMA_MIN_ROWS)) {   // per front, the same path for all its panels
     // 16 rows per wavefront at a time, blocked substitution with the GEMM part on the matrix cores
     for (int R0 = rbeg + 16 * ty; R0 < rend; R0 += 16 * ny)
       panel_rows_mfma(Fs, ld, rend, k0, kb, R0, S, ds, RB + ty * (NB * 17), tx, staged);
@@ -1004,15 +1006,6 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
 #ifndef SDM_NI_TILES
 #define SDM_NI_TILES __forceinline__      // (the throughput role of big fronts: as a call it saved and reloaded 40 callee-saved VGPRs per workgroup, +4 us per launch on MAXCUT-4000 -- before not_tail_called; not measured again)
 #endif
-#ifndef SDM_NI_DUPD
-#define SDM_NI_DUPD SDM_NOINLINE
-#endif
-#ifndef SDM_NI_DBLK
-#define SDM_NI_DBLK SDM_NOINLINE
-#endif
-#ifndef SDM_NI_DROWS
-#define SDM_NI_DROWS SDM_NOINLINE
-#endif
 // The roles of a k_ldl_panel workgroup are REAL function calls (as in k_ldl_front below): inlined into one body they shared one
 // register allocation and the kernel spilled 167 VGPRs (round 2); each role alone fits.
 // ---- row-solve workgroup b of panel `panel` (see k_ldl_panel)
@@ -1107,21 +1100,60 @@ __device__ SDM_NI_TILES void panel_role_tiles(char *smem, double *Fs, const doub
   }
   SDM_ENDPGM();
 }
-// ---- workgroup 0, first piece: tile (0,0) of the previous update = this panel's diagonal block, straight into S
-__device__ SDM_NI_DUPD void panel_diag_update(char *smem, SDM_GP(double) Fs_, SDM_GP(const double) d_, int ms, int ld, int first, int panel, int kbc) {
-  SDM_FP_STRICT;
-  double *Fs = (double *)Fs_;
-  const double *d = (const double *)d_;
-  double (*As)[UTP] = (double (*)[UTP])smem;
-  double (*Bs)[UTP] = As + NB;
-  __shared__ double dsh[NB];
-  update_tile<LDL_THREADS / 64, true>(Fs, ld, ms, first, (panel - 1) * NB, NB, 0, 0, d, As, Bs, dsh,
-                                      (double (*)[NB + 1])smem, (double *)smem + NB * (NB + 1), kbc);
+// ---- workgroup 0 = the dependency chain of the launch, as a CHAIN OF STAGES that never return: the role's prologue calls the update
+// of its diagonal tile, which calls the LDL' of the block, which calls the rows left to this workgroup -- each call the last thing its
+// caller does.  Each stage is a function for the sake of its own register allocation (inlined into one body they spilled 167 VGPRs,
+// round 2); as calls that RETURN they made their caller park what it needed afterwards -- the work-item id, a dozen addresses --
+// in scratch around every call, because a called stage uses the whole register file and saves nothing (SDM_NOINLINE).  A caller
+// with nothing left to do has nothing to park: what the later stages need travels along as arguments, in registers.
+// (The emulator's functions do return: every stage ends with SDM_ENDPGM = return there.)
+
+// (its few-rows form: fronts whose rows below the first block are fewer than MFMA_MIN_ROWS -- the small fronts of arch0, nb)
+__device__ SDM_NOINLINE SDM_NORETURN void panel_stage_rows_few(char *smem, SDM_GP(double) Fs_, int ld, int ns, int ms, int k0, int kb, int rbeg, int rend, const double *ds) {
+  panel_rows<2>((double *)Fs_, ld, ns, ms, k0, kb, rbeg, rend, TRSM_ROWS, (const double (*)[NB + 1])smem, ds, (double *)smem + NB * (NB + 1));
+  SDM_ENDPGM();
 }
-// ---- workgroup 0, second piece: the LDL' of the block
-__device__ SDM_NI_DBLK bool panel_diag_block(char *smem, SDM_GP(double) F_, SDM_GP(double) DT_, const FrontDesc *fd, int panel, SDM_GP(double) d_, SDM_GP(double) lb_,
-                                              SDM_GP(int) pivstat_, SDM_GP(double) pivval_, SDM_GP(const PanelCtx) ctx_, SDM_GP(int) upd_cnt_, SDM_GP(int) diag_cnt_, int q0,
-                                              SDM_GP(int) tmo_, bool load_block, bool publish, double *ds, int *npub) {
+__device__ SDM_NOINLINE SDM_NORETURN void panel_stage_rows_blocked(char *smem, SDM_GP(double) Fs_, int ld, int ns, int ms, int k0, int kb, int rbeg, int rend, const double *ds) {
+  panel_rows<1>((double *)Fs_, ld, ns, ms, k0, kb, rbeg, rend, TRSM_ROWS, (const double (*)[NB + 1])smem, ds, (double *)smem + NB * (NB + 1));
+  SDM_ENDPGM();
+}
+// last stage: the rows of the block column that are this workgroup's own
+__device__ SDM_NOINLINE SDM_NORETURN void panel_stage_rows(char *smem, const FrontDesc *fdp, int panel, SDM_GP(double) F_, SDM_GP(int) upd_cnt_, int q0,
+                                                          SDM_GP(int) tmo_, const double *ds, bool ok) {
+  double *F = (double *)F_;
+  int *upd_cnt = (int *)upd_cnt_;
+  int *tmo = (int *)tmo_;
+  const FrontDesc &fd = *fdp;
+  const int s = fd.s, ns = fd.ns, ms = fd.ms, ld = fd.ld;
+  double *Fs = F + fd.foff;
+  const int k0 = panel * NB, kb = min(NB, ns - k0);
+  const int r0 = k0 + kb, nrows = ms - r0;
+  SDM_PHASE_BEGIN();
+  int rend = r0;                                                   // rows r0 .. rend-1 are solved here (one call site: panel_rows is big)
+  if (nrows > TRSM_ROWS) {
+    // a partial block (kb < 64, last panel of the supernode) leaves rows r0 .. k0+63 in this workgroup's own tile row:
+    // they were updated by its tile (0,0) and are solved here (the row-solve workgroups own whole tile rows)
+    if (kb < NB) {
+      SDM_ACQUIRE_FENCE();                                         // its own tile-(0,0) stores, not a cached copy from before them
+      rend = k0 + NB;
+    }
+  } else if (nrows > 0) {
+    if (panel > 0 && ok) wait_prev_update(upd_cnt + s, ns, ms, panel, q0, tmo);
+    rend = ms;
+  }
+  SDM_PHASE(22);
+  if (rend > r0) {
+    // (the two forms of the row solve as two stages: together in one function the few-rows form spilled inside its chunk loop)
+    if (ms - min(NB, ns) >= MFMA_MIN_ROWS) panel_stage_rows_blocked(smem, (SDM_GP(double))Fs, ld, ns, ms, k0, kb, r0, rend, ds);
+    else panel_stage_rows_few(smem, (SDM_GP(double))Fs, ld, ns, ms, k0, kb, r0, rend, ds);
+  }
+  SDM_PHASE(23);
+  SDM_ENDPGM();
+}
+// middle stage: the LDL' of the block and its publication
+__device__ SDM_NOINLINE SDM_NORETURN void panel_stage_block(char *smem, SDM_GP(double) F_, SDM_GP(double) DT_, const FrontDesc *fdp, int panel, SDM_GP(double) d_, SDM_GP(double) lb_,
+                                                           SDM_GP(int) pivstat_, SDM_GP(double) pivval_, SDM_GP(const PanelCtx) ctx_, SDM_GP(int) upd_cnt_, SDM_GP(int) diag_cnt_,
+                                                           int q0, SDM_GP(int) tmo_) {
   double *F = (double *)F_;
   double *DT = (double *)DT_;
   double *d = (double *)d_;
@@ -1132,71 +1164,59 @@ __device__ SDM_NI_DBLK bool panel_diag_block(char *smem, SDM_GP(double) F_, SDM_
   int *upd_cnt = (int *)upd_cnt_;
   int *diag_cnt = (int *)diag_cnt_;
   int *tmo = (int *)tmo_;
-  return ldl_diag_block<false>(smem, F, DT, *fd, panel, d, lb, pivstat, pivval, ctx, upd_cnt, diag_cnt, q0, tmo, load_block, publish, ds, npub);
+  const FrontDesc &fd = *fdp;
+  const int k0 = panel * NB, kb = min(NB, fd.ns - k0);
+  const int nrows = fd.ms - (k0 + kb);
+  __shared__ double ds[NB];
+  __shared__ int npub;
+  const bool ok = ldl_diag_block<false>(smem, F, DT, fd, panel, d, lb, pivstat, pivval, ctx, upd_cnt, diag_cnt, q0, tmo, panel == 0, nrows > TRSM_ROWS, ds, &npub);
+  if (nrows > TRSM_ROWS) {                                         // the row-solve workgroups of this launch are waiting
+    if (16 * npub < kb) SDM_STORES_DONE();                         // (uniform) something of the block is still unpublished
+    __syncthreads();
+    if (threadIdx.x == 0) sdm_signal_add(&diag_cnt[fd.s], 4 - npub);   // 4 counts per panel: one per 16 columns of the block
+    if (kb == NB) SDM_ENDPGM();                                    // nothing of the block column is left to this workgroup
+  } else {
+    // nobody in this launch waits for this block; the launches to come find the count (= 4 x panels done) in place -- what they
+    // read of THIS launch's rows is ordered by the launch boundary, so the count need not wait for the rows below
+    SDM_STORES_DONE();
+    __syncthreads();
+    if (threadIdx.x == 0) sdm_signal_add(&diag_cnt[fd.s], 4);
+    if (nrows <= 0) SDM_ENDPGM();
+  }
+  panel_stage_rows(smem, fdp, panel, (SDM_GP(double))F, (SDM_GP(int))upd_cnt, q0, (SDM_GP(int))tmo, ds, ok);
+  SDM_ENDPGM();
 }
-// ---- workgroup 0, last piece: rows of its own tile row that are left to it
-__device__ SDM_NI_DROWS void panel_diag_rows(char *smem, SDM_GP(double) Fs_, int ld, int ns, int ms, int k0, int kb, int rbeg, int rend, const double *ds) {
-  double *Fs = (double *)Fs_;
-  panel_rows(Fs, ld, ns, ms, k0, kb, rbeg, rend, TRSM_ROWS, (const double (*)[NB + 1])smem, ds, (double *)smem + NB * (NB + 1));
+// first stage (panels after the first): tile (0,0) of the previous update = this panel's diagonal block, straight into S
+__device__ SDM_NOINLINE SDM_NORETURN void panel_stage_update(char *smem, SDM_GP(double) F_, SDM_GP(double) DT_, const FrontDesc *fdp, int panel, SDM_GP(double) d_, SDM_GP(double) lb_,
+                                                            SDM_GP(int) pivstat_, SDM_GP(double) pivval_, SDM_GP(const PanelCtx) ctx_, SDM_GP(int) upd_cnt_, SDM_GP(int) diag_cnt_,
+                                                            int q0, SDM_GP(int) tmo_) {
+  SDM_FP_STRICT;
+  {
+    const FrontDesc &fd = *fdp;
+    double *Fs = (double *)F_ + fd.foff;
+    const double *d = (const double *)d_;
+    double (*As)[UTP] = (double (*)[UTP])smem;
+    double (*Bs)[UTP] = As + NB;
+    __shared__ double dsh[NB];
+    update_tile<LDL_THREADS / 64, true>(Fs, fd.ld, fd.ms, fd.first, (panel - 1) * NB, NB, 0, 0, d, As, Bs, dsh,
+                                        (double (*)[NB + 1])smem, (double *)smem + NB * (NB + 1), min(NB, fd.ns - panel * NB));
+  }
+  panel_stage_block(smem, F_, DT_, fdp, panel, d_, lb_, pivstat_, pivval_, ctx_, upd_cnt_, diag_cnt_, q0, tmo_);
+  SDM_ENDPGM();
 }
-
-#ifndef SDM_NI_DIAG
-#define SDM_NI_DIAG SDM_NOINLINE
-#endif
-// ---- workgroup 0: its tile of the previous update, the LDL' of the block, the rows left to it, the counts
-__device__ SDM_NI_DIAG SDM_NORETURN void panel_role_diag(char *smem, SDM_GP(double) F_, SDM_GP(double) DT_, FrontDesc *fdp, int panel, SDM_GP(double) d_,
+// the role's prologue
+__device__ SDM_NOINLINE SDM_NORETURN void panel_role_diag(char *smem, SDM_GP(double) F_, SDM_GP(double) DT_, FrontDesc *fdp, int panel, SDM_GP(double) d_,
                                                          SDM_GP(const PanelCtx) ctx_, SDM_GP(int) upd_cnt_, SDM_GP(int) diag_cnt_, int q0, SDM_GP(int) tmo_) {
-  double *F = (double *)F_;
-  double *DT = (double *)DT_;
-  double *d = (double *)d_;
   const PanelCtx *ctx = (const PanelCtx *)ctx_;
-  int *upd_cnt = (int *)upd_cnt_;
-  int *diag_cnt = (int *)diag_cnt_;
-  int *tmo = (int *)tmo_;
   // (uniform loads: one scalar round trip, issued before the tile of the previous update is fetched)
   double *lb = ctx->lb; int *pivstat = ctx->pivstat; double *pivval = ctx->pivval;
-  const FrontDesc &fd = *fdp;
-  const int s = fd.s;
   {
     const double *ubp = ctx->ubp;
     const double maxu = ubp[1], ub = ubp[2] / (maxu * maxu);
     if (threadIdx.x == 0) { fdp->maxu = maxu; fdp->ub = ub; }      // (read behind the first barrier of the diagonal block)
   }
-  const int ns = fd.ns, ms = fd.ms, ld = fd.ld, first = fd.first;
-  double *Fs = F + fd.foff;
-  const int k0 = panel * NB, kb = min(NB, ns - k0);
-  const int r0 = k0 + kb, nrows = ms - r0;
-  if (panel > 0) panel_diag_update(smem, (SDM_GP(double))Fs, (SDM_GP(const double))d, ms, ld, first, panel, kb);
-  __shared__ double ds[NB];
-  __shared__ int npub;
-  const int tid = threadIdx.x;
-  const bool ok = panel_diag_block(smem, (SDM_GP(double))F, (SDM_GP(double))DT, fdp, panel, (SDM_GP(double))d, (SDM_GP(double))lb, (SDM_GP(int))pivstat, (SDM_GP(double))pivval,
-                                   (SDM_GP(const PanelCtx))ctx, (SDM_GP(int))upd_cnt, (SDM_GP(int))diag_cnt, q0, (SDM_GP(int))tmo, panel == 0, nrows > TRSM_ROWS, ds, &npub);
-  SDM_PHASE_BEGIN();
-  if (nrows > TRSM_ROWS) {                                         // the row-solve workgroups of this launch are waiting
-    if (16 * npub < kb) SDM_STORES_DONE();                         // (uniform) something of the block is still unpublished
-    __syncthreads();
-    if (tid == 0) sdm_signal_add(&diag_cnt[s], 4 - npub);          // 4 counts per panel: one per 16 columns of the block
-    // a partial block (kb < 64, last panel of the supernode) leaves rows r0 .. k0+63 in this workgroup's own tile row:
-    // they were updated by its tile (0,0) and are solved here (the row-solve workgroups own whole tile rows)
-    if (kb < NB) {
-      SDM_ACQUIRE_FENCE();                                       // its own tile-(0,0) stores, not a cached copy from before them
-      panel_diag_rows(smem, (SDM_GP(double))Fs, ld, ns, ms, k0, kb, r0, k0 + NB, ds);
-    }
-  }
-  SDM_PHASE(22);
-  if (nrows > 0 && nrows <= TRSM_ROWS) {
-    if (panel > 0 && ok) wait_prev_update(upd_cnt + s, ns, ms, panel, q0, tmo);
-    panel_diag_rows(smem, (SDM_GP(double))Fs, ld, ns, ms, k0, kb, r0, ms, ds);
-  }
-  if (nrows <= TRSM_ROWS) {
-    // nobody in this launch waits for this block: the count (= 4 x panels done) goes up at the very end, behind the
-    // same stores-acknowledged / barrier sequence as every other publication
-    SDM_STORES_DONE();
-    __syncthreads();
-    if (tid == 0) sdm_signal_add(&diag_cnt[s], 4);
-  }
-  SDM_PHASE(23);
+  if (panel > 0) panel_stage_update(smem, F_, DT_, fdp, panel, d_, (SDM_GP(double))lb, (SDM_GP(int))pivstat, (SDM_GP(double))pivval, ctx_, upd_cnt_, diag_cnt_, q0, tmo_);
+  else panel_stage_block(smem, F_, DT_, fdp, panel, d_, (SDM_GP(double))lb, (SDM_GP(int))pivstat, (SDM_GP(double))pivval, ctx_, upd_cnt_, diag_cnt_, q0, tmo_);
   SDM_ENDPGM();
 }
 

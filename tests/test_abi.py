@@ -70,7 +70,7 @@ def test_panel_launch_publishes_only_after_its_stores_are_acknowledged(hiplib, t
             continue
         dis = subprocess.run([objdump, "-d", str(tmp_path / f)], capture_output=True, text=True).stdout
         # the kernel and the device functions its workgroup roles live in (panel_role_diag is a real call)
-        parts = re.findall(r"^[0-9a-f]+ <[^>]*(?:k_ldl_panel|panel_role_|panel_diag_)[^>]*>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)", dis, flags=re.S | re.M)
+        parts = re.findall(r"^[0-9a-f]+ <[^>]*(?:k_ldl_panel|panel_role_|panel_stage_)[^>]*>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)", dis, flags=re.S | re.M)
         if parts:
             body = [l for part in parts for l in part.split("\n") + ["<function boundary>"]]
             break
@@ -125,12 +125,10 @@ def _disassemble_gfx950(hiplib, tmp_path):
 
 def test_no_kernel_spills_vector_registers(hiplib, tmp_path):
     """Code-object metadata of every gfx950 kernel in the library (llvm-readelf --notes on the embedded code objects,
-    tools/code_objects.py): no kernel spills VGPRs inside its code.  k_ldl_panel did (167, round 2) until its workgroup roles
-    became separate register allocations.  ONE exception, checked instruction by instruction: the diagonal-block role of
-    k_ldl_panel calls three stages that use the whole register file and save nothing for their caller (the cheap form of
-    a call: tests below), so the role parks what it needs after a call -- the work-item id, a dozen addresses -- in scratch
-    right before the call and fetches it right after.  The metadata counts those as 3 spilled VGPRs; every scratch
-    instruction of the role must sit within a few instructions of a call, the function's entry or its end."""
+    tools/code_objects.py): no kernel spills VGPRs.  k_ldl_panel did (167, round 2) until its workgroup roles became separate
+    register allocations.  ONE exception, pinned down function by function in the test below: the blocked row solve that
+    workgroup 0 of k_ldl_panel runs on the rows of a partial last block (panel_stage_rows_blocked) keeps five addresses in
+    scratch across its 16-row batches -- 3 spilled VGPRs in the kernel's metadata."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("code_objects", os.path.join(ROOT, "tools", "code_objects.py"))
     co = importlib.util.module_from_spec(spec)
@@ -140,35 +138,29 @@ def test_no_kernel_spills_vector_registers(hiplib, tmp_path):
     ks = co.kernels(hiplib)
     assert len(ks) >= 40 and any("k_ldl_front" in k for k in ks) and any("k_sfw_diag" in k for k in ks)
     spilling = {k: v["vgpr_spill_count"] for k, v in ks.items() if v["vgpr_spill_count"]}
-    assert all("k_ldl_panel" in k and n <= 4 for k, n in spilling.items()), f"kernels that spill vector registers: {spilling}"
+    assert all("k_ldl_panel" in k and n <= 3 for k, n in spilling.items()), f"kernels that spill vector registers: {spilling}"
     scratch = sorted(k for k, v in ks.items() if v["private_segment_fixed_size"])
     assert all("k_ldl_front" in k or "k_ldl_panel" in k for k in scratch), scratch
-    # where the scratch instructions of k_ldl_panel and of its diagonal-block role are
-    dis = _disassemble_gfx950(hiplib, tmp_path)
-    checked = 0
-    for name in ("k_ldl_panel", "panel_role_diag"):
-        for sym, part in re.findall(r"^[0-9a-f]+ <([^>]*sdm\d+%s[A-Z][^>]*)>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)" % name, dis, flags=re.S | re.M):
-            lines = [l for l in part.split("\n") if l.strip()]
-            anchors = [i for i, l in enumerate(lines) if "s_swappc_b64" in l or "s_endpgm" in l or "s_setpc_b64" in l] + [0, len(lines) - 1]
-            for i, l in enumerate(lines):
-                if re.search(r"\bscratch_(?:load|store)", l):
-                    assert min(abs(i - a) for a in anchors) <= 24, (sym, i, l)
-                    checked += 1
-    assert checked > 0
 
 
-def test_called_stages_save_no_registers_for_their_callers(hiplib, tmp_path):
-    """The stages of the two factor kernels are called functions that use most of the register file.  Under the default
-    convention such a function saves and restores every callee-saved VGPR it touches through scratch on each call -- 72 in the
-    diagonal-block stage, 117 in panel_diag_rows (round 3: 2 us per panel of MAXCUT-4000's factor, 0.7 us per panel of
-    control07's).  Internal functions whose calls are not marked as tail calls are exempt (the caller keeps what it needs in
-    registers the callee leaves alone): SDM_NOINLINE carries not_tail_called for that.  Checked here: none of them has more
-    than a handful of scratch instructions."""
+def test_called_stages_of_the_factor_kernels_touch_scratch_only_at_entry(hiplib, tmp_path):
+    """The stages of the two factor kernels are called functions (one register allocation each) that use most of the register
+    file.  Under the default convention such a function saves and restores every callee-saved VGPR it touches through scratch
+    on each call -- 72 in the diagonal-block stage, 117 in the rows stage (round 3: 2 us per panel of MAXCUT-4000's factor,
+    0.7 us per panel of control07's).  Internal functions whose calls are not marked as tail calls are exempt (the caller
+    keeps what it needs in registers the callee leaves alone): SDM_NOINLINE carries not_tail_called for that.  And a caller
+    that needs something AFTER such a call has to park it in scratch around the call -- so the diagonal role of k_ldl_panel
+    is a chain of stages that never return (update -> LDL' -> rows), each call the last thing its caller does.
+    Checked in the disassembly: every stage has at most the handful of scratch instructions of its entry (the register that
+    holds spilled SGPRs), the chain functions of k_ldl_front none at all; the one stage that does spill is named."""
     dis = _disassemble_gfx950(hiplib, tmp_path)
     found = {}
-    for name in ("front_diag", "front_rows_diag", "front_rows", "front_update", "panel_diag_block", "panel_diag_rows", "panel_diag_update"):
+    names = ("front_diag", "front_rows_diag", "front_rows", "front_update", "panel_role_diag", "panel_stage_update", "panel_stage_block",
+             "panel_stage_rows", "panel_stage_rows_few", "panel_stage_rows_blocked", "k_ldl_panel", "k_ldl_front")
+    for name in names:
         for sym, part in re.findall(r"^[0-9a-f]+ <([^>]*sdm\d+%s[A-Z][^>]*)>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)" % name, dis, flags=re.S | re.M):
             found[name] = len(re.findall(r"\bscratch_(?:load|store)", part))
-    assert len(found) == 7, found
-    assert all(v <= 16 for v in found.values()), found
-    assert found["front_rows_diag"] == 0 and found["front_rows"] == 0 and found["front_update"] == 0, found
+    assert set(found) == set(names), found
+    assert found["front_rows_diag"] == 0 and found["front_rows"] == 0 and found["front_update"] == 0 and found["k_ldl_front"] == 0, found
+    assert found["panel_stage_rows_few"] == 0 and found["panel_stage_rows_blocked"] <= 12, found
+    assert all(found[n] <= 4 for n in ("front_diag", "panel_role_diag", "panel_stage_update", "panel_stage_block", "panel_stage_rows", "k_ldl_panel")), found

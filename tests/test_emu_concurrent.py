@@ -62,13 +62,23 @@ def test_concurrent_workgroups_give_the_bits_of_the_phased_launch(refmex, concur
     assert relerr(d1, r[1].ravel()) < TOL and relerr(l1, sp.csc_matrix(r[0]).data) < TOL
 
 
-def test_rank_deficient_fronts_as_concurrent_workgroups(refmex, concurrent_emu):
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_rank_deficient_fronts_as_concurrent_workgroups(refmex, concurrent_emu, reverse):
     """The cases of the GPU soak (helpers.rank_deficient_front_case, 320 .. 450 rows here): skip / add decisions index by
-    index and the pivots of the reference, with the column probe anywhere in a block."""
+    index and the pivots of the reference, with the column probe anywhere in a block.  reverse: the work-items of every
+    workgroup scheduled in descending order (a missing barrier shows as a different result)."""
     from sedumi_amd import mex
-    rng = np.random.default_rng(777)
+    concurrent_emu._Z15emu_set_reversei(reverse)
+    try:
+        _rank_deficient_cases(refmex, mex, 777 + reverse, 18)
+    finally:
+        concurrent_emu._Z15emu_set_reversei(0)
+
+
+def _rank_deficient_cases(refmex, mex, seed, ncases):
+    rng = np.random.default_rng(seed)
     nadd = 0
-    for case in range(30):
+    for case in range(ncases):
         args = helpers.rank_deficient_front_case(rng, 320, 450)
         rr = refmex.call("blkchol", 4, *args)
         o = mex.blkchol(*args)

@@ -200,7 +200,7 @@ void run_block(unsigned bx, unsigned by, unsigned bz, dim3 block, int nthr, cons
             /* nobody moved, somebody polls another workgroup: give the processor away -- briefly at first, then for longer (the
                kernels give a poll 2^21 tries before they raise their time-out flag: this stretches that budget to minutes) */
             g_spinning = false;
-            if (++idle_rounds < 20000) sched_yield(); else usleep(100);
+            if (++idle_rounds < 2000) sched_yield(); else usleep(100);
             continue;
           }
           if (g_progress != before) idle_rounds = 0;

@@ -161,3 +161,8 @@ def test_called_stages_of_the_factor_kernels_touch_scratch_only_at_entry(hiplib,
     assert found["front_rows_diag"] == 0 and found["front_rows"] == 0 and found["front_update"] == 0 and found["k_ldl_front"] == 0, found
     assert found["panel_stage_rows_few"] == 0 and found["panel_stage_rows_blocked"] <= 12, found
     assert all(found[n] <= 4 for n in ("front_diag", "panel_role_diag", "panel_stage_update", "panel_stage_block", "panel_stage_rows", "k_ldl_panel")), found
+    # and nothing else in the library touches scratch at all (solves, ADA', dense columns, PSD, PCG: every kernel and every function)
+    allowed = set(names) | {"pivot_probe"}
+    for sym, part in re.findall(r"^[0-9a-f]+ <([^>]+)>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)", dis, flags=re.S | re.M):
+        if re.search(r"\bscratch_(?:load|store)", part):
+            assert any(re.search(r"sdm\d+%s[A-Z]" % n, sym) for n in allowed), sym

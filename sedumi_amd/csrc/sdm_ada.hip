@@ -856,6 +856,7 @@ k_psd_stage2(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, 
 // 128 MB each way, 715 MB of HBM traffic and two launches of 180 + 200 us).  One workgroup per column j, one pattern entry per work-item as
 // in k_psd_stage2; the symmetry of D_k puts the work-item's own index last in every D access (coalesced).  absd as in getada3.c:341-347.
 constexpr int S1_DIRECT_MAXNZ = 2;
+constexpr size_t S1_DIRECT_LDS_MAX = 48 * 1024;   // its per-block tables (56 bytes per PSD block) must fit the default dynamic-LDS limit
 __global__ void __launch_bounds__(256)
 k_psd_direct(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, const int64_t *Ajc, const int64_t *Ajc_psd, const double *Apr,
              const int *Air, const int *Ablk, const int64_t *c_taskptr, const int *t_blk, const int *t_n, const int64_t *t_udoff,
@@ -1159,14 +1160,18 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
   const int ncols = (int)(A.col1 - A.col0), jbase = (int)A.col0;
   const int task0 = (int)A.h_taskptr[A.col0], ntask = (int)(A.h_taskptr[A.col1] - A.h_taskptr[A.col0]);
   // constraints of one or two nonzeros per PSD block on a pattern swept one entry per work-item: the pairwise form, no z_j (k_psd_direct)
-  const bool direct = A.thread_per_row && !A.ell_ok && A.sdpN == A.rsdpN && A.s1_maxnz <= S1_DIRECT_MAXNZ;
+  // (its per-block tables live in LDS, 56 bytes per PSD block: problems of more than ~850 blocks keep the two-stage path, whose
+  // stage 2 needs 8 bytes per block and raises its LDS attribute itself)
+  const size_t direct_lds = (size_t)(2 * A.sdpN + 2 * S1_DIRECT_MAXNZ * A.sdpN + 2) * sizeof(int) + (size_t)(2 * A.sdpN) * sizeof(long long) +
+                            (size_t)(S1_DIRECT_MAXNZ * A.sdpN) * sizeof(double);
+  const bool direct = A.thread_per_row && !A.ell_ok && A.sdpN == A.rsdpN && A.s1_maxnz <= S1_DIRECT_MAXNZ && direct_lds <= S1_DIRECT_LDS_MAX;
   if (direct) {
     if (sym_input) {
       SDM_KLAUNCH(P, k_symmetrize, dim3(m), dim3(128), 0, A.symtmp.p, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_ADAT.p, m);
       SDM_HIP_CHECK(hipMemcpyAsync(ada, A.symtmp.p, A.symtmp.n * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
     const int nb = (int)A.sdpN;
-    const size_t lds = (size_t)(2 * nb + 2 * S1_DIRECT_MAXNZ * nb + 2) * sizeof(int) + (size_t)(2 * nb) * sizeof(long long) + (size_t)(S1_DIRECT_MAXNZ * nb) * sizeof(double);
+    const size_t lds = direct_lds;
     SDM_KLAUNCH(P, k_psd_direct, dim3(ncols), dim3(256), lds, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p, A.d_Apr.p, A.d_Air.p,
                 A.d_Ablk.p, A.c_taskptr.p, A.t_blk.p, A.t_n.p, A.t_udoff.p, A.t_slotptr.p, A.s_nzptr.p, A.t_end.p, A.d_psd_start.p, A.udsqr.p,
                 d_invperm, nb, jbase);

@@ -173,7 +173,10 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
   std::vector<int> fslot(std::max<sdm_int>(1, C.nsuper), 0);
   int nslot = 0;
   {
-    const bool off = C.front_off_req;                                 // sdm_plan_set_one_launch_fronts(p, 0): the comparison switch of tests and tools
+    // sdm_plan_set_one_launch_fronts(p, 0): the comparison switch of tests and tools; front_disabled: a launch of this plan timed out
+    // before (chol_wait_timeouts) -- the plan stays on the launch-per-panel path across later set_chol calls too, and with no
+    // one-launch level follow_decide (sdm_solve.hip) plans no inverse behind the factor either
+    const bool off = C.front_off_req || C.front_disabled;
     const int maxT_allowed = FRONT_MAXT;
     // k_ldl_front's workgroups wait for each other in both directions (a row workgroup for its tile workgroups and vice
     // versa): they must all be resident, one per compute unit (135 KB of LDS each).  A device -- or a partition of one --

@@ -156,7 +156,7 @@ static void follow_decide(sdm_plan *P) {
   CholPlan &C = P->chol;
   C.follow = false;
   C.lev_followT.assign(C.nlevels, 0);
-  if (C.nlevels == 0 || C.maxns > C.sbw) return;
+  if (C.nlevels == 0 || C.maxns > C.sbw || C.front_disabled) return;
   int ncu = 1 << 20;
 #ifndef SDM_EMU
   SDM_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, P->device));

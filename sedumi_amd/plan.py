@@ -235,6 +235,15 @@ class Plan:
             cp.abstol = max(float(pars.get("abstol", cp.abstol)), 0.0)
         check(self._lib.sdm_plan_blkchol(C.c_void_p(self._p), C.byref(cp), 1 if use_absd else 0))
 
+    def blkchol_wait(self, pars=None, use_absd=False):
+        """blkchol, waited for, with the one recovery of sdm_plan_blkchol_wait (what blkchol.mex calls)."""
+        cp = capi.CholPars(1e-12, 5e5, 1e-20)
+        if pars:
+            cp.canceltol = float(pars.get("canceltol", cp.canceltol))
+            cp.maxu = float(pars.get("maxu", cp.maxu))
+            cp.abstol = max(float(pars.get("abstol", cp.abstol)), 0.0)
+        check(self._lib.sdm_plan_blkchol_wait(C.c_void_p(self._p), C.byref(cp), 1 if use_absd else 0))
+
     # ---- the factorisation and the solve level by level (sedumi_amd.dist.SeparatorShardedSolver)
     def set_active_supernodes(self, active):
         """Before set_chol: the supernodes (0/1 per supernode of the symbolic factor) this plan factors and solves."""

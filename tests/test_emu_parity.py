@@ -93,6 +93,14 @@ def test_iteration_unit_constraints_of_one_or_two_nonzeros_per_block(glue, seed,
     _set_reverse(0)
 
 
+def test_iteration_unit_many_tiny_blocks_keep_the_two_stage_path(glue):
+    """1500 PSD blocks of order 2 with at most two nonzeros per constraint and block: k_psd_direct's per-block LDS tables (56 bytes
+    per block) would pass the dynamic-LDS limit, so ada_psd must fall back to stage 1 + stage 2 (round-3 advisor)."""
+    P = _few_nonzero_sdp(7, 12, (2,) * 1500, 0)
+    errs, S, _ = check_iteration(glue, P, seed=7)
+    assert max(errs.values()) < TOL, errs
+
+
 def test_iteration_unit_maxcut_small(glue):
     from sedumi_amd import problem
     errs, S, _ = check_iteration(glue, problem.maxcut(90), seed=5)
@@ -449,3 +457,41 @@ def test_blocking_blkchol_recovers_from_a_starved_one_launch_level(refmex):
         assert relerr(o[1].ravel(), r[1].ravel()) < TOL
     finally:
         lib._Z19emu_inject_timeoutsi(0)
+
+
+def test_set_chol_after_a_timeout_keeps_the_plan_on_the_panel_path(refmex):
+    """A plan whose one-launch level timed out (front_disabled) and that is then given a symbolic factor again must not plan the
+    inverse-behind-the-factor path: that once left the inverse arenas at zero and the solves returned 0 (round-3 advisor)."""
+    from hipemu import build_emu
+    from oracle import glue as gl
+    from sedumi_amd import plan as pl, problem
+    lib = ctypes.CDLL(build_emu.build())
+    m = 330
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((m, m))
+    X = sp.csc_matrix(B @ B.T + m * np.eye(m)); X.sort_indices()
+    L = problem.dense_symbolic(m)
+    pars = gl.default_pars_chol()
+    LL, Ld, _, _ = refmex.call("blkchol", 4, L, X, pars)
+    Lf = dict(L); Lf["L"] = LL
+    b = rng.standard_normal((m, 1))
+    yref = refmex.call("bwblkslv", 1, Lf, refmex.call("fwblkslv", 1, Lf, b) / Ld)
+    P = pl.Plan()
+    try:
+        P.set_chol(L, X)
+        P.upload("ada", X.data)
+        lib._Z19emu_inject_timeoutsi(1)
+        P.blkchol_wait(pars)                          # first attempt times out, the repeat runs on the launch-per-panel path
+        assert lib._Z25emu_take_injected_timeoutv() == 0
+        for again in range(2):
+            if again:
+                P.set_chol(L, X)                      # a new solve on the same plan
+                P.upload("ada", X.data)
+                P.blkchol_wait(pars)
+            P.upload("rhs", b)
+            P.ldlsolve()
+            assert relerr(P.download("y"), yref.ravel()) < TOL
+            assert relerr(P.download("d"), Ld.ravel()) < TOL
+    finally:
+        lib._Z19emu_inject_timeoutsi(0)
+        P.close()

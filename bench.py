@@ -15,7 +15,9 @@ solves replicated -- they do not shard); the block-diagonal workload deals its i
 (all-gather of the solution only).  `--shard replicas` runs independent units per rank instead (weak scaling).
 
 Prints ONE JSON line (rank 0) with the fields the driver expects plus `roofline`, `cpu_baseline` (the unmodified
-reference MEX, naive BLAS-1) and `cpu_baseline_blas` (the same linked to the host's OpenBLAS), `pcie_inclusive`.
+reference MEX, naive BLAS-1) and `cpu_baseline_blas` (the same linked to the host's OpenBLAS), `pcie_inclusive` and
+`mex_inclusive` (the unit through the built mexFunction shims, host arrays in and out of every gateway: what an unmodified
+sedumi.m pays).
 """
 import argparse
 import json
@@ -380,7 +382,7 @@ def stage1_flops(P):
     return tot
 
 
-def measure_config(name, device, steps, warmup, nprof):
+def measure_config(name, device, steps, warmup, nprof, mex_units=0):
     """One of the other BASELINE configs, measured briefly in this process: ms/unit, dominant kernel, solve rate."""
     try:
         t0 = time.perf_counter()
@@ -390,11 +392,17 @@ def measure_config(name, device, steps, warmup, nprof):
         step = unit_fn(plan)
         el = time_steps(plan, step, steps, warmup)
         roof, phases = profile_unit(plan, P, ud, nprof)
+        mexleg = None
+        if mex_units:
+            plan.upload("rhs", rhs); plan.ldlsolve()
+            mexleg = mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, mex_units, plan.download("y"))
         out = {"workload": name, "problem": P.name, "m": int(P.m), "nnzL": int(plan.nnzL), "nsuper": int(plan._xsuper.size - 1),
                "ms_per_step": 1e3 * el / steps, "iters_per_s": steps / el, "steps": steps,
                "dominant_kernel": roof and {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step")},
                "phases_ms_per_step": {k: phases[k] for k in ("ada_ms", "factor_ms", "solves_ms")},
                "solve": phases["solve"], "factor": phases["factor"], "setup_s": time.perf_counter() - t0 - el}
+        if mexleg is not None:
+            out["mex_inclusive"] = mexleg
         plan.close()
         return out
     except Exception as e:  # never break the bench line
@@ -426,6 +434,59 @@ def pcie_inclusive(plan, P, d, ud, rhs, steps):
     return {"value": steps / el, "unit": "IPM iters/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
             "note": "host buffers cross PCIe around every one of the 6 + 2x4 MEX-equivalent calls (pageable numpy memory, "
                     f"synchronous copies): {8 * (3 * nA + 2 * nL) / 1e6:.1f} MB per unit"}
+
+
+def mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, units, y_resident=None, mex_dir=None):
+    """The unit as an UNMODIFIED sedumi.m would run it: through the built mexFunction shims (sedumi_amd/lib/mex/<name>.so, the
+    sources of sedumi_amd/mexshims compiled against the package's MEX host -- no MATLAB / Octave in this image), host mxArrays in
+    and out of every one of the 4 + 2x4 gateway calls, outputs handed to the next gateway by reference as MATLAB does
+    (sedumi_amd.mexhost.iteration_units).  Times only what happens inside mexFunction, like cpu_baseline does for the reference
+    MEX.  The library's process-wide cache (sdm_mexcache.hip) keeps the analysis of At / K / the patterns and the value arrays that
+    travel between gateways on the device.  Never `value`."""
+    try:
+        import ctypes
+        import scipy.sparse as sp
+        from sedumi_amd import capi, mex, mexhost
+        K = P.K
+        if not np.asarray(K["s"]).size:
+            return {"skipped": "no PSD blocks: sedumi.m:446 takes the getada.m route"}
+        m = P.m
+        At = sp.csc_matrix(P.At)
+        # Aord of sedumi.m:363-378: constraints from sparse to dense (sortnnz: by nonzero count of the part), PSD part by incorder
+        nlq = np.asarray(P.Ablkjc)[:, 2] - At.indptr[:-1]
+        Aord = {"lqperm": (np.argsort(nlq, kind="stable") + 1.0).reshape(-1, 1)}
+        Qm = sp.csc_matrix(Q)
+        if Qm.nnz:
+            Qm = sp.csc_matrix((np.asarray(qpr, dtype=np.float64), Qm.indices, Qm.indptr), shape=Qm.shape)
+            Aord["qperm"] = (np.argsort(np.diff(Qm.indptr), kind="stable") + 1.0).reshape(-1, 1)
+        else:
+            Aord["qperm"] = np.arange(1, m + 1, dtype=np.float64).reshape(-1, 1)
+        sperm, _dz = mex.incorder(At, np.asarray(P.Ablkjc)[:, 2], float(np.asarray(K["mainblks"]).ravel()[2]))
+        Aord["sperm"] = np.asarray(sperm, dtype=np.float64).reshape(-1, 1)
+        dstruct = {"l": np.asarray(d["l"], dtype=np.float64).reshape(-1, 1), "det": np.asarray(d["det"], dtype=np.float64).reshape(-1, 1)}
+        lib = capi.lib()
+        st = (ctypes.c_int64 * 16)()
+        lib.sdm_mexcache_clear()
+        host = mexhost.MexHost(mex_dir)
+        times, y = mexhost.iteration_units(host, At, np.asarray(P.Ablkjc)[:, 2], Aord, K, dstruct, {"q": Qm}, ud, L, ADA, PARS, rhs, units + 1, NSOLVE)
+        lib.sdm_mexcache_stats(st, ctypes.c_int64(16))
+        lib.sdm_mexcache_clear()
+        first, rest = times[0], times[1:]
+        tot = np.array([sum(t.values()) for t in rest])
+        stage = {k: 1e3 * float(np.mean([t[k] for t in rest])) for k in rest[0]}
+        out = {"value": float(len(rest) / tot.sum()), "unit": "IPM iters/s", "ms_per_step": 1e3 * float(tot.mean()), "steps": len(rest),
+               "first_unit_ms": 1e3 * sum(first.values()), "stage_ms_per_unit": stage,
+               "cache_counters": {"ada_build": int(st[0]), "ada_reuse": int(st[1]), "ada_upload": int(st[2]), "ada_resident": int(st[3]), "chol_build": int(st[4]),
+                                  "chol_reuse": int(st[5]), "x_upload": int(st[6]), "x_resident": int(st[7]), "solve_resident": int(st[8]),
+                                  "solve_stateless": int(st[9])},
+               "note": "mexFunction shims (sedumi_amd/lib/mex) on the MEX host of the package; host mxArrays cross PCIe at every gateway: scaling "
+                       "data and right-hand sides up, ADA' (3x), absd, L.L, L.d, pivot lists and solutions down; the first unit (analysis of At, "
+                       "the patterns and the symbolic factor, once per solve) is reported separately"}
+        if y_resident is not None:
+            out["rel_diff_vs_resident_tier"] = float(np.linalg.norm(y - y_resident) / max(np.linalg.norm(y_resident), 1e-300))
+        return out
+    except Exception as e:  # never break the bench line
+        return {"error": repr(e)}
 
 
 def bench_subtrees(args, rank, local_rank, world, torch, dist, coll_dev):
@@ -647,10 +708,12 @@ def main():
     roof, phases = profile_unit(plan, P, ud, min(args.steps, 50))
 
     if rank == 0:
-        base = base_blas = pcie = None
+        base = base_blas = pcie = mexleg = None
         others = []
         if world == 1:
             pcie = pcie_inclusive(plan, P, d, ud, rhs, min(args.steps, 20))
+            plan.upload("rhs", rhs); plan.ldlsolve()
+            mexleg = mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, min(args.steps, 30), plan.download("y"))
             if not args.no_cpu_baseline:
                 base = cpu_baseline(P, d, ud, rhs)
                 try:
@@ -663,9 +726,9 @@ def main():
             if not args.no_other_configs and args.workload == "control07":
                 # the second scaling of the headline config (identity scaling of iteration 1 next to an ill-conditioned one),
                 # the other reference examples at both scalings, then the synthetic configs[3], [4]
-                for nm, st, wu, npf in (("control07_init", 100, 5, 20), ("arch0", 100, 5, 20), ("arch0_init", 100, 5, 20), ("nb", 100, 5, 20),
-                                        ("nb_init", 100, 5, 20), ("maxcut4000", 10, 2, 5), ("blockdiag", 20, 3, 10)):
-                    others.append(measure_config(nm, local_rank, st, wu, npf))
+                for nm, st, wu, npf, mxu in (("control07_init", 100, 5, 20, 0), ("arch0", 100, 5, 20, 0), ("arch0_init", 100, 5, 20, 0), ("nb", 100, 5, 20, 0),
+                                             ("nb_init", 100, 5, 20, 0), ("maxcut4000", 10, 2, 5, 2), ("blockdiag", 20, 3, 10, 0)):
+                    others.append(measure_config(nm, local_rank, st, wu, npf, mxu))
         mult = 1 if (shard_cols or world == 1) else world
         out = {
             "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": mult * args.steps / elapsed, "unit": "IPM iters/s",
@@ -678,8 +741,10 @@ def main():
                                          "blocks": "PSD blocks dealt to the ranks, partial ADA' + RCCL all-reduce, factor/solves replicated",
                                          "replicas": "replicas: independent units per rank, no collective"}[shard] if world > 1 else "single GPU")},
             "roofline": roof, "phases_ms_per_step": phases, "cpu_baseline": base, "cpu_baseline_blas": base_blas,
-            "pcie_inclusive": pcie, "other_configs": others,
+            "pcie_inclusive": pcie, "mex_inclusive": mexleg, "other_configs": others,
         }
+        if base and base.get("value") and mexleg and mexleg.get("value"):
+            out["mex_inclusive_speedup_vs_cpu_reference"] = mexleg["value"] / base["value"]
         if base and base.get("value"):
             out["speedup_vs_cpu_reference"] = out["value"] / mult / base["value"]
         if base_blas and base_blas.get("value"):

@@ -388,12 +388,42 @@ int sdm_plan_blkchol_levels(sdm_plan *p, sdm_int l0, sdm_int l1, int extend_only
 int sdm_plan_blkchol_end(sdm_plan *p);
 int sdm_plan_solve_levels(sdm_plan *p, int what, sdm_int l0, sdm_int l1);
 
-/* ---- one process-wide resident plan for the mexFunction shims: every .mex binary is its own
- * shared object, so the cache lives in this library.  sdm_mexcache_plan returns the plan of the symbolic factor
- * (L.{L pattern, perm, xsuper}) and ADA pattern given, creating it on a miss (NULL + sdm_last_error on failure).
- * blkchol calls sdm_mexcache_remember_factor with the L.L values it returned; fwblkslv / bwblkslv get the plan back
- * from sdm_mexcache_factor_plan only if the values they were handed ARE that factor (content fingerprint: a sampled
- * hash always, the full hash when the array is not the very one blkchol returned), else NULL (stateless path). */
+/* ---- process-wide resident state behind the mexFunction shims (csrc/sdm_mexcache.hip).  Every .mex
+ * binary is its own shared object, so the cache lives in this library.  The sdm_mexcache_<gateway> functions take the
+ * arguments of their stateless counterparts sdm_<gateway> and give the same results, but
+ *   - the device-side analysis of the problem data (At, K, ADA pattern: ada_build; symbolic factor: chol_build) is done
+ *     once per solve and reused while the data presented is the same (content fingerprints, see the source file);
+ *   - a value array that one gateway returned and the next one receives (ADA: getada1 -> getada2 -> getada3 -> blkchol;
+ *     L.L: blkchol -> fwblkslv / bwblkslv) is not uploaded again: the device still holds it.
+ * What sedumi.m:450-462 / wrapPcg.m:56-59 call every iteration therefore costs the per-iteration scaling data up and the
+ * results down.  ADApr_in / ADApr: values of the input array and of the fresh array the shim returns (may alias);
+ * ADAir_out / Lir_out: row indices of the returned array (the shim's copy of the input pattern; NULL allowed).
+ * sdm_mexcache_solve: fw != 0 forward.  sdm_mexcache_stats: counters (ada_build calls, reuses, ADA uploads, ADA taken
+ * from the device, chol builds, reuses, X uploads, X resident, resident solves, stateless solves, At uploads). */
+int sdm_mexcache_getada1(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc, const sdm_int *Air,
+                         const double *Apr, const sdm_int *Ajc2, const sdm_int *perm, sdm_int lpN, const double *dl, sdm_int lorN,
+                         const double *ddet, const sdm_int *qblkstart, double *ADApr, const sdm_int *ADAir_out);
+int sdm_mexcache_getada2(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const double *ADApr_in, double *ADApr, sdm_int lorN,
+                         const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, const sdm_int *qperm, const sdm_int *ADAir_out);
+void sdm_mexcache_getada2_passthrough(sdm_int nnz, const double *ADApr_in, const double *ADApr_out);   /* getada2.c:154-155: copy returned unchanged */
+int sdm_mexcache_getada3(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const double *ADApr_in, double *ADApr, sdm_int N,
+                         const sdm_int *Ajc, const sdm_int *Air, const double *Apr, const sdm_int *Ajc1, const double *udsqr,
+                         const sdm_cone *K, const sdm_int *psd_blkstart, double *absd, const sdm_int *ADAir_out);
+int sdm_mexcache_getada(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc, const sdm_int *Air,
+                        const double *Apr, sdm_int lpN, const double *dl, sdm_int lorN, const double *ddet, const sdm_int *qblkstart,
+                        const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, double *ADApr, double *absd, const sdm_int *ADAir_out);
+int sdm_mexcache_blkchol(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm, sdm_int nsuper, const sdm_int *xsuper,
+                         const sdm_int *Xjc, const sdm_int *Xir, const double *Xpr, const sdm_cholpars *pars, const double *absd,
+                         double *Lpr, double *d, sdm_int *nskip, sdm_int *skip_idx, double *skip_val, sdm_int *nadd, sdm_int *add_idx,
+                         double *add_val, const sdm_int *Lir_out);
+int sdm_mexcache_solve(int fw, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const double *Lpr, const sdm_int *perm, sdm_int nsuper,
+                       const sdm_int *xsuper, sdm_int nrhs, const double *b, double *y);
+void sdm_mexcache_stats(sdm_int *out16, sdm_int n);
+void sdm_mexcache_set_strict(int on);
+/* The cached plan of the factorisation for callers that drive it themselves: sdm_mexcache_plan returns the plan of the
+ * symbolic factor (L.{L pattern, perm, xsuper}) and ADA pattern given, creating it on a miss (NULL + sdm_last_error on
+ * failure); sdm_mexcache_remember_factor records the L.L values a factorisation returned; sdm_mexcache_factor_plan gives
+ * the plan back only if the values presented ARE that factor, else NULL. */
 sdm_plan *sdm_mexcache_plan(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm, sdm_int nsuper,
                             const sdm_int *xsuper, const sdm_int *Xjc, const sdm_int *Xir);
 void sdm_mexcache_remember_factor(const double *Lpr_host, sdm_int nnz);

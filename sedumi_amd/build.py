@@ -69,9 +69,61 @@ def _compile_objects(extra, objdir, verbose):
     return hipcc, objs
 
 
+MEXHOST_DIR = os.path.join(HERE, "mexhost")
+MEXHOST_LIB = os.path.join(LIBDIR, "libsdm_mexhost.so")
+SHIM_DIR = os.path.join(HERE, "mexshims")
+MEX_OUT = os.path.join(LIBDIR, "mex")
+SHIMS = ["getada", "getada1", "getada2", "getada3", "blkchol", "fwblkslv", "bwblkslv", "ordmmdmex", "symfctmex", "choltmpsiz", "cholsplit",
+         "symbfwblk", "finsymbden", "dpr1fact", "fwdpr1", "bwdpr1", "invcholfac", "incorder", "adendotd", "adenscale"]
+
+
+def _newer(target, deps):
+    return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
+
+
+def build_mexhost(verbose=True):
+    """sedumi_amd/lib/libsdm_mexhost.so: the MEX C API for running mexFunction binaries without MATLAB / Octave (gcc, no GPU code)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    src = os.path.join(MEXHOST_DIR, "mexhost.c")
+    if _newer(MEXHOST_LIB, [src, os.path.join(MEXHOST_DIR, "mex.h")]):
+        cmd = ["gcc", "-O2", "-fPIC", "-DNDEBUG", "-w", "-I", MEXHOST_DIR, "-shared", "-o", MEXHOST_LIB, src, "-lm"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return MEXHOST_LIB
+
+
+def build_mexshims(lib=LIB, out=MEX_OUT, verbose=False):
+    """Every mexFunction shim of sedumi_amd/mexshims as a shared object of its own (<out>/<name>.so), linked to the C-ABI library
+    `lib` and to the MEX host -- g++ only: MATLAB / Octave are not needed (with them: mex / mkoctfile)."""
+    from concurrent.futures import ThreadPoolExecutor
+    build_mexhost(verbose)
+    os.makedirs(out, exist_ok=True)
+    inc = ["-I", MEXHOST_DIR, "-I", os.path.join(HERE, "..", "include"), "-I", SHIM_DIR]
+    hdrs = [os.path.join(SHIM_DIR, "mexcommon.h"), os.path.join(MEXHOST_DIR, "mex.h"), os.path.join(HERE, "..", "include", "sedumi_hip.h")]
+    common = os.path.join(out, "mexcommon.o")
+    if _newer(common, [os.path.join(SHIM_DIR, "mexcommon.cpp")] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-Wall", "-c", os.path.join(SHIM_DIR, "mexcommon.cpp"), "-o", common] + inc)
+    jobs = []
+    for name in SHIMS:
+        so = os.path.join(out, name + ".so")
+        if _newer(so, [os.path.join(SHIM_DIR, name + ".cpp"), common, lib, MEXHOST_LIB] + hdrs):
+            libdir, libname = os.path.dirname(os.path.abspath(lib)), os.path.basename(lib)[3:-3]     # (linked by name: found through the run path)
+            jobs.append(["g++", "-O2", "-fPIC", "-Wall", "-shared", os.path.join(SHIM_DIR, name + ".cpp"), common, "-o", so, "-L", libdir, "-l" + libname,
+                         "-L", LIBDIR, "-lsdm_mexhost", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + libdir, "-Wl,-rpath," + LIBDIR] + inc)
+    if verbose:
+        for j in jobs:
+            print(" ".join(j), flush=True)
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(subprocess.check_call, jobs))
+    return out
+
+
 def build(force=False, verbose=True):
-    """Compile every HIP source for gfx950 into sedumi_amd/lib/libsedumi_hip.so."""
+    """Compile every HIP source for gfx950 into sedumi_amd/lib/libsedumi_hip.so; then the MEX host and the mexFunction shims
+    (sedumi_amd/lib/mex/<name>.so) linked to it."""
     if not force and not needs_build():
+        build_mexshims(LIB, MEX_OUT, False)
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
@@ -82,6 +134,7 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    build_mexshims(LIB, MEX_OUT, False)
     return LIB
 
 

@@ -495,7 +495,10 @@ struct PlanGuard {
   PlanGuard() : p(sdm_plan_create(0, nullptr)) { if (!p) throw std::runtime_error(g_err); }
   ~PlanGuard() { sdm_plan_destroy(p); }
 };
-static void upload_invperm(DevBuf<int> &buf, const sdm_int *perm, sdm_int m) {
+}  // extern "C"
+
+namespace sdm {
+void gw_upload_invperm(DevBuf<int> &buf, const sdm_int *perm, sdm_int m) {
   std::vector<int> ip(m);
   for (sdm_int k = 0; k < m; k++) {
     if (perm[k] < 0 || perm[k] >= m) throw std::runtime_error("permutation entry out of range");
@@ -510,28 +513,83 @@ static void set_trivial_chol(sdm_plan *p, sdm_int m, const sdm_int *ADAjc, const
   for (sdm_int j = 0; j < m; j++) { Lir[j] = j; perm[j] = j; }
   if (sdm_plan_set_chol(p, m, Ljc.data(), Lir.data(), perm.data(), m, xs.data(), ADAjc, ADAir)) throw std::runtime_error(g_err);
 }
+// ---- gateway-shaped plans: a plan that holds exactly what ONE of the getada gateways needs (its slice of At / DAt.q, the ADA
+// pattern).  The stateless tier-1 entry points below build one per call; the MEX cache (sdm_mexcache.hip) keeps them.
+// ADA' values live in p->ada_val, absd in p->absd.
+void gw_build_getada1(sdm_plan *p, sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const sdm_int *Ajc, const sdm_int *Air,
+                      const double *Apr, const sdm_int *Ajc2, sdm_int lpN, sdm_int lorN, const sdm_int *qblkstart) {
+  set_trivial_chol(p, m, ADAjc, ADAir);
+  // only the LP/Lorentz rows matter here: present At as if it had no PSD part (rows >= qblkstart[lorN] are never touched:
+  // Ajc2 is the end of the LP/Lorentz nonzeros)
+  std::vector<sdm_int> Qjc(m + 1, 0);
+  const sdm_int nlq = lorN > 0 ? qblkstart[lorN] : lpN;
+  ada_build(p, nlq, m, Ajc, Air, Apr, Ajc2, lpN, lorN, nullptr, 0, 0, nullptr, qblkstart, nullptr, Qjc.data(), nullptr, ADAjc, ADAir);
+}
+void gw_run_getada1(sdm_plan *p, const int *d_invperm, const double *dl, const double *ddet) {
+  AdaPlan &A = p->ada;
+  if (A.lpN) SDM_HIP_CHECK(hipMemcpyAsync(A.dl.p, dl, A.lpN * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  if (A.lorN) SDM_HIP_CHECK(hipMemcpyAsync(A.ddet.p, ddet, A.lorN * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  SDM_HIP_CHECK(hipMemsetAsync(p->ada_val.p, 0, p->ada_val.n * sizeof(double), p->stream));   // getada1.c:222-225
+  ada_lq(p, p->ada_val.p, d_invperm, false);
+}
+void gw_build_getada2(sdm_plan *p, sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int lorN, const sdm_int *Qjc, const sdm_int *Qir) {
+  set_trivial_chol(p, m, ADAjc, ADAir);
+  std::vector<sdm_int> Ajc(m + 1, 0), qb(lorN + 1, 0);
+  ada_build(p, lorN, m, Ajc.data(), nullptr, nullptr, Ajc.data(), 0, lorN, nullptr, 0, 0, nullptr, qb.data(), nullptr, Qjc, Qir, ADAjc, ADAir);
+}
+void gw_run_getada2(sdm_plan *p, const int *d_invperm, const double *Qpr) {   // p->ada_val in/out
+  if (p->ada.nnzQ) SDM_HIP_CHECK(hipMemcpyAsync(p->ada.qpr.p, Qpr, p->ada.nnzQ * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  ada_q(p, p->ada_val.p, d_invperm, true);
+}
+void gw_build_getada3(sdm_plan *p, sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc, const sdm_int *Air,
+                      const double *Apr, const sdm_int *Ajc1, const sdm_cone *K, const sdm_int *psd_blkstart) {
+  set_trivial_chol(p, m, ADAjc, ADAir);
+  std::vector<sdm_int> Qjc(m + 1, 0), qb(K->lorN + 1, 0);
+  // the LP/Lorentz rows are not read by getada3: describe them as plain LP rows up to the first PSD row
+  const sdm_int nlq = K->sdpN > 0 ? psd_blkstart[0] : N;
+  ada_build(p, N, m, Ajc, Air, Apr, Ajc1, nlq, 0, nullptr, K->sdpN, K->rsdpN, K->sdpNL, qb.data(), psd_blkstart, Qjc.data(), nullptr, ADAjc, ADAir);
+}
+void gw_run_getada3(sdm_plan *p, const double *udsqr) {                       // p->ada_val in/out, p->absd out
+  if (p->ada.lenud) SDM_HIP_CHECK(hipMemcpyAsync(p->ada.udsqr.p, udsqr, p->ada.lenud * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  ada_psd(p, p->ada_val.p, nullptr, true);
+}
+// the whole ADA' of a problem WITHOUT PSD blocks (getada.m:13-40)
+void gw_build_getada(sdm_plan *p, sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const sdm_int *Ajc, const sdm_int *Air, const double *Apr,
+                     sdm_int lpN, sdm_int lorN, const sdm_int *qblkstart, const sdm_int *Qjc, const sdm_int *Qir) {
+  set_trivial_chol(p, m, ADAjc, ADAir);
+  const sdm_int nlq = lorN > 0 ? qblkstart[lorN] : lpN;             // = K.mainblks(3)-1: rows of Alq (getada.m:25)
+  std::vector<sdm_int> ajc2(m), zq(m + 1, 0);
+  for (sdm_int j = 0; j < m; j++) ajc2[j] = std::lower_bound(Air + Ajc[j], Air + Ajc[j + 1], nlq) - Air;
+  ada_build(p, nlq, m, Ajc, Air, Apr, ajc2.data(), lpN, lorN, nullptr, 0, 0, nullptr, qblkstart, nullptr,
+            lorN > 0 ? Qjc : zq.data(), lorN > 0 ? Qir : nullptr, ADAjc, ADAir);
+}
+void gw_run_getada(sdm_plan *p, const double *dl, const double *ddet, const double *Qpr) {
+  AdaPlan &A = p->ada;
+  if (A.lpN) SDM_HIP_CHECK(hipMemcpyAsync(A.dl.p, dl, A.lpN * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  if (A.lorN) SDM_HIP_CHECK(hipMemcpyAsync(A.ddet.p, ddet, A.lorN * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  if (A.lorN && A.nnzQ) SDM_HIP_CHECK(hipMemcpyAsync(A.qpr.p, Qpr, A.nnzQ * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  if (sdm_plan_getada(p)) throw std::runtime_error(g_err);
+}
+// values of ADA' (and absd) back to the host once the plan's stream has drained
+void gw_download(sdm_plan *p, double *ADApr, double *absd) {
+  if (ADApr) SDM_HIP_CHECK(hipMemcpyAsync(ADApr, p->ada_val.p, p->ada_val.n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  if (absd) SDM_HIP_CHECK(hipMemcpyAsync(absd, p->absd.p, (size_t)p->chol.m * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+}
+}  // namespace sdm
+
+extern "C" {
 
 int sdm_getada1(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc,
                 const sdm_int *Air, const double *Apr, const sdm_int *Ajc2, const sdm_int *perm, sdm_int lpN,
                 const double *dl, sdm_int lorN, const double *ddet, const sdm_int *qblkstart, double *ADApr) {
   SDM_TRY
-  PlanGuard G; sdm_plan *p = G.p;
-  set_trivial_chol(p, m, ADAjc, ADAir);
-  // only the LP/Lorentz rows matter here: present At as if it had no PSD part
-  sdm_cone K = {lpN, lorN, nullptr, 0, 0, nullptr};
-  std::vector<sdm_int> Qjc(m + 1, 0);
-  // rows >= qblkstart[lorN] (PSD part) are never touched: Ajc2 is the end of the LP/Lorentz nonzeros
-  sdm_int nlq = lorN > 0 ? qblkstart[lorN] : lpN;
   (void)N;
-  ada_build(p, nlq, m, Ajc, Air, Apr, Ajc2, K.lpN, K.lorN, nullptr, 0, 0, nullptr, qblkstart, nullptr, Qjc.data(), nullptr,
-            ADAjc, ADAir);
-  if (lpN) SDM_HIP_CHECK(hipMemcpy(p->ada.dl.p, dl, lpN * sizeof(double), hipMemcpyHostToDevice));
-  if (lorN) SDM_HIP_CHECK(hipMemcpy(p->ada.ddet.p, ddet, lorN * sizeof(double), hipMemcpyHostToDevice));
-  DevBuf<int> ip; upload_invperm(ip, perm, m);
-  SDM_HIP_CHECK(hipMemsetAsync(p->ada_val.p, 0, (size_t)ADAjc[m] * sizeof(double), p->stream));   // getada1.c:222-225
-  ada_lq(p, p->ada_val.p, ip.p, false);
-  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
-  SDM_HIP_CHECK(hipMemcpy(ADApr, p->ada_val.p, (size_t)ADAjc[m] * sizeof(double), hipMemcpyDeviceToHost));
+  PlanGuard G; sdm_plan *p = G.p;
+  gw_build_getada1(p, m, ADAjc, ADAir, Ajc, Air, Apr, Ajc2, lpN, lorN, qblkstart);
+  DevBuf<int> ip; gw_upload_invperm(ip, perm, m);
+  gw_run_getada1(p, ip.p, dl, ddet);
+  gw_download(p, ADApr, nullptr);
   SDM_CATCH
 }
 
@@ -540,16 +598,11 @@ int sdm_getada2(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, double *A
   SDM_TRY
   if (lorN <= 0) return 0;                          // getada2.c:154-155: nothing to do without Lorentz cones
   PlanGuard G; sdm_plan *p = G.p;
-  set_trivial_chol(p, m, ADAjc, ADAir);
-  std::vector<sdm_int> Ajc(m + 1, 0), qb(lorN + 1, 0);
-  ada_build(p, lorN, m, Ajc.data(), nullptr, nullptr, Ajc.data(), 0, lorN, nullptr, 0, 0, nullptr, qb.data(), nullptr,
-            Qjc, Qir, ADAjc, ADAir);
-  if (Qjc[m]) SDM_HIP_CHECK(hipMemcpy(p->ada.qpr.p, Qpr, Qjc[m] * sizeof(double), hipMemcpyHostToDevice));
+  gw_build_getada2(p, m, ADAjc, ADAir, lorN, Qjc, Qir);
   SDM_HIP_CHECK(hipMemcpy(p->ada_val.p, ADApr, (size_t)ADAjc[m] * sizeof(double), hipMemcpyHostToDevice));
-  DevBuf<int> ip; upload_invperm(ip, qperm, m);
-  ada_q(p, p->ada_val.p, ip.p, true);
-  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
-  SDM_HIP_CHECK(hipMemcpy(ADApr, p->ada_val.p, (size_t)ADAjc[m] * sizeof(double), hipMemcpyDeviceToHost));
+  DevBuf<int> ip; gw_upload_invperm(ip, qperm, m);
+  gw_run_getada2(p, ip.p, Qpr);
+  gw_download(p, ADApr, nullptr);
   SDM_CATCH
 }
 
@@ -559,18 +612,10 @@ int sdm_getada3(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, double *A
   SDM_TRY
   (void)sperm;   // the sum is independent of the fill order (see sdm_ada.hip header)
   PlanGuard G; sdm_plan *p = G.p;
-  set_trivial_chol(p, m, ADAjc, ADAir);
-  std::vector<sdm_int> Qjc(m + 1, 0), qb(K->lorN + 1, 0);
-  // the LP/Lorentz rows are not read by getada3: describe them as plain LP rows up to the first PSD row
-  sdm_int nlq = K->sdpN > 0 ? psd_blkstart[0] : N;
-  ada_build(p, N, m, Ajc, Air, Apr, Ajc1, nlq, 0, nullptr, K->sdpN, K->rsdpN, K->sdpNL, qb.data(), psd_blkstart,
-            Qjc.data(), nullptr, ADAjc, ADAir);
-  if (p->ada.lenud) SDM_HIP_CHECK(hipMemcpy(p->ada.udsqr.p, udsqr, p->ada.lenud * sizeof(double), hipMemcpyHostToDevice));
+  gw_build_getada3(p, m, ADAjc, ADAir, N, Ajc, Air, Apr, Ajc1, K, psd_blkstart);
   SDM_HIP_CHECK(hipMemcpy(p->ada_val.p, ADApr, (size_t)ADAjc[m] * sizeof(double), hipMemcpyHostToDevice));
-  ada_psd(p, p->ada_val.p, nullptr, true);
-  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
-  SDM_HIP_CHECK(hipMemcpy(ADApr, p->ada_val.p, (size_t)ADAjc[m] * sizeof(double), hipMemcpyDeviceToHost));
-  SDM_HIP_CHECK(hipMemcpy(absd, p->absd.p, m * sizeof(double), hipMemcpyDeviceToHost));
+  gw_run_getada3(p, udsqr);
+  gw_download(p, ADApr, absd);
   SDM_CATCH
 }
 
@@ -581,21 +626,11 @@ int sdm_getada(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N,
                const double *Apr, sdm_int lpN, const double *dl, sdm_int lorN, const double *ddet, const sdm_int *qblkstart,
                const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, double *ADApr, double *absd) {
   SDM_TRY
-  PlanGuard G; sdm_plan *p = G.p;
-  set_trivial_chol(p, m, ADAjc, ADAir);
-  const sdm_int nlq = lorN > 0 ? qblkstart[lorN] : lpN;             // = K.mainblks(3)-1: rows of Alq (getada.m:25)
-  std::vector<sdm_int> ajc2(m), zq(m + 1, 0);
-  for (sdm_int j = 0; j < m; j++) ajc2[j] = std::lower_bound(Air + Ajc[j], Air + Ajc[j + 1], nlq) - Air;
   (void)N;
-  ada_build(p, nlq, m, Ajc, Air, Apr, ajc2.data(), lpN, lorN, nullptr, 0, 0, nullptr, qblkstart, nullptr,
-            lorN > 0 ? Qjc : zq.data(), lorN > 0 ? Qir : nullptr, ADAjc, ADAir);
-  if (lpN) SDM_HIP_CHECK(hipMemcpy(p->ada.dl.p, dl, lpN * sizeof(double), hipMemcpyHostToDevice));
-  if (lorN) SDM_HIP_CHECK(hipMemcpy(p->ada.ddet.p, ddet, lorN * sizeof(double), hipMemcpyHostToDevice));
-  if (lorN && Qjc[m]) SDM_HIP_CHECK(hipMemcpy(p->ada.qpr.p, Qpr, Qjc[m] * sizeof(double), hipMemcpyHostToDevice));
-  if (sdm_plan_getada(p)) throw std::runtime_error(g_err);
-  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
-  SDM_HIP_CHECK(hipMemcpy(ADApr, p->ada_val.p, (size_t)ADAjc[m] * sizeof(double), hipMemcpyDeviceToHost));
-  SDM_HIP_CHECK(hipMemcpy(absd, p->absd.p, m * sizeof(double), hipMemcpyDeviceToHost));
+  PlanGuard G; sdm_plan *p = G.p;
+  gw_build_getada(p, m, ADAjc, ADAir, Ajc, Air, Apr, lpN, lorN, qblkstart, Qjc, Qir);
+  gw_run_getada(p, dl, ddet, Qpr);
+  gw_download(p, ADApr, absd);
   SDM_CATCH
 }
 

@@ -1,5 +1,6 @@
 // sdm_plan.h -- internal structures of the resident plan (not part of the ABI).
 #pragma once
+#include "../../include/sedumi_hip.h"
 #include "sdm_rt.h"
 #include <mutex>
 #include <string>
@@ -439,6 +440,20 @@ void dpr1fact_host(sdm_int m, sdm_int n, const sdm_int *Xjc, const sdm_int *Xir,
                    const sdm_int *dzjc, const sdm_int *dzir, const sdm_int *colperm, const sdm_int *firstpiv,
                    const double *smult, double maxu, std::vector<sdm_int> &betajc, std::vector<double> &beta,
                    std::vector<double> &p, std::vector<sdm_int> &pivperm, std::vector<int> &ordered);
+// sdm_capi.hip: gateway-shaped plans -- what ONE getada gateway needs (tier 1 builds one per call, sdm_mexcache.hip keeps them)
+void gw_upload_invperm(DevBuf<int> &buf, const sdm_int *perm, sdm_int m);
+void gw_build_getada1(sdm_plan *p, sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const sdm_int *Ajc, const sdm_int *Air,
+                      const double *Apr, const sdm_int *Ajc2, sdm_int lpN, sdm_int lorN, const sdm_int *qblkstart);
+void gw_run_getada1(sdm_plan *p, const int *d_invperm, const double *dl, const double *ddet);
+void gw_build_getada2(sdm_plan *p, sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int lorN, const sdm_int *Qjc, const sdm_int *Qir);
+void gw_run_getada2(sdm_plan *p, const int *d_invperm, const double *Qpr);
+void gw_build_getada3(sdm_plan *p, sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc, const sdm_int *Air,
+                      const double *Apr, const sdm_int *Ajc1, const sdm_cone *K, const sdm_int *psd_blkstart);
+void gw_run_getada3(sdm_plan *p, const double *udsqr);
+void gw_build_getada(sdm_plan *p, sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const sdm_int *Ajc, const sdm_int *Air, const double *Apr,
+                     sdm_int lpN, sdm_int lorN, const sdm_int *qblkstart, const sdm_int *Qjc, const sdm_int *Qir);
+void gw_run_getada(sdm_plan *p, const double *dl, const double *ddet, const double *Qpr);
+void gw_download(sdm_plan *p, double *ADApr, double *absd);
 // sdm_ada.hip
 void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_int *Air, const double *Apr,
                const sdm_int *Ajc_psd, sdm_int lpN, sdm_int lorN, const sdm_int *lorNL, sdm_int sdpN,

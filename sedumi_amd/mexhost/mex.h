@@ -1,16 +1,12 @@
 /*
- * mex.h -- TEST INFRASTRUCTURE ONLY (part of oracle/).
- *
- * A minimal, self-written stand-in for the MATLAB/Octave MEX C API, just big
- * enough to compile the *unmodified* SeDuMi reference sources that live under
- * /root/reference into oracle/_ref/ *.so (see oracle/Makefile), and to compile
- * our own mexFunction shims (sedumi_amd/mex/) for a syntax/link check in a
- * container that has neither MATLAB nor Octave.
- *
- * Nothing in the product path (sedumi_amd/, include/) includes this file.
+ * mex.h -- the MEX C API as far as SeDuMi's hot-path gateways use it, for running mexFunction binaries WITHOUT MATLAB or
+ * Octave (sedumi_amd/mexhost/mexhost.c implements it; sedumi_amd/mexhost.py drives it).  On a machine with MATLAB / Octave
+ * the shims of sedumi_amd/mexshims are compiled against the real mex.h instead and this file is not used.
+ * libsedumi_hip.so itself (sedumi_amd/csrc, include/) never includes it.  The oracle compiles the unmodified reference
+ * sources against it as well (oracle/Makefile).
  */
-#ifndef SDM_ORACLE_MEX_H
-#define SDM_ORACLE_MEX_H
+#ifndef SDM_MEXHOST_MEX_H
+#define SDM_MEXHOST_MEX_H
 
 #include <stddef.h>
 #include <stdlib.h>
@@ -28,10 +24,10 @@ typedef ptrdiff_t mwSignedIndex;
 
 typedef enum { mxREAL = 0, mxCOMPLEX = 1 } mxComplexity;
 
-enum { SHIM_DOUBLE = 0, SHIM_SPARSE = 1, SHIM_STRUCT = 2 };
+enum { MEXHOST_DOUBLE = 0, MEXHOST_SPARSE = 1, MEXHOST_STRUCT = 2 };
 
 typedef struct mxArray_tag {
-  int kind;            /* SHIM_DOUBLE / SHIM_SPARSE / SHIM_STRUCT */
+  int kind;            /* MEXHOST_DOUBLE / MEXHOST_SPARSE / MEXHOST_STRUCT */
   size_t m, n;
   double *pr;          /* values (full: m*n, sparse: nzmax) */
   size_t *ir, *jc;     /* sparse only */
@@ -88,18 +84,18 @@ int mexPutVariable(const char *workspace, const char *name, const mxArray *value
 /* entry point every MEX source defines */
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]);
 
-/* --- shim-only helpers used by the python/ctypes driver --- */
-typedef void (*shim_mexfun_t)(int, mxArray **, int, const mxArray **);
-int shim_call(shim_mexfun_t f, int nlhs, mxArray **plhs, int nrhs, const mxArray **prhs);
-const char *shim_last_error(void);
-int shim_kind(const mxArray *a);
-size_t shim_nzmax(const mxArray *a);
-int shim_nfields(const mxArray *a);
-const char *shim_fieldname(const mxArray *a, int i);
-mxArray *shim_fieldval(const mxArray *a, int i);
-mxArray *shim_new_struct(void);
-void shim_set_global(const char *name, const mxArray *value);   /* copy in (NULL clears) */
-const mxArray *shim_get_global(const char *name);
+/* --- host side: what sedumi_amd/mexhost.py calls --- */
+typedef void (*mexhost_mexfun_t)(int, mxArray **, int, const mxArray **);
+int mexhost_call(mexhost_mexfun_t f, int nlhs, mxArray **plhs, int nrhs, const mxArray **prhs);
+const char *mexhost_last_error(void);
+int mexhost_kind(const mxArray *a);
+size_t mexhost_nzmax(const mxArray *a);
+int mexhost_nfields(const mxArray *a);
+const char *mexhost_fieldname(const mxArray *a, int i);
+mxArray *mexhost_fieldval(const mxArray *a, int i);
+mxArray *mexhost_new_struct(void);
+void mexhost_set_global(const char *name, const mxArray *value);   /* copy in (NULL clears) */
+const mxArray *mexhost_get_global(const char *name);
 
 #ifdef __cplusplus
 }

@@ -18,22 +18,21 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (nrhs >= 4) { if ((sdm_int)numel(prhs[3]) != L.m) mexErrMsgTxt("absd size mismatch"); absd = mxGetPr(prhs[3]); }
   }
   const sdm_int m = L.m, nnzL = L.jc[m];
+  const mxArray *LLin = mxGetField(prhs[0], 0, "L");
   mxArray *out[4];
-  out[0] = mxCreateSparse(m, m, nnzL, mxREAL);
-  memcpy(mxGetJc(out[0]), mxGetJc(mxGetField(prhs[0], 0, "L")), (m + 1) * sizeof(mwIndex));
-  memcpy(mxGetIr(out[0]), mxGetIr(mxGetField(prhs[0], 0, "L")), nnzL * sizeof(mwIndex));
+  out[0] = sparse_like(LLin);                                          // L.L keeps the symbolic pattern (blkchol.c:391-395)
   out[1] = mxCreateDoubleMatrix(m, 1, mxREAL);
-  sdm_plan *p = cached_plan(L, mxGetJc(X), mxGetIr(X));
-  remember_factor(NULL, 0);          // the resident factor is about to be overwritten: whatever the solves are handed before this call has returned is not it
-  sdm_check(sdm_plan_upload(p, "ada", mxGetPr(X), (sdm_int)mxGetJc(X)[m]));
-  if (absd) sdm_check(sdm_plan_upload(p, "absd", absd, m));
-  sdm_check(sdm_plan_blkchol_wait(p, &pars, absd ? 1 : 0));      // (waited for, repeated once on the launch-per-panel path after a time-out)
-  sdm_check(sdm_plan_download(p, "lpr", mxGetPr(out[0]), nnzL));
-  sdm_check(sdm_plan_download(p, "d", mxGetPr(out[1]), m));
   ivec sidx(m > 0 ? m : 1), aidx(m > 0 ? m : 1);
   std::vector<double> sval(m > 0 ? m : 1), aval(m > 0 ? m : 1);
   sdm_int ns = 0, na = 0;
-  sdm_check(sdm_plan_pivots(p, &ns, sidx.data(), sval.data(), &na, aidx.data(), aval.data()));
+  IdxView Xjc = jc_of(X), Xir = ir_of(X);
+  cache_teardown_at_exit();
+  // the factor stays resident in the library's cache for fwblkslv / bwblkslv; X is taken from the device when it is the
+  // array getada3 just returned (sdm_mexcache.hip)
+  sdm_check(sdm_mexcache_blkchol(m, L.jc.data(), L.ir.data(), L.perm.data(), L.nsuper, L.xsuper.data(), Xjc.data(), Xir.data(), mxGetPr(X),
+                                 &pars, absd, mxGetPr(out[0]), mxGetPr(out[1]), &ns, sidx.data(), sval.data(), &na, aidx.data(), aval.data(),
+                                 idx_or_null(mxGetIr(out[0]))));
+  (void)nnzL;
   for (int k = 0; k < 2; k++) {                                       // sparse m x 1 outputs (blkchol.c:396-421)
     const sdm_int n = k ? na : ns;
     out[2 + k] = mxCreateSparse(m, 1, n > 0 ? n : 1, mxREAL);
@@ -41,7 +40,6 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     jc[0] = 0; jc[1] = (mwIndex)n;
     for (sdm_int i = 0; i < n; i++) { ir[i] = (mwIndex)(k ? aidx[i] : sidx[i]); pr[i] = k ? aval[i] : sval[i]; }
   }
-  remember_factor(mxGetPr(out[0]), (size_t)nnzL);
   int keep = nlhs > 1 ? nlhs : 1;
   for (int i = 0; i < keep; i++) plhs[i] = out[i];
   for (int i = keep; i < 4; i++) mxDestroyArray(out[i]);              // unrequested outputs (blkchol.c:436-439)

@@ -20,31 +20,35 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   }
   const mxArray *dl = need_field(prhs[2], "l", "Missing field d.l."), *ddet = need_field(prhs[2], "det", "Missing field d.det.");
   if ((sdm_int)numel(dl) != ck.K.lpN || (sdm_int)numel(ddet) != ck.K.lorN) mexErrMsgTxt("Size mismatch d.l / d.det.");
-  ivec qb(1, 0), Qjc(m + 1, 0), Qir(1, 0);
+  ivec qb(1, 0), Qjc_own(m + 1, 0), Qir_own(1, 0);
   std::vector<double> Qpr(1, 0.0);
   const double *qpr = Qpr.data();
+  IdxView Qjc_v, Qir_v;
+  const sdm_int *Qjc = Qjc_own.data(), *Qir = Qir_own.data();
   if (ck.K.lorN > 0) {
     qb = idx_from_dbl(need_field(prhs[1], "qblkstart", "Missing field K.qblkstart."), -1);
     if ((sdm_int)qb.size() != ck.K.lorN + 1) mexErrMsgTxt("Size mismatch K.qblkstart.");
     const mxArray *Q = need_field(prhs[3], "q", "Missing field DAt.q.");
     if ((sdm_int)mxGetM(Q) != ck.K.lorN || (sdm_int)mxGetN(Q) != m) mexErrMsgTxt("Size mismatch DAt.q.");
     if (mxIsSparse(Q)) {
-      Qjc = idx_from_mw(mxGetJc(Q), m + 1); Qir = idx_from_mw(mxGetIr(Q), mxGetJc(Q)[m]);
+      Qjc_v = jc_of(Q); Qir_v = ir_of(Q);
+      Qjc = Qjc_v.data(); Qir = Qir_v.data();
       qpr = mxGetPr(Q);
     } else {                                                         // a full DAt.q: every entry
       const sdm_int nq = ck.K.lorN;
-      Qir.resize((size_t)(nq * m));
-      for (sdm_int j = 0; j <= m; j++) Qjc[j] = j * nq;
-      for (sdm_int t = 0; t < nq * m; t++) Qir[t] = t % nq;
+      Qir_own.resize((size_t)(nq * m));
+      for (sdm_int j = 0; j <= m; j++) Qjc_own[j] = j * nq;
+      for (sdm_int t = 0; t < nq * m; t++) Qir_own[t] = t % nq;
+      Qjc = Qjc_own.data(); Qir = Qir_own.data();
       qpr = mxGetPr(Q);
     }
   }
-  mxArray *out = mxDuplicateArray(G);                                // same pattern as the global (getsymbada.m covers every product)
+  cache_teardown_at_exit();
+  mxArray *out = sparse_like(G);                                     // same pattern as the global (getsymbada.m covers every product)
   plhs[0] = mxCreateDoubleMatrix(m, 1, mxREAL);
-  ivec jc = idx_from_mw(mxGetJc(G), m + 1), ir = idx_from_mw(mxGetIr(G), mxGetJc(G)[m]);
-  ivec Ajc = idx_from_mw(mxGetJc(A), m + 1), Air = idx_from_mw(mxGetIr(A), mxGetJc(A)[m]);
-  int rc = sdm_getada(m, jc.data(), ir.data(), N, Ajc.data(), Air.data(), mxGetPr(A), ck.K.lpN, mxGetPr(dl), ck.K.lorN, mxGetPr(ddet),
-                      qb.data(), Qjc.data(), Qir.data(), qpr, mxGetPr(out), mxGetPr(plhs[0]));
+  IdxView jc = jc_of(G), ir = ir_of(G), Ajc = jc_of(A), Air = ir_of(A);
+  int rc = sdm_mexcache_getada(m, jc.data(), ir.data(), N, Ajc.data(), Air.data(), mxGetPr(A), ck.K.lpN, mxGetPr(dl), ck.K.lorN, mxGetPr(ddet),
+                               qb.data(), Qjc, Qir, qpr, mxGetPr(out), mxGetPr(plhs[0]), idx_or_null(mxGetIr(out)));
   if (rc) { mxDestroyArray(out); mexErrMsgTxt(sdm_last_error()); }
   if (mexPutVariable("global", "ADA_sedumi_", out)) { mxDestroyArray(out); mexErrMsgTxt("could not update global ADA_sedumi_."); }
   mxDestroyArray(out);                                               // mexPutVariable stored a copy

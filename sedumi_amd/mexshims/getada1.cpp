@@ -14,12 +14,10 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   ivec qb = idx_from_dbl(prhs[5], -1);                              // K.qblkstart
   const sdm_int lorN = (sdm_int)qb.size() - 1;
   if ((sdm_int)numel(ddet) != lorN) mexErrMsgTxt("Size d.det mismatch");
-  ivec jc = idx_from_mw(mxGetJc(ADA), m + 1), ir = idx_from_mw(mxGetIr(ADA), mxGetJc(ADA)[m]);
-  ivec Ajc = idx_from_mw(mxGetJc(A), m + 1), Air = idx_from_mw(mxGetIr(A), mxGetJc(A)[m]);
+  IdxView jc = jc_of(ADA), ir = ir_of(ADA), Ajc = jc_of(A), Air = ir_of(A);
   ivec Ajc2 = idx_from_dbl(prhs[2], 0), perm = idx_from_dbl(prhs[3], -1);
-  plhs[0] = mxCreateSparse(m, m, jc[m], mxREAL);                     // getada1.c:222-225
-  memcpy(mxGetJc(plhs[0]), mxGetJc(ADA), (m + 1) * sizeof(mwIndex));
-  memcpy(mxGetIr(plhs[0]), mxGetIr(ADA), jc[m] * sizeof(mwIndex));
-  sdm_check(sdm_getada1(m, jc.data(), ir.data(), (sdm_int)mxGetM(A), Ajc.data(), Air.data(), mxGetPr(A), Ajc2.data(), perm.data(),
-                        (sdm_int)numel(dl), mxGetPr(dl), lorN, mxGetPr(ddet), qb.data(), mxGetPr(plhs[0])));
+  cache_teardown_at_exit();
+  plhs[0] = sparse_like(ADA);                                        // getada1.c:222-225
+  sdm_check(sdm_mexcache_getada1(m, jc.data(), ir.data(), (sdm_int)mxGetM(A), Ajc.data(), Air.data(), mxGetPr(A), Ajc2.data(), perm.data(),
+                                 (sdm_int)numel(dl), mxGetPr(dl), lorN, mxGetPr(ddet), qb.data(), mxGetPr(plhs[0]), idx_or_null(mxGetIr(plhs[0]))));
 }

@@ -14,14 +14,14 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   ivec blk = idx_from_dbl(bs, -1);
   ivec psd(blk.begin() + ck.K.lorN + 1, blk.end());
   const mxArray *sp = need_field(prhs[3], "sperm", "Missing field Aord.sperm.");
-  if ((sdm_int)numel(sp) != m) mexErrMsgTxt("Aord.sperm size mismatch");
-  ivec jc = idx_from_mw(mxGetJc(ADA), m + 1), ir = idx_from_mw(mxGetIr(ADA), mxGetJc(ADA)[m]);
-  ivec Ajc = idx_from_mw(mxGetJc(A), m + 1), Air = idx_from_mw(mxGetIr(A), mxGetJc(A)[m]);
-  ivec Ajc1 = idx_from_dbl(prhs[2], 0), sperm = idx_from_dbl(sp, -1);
-  mxArray *out0 = mxDuplicateArray(ADA);                            // getada3.c:452
+  if ((sdm_int)numel(sp) != m) mexErrMsgTxt("Aord.sperm size mismatch");      // (only its triangular bookkeeping exists in the reference: the sum is order independent)
+  IdxView jc = jc_of(ADA), ir = ir_of(ADA), Ajc = jc_of(A), Air = ir_of(A);
+  ivec Ajc1 = idx_from_dbl(prhs[2], 0);
+  cache_teardown_at_exit();
+  mxArray *out0 = sparse_like(ADA);                                  // getada3.c:452 (the values come back from the device)
   mxArray *out1 = mxCreateDoubleMatrix(m, 1, mxREAL);
-  sdm_check(sdm_getada3(m, jc.data(), ir.data(), mxGetPr(out0), (sdm_int)mxGetM(A), Ajc.data(), Air.data(), mxGetPr(A), Ajc1.data(),
-                        sperm.data(), mxGetPr(prhs[4]), &ck.K, psd.data(), mxGetPr(out1)));
+  sdm_check(sdm_mexcache_getada3(m, jc.data(), ir.data(), mxGetPr(ADA), mxGetPr(out0), (sdm_int)mxGetM(A), Ajc.data(), Air.data(), mxGetPr(A),
+                                 Ajc1.data(), mxGetPr(prhs[4]), &ck.K, psd.data(), mxGetPr(out1), idx_or_null(mxGetIr(out0))));
   plhs[0] = out0;
   if (nlhs > 1) plhs[1] = out1; else mxDestroyArray(out1);           // getada3.c:565-568
 }

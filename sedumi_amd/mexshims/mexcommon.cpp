@@ -8,8 +8,8 @@ SymbL read_L(const mxArray *L, bool want_perm) {
   if (!mxIsSparse(f)) mexErrMsgTxt("L.L should be sparse.");
   S.m = (sdm_int)mxGetM(f);
   if (S.m != (sdm_int)mxGetN(f)) mexErrMsgTxt("Size L.L mismatch.");
-  S.jc = idx_from_mw(mxGetJc(f), S.m + 1);
-  S.ir = idx_from_mw(mxGetIr(f), (size_t)S.jc[S.m]);
+  S.jc = jc_of(f);
+  S.ir = ir_of(f);
   S.pr = mxGetPr(f);
   if (want_perm) {
     const mxArray *p = need_field(L, "perm", "Missing field L.perm.");
@@ -36,23 +36,12 @@ void read_cone(const mxArray *mxK, ConeK &o) {
 }
 
 // ------------------------------------------------------------------ plan cache
-// The cache itself lives inside libsedumi_hip.so (sdm_mexcache_*, sdm_mexcache.cpp): every .mex binary is its own
-// shared object, statics here would not be shared between blkchol.mex and fwblkslv.mex.
+// The cache itself lives inside libsedumi_hip.so (sdm_mexcache_*, sdm_mexcache.hip): every .mex binary is its own
+// shared object, statics here would not be shared between getada3.mex, blkchol.mex and fwblkslv.mex.
 namespace {
 bool atexit_set = false;
 void teardown(void) { sdm_mexcache_clear(); }
 }  // namespace
-
-sdm_plan *cached_plan(const SymbL &L, const mwIndex *Xjc, const mwIndex *Xir) {
-  ivec xjc = idx_from_mw(Xjc, L.m + 1), xir = idx_from_mw(Xir, (size_t)Xjc[L.m]);
+void cache_teardown_at_exit(void) {
   if (!atexit_set) { mexAtExit(teardown); atexit_set = true; }
-  sdm_plan *p = sdm_mexcache_plan(L.m, L.jc.data(), L.ir.data(), L.perm.data(), L.nsuper, L.xsuper.data(), xjc.data(), xir.data());
-  if (!p) mexErrMsgTxt(sdm_last_error());
-  return p;
-}
-void remember_factor(const double *Lpr_host, size_t nnz) { sdm_mexcache_remember_factor(Lpr_host, (sdm_int)nnz); }
-// non-null iff the values of L.L ARE the factor the cached plan holds (content fingerprint, not just the host address)
-sdm_plan *plan_for_factor(const SymbL &L) {
-  if (!atexit_set) { mexAtExit(teardown); atexit_set = true; }
-  return sdm_mexcache_factor_plan(L.m, L.jc.data(), L.ir.data(), L.pr, L.perm.empty() ? NULL : L.perm.data(), L.nsuper, L.xsuper.data());
 }

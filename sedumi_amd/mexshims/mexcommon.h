@@ -23,9 +23,43 @@ inline ivec idx_from_dbl(const mxArray *a, sdm_int offset) {
 }
 inline size_t numel(const mxArray *a) { return mxGetM(a) * mxGetN(a); }
 
+// Index arrays of a sparse mxArray as the C ABI wants them (0-based int64): mwIndex is a 64-bit unsigned integer in MATLAB and
+// in Octave builds with 64-bit indexing -- the same bits, so the array itself is handed over (the per-iteration gateways are
+// called with patterns of 10^5 .. 10^7 entries: a converted copy per call costs as much as the device work); other widths copy.
+struct IdxView {
+  const sdm_int *p = nullptr;
+  ivec own;
+  IdxView() {}
+  IdxView(const mwIndex *q, size_t n) {
+    if (sizeof(mwIndex) == sizeof(sdm_int)) p = reinterpret_cast<const sdm_int *>(q);
+    else { own = idx_from_mw(q, n); p = own.data(); }
+  }
+  const sdm_int *data() const { return own.empty() ? p : own.data(); }
+  sdm_int operator[](size_t i) const { return data()[i]; }
+};
+inline IdxView jc_of(const mxArray *a) { return IdxView(mxGetJc(a), mxGetN(a) + 1); }
+inline IdxView ir_of(const mxArray *a) { return IdxView(mxGetIr(a), (size_t)mxGetJc(a)[mxGetN(a)]); }
+// a sparse array with the pattern of `src` and UNINITIALISED values (the caller fills them): what getada1.c:222-225 builds with
+// mxCreateSparse + memcpy and getada2/3 with mxDuplicateArray, without the zero fill / value copy of nnz entries
+inline mxArray *sparse_like(const mxArray *src) {
+  const mwSize m = mxGetM(src), n = mxGetN(src);
+  const mwIndex nnz = mxGetJc(src)[n], cap = nnz > 0 ? nnz : 1;
+  mxArray *a = mxCreateSparse(m, n, 1, mxREAL);
+  mwIndex *ir = (mwIndex *)mxMalloc(cap * sizeof(mwIndex));
+  double *pr = (double *)mxMalloc(cap * sizeof(double));
+  mxFree(mxGetIr(a)); mxFree(mxGetPr(a));
+  mxSetIr(a, ir); mxSetPr(a, pr); mxSetNzmax(a, cap);
+  memcpy(mxGetJc(a), mxGetJc(src), (n + 1) * sizeof(mwIndex));
+  if (nnz) memcpy(ir, mxGetIr(src), nnz * sizeof(mwIndex));
+  if (!nnz) pr[0] = 0.0;
+  return a;
+}
+inline const sdm_int *idx_or_null(const mwIndex *q) { return sizeof(mwIndex) == sizeof(sdm_int) ? reinterpret_cast<const sdm_int *>(q) : NULL; }
+
 struct SymbL {                       // L.{L,perm,xsuper} as the numeric gateways read it (blkchol.c:266-286)
   sdm_int m, nsuper;
-  ivec jc, ir, perm, xsuper;
+  IdxView jc, ir;
+  ivec perm, xsuper;
   const double *pr;
 };
 SymbL read_L(const mxArray *L, bool want_perm);
@@ -34,7 +68,5 @@ SymbL read_L(const mxArray *L, bool want_perm);
 struct ConeK { sdm_cone K; ivec q, s; };
 void read_cone(const mxArray *mxK, ConeK &out);
 
-// one resident plan per symbolic factor, torn down at mexAtExit (INTEGRATION.md "Keeping data on the device")
-sdm_plan *cached_plan(const SymbL &L, const mwIndex *Xjc, const mwIndex *Xir);
-void remember_factor(const double *Lpr_host, size_t nnz);
-sdm_plan *plan_for_factor(const SymbL &L);     // non-null iff the values of L.L are the factor the last blkchol left resident
+// the process-wide cache inside libsedumi_hip.so (sdm_mexcache_*) is torn down at mexAtExit (INTEGRATION.md "Keeping data on the device")
+void cache_teardown_at_exit(void);

@@ -149,6 +149,7 @@ emu_double4 emu_mfma_f64_16x16x4(double a, double b, emu_double4 c);
 inline double atomicAdd(double *p, double v) { double o = *p; *p = o + v; return o; }   /* (no kernel of a concurrent launch adds doubles) */
 inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
 inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 inline int atomicExch(int *p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }

@@ -1,5 +1,5 @@
 """The mexFunction shims of sedumi_amd/mexshims: compiled against the declaration-only MEX header
-of oracle/mexshim, linked to the emulated build of the C ABI, and driven through the same mxArray marshalling as
+of the package's MEX host (sedumi_amd/mexhost), linked to the emulated build of the C ABI, and driven through the same mxArray marshalling as
 the reference MEX -- so `prhs/plhs` handling, field lookups, 1-based conversions and sparse outputs are tested
 end to end without MATLAB/Octave."""
 import glob
@@ -12,22 +12,15 @@ import scipy.sparse as sp
 
 from helpers import ROOT, TOL, ref_scaling, relerr, spd_pattern
 
-SHIMS = ["getada", "getada1", "getada2", "getada3", "blkchol", "fwblkslv", "bwblkslv", "ordmmdmex", "symfctmex", "choltmpsiz", "cholsplit",
-         "symbfwblk", "finsymbden", "dpr1fact", "fwdpr1", "bwdpr1", "invcholfac", "incorder", "adendotd", "adenscale"]
+from sedumi_amd.build import SHIMS
 
 
 def build_shims(lib, out):
-    """Every mexFunction shim as a shared object of its own, linked to the C-ABI library `lib` and to the MEX-API shim of
-    the oracle (g++ only: MATLAB / Octave are not needed)."""
-    os.makedirs(out, exist_ok=True)
-    src = os.path.join(ROOT, "sedumi_amd", "mexshims")
-    common = os.path.join(out, "mexcommon.o")
-    inc = ["-I", os.path.join(ROOT, "oracle", "mexshim"), "-I", os.path.join(ROOT, "include"), "-I", src]
-    subprocess.check_call(["g++", "-O1", "-fPIC", "-Wall", "-c", os.path.join(src, "mexcommon.cpp"), "-o", common] + inc)
-    for name in SHIMS:
-        subprocess.check_call(["g++", "-O1", "-fPIC", "-Wall", "-shared", os.path.join(src, name + ".cpp"), common, "-o",
-                               os.path.join(out, name + ".so"), lib, "-L", os.path.join(ROOT, "oracle", "_ref"), "-lmexshim",
-                               "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath," + os.path.join(ROOT, "oracle", "_ref")] + inc)
+    """Every mexFunction shim as a shared object of its own, linked to the C-ABI library `lib` and to the package's MEX host
+    (sedumi_amd.build.build_mexshims: g++ only, MATLAB / Octave are not needed); driven through the same marshalling as the
+    reference MEX."""
+    from sedumi_amd import build as b
+    b.build_mexshims(lib, out)
     from oracle.refmex import RefMex, REF_DIR
     return RefMex(REF_DIR, mex_dir=out)
 
@@ -204,3 +197,59 @@ def test_getada_shim_updates_the_global(glue, refmex, shimmex):
     shimmex.set_global("ADA_sedumi_", None)
     with pytest.raises(RefMexError, match="ADA_sedumi_ does not exist"):
         shimmex.call("getada", 1, S["A"], P.K, dstruct, it["DAt"])
+
+
+def mexcache_stats(shimlib):
+    import ctypes
+    lib = ctypes.CDLL(shimlib)
+    out = (ctypes.c_int64 * 16)()
+    lib.sdm_mexcache_stats(out, ctypes.c_int64(16))
+    keys = ("ada_build", "ada_reuse", "ada_upload", "ada_resident", "chol_build", "chol_reuse", "x_upload", "x_resident",
+            "solve_resident", "solve_stateless", "at_upload")
+    return dict(zip(keys, list(out)))
+
+
+def run_units_by_reference(host, S, K, d, DAt, ud, pars, rhs, nunits, ref_it=None):
+    """`nunits` iteration units through the mexFunction shims, arrays handed on BY REFERENCE (sedumi_amd.mexhost.iteration_units),
+    each unit's ADA', absd, L.L, L.d checked against the reference's when ref_it is given."""
+    from sedumi_amd.mexhost import iteration_units
+    dstruct = {"l": np.asarray(d["l"]).reshape(-1, 1), "det": np.asarray(d["det"]).reshape(-1, 1)}
+
+    def check(A3, absd, LL, Ld):
+        assert relerr(A3, ref_it["ADA"]) < TOL and relerr(absd, ref_it["absd"]) < TOL
+        assert relerr(LL, ref_it["LL"]) < TOL and relerr(Ld, ref_it["Ld"]) < TOL
+    times, y = iteration_units(host, S["A"], S["Ablkjc"][:, 2], S["Aord"], K, dstruct, DAt, ud, S["L"], S["ADA"], pars, rhs, nunits,
+                               check=check if ref_it is not None else None)
+    return [sum(t.values()) for t in times], y
+
+
+def test_iteration_units_by_reference_reuse_the_device_state(glue, refmex, shimmex, shimlib):
+    """What an unmodified sedumi.m does every iteration: the same At / K / patterns, each gateway's output handed to the next.  From
+    the second unit on nothing is analysed again (no ada_build, no chol_build), no ADA' values and no factor cross PCIe towards the
+    device (ADA resident for getada2 / getada3 / blkchol, L.L resident for the eight solves)."""
+    import ctypes
+    from oracle import glue as gl
+    from sedumi_amd import problem
+    ctypes.CDLL(shimlib).sdm_mexcache_clear()
+    P = problem.random_sdp(m=28, seed=21)
+    S = glue.setup(P.At, P.K)
+    d, ud = ref_scaling(P, 2)
+    it = glue.iteration_ref(S, d, ud)
+    pars = gl.default_pars_chol()
+    rhs = np.random.default_rng(0).standard_normal(P.m)
+    s0 = mexcache_stats(shimlib)
+    _, y = run_units_by_reference(shimmex, S, P.K, d, it["DAt"], ud, pars, rhs, 1, it)
+    s1 = mexcache_stats(shimlib)
+    _, y2 = run_units_by_reference(shimmex, S, P.K, d, it["DAt"], ud, pars, rhs, 2, it)
+    s2 = mexcache_stats(shimlib)
+    L = dict(S["L"]); L["L"] = it["LL"]
+    yr = refmex.call("bwblkslv", 1, L, refmex.call("fwblkslv", 1, L, rhs.reshape(-1, 1)) / np.where(it["Ld"] > 0, it["Ld"], 1.0))
+    assert relerr(y, yr.ravel()) < TOL and relerr(y2, yr.ravel()) < TOL
+    nq = int(P.K["q"].size > 0)                                   # getada2 runs on the device only when there are Lorentz cones
+    assert s1["ada_build"] - s0["ada_build"] == 2 + nq and s1["chol_build"] - s0["chol_build"] == 1
+    # the later units: the problem data are re-marshalled by the test (new addresses, same content): recognised by content
+    assert s2["ada_build"] == s1["ada_build"] and s2["chol_build"] == s1["chol_build"], (s1, s2)
+    assert s2["at_upload"] == s1["at_upload"]
+    assert s2["ada_upload"] == s1["ada_upload"] and s2["x_upload"] == s1["x_upload"], (s1, s2)
+    assert s2["ada_resident"] - s1["ada_resident"] == 2 * (1 + nq) and s2["x_resident"] - s1["x_resident"] == 2
+    assert s2["solve_resident"] - s1["solve_resident"] == 16 and s2["solve_stateless"] == s1["solve_stateless"]

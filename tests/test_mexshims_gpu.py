@@ -1,5 +1,5 @@
 """The drop-in boundary on real hardware: the mexFunction shims of sedumi_amd/mexshims built with g++ against
-libsedumi_hip.so (the hipcc build for gfx950) and the MEX-API shim of the oracle, driven through the same mxArray
+libsedumi_hip.so (the hipcc build for gfx950) and the package's MEX host (sedumi_amd/mexhost), driven through the same mxArray
 marshalling as the reference MEX -- the iteration unit, the process-wide factor cache shared between the .mex binaries, the
 dense-column gateways, invcholfac, getada -- plus the host-side N3 entry points (incorder, adendotd, adenscale) on the
 product library.  The tests themselves are those of test_mexshims.py / test_oracle.py / test_dense_columns.py; only the
@@ -10,6 +10,7 @@ import pytest
 
 from helpers import ROOT, use_hip
 from test_mexshims import (build_shims, test_factor_cache_is_shared_between_mex_binaries_and_validated_by_content,  # noqa: F401
+                           test_iteration_units_by_reference_reuse_the_device_state,
                            test_getada_shim_updates_the_global, test_shim_errors_go_through_mexErrMsgTxt, test_shim_incorder,
                            test_shim_invcholfac, test_shims_dense_column_path, test_shims_reproduce_an_iteration_unit,
                            test_shims_symbolic_bit_exact)

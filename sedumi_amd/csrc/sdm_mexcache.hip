@@ -28,7 +28,7 @@ using namespace sdm;
 
 namespace {
 typedef unsigned long long u64;
-constexpr sdm_int SAMPLE = 4096;           // words of the sampled hash
+constexpr sdm_int SAMPLE = 512;            // words of the sampled hash (each a cache and TLB miss on a big array: 4096 of them cost 0.7 ms per check on a 64 MB factor)
 constexpr sdm_int FULL_MAX = 1 << 22;      // full hash only up to 4M words (32 MB, ~2 ms on the host)
 constexpr u64 P1 = 11400714785074694791ull, P2 = 14029467366897019727ull;
 inline u64 rotl(u64 x, int r) { return (x << r) | (x >> (64 - r)); }

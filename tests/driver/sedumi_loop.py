@@ -197,8 +197,9 @@ class PlanHot:
     per iteration the loop uploads d.{l,det,q1,q2,u} (+ d.perm), and per solve one right-hand side."""
     name = "sedumi_amd.plan"
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, device_ops=True):
         self.device, self.plan = device, None
+        self._pcg, self._d, self._want_ops = False, None, device_ops
 
     def factor(self, S, d, DAt, L, pars):
         from sedumi_amd.plan import Plan
@@ -207,7 +208,13 @@ class PlanHot:
             self.plan = Plan(self.device)
             self.plan.set_chol(S["L"], S["ADA"])
             self.plan.set_ada(S["A"], S["Ablkjc"], K, S["DAt"]["q"] if K["q"].size else None)
+            self._N = int(S["A"].shape[0])
+            ks = K["s"].ravel().astype(int); nr = int(K["rsdpN"])
+            self._lenud = int(np.sum(ks[:nr] ** 2) + 2 * np.sum(ks[nr:] ** 2))
+            self.plan.pcg_init()                                    # work vectors "xN" / "psd" (no dense columns in this restatement)
+            self._pcg = True
         pl = self.plan
+        self._d = d
         pl.upload("dl", d["l"]); pl.upload("ddet", d["det"])
         if K["q"].size:
             pl.upload("q1", d["q1"]); pl.upload("q2", d["q2"])
@@ -233,6 +240,31 @@ class PlanHot:
     def bw(self, L, r):
         self.plan.upload("rhs", vec(r)); self.plan.bwsolve()
         return self.plan.download("y")
+
+    # ---- the operators wrapPcg.m:47-66 / loopPcg.m apply around the solves, on the device: the whole-solve tests
+    # (reference-held optimal values of examples/test_sedumi.m:22-28, the reference-hot-path log) pin them through every PCG step
+    def has_ops(self, d=None):
+        return self._want_ops and self.plan is not None and self._pcg and (d is None or d is self._d)
+
+    def Amul(self, x, transp):
+        pl = self.plan
+        if not transp:                                             # Amul.m:46  At' * x
+            pl.upload("xN", vec(x)); pl.amul(0)
+            return pl.download("rhs")
+        pl.upload("y", vec(x)); pl.amul(1)                          # Amul.m:48  At * y
+        return pl.download("xN", self._N)
+
+    def Amul1_vecsym(self, p):
+        """vecsym(Amul(At, dense, p, 1), K)  (wrapPcg.m:65, loopPcg.m) as one device sequence"""
+        pl = self.plan
+        pl.upload("y", vec(p)); pl.amul(1); pl.vecsym()
+        return pl.download("xN", self._N)
+
+    def psdscale(self, d, x, transp):
+        """psdscale(d, x, K[, transp]) with the d of the last factor() (its d.u and pivot order are resident)"""
+        pl = self.plan
+        pl.upload("xN", vec(x)); pl.psdscale(1 if transp else 0, bool(np.size(d["perm"])))
+        return pl.download("psd", self._lenud)
 
 
 class ShadowHot:
@@ -509,13 +541,38 @@ class Sedumi:
         self.hot = hot or RefHot(self.G)
 
     # Amul.m (no dense columns)
+    def _ops(self, d=None):
+        """the hot path's own Amul / vecsym / psdscale (PlanHot: on the device), when it has them for this scaling"""
+        h = self.hot
+        return h if getattr(h, "has_ops", None) and h.has_ops(d) else None
+
     def Amul(self, x, transp=0):
+        h = self._ops()
+        if h is not None:
+            return vec(h.Amul(x, transp))
         return vec(self.A.T @ x) if not transp else vec(self.A @ x)
+
+    def Amul1_vecsym(self, p):
+        """vecsym(Amul(At,dense,p,1), K)   (wrapPcg.m:65)"""
+        h = self._ops()
+        if h is not None:
+            return vec(h.Amul1_vecsym(p))
+        return self.cone.vecsym(vec(self.A @ p))
+
+    def psdscale(self, d, x, transp=False):
+        """psdscale(d, x, K[, transp]); x full length or its PSD part only"""
+        cn = self.cone
+        h = self._ops(d)
+        if h is None or not cn.s.size:
+            return cn.psdscale(d, x, transp)
+        N = self.A.shape[0]
+        xf = vec(x) if np.size(x) == N else np.concatenate((np.zeros(N - np.size(x)), vec(x)))
+        return vec(h.psdscale(d, xf, transp))
 
     def Dx(self, d, x, transp):
         """[sqrt(d.l).*x(1:K.l); asmDxq(d,x,K); psdscale(d,x,K[,transp])]"""
         cn = self.cone
-        return np.concatenate((np.sqrt(d["l"]) * x[:cn.l], cn.asmDxq(d, x), cn.psdscale(d, x, transp)))
+        return np.concatenate((np.sqrt(d["l"]) * x[:cn.l], cn.asmDxq(d, x), self.psdscale(d, x, transp)))
 
     # ---- sdinit.m:40-78
     def sdinit(self):
@@ -571,7 +628,7 @@ class Sedumi:
         p, yv = self.precond(L, r)
         ssqrNew = p @ yv
         p = vec(self.hot.bw(L, yv))
-        x = cn.vecsym(self.Amul(p, 1))
+        x = self.Amul1_vecsym(p)
         dx = self.Dx(d, x, False)
         ssqrdx = dx @ dx
         if ssqrdx <= 0.0:
@@ -609,8 +666,8 @@ class Sedumi:
         i1, i2 = cn.i1, cn.i2
         y = np.concatenate((d["l"] * x[:i1], -d["det"] * x[i1:i2], cn.qblkmul(d["det"], x)))
         ddotx = d["q1"] * x[i1:i2] + cn.ddot(d["q2"], x)
-        Dxp = cn.psdscale(d, x)
-        y = np.concatenate((y, cn.psdscale(d, Dxp, True)))
+        Dxp = self.psdscale(d, x)
+        y = np.concatenate((y, self.psdscale(d, Dxp, True)))
         xTy = x[:cn.lq] @ y[:cn.lq] + np.sum(ddotx ** 2) + np.sum(Dxp ** 2)
         return y, ddotx, Dxp, xTy
 
@@ -634,7 +691,7 @@ class Sedumi:
                 ssqrNew = Lr @ tmp
                 p = (ssqrNew / ssqrOld) * p
                 p = p + vec(self.hot.bw(L, tmp))
-            Ap = cn.vecsym(self.Amul(p, 1))
+            Ap = self.Amul1_vecsym(p)
             DDAp, DApq, DAps, ssqrDAp = self.PopK(d, Ap)
             if ssqrDAp > 0.0:
                 k += 1
@@ -669,7 +726,7 @@ class Sedumi:
         else:
             DAy = 0.0
             for part in y:
-                Ap2 = cn.vecsym(self.Amul(part, 1))
+                Ap2 = self.Amul1_vecsym(part)
                 DAy = DAy + self.Dx(d, Ap2, False)
         return y[0], k, DAy
 

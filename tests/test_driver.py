@@ -66,6 +66,12 @@ def check_objectives(name, r):
 TOL_LOG = {"nb": (1e-6, 1e-2), "control07": (1e-6, 1e-2), "arch0": (1e-3, 1e-1), "quantum": (1e-6, 1e-2)}
 
 
+# rows whose step length sits within rounding of its cap (0.9 .. 0.99 of the way to the boundary): control07's iteration 24 gives
+# tP = 0.8422 or 0.9000 with either solve path -- explicit inverses or plain substitution (profiles/r03d_diag_control07.txt) --
+# and the row after it inherits the other iterate
+KNIFE_EDGE_ROWS = {("control07", 24), ("control07", 25)}
+
+
 def check_log(name, r, ref):
     """Row by row against the reference-hot-path run up to two iterations before the shorter run ends: the objective
     column throughout; gap, precision, delta, rate and the step lengths while the reference gets each direction from ONE
@@ -88,7 +94,8 @@ def check_log(name, r, ref):
         # step lengths (and with them delta / rate) are minima over boundary hits capped at 0.9 .. 0.99 of the way: a row in which a
         # hit lies within rounding of the cap is a coin toss -- control07's iteration 24 (tP 0.8422 or 0.9000) goes either way between
         # super-block widths of the solves and even with the plain substitution (growth bound 0: profiles/r03d_diag_control07.txt),
-        # the gap and objective columns of the rows after it agreeing to four digits all the same.  Up to two such rows may differ.
+        # the gap and objective columns of the rows after it agreeing to four digits all the same.  Only the rows named in KNIFE_EDGE_ROWS may differ
+        # (their gap / prec columns are still asserted above).
         dev = max(abs(A[i][k] - B[i][k]) for k in ("delta", "rate", "tP", "tD"))
         if dev >= tol_row:
             flips.append((i + 1, dev))
@@ -101,7 +108,8 @@ def check_log(name, r, ref):
           {k: float("%.3g" % v) for k, v in worst.items()}, "rows with a different step length:", flips)
     assert worst["by_x0"] < tol_obj, worst
     assert max(worst.get(k, 0.0) for k in ("gap", "prec", "delta", "rate", "tP", "tD")) < tol_row, worst
-    assert len(flips) <= 2, flips
+    # (round-3 advisor: only the named knife-edge rows may flip -- anything else is a solve-accuracy regression)
+    assert all((name, it) in KNIFE_EDGE_ROWS for it, _ in flips), (name, flips)
     assert abs(r["cx"] - ref["cx"]) / abs(ref["cx"]) < TOL_OBJ and abs(r["by"] - ref["by"]) / abs(ref["by"]) < TOL_OBJ
 
 

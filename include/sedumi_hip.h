@@ -341,8 +341,8 @@ int sdm_plan_load_factor(sdm_plan *p, const double *Lpr, const double *d);
  * (m x nden CSC), dz (cumulative dzjc[nden+1], dzir), colperm = symLden.perm-1, first = symLden.first-1.
  * Every iteration: upload the dense columns Ad (m x nden column major, deninfac.m:58-59) into plan buffer "ad", then
  * sdm_plan_deninfac(smult[nden] (deninfac.m:60-62), maxuden): LAD = L \ Ad(perm,:) for all columns in one set of
- * launches, then dpr1fact on the device (scan form of the recurrences; *host_fallback = 1 when a postponed pivot, a
- * dependent row or a Lorentz trace column sent it through the general host algorithm).  Afterwards sdm_plan_ldlsolve
+ * launches, then dpr1fact on the device (the recurrences as scans; postponed pivots, dependent rows and negative multiples
+ * included: *host_fallback is always 0, the argument is kept for callers of earlier versions).  Afterwards sdm_plan_ldlsolve
  * is the whole wrapPcg.m:56-59 body: fwblkslv, fwdpr1, ./Ld, bwdpr1, bwblkslv.  sdm_plan_lden downloads the factors
  * (layout of sdm_dpr1fact; buffers sized pnnz = sum_k dzjc[k+1], Ld[m]). */
 int sdm_plan_set_dense(sdm_plan *p, sdm_int nden, const sdm_int *LADjc, const sdm_int *LADir, const sdm_int *dzjc,

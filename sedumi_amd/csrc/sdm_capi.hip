@@ -387,7 +387,7 @@ int sdm_plan_lden(sdm_plan *p, sdm_int *betajc, double *beta, double *pv, sdm_in
   SDM_TRY
   DensePlan &D = p->dense;
   if (!D.factored) throw std::runtime_error("sdm_plan_lden: no dense-column factor resident");
-  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  dense_fetch_tables(p->stream, D);                                   // (lengths, row-order flags: device tables of the factorisation)
   const sdm_int nden = D.nden, nb = D.betajc[nden], np = D.permoff[nden];
   for (sdm_int k = 0; k <= nden; k++) betajc[k] = D.betajc[k];
   for (sdm_int k = 0; k < nden; k++) dopiv[k] = D.dopiv[k];

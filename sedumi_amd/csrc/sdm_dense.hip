@@ -73,174 +73,6 @@ void symbfwblk(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int 
   Xjc[n] = (sdm_int)Xir.size();
 }
 
-// ===================================================================== dpr1fact (host)
-struct KeyVal { double r; sdm_int k; };
-
-// One rank-1 step: factor diag(d) + p p' / t (dodpr1fact, dpr1fact.c:280-477).  Returns 1 when rows were
-// reordered (perm written, full length m), 0 for the natural order.  beta gets *pn entries.
-static int rank1_factor(double *beta, sdm_int *perm, double *d, double tmul, const double *p, sdm_int m, sdm_int *pn,
-                        std::vector<sdm_int> &dep, sdm_int *pndep, double maxu, std::vector<double> &psqr,
-                        std::vector<KeyVal> &post) {
-  if (tmul == 0.0) { *pn = 0; return 0; }
-  double t = 1 / tmul;
-  sdm_int ndep = *pndep;
-  for (sdm_int i = 0; i < m; i++) psqr[i] = p[i] * p[i];
-  std::vector<double> mu(m > 0 ? m : 1);
-  const double maxu2 = maxu;
-  auto stable = [&](double pj2, double bound, double fij) { const double s = maxu2 * fij; return pj2 * bound <= s * s; };
-  post.clear();
-  if (dep[0] >= m) {
-    // ---- all d > 0 (case A, dpr1fact.c:316-366)
-    *pn = m;
-    double h = 0.0;
-    for (sdm_int i = m; i > 0; i--) { mu[i - 1] = h; h = std::max(h, psqr[i - 1]); }
-    double muph2 = 0.0;
-    for (sdm_int j = 0; j < m; j++) {                     // first round, natural order (dpr1fact.c:97-135)
-      const double dj = d[j], pj2 = psqr[j], fij = pj2 + t * dj;
-      if (stable(pj2, std::max(muph2, mu[j]), fij)) { psqr[j] = fij; d[j] = fij / t; t = fij / dj; }
-      else { post.push_back({pj2, j}); muph2 = std::max(muph2, pj2); }
-    }
-    if (post.empty()) {
-      for (sdm_int j = 0; j < m; j++) beta[j] = p[j] / psqr[j];
-      return 0;
-    }
-    sdm_int q = 0, nextpost = 0;
-    for (sdm_int j = 0; j < m; j++) {
-      if (nextpost < (sdm_int)post.size() && post[nextpost].k == j) { nextpost++; continue; }
-      perm[q] = j; beta[q] = p[j] / psqr[j]; q++;
-    }
-    std::stable_sort(post.begin(), post.end(), [](const KeyVal &a, const KeyVal &b) { return a.r > b.r; });   // kdsortdec
-    for (auto &kv : post) {                                // second round (ph2dpr1fact, dpr1fact.c:224-240)
-      const double dj = d[kv.k];
-      kv.r += t * dj;
-      d[kv.k] = kv.r / t;
-      t = kv.r / dj;
-    }
-    for (size_t i = 0; i < post.size(); i++) { perm[q + i] = post[i].k; beta[q + i] = p[post[i].k] / post[i].r; }
-    return 1;
-  }
-  // ---- some d == 0 (dpr1fact.c:371-476)
-  double psqrdep = 0.0;
-  sdm_int jd = 0, i = 0;
-  for (i = 0; dep[i] < m; i++)
-    if (psqr[dep[i]] > psqrdep) { jd = i; psqrdep = psqr[dep[i]]; }
-  sdm_int idep;
-  double h;
-  int deldep = 0;
-  if (psqrdep > 0.0) {
-    idep = dep[jd];
-    if (t > 0.0) {
-      deldep = 1;
-      for (sdm_int q = jd; q < ndep; q++) dep[q] = dep[q + 1];      // incl. the tail dep[ndep]
-      h = maxu * maxu * psqrdep;
-      dep[ndep] = idep;                                            // remember the removed dependency
-      *pndep = --ndep;
-    } else { h = psqrdep; deldep = 0; }
-  } else { idep = dep[0]; h = 0.0; }
-  sdm_int j = 0, back = m;
-  for (i = 0; i < m; i++) {
-    if (i == idep) continue;
-    if (psqr[i] > h) perm[j++] = i; else perm[--back] = i;
-  }
-  perm[j] = idep;
-  sdm_int n = j;
-  *pn = j + deldep;
-  for (i = n; i > 0; i--) { mu[i - 1] = h; h = std::max(h, psqr[perm[i - 1]]); }
-  double muph2 = 0.0;
-  sdm_int acc = 0;
-  for (i = 0; i < n; i++) {                                 // dpr1factperm (dpr1fact.c:168-202)
-    const sdm_int k = perm[i];
-    const double dj = d[k], pj2 = psqr[k], fij = pj2 + t * dj;
-    if (stable(pj2, std::max(muph2, mu[i]), fij)) { psqr[k] = fij; perm[acc++] = k; d[k] = fij / t; t = fij / dj; }
-    else { post.push_back({pj2, k}); muph2 = std::max(muph2, pj2); }
-  }
-  for (i = 0; i < acc; i++) beta[i] = p[perm[i]] / psqr[perm[i]];
-  if (!post.empty()) {
-    std::stable_sort(post.begin(), post.end(), [](const KeyVal &a, const KeyVal &b) { return a.r > b.r; });
-    for (auto &kv : post) { const double dj = d[kv.k]; kv.r += t * dj; d[kv.k] = kv.r / t; t = kv.r / dj; }
-    for (size_t q = 0; q < post.size(); q++) { perm[acc + q] = post[q].k; beta[acc + q] = p[post[q].k] / post[q].r; }
-  }
-  if (deldep) { d[idep] = psqr[idep] / t; beta[acc + post.size()] = 1.0 / p[idep]; }
-  return 1;
-}
-
-// host versions of the elementary solves, used on the remaining columns inside the factorisation (prodformfact,
-// dpr1fact.c:585-597); the per-solve device kernels below implement the same recurrences
-static void fw_one(double *y, const sdm_int *perm, const double *p, const double *beta, sdm_int m, sdm_int n) {
-  if (n < 1) return;
-  auto at = [&](sdm_int i) { return perm ? perm[i] : i; };
-  double yi = y[at(0)], betai = beta[0], t = 0.0;
-  sdm_int i;
-  for (i = 1; i < n; i++) { t += yi * betai; const sdm_int r = at(i); yi = (y[r] -= t * p[r]); betai = beta[i]; }
-  if (n < m) { t += yi * betai; for (; i < m; i++) { const sdm_int r = at(i); y[r] -= t * p[r]; } }
-}
-
-void dpr1fact_host(sdm_int m, sdm_int n, const sdm_int *Xjc, const sdm_int *Xir, const double *Xpr, double *lab,
-                   const sdm_int *dzjc, const sdm_int *dzir, const sdm_int *colperm, const sdm_int *firstpiv,
-                   const double *smult, double maxu, std::vector<sdm_int> &betajc, std::vector<double> &beta,
-                   std::vector<double> &p, std::vector<sdm_int> &pivperm, std::vector<int> &ordered) {
-  sdm_int pnnz = 0;
-  for (sdm_int i = 1; i <= n; i++) pnnz += dzjc[i];
-  const sdm_int dznnz = dzjc[n];
-  std::vector<double> d(std::max<sdm_int>(dznnz, 1));
-  for (sdm_int i = 0; i < dznnz; i++) d[i] = lab[dzir[i]];
-  std::vector<sdm_int> dep(m + 1);
-  sdm_int ndep = 0;
-  for (sdm_int i = 0; i < dznnz; i++) if (d[i] <= 0.0) dep[ndep++] = i;
-  dep[ndep] = m;
-  std::vector<sdm_int> invrow(std::max<sdm_int>(m, 1), 0);
-  for (sdm_int i = 0; i < dznnz; i++) invrow[dzir[i]] = i;
-  p.assign(std::max<sdm_int>(pnnz + m, 1), 0.0);
-  { sdm_int off = 0;
-    for (sdm_int j = 0; j < n; j++) {
-      off += dzjc[j];
-      for (sdm_int t = Xjc[colperm[j]]; t < Xjc[colperm[j] + 1]; t++) p[off + invrow[Xir[t]]] = Xpr[t];
-    } }
-  p.resize(std::max<sdm_int>(pnnz, 0));
-  beta.assign(std::max<sdm_int>(pnnz, 1), 0.0);
-  betajc.assign(n + 1, 0);
-  pivperm.assign(std::max<sdm_int>(pnnz, 1), 0);
-  ordered.assign(n, 0);
-  std::vector<double> psqr(std::max<sdm_int>(dznnz, 1));
-  std::vector<KeyVal> post;
-  const sdm_int maxndep = ndep;
-  sdm_int inz = 0, poff = 0, permoff = 0;
-  for (sdm_int k = 0; k < n; k++) {                        // prodformfact (dpr1fact.c:549-621)
-    const sdm_int colk = colperm[k];
-    betajc[k] = inz;
-    const sdm_int mk = dzjc[k + 1];
-    poff += dzjc[k];
-    double *pk = p.data() + poff, *betak = beta.data() + inz;
-    sdm_int nk = 0;
-    const int useperm = rank1_factor(betak, pivperm.data() + permoff, d.data(), smult[colk], pk, mk, &nk, dep, &ndep, maxu, psqr, post);
-    ordered[k] = useperm;
-    if (smult[colk] < 0.0) {                                // findnewdep (dpr1fact.c:495-512)
-      sdm_int i;
-      for (i = ndep + 1; i <= maxndep; i++) if (d[dep[i]] <= 0.0) break;
-      if (i <= maxndep) {
-        const sdm_int idep = dep[i];
-        const sdm_int j = lower_from(dep.data(), 0, ndep, idep);
-        for (sdm_int q = i; q > j; q--) dep[q] = dep[q - 1];
-        dep[j] = idep;
-        ndep++;
-      }
-    }
-    if (smult[colk] != 0.0) {
-      sdm_int joff = poff;
-      for (sdm_int j = k + 1; j < n; j++) {
-        joff += dzjc[j];
-        if (firstpiv[colperm[j]] <= k) fw_one(p.data() + joff, useperm ? pivperm.data() + permoff : nullptr, pk, betak, mk, nk);
-      }
-      if (useperm) permoff += mk;
-    }
-    inz += nk;
-  }
-  betajc[n] = inz;
-  beta.resize(inz);
-  pivperm.resize(permoff);
-  for (sdm_int i = 0; i < dznnz; i++) lab[dzir[i]] = d[i];
-}
-
 // ===================================================================== fwdpr1 / bwdpr1 (device)
 struct Pr1Tab {
   const int64_t *dzjc;      // cumulative row counts: factor k acts on the first dzjc[k+1] entries of the gathered vector
@@ -437,16 +269,40 @@ int sdm_dpr1fact(sdm_int m, sdm_int n, const sdm_int *Xjc, const sdm_int *Xir, c
                  const double *smult, double maxu, sdm_int *betajc, double *beta, double *p, sdm_int *pivperm,
                  sdm_int *npivperm, sdm_int *dopiv) {
   SDM_TRY
-  std::vector<sdm_int> bj, pp;
-  std::vector<double> be, pv;
-  std::vector<int> ord;
-  dpr1fact_host(m, n, Xjc, Xir, Xpr, d, dzjc, dzir, colperm, first, smult, maxu, bj, be, pv, pp, ord);
-  std::copy(bj.begin(), bj.end(), betajc);
-  std::copy(be.begin(), be.end(), beta);
-  std::copy(pv.begin(), pv.end(), p);
-  std::copy(pp.begin(), pp.end(), pivperm);
-  *npivperm = (sdm_int)pp.size();
-  for (sdm_int k = 0; k < n; k++) dopiv[k] = ord[k];
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available (libsedumi_hip has no CPU fallback)");
+  for (sdm_int k = 0; k <= n; k++) betajc[k] = 0;
+  *npivperm = 0;
+  if (n <= 0) return 0;
+  DensePlan D;
+  dense_tables(D, m, n, dzjc, dzir, colperm, first);
+  const sdm_int dznnz = dzjc[n], pnnz = D.pnnz;
+  // the gateway's marshalling (dpr1fact.c:728-752): d(1:dznnz) = lab(dz.ir), p(invrowperm,:) = x(:,colperm)
+  std::vector<double> dg((size_t)std::max<sdm_int>(dznnz, 1)), pv((size_t)std::max<sdm_int>(pnnz, 1), 0.0);
+  std::vector<sdm_int> invrow((size_t)std::max<sdm_int>(m, 1), -1);
+  for (sdm_int i = 0; i < dznnz; i++) { dg[i] = d[dzir[i]]; invrow[dzir[i]] = i; }
+  for (sdm_int j = 0; j < n; j++)
+    for (sdm_int t = Xjc[colperm[j]]; t < Xjc[colperm[j] + 1]; t++) {
+      const sdm_int r = invrow[Xir[t]];
+      if (r < 0 || r >= dzjc[j + 1]) throw std::runtime_error("dpr1fact: x has a nonzero outside Lsymb.dz");
+      pv[D.poff[j] + r] = Xpr[t];
+    }
+  hipStream_t st = nullptr;
+  SDM_HIP_CHECK(hipMemcpyAsync(D.p.p, pv.data(), (size_t)pnnz * sizeof(double), hipMemcpyHostToDevice, st));
+  SDM_HIP_CHECK(hipMemcpyAsync(D.dgat.p, dg.data(), (size_t)dznnz * sizeof(double), hipMemcpyHostToDevice, st));
+  dense_prodformfact(nullptr, st, D, smult, maxu);
+  dense_fetch_tables(st, D);
+  const sdm_int nb = D.betajc[n], np = D.permoff[n];
+  for (sdm_int k = 0; k <= n; k++) betajc[k] = D.betajc[k];
+  for (sdm_int k = 0; k < n; k++) dopiv[k] = D.dopiv[k];
+  if (nb) SDM_HIP_CHECK(hipMemcpy(beta, D.beta.p, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost));
+  if (pnnz) SDM_HIP_CHECK(hipMemcpy(p, D.p.p, (size_t)pnnz * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<int> pp((size_t)std::max<sdm_int>(np, 1));
+  if (np) SDM_HIP_CHECK(hipMemcpy(pp.data(), D.d_pivperm.p, (size_t)np * sizeof(int), hipMemcpyDeviceToHost));
+  for (sdm_int i = 0; i < np; i++) pivperm[i] = pp[i];
+  *npivperm = np;
+  if (dznnz) SDM_HIP_CHECK(hipMemcpy(dg.data(), D.dgat.p, (size_t)dznnz * sizeof(double), hipMemcpyDeviceToHost));
+  for (sdm_int i = 0; i < dznnz; i++) d[dzir[i]] = dg[i];                // lab(dz.ir) = d (dpr1fact.c:779-780)
   SDM_CATCH
 }
 

@@ -303,16 +303,18 @@ namespace sdm {
 // resident dense-column unit: the dense columns of A re-enter the normal equations as a product of rank-1 factors
 // (deninfac.m:58-94); symbolic data once per solve (dense_set), LAD = L \ Ad and the product-form factors every iteration
 struct DensePlan {
-  sdm_int nden = 0, dznnz = 0, pnnz = 0;
+  sdm_int nden = 0, dznnz = 0, pnnz = 0, mrows = 0;
   bool active = false, factored = false;
+  bool tables_on_host = false;                    // betajc / permoff / dopiv below mirror the device tables of the last factorisation
   std::vector<sdm_int> LADjc, LADir, dzjc, dzir, colperm, first;
   std::vector<int64_t> poff, betajc, permoff;
   std::vector<int> dopiv;
-  std::vector<std::vector<int>> later;            // per factor k: the later columns its inverse is applied to (first <= k)
+  std::vector<int> later_ptr;                     // per factor k: the later columns its inverse is applied to (first <= k), d_later[later_ptr[k] ..)
   DevBuf<int> d_dzir, d_colperm, d_pivperm, d_dopiv, d_later;
   DevBuf<int64_t> d_dzjc, d_poff, d_betajc, d_permoff;
   DevBuf<double> ad, lad, wvb, p, beta, dgat, smult, dden;
-  HostFlag need_host;                             // raised by k_dpr1_factor: a column needs the general (host) path
+  DevBuf<double> w_psq, w_mu, w_key;              // scratch of k_dpr1_general
+  DevBuf<int> w_ord, w_ord2, w_acc, w_post, w_dep, w_st;
 };
 }  // namespace sdm
 
@@ -434,12 +436,10 @@ void pcg_psdscale(sdm_plan *P, int transp, bool with_perm);
 void dense_set(sdm_plan *P, sdm_int nden, const sdm_int *LADjc, const sdm_int *LADir, const sdm_int *dzjc, const sdm_int *dzir,
                const sdm_int *colperm, const sdm_int *first);
 void dense_factor(sdm_plan *P, const double *smult, double maxuden, int *host_fallback);
+void dense_tables(DensePlan &D, sdm_int m, sdm_int nden, const sdm_int *dzjc, const sdm_int *dzir, const sdm_int *colperm, const sdm_int *first);
+void dense_prodformfact(sdm_plan *P, hipStream_t st, DensePlan &D, const double *smult, double maxu);   // the product-form factorisation on the device
+void dense_fetch_tables(hipStream_t st, DensePlan &D);
 void dense_prodform(sdm_plan *P, double *y, bool with_divide);       // y <- bwdpr1(Lden, fwdpr1(Lden, y) ./ Ld)   (permuted order)
-// sdm_dense.hip
-void dpr1fact_host(sdm_int m, sdm_int n, const sdm_int *Xjc, const sdm_int *Xir, const double *Xpr, double *lab,
-                   const sdm_int *dzjc, const sdm_int *dzir, const sdm_int *colperm, const sdm_int *firstpiv,
-                   const double *smult, double maxu, std::vector<sdm_int> &betajc, std::vector<double> &beta,
-                   std::vector<double> &p, std::vector<sdm_int> &pivperm, std::vector<int> &ordered);
 // sdm_capi.hip: gateway-shaped plans -- what ONE getada gateway needs (tier 1 builds one per call, sdm_mexcache.hip keeps them)
 void gw_upload_invperm(DevBuf<int> &buf, const sdm_int *perm, sdm_int m);
 void gw_build_getada1(sdm_plan *p, sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const sdm_int *Ajc, const sdm_int *Air,

@@ -159,7 +159,7 @@ class Plan:
 
     def deninfac(self, smult, maxuden=500.0):
         """LAD = L \\ Ad(perm,:), Lden = dpr1fact(LAD, L.d, symLden, smult, maxuden) on the device (upload "ad" first).
-        Returns True when the general host algorithm had to take over (postponed pivots, dependent rows, ...)."""
+        Returns False (earlier versions: True when a host algorithm had to take over; the whole of dpr1fact runs on the device now)."""
         sm = f64(smult)
         fb = C.c_int(0)
         check(self._lib.sdm_plan_deninfac(C.c_void_p(self._p), pf(sm), C.c_double(float(maxuden)), C.byref(fb)))

@@ -382,12 +382,15 @@ def stage1_flops(P):
     return tot
 
 
-def measure_config(name, device, steps, warmup, nprof, mex_units=0):
-    """One of the other BASELINE configs, measured briefly in this process: ms/unit, dominant kernel, solve rate."""
+def measure_config(name, device, steps, warmup, nprof, mex_units=0, growth_max=None):
+    """One of the other BASELINE configs, measured briefly in this process: ms/unit, dominant kernel, solve rate.  growth_max: the
+    bound beyond which a super-block of the solves falls back to substitution (0 = every block substitutes)."""
     try:
         t0 = time.perf_counter()
         P, L, ADA, Q, d, ud, rhs, qpr, note = build_workload(name, 0)
         plan = make_plan(device, P, L, ADA, Q, d, ud, rhs, qpr)
+        if growth_max is not None:
+            plan.set_growth_max(growth_max)
         plan._xsuper = np.asarray(L["xsuper"]).ravel().astype(np.int64)
         step = unit_fn(plan)
         el = time_steps(plan, step, steps, warmup)
@@ -403,6 +406,8 @@ def measure_config(name, device, steps, warmup, nprof, mex_units=0):
                "solve": phases["solve"], "factor": phases["factor"], "setup_s": time.perf_counter() - t0 - el}
         if mexleg is not None:
             out["mex_inclusive"] = mexleg
+        if growth_max is not None:
+            out["workload"] = f"{name} (solves with growth_max = {growth_max:g}: the other side of the explicit-inverse / substitution cliff)"
         plan.close()
         return out
     except Exception as e:  # never break the bench line
@@ -729,6 +734,9 @@ def main():
                 for nm, st, wu, npf, mxu in (("control07_init", 100, 5, 20, 0), ("arch0", 100, 5, 20, 0), ("arch0_init", 100, 5, 20, 0), ("nb", 100, 5, 20, 0),
                                              ("nb_init", 100, 5, 20, 0), ("maxcut4000", 10, 2, 5, 2), ("blockdiag", 20, 3, 10, 0)):
                     others.append(measure_config(nm, local_rank, st, wu, npf, mxu))
+                # the headline scaling sits just under the growth bound of the explicit inverses (max_growth 9.6e3 against 1e4): the same unit
+                # with every super-block on the substitution path
+                others.append(measure_config("control07", local_rank, 100, 5, 20, 0, growth_max=0.0))
         mult = 1 if (shard_cols or world == 1) else world
         out = {
             "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": mult * args.steps / elapsed, "unit": "IPM iters/s",

@@ -28,6 +28,10 @@
 
 namespace sdm {
 
+#ifndef SDM_EMU
+__global__ void k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, double *lb, const double *ubp, int *pivstat,
+                            double *pivval, const PanelCtx *ctx, int *front_cnt, int *diag_cnt, int phase, int step, int tile_wg0, int *tmo);
+#endif
 // ============================================================ host analysis
 void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm,
                 sdm_int nsuper, const sdm_int *xsuper, const sdm_int *ADAjc, const sdm_int *ADAir) {
@@ -186,6 +190,15 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
     ncu = 1 << 20;
 #else
     SDM_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, P->device));
+    {
+      // the launch is sized from what the runtime says fits: workgroups of k_ldl_front per compute unit at its LDS and register
+      // footprint (1 on gfx950: 135 KB of LDS) -- 0 means the kernel cannot be resident on this device at all (a partition with
+      // less LDS, a debugger's reservation): no level takes the one-launch path then
+      int per_cu = 0;
+      SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FRONT_LDS));
+      SDM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_ldl_front, LDL_THREADS, FRONT_LDS));
+      if (per_cu < 1) ncu = 0;
+    }
 #endif
     const int wg_budget = std::min(224, ncu - ncu / 8);                // leave an eighth of the device to whatever else is running
     for (int l = 0; l < nlev; l++) {
@@ -708,7 +721,7 @@ __device__ __forceinline__ void front_wait_updates(const int *upd_done, int pane
 // Wavefront 0, one sweep: sweep s (columns c0 = s*SW ..) is final and sits in xs (unscaled); the next SW columns cn .. are
 // brought up to date with it (look-ahead), swept in registers (lane = row; pivots and multipliers by v_readlane), written
 // back to S / Lc, and the bookkeeping of their pivots is done in the pivots' own lanes.
-__device__ __forceinline__ void diag_sweep_w0(double (*S)[NB + 1], double *Lc, int s, bool lookahead, double (&xs)[SW], double mylb, int tx, int kb, int k0, int ms,
+__device__ __forceinline__ void diag_sweep_w0(double (*S)[NB + 1], double *Lc, int s, double (&xs)[SW], double mylb, int tx, int kb, int k0, int ms,
                                               double ub, double *ds, int *stt, double *pv, int *badflag_p) {
   SDM_FP_STRICT;
   int &badflag = *badflag_p;
@@ -717,7 +730,7 @@ __device__ __forceinline__ void diag_sweep_w0(double (*S)[NB + 1], double *Lc, i
       SDM_PHASE_BEGIN();
 #pragma unroll
       for (int cc = 0; cc < SW; cc++) x[cc] = S[tx][cn + cc];
-      if (lookahead) {
+      if (s >= 0) {
         // look-ahead: the columns of the next sweep receive sweep s here (x_rj -= l_jk * x_rk, k ascending)
         // (multipliers fetched in two batches of SW/2 columns, all loads of a batch in flight before the first use)
 #pragma unroll
@@ -794,59 +807,6 @@ __device__ __forceinline__ void diag_trail(double (*S)[NB + 1], const double *Lc
       }
 }
 
-// ---- the OPTIMISTIC form of the diagonal block's LDL' (full 64 x 64 blocks; ldl_diag_block runs it first).  Almost every block an
-// interior-point iteration factors has all 64 pivots far above their thresholds: accepted, no column probe.  For such a block the
-// pivot rule of cholonBlk (blkchol2.c:114-161) decides nothing, and the bit-faithful sweep below -- one IEEE division, one multiply
-// and one subtract per entry in the reference's order, 185 dependent clocks per pivot plus the look-ahead wavefront 0 issues itself --
-// buys nothing either: the reference's own values are only defined up to the summation order of its BLAS.  So the block
-// is first factored 16 columns at a time with NO test on the chain: wavefront 0 sweeps a 16-column group in registers (lane = row;
-// the pivot's reciprocal from v_rcp_f64 + two Newton steps instead of the division's fix-up sequence, fused multiply-adds), the
-// other wavefronts apply the group to the rest of the block as 16 x 16 tiles on the FP64 matrix cores, and the group's 16 pivots
-// are compared with their thresholds in one step AFTERWARDS -- with a margin of 2^10 eps x the entry's value at block start, well
-// above the rounding distance between this arithmetic and the reference's (64 terms).  A group with a pivot inside the margin is
-// not written: the bit-faithful sweeps take over from that group's first column, on a block that is up to date through the groups
-// before it (rank-deficient blocks, skipped / added pivots: decisions exactly as before).  Groups that passed are published as
-// they are; nothing published is ever recomputed.
-__device__ __forceinline__ bool opt_sweep16(double (*S)[NB + 1], double *Lc, int g, int tx, double mylb, double marg, double ub, bool no_rows_below, double *ds) {
-  const int cb = 16 * g;
-  double x[16], lsc[16];
-#pragma unroll
-  for (int c = 0; c < 16; c++) x[c] = S[tx][cb + c];
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const double xkk = sdm_bcast_lane(x[k], cb + k);
-    const double l = x[k] * sdm_recip(xkk);
-#pragma unroll
-    for (int j = k + 1; j < 16; j++) x[j] = fma(-sdm_bcast_lane(l, cb + j), x[k], x[j]);
-    lsc[k] = l;
-  }
-  const bool mine = tx >= cb && tx < cb + 16;                        // the pivot of this lane's own row belongs to the group
-  double pval = x[0];
-#pragma unroll
-  for (int k = 1; k < 16; k++) pval = (tx == cb + k) ? x[k] : pval;
-  const bool clear = pval > mylb + marg && (no_rows_below || pval >= ub + marg);      // (NaN: not clear)
-  if (sdm_wave_any(mine && !clear)) return false;
-#pragma unroll
-  for (int k = 0; k < 16; k++) { Lc[(cb + k) * NB + tx] = lsc[k]; S[tx][cb + k] = x[k]; }
-  if (mine) ds[tx] = pval;
-  return true;
-}
-// tile (I, J), I >= J > g, of the block behind group g:  C -= U(rows I, columns of g) Lsc(rows J, columns of g)'  on the matrix cores
-// (U = the unscaled swept columns in S, Lsc = the multipliers in Lc); one wavefront
-__device__ __forceinline__ void opt_tile16(double (*S)[NB + 1], const double *Lc, int g, int I, int J, int lane) {
-  const int li = lane & 15, lk = lane >> 4;
-  sdm_double4 acc;
-#pragma unroll
-  for (int r = 0; r < 4; r++) acc[r] = S[16 * I + lk + 4 * r][16 * J + li];
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int k = 16 * g + 4 * q + lk;
-    acc = SDM_MFMA_F64_16x16x4(-S[16 * I + li][k], Lc[k * NB + 16 * J + li], acc);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; r++) S[16 * I + lk + 4 * r][16 * J + li] = acc[r];
-}
-
 // columns 16 g .. 16 g + 15 of the factored block into its transposed copy DT, one wavefront, lane = row: a row's 16 entries are
 // contiguous there (128 bytes), so they go out as eight 16-byte write-through stores -- full fabric writes -- instead of one
 // 8-byte write per lane and column (the publication lagged the sweeps by 4-5 us per group that way: profiles/r03k).  The pivot
@@ -888,7 +848,7 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
   double *Lc = RB;                                                // Lc[k*NB+i] = l_ik
   __shared__ double lbs[NB], pv[NB];
   __shared__ int stt[NB];
-  __shared__ int badflag, optfail;
+  __shared__ int badflag;
   __shared__ double red_v[LDL_THREADS];
   __shared__ int red_i[LDL_THREADS];
   const int ns = fd.ns, ms = fd.ms, ld = fd.ld, first = fd.first;
@@ -911,76 +871,23 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
     }
   }
   if (tid < NB) { lbs[tid] = lbs_pre ? lbs_pre[tid] : (tid < kb ? lb[first + k0 + tid] : 0.0); ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
-  if (tid == 0) { badflag = 0; *npub = 0; optfail = 0; }
+  if (tid == 0) { badflag = 0; *npub = 0; }
   SDM_PHASE_BEGIN();
   __syncthreads();
   const double ub = fd.ub;                                           // max diagonal (k_prep_pivots) / maxu^2; (k_ldl_panel: written just before this block)
   SDM_PHASE(16);
   if (PERSIST) SDM_TRACE(16 * panel + 0);                              // D: sweeps start
-  // ---- optimistic pass (see opt_sweep16): groups 0 .. g_done-1 of a full block are final, in S / Lc / ds and -- when this block
-  // publishes -- in DT, behind it
-  int g_done = 0, opt_issued = 0, opt_signalled = 0;
-#ifndef SDM_NO_OPT_DIAG
-  if (kb == NB && pub_skip == 0) {
-    double *Dsp = DT + toff_s + (int64_t)panel * NB * NB;
-    const double raw = S[tx][tx];                                      // the pivot's entry as the block starts: scale of the margin
-    const double marg = 0x1p-42 * fabs(raw);                           // 2^10 eps
-    const double mylb = lbs[tx];
-    for (int g = 0; g < 4; g++) {
-      if (ty == 0) {
-        SDM_SETPRIO(3);
-        if (!opt_sweep16(S, Lc, g, tx, mylb, marg, ub, ms - (k0 + tx) <= 1, ds) && tx == 0) optfail = 1;
-        SDM_SETPRIO(0);
-      } else if (ty == ny - 1 && publish && !PERSIST && opt_issued > opt_signalled) {
-        SDM_STORES_DONE();                                             // group g-1 went out during the previous tile phase
-        if (tx == 0) sdm_signal_add(&diag_cnt[s]);
-        opt_signalled = opt_issued;
-      }
-      __syncthreads();
-      if (optfail) break;
-      g_done = g + 1;
-      if (ty >= 1 && ty < ny - 1) {                                    // the block behind the group: (3-g)(4-g)/2 tiles, one per wavefront
-        const int R = 3 - g, t = ty - 1;
-        if (t < R * (R + 1) / 2) { int I, J; tile_index(t, I, J); opt_tile16(S, Lc, g, g + 1 + I, g + 1 + J, tx); }
-      } else if (ty == ny - 1 && publish) {                            // the group is final: out it goes (DT, d), write-through
-        publish_group(Dsp, Lc, ds, g, tx);
-        if (tx < 16) sdm_store_wt(&d[first + k0 + 16 * g + tx], ds[16 * g + tx]);
-        opt_issued = g + 1;
-      }
-      __syncthreads();
-    }
-    if (ty == ny - 1 && publish && opt_issued > opt_signalled && g_done == 4) {       // (with groups left the publisher below counts them)
-      SDM_STORES_DONE();
-      if (tx == 0) sdm_signal_add(&diag_cnt[s], opt_issued - opt_signalled);
-      opt_signalled = opt_issued;
-    }
-    if (tid == 0 && g_done == 4) *npub = publish ? 4 : 0;
-    if (g_done > 0 && g_done < 4) {
-      // the bit-faithful sweeps continue from here; should one of their pivots ask for the column probe, the general path below
-      // redoes the columns from 16 g_done on -- from THIS state of the block, which therefore replaces the raw copy it reloads
-      for (int j = 16 * g_done + ty; j < NB; j += ny)
-        if (tx >= j) {
-          if (raw_in_lds) ((double *)smem)[FRONT_CV_OFF + j * TILE + tx] = S[tx][j];
-          else Fs[(int64_t)(k0 + j) * ld + k0 + tx] = S[tx][j];
-        }
-      __syncthreads();
-    }
-  }
-#endif
   // ---- LDL' of the block (see the header): wavefront 0 sweeps SW columns in registers while the other wavefronts
   // apply the previous sweep to the trailing columns.  The sweep is straight-line code: a skipped pivot gives the
   // multiplier 0, a pivot that needs the probe only raises `bad` (everything computed after it is discarded: the
   // block is redone by the general path), the bookkeeping of pivot gc lives in lane gc.
   const int nsw = (kb + SW - 1) / SW;
-  const int s_first = (16 / SW) * g_done - 1;                          // the sweeps start behind the groups the optimistic pass finished (-1: from scratch)
-  if (g_done == 4) {
-    if (PERSIST && ty == 0) SDM_TRACE(16 * panel + 1);
-  } else if (ty == 0) {
+  if (ty == 0) {
     SDM_SETPRIO(3);
     const double mylb = lbs[tx];
     double xs[SW];                                                     // columns of the sweep just finished (unscaled)
-    for (int s = s_first; s < nsw - 1; s++) {
-      diag_sweep_w0(S, Lc, s, s > s_first, xs, mylb, tx, kb, k0, ms, ub, ds, stt, pv, &badflag);
+    for (int s = -1; s < nsw - 1; s++) {
+      diag_sweep_w0(S, Lc, s, xs, mylb, tx, kb, k0, ms, ub, ds, stt, pv, &badflag);
       SDM_PHASE(17);
       __syncthreads();
       SDM_PHASE(19);
@@ -988,8 +895,8 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
     SDM_SETPRIO(0);
     if (PERSIST) SDM_TRACE(16 * panel + 1);                            // D: sweeps end
   } else if (ty < ny - 1) {
-    __syncthreads();                                                   // first sweep
-    for (int s = s_first + 1; s < nsw - 1; s++) {
+    __syncthreads();                                                   // sweep 0
+    for (int s = 0; s < nsw - 1; s++) {
       diag_trail(S, Lc, s, kb, tx, ty - 1, ny - 2);
       SDM_PHASE(18);
       __syncthreads();
@@ -1001,9 +908,9 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
     // sweep on in which a pivot asked for the probe (the block is redone by the general path; what was published
     // before is what the general path computes again).
     double *Dsp = DT + toff_s + (int64_t)panel * NB * NB;
-    int issued = pub_skip + opt_issued, signalled = pub_skip + opt_signalled;
-    __syncthreads();                                                   // first sweep
-    for (int sw = s_first + 1; sw < nsw - 1; sw++) {
+    int issued = pub_skip, signalled = pub_skip;
+    __syncthreads();                                                   // sweep 0
+    for (int sw = 0; sw < nsw - 1; sw++) {
       if (publish) {
         // (k_ldl_front: the row workgroups read the data-tagged DT itself; the count is for consumers off the chain -- the follower,
         // the column probe -- and goes up behind the last sweep: no acknowledgement wait inside the sweeps, whose barrier it would hold)
@@ -1040,14 +947,13 @@ __device__ __forceinline__ bool ldl_diag_block(char *smem, double *F, double *DT
       if (PERSIST) front_wait_updates(upd_cnt, panel, (ms + TILE - 1) / TILE, tmo);
       else wait_prev_update(upd_cnt + s, ns, ms, panel, q0, tmo);
     }
-    const int kstart = 16 * g_done;                                  // (columns before it: final, from the optimistic pass)
-    for (int j = kstart + ty; j < NB; j += ny) {
+    for (int j = ty; j < NB; j += ny) {
       const double raw = raw_in_lds ? ((const double *)smem)[FRONT_CV_OFF + j * TILE + tx] : Fs[(int64_t)(k0 + min(j, kb - 1)) * ld + k0 + min(tx, kb - 1)];
       S[tx][j] = (tx < kb && j <= tx) ? raw : 0.0; Lc[j * NB + tx] = 0.0;
     }
-    if (tid < NB && tid >= kstart) { ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
+    if (tid < NB) { ds[tid] = 0.0; stt[tid] = 0; pv[tid] = 0.0; }
     __syncthreads();
-    for (int k = kstart; k < kb; k++) {
+    for (int k = 0; k < kb; k++) {
       double xkk = S[k][k];
       if (xkk > lbs[k]) {
         if (ms - (k0 + k) > 1 && xkk < ub) {                         // rare: stability probe of the never-fail rule

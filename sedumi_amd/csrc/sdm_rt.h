@@ -19,10 +19,6 @@ inline double sdm_bcast_lane(double v, int lane) { return emu_shfl(v, lane, 0); 
 #define SDM_SETPRIO(n) do {} while (0)
 // predicate of lane `lane` (uniform), delivered to every lane
 inline bool sdm_lane_pred(bool pred, int lane) { return emu_shfl(pred ? 1.0 : 0.0, lane, 0) != 0.0; }
-// true in every lane iff the predicate holds in any lane of the wavefront
-inline bool sdm_wave_any(bool pred) { double v = pred ? 1.0 : 0.0; for (int o = 32; o > 0; o >>= 1) { const double t = emu_shfl(v, o, 2); v = t > v ? t : v; } return v != 0.0; }
-// 1 / x to working precision for the optimistic diagonal block (the device forms it from v_rcp_f64 and two Newton steps)
-inline double sdm_recip(double x) { return 1.0 / x; }
 // completion counters and published data between workgroups of one launch.  The emulator runs workgroups one after the other --
 // or, for a launch whose workgroups wait for each other (emu_launch_concurrent), as processes side by side over shared memory:
 // hence real atomics, volatile accesses and fences here (x86-64: aligned 8-byte accesses are single copies, stores stay in order)
@@ -90,15 +86,6 @@ __device__ __forceinline__ void sdm_raise_flag(int *p) { __hip_atomic_store(p, 1
 #define SDM_COMPILER_BARRIER() asm volatile("" ::: "memory")
 // predicate of lane `lane` (uniform), delivered to every lane: one compare into a lane mask, one scalar bit test
 __device__ __forceinline__ bool sdm_lane_pred(bool pred, int lane) { return (__ballot(pred) >> lane) & 1ull; }
-__device__ __forceinline__ bool sdm_wave_any(bool pred) { return __ballot(pred) != 0ull; }
-// 1 / x to working precision without the IEEE division's fix-up sequence: v_rcp_f64 and two Newton steps (4 dependent FMAs;
-// x normal and finite here -- a pivot of the optimistic diagonal block, checked against its thresholds afterwards)
-__device__ __forceinline__ double sdm_recip(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return r;
-}
 // v_readlane_b32 x2: a scalar broadcast, no LDS crossbar round trip (ds_bpermute) on the dependency chain
 __device__ __forceinline__ double sdm_bcast_lane(double v, int lane) {
   union { double d; int i[2]; } u;

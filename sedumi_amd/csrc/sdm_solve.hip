@@ -42,6 +42,10 @@ constexpr int GRPW = 1024;       // columns (forward) / rows (backward) of a sla
 
 // ---------------------------------------------------------------- host tables
 static void follow_decide(sdm_plan *P);
+#ifndef SDM_EMU
+__global__ void k_sinv_follow(const double *F, const double *DT, double *S, double *STr, FrontTab tab, const int *list, int *front_cnt, const int *diag_cnt,
+                              unsigned long long *sb_g, int *tmo);
+#endif
 void solve_build(sdm_plan *P) {
   CholPlan &C = P->chol;
   const int nsuper = (int)C.nsuper;
@@ -160,6 +164,13 @@ static void follow_decide(sdm_plan *P) {
   int ncu = 1 << 20;
 #ifndef SDM_EMU
   SDM_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, P->device));
+  {
+    // (one workgroup of either kernel per compute unit is what the count below assumes: the follower must fit at least that)
+    int per_cu = 0;
+    SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_sinv_follow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS));
+    SDM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_sinv_follow, ST, TILE_LDS));
+    if (per_cu < 1) return;
+  }
 #endif
   for (int l = 0; l < C.nlevels; l++) {
     if (!C.lev_persist[l]) return;

@@ -15,6 +15,9 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if ((f = mxGetField(P, 0, "canceltol"))) pars.canceltol = mxGetScalar(f);
     if ((f = mxGetField(P, 0, "maxu"))) pars.maxu = mxGetScalar(f);
     if ((f = mxGetField(P, 0, "abstol"))) { pars.abstol = mxGetScalar(f); if (pars.abstol < 0) pars.abstol = 0; }
+    // pars.delay = 1 (blkchol.c:307-308, 402-414: skipped columns handed back as they were before their pivot, for a pivot-delaying
+    // caller; no .m file of SeDuMi sets it) is not implemented: said loudly instead of returning unit columns under that name
+    if ((f = mxGetField(P, 0, "delay")) && (char)mxGetScalar(f) == 1) mexErrMsgTxt("blkchol: pars.delay = 1 is not supported by libsedumi_hip (skipped columns are returned as unit vectors, pars.delay = 0).");
     if (nrhs >= 4) { if ((sdm_int)numel(prhs[3]) != L.m) mexErrMsgTxt("absd size mismatch"); absd = mxGetPr(prhs[3]); }
   }
   const sdm_int m = L.m, nnzL = L.jc[m];

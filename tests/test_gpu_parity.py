@@ -512,14 +512,26 @@ def test_getada_gateway_nb_example_on_gpu():
         assert relerr(y.ravel(), z[f"{tag}_y"]) < TOL
 
 
-@pytest.mark.parametrize("m,n,ndense,seed,zero_d,maxuden,expect_host", [(120, 900, 6, 2, 0, 500.0, False), (90, 700, 4, 3, 2, 500.0, True),
-                                                                        (80, 600, 5, 4, 0, 1.5, True), (2000, 20000, 8, 1, 0, 500.0, False)])
+@pytest.mark.parametrize("m,n,ndense,seed,zero_d,maxuden,expect_host", [(120, 900, 6, 2, 0, 500.0, False), (90, 700, 4, 3, 2, 500.0, False),
+                                                                        (80, 600, 5, 4, 0, 1.5, False), (110, 800, 5, 13, 3, 3.0, False),
+                                                                        (110, 800, 5, 16, 2, 1.0, False), (2000, 20000, 8, 1, 0, 500.0, False),
+                                                                        (2000, 20000, 8, 2, 4, 1.2, False)])
 def test_resident_dense_column_unit_on_gpu(refmex, glue, m, n, ndense, seed, zero_d, maxuden, expect_host):
     """The dense-column leg of the iteration unit resident on the plan: batched sparse-RHS forward
-    solves, dpr1fact as device scans (general cases through the host algorithm), and the whole wrapPcg.m:56-59 body,
-    against the reference chain -- incl. the synthetic config-3 variant LP m=2000, N=20000, 8 dense columns."""
-    from test_dense_columns import check_resident_dense_unit, dense_case
-    check_resident_dense_unit(refmex, dense_case(refmex, glue, m, n, ndense, seed, zero_d, maxuden), expect_host)
+    solves, dpr1fact on the device -- postponed pivots (maxuden close to 1), dependent rows (zero_d) and their sort included:
+    no host algorithm exists any more (expect_host False everywhere) -- and the whole wrapPcg.m:56-59 body, against the
+    reference chain; incl. the synthetic config-3 variant LP m=2000, N=20000, 8 dense columns, also with postponed pivots."""
+    from test_dense_columns import check_dense_case, check_resident_dense_unit, dense_case
+    c = dense_case(refmex, glue, m, n, ndense, seed, zero_d, maxuden)
+    if m <= 200:
+        check_dense_case(refmex, c)                                    # the stateless entry points (dpr1fact.mex's path) on the same case
+    check_resident_dense_unit(refmex, c, expect_host)
+
+
+@pytest.mark.parametrize("seed,which", [(21, 0), (23, 1)])
+def test_dpr1fact_negative_multiple_on_gpu(refmex, glue, seed, which):
+    from test_dense_columns import test_dpr1fact_with_a_negative_multiple
+    test_dpr1fact_with_a_negative_multiple(refmex, glue, seed, which)
 
 
 @pytest.mark.parametrize("case", range(4))

@@ -1721,7 +1721,6 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
   CholPlan &C = P->chol;
   hipStream_t st = P->stream;
   FrontTab tab = front_tab(C);
-  const int m = (int)C.m;
   const bool follow = C.follow;
   for (int l = std::max(l0, 0); l < std::min(l1, C.nlevels); l++) {
     const int *list = C.d_levlist.p + C.levptr[l];

@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(DT)
 k_dpr1_general(Dpr1G G) {
   __shared__ double sa[DT], sb[DT];
   __shared__ int si[DT];
-  __shared__ int s_n, s_idep, s_deldep, s_caseB, s_changed;
+  __shared__ int s_idep, s_deldep, s_caseB, s_changed;
   __shared__ double s_h;
   const int tid = threadIdx.x, k = G.k, mk = G.mk;
   const double *p = G.p;

@@ -315,7 +315,7 @@ def profile_unit(plan, P, ud, nprof):
                                                           "source": "profiles/" + os.path.basename(pmcs[-1]) + " (rocprofv3 PMC passes of an earlier run of this command, not measured in this run)"}
             except Exception:
                 pass
-    nlaunch = sum(v[0] for k, v in prof.items() if k.startswith("k_sfw") or k.startswith("k_sbw") or k.startswith("k_solve_chain")) / max(1, nprof * NSOLVE)
+    nlaunch = sum(v[0] for k, v in prof.items() if k.startswith("k_sfw") or k.startswith("k_sbw")) / max(1, nprof * NSOLVE)
     t_solve = ph[2] / NSOLVE * 1e-3
     nb, nbad, growth = plan.solve_stats()
     phases = {"ada_ms": ph[0], "factor_ms": ph[1], "solves_ms": ph[2],

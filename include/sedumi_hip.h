@@ -364,11 +364,6 @@ int sdm_plan_set_growth_max(sdm_plan *p, double growth_max);
  * and tools (both paths produce the same bits); also what a caller sharing the device between processes wants (all
  * workgroups of a one-launch level must be resident at once). */
 int sdm_plan_set_one_launch_fronts(sdm_plan *p, int on);
-/* on = 0: sdm_plan_ldlsolve of a single-front factor runs its sweeps as one launch per stage (the form every other factor takes)
- * instead of ONE persistent launch (k_solve_chain: stages chained by counters, the next stage's rows prefetched across each
- * hand-over).  Default 1; takes effect at the next solve.  Comparison switch of tests and tools (the two forms split each row sum
- * differently: results agree to rounding). */
-int sdm_plan_set_one_launch_solves(sdm_plan *p, int on);
 int sdm_plan_set_solve_width(sdm_plan *p, sdm_int width);
 int sdm_plan_get_solve_width(sdm_plan *p, sdm_int *width);      /* the width in force (after sdm_plan_set_chol) */
 int sdm_plan_solve_stats(sdm_plan *p, sdm_int *nblocks, sdm_int *nbad, double *max_growth);

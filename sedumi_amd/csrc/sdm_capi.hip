@@ -323,11 +323,6 @@ int sdm_plan_set_one_launch_fronts(sdm_plan *p, int on) {
   p->chol.front_off_req = !on;
   SDM_CATCH
 }
-int sdm_plan_set_one_launch_solves(sdm_plan *p, int on) {
-  SDM_TRY
-  p->chol.chain_on = on != 0;
-  SDM_CATCH
-}
 int sdm_plan_set_solve_width(sdm_plan *p, sdm_int width) {
   SDM_TRY
   if (width != 0 && (width < sdm::SBW_MIN || width > sdm::SBW_MAX || (width & (width - 1)) != 0))

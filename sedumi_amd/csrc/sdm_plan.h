@@ -146,9 +146,6 @@ struct SolveLevel {
   std::vector<int> slabs_fw;                         // grid.x of the forward step launch behind super-block P (0: none)
 };
 
-// one stage of the one-launch solve of a single-front factor (k_solve_chain, sdm_solve.hip)
-struct ChainStage { int kind, P, nrows, pad; };   // kind 0: forward diagonal block P, 1: forward rows behind block P, 2: backward diagonal block P, 3: backward step of block P
-
 struct CholPlan {
   sdm_int m = 0, nsuper = 0, nnzL = 0, nnzADA = 0;
   int nlevels = 0;
@@ -205,10 +202,6 @@ struct CholPlan {
   std::vector<int> lev_followT;      // grid.x of k_sinv_follow per level: tiles of the inverse of its widest front
   std::vector<int> stage_ptr;        // combine tiles of stage st (= 2 * level + (0: T, 1: X)) are l_items[stage_ptr[st] .. stage_ptr[st+1])
   std::vector<SolveLevel> slev;
-  // one-launch solve (k_solve_chain): plans whose factor is ONE dense front (the shipped examples, MAXCUT) run fw, ./d, bw as one
-  // persistent launch -- stages chained by counters, the next stage's rows of the inverse blocks prefetched across each hand-over
-  bool chain_ok = false, chain_on = true; int chain_nst = 0, chain_wgs = 0, chain_nvec = 0;   // chain_on: sdm_plan_set_one_launch_solves (comparison switch of tests and tools)
-  DevBuf<ChainStage> d_chain; DevBuf<double> chain_vecs;   // stage list; two sets of tagged hand-over vectors (k_solve_chain)
   double growth_max = 1e4;           // a super-block whose max|inv| * max|L| exceeds this is solved by substitution
   double growth_used = 1e4;          // the bound in force at the last solve_prepare
 };

@@ -34,7 +34,6 @@ inline unsigned long long sdm_load_wt_u64(const unsigned long long *p) { return 
 inline int sdm_signal_load(const int *p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 inline void sdm_raise_flag(int *p) { __atomic_store_n(p, 1, __ATOMIC_SEQ_CST); emu_report_timeout(); }
 #define SDM_UNIFORM_INT(x) (x)
-#define SDM_LDS_BARRIER() __syncthreads()
 #define SDM_ACQUIRE_FENCE() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define SDM_COMPILER_BARRIER() __asm__ __volatile__("" ::: "memory")
 #define SDM_SPIN_PAUSE() emu_spin_pause()
@@ -79,11 +78,6 @@ __device__ __forceinline__ int sdm_signal_load(const int *p) { return __hip_atom
 // error flag in pinned host memory (HostFlag): one system-scope store, read by the host after a stream synchronise
 __device__ __forceinline__ void sdm_raise_flag(int *p) { __hip_atomic_store(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 #define SDM_ACQUIRE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
-// workgroup barrier for data exchanged through LDS ONLY: this wavefront's LDS operations have completed (lgkmcnt(0)); its global
-// loads and stores may still be in flight.  __syncthreads() carries a workgroup release that drains them as well (s_waitcnt
-// vmcnt(0) before s_barrier): a kernel that keeps loads in flight ACROSS a barrier on purpose (k_solve_chain's prefetch of the
-// next stage) must not use it
-#define SDM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // a wave-uniform integer the compiler cannot prove uniform (e.g. threadIdx.x >> 6): moved to a scalar register, so that
 // addresses built from it stay scalar and loads through them become s_load
 #define SDM_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane(x)

@@ -42,7 +42,6 @@ constexpr int GRPW = 1024;       // columns (forward) / rows (backward) of a sla
 
 // ---------------------------------------------------------------- host tables
 static void follow_decide(sdm_plan *P);
-static void chain_build(sdm_plan *P);
 #ifndef SDM_EMU
 __global__ void k_sinv_follow(const double *F, const double *DT, double *S, double *STr, FrontTab tab, const int *list, int *front_cnt, const int *diag_cnt,
                               unsigned long long *sb_g, int *tmo);
@@ -152,7 +151,6 @@ void solve_build(sdm_plan *P) {
     }
   }
   follow_decide(P);
-  chain_build(P);
 }
 
 // Can the inverses be built BEHIND the factorisation (k_sinv_follow)?  Every level must be a k_ldl_front level, every front
@@ -712,7 +710,7 @@ k_sinv_follow(const double *F, const double *DT, double *S, double *STr, FrontTa
 constexpr int BSC = 32;          // columns per step of the substitution fallback (its LDS tile: BSC x (BSC + 1) doubles)
 constexpr int BSP = BSC + 1;
 __device__ __noinline__ void block_solve_fw(const double *Fs, int ld, int k0, int nb, double *w, double *Sd) {
-  const int tid = threadIdx.x, lane = tid & 63, ST = (int)blockDim.x;    // (k_solve_chain calls it with 1024 work-items)
+  const int tid = threadIdx.x, lane = tid & 63;
   for (int kk = 0; kk < nb; kk += BSC) {
     const int kb = min(BSC, nb - kk);
     for (int e = tid; e < BSC * BSC; e += ST) {
@@ -735,7 +733,7 @@ __device__ __noinline__ void block_solve_fw(const double *Fs, int ld, int k0, in
   }
 }
 __device__ __noinline__ void block_solve_bw(const double *Fs, int ld, int k0, int nb, double *w, double *Sd) {
-  const int tid = threadIdx.x, lane = tid & 63, ST = (int)blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   for (int kk = ((nb - 1) / BSC) * BSC; kk >= 0; kk -= BSC) {
     const int kb = min(BSC, nb - kk);
     for (int e = tid; e < BSC * BSC; e += ST) {
@@ -1164,208 +1162,6 @@ k_sbw_step(const double *__restrict__ F, FrontTab tab, const int *list, double *
 }
 #undef FT
 
-// ================================================================ one launch per solve (single-front factors)
-// fw, ./d, bw of a factor that is ONE dense front (control07, arch0, nb, MAXCUT: SURVEY H1) as ONE persistent launch.  The sweeps
-// are the same row dots as above -- rows of ST (forward diagonal block), rows of LT (forward step), columns of S (backward diagonal
-// block), columns of the front (backward step) -- in the same order per sum, cut into stages; a stage needs the whole vector the
-// stage before it produced.  Hand-over by the DATA itself: every vector a stage produces is a buffer of its own (one per version
-// of the update vectors), filled with a quiet-NaN tag no computation produces before the solve; producers store write-through,
-// consumers poll the words they need until the tag is gone.  No counter, no wait for store acknowledgements: one trip across the
-// fabric per stage.  (With arrival counters -- stores acknowledged, count, poll the count, then fetch -- a hand-over measured
-// 7 - 8 us against 2 - 3 us for a kernel boundary: profiles/r04f_solves_*_chain_counters.jsonl.)  Two sets of buffers alternate
-// between solves; a solve re-arms the set the next one uses.  Every wavefront issues the loads of its rows of the NEXT stage (they
-// depend on nothing) before it polls, so the inverse blocks keep streaming from HBM while the hand-over is in flight.
-// Geometry: G workgroups of 1024 work-items, one per compute unit, all resident (bounded polls raise the plan's time-out flag).
-// A row belongs to a PAIR of wavefronts (halves of the row, at most 8 KB = eight 16-byte loads per lane each: W <= 2048), row i of
-// a stage to workgroup i mod G, pair (i / G) mod 8; the two partial sums meet in LDS and are added in a fixed order.
-constexpr int CT = 1024;                 // work-items per workgroup of k_solve_chain
-constexpr int CPAIRS = CT / 128;         // rows a workgroup has in flight
-constexpr unsigned long long CHAIN_TAG = 0x7ff8dead5ed00002ull;
-struct ChainArgs {
-  const double *F, *S, *STr, *LT;
-  int ns, ld, sld, first, sboff, W, nst, G, nsb, nvec;
-  int64_t foff, soff, ltoff;
-  const double *src; const int *perm; const double *dscale;
-  double *cv, *cv_next, *yout;           // this solve's set of tagged vectors (nvec x ns), the set to re-arm (both chosen in the kernel)
-  double *sets; unsigned long long *ticket;
-  const unsigned long long *sb_g; double thr;
-  int *tmo;
-};
-// the tagged vectors of a set, by local row: y (forward result), z (y ./ d), x (backward result), a_p = the update vector after
-// forward step p - 1 (p = 1 .. nsb-1), v_q = z after backward step q (q = 1 .. nsb-1)
-__device__ __forceinline__ double *chain_vec_y(const ChainArgs &A) { return A.cv; }
-__device__ __forceinline__ double *chain_vec_z(const ChainArgs &A) { return A.cv + (size_t)A.ns; }
-__device__ __forceinline__ double *chain_vec_x(const ChainArgs &A) { return A.cv + 2 * (size_t)A.ns; }
-__device__ __forceinline__ double *chain_vec_a(const ChainArgs &A, int p) { return A.cv + (size_t)(2 + p) * A.ns; }
-__device__ __forceinline__ double *chain_vec_v(const ChainArgs &A, int q) { return A.cv + (size_t)(1 + A.nsb + q) * A.ns; }
-__device__ __forceinline__ bool chain_is_tag(double v) { union { double d; unsigned long long u; } b; b.d = v; return b.u == CHAIN_TAG; }
-__device__ __forceinline__ double chain_tag() { union { double d; unsigned long long u; } b; b.u = CHAIN_TAG; return b.d; }
-__device__ __forceinline__ double chain_poll(const double *a, double v, int *tmo) {
-  for (long it = 0; chain_is_tag(v) && it < (1L << 21); it++) { SDM_SPIN_PAUSE(); v = sdm_load_wt(a); if (it + 1 == (1L << 21)) sdm_raise_flag(tmo); }
-  return v;
-}
-struct ChainRow { const sdm_double2 *M; int npair, len, jlo; };
-// matrix row of item i of stage (kind, P): 16-byte aligned start, length in doubles, first valid entry
-__device__ __forceinline__ ChainRow chain_row(const ChainArgs &A, int kind, int P, int i) {
-  ChainRow R;
-  const int c0 = P * A.W;
-  const double *M; int len, jlo = 0;
-  if (kind == 0) { M = A.STr + A.soff + (int64_t)c0 * A.sld + (int64_t)i * A.sld; len = i + 1; }
-  else if (kind == 1) { M = A.LT + A.ltoff + lt_boff(A.ns, A.W, P) + (int64_t)i * A.W; len = A.W; }
-  else if (kind == 2) { const int nb = min(A.W, A.ns - c0), ce = i & ~1; M = A.S + A.soff + (int64_t)c0 * A.sld + (int64_t)i * A.sld + ce; len = nb - ce; jlo = i - ce; }
-  else { const int nbq = min(A.W, A.ns - c0); M = A.F + A.foff + (int64_t)i * A.ld + c0; len = nbq; }
-  R.M = (const sdm_double2 *)M; R.len = len; R.jlo = jlo; R.npair = (len + 1) >> 1;
-  return R;
-}
-// the half of its row a wavefront owns (h = 0 / 1): eight 16-byte loads per lane, clamped inside the row
-__device__ __forceinline__ void chain_issue(const ChainRow &R, int h, int lane, sdm_double2 (&v)[8]) {
-  const int half = (R.npair + 1) >> 1, plo = h ? half : 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) v[k] = R.M[min(plo + lane + 64 * k, R.npair - 1)];
-}
-// the vector stage (kind, P) multiplies with (nullptr: the permuted right-hand side), and the value its output row io starts from
-__device__ __forceinline__ const double *chain_stage_vec(const ChainArgs &A, int kind, int P) {
-  const int c0 = P * A.W;
-  if (kind == 0) return P == 0 ? nullptr : chain_vec_a(A, P) + c0;
-  if (kind == 1) return chain_vec_y(A) + c0;
-  if (kind == 2) return (P == A.nsb - 1 ? chain_vec_z(A) : chain_vec_v(A, P + 1)) + c0;
-  return chain_vec_x(A) + c0;
-}
-__device__ __forceinline__ const double *chain_stage_base(const ChainArgs &A, int kind, int P, int io) {
-  if (kind == 1) return P == 0 ? nullptr : chain_vec_a(A, P) + (P + 1) * A.W + io;
-  if (kind == 3) return (P == A.nsb - 1 ? chain_vec_z(A) : chain_vec_v(A, P + 1)) + io;
-  return nullptr;
-}
-__global__ void k_fill_bits(unsigned long long *x, unsigned long long v, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = v;
-}
-__global__ void __launch_bounds__(CT)
-k_solve_chain(ChainArgs A, const ChainStage *stages, int only_stage) {
-  SDM_DYN_SMEM(smem);                                                  // the stage's vector (W doubles) + the rare substitution fallback (BSC * BSP)
-  __shared__ double part[2][CPAIRS][2];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, slot = wave >> 1, h = wave & 1;
-  const int wg = blockIdx.x, G = A.G;
-  double *xs = (double *)smem, *Sd = xs + A.W;
-  sdm_double2 v[8];                                                    // the wavefront's half row: loaded here, or already in flight from the stage before
-  bool have_pv = false;
-  int pb = 0;
-  const int s0 = only_stage >= 0 ? only_stage : 0, s1 = only_stage >= 0 ? only_stage + 1 : A.nst;
-  // which of the two sets: launches of one plan are serialised and have G workgroups each, so the arrival tickets of launch k are
-  // k G .. k G + G - 1 (a number kept on the device: a captured hipGraph replays the same arguments)
-  {
-    if (only_stage <= 0 && !(stages[0].kind == 0 && sb_is_bad(A.sb_g, A.sboff + stages[0].P, A.thr)) && wg + G * slot < stages[0].nrows) {
-      chain_issue(chain_row(A, stages[0].kind, stages[0].P, wg + G * slot), h, lane, v);       // (the first rows are on their way meanwhile)
-      have_pv = true;
-    }
-    __shared__ int s_set;
-    if (tid == 0) {
-      if (only_stage <= 0) { const unsigned long long t = atomicAdd(A.ticket, 1ull); s_set = (int)((t / (unsigned long long)G) & 1); if (only_stage == 0) A.ticket[1] = (unsigned long long)s_set; }
-      else s_set = (int)A.ticket[1];                                   // (the emulator's launch per stage: the set stage 0 chose)
-    }
-    __syncthreads();
-    const size_t setw = (size_t)A.nvec * A.ns;
-    A.cv = A.sets + (size_t)s_set * setw; A.cv_next = A.sets + (size_t)(s_set ^ 1) * setw;
-  }
-  if (s0 == 0) {                                                       // re-arm the set the NEXT solve uses (nobody reads it during this one)
-    const size_t tot = (size_t)A.nvec * A.ns;
-    for (size_t j = (size_t)wg * CT + tid; j < tot; j += (size_t)G * CT) A.cv_next[j] = chain_tag();
-  }
-  for (int s = s0; s < s1; s++) {
-    const ChainStage stg = stages[s];
-    const int kind = stg.kind, P = stg.P, n = stg.nrows, c0 = P * A.W;
-    const bool diag = kind == 0 || kind == 2;
-    const bool bad = diag && sb_is_bad(A.sb_g, A.sboff + P, A.thr);
-    const double *vec = chain_stage_vec(A, kind, P);
-    if (bad) {
-      // a block that failed the growth check: substituted against the factor by workgroup 0 (fwblkslv.c:109-114 / bwblkslv.c:113-122)
-      if (wg == 0) {
-        const int nb = min(A.W, A.ns - c0);
-        __syncthreads();
-        for (int c = tid; c < nb; c += CT) xs[c] = vec ? chain_poll(vec + c, sdm_load_wt(vec + c), A.tmo) : A.src[A.perm[A.first + c0 + c]];
-        __syncthreads();
-        if (kind == 0) {
-          block_solve_fw(A.F + A.foff, A.ld, c0, nb, xs, Sd);
-          for (int i = tid; i < nb; i += CT) {
-            const double yv = xs[i], dk = A.dscale[A.first + c0 + i];
-            sdm_store_wt(chain_vec_y(A) + c0 + i, yv);
-            sdm_store_wt(chain_vec_z(A) + c0 + i, yv / (dk > 0.0 ? dk : 1.0));
-          }
-        } else {
-          block_solve_bw(A.F + A.foff, A.ld, c0, nb, xs, Sd);
-          for (int i = tid; i < nb; i += CT) { sdm_store_wt(chain_vec_x(A) + c0 + i, xs[i]); A.yout[A.perm[A.first + c0 + i]] = xs[i]; }
-        }
-        __syncthreads();
-      }
-      have_pv = false;
-    } else {
-      const int nit = (n + G * CPAIRS - 1) / (G * CPAIRS);
-      for (int it = 0; it < nit; it++, pb ^= 1) {
-        const int i = wg + G * (slot + CPAIRS * it);
-        const bool mine = i < n;
-        const int ii = mine ? i : 0;
-        const ChainRow R = chain_row(A, kind, P, ii);
-        if (!(it == 0 && have_pv)) chain_issue(R, h, lane, v);
-        // what the output row starts from (two stages old: there by now), asked for early by the work-item that writes the row
-        const int io = wg + G * (tid + CPAIRS * it);
-        const double *bp = tid < CPAIRS && io < n ? chain_stage_base(A, kind, P, io) : nullptr;
-        double basev = bp ? sdm_load_wt(bp) : 0.0;
-        // the stage's vector: ONCE per workgroup into LDS (it == 0), polled until the producers' stores have arrived; every half
-        // row reads its entries from there
-        if (it == 0) {
-          const int nv = min(A.W, A.ns - c0);
-          for (int j = tid; j < nv; j += CT) xs[j] = vec ? chain_poll(vec + j, sdm_load_wt(vec + j), A.tmo) : A.src[A.perm[A.first + c0 + j]];
-          SDM_LDS_BARRIER();
-        }
-        const int half = (R.npair + 1) >> 1, plo = h ? half : 0, phi = h ? R.npair : half;
-        const int voff = kind == 2 ? (ii & ~1) : 0;                      // (a column of the inverse starts at its even row)
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const int pi = plo + lane + 64 * k, pc = min(pi, R.npair - 1), j0 = 2 * pc, j1 = min(2 * pc + 1, R.len - 1);
-          const double x0 = xs[voff + j0], x1 = xs[voff + j1];
-          const bool in0 = mine && pi < phi && 2 * pi >= R.jlo, in1 = mine && pi < phi && 2 * pi + 1 < R.len && 2 * pi + 1 >= R.jlo;
-          a0 += (in0 ? v[k].x : 0.0) * (in0 ? x0 : 0.0);
-          a1 += (in1 ? v[k].y : 0.0) * (in1 ? x1 : 0.0);
-        }
-        double sum = a0 + a1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        if (lane == 0) part[pb][slot][h] = sum;
-        SDM_LDS_BARRIER();                                             // (xs and part[pb ^ 1] are free from here on)
-        if (tid < CPAIRS && io < n) {
-          const double t = part[pb][tid][0] + part[pb][tid][1];
-          if (kind == 0) {
-            const double dk = A.dscale[A.first + c0 + io];
-            sdm_store_wt(chain_vec_y(A) + c0 + io, t);
-            sdm_store_wt(chain_vec_z(A) + c0 + io, t / (dk > 0.0 ? dk : 1.0));
-          } else if (kind == 1) {
-            const int r = c0 + A.W + io;
-            const double base = bp ? chain_poll(bp, basev, A.tmo) : A.src[A.perm[A.first + r]];
-            sdm_store_wt(chain_vec_a(A, P + 1) + r, base - t);
-          } else if (kind == 2) {
-            sdm_store_wt(chain_vec_x(A) + c0 + io, t);
-            A.yout[A.perm[A.first + c0 + io]] = t;
-          } else {
-            sdm_store_wt(chain_vec_v(A, P) + io, chain_poll(bp, basev, A.tmo) - t);
-          }
-        }
-      }
-    }
-    // ---- the next stage's rows start streaming before this stage's results are polled for
-    const bool more = only_stage < 0 && s + 1 < A.nst;
-    bool next_pf = false;
-    if (more) {
-      const ChainStage nx = stages[s + 1];
-      const bool nbad = (nx.kind == 0 || nx.kind == 2) && sb_is_bad(A.sb_g, A.sboff + nx.P, A.thr);
-      const int i = wg + G * slot;
-      next_pf = !nbad && i < nx.nrows;
-      if (next_pf) { const ChainRow Rn = chain_row(A, nx.kind, nx.P, i); chain_issue(Rn, h, lane, v); }
-    }
-    have_pv = next_pf;
-    SDM_COMPILER_BARRIER();
-  }
-}
-
 // ================================================================ host drivers
 const double *solve_d(sdm_plan *P) { return P->dense.factored ? (const double *)P->chol.dsolve.p : (const double *)P->chol.d.p; }
 
@@ -1449,66 +1245,6 @@ void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growt
 
 // forward sweeps of nrhs right-hand sides side by side (grid.z): rhs + z*rhs_stride -> y + z*y_stride (permuted order);
 // wv = update-vector scratch of wsize doubles per right-hand side
-// one-launch solve: stage list of a single-front factor (solve_build) and its launch (solve_run, fw + ./d + bw)
-static void chain_build(sdm_plan *P) {
-  CholPlan &C = P->chol;
-  C.chain_ok = false;
-  if (C.nsuper != 1 || C.sn_ms[0] != C.sn_ns[0] || C.sn_ns[0] < 1) return;
-  if (!C.sn_active.empty() && !C.sn_active[0]) return;
-  const int ns = C.sn_ns[0], W = C.sbw, nsb = (ns + W - 1) / W;
-  std::vector<ChainStage> st;
-  int maxrows = 1;
-  for (int Pb = 0; Pb < nsb; Pb++) {
-    st.push_back({0, Pb, std::min(W, ns - Pb * W), 0});
-    if (Pb + 1 < nsb) st.push_back({1, Pb, ns - (Pb + 1) * W, 0});
-  }
-  for (int Q = nsb - 1; Q >= 0; Q--) {
-    st.push_back({2, Q, std::min(W, ns - Q * W), 0});
-    if (Q > 0) st.push_back({3, Q, Q * W, 0});
-  }
-  for (auto &x : st) maxrows = std::max(maxrows, x.nrows);
-  int ncu = 8;
-#ifndef SDM_EMU
-  SDM_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, P->device));
-  {
-    const size_t lds = (size_t)(W + BSC * BSP) * sizeof(double);
-    int per_cu = 0;
-    SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_solve_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SDM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_solve_chain, CT, lds));
-    if (per_cu < 1) return;                                           // cannot be resident: the launches per stage stay
-  }
-#endif
-  // as many workgroups as the longest stage has rows for (fewer arrivals per hand-over for small fronts), all resident: one per compute unit
-  C.chain_wgs = std::max(1, std::min(ncu, (maxrows + CPAIRS - 1) / CPAIRS));
-  C.chain_nst = (int)st.size();
-  C.d_chain.upload(st);
-  C.chain_nvec = 2 * nsb + 1;
-  C.chain_vecs.alloc(2 * (size_t)C.chain_nvec * ns + 2);               // two sets of tagged vectors, both armed; the arrival ticket (+ the emulator's word)
-  SDM_KLAUNCH(P, k_fill_bits, dim3(64), dim3(256), 0, (unsigned long long *)C.chain_vecs.p, CHAIN_TAG, (int64_t)C.chain_vecs.n - 2);
-  SDM_HIP_CHECK(hipMemsetAsync(C.chain_vecs.p + C.chain_vecs.n - 2, 0, 2 * sizeof(double), P->stream));
-  C.chain_ok = true;
-}
-static void solve_chain(sdm_plan *P, const double *rhs, double *yout) {
-  CholPlan &C = P->chol;
-  ChainArgs A;
-  A.F = C.fronts.p; A.S = C.S.p; A.STr = C.ST.p; A.LT = C.LT.p;
-  A.ns = C.sn_ns[0]; A.ld = C.sn_ld[0]; A.sld = C.sn_sld[0]; A.first = C.sn_first[0]; A.sboff = C.sn_sboff[0]; A.W = C.sbw; A.nst = C.chain_nst; A.G = C.chain_wgs;
-  A.foff = C.sn_foff[0]; A.soff = C.sn_soff[0]; A.ltoff = C.sn_ltoff[0];
-  A.src = rhs; A.perm = C.d_perm.p; A.dscale = solve_d(P);
-  const size_t setw = (size_t)C.chain_nvec * A.ns;
-  A.nsb = (A.ns + A.W - 1) / A.W; A.nvec = C.chain_nvec;
-  A.sets = C.chain_vecs.p; A.cv = A.cv_next = nullptr; A.ticket = (unsigned long long *)(C.chain_vecs.p + 2 * setw); A.yout = yout;
-  A.sb_g = C.sb_g.p; A.thr = C.growth_used; A.tmo = C.tmo.dev();
-  const size_t lds = (size_t)(C.sbw + BSC * BSP) * sizeof(double);
-#ifdef SDM_EMU
-  for (int s = 0; s < C.chain_nst; s++)                              // (workgroups run one after the other here: a launch per stage, nothing carried over)
-    SDM_KLAUNCH(P, k_solve_chain, dim3(C.chain_wgs), dim3(CT), lds, A, (const ChainStage *)C.d_chain.p, s);
-#else
-  PersistTurn turn(P);                                                // every workgroup must be resident: launches of this kind take turns per device
-  SDM_KLAUNCH(P, k_solve_chain, dim3(C.chain_wgs), dim3(CT), lds, A, (const ChainStage *)C.d_chain.p, -1);
-#endif
-}
-
 void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *y, int64_t y_stride, double *wv, int nrhs,
                     double *zdiv, const double *dscale, int l0, int l1, int what) {
   // levels l0 .. l1-1 (l1 < 0: all); what: 1 the assembly launches only (k_sfw_init), 2 everything but them, 3 both
@@ -1583,7 +1319,6 @@ void solve_run(sdm_plan *P, const double *rhs, double *yout, int mode) {
   // fw, ./d, bw in one call without dense columns: the forward sweep writes the ./d copy of every block as it becomes
   // final (zdiv), the backward sweep runs on that copy and needs k_sbw_init only where rows below a supernode exist
   const bool fold = (mode == 7) && !dense;
-  if (fold && C.chain_ok && !C.front_disabled && C.chain_on) { solve_chain(P, rhs, yout); return; }   // single-front factor: the whole solve as one launch
   if (mode & 1) {
     solve_fw_batch(P, rhs, 0, y, 0, C.wvec.p, 1, fold ? C.zdiv.p : nullptr, fold ? solve_d(P) : nullptr);
     if (!(mode & 4)) {

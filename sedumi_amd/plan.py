@@ -184,10 +184,6 @@ class Plan:
         """False: the NEXT set_chol plans every front on the launch-per-panel path (the comparison switch of tests and tools)."""
         check(self._lib.sdm_plan_set_one_launch_fronts(C.c_void_p(self._p), C.c_int(1 if on else 0)))
 
-    def set_one_launch_solves(self, on):
-        """False: ldlsolve of a single-front factor as one launch per stage instead of one persistent launch (same sums, split differently: equal to rounding)."""
-        check(self._lib.sdm_plan_set_one_launch_solves(C.c_void_p(self._p), C.c_int(1 if on else 0)))
-
     def set_solve_width(self, width):
         """Super-block width of the solves for the NEXT set_chol (0 = automatic, or a power of two in 256 .. 2048)."""
         check(self._lib.sdm_plan_set_solve_width(C.c_void_p(self._p), C.c_int64(int(width))))

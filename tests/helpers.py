@@ -346,11 +346,9 @@ def check_solve_widths(m, thr, seed=0):
     while wauto < m and wauto < 2048:
         wauto *= 2
     widths = [0] + [w for w in (256, 512, 1024) if w < wauto]
-    from sedumi_amd import capi
-    for width, one_launch in [(w, o) for w in widths for o in (True, False)]:
+    for width in widths:
         plan = Plan(0)
         plan.set_solve_width(width)
-        plan.set_one_launch_solves(one_launch)                     # k_solve_chain (a one-front factor) / one launch per stage
         plan.set_chol(L, problem.dense_pattern(m))
         if thr is not None:
             plan.set_growth_max(thr)
@@ -371,11 +369,7 @@ def check_solve_widths(m, thr, seed=0):
         prof = plan.kprof_summary()
         plan.kprof(False)
         nl = sum(v[0] for k, v in prof.items() if k.startswith("k_sfw") or k.startswith("k_sbw"))
-        nstage = 2 * (2 * nsb - 1)
-        if one_launch:                                               # ONE launch per solve (the emulator steps it stage by stage)
-            assert nl == 0 and prof["k_solve_chain"][0] == len(rhss) * (nstage if capi.backend() == "emu" else 1), (width, prof)
-        else:
-            assert nl == len(rhss) * nstage, (width, prof)
+        assert nl == len(rhss) * 2 * (2 * nsb - 1), (width, prof)
         for y, want in zip(ys, wants):
             assert relerr(y, want) < 1e-9, (width, relerr(y, want))
         plan.close()

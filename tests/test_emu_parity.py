@@ -229,7 +229,7 @@ def test_resident_plan_matches_reference(glue):
     assert len(si) == it["Lskip"].nnz and len(ai) == it["Ladd"].nnz
     prof_before = plan.kprof_summary()
     plan.kprof(True); plan.ldlsolve(); prof = plan.kprof_summary(); plan.kprof(False)
-    assert not prof_before and ("k_solve_chain" in prof or ("k_sfw_diag" in prof and "k_sbw_diag" in prof))   # (a single-front factor: the one-launch solve)
+    assert not prof_before and "k_sfw_diag" in prof and "k_sbw_diag" in prof
     plan.close()
 
 

@@ -161,7 +161,7 @@ def test_resident_plan_and_kernel_timers(glue):
     assert relerr(plan.download("lpr"), it["LL"].data) < TOL
     assert relerr(plan.download("y"), glue.solve_ref(S, it, rhs).ravel()) < TOL
     plan.kprof(True); plan.ldlsolve(); prof = plan.kprof_summary(); plan.kprof(False)
-    assert sum(v[1] for k, v in prof.items() if k in ("k_sfw_diag", "k_sbw_diag", "k_solve_chain")) > 0
+    assert sum(v[1] for k, v in prof.items() if k in ("k_sfw_diag", "k_sbw_diag")) > 0
     # the whole unit replayed from one captured hipGraph gives the same bits as the eager calls
     y_eager, d_eager = plan.download("y"), plan.download("d")
 

@@ -22,8 +22,6 @@ P, L, ADA, Q, d, ud, rhs, qpr, note = bench.build_workload(name, 0)
 for width in widths:
     plan = Plan(0)
     plan.set_solve_width(width)
-    if os.environ.get("SDM_CHAIN") == "0":
-        plan.set_one_launch_solves(False)                             # the launch-per-stage form of a single-front factor's solve
     plan.set_chol(L, ADA)
     plan.set_ada(P.At, P.Ablkjc, P.K, Q)
     plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud); plan.upload("rhs", rhs)
@@ -54,7 +52,7 @@ for width in widths:
     lind = int(np.sum(np.diff(plan.L_pattern.indptr)[(np.asarray(bench.plan_xsuper(plan)) - 1)[:-1]]))
     bytes_solve = 2.0 * (8.0 * plan.nnzL + 8.0 * lind + 16.0 * plan.m)
     us = 1e3 * sol / reps / 4
-    nl = sum(v[0] for k, v in prof.items() if k.startswith("k_sfw") or k.startswith("k_sbw") or k.startswith("k_solve_chain")) / 20.0
+    nl = sum(v[0] for k, v in prof.items() if k.startswith("k_sfw") or k.startswith("k_sbw")) / 20.0
     prep = {k: round(1e3 * v[1] / 5, 2) for k, v in prof.items() if k in ("k_sprep", "k_sinv128", "k_stile")}
     nb, nbad, growth = plan.solve_stats()
     yv = plan.download("y", plan.m)                                   # (residual of the last solve against the matrix that was factored)
@@ -68,5 +66,5 @@ for width in widths:
                       "factor_incl_inversion_ms": round(fac / reps, 4), "inversion_us_by_kernel_with_events": prep,
                       "kernel_us_with_events": {k: round(1e3 * v[1] / v[0], 2) for k, v in prof.items() if k.startswith("k_s") or k.startswith("k_ldl")},
                       "super_blocks": nb, "bad": nbad, "growth": growth, "relres": resid,
-                      "lib": os.environ.get("SDM_LIB", ""), "one_launch_solves": os.environ.get("SDM_CHAIN") != "0"}), flush=True)
+                      "lib": os.environ.get("SDM_LIB", "")}), flush=True)
     plan.close()

@@ -685,9 +685,7 @@ __device__ __forceinline__ int panel_row_wgs(int ns, int ms, int q) {
 // fence = false: the caller reads what it waited for with sdm_load_wt only (no acquire fence needed, 1.7 us less)
 __device__ __forceinline__ void spin_until(const int *cnt, int target, int *tmo, bool fence = true) {
   if (threadIdx.x == 0) {
-    long it = 0;
-    for (; sdm_signal_load(cnt) < target && it < (1L << 21); it++) SDM_SPIN_PAUSE();
-    if (it == (1L << 21)) sdm_raise_flag(tmo);
+    for (long it = 0; sdm_signal_load(cnt) < target; it++) { if (sdm_spin_giveup(it, tmo)) break; SDM_SPIN_PAUSE(); }
   }
   __syncthreads();
   if (fence) SDM_ACQUIRE_FENCE();
@@ -1303,7 +1301,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
 __device__ __forceinline__ bool is_dt_sentinel(double v) { union { double d; unsigned long long u; } b; b.d = v; return b.u == DT_SENTINEL; }
 __device__ __forceinline__ double dt_tagged_load(const double *a, int *tmo) {
   double v = sdm_load_wt(a);
-  for (long it = 0; is_dt_sentinel(v) && it < (1L << 21); it++) { SDM_SPIN_PAUSE(); v = sdm_load_wt(a); if (it + 1 == (1L << 21)) sdm_raise_flag(tmo); }
+  for (long it = 0; is_dt_sentinel(v); it++) { if (sdm_spin_giveup(it, tmo)) break; SDM_SPIN_PAUSE(); v = sdm_load_wt(a); }
   return v;
 }
 // columns 16 blk .. 16 blk + 15 of the block (strictly lower part, rows < kb) into S, their pivots into dsr; all work-items.
@@ -1328,7 +1326,7 @@ __device__ __forceinline__ void diag_group_fetch(const double *Ds, int blk, int 
 #pragma unroll
   for (int t = 0; t <= NE; t++)
     if (need[t])
-      for (long it = 0; is_dt_sentinel(v[t]) && it < (1L << 21); it++) { SDM_SPIN_PAUSE(); v[t] = sdm_load_wt(a[t]); if (it + 1 == (1L << 21)) sdm_raise_flag(tmo); }
+      for (long it = 0; is_dt_sentinel(v[t]); it++) { if (sdm_spin_giveup(it, tmo)) break; SDM_SPIN_PAUSE(); v[t] = sdm_load_wt(a[t]); }
 #pragma unroll
   for (int t = 0; t < NE; t++) {
     const int e = tid + LDL_THREADS * t, i = e >> 4, j = 16 * blk + (e & 15);

@@ -33,6 +33,7 @@ inline unsigned long long sdm_load_wt_u64(const unsigned long long *p) { return 
 #define SDM_STORES_DONE() do { (void)emu_shfl(0.0, 0, 0); __atomic_thread_fence(__ATOMIC_SEQ_CST); } while (0)
 inline int sdm_signal_load(const int *p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 inline void sdm_raise_flag(int *p) { __atomic_store_n(p, 1, __ATOMIC_SEQ_CST); emu_report_timeout(); }
+inline bool sdm_flag_raised(const int *p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST) != 0; }
 #define SDM_UNIFORM_INT(x) (x)
 #define SDM_ACQUIRE_FENCE() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define SDM_COMPILER_BARRIER() __asm__ __volatile__("" ::: "memory")
@@ -77,6 +78,7 @@ __device__ __forceinline__ unsigned long long sdm_load_wt_u64(const unsigned lon
 __device__ __forceinline__ int sdm_signal_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // error flag in pinned host memory (HostFlag): one system-scope store, read by the host after a stream synchronise
 __device__ __forceinline__ void sdm_raise_flag(int *p) { __hip_atomic_store(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ bool sdm_flag_raised(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0; }
 #define SDM_ACQUIRE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 // a wave-uniform integer the compiler cannot prove uniform (e.g. threadIdx.x >> 6): moved to a scalar register, so that
 // addresses built from it stay scalar and loads through them become s_load
@@ -95,6 +97,25 @@ __device__ __forceinline__ double sdm_bcast_lane(double v, int lane) {
   return u.d;
 }
 #endif
+
+// Bounded waits between workgroups of one launch: poll number `it` of a wait gives up -- true -- at the bound (2^19 polls of
+// 0.5 - 1.5 us each: a fraction of a second, against legitimate waits of at most a few milliseconds; it raises the plan's time-out
+// flag in pinned host memory), or as soon as ANOTHER wait of the plan has given up: the flag is looked at (a PCIe round trip) when
+// a wait has lasted 64, 128, 256, ... polls -- never in a healthy hand-over on the chain, a few times in the long idle waits --
+// so a starved launch drains within milliseconds of its first time-out instead of paying the bound once per wait still ahead.
+#ifdef SDM_EMU
+#define SDM_SPIN_MAX (1L << 21)          // (processes sharing a few cores: polls are cheap here and legitimate waits long)
+inline
+#else
+#ifndef SDM_SPIN_MAX
+#define SDM_SPIN_MAX (1L << 19)
+#endif
+__device__ __forceinline__
+#endif
+bool sdm_spin_giveup(long it, int *tmo) {
+  if (it + 1 >= SDM_SPIN_MAX) { sdm_raise_flag(tmo); return true; }
+  return it >= 63 && ((it + 1) & it) == 0 && sdm_flag_raised(tmo);
+}
 
 // Statement-level switch: keep a*b-c as two roundings (gcc -O2 on x86-64 emits no FMA for the reference's
 // daxpy loops); used where a pivot accept/skip decision depends on noise-level values (blkchol2.c:114-161).

@@ -565,9 +565,7 @@ k_stile(const double *F, double *S, double *STr, double *T, FrontTab tab, const 
 // cnt[SPREP_NCNT * sb + 0] = finished leaves, [1 + st] = finished tiles of stage st (zeroed with sb_g by k_prep_pivots).
 __device__ __forceinline__ void prep_wait(const int *cnt, int target, int *tmo) {
   if (threadIdx.x == 0) {
-    long it = 0;
-    for (; sdm_signal_load(cnt) < target && it < (1L << 21); it++) SDM_SPIN_PAUSE();
-    if (it == (1L << 21)) sdm_raise_flag(tmo);
+    for (long it = 0; sdm_signal_load(cnt) < target; it++) { if (sdm_spin_giveup(it, tmo)) break; SDM_SPIN_PAUSE(); }
   }
   __syncthreads();                                                  // no acquire fence: everything waited for is read with sc1 loads
 }
@@ -609,9 +607,7 @@ k_sprep(const double *F, double *S, double *STr, double *T, FrontTab tab, const 
 // xcnt[r * FRONT_MAXT + c] = 1 once X(r, c) is in S (c = r: the diagonal tile); zeroed with front_cnt by k_prep_pivots.
 __device__ __forceinline__ void follow_wait(const int *cnt, int target, int *tmo) {
   if (threadIdx.x == 0) {
-    long it = 0;
-    for (; sdm_signal_load(cnt) < target && it < (1L << 22); it++) SDM_SPIN_PAUSE();
-    if (it == (1L << 22)) sdm_raise_flag(tmo);
+    for (long it = 0; sdm_signal_load(cnt) < target; it++) { if (sdm_spin_giveup(it, tmo)) break; SDM_SPIN_PAUSE(); }
   }
   __syncthreads();
 }

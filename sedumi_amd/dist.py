@@ -360,8 +360,9 @@ class SeparatorShardedSolver:
     8e rows blkchol / fwblkslv / bwblkslv).  Every rank holds the symbolic factor and the full front arena (equal layout
     everywhere, so slices of it travel as they are) and the values of the whole matrix (what the ADA' layers above leave on every
     rank); it FACTORS only the supernodes it owns (sdm_plan_set_active_supernodes).  Exchanges, all on device tensors:
-      factor   one reduce (sum; every slice has one writer) of the subtree roots' fronts to rank 0, which owns the top of the tree;
-      forward  one reduce of the roots' update vectors to rank 0;
+      factor   one reduce (sum; every slice has one writer) of the fronts of the subtree roots of ranks 1.. to rank 0, which owns the
+               top of the tree (the top is NOT distributed: its levels run on rank 0 while the others wait for the broadcast);
+      forward  one reduce of those roots' update vectors to rank 0;
       backward one broadcast of the top's solution;  then one all-reduce of the masked solution segments.
     """
 
@@ -389,9 +390,11 @@ class SeparatorShardedSolver:
         lay = self.lay = self.plan.front_layout(self.nsuper)
         self.nlevels = lay["nlevels"]
         self.ltop = int(lay["level"][self.top].min()) if self.top.any() else self.nlevels
-        # packed exchange buffers: the roots' fronts / update vectors one after the other
-        self.f_off = np.concatenate(([0], np.cumsum(lay["fsize"][self.roots]))).astype(np.int64)
-        self.w_off = np.concatenate(([0], np.cumsum(lay["ms"][self.roots]))).astype(np.int64)
+        # packed exchange buffers: the fronts / update vectors of the subtree roots that have to TRAVEL (those of ranks other than
+        # rank 0, which owns the top: its own roots stay where they are -- and may not even be factored yet when the others arrive)
+        self.xroots = [s for s in self.roots if self.owner[s] != 0]
+        self.f_off = np.concatenate(([0], np.cumsum(lay["fsize"][self.xroots]))).astype(np.int64)
+        self.w_off = np.concatenate(([0], np.cumsum(lay["ms"][self.xroots]))).astype(np.int64)
         self.fbuf = torch.zeros(int(self.f_off[-1]), dtype=torch.float64, device=self.device)
         self.wbuf = torch.zeros(int(self.w_off[-1]), dtype=torch.float64, device=self.device)
         self.xbuf = torch.zeros(self.m, dtype=torch.float64, device=self.device)
@@ -402,7 +405,8 @@ class SeparatorShardedSolver:
         self.mask = torch.as_tensor(mine, device=self.device)           # entries of the solution this rank computes (the others of its y are never written)
 
     def _roots(self, mine):
-        return [(i, s) for i, s in enumerate(self.roots) if (self.owner[s] == self.rank) == mine]
+        """(slot in the exchange buffers, supernode) of the travelling roots this rank owns (mine) / receives (not mine)."""
+        return [(i, s) for i, s in enumerate(self.xroots) if (self.owner[s] == self.rank) == mine]
 
     def factor(self, values, pars=None, absd=None):
         """values: ADA' (the matrix) in the order of its pattern, complete on every rank."""

@@ -1,6 +1,8 @@
 """Parity tests proper: the HIP path on a real MI355X, through the C ABI, against the oracle (compiled reference in
 oracle/_ref -- it travels to the GPU box as a built artefact -- and the committed golden fixtures), plus
 size-independent properties at the BASELINE.json sizes.  Run with `pytest -m gpu`."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -621,6 +623,69 @@ def test_one_launch_front_under_uneven_load(refmex):
         assert np.array_equal(main.download("lpr"), l0) and np.array_equal(main.download("d"), d0) and np.array_equal(main.download("y"), y0), rep
     for pl, (l, d) in zip(others, refs):
         assert np.array_equal(pl.download("lpr"), l) and np.array_equal(pl.download("d"), d)
+
+
+@pytest.mark.parametrize("busy", [216, 232])
+def test_one_launch_front_starved_by_another_process(refmex, busy):
+    """ANOTHER PROCESS holds `busy` of the 256 compute units for 3 s (tests/gpuhog: one idle workgroup per unit, pinned there by its LDS
+    footprint) while control07's shape is factored: k_ldl_front needs its 56 workgroups resident at once (and k_sinv_follow's 66 beside
+    them).  Measured (profiles/r04i_starve_probe.jsonl): up to 204 held units the launch runs as if alone; with 208 - 224 it is
+    STARVED -- some workgroups resident, the bounded waits give up after 0.1 s, sdm_plan_blkchol_wait repeats the factorisation on the
+    launch-per-panel path (which only ever waits for workgroups dispatched earlier) while the other process is still there, and the
+    plan stays on that path; with 228 and more the hardware dispatcher holds the launch back until the other process has left.  In
+    every case: the factor bit for bit the idle one, the solve to 1e-12, no hang."""
+    import subprocess
+    import sys
+    import time
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpuhog"))
+    import build_hog
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    hog = build_hog.build()
+    m = 666
+    rng = np.random.default_rng(1)
+    B = rng.standard_normal((m, m))
+    X = sp.csc_matrix(B @ B.T + m * np.eye(m)); X.sort_indices()
+    plan = Plan(0)
+    plan.set_chol(problem.dense_symbolic(m), X)
+    plan.upload("ada", X.data); plan.upload("rhs", rng.standard_normal(m))
+    plan.blkchol_wait(None, False); plan.ldlsolve()
+    l0, d0, y0 = plan.download("lpr"), plan.download("d"), plan.download("y")
+    plan.kprof(True); plan.blkchol(None, False); plan.sync(); prof = plan.kprof_summary(); plan.kprof(False)
+    assert "k_ldl_front" in prof and "k_ldl_panel" not in prof
+    Xs = sp.csc_matrix(B[:90, :90] @ B[:90, :90].T + 90 * np.eye(90)); Xs.sort_indices()
+    small = Plan(0)
+    small.set_chol(problem.dense_symbolic(90), Xs)
+    small.upload("ada", Xs.data)
+    small.blkchol_wait(None, False)
+    code = "import ctypes, sys; sys.exit(ctypes.CDLL(%r).hog_run(0, %d, 150 * 1024, 3000))" % (hog, busy)
+    other = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True)
+    try:
+        assert other.stdout.readline().strip() == "started"
+        time.sleep(0.05)
+        t0 = time.time()
+        small.blkchol_wait(None, False)                                 # (a small factor on the launch-per-panel path runs beside the other process)
+        dt_small = time.time() - t0
+        t0 = time.time()
+        plan.blkchol_wait(None, False)
+        dt = time.time() - t0
+        plan.ldlsolve()
+        l1, d1, y1 = plan.download("lpr"), plan.download("d"), plan.download("y")
+        assert other.wait(timeout=30) == 0
+    finally:
+        if other.poll() is None:
+            other.kill()
+    plan.kprof(True); plan.blkchol(None, False); plan.sync(); prof = plan.kprof_summary(); plan.kprof(False)
+    fell_back = "k_ldl_panel" in prof and "k_ldl_front" not in prof
+    print("%d units held: a 90-column factor took %.4f s, blkchol_wait of the 666-column front %.3f s next to the other process; the plan %s" %
+          (busy, dt_small, dt, "moved to the launch-per-panel path" if fell_back else "kept the one-launch path (the launch was held back whole)"))
+    assert np.array_equal(l1, l0) and np.array_equal(d1, d0) and relerr(y1, y0) < 1e-12
+    if busy == 216:
+        assert fell_back and dt < 1.0                                   # recovered WHILE the other process was still there
+    assert dt < 6.0
+    plan.blkchol_wait(None, False); plan.ldlsolve()                     # and afterwards, with the device to itself again
+    assert np.array_equal(plan.download("lpr"), l0) and relerr(plan.download("y"), y0) < 1e-12
+    plan.close(); small.close()
 
 
 @pytest.mark.parametrize("m,thr", [(90, None), (300, None), (666, None), (700, 0.0), (700, 1e-3), (1100, None), (256, 0.0), (2500, None), (2500, 0.0)])

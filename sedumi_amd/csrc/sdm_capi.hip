@@ -318,6 +318,13 @@ int sdm_plan_set_growth_max(sdm_plan *p, double growth_max) {
   p->chol.growth_max = growth_max;
   SDM_CATCH
 }
+int sdm_plan_set_refinement(sdm_plan *p, int mode, double refine_max) {
+  SDM_TRY
+  if (mode < 0 || mode > 2) throw std::runtime_error("sdm_plan_set_refinement: mode must be 0, 1 or 2");
+  if (!(refine_max >= 0.0)) throw std::runtime_error("sdm_plan_set_refinement: refine_max must be >= 0");
+  p->chol.refine_mode = mode; p->chol.refine_max = refine_max;
+  SDM_CATCH
+}
 int sdm_plan_set_one_launch_fronts(sdm_plan *p, int on) {
   SDM_TRY
   p->chol.front_off_req = !on;

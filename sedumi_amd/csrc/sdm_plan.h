@@ -204,6 +204,16 @@ struct CholPlan {
   std::vector<SolveLevel> slev;
   double growth_max = 1e4;           // a super-block whose max|inv| * max|L| exceeds this is solved by substitution
   double growth_used = 1e4;          // the bound in force at the last solve_prepare
+  // blocks beyond growth_max but within refine_max: inverse + REFINE_STEPS steps of iterative refinement against the factor
+  // (k_sfw_resid / k_sbw_resid) when the solves run their refinement launches.  refine_mode 1 (default): they do while such blocks
+  // keep turning up -- every sweep that meets one leaves a note in pinned host memory (`noted`, read without synchronising); a
+  // factorisation takes the note as its prediction for its own solves (refine_predicted) and clears it, so a run whose factors
+  // are well conditioned again drops the extra launches.  The first solve that meets such a block -- and any solve enqueued
+  // before the note arrives -- substitutes.  0: never refine; 2: always.
+  double refine_max = 1e10;
+  int refine_mode = 1;
+  bool refine_predicted = false;
+  HostFlag noted;
 };
 
 // device view of the front tables

@@ -52,6 +52,7 @@ void solve_build(sdm_plan *P) {
   int W = C.sbw_req;
   if (W == 0) { W = SBW_MIN; while (W < C.maxns && W < SBW_MAX) W *= 2; }
   C.sbw = W;
+  C.noted.ensure(); *(volatile int *)C.noted.host = 0; C.refine_predicted = false;   // a new solve: no ill-conditioned block met yet
   C.sn_soff.assign(nsuper, 0); C.sn_sld.assign(nsuper, 0); C.sn_sboff.assign(nsuper, 0);
   std::vector<int> i128;
   std::vector<std::vector<int>> stage(2 * SINV_MAXLEV);              // combine tiles per stage st = 2 * level + (0: T, 1: X)
@@ -189,6 +190,13 @@ __device__ __forceinline__ unsigned long long double_to_bits(double d) { union {
 // growth check of super-block sb: max|inv| * max|L| within bounds (NaN counts as bad)
 __device__ __forceinline__ bool sb_is_bad(const unsigned long long *g, int sb, double thr) {
   return !(bits_to_double(g[2 * sb]) * bits_to_double(g[2 * sb + 1]) <= thr);
+}
+// the three kinds of super-block: 0 within the bound (applied as its explicit inverse), 1 beyond it but no further than `thr2`
+// (inverse + iterative refinement against the factor when the solve runs its refinement launches, substitution otherwise),
+// 2 beyond thr2 or not a number (always substituted)
+__device__ __forceinline__ int sb_class(const unsigned long long *g, int sb, double thr, double thr2) {
+  const double gr = bits_to_double(g[2 * sb]) * bits_to_double(g[2 * sb + 1]);
+  return gr <= thr ? 0 : (gr <= thr2 ? 1 : 2);
 }
 // max over the wavefront, then one order-independent atomicMax on the bit pattern of a non-negative double
 __device__ __forceinline__ void wave_atomic_max(unsigned long long *dst, double v, int lane) {
@@ -962,7 +970,10 @@ k_sfw_init(FrontTab tab, const int *list, double *wv, const double *src, const i
 __global__ void __launch_bounds__(ST)
 k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTab tab, const int *list, const double *wv, const double *src,
            const int *perm, double *y, const unsigned long long *sb_g, double thr, int Pb, int gather0, FwBatch bt,
-           double *zdiv, const double *dscale, int W) {
+           double *zdiv, const double *dscale, int W, int mode, double thr2, const double *resid, int *noted) {
+  // mode 0: the sweep as planned for well-conditioned factors (blocks beyond the bound are substituted by workgroup 0);
+  // mode 1: the first of the refinement launches: blocks of kind 1 are applied as their inverse like the good ones;
+  // mode 2: blocks of kind 1 only:  y_P += inv(L_PP) r_P  with the residual r_P = t_P - L_PP y_P of k_sfw_resid (`resid`)
   SDM_DYN_SMEM(smem);                                                // (the rare substitution fallback only: W + BSC * BSP doubles -- as static
   double *xs = (double *)smem, *Sd = xs + W;                          // arrays sized for the widest block they cost every launch 49 KB per workgroup)
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
@@ -975,9 +986,14 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTa
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int sld = FT(sld);
   const double *a = wv + FT(woff) + c0;
-  const bool gather = gather0 && Pb == 0;
+  const int cls = sb_class(sb_g, FT(sboff) + Pb, thr, thr2);
+  if (mode == 2 && cls != 1) return;
+  if (mode == 2) a = resid + first + c0;
+  const bool gather = gather0 && Pb == 0 && mode != 2;
   const int *pp = perm + first + c0;
-  if (sb_is_bad(sb_g, FT(sboff) + Pb, thr)) {
+  // (a block of kind 1 met by a sweep: the host plans the refinement launches while such blocks keep turning up -- solve_refines)
+  if (cls == 1 && mode != 2 && blockIdx.x == 0 && tid == 0 && noted) sdm_host_note(noted);
+  if (cls == 2 || (cls == 1 && mode == 0)) {
     if (blockIdx.x != 0) return;
     for (int c = tid; c < nb; c += ST) xs[c] = gather ? src[pp[c]] : a[c];
     __syncthreads();
@@ -995,8 +1011,9 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTa
     const double *M = STr + FT(soff) + (int64_t)c0 * sld + (int64_t)rc * sld;
     const double sum = gather ? row_dot<true, 16>(M, src, pp, rc + 1, 0, l16) : row_dot<false, 16>(M, a, nullptr, rc + 1, 0, l16);
     if (l16 == 0 && r < nb) {
-      y[first + c0 + r] = sum;
-      if (zdiv) { const double dk = dscale[first + c0 + r]; zdiv[first + c0 + r] = sum / (dk > 0.0 ? dk : 1.0); }
+      const double yv = mode == 2 ? y[first + c0 + r] + sum : sum;
+      y[first + c0 + r] = yv;
+      if (zdiv) { const double dk = dscale[first + c0 + r]; zdiv[first + c0 + r] = yv / (dk > 0.0 ? dk : 1.0); }
     }
     return;
   }
@@ -1005,8 +1022,52 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTa
   const double *M = STr + FT(soff) + (int64_t)c0 * sld + (int64_t)r * sld;
   const double sum = gather ? row_dot<true>(M, src, pp, r + 1, 0, lane) : row_dot<false>(M, a, nullptr, r + 1, 0, lane);
   if (lane == 0) {
-    y[first + c0 + r] = sum;
-    if (zdiv) { const double dk = dscale[first + c0 + r]; zdiv[first + c0 + r] = sum / (dk > 0.0 ? dk : 1.0); }
+    const double yv = mode == 2 ? y[first + c0 + r] + sum : sum;
+    y[first + c0 + r] = yv;
+    if (zdiv) { const double dk = dscale[first + c0 + r]; zdiv[first + c0 + r] = yv / (dk > 0.0 ? dk : 1.0); }
+  }
+}
+
+// r_P = t_P - L_PP y_P for the super-blocks of kind 1 (iterative refinement of y_P = inv(L_PP) t_P against the factor itself: the
+// explicit inverse of an ill-conditioned block loses accuracy in proportion to its growth, the refined result has the accuracy of
+// the substitution it replaces).  L is stored by columns: a workgroup takes 64 rows (one per lane), its four wavefronts the
+// columns j = w, w + 4, ... left of the diagonal (512-byte coalesced reads), the partial sums meet in LDS.
+constexpr int RT = 1024;          // work-items of k_sfw_resid: sixteen wavefronts keep 64 KB of a 64-row slab in flight (with four, the last slab of a
+                                  // 2048-wide block was 64 dependent round trips: 55 us)
+__global__ void __launch_bounds__(RT)
+k_sfw_resid(const double *__restrict__ F, FrontTab tab, const int *list, const double *wv, const double *src, const int *perm, const double *y,
+            double *resid, const unsigned long long *sb_g, double thr, double thr2, int Pb, int gather0, int W) {
+  __shared__ double ys[SBW_MAX], red[RT / 64][64];
+  const int s = tab.one ? tab.o_s : list[blockIdx.y];
+  const int ns = FT(ns), first = FT(first), ld = FT(ld);
+  const int c0 = Pb * W;
+  if (c0 >= ns) return;
+  const int nb = min(W, ns - c0);
+  const int i0 = 64 * blockIdx.x;
+  if (i0 >= nb) return;
+  if (sb_class(sb_g, FT(sboff) + Pb, thr, thr2) != 1) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int jend = min(i0 + 64, nb);
+  for (int c = tid; c < jend; c += RT) ys[c] = y[first + c0 + c];
+  __syncthreads();
+  const int i = i0 + lane, ic = min(i, nb - 1);
+  const double *Fi = F + FT(foff) + (int64_t)c0 * ld + c0 + ic;        // L(c0 + i, c0 + j) = Fi[j * ld]
+  double acc = 0.0;
+  for (int j0 = wave; j0 < jend; j0 += 8 * (RT / 64)) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = Fi[(int64_t)min(j0 + (RT / 64) * k, jend - 1) * ld];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int j = j0 + (RT / 64) * k; if (j < i && j < jend) acc += v[k] * ys[j]; }
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && i < nb) {
+    double sum = 0.0;
+    for (int w = 0; w < RT / 64; w++) sum += red[w][lane];
+    const bool gather = gather0 && Pb == 0;
+    const double t = gather ? src[perm[first + c0 + i]] : wv[FT(woff) + c0 + i];
+    resid[first + c0 + i] = (t - ys[i]) - sum;
   }
 }
 
@@ -1106,7 +1167,8 @@ k_sbw_init(const double *__restrict__ F, FrontTab tab, const int *list, double *
 // by workgroup 0.
 __global__ void __launch_bounds__(ST)
 k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, const double *y, double *xfin, double *yout,
-           const int *perm, const unsigned long long *sb_g, double thr, int Q, int W) {
+           const int *perm, const unsigned long long *sb_g, double thr, int Q, int W, int mode, double thr2, const double *wv, int *noted) {
+  // mode 0 / 1 / 2 as in k_sfw_diag; mode 2:  x_Q += inv(L_QQ)' r_Q  with the residual of k_sbw_resid (in the front's slice of wv)
   SDM_DYN_SMEM(smem);
   double *xs = (double *)smem, *Sd = xs + W;
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
@@ -1116,8 +1178,11 @@ k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
   const int nb = min(W, ns - rb);
   if ((W <= 256 ? 16 : 4) * (int)blockIdx.x >= nb) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const double *vp = y + first + rb;
-  if (sb_is_bad(sb_g, FT(sboff) + Q, thr)) {
+  const int cls = sb_class(sb_g, FT(sboff) + Q, thr, thr2);
+  if (mode == 2 && cls != 1) return;
+  const double *vp = mode == 2 ? wv + FT(woff) + rb : y + first + rb;
+  if (cls == 1 && mode != 2 && blockIdx.x == 0 && tid == 0 && noted) sdm_host_note(noted);
+  if (cls == 2 || (cls == 1 && mode == 0)) {
     if (blockIdx.x != 0) return;
     for (int i = tid; i < nb; i += ST) xs[i] = vp[i];
     __syncthreads();
@@ -1131,7 +1196,7 @@ k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
     const int cc = min(c, nb - 1), ce = cc & ~1;
     const double *M = S + FT(soff) + (int64_t)rb * sld + (int64_t)cc * sld + ce;
     const double sum = row_dot<false, 16>(M, vp + ce, nullptr, nb - ce, cc - ce, l16);
-    if (l16 == 0 && c < nb) { xfin[first + rb + c] = sum; if (yout) yout[perm[first + rb + c]] = sum; }
+    if (l16 == 0 && c < nb) { const double xv = mode == 2 ? xfin[first + rb + c] + sum : sum; xfin[first + rb + c] = xv; if (yout) yout[perm[first + rb + c]] = xv; }
     return;
   }
   const int c = 4 * blockIdx.x + wave;
@@ -1139,7 +1204,27 @@ k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
   const int ce = c & ~1;                                              // 16-byte aligned start (the entry above the diagonal is skipped: jlo)
   const double *M = S + FT(soff) + (int64_t)rb * sld + (int64_t)c * sld + ce;
   const double sum = row_dot<false>(M, vp + ce, nullptr, nb - ce, c - ce, lane);
-  if (lane == 0) { xfin[first + rb + c] = sum; if (yout) yout[perm[first + rb + c]] = sum; }
+  if (lane == 0) { const double xv = mode == 2 ? xfin[first + rb + c] + sum : sum; xfin[first + rb + c] = xv; if (yout) yout[perm[first + rb + c]] = xv; }
+}
+
+// r_Q = v_Q - L_QQ' x_Q for the super-blocks of kind 1 (see k_sfw_resid): a column of L is contiguous, one wavefront per column;
+// the residual goes to the front's slice of the forward sweep's update vectors (idle during the backward sweep)
+__global__ void __launch_bounds__(ST)
+k_sbw_resid(const double *__restrict__ F, FrontTab tab, const int *list, const double *y, const double *xfin, double *wv,
+            const unsigned long long *sb_g, double thr, double thr2, int Q, int W) {
+  const int s = tab.one ? tab.o_s : list[blockIdx.y];
+  const int ns = FT(ns), first = FT(first), ld = FT(ld);
+  const int rb = Q * W;
+  if (rb >= ns) return;
+  const int nb = min(W, ns - rb);
+  const int c = 4 * blockIdx.x + (threadIdx.x >> 6);
+  if (c >= nb) return;
+  if (sb_class(sb_g, FT(sboff) + Q, thr, thr2) != 1) return;
+  const int lane = threadIdx.x & 63;
+  const int s0 = rb + c + 1, sa = s0 & ~1, send = rb + nb;           // rows below the diagonal, from a 16-byte aligned start
+  double sum = 0.0;
+  if (s0 < send) sum = row_dot<false>(F + FT(foff) + (int64_t)(rb + c) * ld + sa, xfin + first + sa, nullptr, send - sa, s0 - sa, lane);
+  if (lane == 0) wv[FT(woff) + rb + c] = (y[first + rb + c] - xfin[first + rb + c]) - sum;
 }
 
 // step Q: x_Q is final; every column left of super-block Q receives  - L(Q rows, c)' x_Q , read from the factor (a column
@@ -1239,6 +1324,13 @@ void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growt
   if (max_growth) *max_growth = mx;
 }
 
+// do the sweeps run the refinement launches for blocks beyond the growth bound?  (CholPlan::refine_mode; the note is read as it is
+// now, without waiting for the device)
+constexpr int REFINE_STEPS = 2;
+static bool solve_refines(CholPlan &C) {
+  if (C.refine_mode == 2) return true;
+  return C.refine_mode == 1 && (C.refine_predicted || (C.noted.host && *(volatile int *)C.noted.host != 0));
+}
 // forward sweeps of nrhs right-hand sides side by side (grid.z): rhs + z*rhs_stride -> y + z*y_stride (permuted order);
 // wv = update-vector scratch of wsize doubles per right-hand side
 void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *y, int64_t y_stride, double *wv, int nrhs,
@@ -1251,6 +1343,8 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
   bt.src = nrhs > 1 ? rhs_stride : 0; bt.y = nrhs > 1 ? y_stride : 0; bt.wv = nrhs > 1 ? C.wsize : 0;
   const FrontTab tab0 = front_tab(C);
   if (l1 < 0) l1 = C.nlevels;
+  const bool refine = nrhs == 1 && solve_refines(C);
+  int *noted = C.refine_mode == 1 ? C.noted.dev() : nullptr;
   for (int l = std::max(l0, 0); l < std::min(l1, C.nlevels); l++) {
     const SolveLevel &L = C.slev[l];
     if (L.nfronts == 0) continue;
@@ -1261,8 +1355,15 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
     if (!(what & 2)) continue;
     for (int Pb = 0; Pb < L.nsb; Pb++) {
       const int nbmax = std::min(W, L.maxns - Pb * W);
-      SDM_KLAUNCH(P, k_sfw_diag, dim3(W <= 256 ? (nbmax + 15) / 16 : (nbmax + 3) / 4, L.nfronts, nrhs), dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.ST.p, tab, list, wv, rhs,
-                  C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W);
+      const dim3 gdiag(W <= 256 ? (nbmax + 15) / 16 : (nbmax + 3) / 4, L.nfronts, nrhs);
+      SDM_KLAUNCH(P, k_sfw_diag, gdiag, dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.ST.p, tab, list, wv, rhs,
+                  C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W, refine ? 1 : 0, C.refine_max, (const double *)nullptr, noted);
+      for (int it = 0; refine && it < REFINE_STEPS; it++) {            // (blocks within the bound leave these launches at once)
+        SDM_KLAUNCH(P, k_sfw_resid, dim3((nbmax + 63) / 64, L.nfronts), dim3(RT), 0, C.fronts.p, tab, list, wv, rhs, C.d_perm.p, y, C.xfin.p, C.sb_g.p, thr,
+                    C.refine_max, Pb, gather, W);
+        SDM_KLAUNCH(P, k_sfw_diag, gdiag, dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.ST.p, tab, list, wv, rhs,
+                    C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W, 2, C.refine_max, (const double *)C.xfin.p, (int *)nullptr);
+      }
       const int assign0 = (gather && Pb == 0) ? 1 : 0;
       if (L.maxns > (Pb + 1) * W)                                    // the fronts' own rows of later super-blocks
         SDM_KLAUNCH(P, k_sfw_rows, dim3((L.maxns - (Pb + 1) * W + 3) / 4, L.nfronts, nrhs), dim3(ST), 0, C.LT.p, tab, list, wv, rhs, C.d_perm.p, y, Pb,
@@ -1282,6 +1383,8 @@ static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double 
   const int W = C.sbw;
   const FrontTab tab0 = front_tab(C);
   if (l1 < 0) l1 = C.nlevels;
+  const bool refine = solve_refines(C);
+  int *noted = C.refine_mode == 1 ? C.noted.dev() : nullptr;
   for (int l = std::min(l1, C.nlevels) - 1; l >= std::max(l0, 0); l--) {
     const SolveLevel &L = C.slev[l];
     if (L.nfronts == 0) continue;
@@ -1291,8 +1394,14 @@ static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double 
       SDM_KLAUNCH(P, k_sbw_init, dim3((L.maxns + SROWS - 1) / SROWS, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, dscale);
     for (int Q = L.nsb - 1; Q >= 0; Q--) {
       const int nbmax = std::min(W, L.maxns - Q * W);
-      SDM_KLAUNCH(P, k_sbw_diag, dim3(W <= 256 ? (nbmax + 15) / 16 : (nbmax + 3) / 4, L.nfronts), dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
-                  C.d_perm.p, C.sb_g.p, thr, Q, W);
+      const dim3 gdiag(W <= 256 ? (nbmax + 15) / 16 : (nbmax + 3) / 4, L.nfronts);
+      SDM_KLAUNCH(P, k_sbw_diag, gdiag, dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
+                  C.d_perm.p, C.sb_g.p, thr, Q, W, refine ? 1 : 0, C.refine_max, (const double *)nullptr, noted);
+      for (int it = 0; refine && it < REFINE_STEPS; it++) {
+        SDM_KLAUNCH(P, k_sbw_resid, dim3((nbmax + 3) / 4, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, C.wvec.p, C.sb_g.p, thr, C.refine_max, Q, W);
+        SDM_KLAUNCH(P, k_sbw_diag, gdiag, dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
+                    C.d_perm.p, C.sb_g.p, thr, Q, W, 2, C.refine_max, (const double *)C.wvec.p, (int *)nullptr);
+      }
       if (Q > 0) SDM_KLAUNCH(P, k_sbw_step, dim3(Q * (W / 4), L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, Q, W);
     }
   }

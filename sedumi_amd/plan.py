@@ -180,6 +180,11 @@ class Plan:
         inverse (0 = substitution everywhere); effective from the next blkchol."""
         check(self._lib.sdm_plan_set_growth_max(C.c_void_p(self._p), C.c_double(float(growth_max))))
 
+    def set_refinement(self, mode, refine_max=1e10):
+        """Blocks beyond growth_max but within refine_max: 1 = inverse + iterative refinement once a solve has met one (default),
+        0 = always substitution, 2 = refinement launches in every solve."""
+        check(self._lib.sdm_plan_set_refinement(C.c_void_p(self._p), C.c_int(int(mode)), C.c_double(float(refine_max))))
+
     def set_one_launch_fronts(self, on):
         """False: the NEXT set_chol plans every front on the launch-per-panel path (the comparison switch of tests and tools)."""
         check(self._lib.sdm_plan_set_one_launch_fronts(C.c_void_p(self._p), C.c_int(1 if on else 0)))

@@ -329,8 +329,10 @@ def check_rank_deficient_fronts(refmex, ncases, seed=777):
 def check_solve_widths(m, thr, seed=0):
     """The solves of a one-front factor with every super-block width the front admits (sdm_plan_set_solve_width: 256, 512,
     ... up to the automatic choice = one block when m <= 2048): every width against numpy's solve -- on the inverse path,
-    with every super-block on the substitution fallback (bound 0) and with good and bad blocks mixed -- several solves in
-    a row, and the launch count 2 (2 nsb - 1) per fw + bw."""
+    with every super-block beyond the growth bound (bound 0) and with good and bad blocks mixed -- several solves in
+    a row, and the launch count 2 (2 nsb - 1) per fw + bw.  Blocks beyond the bound three ways (sdm_plan_set_refinement): always
+    substituted (mode 0), inverse + iterative refinement in every solve (mode 2: 4 more launches per diagonal stage), and the default
+    (mode 1): the first solve substitutes and leaves a note, the later ones refine."""
     from sedumi_amd import problem
     from sedumi_amd.plan import Plan
     rng = np.random.default_rng(m + seed)
@@ -346,9 +348,10 @@ def check_solve_widths(m, thr, seed=0):
     while wauto < m and wauto < 2048:
         wauto *= 2
     widths = [0] + [w for w in (256, 512, 1024) if w < wauto]
-    for width in widths:
+    for width, refine in [(w, r) for w in widths for r in ((1,) if thr is None else (0, 1, 2))]:
         plan = Plan(0)
         plan.set_solve_width(width)
+        plan.set_refinement(refine)
         plan.set_chol(L, problem.dense_pattern(m))
         if thr is not None:
             plan.set_growth_max(thr)
@@ -369,7 +372,111 @@ def check_solve_widths(m, thr, seed=0):
         prof = plan.kprof_summary()
         plan.kprof(False)
         nl = sum(v[0] for k, v in prof.items() if k.startswith("k_sfw") or k.startswith("k_sbw"))
-        assert nl == len(rhss) * 2 * (2 * nsb - 1), (width, prof)
+        lean, robust = 2 * (2 * nsb - 1), 2 * (2 * nsb - 1) + 8 * nsb
+        if refine == 2:
+            assert nl == len(rhss) * robust, (width, refine, prof)
+        elif refine == 1 and thr is not None and bad > 0:
+            # the download after the first solve made the note visible (the emulator runs a launch to its end at once: there the
+            # first solve's backward sweep already sees the note its forward sweep left)
+            assert lean + (len(rhss) - 1) * robust <= nl <= len(rhss) * robust, (width, refine, prof)
+        else:
+            assert nl == len(rhss) * lean, (width, refine, prof)
         for y, want in zip(ys, wants):
-            assert relerr(y, want) < 1e-9, (width, relerr(y, want))
+            assert relerr(y, want) < 1e-9, (width, refine, relerr(y, want))
         plan.close()
+
+
+def check_refined_solve_accuracy(m=320, seed=3, glo=1e5, ghi=1e7, cancelling=False):
+    """An ILL-CONDITIONED unit lower factor (growth max|inv(L)| max|L| between the default bound 1e4 and 1e8, as in the late iterations of an
+    interior-point run): the solve by substitution (sdm_plan_set_refinement mode 0), by the explicit inverse refined twice against the
+    factor (mode 2) and by the bare inverse (bound lifted), each against the solution in extended precision.  The refined result is as
+    accurate as the substitution it replaces (cancelling: a right-hand side L * ones, for which inv(L) b cancels by the size of inv(L)'s
+    entries -- there the bare inverse is up to 10x worse than either); the errors are returned for the record."""
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    G = np.tril(rng.standard_normal((m, m)), -1)
+    d = 0.5 + rng.random(m)
+    b = rng.standard_normal(m)
+
+    def make(alpha, mode, bound):
+        Lv = np.eye(m) + alpha * G
+        plan = Plan(0)
+        plan.set_refinement(mode)
+        if bound is not None:
+            plan.set_growth_max(bound)
+        plan.set_chol(problem.dense_symbolic(m), problem.dense_pattern(m))
+        plan.load_factor(sp.csc_matrix(np.tril(np.where(Lv != 0, Lv, 0.0)) + 0.0 * np.tril(np.ones((m, m)))), d)
+        return plan, Lv
+
+    alpha = 0.02
+    for _ in range(40):                                     # (growth rises monotonically with alpha)
+        plan, Lv = make(alpha, 0, None)
+        growth = plan.solve_stats()[2]
+        plan.close()
+        if glo <= growth <= ghi:
+            break
+        alpha *= 1.15 if growth < glo else 0.93
+    assert glo <= growth <= ghi, growth
+    if cancelling:                                          # b = L * ones: inv(L) b cancels from the size of inv(L)'s entries down to 1
+        b = np.asarray(Lv.astype(np.longdouble) @ np.ones(m, dtype=np.longdouble), dtype=np.float64)
+    Lx = Lv.astype(np.longdouble)
+    y = b.astype(np.longdouble).copy()
+    for i in range(m):
+        y[i] -= Lx[i, :i] @ y[:i]
+    z = y / d.astype(np.longdouble)
+    for i in range(m - 1, -1, -1):
+        z[i] -= Lx[i + 1:, i] @ z[i + 1:]
+    want = z
+    errs = {}
+    for name, mode, bound in (("substitution", 0, None), ("refined", 2, None), ("bare_inverse", 0, 1e300)):
+        plan, _ = make(alpha, mode, bound)
+        nb, bad, g = plan.solve_stats()
+        assert bad == (0 if bound else 1), (name, bad)
+        plan.upload("rhs", b); plan.ldlsolve()
+        got = plan.download("y").astype(np.longdouble)
+        errs[name] = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+        plan.close()
+    # (same accuracy class: both are bounded by eps * | |inv(L)| |L| |x| |, with different constants and summation orders)
+    assert errs["refined"] <= 8 * errs["substitution"] + 4e-15, (growth, errs)
+    return growth, errs
+
+
+def check_refinement_prediction(m=300):
+    """sdm_plan_set_refinement mode 1 across factorisations: the first solve that meets a block beyond the bound substitutes and leaves a
+    note, the later ones of that factorisation refine; the next factorisation takes the note as its prediction (its first solve
+    refines at once); when the factors are within the bound again, one factorisation later the extra launches are gone."""
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    rng = np.random.default_rng(m)
+    Lv = np.tril(rng.standard_normal((m, m)) * (0.5 / np.sqrt(m)), -1) + np.eye(m)
+    X = Lv @ np.diag(0.5 + rng.random(m)) @ Lv.T
+    b = rng.standard_normal(m)
+    want = np.linalg.solve(X, b)
+    plan = Plan(0)
+    plan.set_chol(problem.dense_symbolic(m), problem.dense_pattern(m))
+    plan.upload("ada", X.ravel(order="F")); plan.upload("rhs", b)
+    lean, robust = 2, 10                                              # one super-block: launches per solve
+
+    def solves(n):
+        counts = []
+        for _ in range(n):
+            plan.kprof(True); plan.ldlsolve(); y = plan.download("y"); prof = plan.kprof_summary(); plan.kprof(False)
+            assert relerr(y, want) < 1e-9
+            counts.append(sum(v[0] for k, v in prof.items() if k.startswith("k_sfw") or k.startswith("k_sbw")))
+        return counts
+    plan.blkchol(None, False)
+    assert solves(2) == [lean, lean]                                  # within the bound
+    plan.set_growth_max(0.0)
+    plan.blkchol(None, False)
+    c = solves(3)
+    assert c[0] in (lean, (lean + robust) // 2) and c[1:] == [robust, robust], c     # (the emulator's backward sweep already sees the forward sweep's note)
+    plan.blkchol(None, False)
+    assert solves(2) == [robust, robust]                              # predicted from the factorisation before
+    plan.set_growth_max(1e4)
+    plan.blkchol(None, False)
+    assert solves(2) == [robust, robust]                              # still predicted (nothing is noted any more)
+    plan.blkchol(None, False)
+    assert solves(2) == [lean, lean]
+    plan.close()

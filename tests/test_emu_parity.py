@@ -430,6 +430,17 @@ def test_solve_widths(m, thr):
     helpers.check_solve_widths(m, thr)
 
 
+@pytest.mark.parametrize("m,seed,glo,ghi,cancelling", [(320, 3, 1e5, 1e7, False), (520, 7, 3e6, 5e7, False), (520, 7, 3e6, 5e7, True), (600, 11, 3e8, 8e9, False)])
+def test_refined_solves_are_as_accurate_as_substitution(m, seed, glo, ghi, cancelling):
+    """Super-blocks beyond the growth bound: explicit inverse + two refinement steps against the factor (k_sfw_resid / k_sbw_resid)
+    give the accuracy of the substitution they replace -- measured against an extended-precision solve on ill-conditioned factors."""
+    helpers.check_refined_solve_accuracy(m, seed, glo, ghi, cancelling)
+
+
+def test_refinement_launches_follow_the_conditioning_of_the_factors():
+    helpers.check_refinement_prediction()
+
+
 def test_blocking_blkchol_recovers_from_a_starved_one_launch_level(refmex):
     """sdm_plan_blkchol_wait (what blkchol.mex and sdm_blkchol call): a one-launch level whose workgroups could not all become
     resident raises the plan's time-out flag; the factorisation is repeated once on the launch-per-panel path and the plan

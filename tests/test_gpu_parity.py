@@ -625,6 +625,19 @@ def test_one_launch_front_under_uneven_load(refmex):
         assert np.array_equal(pl.download("lpr"), l) and np.array_equal(pl.download("d"), d)
 
 
+@pytest.mark.parametrize("m,seed,glo,ghi,cancelling", [(320, 3, 1e5, 1e7, False), (520, 7, 3e6, 5e7, False), (1500, 9, 1e5, 5e7, False), (320, 3, 1e5, 1e7, True), (520, 7, 3e6, 5e7, True), (600, 11, 3e8, 8e9, False)])
+def test_refined_solves_are_as_accurate_as_substitution(m, seed, glo, ghi, cancelling):
+    """Ill-conditioned factors (growth 1e5 .. 5e7): inverse + two refinement steps against the factor as accurate as substitution
+    (extended-precision reference); see helpers.check_refined_solve_accuracy."""
+    growth, errs = helpers.check_refined_solve_accuracy(m, seed, glo, ghi, cancelling)
+    print("growth %.2e:" % growth, errs)
+
+
+def test_refinement_launches_follow_the_conditioning_of_the_factors():
+    helpers.check_refinement_prediction()
+    helpers.check_refinement_prediction(700)
+
+
 @pytest.mark.parametrize("busy", [216, 232])
 def test_one_launch_front_starved_by_another_process(refmex, busy):
     """ANOTHER PROCESS holds `busy` of the 256 compute units for 3 s (tests/gpuhog: one idle workgroup per unit, pinned there by its LDS

@@ -325,7 +325,7 @@ def profile_unit(plan, P, ud, nprof):
                         "dependency_chain": f"{nlaunch:.0f} dependent launches per solve x measured {1e6 * t_solve / max(nlaunch, 1):.2f} us per launch "
                                             "(launch boundary + the launch's own streaming)",
                         "super_block_width": plan.solve_width(),
-                        "super_blocks": nb, "blocks_on_substitution_fallback": nbad, "max_growth": growth},
+                        "super_blocks": nb, "blocks_beyond_growth_bound": nbad, "max_growth": growth},
               "factor": {"flops": fac_flops, "achieved_TFLOPs": fac_flops / (ph[1] * 1e-3) / 1e12,
                          "frac_of_fp64_matrix_peak": fac_flops / (ph[1] * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFS}}
     return roof, phases
@@ -382,15 +382,17 @@ def stage1_flops(P):
     return tot
 
 
-def measure_config(name, device, steps, warmup, nprof, mex_units=0, growth_max=None):
+def measure_config(name, device, steps, warmup, nprof, mex_units=0, growth_max=None, refine=1):
     """One of the other BASELINE configs, measured briefly in this process: ms/unit, dominant kernel, solve rate.  growth_max: the
-    bound beyond which a super-block of the solves falls back to substitution (0 = every block substitutes)."""
+    bound beyond which a super-block of the solves is no longer applied as its bare inverse (0 = every block is beyond it); refine:
+    what happens to those blocks (sdm_plan_set_refinement: 1 = inverse + iterative refinement, the default; 0 = substitution)."""
     try:
         t0 = time.perf_counter()
         P, L, ADA, Q, d, ud, rhs, qpr, note = build_workload(name, 0)
         plan = make_plan(device, P, L, ADA, Q, d, ud, rhs, qpr)
         if growth_max is not None:
             plan.set_growth_max(growth_max)
+            plan.set_refinement(refine)
         plan._xsuper = np.asarray(L["xsuper"]).ravel().astype(np.int64)
         step = unit_fn(plan)
         el = time_steps(plan, step, steps, warmup)
@@ -407,7 +409,8 @@ def measure_config(name, device, steps, warmup, nprof, mex_units=0, growth_max=N
         if mexleg is not None:
             out["mex_inclusive"] = mexleg
         if growth_max is not None:
-            out["workload"] = f"{name} (solves with growth_max = {growth_max:g}: the other side of the explicit-inverse / substitution cliff)"
+            out["workload"] = (f"{name} (solves with growth_max = {growth_max:g}: every super-block beyond the bound, as in the last iterations of a run; " +
+                               ("inverse + two refinement steps against the factor)" if refine else "substituted by one workgroup: sdm_plan_set_refinement(0))"))
         plan.close()
         return out
     except Exception as e:  # never break the bench line
@@ -737,6 +740,7 @@ def main():
                 # the headline scaling sits just under the growth bound of the explicit inverses (max_growth 9.6e3 against 1e4): the same unit
                 # with every super-block on the substitution path
                 others.append(measure_config("control07", local_rank, 100, 5, 20, 0, growth_max=0.0))
+                others.append(measure_config("control07", local_rank, 30, 3, 10, 0, growth_max=0.0, refine=0))
         mult = 1 if (shard_cols or world == 1) else world
         out = {
             "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": mult * args.steps / elapsed, "unit": "IPM iters/s",

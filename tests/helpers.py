@@ -348,7 +348,8 @@ def check_solve_widths(m, thr, seed=0):
     while wauto < m and wauto < 2048:
         wauto *= 2
     widths = [0] + [w for w in (256, 512, 1024) if w < wauto]
-    for width, refine in [(w, r) for w in widths for r in ((1,) if thr is None else (0, 1, 2))]:
+    # (all three refinement modes at the automatic width, the default mode at the others)
+    for width, refine in [(w, r) for w in widths for r in ((1,) if thr is None or w != 0 else (0, 1, 2))]:
         plan = Plan(0)
         plan.set_solve_width(width)
         plan.set_refinement(refine)

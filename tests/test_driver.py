@@ -127,7 +127,9 @@ def test_loop_restatement_reproduces_the_reference_objectives(name):
 def test_loop_on_the_emulated_library_follows_the_reference_log(name, tier):
     from driver import sedumi_loop as sl
     helpers.use_emu()
-    r = run(name, sl.HipHot() if tier == "mex" else sl.PlanHot())
+    # (arch0's 32 iterations with every PCG step's Amul / vecsym / psdscale emulated take two minutes: here its PCG operations stay on
+    # the host -- nb and quantum pin them under the emulator, all four problems on the GPU)
+    r = run(name, sl.HipHot() if tier == "mex" else sl.PlanHot(device_ops=name != "arch0"))
     check_objectives(name, r)
     check_log(name, r, reference_run(name))
 

@@ -430,7 +430,7 @@ def test_solve_widths(m, thr):
     helpers.check_solve_widths(m, thr)
 
 
-@pytest.mark.parametrize("m,seed,glo,ghi,cancelling", [(320, 3, 1e5, 1e7, False), (520, 7, 3e6, 5e7, False), (520, 7, 3e6, 5e7, True), (600, 11, 3e8, 8e9, False)])
+@pytest.mark.parametrize("m,seed,glo,ghi,cancelling", [(320, 3, 1e5, 1e7, False), (400, 7, 3e6, 5e7, True), (400, 11, 3e8, 8e9, False)])
 def test_refined_solves_are_as_accurate_as_substitution(m, seed, glo, ghi, cancelling):
     """Super-blocks beyond the growth bound: explicit inverse + two refinement steps against the factor (k_sfw_resid / k_sbw_resid)
     give the accuracy of the substitution they replace -- measured against an extended-precision solve on ill-conditioned factors."""

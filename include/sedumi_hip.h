@@ -363,9 +363,12 @@ int sdm_plan_set_growth_max(sdm_plan *p, double growth_max);
  * run -- need not fall back to substitution (one workgroup, hundreds of microseconds): the solve can apply the explicit inverse
  * and refine the block's result twice against the factor itself (r = t - L_PP y, y += inv(L_PP) r: four short launches per
  * block and sweep), which restores the accuracy of the substitution.  mode 1 (default): the refinement launches are planned
- * while such blocks keep turning up (every sweep that meets one leaves a note in pinned host memory; the host reads it
- * without synchronising and carries it over to the solves of the next factorisation, so only the first solve that meets
- * such a block -- and solves enqueued before the note arrives -- substitute); mode 0: never (always substitute); mode 2: always.  Blocks beyond refine_max, or with a growth that is not a number, are always substituted. */
+ * while such blocks keep turning up: every sweep is numbered, a launch that meets such a block leaves the sweep's number in
+ * pinned host memory, the first launch of every sweep the number of the sweep before it; the host reads both when it
+ * enqueues the next sweep (no synchronisation) and switches the refinement launches on when the latest sweep known to have
+ * run met such a block, off when two sweeps have run since the last one that did.  So only the first sweeps that meet such a
+ * block -- those enqueued before the news arrives -- substitute.  mode 0: never (always substitute); mode 2: always.
+ * Blocks beyond refine_max, or with a growth that is not a number, are always substituted. */
 int sdm_plan_set_refinement(sdm_plan *p, int mode, double refine_max);
 /* on = 0: the NEXT sdm_plan_set_chol plans every front on the launch-per-panel path (k_ldl_panel) -- no level is factored
  * by the one-launch kernel (k_ldl_front) and no inverse is built beside it.  Default 1.  The comparison switch of the tests

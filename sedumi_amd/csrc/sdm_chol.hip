@@ -1683,7 +1683,6 @@ void chol_begin(sdm_plan *P, const double canceltol, const double maxu, const do
   hipStream_t st = P->stream;
   const int m = (int)C.m;
   P->factored = false;               // until the launches below have all been issued: a factorisation that throws leaves no factor behind
-  if (C.noted.host) { C.refine_predicted = *(volatile int *)C.noted.host != 0; *(volatile int *)C.noted.host = 0; }   // (sdm_plan.h: refine_mode)
 #ifndef SDM_EMU
   SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_RIDE));
   SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FRONT_LDS));

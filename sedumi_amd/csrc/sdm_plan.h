@@ -96,8 +96,8 @@ struct HostFlag {
   ~HostFlag() { if (host) (void)hipHostFree(host); }
   void ensure() {
     if (host) return;
-    SDM_HIP_CHECK(hipHostMalloc((void **)&host, sizeof(int), 0));
-    *host = 0;
+    SDM_HIP_CHECK(hipHostMalloc((void **)&host, 4 * sizeof(int), 0));      // (CholPlan::noted uses two of them)
+    for (int i = 0; i < 4; i++) host[i] = 0;
   }
   int *dev() {
     ensure();
@@ -205,14 +205,16 @@ struct CholPlan {
   double growth_max = 1e4;           // a super-block whose max|inv| * max|L| exceeds this is solved by substitution
   double growth_used = 1e4;          // the bound in force at the last solve_prepare
   // blocks beyond growth_max but within refine_max: inverse + REFINE_STEPS steps of iterative refinement against the factor
-  // (k_sfw_resid / k_sbw_resid) when the solves run their refinement launches.  refine_mode 1 (default): they do while such blocks
-  // keep turning up -- every sweep that meets one leaves a note in pinned host memory (`noted`, read without synchronising); a
-  // factorisation takes the note as its prediction for its own solves (refine_predicted) and clears it, so a run whose factors
-  // are well conditioned again drops the extra launches.  The first solve that meets such a block -- and any solve enqueued
-  // before the note arrives -- substitutes.  0: never refine; 2: always.
+  // (k_sfw_resid / k_sbw_resid) when the sweeps run their refinement launches.  refine_mode 1 (default): they do while such blocks
+  // keep turning up.  Every sweep has a number (sweep_seq); a launch that meets such a block stores the sweep's number in
+  // noted[0], the last diagonal-block launch of every sweep stores it in noted[1] (pinned host memory, read without
+  // synchronising when the next sweep is enqueued): refinement is switched ON when the latest sweep known to have run (or the one
+  // before it) met such a block, OFF when two sweeps have run since the last one that did, and stays as it is otherwise.  The
+  // first sweeps that meet such a block -- those enqueued before the news arrives -- substitute.  0: never refine; 2: always.
   double refine_max = 1e10;
   int refine_mode = 1;
-  bool refine_predicted = false;
+  bool refine_on = false;
+  int sweep_seq = 0;
   HostFlag noted;
 };
 

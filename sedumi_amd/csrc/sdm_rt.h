@@ -34,7 +34,7 @@ inline unsigned long long sdm_load_wt_u64(const unsigned long long *p) { return 
 inline int sdm_signal_load(const int *p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 inline void sdm_raise_flag(int *p) { __atomic_store_n(p, 1, __ATOMIC_SEQ_CST); emu_report_timeout(); }
 inline bool sdm_flag_raised(const int *p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST) != 0; }
-inline void sdm_host_note(int *p) { __atomic_store_n(p, 1, __ATOMIC_SEQ_CST); }
+inline void sdm_host_note(int *p, int v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 #define SDM_UNIFORM_INT(x) (x)
 #define SDM_ACQUIRE_FENCE() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define SDM_COMPILER_BARRIER() __asm__ __volatile__("" ::: "memory")
@@ -81,7 +81,7 @@ __device__ __forceinline__ int sdm_signal_load(const int *p) { return __hip_atom
 __device__ __forceinline__ void sdm_raise_flag(int *p) { __hip_atomic_store(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ bool sdm_flag_raised(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0; }
 // a note for the host in pinned memory that is no error (read without synchronising: late is fine)
-__device__ __forceinline__ void sdm_host_note(int *p) { __hip_atomic_store(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sdm_host_note(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 #define SDM_ACQUIRE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 // a wave-uniform integer the compiler cannot prove uniform (e.g. threadIdx.x >> 6): moved to a scalar register, so that
 // addresses built from it stay scalar and loads through them become s_load

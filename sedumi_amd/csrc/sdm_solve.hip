@@ -52,7 +52,7 @@ void solve_build(sdm_plan *P) {
   int W = C.sbw_req;
   if (W == 0) { W = SBW_MIN; while (W < C.maxns && W < SBW_MAX) W *= 2; }
   C.sbw = W;
-  C.noted.ensure(); *(volatile int *)C.noted.host = 0; C.refine_predicted = false;   // a new solve: no ill-conditioned block met yet
+  C.noted.ensure(); C.noted.host[0] = C.noted.host[1] = 0; C.refine_on = false; C.sweep_seq = 0;   // a new solve: no ill-conditioned block met yet
   C.sn_soff.assign(nsuper, 0); C.sn_sld.assign(nsuper, 0); C.sn_sboff.assign(nsuper, 0);
   std::vector<int> i128;
   std::vector<std::vector<int>> stage(2 * SINV_MAXLEV);              // combine tiles per stage st = 2 * level + (0: T, 1: X)
@@ -970,12 +970,14 @@ k_sfw_init(FrontTab tab, const int *list, double *wv, const double *src, const i
 __global__ void __launch_bounds__(ST)
 k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTab tab, const int *list, const double *wv, const double *src,
            const int *perm, double *y, const unsigned long long *sb_g, double thr, int Pb, int gather0, FwBatch bt,
-           double *zdiv, const double *dscale, int W, int mode, double thr2, const double *resid, int *noted) {
+           double *zdiv, const double *dscale, int W, int mode, double thr2, const double *resid, int *noted, int seq, int mark) {
   // mode 0: the sweep as planned for well-conditioned factors (blocks beyond the bound are substituted by workgroup 0);
   // mode 1: the first of the refinement launches: blocks of kind 1 are applied as their inverse like the good ones;
   // mode 2: blocks of kind 1 only:  y_P += inv(L_PP) r_P  with the residual r_P = t_P - L_PP y_P of k_sfw_resid (`resid`)
   SDM_DYN_SMEM(smem);                                                // (the rare substitution fallback only: W + BSC * BSP doubles -- as static
   double *xs = (double *)smem, *Sd = xs + W;                          // arrays sized for the widest block they cost every launch 49 KB per workgroup)
+  // (the first diagonal-block launch of a sweep tells the host that the sweep before it has run: CholPlan::noted)
+  if (mark >= 0 && noted && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) sdm_host_note(noted + 1, mark);
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), first = FT(first);
   const int c0 = Pb * W;
@@ -992,7 +994,7 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTa
   const bool gather = gather0 && Pb == 0 && mode != 2;
   const int *pp = perm + first + c0;
   // (a block of kind 1 met by a sweep: the host plans the refinement launches while such blocks keep turning up -- solve_refines)
-  if (cls == 1 && mode != 2 && blockIdx.x == 0 && tid == 0 && noted) sdm_host_note(noted);
+  if (cls == 1 && mode != 2 && blockIdx.x == 0 && tid == 0 && noted) sdm_host_note(noted, seq);
   if (cls == 2 || (cls == 1 && mode == 0)) {
     if (blockIdx.x != 0) return;
     for (int c = tid; c < nb; c += ST) xs[c] = gather ? src[pp[c]] : a[c];
@@ -1167,10 +1169,11 @@ k_sbw_init(const double *__restrict__ F, FrontTab tab, const int *list, double *
 // by workgroup 0.
 __global__ void __launch_bounds__(ST)
 k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, const double *y, double *xfin, double *yout,
-           const int *perm, const unsigned long long *sb_g, double thr, int Q, int W, int mode, double thr2, const double *wv, int *noted) {
+           const int *perm, const unsigned long long *sb_g, double thr, int Q, int W, int mode, double thr2, const double *wv, int *noted, int seq, int mark) {
   // mode 0 / 1 / 2 as in k_sfw_diag; mode 2:  x_Q += inv(L_QQ)' r_Q  with the residual of k_sbw_resid (in the front's slice of wv)
   SDM_DYN_SMEM(smem);
   double *xs = (double *)smem, *Sd = xs + W;
+  if (mark >= 0 && noted && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sdm_host_note(noted + 1, mark);
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), first = FT(first);
   const int rb = Q * W;
@@ -1181,7 +1184,7 @@ k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
   const int cls = sb_class(sb_g, FT(sboff) + Q, thr, thr2);
   if (mode == 2 && cls != 1) return;
   const double *vp = mode == 2 ? wv + FT(woff) + rb : y + first + rb;
-  if (cls == 1 && mode != 2 && blockIdx.x == 0 && tid == 0 && noted) sdm_host_note(noted);
+  if (cls == 1 && mode != 2 && blockIdx.x == 0 && tid == 0 && noted) sdm_host_note(noted, seq);
   if (cls == 2 || (cls == 1 && mode == 0)) {
     if (blockIdx.x != 0) return;
     for (int i = tid; i < nb; i += ST) xs[i] = vp[i];
@@ -1328,8 +1331,13 @@ void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growt
 // now, without waiting for the device)
 constexpr int REFINE_STEPS = 2;
 static bool solve_refines(CholPlan &C) {
-  if (C.refine_mode == 2) return true;
-  return C.refine_mode == 1 && (C.refine_predicted || (C.noted.host && *(volatile int *)C.noted.host != 0));
+  if (C.refine_mode != 1) return C.refine_mode == 2;
+  if (C.noted.host) {
+    const int done = ((volatile int *)C.noted.host)[1], bad = ((volatile int *)C.noted.host)[0];   // (done first: a sweep's own marks precede the next sweep's)
+    if (bad > 0 && bad >= done) C.refine_on = true;                  // the latest sweep known to have run (or the one in flight) met such a block
+    else if (done - bad >= 2) C.refine_on = false;                   // two sweeps have run since the last one that did
+  }
+  return C.refine_on;
 }
 // forward sweeps of nrhs right-hand sides side by side (grid.z): rhs + z*rhs_stride -> y + z*y_stride (permuted order);
 // wv = update-vector scratch of wsize doubles per right-hand side
@@ -1345,6 +1353,8 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
   if (l1 < 0) l1 = C.nlevels;
   const bool refine = nrhs == 1 && solve_refines(C);
   int *noted = C.refine_mode == 1 ? C.noted.dev() : nullptr;
+  const int seq = ++C.sweep_seq;
+  bool marked = false;
   for (int l = std::max(l0, 0); l < std::min(l1, C.nlevels); l++) {
     const SolveLevel &L = C.slev[l];
     if (L.nfronts == 0) continue;
@@ -1357,12 +1367,13 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
       const int nbmax = std::min(W, L.maxns - Pb * W);
       const dim3 gdiag(W <= 256 ? (nbmax + 15) / 16 : (nbmax + 3) / 4, L.nfronts, nrhs);
       SDM_KLAUNCH(P, k_sfw_diag, gdiag, dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.ST.p, tab, list, wv, rhs,
-                  C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W, refine ? 1 : 0, C.refine_max, (const double *)nullptr, noted);
+                  C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W, refine ? 1 : 0, C.refine_max, (const double *)nullptr, noted, seq, marked ? -1 : seq - 1);
+      marked = true;
       for (int it = 0; refine && it < REFINE_STEPS; it++) {            // (blocks within the bound leave these launches at once)
         SDM_KLAUNCH(P, k_sfw_resid, dim3((nbmax + 63) / 64, L.nfronts), dim3(RT), 0, C.fronts.p, tab, list, wv, rhs, C.d_perm.p, y, C.xfin.p, C.sb_g.p, thr,
                     C.refine_max, Pb, gather, W);
         SDM_KLAUNCH(P, k_sfw_diag, gdiag, dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.ST.p, tab, list, wv, rhs,
-                    C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W, 2, C.refine_max, (const double *)C.xfin.p, (int *)nullptr);
+                    C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W, 2, C.refine_max, (const double *)C.xfin.p, (int *)nullptr, seq, -1);
       }
       const int assign0 = (gather && Pb == 0) ? 1 : 0;
       if (L.maxns > (Pb + 1) * W)                                    // the fronts' own rows of later super-blocks
@@ -1385,6 +1396,8 @@ static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double 
   if (l1 < 0) l1 = C.nlevels;
   const bool refine = solve_refines(C);
   int *noted = C.refine_mode == 1 ? C.noted.dev() : nullptr;
+  const int seq = ++C.sweep_seq;
+  bool marked = false;
   for (int l = std::min(l1, C.nlevels) - 1; l >= std::max(l0, 0); l--) {
     const SolveLevel &L = C.slev[l];
     if (L.nfronts == 0) continue;
@@ -1396,11 +1409,12 @@ static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double 
       const int nbmax = std::min(W, L.maxns - Q * W);
       const dim3 gdiag(W <= 256 ? (nbmax + 15) / 16 : (nbmax + 3) / 4, L.nfronts);
       SDM_KLAUNCH(P, k_sbw_diag, gdiag, dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
-                  C.d_perm.p, C.sb_g.p, thr, Q, W, refine ? 1 : 0, C.refine_max, (const double *)nullptr, noted);
+                  C.d_perm.p, C.sb_g.p, thr, Q, W, refine ? 1 : 0, C.refine_max, (const double *)nullptr, noted, seq, marked ? -1 : seq - 1);
+      marked = true;
       for (int it = 0; refine && it < REFINE_STEPS; it++) {
         SDM_KLAUNCH(P, k_sbw_resid, dim3((nbmax + 3) / 4, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, C.wvec.p, C.sb_g.p, thr, C.refine_max, Q, W);
         SDM_KLAUNCH(P, k_sbw_diag, gdiag, dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
-                    C.d_perm.p, C.sb_g.p, thr, Q, W, 2, C.refine_max, (const double *)C.wvec.p, (int *)nullptr);
+                    C.d_perm.p, C.sb_g.p, thr, Q, W, 2, C.refine_max, (const double *)C.wvec.p, (int *)nullptr, seq, -1);
       }
       if (Q > 0) SDM_KLAUNCH(P, k_sbw_step, dim3(Q * (W / 4), L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, Q, W);
     }

@@ -445,9 +445,9 @@ def check_refined_solve_accuracy(m=320, seed=3, glo=1e5, ghi=1e7, cancelling=Fal
 
 
 def check_refinement_prediction(m=300):
-    """sdm_plan_set_refinement mode 1 across factorisations: the first solve that meets a block beyond the bound substitutes and leaves a
-    note, the later ones of that factorisation refine; the next factorisation takes the note as its prediction (its first solve
-    refines at once); when the factors are within the bound again, one factorisation later the extra launches are gone."""
+    """sdm_plan_set_refinement mode 1 over a sequence of factorisations: the first sweeps that meet a block beyond the bound substitute
+    (and say so to the host), the later ones refine -- also across the next factorisations -- and once the factors are within the
+    bound again the extra launches are dropped after a few sweeps."""
     from sedumi_amd import problem
     from sedumi_amd.plan import Plan
     rng = np.random.default_rng(m)
@@ -472,12 +472,11 @@ def check_refinement_prediction(m=300):
     plan.set_growth_max(0.0)
     plan.blkchol(None, False)
     c = solves(3)
-    assert c[0] in (lean, (lean + robust) // 2) and c[1:] == [robust, robust], c     # (the emulator's backward sweep already sees the forward sweep's note)
+    assert lean <= c[0] <= robust and c[1:] == [robust, robust], c    # (the first solve's sweeps may or may not have the news yet)
     plan.blkchol(None, False)
-    assert solves(2) == [robust, robust]                              # predicted from the factorisation before
+    assert solves(2) == [robust, robust]                              # stays on across factorisations
     plan.set_growth_max(1e4)
     plan.blkchol(None, False)
-    assert solves(2) == [robust, robust]                              # still predicted (nothing is noted any more)
-    plan.blkchol(None, False)
-    assert solves(2) == [lean, lean]
+    c = solves(4)
+    assert c[0] >= c[1] >= c[2] >= c[3] and c[2:] == [lean, lean], c  # dropped after a few clean sweeps
     plan.close()

@@ -313,6 +313,13 @@ def profile_unit(plan, P, ud, nprof):
             try:
                 roof["traffic_from_committed_profile"] = {"bytes_per_launch": json.load(open(pmcs[-1])).get(dom),
                                                           "source": "profiles/" + os.path.basename(pmcs[-1]) + " (rocprofv3 PMC passes of an earlier run of this command, not measured in this run)"}
+                if dom in ("k_ldl_front", "k_ldl_panel") and roof["traffic_from_committed_profile"]["bytes_per_launch"]:
+                    # what the factor kernel has to move at least: every front read once and written once, per launch
+                    nsup = int(np.asarray(plan_xsuper(plan)).size - 1)
+                    fs = float(np.sum(plan.front_layout(nsup)["fsize"]))
+                    alg = 16.0 * fs / max(roof["launches_per_step"], 1e-9)
+                    roof["traffic_from_committed_profile"]["algorithmic_bytes_per_launch"] = alg
+                    roof["traffic_from_committed_profile"]["traffic_over_algorithmic_bytes"] = roof["traffic_from_committed_profile"]["bytes_per_launch"] / alg
             except Exception:
                 pass
     nlaunch = sum(v[0] for k, v in prof.items() if k.startswith("k_sfw") or k.startswith("k_sbw")) / max(1, nprof * NSOLVE)

@@ -34,7 +34,8 @@ while time.time() < t_end:
             plan.upload("absd", absd.ravel())
         plan.blkchol(pars, absd is not None)
         (si, _), (ai, _) = plan.pivots()
-        o = (None, plan.download("d"), sp.csc_matrix((np.ones(si.size), si, [0, si.size]), shape=(m, 1)), sp.csc_matrix((np.ones(ai.size), ai, [0, ai.size]), shape=(m, 1)))
+        o = (None, plan.download("d").reshape(-1, 1), sp.csc_matrix((np.ones(si.size), si, [0, si.size]), shape=(m, 1)), sp.csc_matrix((np.ones(ai.size), ai, [0, ai.size]), shape=(m, 1)))
+        plan.close()
     else:
         o = mex.blkchol(*args)
     ok = np.array_equal(o[2].indices, rr[2].indices) and np.array_equal(o[3].indices, rr[3].indices) and relerr(o[1], rr[1]) < 1e-8

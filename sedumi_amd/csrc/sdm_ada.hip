@@ -671,8 +671,11 @@ k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0
 // fixed set of 16x16 tiles of Z in registers.  The targets are read off the finished Z in LDS:
 // z(r,c) = (Z[r][c] + Z[c][r]) / 2  -- the same two sums as spscale.c:283-304.
 __global__ void __launch_bounds__(64 * S1_WAVES, 4)
-k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0, const int *order) {
+k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0, const int *order, double *zero_ptr, long long zero_n) {
   SDM_DYN_SMEM(smem);
+  // (a zero LP / Lorentz part of ADA': cleared here, by everybody a slice, instead of by a memset launch of its own in front of
+  // this one -- stage 2, the first reader, is a launch later)
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += (long long)gridDim.x * blockDim.x) zero_ptr[i] = 0.0;
   const int task = order ? order[blockIdx.x] : blockIdx.x + task0;      // heaviest tasks first (full-range launches)
   const int n = T.t_n[task], nslot = T.t_nslot[task], ulen = T.t_ulen[task];
   const int np = (n + 15) & ~15, nt = np >> 4, ntile = nt * nt;
@@ -1073,6 +1076,13 @@ __global__ void k_diag(double *absd, const double *ada, const int64_t *ADAjc, co
 // ============================================================ host drivers
 // Column range [A.col0, A.col1) of ADA' (all columns by default): every stage below only touches those columns,
 // which is what lets the ranks of a job form disjoint column panels of one ADA' (sdm_plan_getada_cols).
+// the zero LP / Lorentz part of ADA' that ada_lq left to the next stage (AdaPlan::zero_ptr): cleared now, by a memset, unless
+// the stage-1 launch of ada_psd has taken it over.  Everything that reads or adds to ADA' calls this first.
+void ada_zero_flush(sdm_plan *P) {
+  AdaPlan &A = P->ada;
+  if (A.zero_ptr && A.zero_n > 0) SDM_HIP_CHECK(hipMemsetAsync(A.zero_ptr, 0, (size_t)A.zero_n * sizeof(double), P->stream));
+  A.zero_ptr = nullptr; A.zero_n = 0;
+}
 void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
   AdaPlan &A = P->ada;
   if (A.col1 <= A.col0) return;
@@ -1080,7 +1090,9 @@ void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
     // no LP / Lorentz nonzeros at all (e.g. MAXCUT): the LP part of ADA' is the zero matrix -- one memset of the
     // column panel instead of nnz(ADA') empty sparse dot products
     const sdm_int e0 = P->ada_jc[A.col0], e1 = P->ada_jc[A.col1];
-    if (e1 > e0) SDM_HIP_CHECK(hipMemsetAsync(ada + e0, 0, (size_t)(e1 - e0) * sizeof(double), P->stream));
+    ada_zero_flush(P);
+    if (e1 > e0) { A.zero_ptr = ada + e0; A.zero_n = (long long)(e1 - e0); }
+    if (!A.zero_defer) ada_zero_flush(P);                            // (only sdm_plan_getada's own sequence lets the next stage take it over)
     return;
   }
   if (A.nlq > 0)
@@ -1110,6 +1122,7 @@ void ada_datq(sdm_plan *P) {
 void ada_q(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate) {
   AdaPlan &A = P->ada;
   if (A.lorN == 0 || A.nnzQ == 0 || A.col1 <= A.col0) return;
+  ada_zero_flush(P);
   if (A.q_dense) {
     const int m = (int)A.m, nt = (m + TILE - 1) / TILE;
     SDM_HIP_CHECK(hipMemsetAsync(A.Q_d.p, 0, (size_t)A.lorN * (size_t)m * sizeof(double), P->stream));
@@ -1148,6 +1161,7 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
   AdaPlan &A = P->ada;
   hipStream_t st = P->stream;
   const int m = (int)A.m;
+  if (A.sdpN == 0 || sym_input || A.col1 <= A.col0) ada_zero_flush(P);
   if (A.sdpN == 0) {
     if (sym_input) {
       SDM_KLAUNCH(P, k_symmetrize, dim3(m), dim3(128), 0, A.symtmp.p, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_ADAT.p, m);
@@ -1165,6 +1179,7 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
   const size_t direct_lds = (size_t)(2 * A.sdpN + 2 * S1_DIRECT_MAXNZ * A.sdpN + 2) * sizeof(int) + (size_t)(2 * A.sdpN) * sizeof(long long) +
                             (size_t)(S1_DIRECT_MAXNZ * A.sdpN) * sizeof(double);
   const bool direct = A.thread_per_row && !A.ell_ok && A.sdpN == A.rsdpN && A.s1_maxnz <= S1_DIRECT_MAXNZ && direct_lds <= S1_DIRECT_LDS_MAX;
+  if (direct || ntask <= 0 || !(A.maxn <= S1_MAXN && A.sdpN == A.rsdpN)) ada_zero_flush(P);     // (only the matrix-core stage 1 takes the clearing over)
   if (direct) {
     if (sym_input) {
       SDM_KLAUNCH(P, k_symmetrize, dim3(m), dim3(128), 0, A.symtmp.p, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_ADAT.p, m);
@@ -1193,8 +1208,10 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
 #ifndef SDM_EMU
       if (lds > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage1_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
+      double *zp = A.zero_ptr; const long long zn = A.zero_n;         // (taken over from ada_lq: see ada_zero_flush)
+      A.zero_ptr = nullptr; A.zero_n = 0;
       SDM_KLAUNCH(P, k_psd_stage1_mfma, dim3((unsigned)ntask), dim3(64 * S1_WAVES), lds, T, A.udsqr.p, A.zbuf.p, task0,
-                  (ntask == (int)A.ntask) ? (const int *)A.t_order.p : (const int *)nullptr);
+                  (ntask == (int)A.ntask) ? (const int *)A.t_order.p : (const int *)nullptr, zp, zn);
     } else
     {
       // LDS per task: at least one slot (Y and D row, x2 for Hermitian); beyond that S1_GEN_LDS -- several tasks per CU

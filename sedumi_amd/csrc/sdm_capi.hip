@@ -161,9 +161,14 @@ int sdm_plan_getada(sdm_plan *p) {
   SDM_TRY
   if (!p->has_ada) throw std::runtime_error("sdm_plan_getada: no ADA data set");
   if (ada_lq_q(p, p->ada_val.p)) { ada_psd(p, p->ada_val.p, nullptr, false, true); return 0; }
-  ada_lq(p, p->ada_val.p, nullptr, false);
-  ada_q(p, p->ada_val.p, nullptr, true);
-  ada_psd(p, p->ada_val.p, nullptr, false);
+  p->ada.zero_defer = true;                  // (a zero LP / Lorentz part may be cleared by the stage-1 launch of ada_psd: ada_zero_flush)
+  try {
+    ada_lq(p, p->ada_val.p, nullptr, false);
+    ada_q(p, p->ada_val.p, nullptr, true);
+    ada_psd(p, p->ada_val.p, nullptr, false);
+  } catch (...) { p->ada.zero_defer = false; ada_zero_flush(p); throw; }
+  p->ada.zero_defer = false;
+  ada_zero_flush(p);
   SDM_CATCH
 }
 int sdm_plan_getdatq(sdm_plan *p) {

@@ -283,25 +283,27 @@ constexpr unsigned long long DT_SENTINEL = 0x7ff8dead5ed00001ull;     // what DT
 //   ub = max_j P(perm_j,perm_j) / maxu^2 ;  lb_j = max(abstol, canceltol * orgd_j)
 // ub[2] collects max_j as the bit pattern of a non-negative double (ordered like the unsigned integer: atomicMax is
 // exact and order independent); ub[1] = maxu; k_ldl_panel forms ub from them.  ub[2] is zeroed by the host before.
-__global__ void k_prep_pivots(int m, const double *ada, const int *asm_src, const int64_t *Ljc, const int *perm,
-                              const double *absd, int use_absd, double canceltol, double maxu, double abstol,
-                              double *lb, double *ub, int *pivstat, double *pivval, int nsuper, int *upd_cnt, int *diag_cnt,
-                              unsigned long long *sb_g, int nsbg, int *front_cnt, int nfc, unsigned long long *DTbits, int64_t ndt) {
-  __shared__ double red[256];
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
-  for (int64_t i = gid; i < ndt; i += gstride) DTbits[i] = DT_SENTINEL;                 // the data-tagged hand-over of the diagonal blocks (k_ldl_front)
-  for (int i = gid; i < nsuper; i += gstride) { upd_cnt[i] = 0; diag_cnt[i] = 0; }     // counters of k_ldl_panel
-  for (int i = gid; i < nfc; i += gstride) front_cnt[i] = 0;                            // counters of k_ldl_front
-  for (int i = gid; i < nsbg; i += gstride) sb_g[i] = 0ull;                             // growth records of the solve inverses (sdm_solve.hip)
+struct PrepArgs {
+  int m; const double *ada; const int *asm_src; const int64_t *Ljc; const int *perm; const double *absd; int use_absd;
+  double canceltol, maxu, abstol; double *lb, *ub; int *pivstat; double *pivval; int nsuper; int *upd_cnt, *diag_cnt;
+  unsigned long long *sb_g; int nsbg; int *front_cnt; int nfc; unsigned long long *DTbits; int64_t ndt;
+};
+// the work of workgroup `bx` of `nb`: re-arms counters / tags, thresholds of its columns; returns the largest diagonal entry it saw
+__device__ __forceinline__ double prep_pivots_part(const PrepArgs &A, int bx, int nb, double *red) {
+  const int gid = bx * blockDim.x + threadIdx.x, gstride = nb * blockDim.x;
+  for (int64_t i = gid; i < A.ndt; i += gstride) A.DTbits[i] = DT_SENTINEL;             // the data-tagged hand-over of the diagonal blocks (k_ldl_front)
+  for (int i = gid; i < A.nsuper; i += gstride) { A.upd_cnt[i] = 0; A.diag_cnt[i] = 0; }   // counters of k_ldl_panel
+  for (int i = gid; i < A.nfc; i += gstride) A.front_cnt[i] = 0;                        // counters of k_ldl_front
+  for (int i = gid; i < A.nsbg; i += gstride) A.sb_g[i] = 0ull;                         // growth records of the solve inverses (sdm_solve.hip)
   double mx = 0.0;
-  for (int j = gid; j < m; j += gstride) {
-    int s = asm_src[Ljc[j]];
-    double dj = s < 0 ? 0.0 : ada[s];
+  for (int j = gid; j < A.m; j += gstride) {
+    int s = A.asm_src[A.Ljc[j]];
+    double dj = s < 0 ? 0.0 : A.ada[s];
     if (dj > mx) mx = dj;
-    double org = use_absd ? absd[perm[j]] : dj;
-    double v = canceltol * org;
-    lb[j] = v > abstol ? v : abstol;
-    pivstat[j] = 0; pivval[j] = 0.0;
+    double org = A.use_absd ? A.absd[A.perm[j]] : dj;
+    double v = A.canceltol * org;
+    A.lb[j] = v > A.abstol ? v : A.abstol;
+    A.pivstat[j] = 0; A.pivval[j] = 0.0;
   }
   red[threadIdx.x] = mx;
   __syncthreads();
@@ -309,11 +311,49 @@ __global__ void k_prep_pivots(int m, const double *ada, const int *asm_src, cons
     if ((int)threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s];
     __syncthreads();
   }
+  return red[0];
+}
+__global__ void k_prep_pivots(PrepArgs A) {
+  __shared__ double red[256];
+  const double mx = prep_pivots_part(A, blockIdx.x, gridDim.x, red);
   if (threadIdx.x == 0) {
-    union { double d; unsigned long long u; } b; b.d = red[0];
-    atomicMax((unsigned long long *)&ub[2], b.u);
-    ub[1] = maxu;
+    union { double d; unsigned long long u; } b; b.d = mx;
+    atomicMax((unsigned long long *)&A.ub[2], b.u);
+    A.ub[1] = A.maxu;
   }
+}
+// k_assemble_full and k_prep_pivots as ONE launch (fronts small enough for the inverse map: the bench workloads): workgroups
+// [0, nprep) do the pivot bounds, the rest assemble.  The largest diagonal entry cannot be an atomicMax into a cell that this same
+// launch would have to clear first: every bounds workgroup leaves its maximum in `part`, the last one to finish (a ticket that
+// resets itself) takes the maximum of them -- order independent, like the atomicMax.
+__global__ void k_begin_factor(PrepArgs A, int nprep, double *part, int *ticket, double *F, const int *fsrc, int64_t fsize) {
+  if ((int)blockIdx.x >= nprep) {
+    int64_t t = (int64_t)((int)blockIdx.x - nprep) * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)((int)gridDim.x - nprep) * blockDim.x;
+    for (; t < fsize; t += stride) { const int s = fsrc[t]; F[t] = s < 0 ? 0.0 : A.ada[s]; }
+    return;
+  }
+  __shared__ double red[256];
+  __shared__ int last;
+  const double mx = prep_pivots_part(A, blockIdx.x, nprep, red);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = mx;
+    __threadfence();
+    last = atomicAdd(ticket, 1) == nprep - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  double m2 = 0.0;
+  for (int i = threadIdx.x; i < nprep; i += blockDim.x) { const double v = ((volatile double *)part)[i]; if (v > m2) m2 = v; }
+  __syncthreads();
+  red[threadIdx.x] = m2;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { A.ub[0] = 0.0; A.ub[1] = A.maxu; A.ub[2] = red[0]; *ticket = 0; }
 }
 
 // ---- extend-add: parent front += children's Schur complements.
@@ -1687,20 +1727,22 @@ void chol_begin(sdm_plan *P, const double canceltol, const double maxu, const do
   SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_RIDE));
   SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldl_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FRONT_LDS));
 #endif
-  if (C.d_asm_fsrc.n) {
-    SDM_KLAUNCH(P, k_assemble_full, dim3(grid1d(C.fsize, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_fsrc.p, (int64_t)C.fsize, C.ub.p);
-  } else {
-    SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), st));
-    SDM_KLAUNCH(P, k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
-               C.d_asm_dst.p, (int64_t)C.nnzL, C.ub.p);
-  }
   // (DT needs its sentinel only where k_ldl_front runs; the launch-per-panel levels wait on counters)
   bool any_persist = false;
   for (int l = 0; l < C.nlevels; l++) any_persist = any_persist || C.lev_persist[l];
   const int64_t ndt = any_persist ? C.tsize : 0;
-  SDM_KLAUNCH(P, k_prep_pivots, dim3(grid1d(std::max<int64_t>(m, ndt / 4), 256, 256)), dim3(256), 0, m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p,
-             P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, (int)C.nsuper, C.upd_cnt.p, C.diag_cnt.p,
-             C.sb_g.p, (int)C.sb_g.n, C.front_cnt.p, (int)C.front_cnt.n, (unsigned long long *)C.frontsT.p, ndt);
+  PrepArgs pa = {m, P->ada_val.p, C.d_asm_src.p, C.d_Ljc.p, C.d_perm.p, P->absd.p, use_absd, canceltol, maxu, abstol, C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p,
+                 (int)C.nsuper, C.upd_cnt.p, C.diag_cnt.p, C.sb_g.p, (int)C.sb_g.n, C.front_cnt.p, (int)C.front_cnt.n, (unsigned long long *)C.frontsT.p, ndt};
+  const int nprep = grid1d(std::max<int64_t>(m, ndt / 4), 256, 256);
+  if (C.d_asm_fsrc.n) {
+    if (!C.prep_part.p) { C.prep_part.alloc(256); C.prep_ticket.alloc(1); SDM_HIP_CHECK(hipMemsetAsync(C.prep_ticket.p, 0, sizeof(int), st)); }
+    SDM_KLAUNCH(P, k_begin_factor, dim3(nprep + grid1d(C.fsize, 256)), dim3(256), 0, pa, nprep, C.prep_part.p, C.prep_ticket.p, C.fronts.p, C.d_asm_fsrc.p, (int64_t)C.fsize);
+  } else {
+    SDM_HIP_CHECK(hipMemsetAsync(C.fronts.p, 0, (size_t)C.fsize * sizeof(double), st));
+    SDM_KLAUNCH(P, k_assemble, dim3(grid1d(C.nnzL, 256)), dim3(256), 0, C.fronts.p, P->ada_val.p, C.d_asm_src.p,
+               C.d_asm_dst.p, (int64_t)C.nnzL, C.ub.p);
+    SDM_KLAUNCH(P, k_prep_pivots, dim3(nprep), dim3(256), 0, pa);
+  }
   C.pars_canceltol = canceltol; C.pars_maxu = maxu; C.pars_abstol = abstol; C.pars_use_absd = use_absd;
   {
     PanelCtx c = {};

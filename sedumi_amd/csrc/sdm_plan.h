@@ -202,6 +202,7 @@ struct CholPlan {
   std::vector<int> lev_followT;      // grid.x of k_sinv_follow per level: tiles of the inverse of its widest front
   std::vector<int> stage_ptr;        // combine tiles of stage st (= 2 * level + (0: T, 1: X)) are l_items[stage_ptr[st] .. stage_ptr[st+1])
   std::vector<SolveLevel> slev;
+  DevBuf<double> prep_part; DevBuf<int> prep_ticket;   // k_begin_factor: maxima per bounds workgroup, the ticket of the last one
   double growth_max = 1e4;           // a super-block whose max|inv| * max|L| exceeds this is solved by substitution
   double growth_used = 1e4;          // the bound in force at the last solve_prepare
   // blocks beyond growth_max but within refine_max: inverse + REFINE_STEPS steps of iterative refinement against the factor
@@ -240,6 +241,7 @@ struct AdaPlan {
   int maxn = 0;
   bool thread_per_row = false;
   sdm_int col0 = 0, col1 = 0;            // column range of ADA' formed by this plan (sdm_plan_getada_cols)
+  double *zero_ptr = nullptr; long long zero_n = 0; bool zero_defer = false;   // a clearing of ADA' left to the next stage (ada_zero_flush, sdm_ada.hip)
   std::vector<int64_t> h_taskptr;       // host copy of c_taskptr
   std::vector<sdm_int> psd_n, psd_start, psd_udoff;
   DevBuf<int64_t> d_Ajc, d_Ajc_psd, d_Qjc, d_ADAjc;
@@ -474,6 +476,7 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
 // mode bits: 1 = LP/Lorentz-det part (getada1), 2 = Lorentz rank-1 part (getada2), 4 = PSD part (getada3)
 // tri_perm (device, length m, inverse permutation) != nullptr -> only entries with invperm[i] <= invperm[j]
 // are touched (the reference's triangular bookkeeping); symmetrize -> spmakesym afterwards.
+void ada_zero_flush(sdm_plan *P);
 void ada_lq(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate);
 void ada_q(sdm_plan *P, double *ada, const int *d_invperm, bool accumulate);
 void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, bool absd_done = false);

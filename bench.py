@@ -266,11 +266,17 @@ def profile_unit(plan, P, ud, nprof):
     lind = int(np.sum(np.diff(plan.L_pattern.indptr)[(np.asarray(plan_xsuper(plan)) - 1)[:-1]])) if hasattr(plan, "L_pattern") else m
     solve_bytes = 8.0 * nnzL + 8.0 * lind + 16.0 * m    # per triangular sweep: 8*nnz(L) + 8*len(lindx) + 16*m
     fac_flops = factor_flops(plan)
+    # on the device the LAST workgroups of a k_ldl_front launch build the triangular inverses of the fronts' diagonal super-blocks for the
+    # solves (n^3 / 3 flops per front of n columns): the launch's work is both -- recognised by no inverse kernel of its own in the profile
+    xs_ = np.asarray(plan_xsuper(plan), dtype=np.float64)
+    inv_flops = float(np.sum(np.diff(xs_) ** 3) / 3.0)
+    inv_in_front_launch = "k_ldl_front" in prof and not any(k in prof for k in ("k_sprep", "k_sinv128", "k_sinv_follow", "k_stile"))
+    front_flops = fac_flops + (inv_flops if inv_in_front_launch else 0.0)
     npanel = max(1, prof.get("k_ldl_panel", (1, 0))[0] // nprof)
     ada_bytes = 8.0 * (ud.size + P.At.nnz + plan.nnzADA)
     model = {
         "k_ldl_panel": ("mfma", fac_flops / npanel),                               # the panel launches carry the whole LDL'
-        "k_ldl_front": ("mfma", fac_flops / max(1, prof.get("k_ldl_front", (nprof, 0))[0] // nprof)),   # ... or ONE launch per level does
+        "k_ldl_front": ("mfma", front_flops / max(1, prof.get("k_ldl_front", (nprof, 0))[0] // nprof)),   # ... or ONE launch per level does
         "k_ldl_update": ("mfma", fac_flops / npanel),
         "k_psd_stage1_mfma": ("mfma", None), "k_psd_stage1": ("fp64_vector", None),  # flops filled below from the task list (the two-dot kernel has no MFMA in it)
         "k_psd_stage2": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)), "k_psd_stage2_ell": ("hbm", 8.0 * (P.At.nnz + plan.nnzADA)),
@@ -280,7 +286,7 @@ def profile_unit(plan, P, ud, nprof):
     }
     peaks = {"hbm": (HBM_PEAK_GBS, "GB/s", 1e9), "mfma": (FP64_MATRIX_PEAK_TFS, "TFLOP/s", 1e12),
              "fp64_vector": (FP64_MATRIX_PEAK_TFS, "TFLOP/s", 1e12)}                    # (the FP64 vector rate equals the matrix rate on CDNA4)
-    # (k_sinv_follow runs NEXT to k_ldl_front on the plan's second stream and spends most of its time waiting for it:
+    # (k_sinv_follow -- the emulator's form of the workgroups that build the inverse behind the factor -- spends most of its time waiting for it:
     # its events overlap that kernel's, it is not a stage of its own)
     dom = max(((k, v) for k, v in prof.items() if k != "k_sinv_follow"), key=lambda kv: kv[1][1])[0] if prof else None
     roof = None
@@ -300,6 +306,8 @@ def profile_unit(plan, P, ud, nprof):
         roof = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                 "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_per_step": calls / nprof,
                 "algorithmic_work_per_launch": work,
+                **({"work_is": "LDL' of the fronts (%.4g flops) + the triangular inverses of their diagonal super-blocks for the solves (%.4g flops), "
+                               "built by the last workgroups of the same launch" % (fac_flops, inv_flops)} if key == "k_ldl_front" and inv_in_front_launch else {}),
                 "timing": "HIP events around every launch on the plan's stream (adds ~2 us per launch; kernels shorter than "
                           "~7 us read as ~7 us: see phases_ms_per_step for those)",
                 "stage_ms_per_step": {k: v[1] / nprof for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}

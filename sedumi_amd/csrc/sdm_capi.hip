@@ -63,9 +63,6 @@ void sdm_plan_destroy(sdm_plan *p) {
   chol_forget_plan(p);
   for (auto g : p->graphs) (void)hipGraphExecDestroy(g);
   for (int i = 0; i < 16; i++) { if (p->ev_begin[i]) (void)hipEventDestroy(p->ev_begin[i]); if (p->ev_end[i]) (void)hipEventDestroy(p->ev_end[i]); }
-  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
-  if (p->stream2) (void)hipStreamDestroy(p->stream2);
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
 }

@@ -20,7 +20,7 @@
 // columns returned as unit vectors, blkchol.c:409-414) up to rounding, and the
 // pivot DECISIONS follow blkchol2.c:114-161 including the idamax quirk of
 // maxabs (blkchol2.c:66-70).
-#include "sdm_plan.h"
+#include "sdm_follow.h"
 #include <cstring>
 #include <algorithm>
 #include <cmath>
@@ -29,8 +29,11 @@
 namespace sdm {
 
 #ifndef SDM_EMU
+struct FollowArgs { double *S, *STr; unsigned long long *sb_g; int nfront; };   // (k_ldl_front: the follower's workgroups behind the front's)
 __global__ void k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, double *lb, const double *ubp, int *pivstat,
-                            double *pivval, const PanelCtx *ctx, int *front_cnt, int *diag_cnt, int phase, int step, int tile_wg0, int *tmo);
+                            double *pivval, const PanelCtx *ctx, int *front_cnt, int *diag_cnt, int phase, int step, int tile_wg0, int *tmo, FollowArgs fa);
+#else
+struct FollowArgs { double *S, *STr; unsigned long long *sb_g; int nfront; };
 #endif
 // ============================================================ host analysis
 void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm,
@@ -336,16 +339,15 @@ __global__ void k_begin_factor(PrepArgs A, int nprep, double *part, int *ticket,
   __shared__ double red[256];
   __shared__ int last;
   const double mx = prep_pivots_part(A, blockIdx.x, nprep, red);
-  if (threadIdx.x == 0) {
-    part[blockIdx.x] = mx;
-    __threadfence();
-    last = atomicAdd(ticket, 1) == nprep - 1;
-  }
+  // (write-through store, acknowledged, then the ticket; the last workgroup reads with L2-bypassing loads: the workgroups sit on
+  // different XCDs -- with plain stores and a fence the soak of round 4 met a stale maximum twice in 3471 fronts)
+  if (threadIdx.x == 0) sdm_store_wt(&part[blockIdx.x], mx);
+  SDM_STORES_DONE();
+  if (threadIdx.x == 0) last = sdm_ticket_take(ticket) == nprep - 1;
   __syncthreads();
   if (!last) return;
-  __threadfence();
   double m2 = 0.0;
-  for (int i = threadIdx.x; i < nprep; i += blockDim.x) { const double v = ((volatile double *)part)[i]; if (v > m2) m2 = v; }
+  for (int i = threadIdx.x; i < nprep; i += blockDim.x) { const double v = sdm_load_wt(&part[i]); if (v > m2) m2 = v; }
   __syncthreads();
   red[threadIdx.x] = m2;
   __syncthreads();
@@ -1533,11 +1535,33 @@ __device__ SDM_NOINLINE void front_rows_diag(SDM_GP(double) Fs_, SDM_GP(const do
 // path (same device functions), so both produce the same bits.  upd_done[r] counts the U steps finished (the rare column
 // probe of a later diagonal block waits for them).  The emulator runs workgroups one after the other: there the host
 // loops over (step, phase 1 = D, 2 = R, 3 = U) and nothing is carried in LDS.
+// (scalar arguments: they travel in the 32 argument registers of the convention; a FrontTab by reference made the kernel keep its copy in scratch)
+__device__ SDM_NOINLINE void front_follow_stage(char *smem, int bx, int fs, int ns, int ld, int sld, int slot, int sboff, int64_t foff, int64_t soff, int64_t toff,
+                                                 SDM_GP(const double) F_, SDM_GP(const double) DT_, SDM_GP(double) S_, SDM_GP(double) STr_, SDM_GP(int) front_cnt_,
+                                                 SDM_GP(const int) diag_cnt_, SDM_GP(unsigned long long) sb_g_, SDM_GP(int) tmo_) {
+  FollowDesc fd;
+  fd.s = fs; fd.ns = ns; fd.ld = ld; fd.sld = sld; fd.slot = slot; fd.sboff = sboff; fd.foff = foff; fd.soff = soff; fd.toff = toff;
+  sinv_follow_body(smem, bx, fd, (const double *)F_, (const double *)DT_, (double *)S_, (double *)STr_, (int *)front_cnt_, (const int *)diag_cnt_,
+                   (unsigned long long *)sb_g_, (int *)tmo_);
+}
 __global__ void __launch_bounds__(LDL_THREADS)
 k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, double *lb, const double *ubp, int *pivstat,
-            double *pivval, const PanelCtx *ctx, int *front_cnt, int *diag_cnt, int phase, int step, int tile_wg0, int *tmo) {
+            double *pivval, const PanelCtx *ctx, int *front_cnt, int *diag_cnt, int phase, int step, int tile_wg0, int *tmo, FollowArgs fa) {
   SDM_FP_STRICT;
   SDM_DYN_SMEM(smem);
+  if (fa.S && (int)blockIdx.x >= fa.nfront) {
+    // ---- the workgroups that build the front's inverse for the solves BEHIND its factorisation (sdm_follow.h; they poll the counters
+    // the workgroups below count).  They used to be a launch of their own on a second stream: forking to it and joining it again cost
+    // 6.8 + 11.5 us of every factorisation (event record, cross-queue wait: profiles/r04p_*, r04q_*); as the last workgroups of this
+    // launch -- dispatched after every workgroup they wait for -- they cost nothing.  256 of the 512 work-items do the work: a
+    // wavefront that has ended is not waited for by the barriers of the others.
+    if (threadIdx.x >= ST) return;
+    const FollowDesc fd = follow_desc(tab, list, (int)blockIdx.y);
+    front_follow_stage(smem, (int)blockIdx.x - fa.nfront, fd.s, fd.ns, fd.ld, fd.sld, fd.slot, fd.sboff, fd.foff, fd.soff, fd.toff, (SDM_GP(const double))F,
+                       (SDM_GP(const double))DT, (SDM_GP(double))fa.S, (SDM_GP(double))fa.STr, (SDM_GP(int))front_cnt, (SDM_GP(const int))diag_cnt,
+                       (SDM_GP(unsigned long long))fa.sb_g, (SDM_GP(int))tmo);
+    return;
+  }
   const int s = list[blockIdx.y];
   const int ns = tab.ns[s], ms = tab.ms[s], ld = tab.ld[s], first = tab.first[s];
   const int T = (ms + TILE - 1) / TILE, NP = (ns + NB - 1) / NB;
@@ -1759,7 +1783,7 @@ void chol_begin(sdm_plan *P, const double canceltol, const double maxu, const do
 // levels l0 .. l1-1: children's update matrices into the fronts of the level (extend-add), then -- unless extend_only -- its LDL'
 void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
   CholPlan &C = P->chol;
-  hipStream_t st = P->stream;
+  hipStream_t st = P->stream; (void)st;                              // (used by the emulator's launches of the follower only)
   FrontTab tab = front_tab(C);
   const bool follow = C.follow;
   for (int l = std::max(l0, 0); l < std::min(l1, C.nlevels); l++) {
@@ -1779,8 +1803,8 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
         // the data-tagged hand-over): one process per workgroup, all at once (tests/hipemu: emu_launch_concurrent)
         SDM_KLAUNCH_CONCURRENT(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
                                C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.panel_ctx.p, C.front_cnt.p,
-                               C.diag_cnt.p, 0, 0, C.lev_maxT[l], C.tmo.dev());
-        if (follow) solve_follow(P, l, st);                          // beside it, polling its counters -- as on the second stream of the device
+                               C.diag_cnt.p, 0, 0, C.lev_maxT[l], C.tmo.dev(), FollowArgs{nullptr, nullptr, nullptr, 0});
+        if (follow) solve_follow(P, l, st);                          // beside it, polling its counters -- as the last workgroups of the launch do on the device
         emu_group_end();
         continue;
       }
@@ -1788,34 +1812,17 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
         for (int phase = 1; phase <= 3; phase++)
           SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
                       C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.panel_ctx.p, C.front_cnt.p,
-                      C.diag_cnt.p, phase, step, C.lev_maxT[l], C.tmo.dev());
+                      C.diag_cnt.p, phase, step, C.lev_maxT[l], C.tmo.dev(), FollowArgs{nullptr, nullptr, nullptr, 0});
       if (follow) solve_follow(P, l, st);                            // (workgroups run one after the other here: behind = after)
       if (emu_take_injected_timeout()) *(volatile int *)C.tmo.host = 1;   // (tests: as if a workgroup of this launch had given up waiting)
 #else
-      if (follow) {
-        // fork: the inverse of the level's fronts follows the factorisation on the second stream (k_sinv_follow polls
-        // k_ldl_front's progress counters; both kernels' workgroups fit the device together: solve_build), join behind both
-        if (!P->stream2) {
-          // its own PRIORITY class: streams of one class share a few hardware queues round robin, and two streams on one queue run
-          // their kernels one after the other -- the follower would start when the factorisation ends (measured: a second plan of the
-          // same process paid 100 us per factorisation that way, profiles/r03m other_configs).  Queues of different classes are distinct.
-          int prio_least = 0, prio_greatest = 0;
-          SDM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-          SDM_HIP_CHECK(hipStreamCreateWithPriority(&P->stream2, hipStreamNonBlocking, prio_least));
-          SDM_HIP_CHECK(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
-          SDM_HIP_CHECK(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming));
-        }
-        SDM_HIP_CHECK(hipEventRecord(P->ev_fork, st));
-        SDM_HIP_CHECK(hipStreamWaitEvent(P->stream2, P->ev_fork, 0));
-      }
-      SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
+      // the inverse of the level's fronts is built BEHIND their factorisation by the last workgroups of the same launch (k_ldl_front,
+      // sdm_follow.h: they poll the progress counters; both kinds of workgroup fit the device together: solve_build)
+      FollowArgs fa = {nullptr, nullptr, nullptr, C.lev_maxT[l] + C.lev_ntw[l]};
+      if (follow) { fa.S = C.S.p; fa.STr = C.ST.p; fa.sb_g = C.sb_g.p; C.growth_used = C.growth_max; }
+      SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l] + (follow ? C.lev_followT[l] : 0), nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
                   C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.panel_ctx.p, C.front_cnt.p,
-                  C.diag_cnt.p, 0, 0, C.lev_maxT[l], C.tmo.dev());
-      if (follow) {
-        solve_follow(P, l, P->stream2);
-        SDM_HIP_CHECK(hipEventRecord(P->ev_join, P->stream2));
-        SDM_HIP_CHECK(hipStreamWaitEvent(st, P->ev_join, 0));
-      }
+                  C.diag_cnt.p, 0, 0, C.lev_maxT[l], C.tmo.dev(), fa);
 #endif
       continue;
     }

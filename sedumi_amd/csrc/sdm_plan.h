@@ -338,8 +338,6 @@ struct sdm_plan {
   sdm::KProf kprof;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipStream_t stream2 = nullptr;         // k_sinv_follow runs here, next to k_ldl_front on `stream` (created on first use)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool has_chol = false, has_ada = false, factored = false;
   sdm::CholPlan chol;
   sdm::AdaPlan ada;

@@ -416,7 +416,8 @@ int sdm_mexcache_getada1(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, 
                          const double *ddet, const sdm_int *qblkstart, double *ADApr, const sdm_int *ADAir_out);
 int sdm_mexcache_getada2(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const double *ADApr_in, double *ADApr, sdm_int lorN,
                          const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, const sdm_int *qperm, const sdm_int *ADAir_out);
-void sdm_mexcache_getada2_passthrough(sdm_int nnz, const double *ADApr_in, const double *ADApr_out);   /* getada2.c:154-155: copy returned unchanged */
+void sdm_mexcache_getada2_passthrough(sdm_int nnz, const double *ADApr_in, const double *ADApr_out, const sdm_int *ADAir_in,
+                                      const sdm_int *ADAir_out);   /* getada2.c:154-155: the copy returned unchanged is the same ADA' to the cache (values and pattern) */
 int sdm_mexcache_getada3(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const double *ADApr_in, double *ADApr, sdm_int N,
                          const sdm_int *Ajc, const sdm_int *Air, const double *Apr, const sdm_int *Ajc1, const double *udsqr,
                          const sdm_cone *K, const sdm_int *psd_blkstart, double *absd, const sdm_int *ADAir_out);

@@ -87,17 +87,19 @@ struct Finger {
   sdm_int n = -1;
   u64 sample = 0, full = 0;
   bool have_full = false;
-  const void *at[4] = {nullptr, nullptr, nullptr, nullptr};
+  const void *at[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // (the last eight addresses it was seen at)
   int nat = 0;
   void seen_at(const void *p) {
-    for (int i = 0; i < 4; i++) if (at[i] == p) return;
-    at[nat++ & 3] = p;
+    for (int i = 0; i < 8; i++) if (at[i] == p) return;
+    at[nat++ & 7] = p;
   }
   // want_full = false: the content is only ever recognised at this address (value arrays that travel from one gateway to
   // the next by reference; at another address they are simply uploaded again)
-  void take(const void *p, sdm_int len, bool want_full = true) {
+  // any_size: the full checksum whatever the length (patterns: once per solve; without it an array beyond FULL_MAX is only ever
+  // recognised at an address it has been seen at)
+  void take(const void *p, sdm_int len, bool want_full = true, bool any_size = false) {
     n = len; sample = hash_sampled(p, len);
-    have_full = want_full && len <= FULL_MAX;
+    have_full = want_full && (any_size || len <= FULL_MAX);
     full = have_full ? hash_full(p, len) : 0;
     for (auto &a : at) a = nullptr;
     nat = 0; seen_at(p);
@@ -110,7 +112,7 @@ struct Finger {
   bool same(const void *p, sdm_int len) {
     if (len != n || n < 0) return false;
     if (hash_sampled(p, len) != sample) return false;
-    for (int i = 0; i < 4; i++) if (at[i] == p && p) return !(strict && have_full) || hash_full(p, len) == full;
+    for (int i = 0; i < 8; i++) if (at[i] == p && p) return !(strict && have_full) || hash_full(p, len) == full;
     if (!have_full || hash_full(p, len) != full) return false;
     seen_at(p);
     return true;
@@ -128,7 +130,7 @@ u64 intern(sdm_int ncol, const sdm_int *jc, const sdm_int *ir) {
     if (p.id && p.ncol == ncol && p.jc.same(jc, ncol + 1) && p.ir.same(ir, nnz)) { p.used = ++g_clock; return p.id; }
   Pattern *v = &g_pat[0];
   for (auto &p : g_pat) if (p.used < v->used) v = &p;                 // least recently used (empty entries first: used = 0)
-  v->ncol = ncol; v->jc.take(jc, ncol + 1); v->ir.take(ir, nnz); v->id = g_next_id++; v->used = ++g_clock;
+  v->ncol = ncol; v->jc.take(jc, ncol + 1, true, true); v->ir.take(ir, nnz, true, true); v->id = g_next_id++; v->used = ++g_clock;
   return v->id;
 }
 // `ir` is a copy of the row indices of pattern `id` that a shim made for the array it returns: the next call presents it
@@ -293,8 +295,12 @@ int sdm_mexcache_getada2(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, 
   MC_CATCH
 }
 // the copy getada2 returns when there is nothing to add (getada2.c:154-155): the device copy stays the current one
-void sdm_mexcache_getada2_passthrough(sdm_int nnz, const double *ADApr_in, const double *ADApr_out) {
+void sdm_mexcache_getada2_passthrough(sdm_int nnz, const double *ADApr_in, const double *ADApr_out, const sdm_int *ADAir_in, const sdm_int *ADAir_out) {
   if (g_last.plan && g_last.vals.same(ADApr_in, nnz)) g_last.vals.seen_at(ADApr_out);
+  // (the copy's row indices too: a pattern too big for the full checksum is only recognised at an address the cache knows -- with an
+  // allocator that does not hand out the same address every iteration getada3 took the copy for a new pattern and rebuilt its analysis)
+  if (ADAir_in && ADAir_out)
+    for (auto &p : g_pat) if (p.id && p.ir.n == nnz && p.ir.same(ADAir_in, nnz)) { p.ir.seen_at(ADAir_out); break; }
 }
 
 // [ADA, absd] = getada3(ADA, A, Ajc1, Aord, udsqr, K)

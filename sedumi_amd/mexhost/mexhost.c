@@ -18,8 +18,9 @@
 /* Memory policy of this host.  SeDuMi's gateways hand back whole arrays (ADA' three times per iteration, L.L once: megabytes each),
  * so every call allocates and frees blocks far above glibc's mmap threshold: by default each of them is a fresh mmap -- page
  * faults for every 4 KB on first touch -- and a munmap on free.  In the build container that is 2.8 ms per 7 MB sparse array
- * (calloc, fill, free) against 0.58 ms from a heap that keeps its pages; on the GPU boxes of round 4 the two measured the same
- * (509 against 513 control07 units/s through the shims: profiles/r04n_*).  Like MATLAB's own memory manager this host keeps
+ * (calloc, fill, free) against 0.58 ms from a heap that keeps its pages; on the GPU boxes of round 4 control07's 3.5 MB arrays measured
+ * the same either way (509 against 513 units/s through the shims), MAXCUT-4000's 128 MB arrays 41 ms against 140 ms per unit
+ * (profiles/r04n_*, r04u_*).  Like MATLAB's own memory manager this host keeps
  * freed blocks: no mmap for single blocks, no trimming.  (Process-wide, set when the library is loaded; MEXHOST_DEFAULT_MALLOC=1 in the
  * environment leaves glibc's defaults alone.) */
 __attribute__((constructor)) static void mexhost_memory_policy(void) {

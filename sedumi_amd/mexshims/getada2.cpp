@@ -9,7 +9,8 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   cache_teardown_at_exit();
   if (ck.K.lorN == 0) {                                              // getada2.c:153-155: the copy, nothing added
     plhs[0] = mxDuplicateArray(ADA);
-    sdm_mexcache_getada2_passthrough((sdm_int)mxGetJc(ADA)[mxGetN(ADA)], mxGetPr(ADA), mxGetPr(plhs[0]));
+    sdm_mexcache_getada2_passthrough((sdm_int)mxGetJc(ADA)[mxGetN(ADA)], mxGetPr(ADA), mxGetPr(plhs[0]), (const sdm_int *)mxGetIr(ADA),
+                                     (const sdm_int *)mxGetIr(plhs[0]));
     return;
   }
   const mxArray *Q = need_field(prhs[1], "q", "Missing field DAt.q.");

@@ -223,20 +223,23 @@ def run_units_by_reference(host, S, K, d, DAt, ud, pars, rhs, nunits, ref_it=Non
     return [sum(t.values()) for t in times], y
 
 
-def test_iteration_units_by_reference_reuse_the_device_state(glue, refmex, shimmex, shimlib):
-    """What an unmodified sedumi.m does every iteration: the same At / K / patterns, each gateway's output handed to the next.  From
+@pytest.mark.parametrize("lorentz", [True, False])
+def test_iteration_units_by_reference_reuse_the_device_state(glue, refmex, shimmex, shimlib, lorentz):
+    """(lorentz = False: getada2.mex has nothing to add and returns a COPY of its input, getada2.c:153-155 -- the copy must be the same
+    ADA' to the cache, values and pattern.)  What an unmodified sedumi.m does every iteration: the same At / K / patterns, each gateway's output handed to the next.  From
     the second unit on nothing is analysed again (no ada_build, no chol_build), no ADA' values and no factor cross PCIe towards the
     device (ADA resident for getada2 / getada3 / blkchol, L.L resident for the eight solves)."""
     import ctypes
     from oracle import glue as gl
     from sedumi_amd import problem
     ctypes.CDLL(shimlib).sdm_mexcache_clear()
-    P = problem.random_sdp(m=28, seed=21)
+    P = problem.random_sdp(m=28, seed=21) if lorentz else problem.random_sdp(m=28, lp=4, q=(), s=(6, 5), seed=22)
     S = glue.setup(P.At, P.K)
     d, ud = ref_scaling(P, 2)
     it = glue.iteration_ref(S, d, ud)
     pars = gl.default_pars_chol()
     rhs = np.random.default_rng(0).standard_normal(P.m)
+    assert (P.K["q"].size > 0) == lorentz
     s0 = mexcache_stats(shimlib)
     _, y = run_units_by_reference(shimmex, S, P.K, d, it["DAt"], ud, pars, rhs, 1, it)
     s1 = mexcache_stats(shimlib)

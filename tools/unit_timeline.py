@@ -1,4 +1,4 @@
-"""tools/unit_timeline.py <kernel_trace.csv> -- the kernels of the last complete bench units of a rocprofv3 --kernel-trace run as a
+"""tools/unit_timeline.py <kernel_trace.csv> [first kernel of a unit] -- the kernels of the last complete bench units of a rocprofv3 --kernel-trace run as a
 timeline: start and duration of every launch relative to the unit's first kernel, and the gaps between them (median over the units)."""
 import csv
 import sys
@@ -9,7 +9,8 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"].split("(")[0].replace("sdm::", "").replace("void ", "") for r in rows]
 first = "k_lq_q_prep" if any(n.startswith("k_lq_q_prep") for n in names) else names[0]
 # units = runs starting with the unit's first kernel; keep those of the most common length
-starts = [i for i, n in enumerate(names) if n.startswith("k_psd_stage1_mfma")]
+delim = sys.argv[2] if len(sys.argv) > 2 else "k_psd_stage1_mfma"
+starts = [i for i, n in enumerate(names) if n.startswith(delim)]
 units = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)]
 lens = [b - a for a, b in units]
 common = statistics.mode(lens)

@@ -33,7 +33,14 @@ constexpr int LDL_THREADS = 512;      // workgroup of the diagonal-block kernel:
 constexpr int PANEL_THREADS = 256;    // workgroup of the row-solve kernel: 4 wavefronts, one per SIMD (the solve is issue bound)
 constexpr int ROWS_BATCH = 16 * (PANEL_THREADS / 64);   // rows per workgroup of the row-solve kernel (16 per wavefront on the matrix cores)
 constexpr int TRSM_ROWS = 128;        // up to this many rows below the diagonal block are solved by the diagonal-block kernel itself
-constexpr int MFMA_MIN_ROWS = 256;    // fronts with fewer rows below their first panel use the bit-faithful row substitution
+// fronts with fewer rows below their first panel use the bit-faithful row substitution, one row per work-item; the others the blocked
+// matrix-core row solve, and -- levels that fit the device -- the one-launch path (k_ldl_front).  256 until round 4; with 48 the
+// reference's small examples take the one-launch path: arch0 (174 rows) factor + inverse 0.178 -> 0.085 ms, nb (123) 0.106 -> 0.068
+// (profiles/r04x_small_fronts.txt; golden fixtures and 150 rank-deficient fronts of 100 .. 330 rows identical in decisions)
+#ifndef SDM_MFMA_MIN_ROWS
+#define SDM_MFMA_MIN_ROWS 48
+#endif
+constexpr int MFMA_MIN_ROWS = SDM_MFMA_MIN_ROWS;
 constexpr int CHK = 16;               // column chunk of the row substitution held in registers
 constexpr int64_t ASM_FULL_MAX = 4 << 20;   // arenas of up to this many entries are assembled with the zero fill folded in
 constexpr int FRONT_MAXT = 64;        // fronts of up to this many 64-row tile rows (and at least MFMA_MIN_ROWS + NB rows) are factored by ONE launch (k_ldl_front)

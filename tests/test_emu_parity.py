@@ -406,7 +406,7 @@ def test_getada_gateway_on_the_nb_example():
         assert relerr(absd.ravel(), z[f"{tag}_absd"]) < TOL
 
 
-@pytest.mark.parametrize("m", [330, 512, 666, 1000])
+@pytest.mark.parametrize("m", [112, 123, 174, 330, 512, 666, 1000])
 def test_one_launch_front_matches_the_panel_launches_bit_for_bit(refmex, m):
     helpers.check_one_launch_front(refmex, m)
 

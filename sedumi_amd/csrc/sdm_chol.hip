@@ -355,7 +355,7 @@ __global__ void k_begin_factor(PrepArgs A, int nprep, double *part, int *ticket,
     if ((int)threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) { A.ub[0] = 0.0; A.ub[1] = A.maxu; A.ub[2] = red[0]; *ticket = 0; }
+  if (threadIdx.x == 0) { A.ub[0] = 0.0; A.ub[1] = A.maxu; A.ub[2] = red[0]; sdm_signal_add(ticket, -nprep); }   // (the ticket back to 0, where the tickets are counted)
 }
 
 // ---- extend-add: parent front += children's Schur complements.

@@ -1,7 +1,9 @@
-"""tools/dpr1_fallback_rate.py [m n ndense] -- how often does dpr1fact leave the device?
+"""tools/dpr1_fallback_rate.py [m n ndense] -- how often does dpr1fact leave the device?  (Since round 4: never -- k_dpr1_general is the
+whole of dodpr1fact and *host_fallback is always 0; the tool now counts how many iterations of a real run NEED the general case, i.e.
+postponed pivots or dependent rows, by the factors' dopiv flags.)
 
-sdm_plan_deninfac factors the dense columns with the scan kernels (k_dpr1_factor) when every pivot is accepted in the first round
-and hands the case to the host algorithm otherwise (postponed pivots, dependent rows: dpr1fact.c:168-202, 224-240, 371-476).  This tool
+Until round 3 sdm_plan_deninfac factored the dense columns with scan kernels when every pivot was accepted in the first round
+and handed the case to a host algorithm otherwise (postponed pivots, dependent rows: dpr1fact.c:168-202, 224-240, 371-476).  This tool
 drives a whole interior-point solve of a sparse LP with dense columns -- a plain infeasible primal-dual path-following method in numpy
 (Mehrotra predictor-corrector, normal equations; the iterates only serve as REAL scalings d = x ./ z for the hot path) -- and per
 iteration runs getada / blkchol / deninfac on the resident plan exactly as sedumi.m:449-462 does (dense rows removed from At, smult =
@@ -52,7 +54,8 @@ for it in range(60):
     plan.upload("dl", d)
     plan.getada(); plan.blkchol(bench.PARS, True)
     fb = plan.deninfac(d[rows_dense], 500.0)
-    log.append({"it": it, "mu": float(mu), "cond_d": float(d.max() / d.min()), "host": bool(fb)})
+    general = bool(np.asarray(plan.lden()[0]["dopiv"]).any())      # a column whose rows were reordered: postponed pivots / dependent rows
+    log.append({"it": it, "mu": float(mu), "cond_d": float(d.max() / d.min()), "host": bool(fb), "general": general})
     if max(np.linalg.norm(rp) / (1 + np.linalg.norm(b)), np.linalg.norm(rd) / (1 + np.linalg.norm(c)), gap) < 1e-9:
         break
     M = (Ad * d) @ Ad.T
@@ -76,6 +79,8 @@ for it in range(60):
     x, y, z = x + ap * dx, y + ad_ * dy, z + ad_ * dzz
 plan.close()
 hits = [e["it"] for e in log if e["host"]]
+gen = [e["it"] for e in log if e["general"]]
 print(json.dumps({"problem": f"LP m={m} n={n} dense={nd}", "iterations": len(log), "final_mu": log[-1]["mu"], "final_cond_d": log[-1]["cond_d"],
                   "deninfac_calls": len(log), "host_algorithm_needed": len(hits), "at_iterations": hits,
+                  "general_case_on_the_device": len(gen), "general_case_at_iterations": gen,
                   "cond_d_at_first_hit": (log[hits[0]]["cond_d"] if hits else None)}), flush=True)

@@ -407,31 +407,35 @@ int sdm_plan_solve_levels(sdm_plan *p, int what, sdm_int l0, sdm_int l1);
  *   - a value array that one gateway returned and the next one receives (ADA: getada1 -> getada2 -> getada3 -> blkchol;
  *     L.L: blkchol -> fwblkslv / bwblkslv) is not uploaded again: the device still holds it.
  * What sedumi.m:450-462 / wrapPcg.m:56-59 call every iteration therefore costs the per-iteration scaling data up and the
- * results down.  ADApr_in / ADApr: values of the input array and of the fresh array the shim returns (may alias);
- * ADAir_out / Lir_out: row indices of the returned array (the shim's copy of the input pattern; NULL allowed).
+ * results down.  ADApr_in / ADApr: values of the input array and of the fresh array the shim returns (may alias).
  * sdm_mexcache_solve: fw != 0 forward.  sdm_mexcache_stats: counters (ada_build calls, reuses, ADA uploads, ADA taken
  * from the device, chol builds, reuses, X uploads, X resident, resident solves, stateless solves, At uploads). */
 int sdm_mexcache_getada1(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc, const sdm_int *Air,
                          const double *Apr, const sdm_int *Ajc2, const sdm_int *perm, sdm_int lpN, const double *dl, sdm_int lorN,
-                         const double *ddet, const sdm_int *qblkstart, double *ADApr, const sdm_int *ADAir_out);
+                         const double *ddet, const sdm_int *qblkstart, double *ADApr);
 int sdm_mexcache_getada2(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const double *ADApr_in, double *ADApr, sdm_int lorN,
-                         const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, const sdm_int *qperm, const sdm_int *ADAir_out);
-void sdm_mexcache_getada2_passthrough(sdm_int nnz, const double *ADApr_in, const double *ADApr_out, const sdm_int *ADAir_in,
-                                      const sdm_int *ADAir_out);   /* getada2.c:154-155: the copy returned unchanged is the same ADA' to the cache (values and pattern) */
+                         const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, const sdm_int *qperm);
 int sdm_mexcache_getada3(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const double *ADApr_in, double *ADApr, sdm_int N,
                          const sdm_int *Ajc, const sdm_int *Air, const double *Apr, const sdm_int *Ajc1, const double *udsqr,
-                         const sdm_cone *K, const sdm_int *psd_blkstart, double *absd, const sdm_int *ADAir_out);
+                         const sdm_cone *K, const sdm_int *psd_blkstart, double *absd);
 int sdm_mexcache_getada(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc, const sdm_int *Air,
                         const double *Apr, sdm_int lpN, const double *dl, sdm_int lorN, const double *ddet, const sdm_int *qblkstart,
-                        const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, double *ADApr, double *absd, const sdm_int *ADAir_out);
+                        const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, double *ADApr, double *absd);
 int sdm_mexcache_blkchol(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm, sdm_int nsuper, const sdm_int *xsuper,
                          const sdm_int *Xjc, const sdm_int *Xir, const double *Xpr, const sdm_cholpars *pars, const double *absd,
                          double *Lpr, double *d, sdm_int *nskip, sdm_int *skip_idx, double *skip_val, sdm_int *nadd, sdm_int *add_idx,
-                         double *add_val, const sdm_int *Lir_out);
+                         double *add_val);
 int sdm_mexcache_solve(int fw, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const double *Lpr, const sdm_int *perm, sdm_int nsuper,
                        const sdm_int *xsuper, sdm_int nrhs, const double *b, double *y);
-void sdm_mexcache_stats(sdm_int *out16, sdm_int n);
+void sdm_mexcache_stats(sdm_int *out16, sdm_int n);   /* [11] words checksummed on the host since the last clear, [12] the epoch */
+/* Residency is decided by content (a checksum of every word of the host array against that of the resident data).  Arrays of up to
+ * `full_below` words (default 65536) are checksummed at every presentation; a larger one once per address and epoch (= between two
+ * blkchol calls), later presentations at that address in that epoch pass on length + a 512-word sampled hash: an in-place edit of
+ * such an array between two calls of one iteration, at words the sample does not touch, goes unnoticed (sedumi.m never does that).
+ * set_strict(1): no shortcut, every presentation is checksummed completely. */
 void sdm_mexcache_set_strict(int on);
+void sdm_mexcache_set_full_below(sdm_int words);
+unsigned long long sdm_mexcache_checksum(const void *words, sdm_int n);   /* the content checksum of n 8-byte host words */
 /* The cached plan of the factorisation for callers that drive it themselves: sdm_mexcache_plan returns the plan of the
  * symbolic factor (L.{L pattern, perm, xsuper}) and ADA pattern given, creating it on a miss (NULL + sdm_last_error on
  * failure); sdm_mexcache_remember_factor records the L.L values a factorisation returned; sdm_mexcache_factor_plan gives

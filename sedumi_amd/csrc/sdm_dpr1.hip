@@ -213,11 +213,11 @@ k_dpr1_general(Dpr1G G) {
   }, plus, si);
   const int npost = n - nacc;
   double *beta = G.beta_base + G.betajc[k];
-  if (!caseB && npost == 0) {                                         // natural order, nothing reordered (dpr1fact.c:330-333)
+  const bool natural = !caseB && npost == 0;                          // (uniform over the workgroup)
+  if (natural) {                                                      // natural order, nothing reordered (dpr1fact.c:330-333)
     for (int i = tid; i < mk; i += DT) beta[i] = p[i] / psq[i];
     if (tid == 0) { G.betajc[k + 1] = G.betajc[k] + mk; G.permoff[k + 1] = G.permoff[k]; G.dopiv[k] = 0; }
-    return;
-  }
+  } else {
   int *perm = G.pivperm + G.permoff[k];
   for (int q = tid; q < nacc; q += DT) { const int r = G.ord2[q]; perm[q] = r; beta[q] = p[r] / psq[r]; }
   // ---- postponed rows: sort by (p_j^2 descending, row ascending), second round (ph2dpr1fact, dpr1fact.c:224-240)
@@ -261,7 +261,9 @@ k_dpr1_general(Dpr1G G) {
     G.permoff[k + 1] = G.permoff[k] + mk;
     G.dopiv[k] = 1;
   }
-  // ---- subtracting a rank-1 term (Lorentz trace columns) may bring a removed dependency back (findnewdep, dpr1fact.c:495-512)
+  }
+  // ---- subtracting a rank-1 term (Lorentz trace columns) may bring a removed dependency back (findnewdep, dpr1fact.c:495-512;
+  // prodformfact calls it after EVERY column with a negative multiple, :575-576, whichever way dodpr1fact went)
   __syncthreads();
   if (tid == 0 && G.tmul < 0.0) {
     int *dep = G.dep;

@@ -8,35 +8,42 @@
 //     (below), their device-side analysis (ada_build, chol_build) is done once and kept;
 //   * the value arrays one gateway returned as the next one's input -- ADA from getada1 -> getada2 -> getada3 -> blkchol,
 //     L.L from blkchol -> fwblkslv / bwblkslv: the device still holds them, so they are not uploaded again.
-// Residency is never assumed from a host address alone (MATLAB may free an array and hand the same address to another one
-// of the same shape): every reuse is backed by a content fingerprint of what the host array holds NOW.
-//
-// Fingerprints.  `Finger` records length, a sampled hash (SAMPLE evenly spaced words) and, up to FULL_MAX words, the hash
-// of every word, plus the addresses at which this content has been seen.  A candidate matches if its sampled hash agrees
-// and (a) it sits at a known address, or (b) its full hash agrees (the address is then remembered).  Arrays beyond
-// FULL_MAX words at an unknown address do not match: the analysis is redone / the values are uploaded (correct, slower).
-// Limit of (a): an edit IN PLACE of an array the cache has seen, at words the sample does not touch, goes unnoticed --
-// MATLAB's value semantics make that an exclusive-owner `X(i) = v` between two gateway calls, which sedumi.m never does;
-// sdm_mexcache_set_strict(1) hashes every word in case (a) as well.
+// Residency is decided by CONTENT: an array is taken for the one the device holds only if a checksum over EVERY word of what the
+// host array holds now equals the checksum of the resident data (for arrays a gateway produced: summed on the device over what
+// it left in HBM, k_words_checksum).  The one shortcut, and its limit:
+//   * arrays of up to `full_below` words (default 65 536 = 512 KB, ~15 us) are checksummed completely at EVERY presentation;
+//   * a larger array is checksummed completely the first time an address presents it in an EPOCH (one epoch = the interval
+//     between two blkchol calls, i.e. one IPM iteration); further presentations AT THAT ADDRESS IN THAT EPOCH are accepted on
+//     length + a sampled hash (SAMPLE evenly spaced words + first and last).  An address is trusted only for the epoch in
+//     which this cache itself READ every word there and found the resident content.  Not trusted: the output buffer a gateway has
+//     just written (the host may copy the result and free the buffer -- Octave and this package's own MEX host do -- and hand the
+//     address to another array; GPUTEST r04 / r05a failed on exactly that); nothing is remembered across epochs.
+// Limit of the shortcut (stated in DESIGN.md 1a / INTEGRATION.md, asserted by tests/test_mexshims.py): a large array that is
+// edited IN PLACE -- or freed and replaced at the same address by an array of the same length -- at words the sample does not
+// touch, between two presentations inside one epoch, is still taken for the resident one.  sedumi.m never does that
+// (sedumi.m:450-462, wrapPcg.m:56-59 hand the gateways' outputs on untouched).  sdm_mexcache_set_strict(1) removes the shortcut:
+// every presentation is checksummed completely, whatever the size.
 #include "sdm_plan.h"
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace sdm;
 
 namespace {
 typedef unsigned long long u64;
-constexpr sdm_int SAMPLE = 512;            // words of the sampled hash (each a cache and TLB miss on a big array: 4096 of them cost 0.7 ms per check on a 64 MB factor)
-constexpr sdm_int FULL_MAX = 1 << 22;      // full hash only up to 4M words (32 MB, ~2 ms on the host)
+constexpr sdm_int SAMPLE = 512;            // words of the sampled hash
+constexpr sdm_int THREADS_FROM = 1 << 20;  // arrays from 1M words (8 MB) on are checksummed by several host threads
 constexpr u64 P1 = 11400714785074694791ull, P2 = 14029467366897019727ull;
 inline u64 rotl(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
 inline u64 lane(u64 acc, u64 v) { return rotl(acc + v * P2, 31) * P1; }
 // every word, position dependent, as eight independent wrap-around sums of 32 x 32 -> 64 bit products: the compiler vectorises
 // it on the host, and -- sums commute -- the same value comes out of a parallel reduction on the device (k_words_checksum:
-// what blkchol leaves in HBM is fingerprinted there for free instead of by a pass over the host copy).  A change detector, not a
-// cryptographic hash: any single changed word changes its sum.
+// what a gateway leaves in HBM is fingerprinted there instead of by a pass over the host copy) or of several host threads.
+// A change detector, not a cryptographic hash: any single changed word changes its sum.
 #define SDM_CK_C1 {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u}
 #define SDM_CK_C2 {0x8DA6B343u, 0xD8163841u, 0xCB1AB31Fu, 0x9F6B3F4Bu, 0xA54FF53Bu, 0x3C6EF373u, 0xBB67AE85u, 0x6A09E667u}
 u64 fold_sums(const u64 *acc, sdm_int n) {
@@ -44,19 +51,54 @@ u64 fold_sums(const u64 *acc, sdm_int n) {
   for (int k = 0; k < 8; k++) h = lane(h, acc[k]);
   return h;
 }
+// the eight sums over the words [i0, i1) of v (i0 a multiple of 8), added into acc; one body, compiled for the baseline ISA and for
+// AVX2 / AVX-512 (the host of a GPU box has them; picked once at run time)
+#define SDM_CK_BODY                                                                                                          \
+  static const u64 C1[8] = SDM_CK_C1, C2[8] = SDM_CK_C2;                                                                     \
+  u64 a[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                                                                       \
+  sdm_int i = i0;                                                                                                            \
+  for (; i + 8 <= i1; i += 8)                                                                                                \
+    for (int k = 0; k < 8; k++) {                                                                                            \
+      const u64 w = v[i + k];                                                                                                \
+      a[k] += (u64)((unsigned)w ^ (unsigned)i) * C1[k] + (u64)((unsigned)(w >> 32) ^ (unsigned)i) * C2[k];                   \
+    }                                                                                                                        \
+  for (int k = 0; i + k < i1; k++) {                                                                                         \
+    const u64 w = v[i + k];                                                                                                  \
+    a[k] += (u64)((unsigned)w ^ (unsigned)i) * C1[k] + (u64)((unsigned)(w >> 32) ^ (unsigned)i) * C2[k];                     \
+  }                                                                                                                          \
+  for (int k = 0; k < 8; k++) acc[k] += a[k];
+void sums_base(const u64 *v, sdm_int i0, sdm_int i1, u64 *acc) { SDM_CK_BODY }
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__) && !defined(SDM_NO_MULTIVERSION)
+__attribute__((target("avx2"))) void sums_avx2(const u64 *v, sdm_int i0, sdm_int i1, u64 *acc) { SDM_CK_BODY }
+__attribute__((target("avx512f,avx512dq,avx512vl"))) void sums_avx512(const u64 *v, sdm_int i0, sdm_int i1, u64 *acc) { SDM_CK_BODY }
+typedef void (*sums_fn)(const u64 *, sdm_int, sdm_int, u64 *);
+sums_fn pick_sums() {
+  __builtin_cpu_init();
+  if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl")) return sums_avx512;
+  if (__builtin_cpu_supports("avx2")) return sums_avx2;
+  return sums_base;
+}
+const sums_fn sums = pick_sums();
+#else
+#define sums sums_base
+#endif
 u64 hash_full(const void *pv, sdm_int n) {
   const u64 *v = (const u64 *)pv;
-  static const u64 C1[8] = SDM_CK_C1, C2[8] = SDM_CK_C2;
   u64 acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  sdm_int i = 0;
-  for (; i + 8 <= n; i += 8)
-    for (int k = 0; k < 8; k++) {
-      const u64 w = v[i + k];
-      acc[k] += (u64)((unsigned)w ^ (unsigned)i) * C1[k] + (u64)((unsigned)(w >> 32) ^ (unsigned)i) * C2[k];
+  unsigned nt = n >= THREADS_FROM ? std::thread::hardware_concurrency() : 1;
+  if (nt > 8) nt = 8;
+  if (nt <= 1) sums(v, 0, n, acc);
+  else {
+    u64 part[8][8] = {};
+    const sdm_int chunk = ((n + nt - 1) / nt + 7) & ~(sdm_int)7;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) {
+      const sdm_int i0 = std::min(n, (sdm_int)t * chunk), i1 = std::min(n, i0 + chunk);
+      th.emplace_back([=, &part] { sums(v, i0, i1, part[t]); });
     }
-  for (int k = 0; i + k < n; k++) {
-    const u64 w = v[i + k];
-    acc[k] += (u64)((unsigned)w ^ (unsigned)i) * C1[k] + (u64)((unsigned)(w >> 32) ^ (unsigned)i) * C2[k];
+    sums(v, 0, std::min(n, chunk), part[0]);
+    for (auto &t : th) t.join();
+    for (unsigned t = 0; t < nt; t++) for (int k = 0; k < 8; k++) acc[k] += part[t][k];
   }
   return fold_sums(acc, n);
 }
@@ -82,39 +124,47 @@ u64 hash_sampled(const void *pv, sdm_int n) {                         // always 
   for (sdm_int i = 0; i < n; i += step) h = lane(h, v[i]);
   return lane(h, v[n - 1]);
 }
-bool strict = false;      // sdm_mexcache_set_strict: every word of an array at a known address is hashed too (in-place edits between calls)
+bool strict = false;            // sdm_mexcache_set_strict: no shortcut, every presentation is checksummed completely
+sdm_int full_below = 1 << 16;   // sdm_mexcache_set_full_below: arrays up to this many words are checksummed completely at every presentation
+u64 g_epoch = 1;                // advances with every blkchol call: the lifetime of a trusted address (file header)
+sdm_int g_fullsum_words = 0;    // words checksummed on the host since the last sdm_mexcache_clear (the cost of the content checks; stats[11])
+
+// What is known about one array the device holds a copy of (or the analysis of): its length, the sampled hash, the checksum of every
+// word, and the addresses at which THIS epoch every word has been read (or written) by the cache itself.
 struct Finger {
   sdm_int n = -1;
   u64 sample = 0, full = 0;
-  bool have_full = false;
-  const void *at[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // (the last eight addresses it was seen at)
-  int nat = 0;
-  void seen_at(const void *p) {
-    for (int i = 0; i < 8; i++) if (at[i] == p) return;
-    at[nat++ & 7] = p;
+  struct { const void *p; u64 epoch; } ok[8] = {};
+  int nok = 0;
+  bool trusted(const void *p) const {
+    for (int i = 0; i < 8; i++) if (p && ok[i].p == p && ok[i].epoch == g_epoch) return true;
+    return false;
   }
-  // want_full = false: the content is only ever recognised at this address (value arrays that travel from one gateway to
-  // the next by reference; at another address they are simply uploaded again)
-  // any_size: the full checksum whatever the length (patterns: once per solve; without it an array beyond FULL_MAX is only ever
-  // recognised at an address it has been seen at)
-  void take(const void *p, sdm_int len, bool want_full = true, bool any_size = false) {
-    n = len; sample = hash_sampled(p, len);
-    have_full = want_full && (any_size || len <= FULL_MAX);
-    full = have_full ? hash_full(p, len) : 0;
-    for (auto &a : at) a = nullptr;
-    nat = 0; seen_at(p);
+  // every word at p was read (or written) by the cache in this epoch and is this content
+  void verified(const void *p) {
+    if (!p || trusted(p)) return;
+    for (int i = 0; i < 8; i++) if (ok[i].p == p) { ok[i].epoch = g_epoch; return; }
+    ok[nok & 7].p = p; ok[nok++ & 7].epoch = g_epoch;
   }
-  // the full hash computed elsewhere (on the device copy of the same values)
+  void take(const void *p, sdm_int len) {
+    n = len; sample = hash_sampled(p, len); full = hash_full(p, len); g_fullsum_words += len;
+    for (auto &a : ok) a.p = nullptr;
+    nok = 0; verified(p);
+  }
+  // the checksum computed elsewhere: on the device copy of the values that have just been downloaded to p.  No address is trusted
+  // yet: whoever presents this content has it read completely once (file header)
   void take_with_full(const void *p, sdm_int len, u64 fullhash) {
-    take(p, len, false);
-    have_full = true; full = fullhash;
+    n = len; sample = hash_sampled(p, len); full = fullhash;
+    for (auto &a : ok) a.p = nullptr;
+    nok = 0;
   }
   bool same(const void *p, sdm_int len) {
     if (len != n || n < 0) return false;
-    if (hash_sampled(p, len) != sample) return false;
-    for (int i = 0; i < 8; i++) if (at[i] == p && p) return !(strict && have_full) || hash_full(p, len) == full;
-    if (!have_full || hash_full(p, len) != full) return false;
-    seen_at(p);
+    if (hash_sampled(p, len) != sample) return false;                 // (a cheap reject; never an accept on its own below full_below)
+    if (!strict && len > full_below && trusted(p)) return true;       // the shortcut of the file header
+    g_fullsum_words += len;
+    if (hash_full(p, len) != full) return false;
+    verified(p);
     return true;
   }
   void forget() { n = -1; }
@@ -130,13 +180,8 @@ u64 intern(sdm_int ncol, const sdm_int *jc, const sdm_int *ir) {
     if (p.id && p.ncol == ncol && p.jc.same(jc, ncol + 1) && p.ir.same(ir, nnz)) { p.used = ++g_clock; return p.id; }
   Pattern *v = &g_pat[0];
   for (auto &p : g_pat) if (p.used < v->used) v = &p;                 // least recently used (empty entries first: used = 0)
-  v->ncol = ncol; v->jc.take(jc, ncol + 1, true, true); v->ir.take(ir, nnz, true, true); v->id = g_next_id++; v->used = ++g_clock;
+  v->ncol = ncol; v->jc.take(jc, ncol + 1); v->ir.take(ir, nnz); v->id = g_next_id++; v->used = ++g_clock;
   return v->id;
-}
-// `ir` is a copy of the row indices of pattern `id` that a shim made for the array it returns: the next call presents it
-void alias(u64 id, const sdm_int *ir) {
-  if (!ir) return;
-  for (auto &p : g_pat) if (p.id == id) p.ir.seen_at(ir);
 }
 
 sdm_int g_stat[16];       // counters for tests and the bench (sdm_mexcache_stats)
@@ -169,7 +214,23 @@ AdaSlot g_s1, g_s2, g_s3, g_s0;
 
 // whose ada_val holds the ADA values most recently handed back to the host, and what they were
 struct { sdm_plan *plan = nullptr; Finger vals; } g_last;
-void returned(sdm_plan *p, const double *pr, sdm_int nnz) { g_last.plan = p; g_last.vals.take(pr, nnz, false); }
+DevBuf<u64> g_ck;                       // eight device words: checksum of values a gateway leaves in HBM (k_words_checksum)
+// the eight sums of n device words -> acc8 (host), queued on the plan's stream: valid once the stream has been drained
+void device_checksum(sdm_plan *p, const double *v, sdm_int n, u64 *acc8) {
+  if (!g_ck.p) g_ck.alloc(8);
+  const sdm_int wg = std::min<sdm_int>(2048, std::max<sdm_int>(64, n / 8192));
+  SDM_HIP_CHECK(hipMemsetAsync(g_ck.p, 0, 8 * sizeof(u64), p->stream));
+  SDM_LAUNCH(k_words_checksum, dim3((unsigned)wg), dim3(256), 0, p->stream, (const unsigned long long *)v, (long long)n, g_ck.p);
+  SDM_HIP_CHECK(hipMemcpyAsync(acc8, g_ck.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, p->stream));
+}
+// ADA' values and absd of plan p -> the host arrays the shim returns, together with the checksum of the values summed on the device:
+// the array at pr is, from now on, known to hold what p->ada_val holds
+void download_returned(sdm_plan *p, double *pr, double *absd, sdm_int nnz) {
+  u64 acc[8];
+  device_checksum(p, p->ada_val.p, nnz, acc);
+  gw_download(p, pr, absd);                                           // (drains the stream)
+  g_last.plan = p; g_last.vals.take_with_full(pr, nnz, fold_sums(acc, nnz));
+}
 // the input values of a gateway -> p->ada_val: from the device if they are what the previous gateway returned, else from the host
 void ada_input(sdm_plan *p, const double *pr, sdm_int nnz) {
   if (g_last.plan && g_last.vals.same(pr, nnz)) {
@@ -190,18 +251,18 @@ struct Chol {
   std::vector<sdm_int> perm, xsuper;
   bool have_factor = false;
   Finger lpr;
-  DevBuf<u64> ck;                        // eight device words: checksum of the factor's values (k_words_checksum)
 } g;
 
 void drop_chol() {
   if (g.plan) { forget_plan(g.plan); sdm_plan_destroy(g.plan); }
-  g.ck.release();
   g.plan = nullptr; g.pat_l = g.pat_x = 0; g.perm.clear(); g.xsuper.clear(); g.have_factor = false; g.lpr.forget();
 }
 void drop_all() {
   for (AdaSlot *s : {&g_s1, &g_s2, &g_s3, &g_s0}) { if (s->plan) forget_plan(s->plan); s->drop(); }
   drop_chol();
+  g_ck.release();
   for (auto &p : g_pat) p = Pattern();
+  g_fullsum_words = 0;
 }
 void at_exit_once() {
   // the cached plans own streams, events and device memory: they go before the HIP runtime's own exit handlers run (registered
@@ -215,8 +276,9 @@ bool vec_is(const std::vector<sdm_int> &v, const sdm_int *p, sdm_int n) {
 }
 
 sdm_plan *chol_plan(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm, sdm_int nsuper, const sdm_int *xsuper,
-                    const sdm_int *Xjc, const sdm_int *Xir) {
-  const u64 pl = intern(m, Ljc, Lir), px = intern(m, Xjc, Xir);
+                    const sdm_int *Xjc, const sdm_int *Xir, u64 px = 0) {
+  const u64 pl = intern(m, Ljc, Lir);
+  if (!px) px = intern(m, Xjc, Xir);
   if (g.plan && g.pat_l == pl && g.pat_x == px && vec_is(g.perm, perm, m) && vec_is(g.xsuper, xsuper, nsuper + 1)) { g_stat[ST_CHOL_REUSE]++; return g.plan; }
   drop_chol();
   g.plan = new_plan();
@@ -238,16 +300,22 @@ sdm_plan *chol_plan(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm
 extern "C" {
 
 void sdm_mexcache_clear(void) { drop_all(); }
-// on != 0: an array presented at an address the cache knows is compared word for word (full hash) instead of by its sampled
-// hash -- for callers that edit arrays IN PLACE between gateway calls (sedumi.m never does); costs ~0.7 ns per word and call
+// the content checksum of n 8-byte words on the host (what residency is decided on; tests, and the bench's statement of its cost)
+unsigned long long sdm_mexcache_checksum(const void *words, sdm_int n) { return hash_full(words, n); }
+// on != 0: every presentation of every array is checksummed completely (no address is ever trusted) -- for callers that edit arrays
+// IN PLACE between gateway calls of one iteration (sedumi.m never does); costs a pass over the host array per call
 void sdm_mexcache_set_strict(int on) { strict = on != 0; }
-void sdm_mexcache_stats(sdm_int *out, sdm_int n) { for (sdm_int i = 0; i < n && i < 16; i++) out[i] = g_stat[i]; }
+void sdm_mexcache_stats(sdm_int *out, sdm_int n) {
+  g_stat[11] = g_fullsum_words; g_stat[12] = (sdm_int)g_epoch;
+  for (sdm_int i = 0; i < n && i < 16; i++) out[i] = g_stat[i];
+}
+// arrays of up to `words` words are checksummed completely at every presentation (default 65 536); larger ones once per address and epoch
+void sdm_mexcache_set_full_below(sdm_int words) { full_below = words < 0 ? 0 : words; }
 
-// ADA = getada1(ADA, A, Ajc2, perm, d, blkstart) on the cache (same arguments as sdm_getada1; ADAir_out: the row indices of
-// the array the shim returns, a copy of ADAir, or NULL)
+// ADA = getada1(ADA, A, Ajc2, perm, d, blkstart) on the cache (same arguments as sdm_getada1)
 int sdm_mexcache_getada1(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc, const sdm_int *Air,
                          const double *Apr, const sdm_int *Ajc2, const sdm_int *perm, sdm_int lpN, const double *dl, sdm_int lorN,
-                         const double *ddet, const sdm_int *qblkstart, double *ADApr, const sdm_int *ADAir_out) {
+                         const double *ddet, const sdm_int *qblkstart, double *ADApr) {
   MC_TRY
   AdaSlot &S = g_s1;
   const u64 pa = intern(m, ADAjc, ADAir), pA = intern(m, Ajc, Air);
@@ -264,15 +332,13 @@ int sdm_mexcache_getada1(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, 
   } else g_stat[ST_ADA_REUSE]++;
   S.set_perm(perm, m);
   gw_run_getada1(S.plan, S.invperm.p, dl, ddet);
-  gw_download(S.plan, ADApr, nullptr);
-  returned(S.plan, ADApr, ADAjc[m]);
-  alias(pa, ADAir_out);
+  download_returned(S.plan, ADApr, nullptr, ADAjc[m]);
   MC_CATCH
 }
 
 // ADA = getada2(ADA, DAt, Aord, K): ADApr_in the values of the input array, ADApr (out) those of the copy the shim returns
 int sdm_mexcache_getada2(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const double *ADApr_in, double *ADApr, sdm_int lorN,
-                         const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, const sdm_int *qperm, const sdm_int *ADAir_out) {
+                         const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, const sdm_int *qperm) {
   MC_TRY
   AdaSlot &S = g_s2;
   const u64 pa = intern(m, ADAjc, ADAir), pq = intern(m, Qjc, Qir);
@@ -289,24 +355,13 @@ int sdm_mexcache_getada2(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, 
   S.set_perm(qperm, m);
   ada_input(S.plan, ADApr_in, ADAjc[m]);
   gw_run_getada2(S.plan, S.invperm.p, Qpr);
-  gw_download(S.plan, ADApr, nullptr);
-  returned(S.plan, ADApr, ADAjc[m]);
-  alias(pa, ADAir_out);
+  download_returned(S.plan, ADApr, nullptr, ADAjc[m]);
   MC_CATCH
 }
-// the copy getada2 returns when there is nothing to add (getada2.c:154-155): the device copy stays the current one
-void sdm_mexcache_getada2_passthrough(sdm_int nnz, const double *ADApr_in, const double *ADApr_out, const sdm_int *ADAir_in, const sdm_int *ADAir_out) {
-  if (g_last.plan && g_last.vals.same(ADApr_in, nnz)) g_last.vals.seen_at(ADApr_out);
-  // (the copy's row indices too: a pattern too big for the full checksum is only recognised at an address the cache knows -- with an
-  // allocator that does not hand out the same address every iteration getada3 took the copy for a new pattern and rebuilt its analysis)
-  if (ADAir_in && ADAir_out)
-    for (auto &p : g_pat) if (p.id && p.ir.n == nnz && p.ir.same(ADAir_in, nnz)) { p.ir.seen_at(ADAir_out); break; }
-}
-
 // [ADA, absd] = getada3(ADA, A, Ajc1, Aord, udsqr, K)
 int sdm_mexcache_getada3(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const double *ADApr_in, double *ADApr, sdm_int N,
                          const sdm_int *Ajc, const sdm_int *Air, const double *Apr, const sdm_int *Ajc1, const double *udsqr,
-                         const sdm_cone *K, const sdm_int *psd_blkstart, double *absd, const sdm_int *ADAir_out) {
+                         const sdm_cone *K, const sdm_int *psd_blkstart, double *absd) {
   MC_TRY
   AdaSlot &S = g_s3;
   const u64 pa = intern(m, ADAjc, ADAir), pA = intern(m, Ajc, Air);
@@ -324,16 +379,14 @@ int sdm_mexcache_getada3(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, 
   } else g_stat[ST_ADA_REUSE]++;
   ada_input(S.plan, ADApr_in, ADAjc[m]);
   gw_run_getada3(S.plan, udsqr);
-  gw_download(S.plan, ADApr, absd);
-  returned(S.plan, ADApr, ADAjc[m]);
-  alias(pa, ADAir_out);
+  download_returned(S.plan, ADApr, absd, ADAjc[m]);
   MC_CATCH
 }
 
 // absd = getada(A, K, d, DAt) [global ADA_sedumi_]: the whole ADA' of a problem without PSD blocks (getada.m:13-40)
 int sdm_mexcache_getada(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc, const sdm_int *Air,
                         const double *Apr, sdm_int lpN, const double *dl, sdm_int lorN, const double *ddet, const sdm_int *qblkstart,
-                        const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, double *ADApr, double *absd, const sdm_int *ADAir_out) {
+                        const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, double *ADApr, double *absd) {
   MC_TRY
   AdaSlot &S = g_s0;
   const u64 pa = intern(m, ADAjc, ADAir), pA = intern(m, Ajc, Air), pq = lorN > 0 ? intern(m, Qjc, Qir) : 0;
@@ -349,23 +402,24 @@ int sdm_mexcache_getada(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, s
     S.built = true;
   } else g_stat[ST_ADA_REUSE]++;
   gw_run_getada(S.plan, dl, ddet, Qpr);
-  gw_download(S.plan, ADApr, absd);
-  returned(S.plan, ADApr, ADAjc[m]);
-  alias(pa, ADAir_out);
+  download_returned(S.plan, ADApr, absd, ADAjc[m]);
   MC_CATCH
 }
 
-// [L.L, L.d, L.skip, L.add] = blkchol(L, X, pars, absd) on the cache (arguments of sdm_blkchol; Lir_out: the row indices of the
-// L.L the shim returns, a copy of Lir, or NULL).  The factor stays resident for the solves.
+// [L.L, L.d, L.skip, L.add] = blkchol(L, X, pars, absd) on the cache (arguments of sdm_blkchol).  The factor stays resident for the solves.
 int sdm_mexcache_blkchol(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm, sdm_int nsuper, const sdm_int *xsuper,
                          const sdm_int *Xjc, const sdm_int *Xir, const double *Xpr, const sdm_cholpars *pars, const double *absd,
                          double *Lpr, double *d, sdm_int *nskip, sdm_int *skip_idx, double *skip_val, sdm_int *nadd, sdm_int *add_idx,
-                         double *add_val, const sdm_int *Lir_out) {
+                         double *add_val) {
   MC_TRY
-  sdm_plan *p = chol_plan(m, Ljc, Lir, perm, nsuper, xsuper, Xjc, Xir);
-  g.have_factor = false;             // the resident factor is about to be overwritten: whatever the solves are handed before this call has returned is not it
+  // X is what getada3 returned in the epoch that ends here: its values and pattern are looked at before the epoch advances
   const sdm_int nnzX = Xjc[m], nnzL = Ljc[m];
-  if (g_last.plan && g_last.vals.same(Xpr, nnzX)) {
+  const u64 px = intern(m, Xjc, Xir);
+  const bool x_resident = g_last.plan && g_last.vals.same(Xpr, nnzX);
+  g_epoch++;                         // a new factor: every address trusted so far has to present its complete content again (file header)
+  sdm_plan *p = chol_plan(m, Ljc, Lir, perm, nsuper, xsuper, Xjc, Xir, px);
+  g.have_factor = false;             // the resident factor is about to be overwritten: whatever the solves are handed before this call has returned is not it
+  if (x_resident) {
     g_stat[ST_X_RESIDENT]++;
     if (g_last.plan != p)
       SDM_HIP_CHECK(hipMemcpyAsync(p->ada_val.p, g_last.plan->ada_val.p, (size_t)nnzX * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
@@ -377,17 +431,13 @@ int sdm_mexcache_blkchol(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, cons
   if (sdm_plan_blkchol_wait(p, pars, absd ? 1 : 0)) throw std::runtime_error(sdm_last_error());   // (waited for, repeated once on the launch-per-panel path after a time-out)
   // L.L values, L.d and the fingerprint of the factor (summed on the device: no pass over the host copy) in one drain of the stream
   u64 acc[8];
-  if (!g.ck.p) g.ck.alloc(8);
   chol_extract(p, p->lpr.p);
-  SDM_HIP_CHECK(hipMemsetAsync(g.ck.p, 0, 8 * sizeof(u64), p->stream));
-  SDM_LAUNCH(k_words_checksum, dim3(64), dim3(256), 0, p->stream, (const unsigned long long *)p->lpr.p, (long long)nnzL, g.ck.p);
+  device_checksum(p, p->lpr.p, nnzL, acc);
   SDM_HIP_CHECK(hipMemcpyAsync(Lpr, p->lpr.p, (size_t)nnzL * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   SDM_HIP_CHECK(hipMemcpyAsync(d, p->chol.d.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  SDM_HIP_CHECK(hipMemcpyAsync(acc, g.ck.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, p->stream));
   if (sdm_plan_pivots(p, nskip, skip_idx, skip_val, nadd, add_idx, add_val)) throw std::runtime_error(sdm_last_error());   // (drains the stream)
   g.lpr.take_with_full(Lpr, nnzL, fold_sums(acc, nnzL));
   g.have_factor = true;
-  alias(g.pat_l, Lir_out);
   MC_CATCH
 }
 

@@ -33,8 +33,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   // the factor stays resident in the library's cache for fwblkslv / bwblkslv; X is taken from the device when it is the
   // array getada3 just returned (sdm_mexcache.hip)
   sdm_check(sdm_mexcache_blkchol(m, L.jc.data(), L.ir.data(), L.perm.data(), L.nsuper, L.xsuper.data(), Xjc.data(), Xir.data(), mxGetPr(X),
-                                 &pars, absd, mxGetPr(out[0]), mxGetPr(out[1]), &ns, sidx.data(), sval.data(), &na, aidx.data(), aval.data(),
-                                 idx_or_null(mxGetIr(out[0]))));
+                                 &pars, absd, mxGetPr(out[0]), mxGetPr(out[1]), &ns, sidx.data(), sval.data(), &na, aidx.data(), aval.data()));
   (void)nnzL;
   for (int k = 0; k < 2; k++) {                                       // sparse m x 1 outputs (blkchol.c:396-421)
     const sdm_int n = k ? na : ns;

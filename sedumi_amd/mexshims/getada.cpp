@@ -48,7 +48,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   plhs[0] = mxCreateDoubleMatrix(m, 1, mxREAL);
   IdxView jc = jc_of(G), ir = ir_of(G), Ajc = jc_of(A), Air = ir_of(A);
   int rc = sdm_mexcache_getada(m, jc.data(), ir.data(), N, Ajc.data(), Air.data(), mxGetPr(A), ck.K.lpN, mxGetPr(dl), ck.K.lorN, mxGetPr(ddet),
-                               qb.data(), Qjc, Qir, qpr, mxGetPr(out), mxGetPr(plhs[0]), idx_or_null(mxGetIr(out)));
+                               qb.data(), Qjc, Qir, qpr, mxGetPr(out), mxGetPr(plhs[0]));
   if (rc) { mxDestroyArray(out); mexErrMsgTxt(sdm_last_error()); }
   if (mexPutVariable("global", "ADA_sedumi_", out)) { mxDestroyArray(out); mexErrMsgTxt("could not update global ADA_sedumi_."); }
   mxDestroyArray(out);                                               // mexPutVariable stored a copy

@@ -19,5 +19,5 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   cache_teardown_at_exit();
   plhs[0] = sparse_like(ADA);                                        // getada1.c:222-225
   sdm_check(sdm_mexcache_getada1(m, jc.data(), ir.data(), (sdm_int)mxGetM(A), Ajc.data(), Air.data(), mxGetPr(A), Ajc2.data(), perm.data(),
-                                 (sdm_int)numel(dl), mxGetPr(dl), lorN, mxGetPr(ddet), qb.data(), mxGetPr(plhs[0]), idx_or_null(mxGetIr(plhs[0]))));
+                                 (sdm_int)numel(dl), mxGetPr(dl), lorN, mxGetPr(ddet), qb.data(), mxGetPr(plhs[0])));
 }

@@ -8,9 +8,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   const sdm_int m = (sdm_int)mxGetM(ADA);
   cache_teardown_at_exit();
   if (ck.K.lorN == 0) {                                              // getada2.c:153-155: the copy, nothing added
-    plhs[0] = mxDuplicateArray(ADA);
-    sdm_mexcache_getada2_passthrough((sdm_int)mxGetJc(ADA)[mxGetN(ADA)], mxGetPr(ADA), mxGetPr(plhs[0]), (const sdm_int *)mxGetIr(ADA),
-                                     (const sdm_int *)mxGetIr(plhs[0]));
+    plhs[0] = mxDuplicateArray(ADA);                                // (the same content: getada3 recognises it by that)
     return;
   }
   const mxArray *Q = need_field(prhs[1], "q", "Missing field DAt.q.");
@@ -21,5 +19,5 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   ivec qperm = idx_from_dbl(qp, -1);
   plhs[0] = sparse_like(ADA);                                        // getada2.c:153 (the values come back from the device)
   sdm_check(sdm_mexcache_getada2(m, jc.data(), ir.data(), mxGetPr(ADA), mxGetPr(plhs[0]), ck.K.lorN, Qjc.data(), Qir.data(), mxGetPr(Q),
-                                 qperm.data(), idx_or_null(mxGetIr(plhs[0]))));
+                                 qperm.data()));
 }

@@ -21,7 +21,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   mxArray *out0 = sparse_like(ADA);                                  // getada3.c:452 (the values come back from the device)
   mxArray *out1 = mxCreateDoubleMatrix(m, 1, mxREAL);
   sdm_check(sdm_mexcache_getada3(m, jc.data(), ir.data(), mxGetPr(ADA), mxGetPr(out0), (sdm_int)mxGetM(A), Ajc.data(), Air.data(), mxGetPr(A),
-                                 Ajc1.data(), mxGetPr(prhs[4]), &ck.K, psd.data(), mxGetPr(out1), idx_or_null(mxGetIr(out0))));
+                                 Ajc1.data(), mxGetPr(prhs[4]), &ck.K, psd.data(), mxGetPr(out1)));
   plhs[0] = out0;
   if (nlhs > 1) plhs[1] = out1; else mxDestroyArray(out1);           // getada3.c:565-568
 }

@@ -54,7 +54,6 @@ inline mxArray *sparse_like(const mxArray *src) {
   if (!nnz) pr[0] = 0.0;
   return a;
 }
-inline const sdm_int *idx_or_null(const mwIndex *q) { return sizeof(mwIndex) == sizeof(sdm_int) ? reinterpret_cast<const sdm_int *>(q) : NULL; }
 
 struct SymbL {                       // L.{L,perm,xsuper} as the numeric gateways read it (blkchol.c:266-286)
   sdm_int m, nsuper;

@@ -220,6 +220,30 @@ def test_general_dpr1fact_on_the_device(refmex, glue, seed, zero_d, maxuden):
     check_resident_dense_unit(refmex, c, expect_host=False)
 
 
+@pytest.mark.parametrize("seed,cfac", [(49, 4.0), (57, 4.0), (73, 4.0), (75, 0.9), (79, 0.9), (79, 1.5)])
+def test_negative_multiple_brings_a_removed_dependency_back(refmex, glue, seed, cfac):
+    """Dependent rows (d = 0) whose dependency an earlier column removes, then a LATE column with a negative multiple that drives
+    that d back to <= 0: prodformfact calls findnewdep after EVERY column with smult < 0 (dpr1fact.c:575-576, :495-512), also when
+    dodpr1fact took the natural-order path (:330-333).  (The cases are the ones of a seed sweep on which a device kernel that
+    returned before findnewdep on that path differed from the reference: betajc / pivperm / d depend on dep[].)"""
+    from oracle.refmex import RawSparse
+    from sedumi_amd import mex
+    c = dense_case(refmex, glue, 60, 400, 5, seed, 2, 500.0)
+    r = c["sym_ref"]
+    perm = np.asarray(r["perm"]).ravel().astype(int) - 1
+    k0 = perm[len(perm) - 1 - (seed % 2)]
+    pcol = np.asarray(c["LAD"][:, k0].todense()).ravel()
+    c["smult"] = c["smult"].copy()
+    c["smult"][k0] = -cfac / float(np.sum(pcol ** 2 / np.where(c["Ld"] > 0, c["Ld"], np.inf)))
+    sref = {"dz": RawSparse(r["dz"]), "perm": r["perm"], "first": r["first"]}
+    sym = mex.finsymbden(c["LADsym"], c["perm"], c["dz"], float(c["denseA"].shape[1] + 1))
+    Lr, Ldr = refmex.call("dpr1fact", 2, c["LAD"], c["Ld"].reshape(-1, 1), sref, c["smult"].reshape(-1, 1), c["maxuden"])
+    Lo, Ldo = mex.dpr1fact(c["LAD"], c["Ld"], sym, c["smult"], c["maxuden"])
+    for key in ("betajc", "dopiv", "pivperm"):
+        assert np.array_equal(np.asarray(Lo[key]).ravel(), np.asarray(Lr[key]).ravel()), key
+    assert relerr(Lo["beta"], Lr["beta"]) < TOL and relerr(Lo["p"], Lr["p"]) < TOL and relerr(Ldo, Ldr) < TOL
+
+
 @pytest.mark.parametrize("seed,which", [(21, 0), (22, 0), (23, 1), (24, 2)])
 def test_dpr1fact_with_a_negative_multiple(refmex, glue, seed, which):
     """smult < 0 (the Lorentz trace columns of deninfac.m:62): D - |s| p p' with |s| small enough to stay positive definite;

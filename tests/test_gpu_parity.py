@@ -536,6 +536,12 @@ def test_dpr1fact_negative_multiple_on_gpu(refmex, glue, seed, which):
     test_dpr1fact_with_a_negative_multiple(refmex, glue, seed, which)
 
 
+@pytest.mark.parametrize("seed,cfac", [(49, 4.0), (75, 0.9), (79, 1.5)])
+def test_negative_multiple_brings_a_removed_dependency_back_on_gpu(refmex, glue, seed, cfac):
+    from test_dense_columns import test_negative_multiple_brings_a_removed_dependency_back
+    test_negative_multiple_brings_a_removed_dependency_back(refmex, glue, seed, cfac)
+
+
 @pytest.mark.parametrize("case", range(4))
 def test_pcg_operators_on_gpu(refmex, case):
     """Amul (sparse + dense columns), vecsym and psdscale (real and Hermitian blocks, with and without the

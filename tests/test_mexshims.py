@@ -136,15 +136,41 @@ def test_shim_invcholfac(refmex, shimmex):
         assert relerr(shimmex.call("invcholfac", 1, *args), refmex.call("invcholfac", 1, *args)) < TOL
 
 
+def _factor_probe(lib, L, m):
+    """resident(pattern, values) -> does sdm_mexcache_factor_plan take the host arrays GIVEN (no copies: the addresses are the caller's)
+    for the factor the device holds?"""
+    import ctypes
+    lib.sdm_mexcache_factor_plan.restype = ctypes.c_void_p
+    perm = (np.asarray(L["perm"]).ravel() - 1).astype(np.int64)
+    xs = (np.asarray(L["xsuper"]).ravel() - 1).astype(np.int64)
+    P = ctypes.POINTER(ctypes.c_int64)
+
+    def resident(jc, ir, pr):
+        assert jc.dtype == np.int64 and ir.dtype == np.int64 and pr.dtype == np.float64
+        return bool(lib.sdm_mexcache_factor_plan(ctypes.c_int64(m), jc.ctypes.data_as(P), ir.ctypes.data_as(P),
+                                                 pr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), perm.ctypes.data_as(P),
+                                                 ctypes.c_int64(xs.size - 1), xs.ctypes.data_as(P)))
+    return resident
+
+
+def _csc_arrays(LLv):
+    LL = sp.csc_matrix(LLv); LL.sort_indices()
+    return LL.indptr.astype(np.int64), LL.indices.astype(np.int64), np.array(LL.data, dtype=np.float64)
+
+
 def test_factor_cache_is_shared_between_mex_binaries_and_validated_by_content(glue, refmex, shimmex, shimlib):
     """blkchol.mex leaves the factor resident in the plan cached inside the library (sdm_mexcache_*); fwblkslv.mex /
     bwblkslv.mex -- separate shared objects -- reuse it only when the L.L values they are handed ARE that factor.
     Two blkchol calls on the same symbolic factor, then solves with the FIRST factor's values: the cache holds the
-    second factor, so the content check must reject it and the stateless path must give the first factor's answer."""
+    second factor, so the content check must reject it and the stateless path must give the first factor's answer.
+    Deterministic whatever the allocator does: a copy of the resident factor is accepted at ITS address, then one word of that
+    very array (one the 512-word sample does not look at) is changed in place -- an address the cache has accepted content at
+    -- and must be rejected: arrays of this size are checksummed completely at every presentation."""
     import ctypes
     from oracle import glue as gl
     lib = ctypes.CDLL(shimlib)
-    lib.sdm_mexcache_factor_plan.restype = ctypes.c_void_p
+    lib.sdm_mexcache_set_strict(0)
+    lib.sdm_mexcache_set_full_below(ctypes.c_int64(1 << 16))
     rng = np.random.default_rng(12)
     X1 = spd_pattern("rand", 120, rng, 0.05)
     X2 = sp.csc_matrix(X1 + sp.diags(rng.random(120) + 0.5)); X2.sort_indices()
@@ -154,26 +180,77 @@ def test_factor_cache_is_shared_between_mex_binaries_and_validated_by_content(gl
     LL2, Ld2, _, _ = shimmex.call("blkchol", 4, L, X2, pars)
     assert relerr(LL2, refmex.call("blkchol", 4, L, X2, pars)[0]) < TOL
     rhs = rng.standard_normal((120, 2))
-
-    def resident(LLv):
-        LL = sp.csc_matrix(LLv); LL.sort_indices()
-        jc, ir = LL.indptr.astype(np.int64), LL.indices.astype(np.int64)
-        pr = np.ascontiguousarray(LL.data, dtype=np.float64)
-        perm = (np.asarray(L["perm"]).ravel() - 1).astype(np.int64)
-        xs = (np.asarray(L["xsuper"]).ravel() - 1).astype(np.int64)
-        P = ctypes.POINTER(ctypes.c_int64)
-        return lib.sdm_mexcache_factor_plan(ctypes.c_int64(120), jc.ctypes.data_as(P), ir.ctypes.data_as(P),
-                                            pr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), perm.ctypes.data_as(P),
-                                            ctypes.c_int64(xs.size - 1), xs.ctypes.data_as(P))
-    assert resident(LL2) and not resident(LL1)                # the second factor is resident, the first is not
-    stale = LL2.copy(); stale.data[stale.nnz // 3] += 1e-9    # same shape, one value differs: not the resident factor
-    assert not resident(stale)
+    resident = _factor_probe(lib, L, 120)
+    jc, ir, pr2 = _csc_arrays(LL2)
+    _, _, pr1 = _csc_arrays(LL1)
+    assert resident(jc, ir, pr2) and not resident(jc, ir, pr1)     # the second factor is resident, the first is not
+    k = pr2.size // 3
+    assert pr2.size > 512 and k % -(-pr2.size // 512) != 0         # (a word the sampled hash does not look at)
+    for _ in range(3):
+        assert resident(jc, ir, pr2)                                # accepted at this address ...
+        keep = pr2[k]; pr2[k] += 1e-9
+        assert not resident(jc, ir, pr2)                            # ... and the same address with one value changed is not
+        pr2[k] = keep
+    keep = ir[k]; ir[k] = ir[k - 1] if ir[k - 1] != ir[k] else ir[k] + 1   # the pattern likewise
+    assert not resident(jc, ir, pr2)
+    ir[k] = keep
+    assert resident(jc, ir, pr2)
     for LLv in (LL2, LL1):                                    # resident path, then content-check fallback
         Lf = dict(L); Lf["L"] = LLv
         assert relerr(shimmex.call("fwblkslv", 1, Lf, rhs), refmex.call("fwblkslv", 1, Lf, rhs)) < TOL
         assert relerr(shimmex.call("bwblkslv", 1, Lf, rhs), refmex.call("bwblkslv", 1, Lf, rhs)) < TOL
     lib.sdm_mexcache_clear()
-    assert not resident(LL2)
+    assert not resident(jc, ir, pr2)
+
+
+def test_factor_cache_shortcut_for_large_arrays_is_exactly_the_documented_one(glue, refmex, shimmex, shimlib):
+    """sdm_mexcache.hip's header, DESIGN 1a, INTEGRATION.md: an array LARGER than `full_below` words is checksummed completely the
+    first time an address presents it in an epoch (= between two blkchol calls); later presentations at that address in that epoch
+    pass on length + the sampled hash.  So (the threshold lowered to make this factor `large`):
+      * a changed copy at an address the cache has never accepted is rejected -- always;
+      * a word the sample looks at, changed in place at a trusted address, is rejected;
+      * a word the sample does NOT look at, changed in place at a trusted address inside the epoch, is NOT noticed (the documented
+        limit) -- and IS noticed in strict mode, and after the next blkchol (new epoch: nothing is trusted any more)."""
+    import ctypes
+    from oracle import glue as gl
+    lib = ctypes.CDLL(shimlib)
+    lib.sdm_mexcache_set_strict(0)
+    rng = np.random.default_rng(13)
+    X = spd_pattern("rand", 120, rng, 0.05)
+    L = glue.symbchol(X)
+    pars = gl.default_pars_chol()
+    try:
+        lib.sdm_mexcache_set_full_below(ctypes.c_int64(100))
+        LL, _, _, _ = shimmex.call("blkchol", 4, L, X, pars)
+        resident = _factor_probe(lib, L, 120)
+        jc, ir, pr = _csc_arrays(LL)
+        n = pr.size
+        step = -(-n // 512)
+        k = n // 3
+        assert n > 512 and k % step != 0
+        other = pr.copy(); other[k] += 1e-9
+        assert not resident(jc, ir, other)                          # an address never accepted: complete checksum, rejected
+        assert resident(jc, ir, pr)                                 # complete checksum at this address: trusted for the epoch
+        pr[step * 5] += 1e-9
+        assert not resident(jc, ir, pr)                             # a sampled word
+        pr[step * 5] -= 1e-9
+        keep = pr[k]; pr[k] += 1e-9
+        assert resident(jc, ir, pr)                                 # THE LIMIT: unsampled word, trusted address, same epoch
+        lib.sdm_mexcache_set_strict(1)
+        assert not resident(jc, ir, pr)                             # strict: every presentation is checksummed completely
+        lib.sdm_mexcache_set_strict(0)
+        pr[k] = keep
+        # a new epoch with the same factor values on the device: the edited array has to present its complete content again
+        LLb, _, _, _ = shimmex.call("blkchol", 4, L, X, pars)
+        assert np.array_equal(_csc_arrays(LLb)[2], pr)
+        pr[k] += 1e-9
+        assert not resident(jc, ir, pr)
+        pr[k] = keep
+        assert resident(jc, ir, pr)
+    finally:
+        lib.sdm_mexcache_set_full_below(ctypes.c_int64(1 << 16))
+        lib.sdm_mexcache_set_strict(0)
+        lib.sdm_mexcache_clear()
 
 
 def test_getada_shim_updates_the_global(glue, refmex, shimmex):

@@ -170,10 +170,12 @@ def make_plan(device, P, L, ADA, Q, d, ud, rhs, qpr):
     return plan
 
 
-def cpu_baseline(P, d, ud, rhs, budget_s=12.0, blas=None):
+def cpu_baseline(P, d, ud, rhs, budget_s=12.0, blas=None, max_units=400):
     """The compiled reference MEX (oracle/_ref) timed on this host, one thread, on a bounded sample of the same
-    workload: repeated iteration units until ~budget_s of CPU time is spent.  blas = (path, prefix, suffix): the
-    reference's BLAS-1 calls bound to that host BLAS instead of the shim's naive loops."""
+    workload: repeated iteration units until ~budget_s of CPU time is spent (at most max_units).  blas = (path, prefix, suffix): the
+    reference's BLAS-1 calls bound to that host BLAS instead of the shim's naive loops.  Problems without PSD blocks (nb.mat) take
+    getada.m's route in sedumi.m:446-448 -- MATLAB sparse products, not timeable here: getada1 + getada2 (the same sums as MEX calls)
+    stand in for it and getada3 is not called."""
     kind = {"value": None, "unit": "IPM iters/s", "cores": 1, "kind": "reference"}
     try:
         from oracle import glue as gl, refmex
@@ -195,7 +197,10 @@ def cpu_baseline(P, d, ud, rhs, budget_s=12.0, blas=None):
         while True:
             t1, ADA1 = ref.timed_call("getada1", 1, (S["ADA"], S["A"], S["Ablkjc"][:, 2], S["Aord"]["lqperm"], dstruct, K["qblkstart"]))
             t2, ADA2 = ref.timed_call("getada2", 1, (ADA1, DAt, S["Aord"], K))
-            t3, (ADA3, absd) = ref.timed_call("getada3", 2, (ADA2, S["A"], S["Ablkjc"][:, 2], S["Aord"], np.asarray(ud).reshape(-1, 1), K))
+            if np.asarray(K["s"]).size:
+                t3, (ADA3, absd) = ref.timed_call("getada3", 2, (ADA2, S["A"], S["Ablkjc"][:, 2], S["Aord"], np.asarray(ud).reshape(-1, 1), K))
+            else:
+                t3, ADA3, absd = (0.0,), ADA2, np.asarray(ADA2.diagonal()).reshape(-1, 1)
             t4, (LL, Ld, _, _) = ref.timed_call("blkchol", 4, (S["L"], ADA3, dict(PARS), absd))
             L = dict(S["L"]); L["L"] = LL
             ts = 0.0
@@ -206,7 +211,7 @@ def cpu_baseline(P, d, ud, rhs, budget_s=12.0, blas=None):
             tot += t1[0] + t2[0] + t3[0] + t4[0] + ts
             stage += [t1[0] + t2[0], t3[0], t4[0], ts]
             units += 1
-            if tot >= budget_s or time.perf_counter() - t_wall > 3 * budget_s or units >= 400:
+            if tot >= budget_s or time.perf_counter() - t_wall > 3 * budget_s or units >= max_units:
                 break
         if blas is not None:
             ref.use_blas(None)
@@ -271,7 +276,7 @@ def profile_unit(plan, P, ud, nprof):
     xs_ = np.asarray(plan_xsuper(plan), dtype=np.float64)
     inv_flops = float(np.sum(np.diff(xs_) ** 3) / 3.0)
     inv_in_front_launch = "k_ldl_front" in prof and not any(k in prof for k in ("k_sprep", "k_sinv128", "k_sinv_follow", "k_stile"))
-    front_flops = fac_flops + (inv_flops if inv_in_front_launch else 0.0)
+    front_flops = fac_flops                       # the factorisation's flops only; the inverse the launch also builds is reported beside it
     npanel = max(1, prof.get("k_ldl_panel", (1, 0))[0] // nprof)
     ada_bytes = 8.0 * (ud.size + P.At.nnz + plan.nnzADA)
     model = {
@@ -306,8 +311,9 @@ def profile_unit(plan, P, ud, nprof):
         roof = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                 "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_per_step": calls / nprof,
                 "algorithmic_work_per_launch": work,
-                **({"work_is": "LDL' of the fronts (%.4g flops) + the triangular inverses of their diagonal super-blocks for the solves (%.4g flops), "
-                               "built by the last workgroups of the same launch" % (fac_flops, inv_flops)} if key == "k_ldl_front" and inv_in_front_launch else {}),
+                **({"work_is": "LDL' of the fronts, SURVEY.md 8(d) (%.4g flops)" % fac_flops,
+                    "also_in_this_launch_not_counted": "the triangular inverses of the fronts' diagonal super-blocks for the solves (%.4g flops), built by the "
+                                                       "last workgroups of the same launch" % inv_flops} if key == "k_ldl_front" and inv_in_front_launch else {}),
                 "timing": "HIP events around every launch on the plan's stream (adds ~2 us per launch; kernels shorter than "
                           "~7 us read as ~7 us: see phases_ms_per_step for those)",
                 "stage_ms_per_step": {k: v[1] / nprof for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
@@ -320,7 +326,9 @@ def profile_unit(plan, P, ud, nprof):
         if pmcs:
             try:
                 roof["traffic_from_committed_profile"] = {"bytes_per_launch": json.load(open(pmcs[-1])).get(dom),
-                                                          "source": "profiles/" + os.path.basename(pmcs[-1]) + " (rocprofv3 PMC passes of an earlier run of this command, not measured in this run)"}
+                                                          "source": "profiles/" + os.path.basename(pmcs[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the "
+                                                                    "committed build, tools/profile_round.sh; PMC passes cannot run inside the timed bench)"}
+                roof["traffic"] = roof["traffic_from_committed_profile"]["bytes_per_launch"]
                 if dom in ("k_ldl_front", "k_ldl_panel") and roof["traffic_from_committed_profile"]["bytes_per_launch"]:
                     # what the factor kernel has to move at least: every front read once and written once, per launch
                     nsup = int(np.asarray(plan_xsuper(plan)).size - 1)
@@ -397,10 +405,48 @@ def stage1_flops(P):
     return tot
 
 
-def measure_config(name, device, steps, warmup, nprof, mex_units=0, growth_max=None, refine=1):
+def solve_leg(name, device, nsolve=200):
+    """Only the solves of a workload (one ADA' + factorisation, then `nsolve` fw + ./d + bw solves timed): what the row-dot kernels
+    stream once the launch boundaries amortise (maxcut8000: 256 MB of factor per sweep)."""
+    try:
+        t0 = time.perf_counter()
+        P, L, ADA, Q, d, ud, rhs, qpr, note = build_workload(name, 0)
+        plan = make_plan(device, P, L, ADA, Q, d, ud, rhs, qpr)
+        plan._xsuper = np.asarray(L["xsuper"]).ravel().astype(np.int64)
+        plan.getada(); plan.blkchol(PARS, True)
+        for _ in range(5):
+            plan.ldlsolve()
+        plan.sync()
+        t1 = time.perf_counter()
+        for _ in range(nsolve):
+            plan.ldlsolve()
+        plan.sync()
+        t_solve = (time.perf_counter() - t1) / nsolve
+        plan.kprof(True)
+        for _ in range(10):
+            plan.ldlsolve()
+        prof = plan.kprof_summary()
+        plan.kprof(False)
+        m, nnzL = plan.m, plan.nnzL
+        xs = np.asarray(plan_xsuper(plan))
+        lind = int(np.sum(np.diff(plan.L_pattern.indptr)[(xs - 1)[:-1]]))
+        bytes_solve = 2.0 * (8.0 * nnzL + 8.0 * lind + 16.0 * m)
+        nb, nbad, growth = plan.solve_stats()
+        out = {"workload": name + " (solve leg only)", "problem": P.name, "m": int(m), "nnzL": int(nnzL), "us_per_solve": 1e6 * t_solve,
+               "algorithmic_bytes_per_solve": bytes_solve, "achieved_GBs": bytes_solve / t_solve / 1e9, "frac_of_hbm_peak": bytes_solve / t_solve / 1e9 / HBM_PEAK_GBS,
+               "launches_per_solve": sum(v[0] for v in prof.values()) / 10.0, "super_block_width": plan.solve_width(), "super_blocks": nb,
+               "kernel_us_with_events": {k: v[1] / v[0] * 1e3 for k, v in sorted(prof.items())}, "setup_s": time.perf_counter() - t0 - nsolve * t_solve}
+        plan.close()
+        return out
+    except Exception as e:  # never break the bench line
+        return {"workload": name + " (solve leg only)", "error": repr(e)}
+
+
+def measure_config(name, device, steps, warmup, nprof, mex_units=0, growth_max=None, refine=1, cpu_units=0):
     """One of the other BASELINE configs, measured briefly in this process: ms/unit, dominant kernel, solve rate.  growth_max: the
     bound beyond which a super-block of the solves is no longer applied as its bare inverse (0 = every block is beyond it); refine:
-    what happens to those blocks (sdm_plan_set_refinement: 1 = inverse + iterative refinement, the default; 0 = substitution)."""
+    what happens to those blocks (sdm_plan_set_refinement: 1 = inverse + iterative refinement, the default; 0 = substitution).
+    cpu_units: that many units of the reference MEX on this host beside it (cpu_baseline), and the speed-ups against it."""
     try:
         t0 = time.perf_counter()
         P, L, ADA, Q, d, ud, rhs, qpr, note = build_workload(name, 0)
@@ -423,6 +469,15 @@ def measure_config(name, device, steps, warmup, nprof, mex_units=0, growth_max=N
                "solve": phases["solve"], "factor": phases["factor"], "setup_s": time.perf_counter() - t0 - el}
         if mexleg is not None:
             out["mex_inclusive"] = mexleg
+        if cpu_units:
+            t1 = time.perf_counter()
+            base = cpu_baseline(P, d, ud, rhs, budget_s=8.0, max_units=cpu_units)
+            out["cpu_baseline"] = base
+            out["setup_s"] -= time.perf_counter() - t1
+            if base and base.get("value"):
+                out["speedup_vs_cpu_reference"] = out["iters_per_s"] / base["value"]
+                if mexleg and mexleg.get("value"):
+                    out["mex_inclusive_speedup_vs_cpu_reference"] = mexleg["value"] / base["value"]
         if growth_max is not None:
             out["workload"] = (f"{name} (solves with growth_max = {growth_max:g}: every super-block beyond the bound, as in the last iterations of a run; " +
                                ("inverse + two refinement steps against the factor)" if refine else "substituted by one workgroup: sdm_plan_set_refinement(0))"))
@@ -502,6 +557,9 @@ def mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, units, y_resident=None, mex_dir
                "cache_counters": {"ada_build": int(st[0]), "ada_reuse": int(st[1]), "ada_upload": int(st[2]), "ada_resident": int(st[3]), "chol_build": int(st[4]),
                                   "chol_reuse": int(st[5]), "x_upload": int(st[6]), "x_resident": int(st[7]), "solve_resident": int(st[8]),
                                   "solve_stateless": int(st[9])},
+               "content_checks": {"host_words_checksummed_per_unit": float(st[11]) / len(times), "MB_per_unit": 8e-6 * float(st[11]) / len(times),
+                                  "rule": "residency is decided by a checksum of every word of the host array (sdm_mexcache.hip): arrays up to 65536 words at every "
+                                          "presentation, larger ones once per address and epoch (= between two blkchol calls)"},
                "note": "mexFunction shims (sedumi_amd/lib/mex) on the MEX host of the package; host mxArrays cross PCIe at every gateway: scaling "
                        "data and right-hand sides up, ADA' (3x), absd, L.L, L.d, pivot lists and solutions down; the first unit (analysis of At, "
                        "the patterns and the symbolic factor, once per solve) is reported separately"}
@@ -749,14 +807,28 @@ def main():
             if not args.no_other_configs and args.workload == "control07":
                 # the second scaling of the headline config (identity scaling of iteration 1 next to an ill-conditioned one),
                 # the other reference examples at both scalings, then the synthetic configs[3], [4]
-                for nm, st, wu, npf, mxu in (("control07_init", 100, 5, 20, 0), ("arch0", 100, 5, 20, 0), ("arch0_init", 100, 5, 20, 0), ("nb", 100, 5, 20, 0),
-                                             ("nb_init", 100, 5, 20, 0), ("maxcut4000", 10, 2, 5, 2), ("blockdiag", 20, 3, 10, 0)):
-                    others.append(measure_config(nm, local_rank, st, wu, npf, mxu))
+                nocpu = args.no_cpu_baseline
+                for nm, st, wu, npf, mxu, cpu in (("control07_init", 100, 5, 20, 0, 0), ("arch0", 100, 5, 20, 5, 20), ("arch0_init", 100, 5, 20, 0, 0), ("nb", 100, 5, 20, 0, 20),
+                                                  ("nb_init", 100, 5, 20, 0, 0), ("maxcut4000", 10, 2, 5, 2, 1), ("blockdiag", 20, 3, 10, 2, 3)):
+                    others.append(measure_config(nm, local_rank, st, wu, npf, mxu, cpu_units=0 if nocpu else cpu))
+                others.append(solve_leg("maxcut8000", local_rank))
                 # the headline scaling sits just under the growth bound of the explicit inverses (max_growth 9.6e3 against 1e4): the same unit
                 # with every super-block on the substitution path
                 others.append(measure_config("control07", local_rank, 100, 5, 20, 0, growth_max=0.0))
                 others.append(measure_config("control07", local_rank, 30, 3, 10, 0, growth_max=0.0, refine=0))
         mult = 1 if (shard_cols or world == 1) else world
+        weighted = None
+        if args.workload == "control07" and world == 1:
+            # a WHOLE solve of control07.mat (41 factorisations, profiles/r04_control07_whole_solve_growth_by_iteration.txt): the explicit inverse of
+            # the solves' super-block stays within the growth bound for the first 35 and is beyond it for the last 6 (inverse + refinement):
+            # `value` is the first regime; this is the iteration-weighted figure from the two units measured in this run
+            beyond = next((o for o in others if isinstance(o, dict) and "growth_max = 0" in str(o.get("workload", "")) and "refinement steps" in str(o.get("workload", "")) and "ms_per_step" in o), None)
+            if beyond:
+                n_in, n_out = 35, 6
+                ms_w = (n_in * 1e3 * elapsed / args.steps + n_out * beyond["ms_per_step"]) / (n_in + n_out)
+                weighted = {"value": 1e3 / ms_w, "unit": "IPM iters/s", "ms_per_step": ms_w, "iterations_within_growth_bound": n_in, "iterations_beyond": n_out,
+                            "ms_per_step_within": 1e3 * elapsed / args.steps, "ms_per_step_beyond": beyond["ms_per_step"],
+                            "source": "regimes per iteration from profiles/r04_control07_whole_solve_growth_by_iteration.txt (tools/driver_log.py on the GPU box)"}
         out = {
             "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": mult * args.steps / elapsed, "unit": "IPM iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -768,7 +840,7 @@ def main():
                                          "blocks": "PSD blocks dealt to the ranks, partial ADA' + RCCL all-reduce, factor/solves replicated",
                                          "replicas": "replicas: independent units per rank, no collective"}[shard] if world > 1 else "single GPU")},
             "roofline": roof, "phases_ms_per_step": phases, "cpu_baseline": base, "cpu_baseline_blas": base_blas,
-            "pcie_inclusive": pcie, "mex_inclusive": mexleg, "other_configs": others,
+            "pcie_inclusive": pcie, "mex_inclusive": mexleg, "whole_solve_weighted": weighted, "other_configs": others,
         }
         if base and base.get("value") and mexleg and mexleg.get("value"):
             out["mex_inclusive_speedup_vs_cpu_reference"] = mexleg["value"] / base["value"]

@@ -375,6 +375,9 @@ int sdm_plan_set_refinement(sdm_plan *p, int mode, double refine_max);
  * and tools (both paths produce the same bits); also what a caller sharing the device between processes wants (all
  * workgroups of a one-launch level must be resident at once). */
 int sdm_plan_set_one_launch_fronts(sdm_plan *p, int on);
+/* n > 0: the NEXT sdm_plan_set_chol deals the trailing-update tiles of a big front's panel launch to at most n workgroups beside the
+ * chain and the row solves (each works through its tile pairs as a pipeline); 0 = as many as the device has compute units. */
+int sdm_plan_set_tile_workgroups(sdm_plan *p, int n);
 int sdm_plan_set_solve_width(sdm_plan *p, sdm_int width);
 int sdm_plan_get_solve_width(sdm_plan *p, sdm_int *width);      /* the width in force (after sdm_plan_set_chol) */
 int sdm_plan_solve_stats(sdm_plan *p, sdm_int *nblocks, sdm_int *nbad, double *max_growth);

@@ -332,6 +332,12 @@ int sdm_plan_set_one_launch_fronts(sdm_plan *p, int on) {
   p->chol.front_off_req = !on;
   SDM_CATCH
 }
+int sdm_plan_set_tile_workgroups(sdm_plan *p, int n) {
+  SDM_TRY
+  if (n < 0) throw std::runtime_error("sdm_plan_set_tile_workgroups: n must be >= 0");
+  p->chol.tile_wgs_req = n;
+  SDM_CATCH
+}
 int sdm_plan_set_solve_width(sdm_plan *p, sdm_int width) {
   SDM_TRY
   if (width != 0 && (width < sdm::SBW_MIN || width > sdm::SBW_MAX || (width & (width - 1)) != 0))

@@ -135,6 +135,14 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
     }
   }
   // factor launch schedule
+  int tile_wg_cap = C.tile_wgs_req;                                  // sdm_plan_set_tile_workgroups: tests (a small number makes every workgroup loop)
+  if (tile_wg_cap <= 0) {
+#ifdef SDM_EMU
+    tile_wg_cap = 1 << 20;
+#else
+    SDM_HIP_CHECK(hipDeviceGetAttribute(&tile_wg_cap, hipDeviceAttributeMultiprocessorCount, P->device));
+#endif
+  }
   C.launches.clear(); C.lev_first_launch.assign(nlev + 1, 0); C.lev_T.assign(nlev, 1);
   for (int l = 0; l < nlev; l++) {
     C.lev_first_launch[l] = (int)C.launches.size();
@@ -161,6 +169,9 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
         if (p > 0) {
           const int ntp = (C.sn_ms[s] - p * NB + TILE - 1) / TILE;            // tile rows of the update of panel p-1
           tw = nrw > 0 ? ((ntp - 1) * ntp / 2 + 1) / 2 : (ntp * (ntp + 1) / 2 - 1 + 1) / 2;
+          // big fronts: the tile pairs are dealt to as many workgroups as the device holds beside the chain and the row solves (one
+          // workgroup per compute unit at this launch's LDS footprint); each works through its pairs as a pipeline (panel_role_tiles_stream)
+          if (nrw > 0) tw = std::min(tw, std::max(16, tile_wg_cap / (e - b) - 1 - nrw));
         }
         L.ride_wgs = std::max(L.ride_wgs, nrw + tw);
       }
@@ -1156,6 +1167,102 @@ __device__ SDM_NI_TILES void panel_role_tiles(char *smem, double *Fs, const doub
   }
   SDM_ENDPGM();
 }
+// ---- the same for big fronts (those with row-solve workgroups: nobody in the launch reads these tiles): workgroup w of ntw works
+// through the tile pairs w, w + ntw, ... as ONE PIPELINE -- the operands of the next pair travel from memory into registers while
+// the matrix cores work on the current one.  One pair per workgroup (panel_role_tiles) spends 3.4 us of its ~10 us in the MFMA loop
+// (the rest: dispatch, one memory round trip for the operands, the acknowledgement of its write-through stores) and, with one
+// workgroup per compute unit (the launch's LDS footprint), nothing else runs there meanwhile: MAXCUT-4000's first twenty launches
+// were bound by their 945 ... 400 pairs in 4 ... 2 rounds of ~10 us instead of by the chain (profiles/r04w_unit_timeline_maxcut4000.txt).
+// Same operands, same instructions, same order per tile: the same bits.
+__device__ SDM_NI_TILES void panel_role_tiles_stream(char *smem, double *Fs, const double *d, int ms, int ld, int first, int panel, int w, int ntw, int nt) {
+  SDM_FP_STRICT;
+  constexpr int NW = 4, BJ = 2, NQ = NB / NW;
+  const int half = threadIdx.x >> 8, tid = (int)threadIdx.x & 255;
+  double (*As)[UTP] = (double (*)[UTP])smem + half * 2 * NB;
+  double (*Bs)[UTP] = As + NB;
+  __shared__ double dshs[NB];
+  const int kp = (panel - 1) * NB, r0 = kp + NB;
+  const int ntl = (nt - 1) * nt / 2, npairs = (ntl + 1) / 2;
+  if (w >= npairs) SDM_ENDPGM();
+  if (threadIdx.x < NB) dshs[threadIdx.x] = d[first + kp + threadIdx.x];
+  const int wv = tid >> 6, l = tid & 63;
+  const int wi = wv >> 1, wj = wv & 1, cj = wj * 16 * BJ, lk = l >> 4, ll = l & 15;
+  const int i = tid & 63, kq = tid >> 6;
+  double av[NQ], bv[NQ];
+  int I, J;
+  bool active;
+  auto locate = [&](int pair, int &I_, int &J_, bool &act) {
+    const int u = 2 * pair + half;
+    act = u < ntl;
+    tile_index(act ? u : 0, I_, J_);
+    I_++; J_++;                                                // block column 0 belongs to the row-solve workgroups
+  };
+  auto fetch_operands = [&](int I_, int J_) {                  // all loads issued before the first use (clamped addresses, masked when staged)
+    const double *pa = Fs + min(r0 + I_ * TILE + i, ms - 1), *pb = Fs + min(r0 + J_ * TILE + i, ms - 1);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) { const int64_t off = (int64_t)(kp + kq + NW * q) * ld; av[q] = pa[off]; bv[q] = pb[off]; }
+  };
+  locate(w, I, J, active);
+  fetch_operands(I, J);
+  for (int pair = w; pair < npairs; pair += ntw) {
+    __syncthreads();                                           // the pair before is through with As / Bs (first round: dshs is there)
+    {
+      const bool iok = r0 + I * TILE + i < ms, jok = r0 + J * TILE + i < ms;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) { const int k = kq + NW * q; As[k][i] = iok ? av[q] : 0.0; Bs[k][i] = jok ? bv[q] * dshs[k] : 0.0; }
+    }
+    __syncthreads();
+    // this tile's own values (read-modify-write) and the NEXT pair's operands go out now and arrive behind the MFMA loop
+    double cv[2][BJ][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < BJ; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int gi = r0 + I * TILE + wi * 32 + a * 16 + ll, gj = r0 + J * TILE + cj + b * 16 + lk + 4 * r;
+          cv[a][b][r] = Fs[(int64_t)min(gj, ms - 1) * ld + min(gi, ms - 1)];
+        }
+    const int I0 = I, J0 = J;
+    const bool act0 = active;
+    if (pair + ntw < npairs) { locate(pair + ntw, I, J, active); fetch_operands(I, J); }
+    sdm_double4 acc[2][BJ];
+    for (int a = 0; a < 2; a++) for (int b = 0; b < BJ; b++) for (int r = 0; r < 4; r++) acc[a][b][r] = 0.0;
+    double bo[BJ], ao[2];
+#pragma unroll
+    for (int b = 0; b < BJ; b++) bo[b] = Bs[lk][cj + b * 16 + ll];
+#pragma unroll
+    for (int a = 0; a < 2; a++) ao[a] = As[lk][wi * 32 + a * 16 + ll];
+#pragma unroll
+    for (int kk = 0; kk < NB; kk += 4) {
+      double bn[BJ], an[2];
+      const int kn = min(kk + 4, NB - 4);
+#pragma unroll
+      for (int b = 0; b < BJ; b++) bn[b] = Bs[kn + lk][cj + b * 16 + ll];
+#pragma unroll
+      for (int a = 0; a < 2; a++) an[a] = As[kn + lk][wi * 32 + a * 16 + ll];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < BJ; b++) acc[a][b] = SDM_MFMA_F64_16x16x4(bo[b], ao[a], acc[a][b]);
+#pragma unroll
+      for (int b = 0; b < BJ; b++) bo[b] = bn[b];
+#pragma unroll
+      for (int a = 0; a < 2; a++) ao[a] = an[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < BJ; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int ti = wi * 32 + a * 16 + ll, tj = cj + b * 16 + lk + 4 * r;
+          const int gi = r0 + I0 * TILE + ti, gj = r0 + J0 * TILE + tj;
+          if (act0 && gi < ms && gj < ms && gi >= gj) sdm_store_wt(&Fs[(int64_t)gj * ld + gi], cv[a][b][r] - acc[a][b][r]);
+        }
+  }
+  SDM_ENDPGM();
+}
 // ---- workgroup 0 = the dependency chain of the launch, as a CHAIN OF STAGES that never return: the role's prologue calls the update
 // of its diagonal tile, which calls the LDL' of the block, which calls the rows left to this workgroup -- each call the last thing its
 // caller does.  Each stage is a function for the sake of its own register allocation (inlined into one body they spilled 167 VGPRs,
@@ -1322,7 +1429,8 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   }
   if (bx > nrw) {
     if (phase == 2 || panel == 0) return;
-    panel_role_tiles(smem, Fs, d, ms, ld, first, panel, bx - 1 - nrw, nrw, nt, upd_cnt + s);
+    if (nrw > 0) panel_role_tiles_stream(smem, Fs, d, ms, ld, first, panel, bx - 1 - nrw, (int)gridDim.x - 1 - nrw, nt);
+    else panel_role_tiles(smem, Fs, d, ms, ld, first, panel, bx - 1 - nrw, nrw, nt, upd_cnt + s);
     return;
   }
   // ---- workgroup 0
@@ -1577,7 +1685,7 @@ k_ldl_front(double *F, double *DT, FrontTab tab, const int *list, double *d, dou
     // chain needs next (column q + 2) come first.  Everything it waits for (the rows of panel q) depends on tile updates
     // of EARLIER panels only, which this loop has finished by then.
     if (phase != 0 && phase != 3) return;
-    const int w = (int)blockIdx.x - tile_wg0, ntw = (int)gridDim.x - tile_wg0;
+    const int w = (int)blockIdx.x - tile_wg0, ntw = fa.nfront - tile_wg0;   // (the grid carries the follower workgroups behind the fa.nfront of the factorisation)
     if (w >= (T - 1) * (T - 2) / 2) return;
     for (int q = (phase == 0 ? 0 : step); q < (phase == 0 ? NP : step + 1) && q <= T - 3; q++) {
       int ct = 2, c0 = 0;                                              // c0 = index of tile (ct, ct)
@@ -1803,7 +1911,7 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
         // the data-tagged hand-over): one process per workgroup, all at once (tests/hipemu: emu_launch_concurrent)
         SDM_KLAUNCH_CONCURRENT(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
                                C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.panel_ctx.p, C.front_cnt.p,
-                               C.diag_cnt.p, 0, 0, C.lev_maxT[l], C.tmo.dev(), FollowArgs{nullptr, nullptr, nullptr, 0});
+                               C.diag_cnt.p, 0, 0, C.lev_maxT[l], C.tmo.dev(), FollowArgs{nullptr, nullptr, nullptr, C.lev_maxT[l] + C.lev_ntw[l]});
         if (follow) solve_follow(P, l, st);                          // beside it, polling its counters -- as the last workgroups of the launch do on the device
         emu_group_end();
         continue;
@@ -1812,7 +1920,7 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
         for (int phase = 1; phase <= 3; phase++)
           SDM_KLAUNCH(P, k_ldl_front, dim3(C.lev_maxT[l] + C.lev_ntw[l], nfr), dim3(LDL_THREADS), FRONT_LDS, C.fronts.p, C.frontsT.p, tab, list, C.d.p,
                       C.lb.p, C.ub.p, C.pivstat.p, C.pivval.p, C.panel_ctx.p, C.front_cnt.p,
-                      C.diag_cnt.p, phase, step, C.lev_maxT[l], C.tmo.dev(), FollowArgs{nullptr, nullptr, nullptr, 0});
+                      C.diag_cnt.p, phase, step, C.lev_maxT[l], C.tmo.dev(), FollowArgs{nullptr, nullptr, nullptr, C.lev_maxT[l] + C.lev_ntw[l]});
       if (follow) solve_follow(P, l, st);                            // (workgroups run one after the other here: behind = after)
       if (emu_take_injected_timeout()) *(volatile int *)C.tmo.host = 1;   // (tests: as if a workgroup of this launch had given up waiting)
 #else

@@ -48,7 +48,10 @@ void solve_build(sdm_plan *P) {
   int W = C.sbw_req;
   if (W == 0) { W = SBW_MIN; while (W < C.maxns && W < SBW_MAX) W *= 2; }
   C.sbw = W;
-  C.noted.ensure(); C.noted.host[0] = C.noted.host[1] = 0; C.refine_on = false; C.sweep_seq = 0;   // a new solve: no ill-conditioned block met yet
+  // a new solve: no ill-conditioned block met yet (sweeps of the previous symbolic factor still in flight would write their notes
+  // after this reset: drained first -- set_chol happens once per solve)
+  if (C.noted.host) SDM_HIP_CHECK(hipStreamSynchronize(P->stream));
+  C.noted.ensure(); C.noted.host[0] = C.noted.host[1] = 0; C.refine_on = false; C.sweep_seq = 0;
   C.sn_soff.assign(nsuper, 0); C.sn_sld.assign(nsuper, 0); C.sn_sboff.assign(nsuper, 0);
   std::vector<int> i128;
   std::vector<std::vector<int>> stage(2 * SINV_MAXLEV);              // combine tiles per stage st = 2 * level + (0: T, 1: X)
@@ -1013,8 +1016,10 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
   const FrontTab tab0 = front_tab(C);
   if (l1 < 0) l1 = C.nlevels;
   const bool refine = nrhs == 1 && solve_refines(C);
-  int *noted = C.refine_mode == 1 ? C.noted.dev() : nullptr;
-  const int seq = ++C.sweep_seq;
+  // (inside a graph capture the sweep numbers would be baked into the kernel arguments and replayed stale: a captured sweep leaves
+  // no notes and keeps the mode decided at capture; blocks beyond the bound it was not planned for are substituted, as accurate)
+  int *noted = C.refine_mode == 1 && !P->capturing ? C.noted.dev() : nullptr;
+  const int seq = P->capturing ? C.sweep_seq : ++C.sweep_seq;
   bool marked = false;
   for (int l = std::max(l0, 0); l < std::min(l1, C.nlevels); l++) {
     const SolveLevel &L = C.slev[l];
@@ -1056,8 +1061,8 @@ static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double 
   const FrontTab tab0 = front_tab(C);
   if (l1 < 0) l1 = C.nlevels;
   const bool refine = solve_refines(C);
-  int *noted = C.refine_mode == 1 ? C.noted.dev() : nullptr;
-  const int seq = ++C.sweep_seq;
+  int *noted = C.refine_mode == 1 && !P->capturing ? C.noted.dev() : nullptr;
+  const int seq = P->capturing ? C.sweep_seq : ++C.sweep_seq;
   bool marked = false;
   for (int l = std::min(l1, C.nlevels) - 1; l >= std::max(l0, 0); l--) {
     const SolveLevel &L = C.slev[l];

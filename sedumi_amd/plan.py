@@ -189,6 +189,10 @@ class Plan:
         """False: the NEXT set_chol plans every front on the launch-per-panel path (the comparison switch of tests and tools)."""
         check(self._lib.sdm_plan_set_one_launch_fronts(C.c_void_p(self._p), C.c_int(1 if on else 0)))
 
+    def set_tile_workgroups(self, n):
+        """Workgroups the update tiles of a big front's panel launch are dealt to, for the NEXT set_chol (0 = the device's compute units)."""
+        check(self._lib.sdm_plan_set_tile_workgroups(C.c_void_p(self._p), C.c_int(int(n))))
+
     def set_solve_width(self, width):
         """Super-block width of the solves for the NEXT set_chol (0 = automatic, or a power of two in 256 .. 2048)."""
         check(self._lib.sdm_plan_set_solve_width(C.c_void_p(self._p), C.c_int64(int(width))))

@@ -212,6 +212,34 @@ def _factor_both_ways(X, L, pars=None, rhs=None):
     return out
 
 
+def check_streamed_update_tiles(refmex, m, caps=(3, 16, 0)):
+    """Launch-per-panel path of one dense front with the trailing-update tiles of every launch dealt to `cap` workgroups, each working
+    through its tile pairs as a pipeline (panel_role_tiles_stream; Plan.set_tile_workgroups): whatever the number of workgroups -- 3:
+    every one loops many times; 0: as many as the device has compute units -- every tile gets the same operations in the same order:
+    the same bits, and within tolerance of the reference."""
+    from oracle import glue as gl
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    rng = np.random.default_rng(m)
+    B = rng.standard_normal((m, m))
+    X = sp.csc_matrix(B @ B.T + m * np.eye(m)); X.sort_indices()
+    L = problem.dense_symbolic(m)
+    res = []
+    for cap in caps:
+        plan = Plan(0)
+        plan.set_one_launch_fronts(False)
+        plan.set_tile_workgroups(cap)
+        plan.set_chol(L, X)
+        plan.upload("ada", sp.csc_matrix(X).data)
+        plan.blkchol(None, False)
+        res.append((plan.download("lpr"), plan.download("d")))
+        plan.close()
+    for lpr, d in res[1:]:
+        assert np.array_equal(lpr, res[0][0]) and np.array_equal(d, res[0][1])
+    r = refmex.call("blkchol", 4, L, X, gl.default_pars_chol())
+    assert relerr(res[0][1], r[1].ravel()) < TOL and relerr(res[0][0], sp.csc_matrix(r[0]).data) < TOL
+
+
 def check_one_launch_front(refmex, m):
     """k_ldl_front (one workgroup per tile row, the whole front in one launch) against the launch-per-panel path on single
     dense fronts: same device functions in the same order per entry, so the same bits -- and both within tolerance of

@@ -4,7 +4,7 @@ repository's library (tests/driver/sedumi_loop.py), and the accuracy of the libr
   * reference hot path:  the restatement itself reproduces examples/test_sedumi.m:22-25's optimal values (tol 1e-6, as there);
   * library, emulated (CPU: nb, arch0, quantum) and on the GPU (nb, arch0, control07, quantum; trto3 and OH_2Pi against a
     committed log), through the MEX-shaped calls and through the
-    resident plan: same optimal values, iteration count within two, and the iteration log of the reference-hot-path run
+    resident plan: same optimal values, the same iteration count as the same-host reference run, and the iteration log of the reference-hot-path run
     ON THE SAME HOST followed row by row (check_log);
   * accuracy (tests/driver/accuracy.py): at chosen iterations of the reference run, ADA', the factor and the solves of both
     paths against extended precision -- the library's error is at most 10 x the reference's (+ 1e-15).
@@ -70,6 +70,11 @@ TOL_LOG = {"nb": (1e-6, 1e-2), "control07": (1e-6, 1e-2), "arch0": (1e-3, 1e-1),
 # tP = 0.8422 or 0.9000 with either solve path -- explicit inverses or plain substitution (profiles/r03d_diag_control07.txt) --
 # and the row after it inherits the other iterate
 KNIFE_EDGE_ROWS = {("control07", 24), ("control07", 25)}
+# iteration counts: EQUAL to the same-host reference run, except the one named problem whose last iteration is decided by rounding:
+# arch0 stops after 31 or 32 iterations depending on the last bits of the final directions -- the REFERENCE hot path itself takes 32
+# (STOP 1) in the build container and 31 (STOP -1) on the GPU box (profiles/r04z_arch0_iterations_same_box.txt); the library takes 31
+# on both (on the GPU box: 31 = 31).  One iteration of margin for arch0, none for anything else.
+ITER_MARGIN = {"arch0": 1}
 
 
 def check_log(name, r, ref):
@@ -77,7 +82,9 @@ def check_log(name, r, ref):
     column throughout; gap, precision, delta, rate and the step lengths while the reference gets each direction from ONE
     preconditioned step (beyond that the CG / refinement counts hinge on comparisons at the rounding level of the factor)."""
     tol_obj, tol_row = TOL_LOG[name]
-    assert abs(r["iter"] - ref["iter"]) <= 2, (r["iter"], ref["iter"])
+    # north_star: "unchanged iteration count" -- against the reference hot path run on THIS host (same LAPACK kernels, same rounding
+    # of everything outside the hot path): equality, for every problem and tier
+    assert abs(r["iter"] - ref["iter"]) <= ITER_MARGIN.get(name, 0), (name, r["iter"], ref["iter"])
     A, B = r["rows"], ref["rows"]
     upto = min(len(A), len(B)) - 2
     # (the first row in which EITHER run needs a second CG step ends the strict zone: whether a residual of 4.9e-3 or 5.1e-3 times
@@ -157,6 +164,9 @@ def test_the_larger_examples_reach_their_optimal_values_on_the_gpu(name):
     g = problem(name)[2]
     print(name, "iter", r["iter"], "vs", int(g["iter"]), "STOP", r["STOP"], "cx", r["cx"], "by", r["by"])
     check_objectives(name, r)
+    # (against a fixture made on ANOTHER host: the reference's own count moves by one between hosts with different LAPACK kernels --
+    # arch0: 32 in the build container, 31 on the GPU box, profiles/r04z_arch0_iterations_same_box.txt -- so this one keeps a margin;
+    # the same-host comparisons of check_log assert equality)
     assert abs(r["iter"] - int(g["iter"])) <= 2
     assert abs(r["cx"] - float(g["cx"])) / abs(float(g["cx"])) < TOL_OBJ and abs(r["by"] - float(g["by"])) / abs(float(g["by"])) < TOL_OBJ
 

@@ -411,6 +411,11 @@ def test_one_launch_front_matches_the_panel_launches_bit_for_bit(refmex, m):
     helpers.check_one_launch_front(refmex, m)
 
 
+@pytest.mark.parametrize("m", [330, 1000])
+def test_streamed_update_tiles_give_the_same_bits_whatever_the_number_of_workgroups(refmex, m):
+    helpers.check_streamed_update_tiles(refmex, m)
+
+
 @pytest.mark.parametrize("two_leaves", [False, True])
 def test_one_launch_front_levels_with_rows_below(refmex, glue, two_leaves):
     helpers.check_one_launch_levels(refmex, glue, two_leaves)

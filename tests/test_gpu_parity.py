@@ -550,6 +550,13 @@ def test_pcg_operators_on_gpu(refmex, case):
     check_pcg_ops(refmex, CASES[case], seed=case)
 
 
+@pytest.mark.parametrize("m,caps", [(1000, (3, 16, 0)), (2500, (40, 0))])
+def test_streamed_update_tiles_give_the_same_bits_whatever_the_number_of_workgroups(refmex, m, caps):
+    """The update tiles of a big front's panel launches, dealt to 3 / 16 / 40 / all-compute-units workgroups that each pipeline
+    their tile pairs (panel_role_tiles_stream): bit-identical factors, within tolerance of the reference."""
+    helpers.check_streamed_update_tiles(refmex, m, caps)
+
+
 @pytest.mark.parametrize("m", [112, 123, 174, 200, 330, 512, 666, 1000, 1024, 1100, 1344])
 def test_one_launch_front_matches_the_panel_launches_bit_for_bit(refmex, m):
     """k_ldl_front (workgroups of one launch hand the factor on through device-scope counters) against the launch-per-panel

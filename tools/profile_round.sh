@@ -18,6 +18,9 @@ if [ -z "$NOPMC" ]; then
   PS=$(( STEPS / 10 > 2 ? STEPS / 10 : 2 ))
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python $REPO/bench.py --workload $WL --steps $PS --warmup 2 --no-cpu-baseline --no-other-configs > /dev/null 2> $OUT/fetch.err
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python $REPO/bench.py --workload $WL --steps $PS --warmup 2 --no-cpu-baseline --no-other-configs > /dev/null 2> $OUT/write.err
+  # matrix-core utilisation (north_star: "rocprof HBM GB/s and MFMA utilisation"): busy cycles of the MFMA pipes and the FP64 MFMA
+  # operations issued, beside the cycles the GPU was active -- SQ and GRBM counters, their own pass
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -o mfma -- python $REPO/bench.py --workload $WL --steps $PS --warmup 2 --no-cpu-baseline --no-other-configs > /dev/null 2> $OUT/mfma.err
 fi
 cd $REPO
 python tools/summarize_prof.py $OUT $TAG

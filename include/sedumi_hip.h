@@ -438,6 +438,7 @@ void sdm_mexcache_stats(sdm_int *out16, sdm_int n);   /* [11] words checksummed 
  * set_strict(1): no shortcut, every presentation is checksummed completely. */
 void sdm_mexcache_set_strict(int on);
 void sdm_mexcache_set_full_below(sdm_int words);
+void sdm_mexcache_set_threads(int n);   /* host threads of a checksum from 128K words on: -1 automatic (4; 8 from 1M words), 1 none */
 unsigned long long sdm_mexcache_checksum(const void *words, sdm_int n);   /* the content checksum of n 8-byte host words */
 /* The cached plan of the factorisation for callers that drive it themselves: sdm_mexcache_plan returns the plan of the
  * symbolic factor (L.{L pattern, perm, xsuper}) and ADA pattern given, creating it on a miss (NULL + sdm_last_error on

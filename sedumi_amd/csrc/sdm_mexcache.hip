@@ -27,6 +27,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -82,24 +84,77 @@ const sums_fn sums = pick_sums();
 #else
 #define sums sums_base
 #endif
+void pool_shutdown();
+// A few helper threads for the checksums of arrays from POOL_FROM words on: what a gateway is handed has usually just been written by
+// the DMA engine (or by a memcpy with streaming stores) and comes from DRAM at 8 - 10 GB/s through one core.  The helpers are created
+// at the first such array, sleep on a condition variable in between (woken in ~10 us) and are joined when the cache is torn down.
+constexpr sdm_int POOL_FROM = 1 << 17;     // 128K words = 1 MB
+class SumPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  const u64 *v = nullptr;
+  sdm_int n = 0, chunk = 0;
+  int nparts = 0, pending = 0;
+  u64 gen = 0;
+  bool stop = false;
+  u64 part[16][8];
+  void worker(int id) {
+    u64 seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_go.wait(lk, [&] { return stop || gen != seen; });
+      if (stop) return;
+      seen = gen;
+      const bool mine = id < nparts;
+      const u64 *vv = v; const sdm_int i0 = std::min(n, (sdm_int)id * chunk), i1 = std::min(n, i0 + chunk);
+      lk.unlock();
+      if (mine) { for (int k = 0; k < 8; k++) part[id][k] = 0; sums(vv, i0, i1, part[id]); }
+      lk.lock();
+      if (mine && --pending == 0) cv_done.notify_one();
+    }
+  }
+ public:
+  // the eight sums of v[0, n) into acc, by `want` threads (the caller is one of them)
+  void run(const u64 *vp, sdm_int len, int want, u64 *acc) {
+    want = std::max(1, std::min(want, 16));
+    if (th.empty()) { static bool reg = false; if (!reg) { reg = true; std::atexit([] { pool_shutdown(); }); } }   // sleeping helpers are joined before the process ends
+    while ((int)th.size() < want - 1) { const int id = (int)th.size() + 1; th.emplace_back([this, id] { worker(id); }); }
+    const sdm_int ch = ((len + want - 1) / want + 7) & ~(sdm_int)7;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      v = vp; n = len; chunk = ch; nparts = want; pending = want - 1; gen++;
+    }
+    cv_go.notify_all();
+    for (int k = 0; k < 8; k++) part[0][k] = 0;
+    sums(vp, 0, std::min(len, ch), part[0]);
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    for (int t = 0; t < want; t++) for (int k = 0; k < 8; k++) acc[k] += part[t][k];
+  }
+  void shutdown() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv_go.notify_all();
+    for (auto &t : th) t.join();
+    th.clear(); stop = false;
+  }
+  ~SumPool() { shutdown(); }
+} g_pool;
+void pool_shutdown() { g_pool.shutdown(); }
+int g_threads = -1;        // sdm_mexcache_set_threads: threads of a big checksum (-1: 4 from POOL_FROM words, up to 8 from 1M; never more than the host has)
 u64 hash_full(const void *pv, sdm_int n) {
   const u64 *v = (const u64 *)pv;
   u64 acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned nt = n >= THREADS_FROM ? std::thread::hardware_concurrency() : 1;
-  if (nt > 8) nt = 8;
-  if (nt <= 1) sums(v, 0, n, acc);
-  else {
-    u64 part[8][8] = {};
-    const sdm_int chunk = ((n + nt - 1) / nt + 7) & ~(sdm_int)7;
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) {
-      const sdm_int i0 = std::min(n, (sdm_int)t * chunk), i1 = std::min(n, i0 + chunk);
-      th.emplace_back([=, &part] { sums(v, i0, i1, part[t]); });
-    }
-    sums(v, 0, std::min(n, chunk), part[0]);
-    for (auto &t : th) t.join();
-    for (unsigned t = 0; t < nt; t++) for (int k = 0; k < 8; k++) acc[k] += part[t][k];
+  int nt = 1;
+  if (n >= POOL_FROM) {
+    const int hw = (int)std::thread::hardware_concurrency();
+    nt = g_threads >= 0 ? g_threads : (n >= THREADS_FROM ? 8 : 4);
+    nt = std::max(1, std::min(nt, std::max(1, hw)));
   }
+  if (nt <= 1) sums(v, 0, n, acc);
+  else g_pool.run(v, n, nt, acc);
   return fold_sums(acc, n);
 }
 // the same eight sums of n words in device memory, added into acc8 (zeroed by the caller): work-item t owns the words
@@ -160,8 +215,7 @@ struct Finger {
   }
   bool same(const void *p, sdm_int len) {
     if (len != n || n < 0) return false;
-    if (hash_sampled(p, len) != sample) return false;                 // (a cheap reject; never an accept on its own below full_below)
-    if (!strict && len > full_below && trusted(p)) return true;       // the shortcut of the file header
+    if (!strict && len > full_below && trusted(p)) return hash_sampled(p, len) == sample;   // the shortcut of the file header
     g_fullsum_words += len;
     if (hash_full(p, len) != full) return false;
     verified(p);
@@ -260,6 +314,7 @@ void drop_chol() {
 void drop_all() {
   for (AdaSlot *s : {&g_s1, &g_s2, &g_s3, &g_s0}) { if (s->plan) forget_plan(s->plan); s->drop(); }
   drop_chol();
+  g_pool.shutdown();
   g_ck.release();
   for (auto &p : g_pat) p = Pattern();
   g_fullsum_words = 0;
@@ -311,6 +366,8 @@ void sdm_mexcache_stats(sdm_int *out, sdm_int n) {
 }
 // arrays of up to `words` words are checksummed completely at every presentation (default 65 536); larger ones once per address and epoch
 void sdm_mexcache_set_full_below(sdm_int words) { full_below = words < 0 ? 0 : words; }
+// threads of the checksum of an array from 128K words on (the caller's included): -1 = automatic (4, and 8 from 1M words), 1 = none
+void sdm_mexcache_set_threads(int n) { g_threads = n; }
 
 // ADA = getada1(ADA, A, Ajc2, perm, d, blkstart) on the cache (same arguments as sdm_getada1)
 int sdm_mexcache_getada1(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc, const sdm_int *Air,

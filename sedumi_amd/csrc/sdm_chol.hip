@@ -35,6 +35,60 @@ __global__ void k_ldl_front(double *F, double *DT, FrontTab tab, const int *list
 #else
 struct FollowArgs { double *S, *STr; unsigned long long *sb_g; int nfront; };
 #endif
+// ============================================================ schedule of the trailing updates of a big front (host + device)
+// Panel p's rank-64 update of the trailing matrix, applied in the launch after it (the "eager" schedule), is a read-modify-write of every
+// trailing tile per panel: 8 flops per byte of tile traffic, HBM-bound (MAXCUT-4000: 121 MB per launch at 2.4 TB/s = 50 us against a chain of
+// 26 us).  The panels are therefore taken four at a time (a GROUP g = panels 4g .. 4g+3):
+//   * tile columns up to 4g+7 (those factored before the group's deferred update can have reached them) get every panel of the group eagerly, as
+//     before: K = 64 in the launch after the panel;
+//   * tile columns from 4g+8 on get the whole group in ONE read-modify-write with K = 256 once its last panel is final: columns 4g+8 .. 4g+11
+//     (the next group's eager window) in launch 4g+4, the rest dealt over the launches 4g+4 .. 4g+7 (10 % / 30 % / 30 % / 30 %: the first one
+//     carries those four columns as well).
+// Every tile still receives the panels in ascending order, each as  c <- c - (product over the panel's 64 columns, accumulated from zero):
+// the same operations in the same order as the eager schedule, i.e. the SAME BITS; only the trips of c through memory are saved.
+// A group is deferred only if all its launches exist and have row-solve workgroups (NP >= 4g+8 panels, T >= 4g+12 tile rows).
+__host__ __device__ inline bool upd_group_deferred(int ns, int ms, int g) {
+  return g >= 0 && (ns + NB - 1) / NB >= 4 * g + 8 && (ms + TILE - 1) / TILE >= 4 * g + 12;
+}
+// tiles (I, J) with J0 <= J < J0 + JW and J <= I < nt
+__host__ __device__ inline int band_count(int nt, int J0, int JW) {
+  const int n = nt - J0;
+  if (n <= 0 || JW <= 0) return 0;
+  if (JW > n) JW = n;
+  return JW * (JW + 1) / 2 + (n - JW) * JW;
+}
+// of N tiles, those dealt to launch r (0 .. 3) of the four: t % 10 == 0 | {1,4,7} | {2,5,8} | {3,6,9}
+__host__ __device__ inline int share_count(int N, int r) {
+  if (r == 0) return (N + 9) / 10;
+  int c = 3 * (N / 10);
+  const int rem = N % 10;
+  for (int x = r; x <= r + 6; x += 3) if (x < rem) c++;
+  return c;
+}
+__host__ __device__ inline int share_tile(int k, int r) { return r == 0 ? 10 * k : 10 * (k / 3) + r + 3 * (k % 3); }
+// what the tile workgroups of launch q (the launch that factors panel q) of a front do: NE eager tiles of panel q-1 in the columns
+// 1 .. JE (relative to tile column q; column 0 is the row-solve workgroups'), NH + NR deferred tiles of group g2 (in its first launch the
+// four columns 4 .. 7, and this launch's share of the triangle of the columns beyond them -- tile column 4 g2 + 12 of the front = column
+// 8 - r relative to this launch; `all`: the whole triangle at once, when the next group is not deferred and its eager updates would
+// otherwise meet these tiles in the launches to come)
+struct TileSched { int nt, JE, NE, NH, NR, g2, r, all; };
+__host__ __device__ inline TileSched tile_sched(int ns, int ms, int q) {
+  TileSched S;
+  S.nt = (ms - q * NB + TILE - 1) / TILE;
+  const int g = (q - 1) / 4;
+  S.JE = upd_group_deferred(ns, ms, g) ? min(4 * g + 7 - q, S.nt - 1) : S.nt - 1;
+  S.NE = band_count(S.nt, 1, S.JE);
+  S.g2 = q >= 4 ? q / 4 - 1 : -1; S.r = q % 4; S.NH = 0; S.NR = 0; S.all = 0;
+  if (upd_group_deferred(ns, ms, S.g2)) {
+    const int n = S.nt + S.r - 8, N = n > 0 ? n * (n + 1) / 2 : 0;      // (the same triangle in all four launches: T - (4 g2 + 12) tile rows)
+    S.all = upd_group_deferred(ns, ms, S.g2 + 1) ? 0 : 1;
+    if (S.r == 0) S.NH = band_count(S.nt, 4, 4);
+    S.NR = S.all ? (S.r == 0 ? N : 0) : share_count(N, S.r);
+  } else S.g2 = -1;
+  return S;
+}
+__host__ __device__ inline int tile_sched_items(const TileSched &S) { return S.NE + S.NH + S.NR; }
+
 // ============================================================ host analysis
 void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm,
                 sdm_int nsuper, const sdm_int *xsuper, const sdm_int *ADAjc, const sdm_int *ADAir) {
@@ -168,10 +222,11 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
         int tw = 0;
         if (p > 0) {
           const int ntp = (C.sn_ms[s] - p * NB + TILE - 1) / TILE;            // tile rows of the update of panel p-1
-          tw = nrw > 0 ? ((ntp - 1) * ntp / 2 + 1) / 2 : (ntp * (ntp + 1) / 2 - 1 + 1) / 2;
-          // big fronts: the tile pairs are dealt to as many workgroups as the device holds beside the chain and the row solves (one
-          // workgroup per compute unit at this launch's LDS footprint); each works through its pairs as a pipeline (panel_role_tiles_stream)
-          if (nrw > 0) tw = std::min(tw, std::max(16, tile_wg_cap / (e - b) - 1 - nrw));
+          tw = nrw > 0 ? tile_sched_items(tile_sched(C.sn_ns[s], C.sn_ms[s], p)) : (ntp * (ntp + 1) / 2 - 1 + 1) / 2;
+          // big fronts: the tiles are dealt to as many workgroups as the device holds beside the chain and the row solves (one workgroup
+          // per compute unit at this launch's LDS footprint, a few compute units left free: a workgroup that finds none starts when the
+          // first one has finished); each works through its tiles as a pipeline (panel_role_tiles_stream)
+          if (nrw > 0) tw = std::min(tw, std::max(16, (tile_wg_cap - (C.tile_wgs_req > 0 ? 0 : 8)) / (e - b) - 1 - nrw));
         }
         L.ride_wgs = std::max(L.ride_wgs, nrw + tw);
       }
@@ -1168,99 +1223,152 @@ __device__ SDM_NI_TILES void panel_role_tiles(char *smem, double *Fs, const doub
   SDM_ENDPGM();
 }
 // ---- the same for big fronts (those with row-solve workgroups: nobody in the launch reads these tiles): workgroup w of ntw works
-// through the tile pairs w, w + ntw, ... as ONE PIPELINE -- the operands of the next pair travel from memory into registers while
-// the matrix cores work on the current one.  One pair per workgroup (panel_role_tiles) spends 3.4 us of its ~10 us in the MFMA loop
-// (the rest: dispatch, one memory round trip for the operands, the acknowledgement of its write-through stores) and, with one
-// workgroup per compute unit (the launch's LDS footprint), nothing else runs there meanwhile: MAXCUT-4000's first twenty launches
-// were bound by their 945 ... 400 pairs in 4 ... 2 rounds of ~10 us instead of by the chain (profiles/r04w_unit_timeline_maxcut4000.txt).
-// Same operands, same instructions, same order per tile: the same bits.
-__device__ SDM_NI_TILES void panel_role_tiles_stream(char *smem, double *Fs, const double *d, int ms, int ld, int first, int panel, int w, int ntw, int nt) {
+// through the tiles w, w + ntw, ... of the launch's schedule (tile_sched: eager tiles of the panel before, K = 64; deferred tiles of a
+// whole group of four panels, K = 256 in four steps of 64) as ONE PIPELINE over the steps:
+//   * all 8 wavefronts share one 64 x 64 tile (32 x 16 each, two MFMA accumulators);
+//   * the operands of a step sit in one of TWO LDS buffers; while the matrix cores work on it, the operands of the next step -- already in
+//     registers, fetched a whole step earlier -- are written to the other buffer and the loads of the step after that are issued: one
+//     barrier per step, no memory round trip in front of an MFMA loop;
+//   * a tile's own values make ONE trip through the registers per tile, not one per panel, and a finished tile is stored one step
+//     later (the counter of outstanding memory operations is one for loads and stores: stores issued right behind their MFMA loop sit in
+//     front of the next wait for operands).
+// Per tile: the same operands, the same instructions on the same accumulator layout, the same order as the eager schedule -- the same bits.
+// What this is worth and what it is not (MAXCUT-4000, profiles/r05_factor_update_variants.txt): the 63 panel launches 1.99 ms against 2.04
+// (round 4: one pair of tiles per workgroup and launch, K = 64 only) with the tiles' read-modify-write traffic cut to a quarter; a step
+// costs 4.2 us of which 2.0 are its 64 MFMAs per SIMD -- the other half is the wavefronts' own instruction issue for the next step
+// (addresses, 16 loads, masks, 16 LDS writes, the tile's values), which the lock step of a barrier per step puts in front of the MFMAs
+// instead of beside them.  Two streams per workgroup half a step out of phase (one wavefront per SIMD in the MFMA loop, the other one
+// preparing) were built and measured at 4.9 us per half step: a single wavefront per SIMD exposes the LDS latency of every operand
+// read in the MFMA loop.  The launches from the 22nd on are bound by the chain of the diagonal blocks (26 us) either way.
+struct TileItem { int I, J, nch, kp0, ds0; };
+__device__ SDM_NI_TILES void panel_role_tiles_stream(char *smem, double *Fs, const double *d, int ns, int ms, int ld, int first, int panel, int w, int ntw) {
   SDM_FP_STRICT;
-  constexpr int NW = 4, BJ = 2, NQ = NB / NW;
-  const int half = threadIdx.x >> 8, tid = (int)threadIdx.x & 255;
-  double (*As)[UTP] = (double (*)[UTP])smem + half * 2 * NB;
-  double (*Bs)[UTP] = As + NB;
-  __shared__ double dshs[NB];
-  const int kp = (panel - 1) * NB, r0 = kp + NB;
-  const int ntl = (nt - 1) * nt / 2, npairs = (ntl + 1) / 2;
-  if (w >= npairs) SDM_ENDPGM();
-  if (threadIdx.x < NB) dshs[threadIdx.x] = d[first + kp + threadIdx.x];
+  constexpr int NW = LDL_THREADS / 64, NQ = NB / NW;           // 8 wavefronts, 8 operand rows per work-item and array
+  const int tid = threadIdx.x;
+  double (*Ab)[UTP] = (double (*)[UTP])smem;                   // buffer u: As = Ab + u * 2 NB, Bs = As + NB   (4 NB UTP doubles = PANEL_LDS_RIDE)
+  __shared__ double dshs[5][NB];                               // pivots: row 0 the panel before, rows 1 .. 4 the panels of the deferred group
+  const TileSched sc = tile_sched(ns, ms, panel);
+  const int nitems = tile_sched_items(sc);
+  if (w >= nitems) SDM_ENDPGM();
+  const int r0 = panel * NB;
+  for (int e = tid; e < 5 * NB; e += LDL_THREADS) {
+    const int row = e / NB, k = e % NB;
+    dshs[row][k] = row == 0 ? d[first + (panel - 1) * NB + k] : (sc.g2 >= 0 ? d[first + (4 * sc.g2 + row - 1) * NB + k] : 0.0);
+  }
   const int wv = tid >> 6, l = tid & 63;
-  const int wi = wv >> 1, wj = wv & 1, cj = wj * 16 * BJ, lk = l >> 4, ll = l & 15;
+  const int wi = wv >> 2, cj = (wv & 3) * 16, lk = l >> 4, ll = l & 15;
   const int i = tid & 63, kq = tid >> 6;
-  double av[NQ], bv[NQ];
-  int I, J;
-  bool active;
-  auto locate = [&](int pair, int &I_, int &J_, bool &act) {
-    const int u = 2 * pair + half;
-    act = u < ntl;
-    tile_index(act ? u : 0, I_, J_);
-    I_++; J_++;                                                // block column 0 belongs to the row-solve workgroups
+  auto locate = [&](int u, TileItem &t) {
+    if (u < sc.NE) {                                           // band (1, JE): eager tiles of the panel before
+      t.nch = 1; t.kp0 = (panel - 1) * NB; t.ds0 = 0;
+      const int JW = min(sc.JE, sc.nt - 1), tri = JW * (JW + 1) / 2;
+      if (u < tri) { tile_index(u, t.I, t.J); t.I += 1; t.J += 1; } else { t.I = 1 + JW + (u - tri) / JW; t.J = 1 + (u - tri) % JW; }
+    } else if (u < sc.NE + sc.NH) {                            // band (4, 4): the deferred group's first four columns
+      const int x = u - sc.NE, JW = min(4, sc.nt - 4), tri = JW * (JW + 1) / 2;
+      t.nch = 4; t.kp0 = 4 * sc.g2 * NB; t.ds0 = 1;
+      if (x < tri) { tile_index(x, t.I, t.J); t.I += 4; t.J += 4; } else { t.I = 4 + JW + (x - tri) / JW; t.J = 4 + (x - tri) % JW; }
+    } else {                                                   // this launch's share of the triangle from tile column 4 g2 + 12 on
+      const int x = u - sc.NE - sc.NH;
+      t.nch = 4; t.kp0 = 4 * sc.g2 * NB; t.ds0 = 1;
+      tile_index(sc.all ? x : share_tile(x, sc.r), t.I, t.J);
+      t.I += 8 - sc.r; t.J += 8 - sc.r;
+    }
   };
-  auto fetch_operands = [&](int I_, int J_) {                  // all loads issued before the first use (clamped addresses, masked when staged)
-    const double *pa = Fs + min(r0 + I_ * TILE + i, ms - 1), *pb = Fs + min(r0 + J_ * TILE + i, ms - 1);
+  double av[NQ], bv[NQ];
+  auto fetch_operands = [&](const TileItem &t, int kp) {       // 16 loads per work-item, issued together (rows clamped, masked when staged)
+    const double *pa = Fs + min(r0 + t.I * TILE + i, ms - 1), *pb = Fs + min(r0 + t.J * TILE + i, ms - 1);
 #pragma unroll
     for (int q = 0; q < NQ; q++) { const int64_t off = (int64_t)(kp + kq + NW * q) * ld; av[q] = pa[off]; bv[q] = pb[off]; }
   };
-  locate(w, I, J, active);
-  fetch_operands(I, J);
-  for (int pair = w; pair < npairs; pair += ntw) {
-    __syncthreads();                                           // the pair before is through with As / Bs (first round: dshs is there)
-    {
-      const bool iok = r0 + I * TILE + i < ms, jok = r0 + J * TILE + i < ms;
+  auto stage = [&](const TileItem &t, int ch, int u) {         // registers -> LDS buffer u, B scaled by the pivots
+    double (*As)[UTP] = Ab + u * 2 * NB, (*Bs)[UTP] = As + NB;
+    const bool iok = r0 + t.I * TILE + i < ms, jok = r0 + t.J * TILE + i < ms;
+    const double *dsh = dshs[t.ds0 + ch];
 #pragma unroll
-      for (int q = 0; q < NQ; q++) { const int k = kq + NW * q; As[k][i] = iok ? av[q] : 0.0; Bs[k][i] = jok ? bv[q] * dshs[k] : 0.0; }
-    }
-    __syncthreads();
-    // this tile's own values (read-modify-write) and the NEXT pair's operands go out now and arrive behind the MFMA loop
-    double cv[2][BJ][4];
+    for (int q = 0; q < NQ; q++) { const int k = kq + NW * q; As[k][i] = iok ? av[q] : 0.0; Bs[k][i] = jok ? bv[q] * dsh[k] : 0.0; }
+  };
+  // step = (tile, chunk); `it`/`ch` the step in the buffer, `nx`/`nch` the one in the registers
+  int item = w, ch = 0, buf = 0;
+  TileItem it, nx;
+  locate(item, it);
+  fetch_operands(it, it.kp0);
+  __syncthreads();                                             // dshs
+  stage(it, 0, 0);
+  int nitem = item, nch = 1;
+  bool more = true;
+  nx = it;
+  if (nch == it.nch) { nitem = item + ntw; nch = 0; more = nitem < nitems; if (more) locate(nitem, nx); }
+  if (more) fetch_operands(nx, nx.kp0 + nch * NB);
+  __syncthreads();
+  double c[2][4], cs[2][4];
+  int Is = 0, Js = 0;
+  bool pend = false;                                           // cs = the finished values of tile (Is, Js), not stored yet
+  auto store_tile = [&]() {
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-      for (int b = 0; b < BJ; b++)
+      for (int r = 0; r < 4; r++) {
+        const int gi = r0 + Is * TILE + wi * 32 + a * 16 + ll, gj = r0 + Js * TILE + cj + lk + 4 * r;
+        if (gi < ms && gj < ms && gi >= gj) sdm_store_wt(&Fs[(int64_t)gj * ld + gi], cs[a][r]);
+      }
+  };
+  for (;;) {
+    double (*As)[UTP] = Ab + buf * 2 * NB, (*Bs)[UTP] = As + NB;
+    // the next step: its operands (in flight since the step before) into the other buffer
+    if (more) stage(nx, nch, buf ^ 1);
+    if (pend) { store_tile(); pend = false; }                 // the tile finished in the step before: its stores have this whole step to be acknowledged
+    if (ch == 0) {                                             // the tile's own values: arrive behind the MFMA loop
+#pragma unroll
+      for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int gi = r0 + I * TILE + wi * 32 + a * 16 + ll, gj = r0 + J * TILE + cj + b * 16 + lk + 4 * r;
-          cv[a][b][r] = Fs[(int64_t)min(gj, ms - 1) * ld + min(gi, ms - 1)];
+          const int gi = r0 + it.I * TILE + wi * 32 + a * 16 + ll, gj = r0 + it.J * TILE + cj + lk + 4 * r;
+          c[a][r] = Fs[(int64_t)min(gj, ms - 1) * ld + min(gi, ms - 1)];
         }
-    const int I0 = I, J0 = J;
-    const bool act0 = active;
-    if (pair + ntw < npairs) { locate(pair + ntw, I, J, active); fetch_operands(I, J); }
-    sdm_double4 acc[2][BJ];
-    for (int a = 0; a < 2; a++) for (int b = 0; b < BJ; b++) for (int r = 0; r < 4; r++) acc[a][b][r] = 0.0;
-    double bo[BJ], ao[2];
-#pragma unroll
-    for (int b = 0; b < BJ; b++) bo[b] = Bs[lk][cj + b * 16 + ll];
+    }
+    // ... and the loads of the step after the next
+    TileItem n2 = nx;
+    int n2item = nitem, n2ch = nch + 1;
+    bool more2 = more;
+    if (more) {
+      if (n2ch == nx.nch) { n2item = nitem + ntw; n2ch = 0; more2 = n2item < nitems; if (more2) locate(n2item, n2); }
+      if (more2) fetch_operands(n2, n2.kp0 + n2ch * NB);
+    }
+    sdm_double4 acc[2];
+    for (int a = 0; a < 2; a++) for (int r = 0; r < 4; r++) acc[a][r] = 0.0;
+    double bo = Bs[lk][cj + ll], ao[2];
 #pragma unroll
     for (int a = 0; a < 2; a++) ao[a] = As[lk][wi * 32 + a * 16 + ll];
 #pragma unroll
     for (int kk = 0; kk < NB; kk += 4) {
-      double bn[BJ], an[2];
       const int kn = min(kk + 4, NB - 4);
-#pragma unroll
-      for (int b = 0; b < BJ; b++) bn[b] = Bs[kn + lk][cj + b * 16 + ll];
+      const double bn = Bs[kn + lk][cj + ll];
+      double an[2];
 #pragma unroll
       for (int a = 0; a < 2; a++) an[a] = As[kn + lk][wi * 32 + a * 16 + ll];
 #pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < BJ; b++) acc[a][b] = SDM_MFMA_F64_16x16x4(bo[b], ao[a], acc[a][b]);
-#pragma unroll
-      for (int b = 0; b < BJ; b++) bo[b] = bn[b];
+      for (int a = 0; a < 2; a++) acc[a] = SDM_MFMA_F64_16x16x4(bo, ao[a], acc[a]);
+      bo = bn;
 #pragma unroll
       for (int a = 0; a < 2; a++) ao[a] = an[a];
     }
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-      for (int b = 0; b < BJ; b++)
+      for (int r = 0; r < 4; r++) c[a][r] = c[a][r] - acc[a][r];
+    if (ch == it.nch - 1) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int ti = wi * 32 + a * 16 + ll, tj = cj + b * 16 + lk + 4 * r;
-          const int gi = r0 + I0 * TILE + ti, gj = r0 + J0 * TILE + tj;
-          if (act0 && gi < ms && gj < ms && gi >= gj) sdm_store_wt(&Fs[(int64_t)gj * ld + gi], cv[a][b][r] - acc[a][b][r]);
-        }
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) cs[a][r] = c[a][r];
+      Is = it.I; Js = it.J; pend = true;
+    }
+    if (!more) break;
+    __syncthreads();                                           // the other buffer is complete, this one is free
+    it = nx; item = nitem; ch = nch; buf ^= 1;
+    nx = n2; nitem = n2item; nch = n2ch; more = more2;
   }
+  if (pend) store_tile();
   SDM_ENDPGM();
 }
 // ---- workgroup 0 = the dependency chain of the launch, as a CHAIN OF STAGES that never return: the role's prologue calls the update
@@ -1429,7 +1537,7 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
   }
   if (bx > nrw) {
     if (phase == 2 || panel == 0) return;
-    if (nrw > 0) panel_role_tiles_stream(smem, Fs, d, ms, ld, first, panel, bx - 1 - nrw, (int)gridDim.x - 1 - nrw, nt);
+    if (nrw > 0) panel_role_tiles_stream(smem, Fs, d, ns, ms, ld, first, panel, bx - 1 - nrw, (int)gridDim.x - 1 - nrw);
     else panel_role_tiles(smem, Fs, d, ms, ld, first, panel, bx - 1 - nrw, nrw, nt, upd_cnt + s);
     return;
   }

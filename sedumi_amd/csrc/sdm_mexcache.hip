@@ -99,8 +99,7 @@ class SumPool {
   u64 gen = 0;
   bool stop = false;
   u64 part[16][8];
-  void worker(int id) {
-    u64 seen = 0;
+  void worker(int id, u64 seen) {                              // seen: the generation current when the helper was created (by the one thread that advances it)
     for (;;) {
       std::unique_lock<std::mutex> lk(mu);
       cv_go.wait(lk, [&] { return stop || gen != seen; });
@@ -119,7 +118,7 @@ class SumPool {
   void run(const u64 *vp, sdm_int len, int want, u64 *acc) {
     want = std::max(1, std::min(want, 16));
     if (th.empty()) { static bool reg = false; if (!reg) { reg = true; std::atexit([] { pool_shutdown(); }); } }   // sleeping helpers are joined before the process ends
-    while ((int)th.size() < want - 1) { const int id = (int)th.size() + 1; th.emplace_back([this, id] { worker(id); }); }
+    while ((int)th.size() < want - 1) { const int id = (int)th.size() + 1; const u64 g0 = gen; th.emplace_back([this, id, g0] { worker(id, g0); }); }
     const sdm_int ch = ((len + want - 1) / want + 7) & ~(sdm_int)7;
     {
       std::lock_guard<std::mutex> lk(mu);

@@ -406,13 +406,15 @@ def test_getada_gateway_on_the_nb_example():
         assert relerr(absd.ravel(), z[f"{tag}_absd"]) < TOL
 
 
-@pytest.mark.parametrize("m", [112, 123, 174, 330, 512, 666, 1000])
+@pytest.mark.parametrize("m", [112, 123, 174, 330, 512, 666, 900, 1000])
 def test_one_launch_front_matches_the_panel_launches_bit_for_bit(refmex, m):
     helpers.check_one_launch_front(refmex, m)
 
 
-@pytest.mark.parametrize("m", [330, 1000])
+@pytest.mark.parametrize("m", [330, 900, 1000])
 def test_streamed_update_tiles_give_the_same_bits_whatever_the_number_of_workgroups(refmex, m):
+    """(m = 900, 15 tile rows: one deferred group whose far triangle goes in one launch; m = 1000, 16: two groups, the first one's far
+    triangle dealt over four launches -- tile_sched in sdm_chol.hip)"""
     helpers.check_streamed_update_tiles(refmex, m)
 
 

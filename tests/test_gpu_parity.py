@@ -557,7 +557,7 @@ def test_streamed_update_tiles_give_the_same_bits_whatever_the_number_of_workgro
     helpers.check_streamed_update_tiles(refmex, m, caps)
 
 
-@pytest.mark.parametrize("m", [112, 123, 174, 200, 330, 512, 666, 1000, 1024, 1100, 1344])
+@pytest.mark.parametrize("m", [112, 123, 174, 200, 330, 512, 666, 900, 1000, 1024, 1100, 1344])
 def test_one_launch_front_matches_the_panel_launches_bit_for_bit(refmex, m):
     """k_ldl_front (workgroups of one launch hand the factor on through device-scope counters) against the launch-per-panel
     path: same bits, and both within tolerance of the reference.  1344 rows = 21 tile rows + 190 tiles = 211 workgroups is

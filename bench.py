@@ -458,10 +458,13 @@ def measure_config(name, device, steps, warmup, nprof, mex_units=0, growth_max=N
         step = unit_fn(plan)
         el = time_steps(plan, step, steps, warmup)
         roof, phases = profile_unit(plan, P, ud, nprof)
-        mexleg = None
+        mexleg = mexlazy = None
         if mex_units:
             plan.upload("rhs", rhs); plan.ldlsolve()
-            mexleg = mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, mex_units, plan.download("y"))
+            yres = plan.download("y")
+            mexleg = mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, mex_units, yres)
+            if name.startswith("maxcut") or name.startswith("blockdiag"):
+                mexlazy = {"level_%d" % lv: mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, mex_units, yres, lazy=lv) for lv in (1, 2)}
         out = {"workload": name, "problem": P.name, "m": int(P.m), "nnzL": int(plan.nnzL), "nsuper": int(plan._xsuper.size - 1),
                "ms_per_step": 1e3 * el / steps, "iters_per_s": steps / el, "steps": steps,
                "dominant_kernel": roof and {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step")},
@@ -469,6 +472,8 @@ def measure_config(name, device, steps, warmup, nprof, mex_units=0, growth_max=N
                "solve": phases["solve"], "factor": phases["factor"], "setup_s": time.perf_counter() - t0 - el}
         if mexleg is not None:
             out["mex_inclusive"] = mexleg
+        if mexlazy:
+            out["mex_inclusive_lazy"] = mexlazy
         if cpu_units:
             t1 = time.perf_counter()
             base = cpu_baseline(P, d, ud, rhs, budget_s=8.0, max_units=cpu_units)
@@ -478,6 +483,9 @@ def measure_config(name, device, steps, warmup, nprof, mex_units=0, growth_max=N
                 out["speedup_vs_cpu_reference"] = out["iters_per_s"] / base["value"]
                 if mexleg and mexleg.get("value"):
                     out["mex_inclusive_speedup_vs_cpu_reference"] = mexleg["value"] / base["value"]
+                for k, v in (mexlazy or {}).items():
+                    if v.get("value"):
+                        out["mex_inclusive_lazy_" + k + "_speedup_vs_cpu_reference"] = v["value"] / base["value"]
         if growth_max is not None:
             out["workload"] = (f"{name} (solves with growth_max = {growth_max:g}: every super-block beyond the bound, as in the last iterations of a run; " +
                                ("inverse + two refinement steps against the factor)" if refine else "substituted by one workgroup: sdm_plan_set_refinement(0))"))
@@ -514,7 +522,7 @@ def pcie_inclusive(plan, P, d, ud, rhs, steps):
                     f"synchronous copies): {8 * (3 * nA + 2 * nL) / 1e6:.1f} MB per unit"}
 
 
-def mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, units, y_resident=None, mex_dir=None):
+def mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, units, y_resident=None, mex_dir=None, lazy=0):
     """The unit as an UNMODIFIED sedumi.m would run it: through the built mexFunction shims (sedumi_amd/lib/mex/<name>.so, the
     sources of sedumi_amd/mexshims compiled against the package's MEX host -- no MATLAB / Octave in this image), host mxArrays in
     and out of every one of the 4 + 2x4 gateway calls, outputs handed to the next gateway by reference as MATLAB does
@@ -545,8 +553,12 @@ def mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, units, y_resident=None, mex_dir
         lib = capi.lib()
         st = (ctypes.c_int64 * 16)()
         lib.sdm_mexcache_clear()
+        lib.sdm_mexcache_set_lazy(int(lazy))                          # (0: every gateway returns the reference's arrays, the default)
         host = mexhost.MexHost(mex_dir)
-        times, y = mexhost.iteration_units(host, At, np.asarray(P.Ablkjc)[:, 2], Aord, K, dstruct, {"q": Qm}, ud, L, ADA, PARS, rhs, units + 1, NSOLVE)
+        try:
+            times, y = mexhost.iteration_units(host, At, np.asarray(P.Ablkjc)[:, 2], Aord, K, dstruct, {"q": Qm}, ud, L, ADA, PARS, rhs, units + 1, NSOLVE)
+        finally:
+            lib.sdm_mexcache_set_lazy(0)
         lib.sdm_mexcache_stats(st, ctypes.c_int64(16))
         lib.sdm_mexcache_clear()
         first, rest = times[0], times[1:]
@@ -560,6 +572,7 @@ def mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, units, y_resident=None, mex_dir
                "content_checks": {"host_words_checksummed_per_unit": float(st[11]) / len(times), "MB_per_unit": 8e-6 * float(st[11]) / len(times),
                                   "rule": "residency is decided by a checksum of every word of the host array (sdm_mexcache.hip): arrays up to 65536 words at every "
                                           "presentation, larger ones once per address and epoch (= between two blkchol calls)"},
+               **({"lazy_level": int(lazy), "lazy": "opt-in SEDUMI_HIP_LAZY=%d: getada1 / getada2%s return a token, ADA' stays on the device (sdm_mexcache.hip)" % (lazy, " / getada3" if lazy > 1 else "")} if lazy else {}),
                "note": "mexFunction shims (sedumi_amd/lib/mex) on the MEX host of the package; host mxArrays cross PCIe at every gateway: scaling "
                        "data and right-hand sides up, ADA' (3x), absd, L.L, L.d, pivot lists and solutions down; the first unit (analysis of At, "
                        "the patterns and the symbolic factor, once per solve) is reported separately"}

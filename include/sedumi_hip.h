@@ -415,19 +415,19 @@ int sdm_plan_solve_levels(sdm_plan *p, int what, sdm_int l0, sdm_int l1);
  * from the device, chol builds, reuses, X uploads, X resident, resident solves, stateless solves, At uploads). */
 int sdm_mexcache_getada1(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc, const sdm_int *Air,
                          const double *Apr, const sdm_int *Ajc2, const sdm_int *perm, sdm_int lpN, const double *dl, sdm_int lorN,
-                         const double *ddet, const sdm_int *qblkstart, double *ADApr);
+                         const double *ddet, const sdm_int *qblkstart, double *ADApr, double token_in, double *token_out);
 int sdm_mexcache_getada2(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const double *ADApr_in, double *ADApr, sdm_int lorN,
-                         const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, const sdm_int *qperm);
+                         const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, const sdm_int *qperm, double token_in, double *token_out);
 int sdm_mexcache_getada3(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const double *ADApr_in, double *ADApr, sdm_int N,
                          const sdm_int *Ajc, const sdm_int *Air, const double *Apr, const sdm_int *Ajc1, const double *udsqr,
-                         const sdm_cone *K, const sdm_int *psd_blkstart, double *absd);
+                         const sdm_cone *K, const sdm_int *psd_blkstart, double *absd, double token_in, double *token_out);
 int sdm_mexcache_getada(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc, const sdm_int *Air,
                         const double *Apr, sdm_int lpN, const double *dl, sdm_int lorN, const double *ddet, const sdm_int *qblkstart,
                         const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, double *ADApr, double *absd);
 int sdm_mexcache_blkchol(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm, sdm_int nsuper, const sdm_int *xsuper,
                          const sdm_int *Xjc, const sdm_int *Xir, const double *Xpr, const sdm_cholpars *pars, const double *absd,
                          double *Lpr, double *d, sdm_int *nskip, sdm_int *skip_idx, double *skip_val, sdm_int *nadd, sdm_int *add_idx,
-                         double *add_val);
+                         double *add_val, double token_in);
 int sdm_mexcache_solve(int fw, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const double *Lpr, const sdm_int *perm, sdm_int nsuper,
                        const sdm_int *xsuper, sdm_int nrhs, const double *b, double *y);
 void sdm_mexcache_stats(sdm_int *out16, sdm_int n);   /* [11] words checksummed on the host since the last clear, [12] the epoch */
@@ -438,6 +438,15 @@ void sdm_mexcache_stats(sdm_int *out16, sdm_int n);   /* [11] words checksummed 
  * set_strict(1): no shortcut, every presentation is checksummed completely. */
 void sdm_mexcache_set_strict(int on);
 void sdm_mexcache_set_full_below(sdm_int words);
+/* Lazy intermediates, opt-in (environment SEDUMI_HIP_LAZY = 1 | 2, or set_lazy): getada1.mex / getada2.mex (level 2: getada3.mex too) return
+ * a TOKEN instead of ADA' -- an m x m sparse matrix whose one nonzero (1,1) is sdm_mexcache_token_base() + a serial number -- and leave the
+ * values on the device; the next gateway recognises the current token (token_in of the functions above; token_out != NULL asks for one) and
+ * fails loudly on any other.  sedumi.m:450-458 never looks at these arrays; default (level 0): every gateway returns the reference's array. */
+void sdm_mexcache_set_lazy(int level);
+int sdm_mexcache_lazy(void);
+int sdm_mexcache_token_info(double token, sdm_int m, sdm_int *nnz);
+int sdm_mexcache_token_pattern(double token, sdm_int m, sdm_int *jc_out, sdm_int *ir_out);
+double sdm_mexcache_token_base(void);
 void sdm_mexcache_set_threads(int n);   /* host threads of a checksum from 128K words on: -1 automatic (4; 8 from 1M words), 1 none */
 unsigned long long sdm_mexcache_checksum(const void *words, sdm_int n);   /* the content checksum of n 8-byte host words */
 /* The cached plan of the factorisation for callers that drive it themselves: sdm_mexcache_plan returns the plan of the

@@ -224,16 +224,39 @@ struct Finger {
 };
 
 // ---- index patterns (CSC jc / ir pairs): interned, so that the slots below compare small integers.  An id is never reused.
-struct Pattern { sdm_int ncol = -1; Finger jc, ir; u64 id = 0, used = 0; };
+struct Pattern { sdm_int ncol = -1; Finger jc, ir; u64 id = 0, used = 0; std::vector<sdm_int> jcc, irc; };   // (jcc / irc: a host copy, lazy mode only)
 Pattern g_pat[12];
 u64 g_next_id = 1, g_clock = 0;
+// ---- lazy intermediates (opt-in: SEDUMI_HIP_LAZY = 1 | 2, or sdm_mexcache_set_lazy).  sedumi.m:450-458 hands ADA' from getada1 to getada2
+// to getada3 to blkchol and never looks at it.  Level 1: getada1.mex / getada2.mex return, instead of ADA' (values + a copy of the pattern,
+// 2 x 128 MB for MAXCUT-4000, each read again by the next gateway's content check), a TOKEN: an m x m sparse matrix with the one nonzero
+// (1,1) = LAZY_BASE + a serial number that is never reused; the values stay on the device.  A gateway handed a token takes the
+// device's ADA' if the token is the current one and fails loudly otherwise (there are no values to fall back on).  getada3.mex
+// materialises: its ADA' and absd are the reference's.  Level 2: getada3.mex returns a token as well (absd is real) and blkchol.mex
+// factors the device's ADA' -- what crosses PCIe per iteration is then absd, L.L, L.d, the pivot lists and the solves' vectors.
+constexpr double LAZY_BASE = 6755399441055744.0;             // 1.5 * 2^52: token = LAZY_BASE + serial, exact in a double
+int g_lazy = -1;                                             // -1: not read from the environment yet
+u64 g_serial = 0;
+struct { u64 serial = 0, pat = 0; sdm_int m = 0, nnz = 0; } g_tok;      // the current token: which pattern the device's ADA' (g_last.plan) has
+int lazy_level() {
+  if (g_lazy < 0) { const char *e = getenv("SEDUMI_HIP_LAZY"); g_lazy = e ? std::max(0, std::min(2, atoi(e))) : 0; }
+  return g_lazy;
+}
+bool is_token(double t) { return t > LAZY_BASE && t < LAZY_BASE + 4294967296.0; }
+Pattern *pattern_by_id(u64 id) { for (auto &p : g_pat) if (p.id == id) return &p; return nullptr; }
 u64 intern(sdm_int ncol, const sdm_int *jc, const sdm_int *ir) {
   const sdm_int nnz = jc[ncol];
   for (auto &p : g_pat)
-    if (p.id && p.ncol == ncol && p.jc.same(jc, ncol + 1) && p.ir.same(ir, nnz)) { p.used = ++g_clock; return p.id; }
+    if (p.id && p.ncol == ncol && p.jc.same(jc, ncol + 1) && p.ir.same(ir, nnz)) {
+      p.used = ++g_clock;
+      if (lazy_level() > 0 && p.irc.empty() && nnz > 0) { p.jcc.assign(jc, jc + ncol + 1); p.irc.assign(ir, ir + nnz); }
+      return p.id;
+    }
   Pattern *v = &g_pat[0];
   for (auto &p : g_pat) if (p.used < v->used) v = &p;                 // least recently used (empty entries first: used = 0)
   v->ncol = ncol; v->jc.take(jc, ncol + 1); v->ir.take(ir, nnz); v->id = g_next_id++; v->used = ++g_clock;
+  v->jcc.clear(); v->irc.clear();
+  if (lazy_level() > 0) { v->jcc.assign(jc, jc + ncol + 1); v->irc.assign(ir, ir + nnz); }
   return v->id;
 }
 
@@ -284,6 +307,24 @@ void download_returned(sdm_plan *p, double *pr, double *absd, sdm_int nnz) {
   gw_download(p, pr, absd);                                           // (drains the stream)
   g_last.plan = p; g_last.vals.take_with_full(pr, nnz, fold_sums(acc, nnz));
 }
+// a gateway leaves its ADA' on the device and hands out a token for it (lazy mode)
+double returned_token(sdm_plan *p, u64 pat, sdm_int m, sdm_int nnz) {
+  SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+  g_last.plan = p; g_last.vals.forget();
+  g_tok.serial = ++g_serial; g_tok.pat = pat; g_tok.m = m; g_tok.nnz = nnz;
+  return LAZY_BASE + (double)g_tok.serial;
+}
+// the pattern id of the ADA' a token stands for; throws unless it is the current token
+u64 token_pattern(double tok, sdm_int m) {
+  if (!g_last.plan || !is_token(tok) || tok != LAZY_BASE + (double)g_tok.serial || g_tok.m != m)
+    throw std::runtime_error("lazy ADA token is not the current one (SEDUMI_HIP_LAZY: the array a getada gateway returned must be handed to the next gateway untouched)");
+  return g_tok.pat;
+}
+void ada_input_token(sdm_plan *p, sdm_int nnz) {
+  g_stat[ST_ADA_RESIDENT]++;
+  if (g_last.plan != p)
+    SDM_HIP_CHECK(hipMemcpyAsync(p->ada_val.p, g_last.plan->ada_val.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+}
 // the input values of a gateway -> p->ada_val: from the device if they are what the previous gateway returned, else from the host
 void ada_input(sdm_plan *p, const double *pr, sdm_int nnz) {
   if (g_last.plan && g_last.vals.same(pr, nnz)) {
@@ -295,7 +336,7 @@ void ada_input(sdm_plan *p, const double *pr, sdm_int nnz) {
   g_stat[ST_ADA_UPLOAD]++;
   SDM_HIP_CHECK(hipMemcpyAsync(p->ada_val.p, pr, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, p->stream));
 }
-void forget_plan(sdm_plan *p) { if (g_last.plan == p) { g_last.plan = nullptr; g_last.vals.forget(); } }
+void forget_plan(sdm_plan *p) { if (g_last.plan == p) { g_last.plan = nullptr; g_last.vals.forget(); g_tok.serial = 0; } }
 
 // ---- the factorisation's plan
 struct Chol {
@@ -365,16 +406,36 @@ void sdm_mexcache_stats(sdm_int *out, sdm_int n) {
 }
 // arrays of up to `words` words are checksummed completely at every presentation (default 65 536); larger ones once per address and epoch
 void sdm_mexcache_set_full_below(sdm_int words) { full_below = words < 0 ? 0 : words; }
+// lazy intermediates (the block comment at LAZY_BASE): level 0 (default) | 1 | 2; -1: as the environment variable SEDUMI_HIP_LAZY says
+void sdm_mexcache_set_lazy(int level) { g_lazy = level < 0 ? -1 : std::min(level, 2); }
+int sdm_mexcache_lazy(void) { return lazy_level(); }
+// m x m of the ADA' a token stands for and its number of nonzeros; returns 1 (with sdm_last_error) unless `token` is the current token
+int sdm_mexcache_token_info(double token, sdm_int m, sdm_int *nnz) {
+  try { token_pattern(token, m); *nnz = g_tok.nnz; return 0; } catch (const std::exception &e) { set_error(e.what()); return 1; }
+}
+// the pattern behind the current token into the caller's arrays (m + 1 and nnz entries)
+int sdm_mexcache_token_pattern(double token, sdm_int m, sdm_int *jc_out, sdm_int *ir_out) {
+  try {
+    Pattern *pp = pattern_by_id(token_pattern(token, m));
+    if (!pp || pp->irc.empty()) throw std::runtime_error("lazy ADA token: its pattern is not cached any more");
+    memcpy(jc_out, pp->jcc.data(), pp->jcc.size() * sizeof(sdm_int)); memcpy(ir_out, pp->irc.data(), pp->irc.size() * sizeof(sdm_int));
+    return 0;
+  } catch (const std::exception &e) { set_error(e.what()); return 1; }
+}
+double sdm_mexcache_token_base(void) { return LAZY_BASE; }
 // threads of the checksum of an array from 128K words on (the caller's included): -1 = automatic (4, and 8 from 1M words), 1 = none
 void sdm_mexcache_set_threads(int n) { g_threads = n; }
 
 // ADA = getada1(ADA, A, Ajc2, perm, d, blkstart) on the cache (same arguments as sdm_getada1)
 int sdm_mexcache_getada1(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc, const sdm_int *Air,
                          const double *Apr, const sdm_int *Ajc2, const sdm_int *perm, sdm_int lpN, const double *dl, sdm_int lorN,
-                         const double *ddet, const sdm_int *qblkstart, double *ADApr) {
+                         const double *ddet, const sdm_int *qblkstart, double *ADApr, double token_in, double *token_out) {
+  // token_in != 0: the ADA' handed in is a lazy token (ADAjc / ADAir may be NULL: only its pattern matters and the cache knows it);
+  // token_out != NULL: the values stay on the device and *token_out stands for them (ADApr may be NULL)
   MC_TRY
   AdaSlot &S = g_s1;
-  const u64 pa = intern(m, ADAjc, ADAir), pA = intern(m, Ajc, Air);
+  const u64 pa = token_in != 0.0 ? token_pattern(token_in, m) : intern(m, ADAjc, ADAir), pA = intern(m, Ajc, Air);
+  if (token_in != 0.0) { Pattern *pp = pattern_by_id(pa); if (!pp || pp->irc.empty()) throw std::runtime_error("lazy ADA token: its pattern is not cached any more"); ADAjc = pp->jcc.data(); ADAir = pp->irc.data(); }
   std::vector<sdm_int> ints = {m, N, lpN, lorN};
   ints.insert(ints.end(), qblkstart, qblkstart + lorN + 1);
   if (!(S.built && S.pat_ada == pa && S.pat_a == pA && S.ints == ints && vec_is(S.split, Ajc2, m) && S.apr.same(Apr, Ajc[m]))) {
@@ -388,16 +449,18 @@ int sdm_mexcache_getada1(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, 
   } else g_stat[ST_ADA_REUSE]++;
   S.set_perm(perm, m);
   gw_run_getada1(S.plan, S.invperm.p, dl, ddet);
-  download_returned(S.plan, ADApr, nullptr, ADAjc[m]);
+  if (token_out) *token_out = returned_token(S.plan, pa, m, ADAjc[m]);
+  else download_returned(S.plan, ADApr, nullptr, ADAjc[m]);
   MC_CATCH
 }
 
 // ADA = getada2(ADA, DAt, Aord, K): ADApr_in the values of the input array, ADApr (out) those of the copy the shim returns
 int sdm_mexcache_getada2(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const double *ADApr_in, double *ADApr, sdm_int lorN,
-                         const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, const sdm_int *qperm) {
+                         const sdm_int *Qjc, const sdm_int *Qir, const double *Qpr, const sdm_int *qperm, double token_in, double *token_out) {
   MC_TRY
   AdaSlot &S = g_s2;
-  const u64 pa = intern(m, ADAjc, ADAir), pq = intern(m, Qjc, Qir);
+  const u64 pa = token_in != 0.0 ? token_pattern(token_in, m) : intern(m, ADAjc, ADAir), pq = intern(m, Qjc, Qir);
+  if (token_in != 0.0) { Pattern *pp = pattern_by_id(pa); if (!pp || pp->irc.empty()) throw std::runtime_error("lazy ADA token: its pattern is not cached any more"); ADAjc = pp->jcc.data(); ADAir = pp->irc.data(); }
   std::vector<sdm_int> ints = {m, lorN};
   if (!(S.built && S.pat_ada == pa && S.pat_q == pq && S.ints == ints)) {
     if (!S.plan) S.plan = new_plan();
@@ -409,18 +472,20 @@ int sdm_mexcache_getada2(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, 
     S.built = true;
   } else g_stat[ST_ADA_REUSE]++;
   S.set_perm(qperm, m);
-  ada_input(S.plan, ADApr_in, ADAjc[m]);
+  if (token_in != 0.0) ada_input_token(S.plan, ADAjc[m]); else ada_input(S.plan, ADApr_in, ADAjc[m]);
   gw_run_getada2(S.plan, S.invperm.p, Qpr);
-  download_returned(S.plan, ADApr, nullptr, ADAjc[m]);
+  if (token_out) *token_out = returned_token(S.plan, pa, m, ADAjc[m]);
+  else download_returned(S.plan, ADApr, nullptr, ADAjc[m]);
   MC_CATCH
 }
 // [ADA, absd] = getada3(ADA, A, Ajc1, Aord, udsqr, K)
 int sdm_mexcache_getada3(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const double *ADApr_in, double *ADApr, sdm_int N,
                          const sdm_int *Ajc, const sdm_int *Air, const double *Apr, const sdm_int *Ajc1, const double *udsqr,
-                         const sdm_cone *K, const sdm_int *psd_blkstart, double *absd) {
+                         const sdm_cone *K, const sdm_int *psd_blkstart, double *absd, double token_in, double *token_out) {
   MC_TRY
   AdaSlot &S = g_s3;
-  const u64 pa = intern(m, ADAjc, ADAir), pA = intern(m, Ajc, Air);
+  const u64 pa = token_in != 0.0 ? token_pattern(token_in, m) : intern(m, ADAjc, ADAir), pA = intern(m, Ajc, Air);
+  if (token_in != 0.0) { Pattern *pp = pattern_by_id(pa); if (!pp || pp->irc.empty()) throw std::runtime_error("lazy ADA token: its pattern is not cached any more"); ADAjc = pp->jcc.data(); ADAir = pp->irc.data(); }
   std::vector<sdm_int> ints = {m, N, K->lorN, K->sdpN, K->rsdpN};
   ints.insert(ints.end(), K->sdpNL, K->sdpNL + K->sdpN);
   ints.insert(ints.end(), psd_blkstart, psd_blkstart + K->sdpN + (K->sdpN > 0 ? 1 : 0));
@@ -433,9 +498,10 @@ int sdm_mexcache_getada3(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, 
     S.pat_ada = pa; S.pat_a = pA; S.ints = ints; S.split.assign(Ajc1, Ajc1 + m); S.apr.take(Apr, Ajc[m]);
     S.built = true;
   } else g_stat[ST_ADA_REUSE]++;
-  ada_input(S.plan, ADApr_in, ADAjc[m]);
+  if (token_in != 0.0) ada_input_token(S.plan, ADAjc[m]); else ada_input(S.plan, ADApr_in, ADAjc[m]);
   gw_run_getada3(S.plan, udsqr);
-  download_returned(S.plan, ADApr, absd, ADAjc[m]);
+  if (token_out) { gw_download(S.plan, nullptr, absd); *token_out = returned_token(S.plan, pa, m, ADAjc[m]); }
+  else download_returned(S.plan, ADApr, absd, ADAjc[m]);
   MC_CATCH
 }
 
@@ -466,12 +532,14 @@ int sdm_mexcache_getada(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, s
 int sdm_mexcache_blkchol(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm, sdm_int nsuper, const sdm_int *xsuper,
                          const sdm_int *Xjc, const sdm_int *Xir, const double *Xpr, const sdm_cholpars *pars, const double *absd,
                          double *Lpr, double *d, sdm_int *nskip, sdm_int *skip_idx, double *skip_val, sdm_int *nadd, sdm_int *add_idx,
-                         double *add_val) {
+                         double *add_val, double token_in) {
+  // token_in != 0: X is a lazy token (level 2: Xjc / Xir / Xpr may be NULL)
   MC_TRY
   // X is what getada3 returned in the epoch that ends here: its values and pattern are looked at before the epoch advances
+  const u64 px = token_in != 0.0 ? token_pattern(token_in, m) : intern(m, Xjc, Xir);
+  if (token_in != 0.0) { Pattern *pp = pattern_by_id(px); if (!pp || pp->irc.empty()) throw std::runtime_error("lazy ADA token: its pattern is not cached any more"); Xjc = pp->jcc.data(); Xir = pp->irc.data(); }
   const sdm_int nnzX = Xjc[m], nnzL = Ljc[m];
-  const u64 px = intern(m, Xjc, Xir);
-  const bool x_resident = g_last.plan && g_last.vals.same(Xpr, nnzX);
+  const bool x_resident = token_in != 0.0 || (g_last.plan && g_last.vals.same(Xpr, nnzX));
   g_epoch++;                         // a new factor: every address trusted so far has to present its complete content again (file header)
   sdm_plan *p = chol_plan(m, Ljc, Lir, perm, nsuper, xsuper, Xjc, Xir, px);
   g.have_factor = false;             // the resident factor is about to be overwritten: whatever the solves are handed before this call has returned is not it

@@ -28,12 +28,15 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   ivec sidx(m > 0 ? m : 1), aidx(m > 0 ? m : 1);
   std::vector<double> sval(m > 0 ? m : 1), aval(m > 0 ? m : 1);
   sdm_int ns = 0, na = 0;
-  IdxView Xjc = jc_of(X), Xir = ir_of(X);
+  const double tin = lazy_token_of(X);                               // lazy intermediates, level 2: X is getada3's token, ADA' is on the device
+  IdxView Xjc, Xir;
+  if (tin == 0.0) { Xjc = jc_of(X); Xir = ir_of(X); }
   cache_teardown_at_exit();
   // the factor stays resident in the library's cache for fwblkslv / bwblkslv; X is taken from the device when it is the
   // array getada3 just returned (sdm_mexcache.hip)
-  sdm_check(sdm_mexcache_blkchol(m, L.jc.data(), L.ir.data(), L.perm.data(), L.nsuper, L.xsuper.data(), Xjc.data(), Xir.data(), mxGetPr(X),
-                                 &pars, absd, mxGetPr(out[0]), mxGetPr(out[1]), &ns, sidx.data(), sval.data(), &na, aidx.data(), aval.data()));
+  sdm_check(sdm_mexcache_blkchol(m, L.jc.data(), L.ir.data(), L.perm.data(), L.nsuper, L.xsuper.data(), tin == 0.0 ? Xjc.data() : NULL,
+                                 tin == 0.0 ? Xir.data() : NULL, tin == 0.0 ? mxGetPr(X) : NULL, &pars, absd, mxGetPr(out[0]), mxGetPr(out[1]), &ns,
+                                 sidx.data(), sval.data(), &na, aidx.data(), aval.data(), tin));
   (void)nnzL;
   for (int k = 0; k < 2; k++) {                                       // sparse m x 1 outputs (blkchol.c:396-421)
     const sdm_int n = k ? na : ns;

@@ -14,10 +14,18 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   ivec qb = idx_from_dbl(prhs[5], -1);                              // K.qblkstart
   const sdm_int lorN = (sdm_int)qb.size() - 1;
   if ((sdm_int)numel(ddet) != lorN) mexErrMsgTxt("Size d.det mismatch");
-  IdxView jc = jc_of(ADA), ir = ir_of(ADA), Ajc = jc_of(A), Air = ir_of(A);
+  IdxView Ajc = jc_of(A), Air = ir_of(A);
   ivec Ajc2 = idx_from_dbl(prhs[2], 0), perm = idx_from_dbl(prhs[3], -1);
   cache_teardown_at_exit();
-  plhs[0] = sparse_like(ADA);                                        // getada1.c:222-225
-  sdm_check(sdm_mexcache_getada1(m, jc.data(), ir.data(), (sdm_int)mxGetM(A), Ajc.data(), Air.data(), mxGetPr(A), Ajc2.data(), perm.data(),
-                                 (sdm_int)numel(dl), mxGetPr(dl), lorN, mxGetPr(ddet), qb.data(), mxGetPr(plhs[0])));
+  // lazy intermediates (SEDUMI_HIP_LAZY >= 1): the result is a token, the values stay on the device; at level 2 the input is getada3's token
+  const double tin = lazy_token_of(ADA);
+  const bool lazy = sdm_mexcache_lazy() >= 1;
+  IdxView jc, ir;
+  if (tin == 0.0) { jc = jc_of(ADA); ir = ir_of(ADA); }
+  double tout = 0.0;
+  if (!lazy) plhs[0] = tin == 0.0 ? sparse_like(ADA) : sparse_of_token(tin, m);   // getada1.c:222-225
+  sdm_check(sdm_mexcache_getada1(m, tin == 0.0 ? jc.data() : NULL, tin == 0.0 ? ir.data() : NULL, (sdm_int)mxGetM(A), Ajc.data(), Air.data(), mxGetPr(A),
+                                 Ajc2.data(), perm.data(), (sdm_int)numel(dl), mxGetPr(dl), lorN, mxGetPr(ddet), qb.data(), lazy ? NULL : mxGetPr(plhs[0]),
+                                 tin, lazy ? &tout : NULL));
+  if (lazy) plhs[0] = make_token(m, tout);
 }

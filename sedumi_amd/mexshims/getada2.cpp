@@ -15,9 +15,15 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   if (!mxIsSparse(Q) || (sdm_int)mxGetM(Q) != ck.K.lorN || (sdm_int)mxGetN(Q) != m) mexErrMsgTxt("Size mismatch DAt.q.");
   const mxArray *qp = need_field(prhs[2], "qperm", "Missing field Aord.qperm.");
   if ((sdm_int)numel(qp) != m) mexErrMsgTxt("Aord.qperm size mismatch");
-  IdxView jc = jc_of(ADA), ir = ir_of(ADA), Qjc = jc_of(Q), Qir = ir_of(Q);
+  IdxView Qjc = jc_of(Q), Qir = ir_of(Q);
   ivec qperm = idx_from_dbl(qp, -1);
-  plhs[0] = sparse_like(ADA);                                        // getada2.c:153 (the values come back from the device)
-  sdm_check(sdm_mexcache_getada2(m, jc.data(), ir.data(), mxGetPr(ADA), mxGetPr(plhs[0]), ck.K.lorN, Qjc.data(), Qir.data(), mxGetPr(Q),
-                                 qperm.data()));
+  const double tin = lazy_token_of(ADA);                             // (lazy intermediates: token in -> token out)
+  IdxView jc, ir;
+  if (tin == 0.0) { jc = jc_of(ADA); ir = ir_of(ADA); }
+  const bool lazy = sdm_mexcache_lazy() >= 1;
+  double tout = 0.0;
+  if (!lazy) plhs[0] = tin == 0.0 ? sparse_like(ADA) : sparse_of_token(tin, m);   // getada2.c:153 (the values come back from the device)
+  sdm_check(sdm_mexcache_getada2(m, tin == 0.0 ? jc.data() : NULL, tin == 0.0 ? ir.data() : NULL, tin == 0.0 ? mxGetPr(ADA) : NULL, lazy ? NULL : mxGetPr(plhs[0]),
+                                 ck.K.lorN, Qjc.data(), Qir.data(), mxGetPr(Q), qperm.data(), tin, lazy ? &tout : NULL));
+  if (lazy) plhs[0] = make_token(m, tout);
 }

@@ -15,13 +15,21 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   ivec psd(blk.begin() + ck.K.lorN + 1, blk.end());
   const mxArray *sp = need_field(prhs[3], "sperm", "Missing field Aord.sperm.");
   if ((sdm_int)numel(sp) != m) mexErrMsgTxt("Aord.sperm size mismatch");      // (only its triangular bookkeeping exists in the reference: the sum is order independent)
-  IdxView jc = jc_of(ADA), ir = ir_of(ADA), Ajc = jc_of(A), Air = ir_of(A);
+  IdxView Ajc = jc_of(A), Air = ir_of(A);
   ivec Ajc1 = idx_from_dbl(prhs[2], 0);
   cache_teardown_at_exit();
-  mxArray *out0 = sparse_like(ADA);                                  // getada3.c:452 (the values come back from the device)
+  // lazy intermediates: the input may be a token (level >= 1); at level 2 the result is one, too (absd is always real)
+  const double tin = lazy_token_of(ADA);
+  const bool lazy_out = sdm_mexcache_lazy() >= 2;
+  IdxView jc, ir;
+  if (tin == 0.0) { jc = jc_of(ADA); ir = ir_of(ADA); }
+  double tout = 0.0;
+  mxArray *out0 = lazy_out ? NULL : (tin == 0.0 ? sparse_like(ADA) : sparse_of_token(tin, m));   // getada3.c:452 (the values come back from the device)
   mxArray *out1 = mxCreateDoubleMatrix(m, 1, mxREAL);
-  sdm_check(sdm_mexcache_getada3(m, jc.data(), ir.data(), mxGetPr(ADA), mxGetPr(out0), (sdm_int)mxGetM(A), Ajc.data(), Air.data(), mxGetPr(A),
-                                 Ajc1.data(), mxGetPr(prhs[4]), &ck.K, psd.data(), mxGetPr(out1)));
+  sdm_check(sdm_mexcache_getada3(m, tin == 0.0 ? jc.data() : NULL, tin == 0.0 ? ir.data() : NULL, tin == 0.0 ? mxGetPr(ADA) : NULL, lazy_out ? NULL : mxGetPr(out0),
+                                 (sdm_int)mxGetM(A), Ajc.data(), Air.data(), mxGetPr(A), Ajc1.data(), mxGetPr(prhs[4]), &ck.K, psd.data(), mxGetPr(out1),
+                                 tin, lazy_out ? &tout : NULL));
+  if (lazy_out) out0 = make_token(m, tout);
   plhs[0] = out0;
   if (nlhs > 1) plhs[1] = out1; else mxDestroyArray(out1);           // getada3.c:565-568
 }

@@ -55,6 +55,41 @@ inline mxArray *sparse_like(const mxArray *src) {
   return a;
 }
 
+// ---- lazy intermediates (sdm_mexcache.hip, SEDUMI_HIP_LAZY): the token of an ADA' whose values stayed on the device is an m x m
+// sparse matrix with the single nonzero (1,1) = token; 0 if `a` is not one
+inline double lazy_token_of(const mxArray *a) {
+  if (!mxIsSparse(a) || mxGetM(a) < 2 || mxGetJc(a)[mxGetN(a)] != 1 || mxGetJc(a)[1] != 1 || mxGetIr(a)[0] != 0) return 0.0;
+  const double t = mxGetPr(a)[0], b = sdm_mexcache_token_base();
+  return (t > b && t < b + 4294967296.0) ? t : 0.0;
+}
+inline mxArray *make_token(mwSize m, double tok) {
+  mxArray *a = mxCreateSparse(m, m, 1, mxREAL);
+  mwIndex *jc = mxGetJc(a);
+  jc[0] = 0;
+  for (mwSize j = 1; j <= m; j++) jc[j] = 1;
+  mxGetIr(a)[0] = 0; mxGetPr(a)[0] = tok;
+  return a;
+}
+// the full-pattern ADA' array behind a token, values uninitialised (getada3.mex materialising at level 1)
+inline mxArray *sparse_of_token(double tok, sdm_int m) {
+  sdm_int nnz = 0;
+  sdm_check(sdm_mexcache_token_info(tok, m, &nnz));
+  const mwIndex cap = nnz > 0 ? (mwIndex)nnz : 1;
+  mxArray *a = mxCreateSparse(m, m, 1, mxREAL);
+  mwIndex *ir = (mwIndex *)mxMalloc(cap * sizeof(mwIndex));
+  double *pr = (double *)mxMalloc(cap * sizeof(double));
+  mxFree(mxGetIr(a)); mxFree(mxGetPr(a));
+  mxSetIr(a, ir); mxSetPr(a, pr); mxSetNzmax(a, cap);
+  if (sizeof(mwIndex) == sizeof(sdm_int)) sdm_check(sdm_mexcache_token_pattern(tok, m, (sdm_int *)mxGetJc(a), (sdm_int *)ir));
+  else {
+    ivec jc(m + 1), iv(cap);
+    sdm_check(sdm_mexcache_token_pattern(tok, m, jc.data(), iv.data()));
+    for (sdm_int j = 0; j <= m; j++) mxGetJc(a)[j] = (mwIndex)jc[j];
+    for (sdm_int k = 0; k < nnz; k++) ir[k] = (mwIndex)iv[k];
+  }
+  return a;
+}
+
 struct SymbL {                       // L.{L,perm,xsuper} as the numeric gateways read it (blkchol.c:266-286)
   sdm_int m, nsuper;
   IdxView jc, ir;

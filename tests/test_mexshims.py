@@ -333,3 +333,74 @@ def test_iteration_units_by_reference_reuse_the_device_state(glue, refmex, shimm
     assert s2["ada_upload"] == s1["ada_upload"] and s2["x_upload"] == s1["x_upload"], (s1, s2)
     assert s2["ada_resident"] - s1["ada_resident"] == 2 * (1 + nq) and s2["x_resident"] - s1["x_resident"] == 2
     assert s2["solve_resident"] - s1["solve_resident"] == 16 and s2["solve_stateless"] == s1["solve_stateless"]
+
+
+@pytest.mark.parametrize("level,lorentz", [(1, True), (1, False), (2, True), (2, False)])
+def test_lazy_intermediates_leave_ada_on_the_device(glue, refmex, shimmex, shimlib, level, lorentz):
+    """Opt-in (SEDUMI_HIP_LAZY / sdm_mexcache_set_lazy): getada1.mex / getada2.mex return a token instead of ADA' (level 2: getada3.mex too)
+    and the next gateway takes the device's values.  What sedumi.m uses is unchanged: level 1 -- ADA' and absd after getada3, L.L, L.d and
+    the solves are the reference's; level 2 -- absd, L.L, L.d and the solves.  No ADA' value crosses PCIe towards the device, and a token
+    that is not the current one is refused loudly.  (lorentz = False: getada2.mex has nothing to add and copies the token, getada2.c:153-155.)"""
+    import ctypes
+    from oracle import glue as gl
+    from oracle.refmex import RefMexError
+    from sedumi_amd import problem
+    from sedumi_amd.mexhost import iteration_units
+    lib = ctypes.CDLL(shimlib)
+    lib.sdm_mexcache_token_base.restype = ctypes.c_double
+    lib.sdm_mexcache_clear()
+    P = problem.random_sdp(m=28, seed=21) if lorentz else problem.random_sdp(m=28, lp=4, q=(), s=(6, 5), seed=22)
+    S = glue.setup(P.At, P.K)
+    d, ud = ref_scaling(P, 2)
+    it = glue.iteration_ref(S, d, ud)
+    pars = gl.default_pars_chol()
+    rhs = np.random.default_rng(0).standard_normal(P.m)
+    dstruct = {"l": np.asarray(d["l"]).reshape(-1, 1), "det": np.asarray(d["det"]).reshape(-1, 1)}
+    seen = []
+
+    def check(A3, absd, LL, Ld):
+        seen.append(A3)
+        if level == 1:
+            assert relerr(A3, it["ADA"]) < TOL
+        else:
+            A3 = sp.csc_matrix(A3)
+            assert A3.nnz == 1 and A3[0, 0] > lib.sdm_mexcache_token_base()        # a token, not ADA'
+        assert relerr(absd, it["absd"]) < TOL and relerr(LL, it["LL"]) < TOL and relerr(Ld, it["Ld"]) < TOL
+    try:
+        lib.sdm_mexcache_set_lazy(level)
+        s0 = mexcache_stats(shimlib)
+        _, y = iteration_units(shimmex, S["A"], S["Ablkjc"][:, 2], S["Aord"], P.K, dstruct, it["DAt"], ud, S["L"], S["ADA"], pars, rhs, 3, check=check)
+        s1 = mexcache_stats(shimlib)
+        L = dict(S["L"]); L["L"] = it["LL"]
+        yr = refmex.call("bwblkslv", 1, L, refmex.call("fwblkslv", 1, L, rhs.reshape(-1, 1)) / np.where(it["Ld"] > 0, it["Ld"], 1.0))
+        assert relerr(y, yr.ravel()) < TOL and len(seen) == 3
+        assert s1["ada_upload"] == s0["ada_upload"] and s1["x_upload"] - s0["x_upload"] == 0, (s0, s1)
+        # a token of an earlier call is not the current one: refused, not silently wrong
+        tok = shimmex.call("getada1", 1, S["ADA"], S["A"], S["Ablkjc"][:, 2], S["Aord"]["lqperm"], dstruct, P.K["qblkstart"])
+        assert sp.csc_matrix(tok).nnz == 1
+        shimmex.call("getada1", 1, S["ADA"], S["A"], S["Ablkjc"][:, 2], S["Aord"]["lqperm"], dstruct, P.K["qblkstart"])   # ... a newer one exists now
+        with pytest.raises(RefMexError, match="not the current one"):
+            shimmex.call("getada3", 2, tok, S["A"], S["Ablkjc"][:, 2], S["Aord"], ud.reshape(-1, 1), P.K)
+    finally:
+        lib.sdm_mexcache_set_lazy(0)
+        lib.sdm_mexcache_clear()
+
+
+def test_checksum_threads_give_the_value_of_one_thread(shimlib):
+    """sdm_mexcache_checksum: arrays from 128K words on are summed by a few helper threads that sleep in between (eight wrap-around sums:
+    any partition gives the same value); clearing the cache joins them, the next big array starts them again."""
+    import ctypes
+    lib = ctypes.CDLL(shimlib)
+    lib.sdm_mexcache_checksum.restype = ctypes.c_uint64
+    a = np.random.default_rng(3).standard_normal(300_001)
+    p = a.ctypes.data_as(ctypes.c_void_p)
+    vals = []
+    for nthreads in (1, 4, 3, -1):
+        lib.sdm_mexcache_set_threads(nthreads)
+        vals.append(lib.sdm_mexcache_checksum(p, ctypes.c_int64(a.size)))
+        lib.sdm_mexcache_clear()                                       # joins the helpers
+    lib.sdm_mexcache_set_threads(-1)
+    assert len(set(vals)) == 1
+    a[123_457] += 1e-12
+    assert lib.sdm_mexcache_checksum(p, ctypes.c_int64(a.size)) != vals[0]
+    lib.sdm_mexcache_clear()

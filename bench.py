@@ -570,6 +570,7 @@ def mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, units, y_resident=None, mex_dir
                                   "chol_reuse": int(st[5]), "x_upload": int(st[6]), "x_resident": int(st[7]), "solve_resident": int(st[8]),
                                   "solve_stateless": int(st[9])},
                "content_checks": {"host_words_checksummed_per_unit": float(st[11]) / len(times), "MB_per_unit": 8e-6 * float(st[11]) / len(times),
+                                  "ms_per_unit": 1e-6 * float(st[13]) / len(times), "checksums_per_unit": float(st[14]) / len(times),
                                   "rule": "residency is decided by a checksum of every word of the host array (sdm_mexcache.hip): arrays up to 65536 words at every "
                                           "presentation, larger ones once per address and epoch (= between two blkchol calls)"},
                **({"lazy_level": int(lazy), "lazy": "opt-in SEDUMI_HIP_LAZY=%d: getada1 / getada2%s return a token, ADA' stays on the device (sdm_mexcache.hip)" % (lazy, " / getada3" if lazy > 1 else "")} if lazy else {}),

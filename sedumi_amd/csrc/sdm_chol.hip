@@ -1243,7 +1243,7 @@ __device__ SDM_NI_TILES void panel_role_tiles(char *smem, double *Fs, const doub
 struct TileItem { int I, J, nch, kp0, ds0; };
 __device__ SDM_NI_TILES void panel_role_tiles_stream(char *smem, double *Fs, const double *d, int ns, int ms, int ld, int first, int panel, int w, int ntw) {
   SDM_FP_STRICT;
-  constexpr int NW = LDL_THREADS / 64, NQ = NB / NW;           // 8 wavefronts, 8 operand rows per work-item and array
+  constexpr int NW = LDL_THREADS / 64;                         // 8 wavefronts
   const int tid = threadIdx.x;
   double (*Ab)[UTP] = (double (*)[UTP])smem;                   // buffer u: As = Ab + u * 2 NB, Bs = As + NB   (4 NB UTP doubles = PANEL_LDS_RIDE)
   __shared__ double dshs[5][NB];                               // pivots: row 0 the panel before, rows 1 .. 4 the panels of the deferred group
@@ -1257,7 +1257,7 @@ __device__ SDM_NI_TILES void panel_role_tiles_stream(char *smem, double *Fs, con
   }
   const int wv = tid >> 6, l = tid & 63;
   const int wi = wv >> 2, cj = (wv & 3) * 16, lk = l >> 4, ll = l & 15;
-  const int i = tid & 63, kq = tid >> 6;
+  const int i2 = (tid & 31) * 2, kq = tid >> 5;                // operand staging: a work-item takes the row pair i2, i2 + 1 of the columns kq + 16 q
   auto locate = [&](int u, TileItem &t) {
     if (u < sc.NE) {                                           // band (1, JE): eager tiles of the panel before
       t.nch = 1; t.kp0 = (panel - 1) * NB; t.ds0 = 0;
@@ -1274,18 +1274,32 @@ __device__ SDM_NI_TILES void panel_role_tiles_stream(char *smem, double *Fs, con
       t.I += 8 - sc.r; t.J += 8 - sc.r;
     }
   };
-  double av[NQ], bv[NQ];
-  auto fetch_operands = [&](const TileItem &t, int kp) {       // 16 loads per work-item, issued together (rows clamped, masked when staged)
-    const double *pa = Fs + min(r0 + t.I * TILE + i, ms - 1), *pb = Fs + min(r0 + t.J * TILE + i, ms - 1);
+  // 16-byte loads and LDS writes (a compute unit gets ~10 bytes per clock out of its vector memory pipe, MI355X_MICROARCH.md, and fewer with
+  // 8-byte loads: measured here as 2.2 us to ISSUE the 16 eight-byte loads of a step, profiles/r05l_phase_tiles.txt): two rows per work-item
+  constexpr int NQ2 = NB / 16;
+  sdm_double2 av[NQ2], bv[NQ2];
+  const int rowcap = (ms - 1) & ~1;                            // (the row pair stays inside the column: ld is even)
+  auto fetch_operands = [&](const TileItem &t, int kp) {       // 8 loads per work-item, issued together (rows clamped, masked when staged)
+    const double *pa = Fs + min(r0 + t.I * TILE + i2, rowcap), *pb = Fs + min(r0 + t.J * TILE + i2, rowcap);
 #pragma unroll
-    for (int q = 0; q < NQ; q++) { const int64_t off = (int64_t)(kp + kq + NW * q) * ld; av[q] = pa[off]; bv[q] = pb[off]; }
+    for (int q = 0; q < NQ2; q++) {
+      const int64_t off = (int64_t)(kp + kq + 16 * q) * ld;
+      av[q] = *(const sdm_double2 *)(pa + off); bv[q] = *(const sdm_double2 *)(pb + off);
+    }
   };
   auto stage = [&](const TileItem &t, int ch, int u) {         // registers -> LDS buffer u, B scaled by the pivots
     double (*As)[UTP] = Ab + u * 2 * NB, (*Bs)[UTP] = As + NB;
-    const bool iok = r0 + t.I * TILE + i < ms, jok = r0 + t.J * TILE + i < ms;
+    const int ra = r0 + t.I * TILE + i2, rb = r0 + t.J * TILE + i2;
     const double *dsh = dshs[t.ds0 + ch];
 #pragma unroll
-    for (int q = 0; q < NQ; q++) { const int k = kq + NW * q; As[k][i] = iok ? av[q] : 0.0; Bs[k][i] = jok ? bv[q] * dsh[k] : 0.0; }
+    for (int q = 0; q < NQ2; q++) {
+      const int k = kq + 16 * q;
+      const double dk = dsh[k];
+      sdm_double2 x, y;
+      x.x = ra < ms ? av[q].x : 0.0; x.y = ra + 1 < ms ? av[q].y : 0.0;
+      y.x = rb < ms ? bv[q].x * dk : 0.0; y.y = rb + 1 < ms ? bv[q].y * dk : 0.0;
+      *(sdm_double2 *)&As[k][i2] = x; *(sdm_double2 *)&Bs[k][i2] = y;
+    }
   };
   // step = (tile, chunk); `it`/`ch` the step in the buffer, `nx`/`nch` the one in the registers
   int item = w, ch = 0, buf = 0;
@@ -1299,8 +1313,18 @@ __device__ SDM_NI_TILES void panel_role_tiles_stream(char *smem, double *Fs, con
   nx = it;
   if (nch == it.nch) { nitem = item + ntw; nch = 0; more = nitem < nitems; if (more) locate(nitem, nx); }
   if (more) fetch_operands(nx, nx.kp0 + nch * NB);
+  double c[2][4], cn[2][4], cs[2][4];                          // the tile's values, those of the next tile (on their way), those of the finished one
+  auto load_tile = [&](const TileItem &t, double (&v)[2][4]) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = r0 + t.I * TILE + wi * 32 + a * 16 + ll, gj = r0 + t.J * TILE + cj + lk + 4 * r;
+        v[a][r] = Fs[(int64_t)min(gj, ms - 1) * ld + min(gi, ms - 1)];
+      }
+  };
+  load_tile(it, c);
   __syncthreads();
-  double c[2][4], cs[2][4];
   int Is = 0, Js = 0;
   bool pend = false;                                           // cs = the finished values of tile (Is, Js), not stored yet
   auto store_tile = [&]() {
@@ -1312,50 +1336,71 @@ __device__ SDM_NI_TILES void panel_role_tiles_stream(char *smem, double *Fs, con
         if (gi < ms && gj < ms && gi >= gj) sdm_store_wt(&Fs[(int64_t)gj * ld + gi], cs[a][r]);
       }
   };
+  // Between two barriers every wavefront does two things that do not depend on each other: the 32 MFMAs of this step (from buffer `buf`), and
+  // everything else of the steps to come (the finished tile out, the next step's operands from the registers into the other buffer, the
+  // loads of the step after it, the next tile's own values).  Wavefronts 0 - 3 take them in this order, wavefronts 4 - 7 in the other one:
+  // each SIMD holds one wavefront of either kind, so its matrix pipe has MFMAs from one of them while the other one issues everything else
+  // -- in lock step (all eight the same order) the two halves took 2.0 + 2.2 us per step, profiles/r05_factor_update_variants.txt.
+  const bool mfma_first = wv >= NW / 2;
+#ifdef SDM_PHASES
+  long long tp_ = wall_clock64();
+  // (free slots of this file's phase array: work-item 0 -> 9 .. 12, work-item 256 -> 0, 24, 25, 27; 13 = steps; n = 5: not recorded)
+#define SDM_TP(n) do { const long long t_ = wall_clock64(); const int sl_[9] = {9, 10, 11, 12, -1, -1, 0, 24, 25}; \
+    if (threadIdx.x == 0 && sl_[(n)] >= 0) atomicAdd(&sdm_phase_acc[sl_[(n)]], (unsigned long long)(t_ - tp_)); tp_ = t_; } while (0)
+#else
+#define SDM_TP(n) do {} while (0)
+#endif
   for (;;) {
     double (*As)[UTP] = Ab + buf * 2 * NB, (*Bs)[UTP] = As + NB;
-    // the next step: its operands (in flight since the step before) into the other buffer
-    if (more) stage(nx, nch, buf ^ 1);
-    if (pend) { store_tile(); pend = false; }                 // the tile finished in the step before: its stores have this whole step to be acknowledged
-    if (ch == 0) {                                             // the tile's own values: arrive behind the MFMA loop
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int gi = r0 + it.I * TILE + wi * 32 + a * 16 + ll, gj = r0 + it.J * TILE + cj + lk + 4 * r;
-          c[a][r] = Fs[(int64_t)min(gj, ms - 1) * ld + min(gi, ms - 1)];
-        }
-    }
-    // ... and the loads of the step after the next
     TileItem n2 = nx;
     int n2item = nitem, n2ch = nch + 1;
     bool more2 = more;
-    if (more) {
-      if (n2ch == nx.nch) { n2item = nitem + ntw; n2ch = 0; more2 = n2item < nitems; if (more2) locate(n2item, n2); }
-      if (more2) fetch_operands(n2, n2.kp0 + n2ch * NB);
+    for (int half = 0; half < 2; half++) {
+      if ((half == 0) != mfma_first) {
+        // ---- everything else
+        SDM_TP(5);
+        if (pend) { store_tile(); pend = false; }
+        SDM_TP(6);
+        if (more) {
+          stage(nx, nch, buf ^ 1);                             // (in flight since the step before)
+          SDM_TP(0);
+          if (nch == 0) load_tile(nx, cn);
+          SDM_TP(7);
+          if (n2ch == nx.nch) { n2item = nitem + ntw; n2ch = 0; more2 = n2item < nitems; if (more2) locate(n2item, n2); }
+          SDM_TP(8);
+          if (more2) fetch_operands(n2, n2.kp0 + n2ch * NB);
+        }
+        SDM_TP(1);
+      } else {
+        // ---- the MFMAs of this step; the operands of k + 4 .. k + 7 are read from LDS before the MFMAs of k .. k + 3 are issued
+        SDM_TP(5);
+        sdm_double4 acc[2];
+        for (int a = 0; a < 2; a++) for (int r = 0; r < 4; r++) acc[a][r] = 0.0;
+        double bo = Bs[lk][cj + ll], ao[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) ao[a] = As[lk][wi * 32 + a * 16 + ll];
+#pragma unroll
+        for (int kk = 0; kk < NB; kk += 4) {
+          const int kn = min(kk + 4, NB - 4);
+          const double bn = Bs[kn + lk][cj + ll];
+          double an[2];
+#pragma unroll
+          for (int a = 0; a < 2; a++) an[a] = As[kn + lk][wi * 32 + a * 16 + ll];
+          SDM_COMPILER_BARRIER();                              // (keeps the reads above ahead of the MFMAs below: without it they are sunk to their use)
+#pragma unroll
+          for (int a = 0; a < 2; a++) acc[a] = SDM_MFMA_F64_16x16x4(bo, ao[a], acc[a]);
+          SDM_COMPILER_BARRIER();
+          bo = bn;
+#pragma unroll
+          for (int a = 0; a < 2; a++) ao[a] = an[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) c[a][r] = c[a][r] - acc[a][r];
+        SDM_TP(2);
+      }
     }
-    sdm_double4 acc[2];
-    for (int a = 0; a < 2; a++) for (int r = 0; r < 4; r++) acc[a][r] = 0.0;
-    double bo = Bs[lk][cj + ll], ao[2];
-#pragma unroll
-    for (int a = 0; a < 2; a++) ao[a] = As[lk][wi * 32 + a * 16 + ll];
-#pragma unroll
-    for (int kk = 0; kk < NB; kk += 4) {
-      const int kn = min(kk + 4, NB - 4);
-      const double bn = Bs[kn + lk][cj + ll];
-      double an[2];
-#pragma unroll
-      for (int a = 0; a < 2; a++) an[a] = As[kn + lk][wi * 32 + a * 16 + ll];
-#pragma unroll
-      for (int a = 0; a < 2; a++) acc[a] = SDM_MFMA_F64_16x16x4(bo, ao[a], acc[a]);
-      bo = bn;
-#pragma unroll
-      for (int a = 0; a < 2; a++) ao[a] = an[a];
-    }
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) c[a][r] = c[a][r] - acc[a][r];
     if (ch == it.nch - 1) {
 #pragma unroll
       for (int a = 0; a < 2; a++)
@@ -1364,8 +1409,19 @@ __device__ SDM_NI_TILES void panel_role_tiles_stream(char *smem, double *Fs, con
       Is = it.I; Js = it.J; pend = true;
     }
     if (!more) break;
+    SDM_TP(5);
     __syncthreads();                                           // the other buffer is complete, this one is free
+    SDM_TP(3);
+#ifdef SDM_PHASES
+    if (threadIdx.x == 0) atomicAdd(&sdm_phase_acc[13], 1ull);
+#endif
     it = nx; item = nitem; ch = nch; buf ^= 1;
+    if (ch == 0) {
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) c[a][r] = cn[a][r];
+    }
     nx = n2; nitem = n2item; nch = n2ch; more = more2;
   }
   if (pend) store_tile();

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -143,9 +144,11 @@ class SumPool {
 } g_pool;
 void pool_shutdown() { g_pool.shutdown(); }
 int g_threads = -1;        // sdm_mexcache_set_threads: threads of a big checksum (-1: 4 from POOL_FROM words, up to 8 from 1M; never more than the host has)
+sdm_int g_hash_ns = 0, g_hash_calls = 0;      // host time spent in complete checksums since the last clear (stats[13], [14])
 u64 hash_full(const void *pv, sdm_int n) {
   const u64 *v = (const u64 *)pv;
   u64 acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const auto t0 = std::chrono::steady_clock::now();
   int nt = 1;
   if (n >= POOL_FROM) {
     const int hw = (int)std::thread::hardware_concurrency();
@@ -154,6 +157,7 @@ u64 hash_full(const void *pv, sdm_int n) {
   }
   if (nt <= 1) sums(v, 0, n, acc);
   else g_pool.run(v, n, nt, acc);
+  g_hash_ns += (sdm_int)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); g_hash_calls++;
   return fold_sums(acc, n);
 }
 // the same eight sums of n words in device memory, added into acc8 (zeroed by the caller): work-item t owns the words
@@ -357,7 +361,7 @@ void drop_all() {
   g_pool.shutdown();
   g_ck.release();
   for (auto &p : g_pat) p = Pattern();
-  g_fullsum_words = 0;
+  g_fullsum_words = 0; g_hash_ns = 0; g_hash_calls = 0;
 }
 void at_exit_once() {
   // the cached plans own streams, events and device memory: they go before the HIP runtime's own exit handlers run (registered
@@ -401,7 +405,7 @@ unsigned long long sdm_mexcache_checksum(const void *words, sdm_int n) { return 
 // IN PLACE between gateway calls of one iteration (sedumi.m never does); costs a pass over the host array per call
 void sdm_mexcache_set_strict(int on) { strict = on != 0; }
 void sdm_mexcache_stats(sdm_int *out, sdm_int n) {
-  g_stat[11] = g_fullsum_words; g_stat[12] = (sdm_int)g_epoch;
+  g_stat[11] = g_fullsum_words; g_stat[12] = (sdm_int)g_epoch; g_stat[13] = g_hash_ns; g_stat[14] = g_hash_calls;
   for (sdm_int i = 0; i < n && i < 16; i++) out[i] = g_stat[i];
 }
 // arrays of up to `words` words are checksummed completely at every presentation (default 65 536); larger ones once per address and epoch

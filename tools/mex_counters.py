@@ -31,12 +31,12 @@ Aord["sperm"] = np.asarray(sperm, dtype=np.float64).reshape(-1, 1)
 dstruct = {"l": np.asarray(d["l"], dtype=np.float64).reshape(-1, 1), "det": np.asarray(d["det"], dtype=np.float64).reshape(-1, 1)}
 lib.sdm_mexcache_clear()
 host = mexhost.MexHost(None)
-names = ["ada_build", "ada_reuse", "ada_upload", "ada_resident", "chol_build", "chol_reuse", "x_upload", "x_resident", "solve_resident", "solve_stateless", "at_upload", "host_words_checksummed", "epoch"]
+names = ["ada_build", "ada_reuse", "ada_upload", "ada_resident", "chol_build", "chol_reuse", "x_upload", "x_resident", "solve_resident", "solve_stateless", "at_upload", "host_words_checksummed", "epoch", "checksum_ns", "checksum_calls"]
 
 
 def after_unit(*_):
     lib.sdm_mexcache_stats(st, ctypes.c_int64(16))
-    print(json.dumps(dict(zip(names, list(st)[:13]))), flush=True)
+    print(json.dumps(dict(zip(names, list(st)[:15]))), flush=True)
 
 
 times, y = mexhost.iteration_units(host, At, np.asarray(P.Ablkjc)[:, 2], Aord, K, dstruct, {"q": Qm}, ud, L, ADA, bench.PARS, rhs, units, 4, check=after_unit)

@@ -37,52 +37,63 @@ struct FollowArgs { double *S, *STr; unsigned long long *sb_g; int nfront; };
 #endif
 // ============================================================ schedule of the trailing updates of a big front (host + device)
 // Panel p's rank-64 update of the trailing matrix, applied in the launch after it (the "eager" schedule), is a read-modify-write of every
-// trailing tile per panel: 8 flops per byte of tile traffic, HBM-bound (MAXCUT-4000: 121 MB per launch at 2.4 TB/s = 50 us against a chain of
-// 26 us).  The panels are therefore taken four at a time (a GROUP g = panels 4g .. 4g+3):
-//   * tile columns up to 4g+7 (those factored before the group's deferred update can have reached them) get every panel of the group eagerly, as
-//     before: K = 64 in the launch after the panel;
-//   * tile columns from 4g+8 on get the whole group in ONE read-modify-write with K = 256 once its last panel is final: columns 4g+8 .. 4g+11
-//     (the next group's eager window) in launch 4g+4, the rest dealt over the launches 4g+4 .. 4g+7 (10 % / 30 % / 30 % / 30 %: the first one
-//     carries those four columns as well).
+// trailing tile per panel.  The panels are therefore taken UPD_G at a time (a GROUP g = panels G g .. G g + G - 1):
+//   * tile columns up to G g + 2 G - 1 (those factored before the group's deferred update can have reached them) get every panel of the
+//     group eagerly, as before: K = 64 in the launch after the panel;
+//   * tile columns from G g + 2 G on get the whole group in ONE read-modify-write with K = 64 G once its last panel is final: columns
+//     G g + 2 G .. G g + 3 G - 1 (the next group's eager window) in launch G g + G, the rest dealt over the launches G g + G .. G g + 2 G - 1.
 // Every tile still receives the panels in ascending order, each as  c <- c - (product over the panel's 64 columns, accumulated from zero):
 // the same operations in the same order as the eager schedule, i.e. the SAME BITS; only the trips of c through memory are saved.
-// A group is deferred only if all its launches exist and have row-solve workgroups (NP >= 4g+8 panels, T >= 4g+12 tile rows).
+// A group is deferred only if all its launches exist and have row-solve workgroups (NP >= G g + 2 G panels, T >= G g + 2 G + 4 tile rows).
+// The unit of work is a MACRO TILE of 2 x 2 tiles (128 x 128; panel_role_tiles_stream says why): a region = the tiles (I, J) with
+// J0 <= J < J0 + JW, J <= I < nt, cut into macro tiles from (J0, J0) on; tiles of a macro tile outside the region are masked.
+constexpr int UPD_G = 2;
 __host__ __device__ inline bool upd_group_deferred(int ns, int ms, int g) {
-  return g >= 0 && (ns + NB - 1) / NB >= 4 * g + 8 && (ms + TILE - 1) / TILE >= 4 * g + 12;
+  return g >= 0 && (ns + NB - 1) / NB >= UPD_G * g + 2 * UPD_G && (ms + TILE - 1) / TILE >= UPD_G * g + 2 * UPD_G + 4;
 }
-// tiles (I, J) with J0 <= J < J0 + JW and J <= I < nt
-__host__ __device__ inline int band_count(int nt, int J0, int JW) {
-  const int n = nt - J0;
-  if (n <= 0 || JW <= 0) return 0;
-  if (JW > n) JW = n;
-  return JW * (JW + 1) / 2 + (n - JW) * JW;
+// macro tiles of the region (nt, J0, JW): macro columns MJ < MC, macro rows MJ <= MI < MR
+__host__ __device__ inline int macro_count(int nt, int J0, int JW) {
+  const int R = nt - J0;
+  if (R <= 0 || JW <= 0) return 0;
+  const int C = JW < R ? JW : R, MC = (C + 1) / 2, MR = (R + 1) / 2;
+  return MC * MR - MC * (MC - 1) / 2;
 }
-// of N tiles, those dealt to launch r (0 .. 3) of the four: t % 10 == 0 | {1,4,7} | {2,5,8} | {3,6,9}
+__host__ __device__ inline void macro_index(int t, int nt, int J0, int JW, int &MI, int &MJ) {   // column by column
+  const int R = nt - J0, C = JW < R ? JW : R, MC = (C + 1) / 2, MR = (R + 1) / 2;
+  MJ = 0;
+  while (MJ + 1 < MC && t >= MR - MJ) { t -= MR - MJ; MJ++; }
+  MI = MJ + t;
+}
+// of N items, those dealt to launch r of the group's UPD_G launches: t % 10 in [cut[r], cut[r+1])  (the first launch carries the
+// group's first columns as well and gets less)
+__host__ __device__ inline void share_range(int r, int &lo, int &hi) {
+  lo = r == 0 ? 0 : 3 + (r - 1) * 7 / (UPD_G - 1 > 0 ? UPD_G - 1 : 1);
+  hi = r == UPD_G - 1 ? 10 : 3 + r * 7 / (UPD_G - 1 > 0 ? UPD_G - 1 : 1);
+  if (UPD_G == 1) { lo = 0; hi = 10; }
+}
 __host__ __device__ inline int share_count(int N, int r) {
-  if (r == 0) return (N + 9) / 10;
-  int c = 3 * (N / 10);
-  const int rem = N % 10;
-  for (int x = r; x <= r + 6; x += 3) if (x < rem) c++;
-  return c;
+  int lo, hi; share_range(r, lo, hi);
+  const int rem = N % 10 - lo;
+  return (N / 10) * (hi - lo) + (rem < 0 ? 0 : (rem > hi - lo ? hi - lo : rem));
 }
-__host__ __device__ inline int share_tile(int k, int r) { return r == 0 ? 10 * k : 10 * (k / 3) + r + 3 * (k % 3); }
-// what the tile workgroups of launch q (the launch that factors panel q) of a front do: NE eager tiles of panel q-1 in the columns
-// 1 .. JE (relative to tile column q; column 0 is the row-solve workgroups'), NH + NR deferred tiles of group g2 (in its first launch the
-// four columns 4 .. 7, and this launch's share of the triangle of the columns beyond them -- tile column 4 g2 + 12 of the front = column
-// 8 - r relative to this launch; `all`: the whole triangle at once, when the next group is not deferred and its eager updates would
+__host__ __device__ inline int share_item(int k, int r) { int lo, hi; share_range(r, lo, hi); return 10 * (k / (hi - lo)) + lo + k % (hi - lo); }
+// what the tile workgroups of launch q (the launch that factors panel q) of a front do, in macro tiles: NE of the eager region (panel q-1
+// into the columns 1 .. JE relative to tile column q; column 0 is the row-solve workgroups'), NH + NR of the deferred group g2 (in its
+// first launch the columns G .. 2G-1, and this launch's share of the triangle beyond them -- tile column G g2 + 3 G of the front = column
+// 2 G - r relative to this launch; `all`: the whole triangle at once, when the next group is not deferred and its eager updates would
 // otherwise meet these tiles in the launches to come)
 struct TileSched { int nt, JE, NE, NH, NR, g2, r, all; };
 __host__ __device__ inline TileSched tile_sched(int ns, int ms, int q) {
   TileSched S;
   S.nt = (ms - q * NB + TILE - 1) / TILE;
-  const int g = (q - 1) / 4;
-  S.JE = upd_group_deferred(ns, ms, g) ? min(4 * g + 7 - q, S.nt - 1) : S.nt - 1;
-  S.NE = band_count(S.nt, 1, S.JE);
-  S.g2 = q >= 4 ? q / 4 - 1 : -1; S.r = q % 4; S.NH = 0; S.NR = 0; S.all = 0;
+  const int g = (q - 1) / UPD_G;
+  S.JE = upd_group_deferred(ns, ms, g) ? min(UPD_G * g + 2 * UPD_G - 1 - q, S.nt - 1) : S.nt - 1;
+  S.NE = macro_count(S.nt, 1, S.JE);
+  S.g2 = q >= UPD_G ? q / UPD_G - 1 : -1; S.r = q % UPD_G; S.NH = 0; S.NR = 0; S.all = 0;
   if (upd_group_deferred(ns, ms, S.g2)) {
-    const int n = S.nt + S.r - 8, N = n > 0 ? n * (n + 1) / 2 : 0;      // (the same triangle in all four launches: T - (4 g2 + 12) tile rows)
+    const int J0 = 2 * UPD_G - S.r, N = macro_count(S.nt, J0, S.nt);   // (the same triangle in all the group's launches: from tile column G g2 + 3 G)
     S.all = upd_group_deferred(ns, ms, S.g2 + 1) ? 0 : 1;
-    if (S.r == 0) S.NH = band_count(S.nt, 4, 4);
+    if (S.r == 0) S.NH = macro_count(S.nt, UPD_G, UPD_G);
     S.NR = S.all ? (S.r == 0 ? N : 0) : share_count(N, S.r);
   } else S.g2 = -1;
   return S;
@@ -1223,208 +1234,198 @@ __device__ SDM_NI_TILES void panel_role_tiles(char *smem, double *Fs, const doub
   SDM_ENDPGM();
 }
 // ---- the same for big fronts (those with row-solve workgroups: nobody in the launch reads these tiles): workgroup w of ntw works
-// through the tiles w, w + ntw, ... of the launch's schedule (tile_sched: eager tiles of the panel before, K = 64; deferred tiles of a
-// whole group of four panels, K = 256 in four steps of 64) as ONE PIPELINE over the steps:
-//   * all 8 wavefronts share one 64 x 64 tile (32 x 16 each, two MFMA accumulators);
-//   * the operands of a step sit in one of TWO LDS buffers; while the matrix cores work on it, the operands of the next step -- already in
-//     registers, fetched a whole step earlier -- are written to the other buffer and the loads of the step after that are issued: one
-//     barrier per step, no memory round trip in front of an MFMA loop;
-//   * a tile's own values make ONE trip through the registers per tile, not one per panel, and a finished tile is stored one step
-//     later (the counter of outstanding memory operations is one for loads and stores: stores issued right behind their MFMA loop sit in
-//     front of the next wait for operands).
-// Per tile: the same operands, the same instructions on the same accumulator layout, the same order as the eager schedule -- the same bits.
-// What this is worth and what it is not (MAXCUT-4000, profiles/r05_factor_update_variants.txt): the 63 panel launches 1.99 ms against 2.04
-// (round 4: one pair of tiles per workgroup and launch, K = 64 only) with the tiles' read-modify-write traffic cut to a quarter; a step
-// costs 4.2 us of which 2.0 are its 64 MFMAs per SIMD -- the other half is the wavefronts' own instruction issue for the next step
-// (addresses, 16 loads, masks, 16 LDS writes, the tile's values), which the lock step of a barrier per step puts in front of the MFMAs
-// instead of beside them.  Two streams per workgroup half a step out of phase (one wavefront per SIMD in the MFMA loop, the other one
-// preparing) were built and measured at 4.9 us per half step: a single wavefront per SIMD exposes the LDS latency of every operand
-// read in the MFMA loop.  The launches from the 22nd on are bound by the chain of the diagonal blocks (26 us) either way.
-struct TileItem { int I, J, nch, kp0, ds0; };
+// through the MACRO tiles w, w + ntw, ... of the launch's schedule (tile_sched: eager macro tiles of the panel before, K = 64; deferred
+// ones of a whole group of panels, K = 64 UPD_G) as one pipeline over steps of half a chunk (32 columns).
+// What shaped it, each step measured on MAXCUT-4000 (profiles/r05_factor_update_variants.txt, r05l / r05m / r05s_phase_tiles_*, r05r_ubench9_*):
+//   * one pair of 64 x 64 tiles per workgroup and launch (round 4, panel_role_tiles): ~10 us per pair -- dispatch, a memory round trip,
+//     staging, 3.4 us of MFMAs, acknowledged write-through stores, one after the other with nothing else on the compute unit;
+//   * the same tiles streamed through persistent workgroups with prefetched operands, one or two LDS buffers, lock step or the wavefront
+//     halves out of phase, 8- or 16-byte loads: 4.2 us per tile step whatever the arrangement -- a step fetches 64 KB of operands, and what
+//     the workgroups get delivered together is ~3 TB/s (16 GB/s each), not what the matrix cores could take (2.0 us per step);
+//   * hence 2 x 2 MACRO tiles: the operand blocks A(I), A(I+1), B(J), B(J+1) of a chunk are fetched once (all four in LDS: the launch's
+//     whole LDS footprint) for FOUR tile products -- half the bytes per flop -- and the macro tile is ONE 128 x 128 product, 64 x 32 per
+//     wavefront (8 accumulators, 6 operand reads from LDS per 8 MFMAs: the loop runs at the matrix rate, 3.97 us per half chunk against
+//     3.95 for the loop alone, tools/ubench/ubench9; as four 64 x 64 products of 32 x 16 per wavefront it ran at 55 %);
+//   * steps of HALF a chunk: the 32 prefetch registers more of a whole chunk spilled, and the reloads' s_waitcnt vmcnt(0) in front of
+//     the MFMA loop waited for the prefetch itself (16 us per chunk instead of 8); with half chunks the LDS blocks double-buffer in place
+//     (MFMAs on one half of their columns while the other half is written) and a step needs one barrier;
+//   * a macro tile's own values first, operand loads behind them (the counter of outstanding loads retires in order), plain stores for the
+//     finished tile (32 write-through stores took 8 us to issue; nobody reads these tiles before the launch ends);
+//   * groups of UPD_G = 2 panels: a deferred macro tile of four panels is 32 us of MFMAs on one compute unit -- more than the 26 us of the
+//     chain the tiles are meant to hide behind.
+// What is left: a step is 4.0 us of MFMAs + 5.6 us of everything else (waiting for operands and tile values -- a macro tile moves 512 KB for
+// its 15.8 us of MFMAs, the workgroups together ask for 3 TB/s --, LDS writes, stores, barrier) that the lock step of a barrier per step
+// puts in front of the MFMAs instead of beside them.  The launches from the 15th on are bound by the chain of the diagonal blocks.
+// A tile's own values make one trip through the registers per macro tile and group.  Per tile: the same operands, the same instructions on
+// the same accumulators, the same order as the eager schedule -- the same bits.
+struct TileItem { int I, J, nch, kp0, ds0, act; };               // first tile of the macro tile (relative to tile column q); act: bit 2a+b = tile (I+a, J+b) is the item's
 __device__ SDM_NI_TILES void panel_role_tiles_stream(char *smem, double *Fs, const double *d, int ns, int ms, int ld, int first, int panel, int w, int ntw) {
   SDM_FP_STRICT;
-  constexpr int NW = LDL_THREADS / 64;                         // 8 wavefronts
   const int tid = threadIdx.x;
-  double (*Ab)[UTP] = (double (*)[UTP])smem;                   // buffer u: As = Ab + u * 2 NB, Bs = As + NB   (4 NB UTP doubles = PANEL_LDS_RIDE)
-  __shared__ double dshs[5][NB];                               // pivots: row 0 the panel before, rows 1 .. 4 the panels of the deferred group
+  double (*Ab)[UTP] = (double (*)[UTP])smem;                   // A(I) = Ab, A(I+1) = Ab + NB, B(J) = Ab + 2 NB, B(J+1) = Ab + 3 NB   (4 NB UTP doubles = PANEL_LDS_RIDE)
+  __shared__ double dshs[1 + UPD_G][NB];                       // pivots: row 0 the panel before, rows 1 .. G the panels of the deferred group
   const TileSched sc = tile_sched(ns, ms, panel);
   const int nitems = tile_sched_items(sc);
   if (w >= nitems) SDM_ENDPGM();
   const int r0 = panel * NB;
-  for (int e = tid; e < 5 * NB; e += LDL_THREADS) {
+  for (int e = tid; e < (1 + UPD_G) * NB; e += LDL_THREADS) {
     const int row = e / NB, k = e % NB;
-    dshs[row][k] = row == 0 ? d[first + (panel - 1) * NB + k] : (sc.g2 >= 0 ? d[first + (4 * sc.g2 + row - 1) * NB + k] : 0.0);
+    dshs[row][k] = row == 0 ? d[first + (panel - 1) * NB + k] : (sc.g2 >= 0 ? d[first + (UPD_G * sc.g2 + row - 1) * NB + k] : 0.0);
   }
+  // the macro tile as ONE 128 x 128 product: wavefront wv owns the block of 64 rows x 32 columns (4 x 2 MFMA accumulators: 6 operand reads
+  // from LDS per 8 MFMAs; as four 64 x 64 products of 32 x 16 per wavefront it was 3 reads per 2 MFMAs and the LDS kept the matrix pipes at
+  // 55 %: 3.6 us per product against 2.0) -- inside tile (qa, qb) of the macro tile
   const int wv = tid >> 6, l = tid & 63;
-  const int wi = wv >> 2, cj = (wv & 3) * 16, lk = l >> 4, ll = l & 15;
+  const int qa = wv >> 2, qb = (wv & 3) >> 1, cj = (wv & 1) * 32, lk = l >> 4, ll = l & 15;
   const int i2 = (tid & 31) * 2, kq = tid >> 5;                // operand staging: a work-item takes the row pair i2, i2 + 1 of the columns kq + 16 q
   auto locate = [&](int u, TileItem &t) {
-    if (u < sc.NE) {                                           // band (1, JE): eager tiles of the panel before
-      t.nch = 1; t.kp0 = (panel - 1) * NB; t.ds0 = 0;
-      const int JW = min(sc.JE, sc.nt - 1), tri = JW * (JW + 1) / 2;
-      if (u < tri) { tile_index(u, t.I, t.J); t.I += 1; t.J += 1; } else { t.I = 1 + JW + (u - tri) / JW; t.J = 1 + (u - tri) % JW; }
-    } else if (u < sc.NE + sc.NH) {                            // band (4, 4): the deferred group's first four columns
-      const int x = u - sc.NE, JW = min(4, sc.nt - 4), tri = JW * (JW + 1) / 2;
-      t.nch = 4; t.kp0 = 4 * sc.g2 * NB; t.ds0 = 1;
-      if (x < tri) { tile_index(x, t.I, t.J); t.I += 4; t.J += 4; } else { t.I = 4 + JW + (x - tri) / JW; t.J = 4 + (x - tri) % JW; }
-    } else {                                                   // this launch's share of the triangle from tile column 4 g2 + 12 on
-      const int x = u - sc.NE - sc.NH;
-      t.nch = 4; t.kp0 = 4 * sc.g2 * NB; t.ds0 = 1;
-      tile_index(sc.all ? x : share_tile(x, sc.r), t.I, t.J);
-      t.I += 8 - sc.r; t.J += 8 - sc.r;
+    int J0, JW, x = u;
+    if (u < sc.NE) { J0 = 1; JW = sc.JE; t.nch = 1; t.kp0 = (panel - 1) * NB; t.ds0 = 0; }                         // eager: the panel before
+    else {
+      t.nch = UPD_G; t.kp0 = UPD_G * sc.g2 * NB; t.ds0 = 1;
+      if (u < sc.NE + sc.NH) { x = u - sc.NE; J0 = UPD_G; JW = UPD_G; }                                          // the deferred group's first columns
+      else { x = u - sc.NE - sc.NH; if (!sc.all) x = share_item(x, sc.r); J0 = 2 * UPD_G - sc.r; JW = sc.nt; }  // this launch's share of the triangle beyond them
     }
+    int MI, MJ;
+    macro_index(x, sc.nt, J0, JW, MI, MJ);
+    t.I = J0 + 2 * MI; t.J = J0 + 2 * MJ;
+    const int Jend = min(J0 + JW, sc.nt);
+    t.act = 0;
+    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (t.I + a < sc.nt && t.J + b < Jend && t.I + a >= t.J + b) t.act |= 1 << (2 * a + b);
   };
-  // 16-byte loads and LDS writes (a compute unit gets ~10 bytes per clock out of its vector memory pipe, MI355X_MICROARCH.md, and fewer with
-  // 8-byte loads: measured here as 2.2 us to ISSUE the 16 eight-byte loads of a step, profiles/r05l_phase_tiles.txt): two rows per work-item
-  constexpr int NQ2 = NB / 16;
-  sdm_double2 av[NQ2], bv[NQ2];
+  // A step covers HALF a chunk: 32 columns of the four operand blocks (64 KB: 8 sixteen-byte loads per work-item, two rows each).  The LDS
+  // blocks hold a whole chunk; while the MFMAs read one half of them, the next step's operands go from the registers into the other
+  // half -- one barrier per step -- and the loads of the step after that are issued.  (With whole chunks per step the 32 prefetch registers
+  // more spilled, and the reloads' s_waitcnt vmcnt(0) in front of the MFMA loop waited for the prefetch itself: 16 us per chunk, not 8.)
+  sdm_double2 ov[4][2];
   const int rowcap = (ms - 1) & ~1;                            // (the row pair stays inside the column: ld is even)
-  auto fetch_operands = [&](const TileItem &t, int kp) {       // 8 loads per work-item, issued together (rows clamped, masked when staged)
-    const double *pa = Fs + min(r0 + t.I * TILE + i2, rowcap), *pb = Fs + min(r0 + t.J * TILE + i2, rowcap);
+  auto fetch_operands = [&](const TileItem &t, int kp, int h) {
 #pragma unroll
-    for (int q = 0; q < NQ2; q++) {
-      const int64_t off = (int64_t)(kp + kq + 16 * q) * ld;
-      av[q] = *(const sdm_double2 *)(pa + off); bv[q] = *(const sdm_double2 *)(pb + off);
+    for (int blk = 0; blk < 4; blk++) {
+      const int tr = (blk < 2 ? t.I : t.J) + (blk & 1);
+      const double *pp = Fs + min(r0 + tr * TILE + i2, rowcap);
+#pragma unroll
+      for (int q = 0; q < 2; q++) ov[blk][q] = *(const sdm_double2 *)(pp + (int64_t)(kp + 32 * h + kq + 16 * q) * ld);
     }
   };
-  auto stage = [&](const TileItem &t, int ch, int u) {         // registers -> LDS buffer u, B scaled by the pivots
-    double (*As)[UTP] = Ab + u * 2 * NB, (*Bs)[UTP] = As + NB;
-    const int ra = r0 + t.I * TILE + i2, rb = r0 + t.J * TILE + i2;
+  auto stage = [&](const TileItem &t, int ch, int h) {         // registers -> LDS, B scaled by the pivots
     const double *dsh = dshs[t.ds0 + ch];
 #pragma unroll
-    for (int q = 0; q < NQ2; q++) {
-      const int k = kq + 16 * q;
-      const double dk = dsh[k];
-      sdm_double2 x, y;
-      x.x = ra < ms ? av[q].x : 0.0; x.y = ra + 1 < ms ? av[q].y : 0.0;
-      y.x = rb < ms ? bv[q].x * dk : 0.0; y.y = rb + 1 < ms ? bv[q].y * dk : 0.0;
-      *(sdm_double2 *)&As[k][i2] = x; *(sdm_double2 *)&Bs[k][i2] = y;
+    for (int blk = 0; blk < 4; blk++) {
+      const int row = r0 + ((blk < 2 ? t.I : t.J) + (blk & 1)) * TILE + i2;
+      double (*Xs)[UTP] = Ab + blk * NB;
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int k = 32 * h + kq + 16 * q;
+        const double dk = blk < 2 ? 1.0 : dsh[k];
+        sdm_double2 x;
+        x.x = row < ms ? ov[blk][q].x * dk : 0.0; x.y = row + 1 < ms ? ov[blk][q].y * dk : 0.0;
+        *(sdm_double2 *)&Xs[k][i2] = x;
+      }
     }
   };
-  // step = (tile, chunk); `it`/`ch` the step in the buffer, `nx`/`nch` the one in the registers
-  int item = w, ch = 0, buf = 0;
+  double c[4][2][4];                                           // this wavefront's 64 x 32 block: [16-row block][16-column block][register]
+  auto tile_rw = [&](const TileItem &t, bool store) {
+    if (t.act >> (2 * qa + qb) & 1) {                          // (uniform per wavefront)
+#pragma unroll
+      for (int ra = 0; ra < 4; ra++)
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int gi = r0 + (t.I + qa) * TILE + ra * 16 + ll, gj = r0 + (t.J + qb) * TILE + cj + cb * 16 + lk + 4 * r;
+            double *p = &Fs[(int64_t)min(gj, ms - 1) * ld + min(gi, ms - 1)];
+            if (!store) c[ra][cb][r] = *p;
+            else if (gi < ms && gj < ms && gi >= gj) *p = c[ra][cb][r];   // (plain stores: nobody reads these tiles before the launch ends; write-through ones took 8 us to issue)
+          }
+    }
+  };
+  // step = (macro tile, chunk of 64 columns, half of it); `it`/`ch`/`h` the step in LDS, `nx`/`nch`/`nh` the one in the registers
+  int item = w, ch = 0, h = 0;
   TileItem it, nx;
   locate(item, it);
-  fetch_operands(it, it.kp0);
+  fetch_operands(it, it.kp0, 0);
   __syncthreads();                                             // dshs
   stage(it, 0, 0);
-  int nitem = item, nch = 1;
+  int nitem = item, nch = 0, nh = 1;
   bool more = true;
   nx = it;
-  if (nch == it.nch) { nitem = item + ntw; nch = 0; more = nitem < nitems; if (more) locate(nitem, nx); }
-  if (more) fetch_operands(nx, nx.kp0 + nch * NB);
-  double c[2][4], cn[2][4], cs[2][4];                          // the tile's values, those of the next tile (on their way), those of the finished one
-  auto load_tile = [&](const TileItem &t, double (&v)[2][4]) {
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int gi = r0 + t.I * TILE + wi * 32 + a * 16 + ll, gj = r0 + t.J * TILE + cj + lk + 4 * r;
-        v[a][r] = Fs[(int64_t)min(gj, ms - 1) * ld + min(gi, ms - 1)];
-      }
-  };
-  load_tile(it, c);
+  fetch_operands(nx, nx.kp0, 1);
   __syncthreads();
-  int Is = 0, Js = 0;
-  bool pend = false;                                           // cs = the finished values of tile (Is, Js), not stored yet
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int gi = r0 + Is * TILE + wi * 32 + a * 16 + ll, gj = r0 + Js * TILE + cj + lk + 4 * r;
-        if (gi < ms && gj < ms && gi >= gj) sdm_store_wt(&Fs[(int64_t)gj * ld + gi], cs[a][r]);
-      }
-  };
-  // Between two barriers every wavefront does two things that do not depend on each other: the 32 MFMAs of this step (from buffer `buf`), and
-  // everything else of the steps to come (the finished tile out, the next step's operands from the registers into the other buffer, the
-  // loads of the step after it, the next tile's own values).  Wavefronts 0 - 3 take them in this order, wavefronts 4 - 7 in the other one:
-  // each SIMD holds one wavefront of either kind, so its matrix pipe has MFMAs from one of them while the other one issues everything else
-  // -- in lock step (all eight the same order) the two halves took 2.0 + 2.2 us per step, profiles/r05_factor_update_variants.txt.
-  const bool mfma_first = wv >= NW / 2;
 #ifdef SDM_PHASES
   long long tp_ = wall_clock64();
-  // (free slots of this file's phase array: work-item 0 -> 9 .. 12, work-item 256 -> 0, 24, 25, 27; 13 = steps; n = 5: not recorded)
-#define SDM_TP(n) do { const long long t_ = wall_clock64(); const int sl_[9] = {9, 10, 11, 12, -1, -1, 0, 24, 25}; \
-    if (threadIdx.x == 0 && sl_[(n)] >= 0) atomicAdd(&sdm_phase_acc[sl_[(n)]], (unsigned long long)(t_ - tp_)); tp_ = t_; } while (0)
+  // (free slots of this file's phase array: 9 product, 10 finished tile out, 11 barrier, 12 operands -> LDS (incl. the wait for them), 0 next tile + loads issued, 24 tile values; 13 = steps)
+#define SDM_TP(n) do { const long long t_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&sdm_phase_acc[(n)], (unsigned long long)(t_ - tp_)); tp_ = t_; } while (0)
 #else
 #define SDM_TP(n) do {} while (0)
 #endif
+  sdm_double4 acc[4][2];
   for (;;) {
-    double (*As)[UTP] = Ab + buf * 2 * NB, (*Bs)[UTP] = As + NB;
+    // (a new macro tile's own values first: the counter of outstanding loads retires in order, and  c -= acc  must not wait for operands behind them)
+    if (ch == 0 && h == 0) tile_rw(it, false);
+    SDM_TP(24);
+    // ---- the next step: its operands (in flight since the step before) into the other half of the blocks, then the loads of the step after it
     TileItem n2 = nx;
-    int n2item = nitem, n2ch = nch + 1;
+    int n2item = nitem, n2ch = nch, n2h = nh ^ 1;
     bool more2 = more;
-    for (int half = 0; half < 2; half++) {
-      if ((half == 0) != mfma_first) {
-        // ---- everything else
-        SDM_TP(5);
-        if (pend) { store_tile(); pend = false; }
-        SDM_TP(6);
-        if (more) {
-          stage(nx, nch, buf ^ 1);                             // (in flight since the step before)
-          SDM_TP(0);
-          if (nch == 0) load_tile(nx, cn);
-          SDM_TP(7);
-          if (n2ch == nx.nch) { n2item = nitem + ntw; n2ch = 0; more2 = n2item < nitems; if (more2) locate(n2item, n2); }
-          SDM_TP(8);
-          if (more2) fetch_operands(n2, n2.kp0 + n2ch * NB);
-        }
-        SDM_TP(1);
-      } else {
-        // ---- the MFMAs of this step; the operands of k + 4 .. k + 7 are read from LDS before the MFMAs of k .. k + 3 are issued
-        SDM_TP(5);
-        sdm_double4 acc[2];
-        for (int a = 0; a < 2; a++) for (int r = 0; r < 4; r++) acc[a][r] = 0.0;
-        double bo = Bs[lk][cj + ll], ao[2];
+    if (more) {
+      stage(nx, nch, nh);
+      SDM_TP(12);
+      if (n2h == 0) {                                          // (the step after the next starts a new chunk, or a new macro tile)
+        n2ch = nch + 1;
+        if (n2ch == nx.nch) { n2item = nitem + ntw; n2ch = 0; more2 = n2item < nitems; if (more2) locate(n2item, n2); }
+      }
+      if (more2) fetch_operands(n2, n2.kp0 + n2ch * NB, n2h);
+      SDM_TP(0);
+    }
+    // ---- the product of this step: this wavefront's block of tile (qa, qb) = A(I+qa) B(J+qb)', columns 32 h .. 32 h + 31 of the chunk
+    if (it.act >> (2 * qa + qb) & 1) {
+      double (*As)[UTP] = Ab + qa * NB, (*Bs)[UTP] = Ab + (2 + qb) * NB;
+      if (h == 0) for (int ra = 0; ra < 4; ra++) for (int cb = 0; cb < 2; cb++) for (int r = 0; r < 4; r++) acc[ra][cb][r] = 0.0;
+      const int k0 = 32 * h;
+      double ao[4], bo[2];
 #pragma unroll
-        for (int a = 0; a < 2; a++) ao[a] = As[lk][wi * 32 + a * 16 + ll];
+      for (int ra = 0; ra < 4; ra++) ao[ra] = As[k0 + lk][ra * 16 + ll];
 #pragma unroll
-        for (int kk = 0; kk < NB; kk += 4) {
-          const int kn = min(kk + 4, NB - 4);
-          const double bn = Bs[kn + lk][cj + ll];
-          double an[2];
+      for (int cb = 0; cb < 2; cb++) bo[cb] = Bs[k0 + lk][cj + cb * 16 + ll];
 #pragma unroll
-          for (int a = 0; a < 2; a++) an[a] = As[kn + lk][wi * 32 + a * 16 + ll];
-          SDM_COMPILER_BARRIER();                              // (keeps the reads above ahead of the MFMAs below: without it they are sunk to their use)
+      for (int kk = 0; kk < 32; kk += 4) {
+        const int kn = k0 + min(kk + 4, 28);
+        double an[4], bn[2];
 #pragma unroll
-          for (int a = 0; a < 2; a++) acc[a] = SDM_MFMA_F64_16x16x4(bo, ao[a], acc[a]);
-          SDM_COMPILER_BARRIER();
-          bo = bn;
+        for (int ra = 0; ra < 4; ra++) an[ra] = As[kn + lk][ra * 16 + ll];
 #pragma unroll
-          for (int a = 0; a < 2; a++) ao[a] = an[a];
-        }
+        for (int cb = 0; cb < 2; cb++) bn[cb] = Bs[kn + lk][cj + cb * 16 + ll];
 #pragma unroll
-        for (int a = 0; a < 2; a++)
+        for (int ra = 0; ra < 4; ra++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) c[a][r] = c[a][r] - acc[a][r];
-        SDM_TP(2);
+          for (int cb = 0; cb < 2; cb++) acc[ra][cb] = SDM_MFMA_F64_16x16x4(bo[cb], ao[ra], acc[ra][cb]);
+#pragma unroll
+        for (int ra = 0; ra < 4; ra++) ao[ra] = an[ra];
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) bo[cb] = bn[cb];
+      }
+      if (h == 1) {
+#pragma unroll
+        for (int ra = 0; ra < 4; ra++)
+#pragma unroll
+          for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) c[ra][cb][r] = c[ra][cb][r] - acc[ra][cb][r];
       }
     }
-    if (ch == it.nch - 1) {
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) cs[a][r] = c[a][r];
-      Is = it.I; Js = it.J; pend = true;
-    }
+    SDM_TP(9);
+    if (h == 1 && ch == it.nch - 1) tile_rw(it, true);         // the macro tile is finished
+    SDM_TP(10);
     if (!more) break;
-    SDM_TP(5);
-    __syncthreads();                                           // the other buffer is complete, this one is free
-    SDM_TP(3);
+    __syncthreads();                                           // the other half of the blocks is complete, this one is free
+    SDM_TP(11);
 #ifdef SDM_PHASES
     if (threadIdx.x == 0) atomicAdd(&sdm_phase_acc[13], 1ull);
 #endif
-    it = nx; item = nitem; ch = nch; buf ^= 1;
-    if (ch == 0) {
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) c[a][r] = cn[a][r];
-    }
-    nx = n2; nitem = n2item; nch = n2ch; more = more2;
+    it = nx; item = nitem; ch = nch; h = nh;
+    nx = n2; nitem = n2item; nch = n2ch; nh = n2h; more = more2;
   }
-  if (pend) store_tile();
   SDM_ENDPGM();
 }
 // ---- workgroup 0 = the dependency chain of the launch, as a CHAIN OF STAGES that never return: the role's prologue calls the update

@@ -10,7 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sedumi_amd import capi  # noqa: E402
-capi.use_library(os.path.join(ROOT, "sedumi_amd", "lib", "libsedumi_hip_phases.so"))
+capi.use_library(os.path.join(ROOT, "sedumi_amd", "lib", sys.argv[2] if len(sys.argv) > 2 else "libsedumi_hip_phases.so"))
 lib = capi.lib()
 import bench  # noqa: E402
 P, L, ADA, Q, d, ud, rhs0, qpr, note = bench.build_workload(sys.argv[1] if len(sys.argv) > 1 else "maxcut4000", 0)
@@ -24,6 +24,6 @@ lib.sdm_debug_phases_chol(buf, 0)
 v = np.array(list(buf), dtype=np.float64)
 n = max(v[13], 1.0)
 us = v / 100.0 / n
-print("work-item 0 (a wavefront that prepares first), %d steps, us per step: finished tile stored %.2f | wait for operands + LDS writes %.2f | next tile's values loaded %.2f | "
-      "next tile located %.2f | loads of the step after issued %.2f | MFMA loop + c update %.2f | barrier %.2f"
-      % (int(n), us[0], us[9], us[24], us[25], us[10], us[11], us[12]))
+print("work-item 0, %d steps (half a chunk of a macro tile each), us per step: new macro tile's values loaded %.2f | wait for the next step's operands + LDS writes %.2f | "
+      "next tile located + loads of the step after issued %.2f | product (64 MFMAs per wavefront) %.2f | finished macro tile stored %.2f | barrier %.2f | sum %.2f"
+      % (int(n), us[24], us[12], us[0], us[9], us[10], us[11], us[[24, 12, 0, 9, 10, 11]].sum()))

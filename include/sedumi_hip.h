@@ -448,7 +448,11 @@ int sdm_mexcache_token_info(double token, sdm_int m, sdm_int *nnz);
 int sdm_mexcache_token_pattern(double token, sdm_int m, sdm_int *jc_out, sdm_int *ir_out);
 double sdm_mexcache_token_base(void);
 void sdm_mexcache_set_threads(int n);   /* host threads of a checksum from 128K words on: -1 automatic (4; 8 from 1M words), 1 none */
-unsigned long long sdm_mexcache_checksum(const void *words, sdm_int n);   /* the content checksum of n 8-byte host words */
+unsigned long long sdm_mexcache_checksum(const void *words, sdm_int n);
+/* dst = src (n 8-byte words) and src's content checksum in one pass, noted for the sdm_mexcache_<gateway> call that follows (the shims copy
+ * the pattern of their input into the array they return: the cache then does not read the input's pattern a second time) */
+unsigned long long sdm_mexcache_copy_words(void *dst, const void *src, sdm_int n);
+void sdm_mexcache_forget_notes(void);   /* the shims call it first thing: notes of a gateway call that never reached the cache are dropped */   /* the content checksum of n 8-byte host words */
 /* The cached plan of the factorisation for callers that drive it themselves: sdm_mexcache_plan returns the plan of the
  * symbolic factor (L.{L pattern, perm, xsuper}) and ADA pattern given, creating it on a miss (NULL + sdm_last_error on
  * failure); sdm_mexcache_remember_factor records the L.L values a factorisation returned; sdm_mexcache_factor_plan gives

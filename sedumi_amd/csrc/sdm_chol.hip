@@ -99,6 +99,23 @@ __host__ __device__ inline TileSched tile_sched(int ns, int ms, int q) {
   return S;
 }
 __host__ __device__ inline int tile_sched_items(const TileSched &S) { return S.NE + S.NH + S.NR; }
+// item u of the launch's schedule: first tile (I, J) of its macro tile (relative to tile column q), which of its 2 x 2 tiles are the
+// item's (bit 2a+b: tile (I+a, J+b)), first panel and number of panels it applies
+__host__ __device__ inline void tile_sched_item(const TileSched &sc, int q, int u, int &I, int &J, int &act, int &p0, int &np) {
+  int J0, JW, x = u;
+  if (u < sc.NE) { J0 = 1; JW = sc.JE; np = 1; p0 = q - 1; }                                                  // eager: the panel before
+  else {
+    np = UPD_G; p0 = UPD_G * sc.g2;
+    if (u < sc.NE + sc.NH) { x = u - sc.NE; J0 = UPD_G; JW = UPD_G; }                                        // the deferred group's first columns
+    else { x = u - sc.NE - sc.NH; if (!sc.all) x = share_item(x, sc.r); J0 = 2 * UPD_G - sc.r; JW = sc.nt; }  // this launch's share of the triangle beyond them
+  }
+  int MI, MJ;
+  macro_index(x, sc.nt, J0, JW, MI, MJ);
+  I = J0 + 2 * MI; J = J0 + 2 * MJ;
+  const int Jend = min(J0 + JW, sc.nt);
+  act = 0;
+  for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (I + a < sc.nt && J + b < Jend && I + a >= J + b) act |= 1 << (2 * a + b);
+}
 
 // ============================================================ host analysis
 void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm,
@@ -1279,19 +1296,9 @@ __device__ SDM_NI_TILES void panel_role_tiles_stream(char *smem, double *Fs, con
   const int qa = wv >> 2, qb = (wv & 3) >> 1, cj = (wv & 1) * 32, lk = l >> 4, ll = l & 15;
   const int i2 = (tid & 31) * 2, kq = tid >> 5;                // operand staging: a work-item takes the row pair i2, i2 + 1 of the columns kq + 16 q
   auto locate = [&](int u, TileItem &t) {
-    int J0, JW, x = u;
-    if (u < sc.NE) { J0 = 1; JW = sc.JE; t.nch = 1; t.kp0 = (panel - 1) * NB; t.ds0 = 0; }                         // eager: the panel before
-    else {
-      t.nch = UPD_G; t.kp0 = UPD_G * sc.g2 * NB; t.ds0 = 1;
-      if (u < sc.NE + sc.NH) { x = u - sc.NE; J0 = UPD_G; JW = UPD_G; }                                          // the deferred group's first columns
-      else { x = u - sc.NE - sc.NH; if (!sc.all) x = share_item(x, sc.r); J0 = 2 * UPD_G - sc.r; JW = sc.nt; }  // this launch's share of the triangle beyond them
-    }
-    int MI, MJ;
-    macro_index(x, sc.nt, J0, JW, MI, MJ);
-    t.I = J0 + 2 * MI; t.J = J0 + 2 * MJ;
-    const int Jend = min(J0 + JW, sc.nt);
-    t.act = 0;
-    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (t.I + a < sc.nt && t.J + b < Jend && t.I + a >= t.J + b) t.act |= 1 << (2 * a + b);
+    int p0, np;
+    tile_sched_item(sc, panel, u, t.I, t.J, t.act, p0, np);
+    t.nch = np; t.kp0 = p0 * NB; t.ds0 = np == 1 ? 0 : 1;
   };
   // A step covers HALF a chunk: 32 columns of the four operand blocks (64 KB: 8 sixteen-byte loads per work-item, two rows each).  The LDS
   // blocks hold a whole chunk; while the MFMAs read one half of them, the next step's operands go from the registers into the other
@@ -2190,6 +2197,20 @@ void vec_divd(sdm_plan *P, double *v) {
 extern "C" int sdm_debug_trace_chol(long long *out2048) {
   return hipMemcpyFromSymbol(out2048, HIP_SYMBOL(sdm_trace_buf), 2048 * sizeof(long long)) != hipSuccess;
 }
+#endif
+// (tests) the update work of panel launch q of a front with ns columns and ms rows that has row-solve workgroups: per item five ints
+// {I, J, act, first panel, panels} (tile_sched_item; tile coordinates relative to tile column q); returns the number of items, -1 if the
+// launch has no row-solve workgroups (its tiles are the eager ones of panel_role_tiles: every tile of the trailing matrix but those of column 0)
+extern "C" int sdm_debug_tile_items(int ns, int ms, int q, int *out, int cap) {
+  using namespace sdm;
+  const int kb = std::min(NB, ns - q * NB), nrows = ms - (q * NB + kb);
+  if (nrows <= TRSM_ROWS) return -1;
+  const TileSched sc = tile_sched(ns, ms, q);
+  const int n = tile_sched_items(sc);
+  for (int u = 0; u < n && u < cap; u++) tile_sched_item(sc, q, u, out[5 * u], out[5 * u + 1], out[5 * u + 2], out[5 * u + 3], out[5 * u + 4]);
+  return n;
+}
+#if defined(SDM_PHASES) && !defined(SDM_EMU)
 extern "C" int sdm_debug_phases_chol(unsigned long long *out32, int reset) {
   if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(sdm_phase_acc), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
   if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sdm_phase_acc), z, sizeof(z)) != hipSuccess) return 1; }

@@ -182,6 +182,12 @@ u64 hash_sampled(const void *pv, sdm_int n) {                         // always 
   for (sdm_int i = 0; i < n; i += step) h = lane(h, v[i]);
   return lane(h, v[n - 1]);
 }
+// Checksums a shim has just computed itself while it copied an array (sdm_mexcache_copy_words: the pattern of the array it returns is a copy
+// of its input's -- one pass over the input for both): valid for the gateway call in progress only, dropped when it returns.
+struct Note { const void *p; sdm_int n; u64 sum; };
+Note g_notes[4];
+int g_nnotes = 0;
+void drop_notes() { g_nnotes = 0; }
 bool strict = false;            // sdm_mexcache_set_strict: no shortcut, every presentation is checksummed completely
 sdm_int full_below = 1 << 16;   // sdm_mexcache_set_full_below: arrays up to this many words are checksummed completely at every presentation
 u64 g_epoch = 1;                // advances with every blkchol call: the lifetime of a trusted address (file header)
@@ -219,8 +225,11 @@ struct Finger {
   bool same(const void *p, sdm_int len) {
     if (len != n || n < 0) return false;
     if (!strict && len > full_below && trusted(p)) return hash_sampled(p, len) == sample;   // the shortcut of the file header
-    g_fullsum_words += len;
-    if (hash_full(p, len) != full) return false;
+    u64 sum = 0;
+    bool noted = false;
+    for (int i = 0; i < g_nnotes; i++) if (g_notes[i].p == p && g_notes[i].n == len) { sum = g_notes[i].sum; noted = true; }
+    if (!noted) { g_fullsum_words += len; sum = hash_full(p, len); }
+    if (sum != full) return false;
     verified(p);
     return true;
   }
@@ -295,13 +304,17 @@ AdaSlot g_s1, g_s2, g_s3, g_s0;
 // whose ada_val holds the ADA values most recently handed back to the host, and what they were
 struct { sdm_plan *plan = nullptr; Finger vals; } g_last;
 DevBuf<u64> g_ck;                       // eight device words: checksum of values a gateway leaves in HBM (k_words_checksum)
+u64 *g_ck_host = nullptr;               // ... and where they land on the host: pinned, so that the copy is queued like the rest and the one
+                                        // synchronisation of the gateway (its download) covers it (to pageable memory every copy blocked the host)
 // the eight sums of n device words -> acc8 (host), queued on the plan's stream: valid once the stream has been drained
 void device_checksum(sdm_plan *p, const double *v, sdm_int n, u64 *acc8) {
   if (!g_ck.p) g_ck.alloc(8);
+  if (!g_ck_host) SDM_HIP_CHECK(hipHostMalloc((void **)&g_ck_host, 8 * sizeof(u64), 0));
+  (void)acc8;
   const sdm_int wg = std::min<sdm_int>(2048, std::max<sdm_int>(64, n / 8192));
   SDM_HIP_CHECK(hipMemsetAsync(g_ck.p, 0, 8 * sizeof(u64), p->stream));
   SDM_LAUNCH(k_words_checksum, dim3((unsigned)wg), dim3(256), 0, p->stream, (const unsigned long long *)v, (long long)n, g_ck.p);
-  SDM_HIP_CHECK(hipMemcpyAsync(acc8, g_ck.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, p->stream));
+  SDM_HIP_CHECK(hipMemcpyAsync(g_ck_host, g_ck.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, p->stream));
 }
 // ADA' values and absd of plan p -> the host arrays the shim returns, together with the checksum of the values summed on the device:
 // the array at pr is, from now on, known to hold what p->ada_val holds
@@ -309,7 +322,7 @@ void download_returned(sdm_plan *p, double *pr, double *absd, sdm_int nnz) {
   u64 acc[8];
   device_checksum(p, p->ada_val.p, nnz, acc);
   gw_download(p, pr, absd);                                           // (drains the stream)
-  g_last.plan = p; g_last.vals.take_with_full(pr, nnz, fold_sums(acc, nnz));
+  g_last.plan = p; g_last.vals.take_with_full(pr, nnz, fold_sums(g_ck_host, nnz));
 }
 // a gateway leaves its ADA' on the device and hands out a token for it (lazy mode)
 double returned_token(sdm_plan *p, u64 pat, sdm_int m, sdm_int nnz) {
@@ -360,6 +373,7 @@ void drop_all() {
   drop_chol();
   g_pool.shutdown();
   g_ck.release();
+  if (g_ck_host) { (void)hipHostFree(g_ck_host); g_ck_host = nullptr; }
   for (auto &p : g_pat) p = Pattern();
   g_fullsum_words = 0; g_hash_ns = 0; g_hash_calls = 0;
 }
@@ -390,15 +404,43 @@ sdm_plan *chol_plan(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm
 
 #define MC_TRY try { SDM_HIP_CHECK(hipSetDevice(device()));
 #define MC_CATCH                                                    \
+  drop_notes();                                                     \
   }                                                                 \
-  catch (const std::exception &e) { set_error(e.what()); return 1; } \
-  catch (...) { set_error("unknown error"); return 1; }             \
+  catch (const std::exception &e) { drop_notes(); set_error(e.what()); return 1; } \
+  catch (...) { drop_notes(); set_error("unknown error"); return 1; }             \
   return 0;
 }  // namespace
 
 extern "C" {
 
-void sdm_mexcache_clear(void) { drop_all(); }
+void sdm_mexcache_clear(void) { drop_all(); drop_notes(); }
+void sdm_mexcache_forget_notes(void) { drop_notes(); }
+// dst[0 .. n) = src[0 .. n) (8-byte words) and the content checksum of src in the same pass, noted for the gateway call that follows: the
+// cache then does not read src a second time to check it (a shim copies the pattern of its input into the array it returns anyway)
+unsigned long long sdm_mexcache_copy_words(void *dst, const void *src, sdm_int n) {
+  u64 sum;
+  if (n >= POOL_FROM) { memcpy(dst, src, (size_t)n * 8); sum = hash_full(src, n); g_fullsum_words += n; }
+  else {
+    const u64 *v = (const u64 *)src; u64 *o = (u64 *)dst;
+    static const u64 C1[8] = SDM_CK_C1, C2[8] = SDM_CK_C2;
+    u64 a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    sdm_int i = 0;
+    for (; i + 8 <= n; i += 8)
+      for (int k = 0; k < 8; k++) {
+        const u64 w = v[i + k];
+        o[i + k] = w;
+        a[k] += (u64)((unsigned)w ^ (unsigned)i) * C1[k] + (u64)((unsigned)(w >> 32) ^ (unsigned)i) * C2[k];
+      }
+    for (int k = 0; i + k < n; k++) {
+      const u64 w = v[i + k];
+      o[i + k] = w;
+      a[k] += (u64)((unsigned)w ^ (unsigned)i) * C1[k] + (u64)((unsigned)(w >> 32) ^ (unsigned)i) * C2[k];
+    }
+    sum = fold_sums(a, n);
+  }
+  if (g_nnotes < 4) g_notes[g_nnotes++] = Note{src, n, sum};
+  return sum;
+}
 // the content checksum of n 8-byte words on the host (what residency is decided on; tests, and the bench's statement of its cost)
 unsigned long long sdm_mexcache_checksum(const void *words, sdm_int n) { return hash_full(words, n); }
 // on != 0: every presentation of every array is checksummed completely (no address is ever trusted) -- for callers that edit arrays
@@ -564,7 +606,7 @@ int sdm_mexcache_blkchol(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, cons
   SDM_HIP_CHECK(hipMemcpyAsync(Lpr, p->lpr.p, (size_t)nnzL * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   SDM_HIP_CHECK(hipMemcpyAsync(d, p->chol.d.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   if (sdm_plan_pivots(p, nskip, skip_idx, skip_val, nadd, add_idx, add_val)) throw std::runtime_error(sdm_last_error());   // (drains the stream)
-  g.lpr.take_with_full(Lpr, nnzL, fold_sums(acc, nnzL));
+  g.lpr.take_with_full(Lpr, nnzL, fold_sums(g_ck_host, nnzL));
   g.have_factor = true;
   MC_CATCH
 }

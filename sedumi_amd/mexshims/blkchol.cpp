@@ -23,6 +23,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   const sdm_int m = L.m, nnzL = L.jc[m];
   const mxArray *LLin = mxGetField(prhs[0], 0, "L");
   mxArray *out[4];
+  cache_teardown_at_exit();
   out[0] = sparse_like(LLin);                                          // L.L keeps the symbolic pattern (blkchol.c:391-395)
   out[1] = mxCreateDoubleMatrix(m, 1, mxREAL);
   ivec sidx(m > 0 ? m : 1), aidx(m > 0 ? m : 1);
@@ -31,7 +32,6 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   const double tin = lazy_token_of(X);                               // lazy intermediates, level 2: X is getada3's token, ADA' is on the device
   IdxView Xjc, Xir;
   if (tin == 0.0) { Xjc = jc_of(X); Xir = ir_of(X); }
-  cache_teardown_at_exit();
   // the factor stays resident in the library's cache for fwblkslv / bwblkslv; X is taken from the device when it is the
   // array getada3 just returned (sdm_mexcache.hip)
   sdm_check(sdm_mexcache_blkchol(m, L.jc.data(), L.ir.data(), L.perm.data(), L.nsuper, L.xsuper.data(), tin == 0.0 ? Xjc.data() : NULL,

@@ -44,4 +44,5 @@ void teardown(void) { sdm_mexcache_clear(); }
 }  // namespace
 void cache_teardown_at_exit(void) {
   if (!atexit_set) { mexAtExit(teardown); atexit_set = true; }
+  sdm_mexcache_forget_notes();   // (every gateway calls this first: a checksum noted by a call that ended in an error before it reached the cache dies here)
 }

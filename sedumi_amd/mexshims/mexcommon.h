@@ -50,7 +50,10 @@ inline mxArray *sparse_like(const mxArray *src) {
   mxFree(mxGetIr(a)); mxFree(mxGetPr(a));
   mxSetIr(a, ir); mxSetPr(a, pr); mxSetNzmax(a, cap);
   memcpy(mxGetJc(a), mxGetJc(src), (n + 1) * sizeof(mwIndex));
-  if (nnz) memcpy(ir, mxGetIr(src), nnz * sizeof(mwIndex));
+  if (nnz) {                                                           // (the cache checks this pattern: copied and checksummed in one pass)
+    if (sizeof(mwIndex) == 8) sdm_mexcache_copy_words(ir, mxGetIr(src), (sdm_int)nnz);
+    else memcpy(ir, mxGetIr(src), nnz * sizeof(mwIndex));
+  }
   if (!nnz) pr[0] = 0.0;
   return a;
 }

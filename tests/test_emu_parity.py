@@ -513,3 +513,58 @@ def test_set_chol_after_a_timeout_keeps_the_plan_on_the_panel_path(refmex):
     finally:
         lib._Z19emu_inject_timeoutsi(0)
         P.close()
+
+
+@pytest.mark.parametrize("ns,ms", [(4000, 4000), (1000, 1000), (900, 900), (960, 960), (1100, 1100), (1216, 1216), (700, 1500), (1300, 2100), (1024, 1030),
+                                   (2050, 2050), (333, 2000), (64 * 9, 64 * 9 + 129), (64 * 9, 64 * 9 + 128), (2900, 3333)])
+def test_update_schedule_gives_every_tile_every_panel_once_and_in_order(ns, ms):
+    """tile_sched (sdm_chol.hip): the trailing updates of a big front on the launch-per-panel path -- eager tiles of the panel before, deferred
+    macro tiles of whole groups of panels -- enumerated on the host for every panel launch (sdm_debug_tile_items) and replayed: every tile
+    (I, J) of the front's lower triangle receives the panels 0 .. min(J, NP) - 1, each exactly once, in ascending order, never twice within a
+    launch (two workgroups on one tile), and column q is complete but for panel q - 1 when launch q starts.  Fronts with rows beyond their
+    columns (ms > ns) and partial last panels included."""
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(helpers.ROOT, "tests", "hipemu"))
+    import build_emu
+    lib = ctypes.CDLL(build_emu.build())
+    NB = 64
+    NP, T = -(-ns // NB), -(-ms // NB)
+    got = {(I, J): [] for J in range(T) for I in range(J, T)}
+    buf = (ctypes.c_int * (5 * 8192))()
+    deferred_seen = False
+    for q in range(1, NP):
+        # what launch q needs of its own column: everything but panel q - 1 (the row-solve workgroups and the diagonal block apply that one)
+        for I in range(q, T):
+            assert got[(I, q)] == list(range(q - 1)), (q, I, got[(I, q)])
+        for I in range(q, T):
+            got[(I, q)].append(q - 1)
+        n = lib.sdm_debug_tile_items(ns, ms, q, buf, 8192)
+        touched = set()
+        if n < 0:                                                  # no row-solve workgroups: the eager tiles of the round-4 role, every tile but column q
+            for J in range(q + 1, T):
+                for I in range(J, T):
+                    got[(I, J)].append(q - 1)
+            continue
+        assert n <= 8192
+        for u in range(n):
+            I0, J0, act, p0, npan = buf[5 * u:5 * u + 5]
+            assert act != 0 and npan >= 1
+            deferred_seen |= npan > 1
+            for a in range(2):
+                for b in range(2):
+                    if act >> (2 * a + b) & 1:
+                        I, J = q + I0 + a, q + J0 + b
+                        assert q < J <= I < T and (I, J) not in touched, (q, u, I, J)
+                        touched.add((I, J))
+                        assert p0 + npan <= q                     # only final panels
+                        got[(I, J)].extend(range(p0, p0 + npan))
+    last_has_rows = ms > ns                                        # k_ldl_update: the last panel's update of the rows beyond the supernode
+    for (I, J), panels in got.items():
+        want = list(range(min(J, NP)))
+        if J >= NP and last_has_rows:
+            want = want[:-1]                                       # (applied by the stand-alone k_ldl_update, not by a panel launch)
+        assert panels == want, ((I, J), panels, want)
+    if T >= 12 and NP >= 6:
+        assert deferred_seen

@@ -302,7 +302,7 @@ struct AdaSlot {
 AdaSlot g_s1, g_s2, g_s3, g_s0;
 
 // whose ada_val holds the ADA values most recently handed back to the host, and what they were
-struct { sdm_plan *plan = nullptr; Finger vals; } g_last;
+struct { sdm_plan *plan = nullptr; Finger vals; bool zero = false; } g_last;   // zero: those values are known to be all zero (getada1 with nothing to add)
 DevBuf<u64> g_ck;                       // eight device words: checksum of values a gateway leaves in HBM (k_words_checksum)
 u64 *g_ck_host = nullptr;               // ... and where they land on the host: pinned, so that the copy is queued like the rest and the one
                                         // synchronisation of the gateway (its download) covers it (to pageable memory every copy blocked the host)
@@ -322,12 +322,12 @@ void download_returned(sdm_plan *p, double *pr, double *absd, sdm_int nnz) {
   u64 acc[8];
   device_checksum(p, p->ada_val.p, nnz, acc);
   gw_download(p, pr, absd);                                           // (drains the stream)
-  g_last.plan = p; g_last.vals.take_with_full(pr, nnz, fold_sums(g_ck_host, nnz));
+  g_last.plan = p; g_last.vals.take_with_full(pr, nnz, fold_sums(g_ck_host, nnz)); g_last.zero = false;
 }
 // a gateway leaves its ADA' on the device and hands out a token for it (lazy mode)
 double returned_token(sdm_plan *p, u64 pat, sdm_int m, sdm_int nnz) {
   SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
-  g_last.plan = p; g_last.vals.forget();
+  g_last.plan = p; g_last.vals.forget(); g_last.zero = false;
   g_tok.serial = ++g_serial; g_tok.pat = pat; g_tok.m = m; g_tok.nnz = nnz;
   return LAZY_BASE + (double)g_tok.serial;
 }
@@ -353,7 +353,7 @@ void ada_input(sdm_plan *p, const double *pr, sdm_int nnz) {
   g_stat[ST_ADA_UPLOAD]++;
   SDM_HIP_CHECK(hipMemcpyAsync(p->ada_val.p, pr, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, p->stream));
 }
-void forget_plan(sdm_plan *p) { if (g_last.plan == p) { g_last.plan = nullptr; g_last.vals.forget(); g_tok.serial = 0; } }
+void forget_plan(sdm_plan *p) { if (g_last.plan == p) { g_last.plan = nullptr; g_last.vals.forget(); g_last.zero = false; g_tok.serial = 0; } }
 
 // ---- the factorisation's plan
 struct Chol {
@@ -497,6 +497,7 @@ int sdm_mexcache_getada1(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, 
   gw_run_getada1(S.plan, S.invperm.p, dl, ddet);
   if (token_out) *token_out = returned_token(S.plan, pa, m, ADAjc[m]);
   else download_returned(S.plan, ADApr, nullptr, ADAjc[m]);
+  g_last.zero = gw_getada1_is_zero(S.plan);
   MC_CATCH
 }
 
@@ -519,6 +520,7 @@ int sdm_mexcache_getada2(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, 
   } else g_stat[ST_ADA_REUSE]++;
   S.set_perm(qperm, m);
   if (token_in != 0.0) ada_input_token(S.plan, ADAjc[m]); else ada_input(S.plan, ADApr_in, ADAjc[m]);
+  g_last.zero = false;                                                // (Lorentz terms are being added)
   gw_run_getada2(S.plan, S.invperm.p, Qpr);
   if (token_out) *token_out = returned_token(S.plan, pa, m, ADAjc[m]);
   else download_returned(S.plan, ADApr, nullptr, ADAjc[m]);
@@ -544,8 +546,12 @@ int sdm_mexcache_getada3(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, 
     S.pat_ada = pa; S.pat_a = pA; S.ints = ints; S.split.assign(Ajc1, Ajc1 + m); S.apr.take(Apr, Ajc[m]);
     S.built = true;
   } else g_stat[ST_ADA_REUSE]++;
+  const sdm_int up0 = g_stat[ST_ADA_UPLOAD];
+  const bool was_zero = g_last.zero;
   if (token_in != 0.0) ada_input_token(S.plan, ADAjc[m]); else ada_input(S.plan, ADApr_in, ADAjc[m]);
-  gw_run_getada3(S.plan, udsqr);
+  const bool zero_in = was_zero && g_stat[ST_ADA_UPLOAD] == up0;      // the device's ADA' was taken, and it is the zero matrix getada1 left
+  g_last.zero = false;
+  gw_run_getada3(S.plan, udsqr, zero_in);
   if (token_out) { gw_download(S.plan, nullptr, absd); *token_out = returned_token(S.plan, pa, m, ADAjc[m]); }
   else download_returned(S.plan, ADApr, absd, ADAjc[m]);
   MC_CATCH

@@ -469,7 +469,8 @@ void gw_build_getada2(sdm_plan *p, sdm_int m, const sdm_int *ADAjc, const sdm_in
 void gw_run_getada2(sdm_plan *p, const int *d_invperm, const double *Qpr);
 void gw_build_getada3(sdm_plan *p, sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, sdm_int N, const sdm_int *Ajc, const sdm_int *Air,
                       const double *Apr, const sdm_int *Ajc1, const sdm_cone *K, const sdm_int *psd_blkstart);
-void gw_run_getada3(sdm_plan *p, const double *udsqr);
+void gw_run_getada3(sdm_plan *p, const double *udsqr, bool input_is_zero);
+bool gw_getada1_is_zero(sdm_plan *p);   // getada1 on this plan has nothing to add (no LP / Lorentz nonzeros)
 void gw_build_getada(sdm_plan *p, sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, const sdm_int *Ajc, const sdm_int *Air, const double *Apr,
                      sdm_int lpN, sdm_int lorN, const sdm_int *qblkstart, const sdm_int *Qjc, const sdm_int *Qir);
 void gw_run_getada(sdm_plan *p, const double *dl, const double *ddet, const double *Qpr);

@@ -404,3 +404,29 @@ def test_checksum_threads_give_the_value_of_one_thread(shimlib):
     a[123_457] += 1e-12
     assert lib.sdm_mexcache_checksum(p, ctypes.c_int64(a.size)) != vals[0]
     lib.sdm_mexcache_clear()
+
+
+def test_units_on_a_problem_without_lp_or_lorentz_part(glue, refmex, shimmex, shimlib):
+    """MAXCUT's shape: one PSD block, nothing else.  getada1.mex has nothing to add (ADA' stays the zero matrix: no sparse dots over
+    its pattern), getada2.mex copies, getada3.mex is handed the device's zero matrix and skips the symmetrisation of its input -- ADA',
+    absd, the factor and the solves are the reference's, unit after unit."""
+    import ctypes
+    from oracle import glue as gl
+    from sedumi_amd import problem
+    ctypes.CDLL(shimlib).sdm_mexcache_clear()
+    P = problem.maxcut(14)
+    S = glue.setup(P.At, P.K)
+    assert P.K["q"].size == 0 and np.all(np.asarray(S["Ablkjc"])[:, 2] == sp.csc_matrix(S["A"]).indptr[:-1])     # no LP / Lorentz nonzero in any constraint
+    d, ud = ref_scaling(P, 4)
+    it = glue.iteration_ref(S, d, ud)
+    assert abs(it["ADA1"]).sum() == 0                               # (the reference's getada1 leaves zeros, too)
+    pars = gl.default_pars_chol()
+    rhs = np.random.default_rng(1).standard_normal(P.m)
+    s0 = mexcache_stats(shimlib)
+    _, y = run_units_by_reference(shimmex, S, P.K, d, it["DAt"], ud, pars, rhs, 3, it)
+    s1 = mexcache_stats(shimlib)
+    L = dict(S["L"]); L["L"] = it["LL"]
+    yr = refmex.call("bwblkslv", 1, L, refmex.call("fwblkslv", 1, L, rhs.reshape(-1, 1)) / np.where(it["Ld"] > 0, it["Ld"], 1.0))
+    assert relerr(y, yr.ravel()) < TOL
+    assert s1["ada_upload"] == s0["ada_upload"] and s1["ada_resident"] - s0["ada_resident"] == 3
+    # (an ADA' with values handed to getada3.mex -- uploaded, symmetrised as before -- is test_shims_reproduce_an_iteration_unit's case)

@@ -11,7 +11,7 @@ import pytest
 from helpers import ROOT, use_hip
 from test_mexshims import (build_shims, test_factor_cache_is_shared_between_mex_binaries_and_validated_by_content,  # noqa: F401
                            test_factor_cache_shortcut_for_large_arrays_is_exactly_the_documented_one,
-                           test_iteration_units_by_reference_reuse_the_device_state, test_lazy_intermediates_leave_ada_on_the_device,
+                           test_iteration_units_by_reference_reuse_the_device_state, test_lazy_intermediates_leave_ada_on_the_device, test_units_on_a_problem_without_lp_or_lorentz_part,
                            test_getada_shim_updates_the_global, test_shim_errors_go_through_mexErrMsgTxt, test_shim_incorder,
                            test_shim_invcholfac, test_shims_dense_column_path, test_shims_reproduce_an_iteration_unit,
                            test_shims_symbolic_bit_exact)

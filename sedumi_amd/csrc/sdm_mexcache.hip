@@ -304,6 +304,8 @@ AdaSlot g_s1, g_s2, g_s3, g_s0;
 // whose ada_val holds the ADA values most recently handed back to the host, and what they were
 struct { sdm_plan *plan = nullptr; Finger vals; bool zero = false; } g_last;   // zero: those values are known to be all zero (getada1 with nothing to add)
 DevBuf<u64> g_ck;                       // eight device words: checksum of values a gateway leaves in HBM (k_words_checksum)
+double *g_pin = nullptr;                // pinned staging for the solves' right-hand side and solution (sdm_mexcache_solve)
+sdm_int g_pin_n = 0;
 u64 *g_ck_host = nullptr;               // ... and where they land on the host: pinned, so that the copy is queued like the rest and the one
                                         // synchronisation of the gateway (its download) covers it (to pageable memory every copy blocked the host)
 // the eight sums of n device words -> acc8 (host), queued on the plan's stream: valid once the stream has been drained
@@ -374,6 +376,7 @@ void drop_all() {
   g_pool.shutdown();
   g_ck.release();
   if (g_ck_host) { (void)hipHostFree(g_ck_host); g_ck_host = nullptr; }
+  if (g_pin) { (void)hipHostFree(g_pin); g_pin = nullptr; g_pin_n = 0; }
   for (auto &p : g_pat) p = Pattern();
   g_fullsum_words = 0; g_hash_ns = 0; g_hash_calls = 0;
 }
@@ -631,11 +634,21 @@ int sdm_mexcache_solve(int fw, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir
   }
   g_stat[ST_SOLVE_RESIDENT]++;
   sdm_plan *p = g.plan;
+  // right-hand side and solution travel through a pinned buffer: copies between pageable host memory and the device block the host once
+  // each, and a solve of a small factor is two such copies around 10 us of kernels
+  if (g_pin_n < 2 * m) {
+    if (g_pin) (void)hipHostFree(g_pin);
+    g_pin = nullptr; g_pin_n = 0;
+    SDM_HIP_CHECK(hipHostMalloc((void **)&g_pin, (size_t)2 * m * sizeof(double), 0));
+    g_pin_n = 2 * m;
+  }
   for (sdm_int c = 0; c < nrhs; c++) {
-    SDM_HIP_CHECK(hipMemcpyAsync(p->rhs.p, b + c * m, (size_t)m * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    memcpy(g_pin, b + c * m, (size_t)m * sizeof(double));
+    SDM_HIP_CHECK(hipMemcpyAsync(p->rhs.p, g_pin, (size_t)m * sizeof(double), hipMemcpyHostToDevice, p->stream));
     if (fw ? sdm_plan_fwsolve(p) : sdm_plan_bwsolve(p)) throw std::runtime_error(sdm_last_error());
-    SDM_HIP_CHECK(hipMemcpyAsync(y + c * m, p->y.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    SDM_HIP_CHECK(hipMemcpyAsync(g_pin + m, p->y.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    memcpy(y + c * m, g_pin + m, (size_t)m * sizeof(double));
   }
   if (sdm_plan_sync(p)) throw std::runtime_error(sdm_last_error());     // (time-out flags of the plan)
   MC_CATCH

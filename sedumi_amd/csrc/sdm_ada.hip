@@ -864,7 +864,9 @@ __global__ void __launch_bounds__(256)
 k_psd_direct(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, const int64_t *Ajc, const int64_t *Ajc_psd, const double *Apr,
              const int *Air, const int *Ablk, const int64_t *c_taskptr, const int *t_blk, const int *t_n, const int64_t *t_udoff,
              const int64_t *t_slotptr, const int64_t *s_nzptr, const int64_t *t_end, const int64_t *psd_start, const double *udsqr,
-             const int *invperm, int nblk, int jbase) {
+             const int *invperm, int nblk, int jbase, int base_zero) {
+  // base_zero: the ADA' handed in is the zero matrix ada_lq left uncleared (ada_zero_flush): nothing is read, every entry of the
+  // column is written -- the memset and the read of the zeros were 256 of this stage's 512 MB at n = 4000
   SDM_DYN_SMEM(smem);
   // per block of column j: order n (0 = no nonzero of A_j there), offsets of D_k and of the block's rows, and the nonzeros of A_jk
   int *bn = (int *)smem;                                   // [nblk]
@@ -915,7 +917,7 @@ k_psd_direct(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, 
         const double term = Apr[p] * (zv / 2);
         acc += term; aabs += fabs(term);
       }
-    const double base = ada[e];
+    const double base = base_zero ? 0.0 : ada[e];
     ada[e] = base + acc;
     if (i == j) absd[j] = jhas ? base + aabs : 0.0;
   }
@@ -1179,7 +1181,11 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
   const size_t direct_lds = (size_t)(2 * A.sdpN + 2 * S1_DIRECT_MAXNZ * A.sdpN + 2) * sizeof(int) + (size_t)(2 * A.sdpN) * sizeof(long long) +
                             (size_t)(S1_DIRECT_MAXNZ * A.sdpN) * sizeof(double);
   const bool direct = A.thread_per_row && !A.ell_ok && A.sdpN == A.rsdpN && A.s1_maxnz <= S1_DIRECT_MAXNZ && direct_lds <= S1_DIRECT_LDS_MAX;
-  if (direct || ntask <= 0 || !(A.maxn <= S1_MAXN && A.sdpN == A.rsdpN)) ada_zero_flush(P);     // (only the matrix-core stage 1 takes the clearing over)
+  // (the matrix-core stage 1 takes the clearing over; the pairwise form writes every entry of the panel itself when it has no skipped triangle)
+  const bool direct_zero = direct && !sym_input && !d_invperm && A.zero_ptr == ada + P->ada_jc[A.col0] &&
+                           A.zero_n == (long long)(P->ada_jc[A.col1] - P->ada_jc[A.col0]);
+  if (direct_zero) { A.zero_ptr = nullptr; A.zero_n = 0; }
+  if (direct || ntask <= 0 || !(A.maxn <= S1_MAXN && A.sdpN == A.rsdpN)) ada_zero_flush(P);
   if (direct) {
     if (sym_input) {
       SDM_KLAUNCH(P, k_symmetrize, dim3(m), dim3(128), 0, A.symtmp.p, ada, A.d_ADAjc.p, A.d_ADAir.p, A.d_ADAT.p, m);
@@ -1189,7 +1195,7 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
     const size_t lds = direct_lds;
     SDM_KLAUNCH(P, k_psd_direct, dim3(ncols), dim3(256), lds, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p, A.d_Apr.p, A.d_Air.p,
                 A.d_Ablk.p, A.c_taskptr.p, A.t_blk.p, A.t_n.p, A.t_udoff.p, A.t_slotptr.p, A.s_nzptr.p, A.t_end.p, A.d_psd_start.p, A.udsqr.p,
-                d_invperm, nb, jbase);
+                d_invperm, nb, jbase, direct_zero ? 1 : 0);
     SDM_HIP_CHECK(hipGetLastError());
     return;
   }

@@ -378,6 +378,10 @@ int sdm_plan_set_one_launch_fronts(sdm_plan *p, int on);
 /* n > 0: the NEXT sdm_plan_set_chol deals the trailing-update tiles of a big front's panel launch to at most n workgroups beside the
  * chain and the row solves (each works through its tile pairs as a pipeline); 0 = as many as the device has compute units. */
 int sdm_plan_set_tile_workgroups(sdm_plan *p, int n);
+/* on = 0: the inverses of the diagonal super-blocks are built by one launch per stage (k_sinv128, k_stile) whatever the size of the
+ * problem; default 1: problems whose work items fit the device at once take ONE launch with completion counters (k_sprep).  Takes
+ * effect at the next factorisation.  The comparison switch of the tests: both paths give the same bits. */
+int sdm_plan_set_one_launch_inverse(sdm_plan *p, int on);
 int sdm_plan_set_solve_width(sdm_plan *p, sdm_int width);
 int sdm_plan_get_solve_width(sdm_plan *p, sdm_int *width);      /* the width in force (after sdm_plan_set_chol) */
 int sdm_plan_solve_stats(sdm_plan *p, sdm_int *nblocks, sdm_int *nbad, double *max_growth);

@@ -338,6 +338,11 @@ int sdm_plan_set_tile_workgroups(sdm_plan *p, int n) {
   p->chol.tile_wgs_req = n;
   SDM_CATCH
 }
+int sdm_plan_set_one_launch_inverse(sdm_plan *p, int on) {
+  SDM_TRY
+  p->chol.sprep_off = !on;
+  SDM_CATCH
+}
 int sdm_plan_set_solve_width(sdm_plan *p, sdm_int width) {
   SDM_TRY
   if (width != 0 && (width < sdm::SBW_MIN || width > sdm::SBW_MAX || (width & (width - 1)) != 0))

@@ -190,6 +190,7 @@ struct CholPlan {
   int sbw = SBW_MIN;                 // super-block width of this plan (solve_build: covers the widest front, at most SBW_MAX)
   int sbw_req = 0;                   // != 0: width asked for through sdm_plan_set_solve_width (before set_chol)
   bool front_off_req = false;        // sdm_plan_set_one_launch_fronts(p, 0): the next set_chol plans no k_ldl_front level
+  bool sprep_off = false;            // sdm_plan_set_one_launch_inverse(0): the inverses of small problems by a launch per stage too (k_sinv128 + k_stile, not k_sprep)
   int tile_wgs_req = 0;              // sdm_plan_set_tile_workgroups: workgroups a big front's update tiles are dealt to (0 = the device's compute units)
   int64_t ssize = 0; int nsbtot = 0;
   std::vector<int64_t> sn_soff; std::vector<int> sn_sld, sn_sboff;

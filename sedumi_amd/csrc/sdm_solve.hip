@@ -55,6 +55,7 @@ void solve_build(sdm_plan *P) {
   C.sn_soff.assign(nsuper, 0); C.sn_sld.assign(nsuper, 0); C.sn_sboff.assign(nsuper, 0);
   std::vector<int> i128;
   std::vector<std::vector<int>> stage(2 * SINV_MAXLEV);              // combine tiles per stage st = 2 * level + (0: T, 1: X)
+  std::vector<std::vector<int>> stage_w(2 * SINV_MAXLEV);            // and the number of K steps of each
   int64_t soff = 0; int sb = 0;
   for (int s = 0; s < nsuper; s++) {
     const int ns = C.sn_ns[s];
@@ -82,6 +83,7 @@ void solve_build(sdm_plan *P) {
               for (int J = 0; 64 * J < h; J++) {
                 const int it[8] = {s, Pb, lev, pi, I, J, t, prev};
                 dst.insert(dst.end(), it, it + 8);
+                stage_w[2 * lev + t].push_back(t == 0 ? h / 64 - J : std::min(I + 1, (nc + 63) / 64));   // its K steps (stile_body)
                 if (t == 0) cnt++;
               }
           }
@@ -96,7 +98,17 @@ void solve_build(sdm_plan *P) {
   C.stage_ptr.assign(2 * SINV_MAXLEV + 1, 0);
   for (int st = 0; st < 2 * SINV_MAXLEV; st++) {
     C.stage_ptr[st] = (int)items.size() / 8;
-    items.insert(items.end(), stage[st].begin(), stage[st].end());
+    // Longest items first.  The products are triangular (1 .. h/64 K steps per tile) and a launch of more tiles than fit the device
+    // at once lasts as long as whatever is dispatched last: in the order the tiles are generated (long ones last in stage X) the two
+    // 496-tile stages of MAXCUT-4000 took 107 and 103 us, sorted 83 and 83 (profiles/r07e_timeline_maxcut4000.txt).  Measured and
+    // not kept: workgroups taking the tiles in pairs, longest with shortest (88 us: a workgroup alone on its CU needs 4.6 us per K
+    // step, two on a CU 6.4 us each), and operand blocks two K steps ahead in registers (3 us on all eight launches together, at the
+    // price of the second workgroup per CU) -- a K step is 64 KB of operands at the ~16 GB/s a CU gets when all CUs stream.
+    const std::vector<int> &w = stage_w[st];
+    std::vector<int> ord(w.size());
+    for (size_t i = 0; i < ord.size(); i++) ord[i] = (int)i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return w[a] > w[b]; });
+    for (int i : ord) items.insert(items.end(), stage[st].begin() + 8 * (size_t)i, stage[st].begin() + 8 * (size_t)i + 8);
   }
   C.stage_ptr[2 * SINV_MAXLEV] = (int)items.size() / 8;
   C.n_i128 = (int)i128.size() / 4; C.n_items = (int)items.size() / 8;
@@ -954,7 +966,7 @@ void solve_prepare(sdm_plan *P, bool sb_g_is_zero) {
   const int W = C.sbw;
   if (C.n_lt) SDM_KLAUNCH(P, k_ltrans, dim3(C.n_lt), dim3(ST), 0, C.fronts.p, C.LT.p, tab, C.l_lt.p, W);
   if (C.n_i128 == 0) return;
-  if (C.n_i128 + C.n_items <= SPREP_MAX_ITEMS) {                    // everything resident at once: one launch, counters instead of boundaries
+  if (C.n_i128 + C.n_items <= SPREP_MAX_ITEMS && !C.sprep_off) {    // everything resident at once: one launch, counters instead of boundaries
 #ifdef SDM_EMU
     if (emu_concurrent() && C.n_i128 + C.n_items <= 200) {          // as on the device: its workgroups wait for each other's counters (one process each)
       SDM_KLAUNCH_CONCURRENT(P, k_sprep, dim3(C.n_i128 + C.n_items), dim3(ST), INV_LDS, C.fronts.p, C.S.p, C.ST.p, C.Tarena.p, tab, C.l_i128.p, C.n_i128,

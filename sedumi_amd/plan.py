@@ -193,6 +193,10 @@ class Plan:
         """Workgroups the update tiles of a big front's panel launch are dealt to, for the NEXT set_chol (0 = the device's compute units)."""
         check(self._lib.sdm_plan_set_tile_workgroups(C.c_void_p(self._p), C.c_int(int(n))))
 
+    def set_one_launch_inverse(self, on):
+        """False: the super-block inverses of small problems by a launch per stage too (k_sinv128 + k_stile instead of k_sprep)."""
+        check(self._lib.sdm_plan_set_one_launch_inverse(C.c_void_p(self._p), C.c_int(1 if on else 0)))
+
     def set_solve_width(self, width):
         """Super-block width of the solves for the NEXT set_chol (0 = automatic, or a power of two in 256 .. 2048)."""
         check(self._lib.sdm_plan_set_solve_width(C.c_void_p(self._p), C.c_int64(int(width))))

@@ -356,6 +356,39 @@ def check_rank_deficient_fronts(refmex, ncases, seed=777):
     assert nprobe > 0
 
 
+def check_inverse_launch_paths(m, seed=0):
+    """The inverses of the diagonal super-blocks by ONE launch with completion counters (k_sprep: problems whose items fit the device)
+    and by a launch per stage (k_sinv128 + k_stile, items sorted longest first; Plan.set_one_launch_inverse(False)): the same
+    solutions bit for bit, and numpy's to rounding."""
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    rng = np.random.default_rng(m + seed)
+    Lv = np.tril(rng.standard_normal((m, m)) * (0.5 / np.sqrt(m)), -1) + np.eye(m)
+    d = 0.5 + rng.random(m)
+    X = Lv @ np.diag(d) @ Lv.T
+    L = problem.dense_symbolic(m)
+    rhs = rng.standard_normal(m)
+    want = np.linalg.solve(X, rhs)
+    got = {}
+    for one in (True, False):
+        plan = Plan(0)
+        plan.set_one_launch_inverse(one)
+        plan.set_one_launch_fronts(False)          # (the inverse behind a one-launch front is built by the follower, by neither of the two)
+        plan.set_chol(L, problem.dense_pattern(m))
+        plan.upload("ada", X.ravel(order="F"))
+        plan.kprof(True)
+        plan.blkchol(None, False)
+        prof = plan.kprof_summary()
+        plan.kprof(False)
+        assert ("k_sprep" in prof) == one and ("k_stile" in prof) == (not one), sorted(prof)
+        plan.upload("rhs", rhs); plan.ldlsolve(); got[one] = plan.download("y")
+        nb, bad, _ = plan.solve_stats()
+        assert bad == 0
+        plan.close()
+    assert np.array_equal(got[True], got[False])
+    assert np.max(np.abs(got[True] - want)) / np.max(np.abs(want)) < 1e-10
+
+
 def check_solve_widths(m, thr, seed=0):
     """The solves of a one-front factor with every super-block width the front admits (sdm_plan_set_solve_width: 256, 512,
     ... up to the automatic choice = one block when m <= 2048): every width against numpy's solve -- on the inverse path,

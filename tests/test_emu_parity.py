@@ -437,6 +437,11 @@ def test_solve_widths(m, thr):
     helpers.check_solve_widths(m, thr)
 
 
+@pytest.mark.parametrize("m", [300, 530, 700])
+def test_inverse_by_one_launch_and_by_a_launch_per_stage(m):
+    helpers.check_inverse_launch_paths(m)
+
+
 @pytest.mark.parametrize("m,seed,glo,ghi,cancelling", [(320, 3, 1e5, 1e7, False), (400, 7, 3e6, 5e7, True), (400, 11, 3e8, 8e9, False)])
 def test_refined_solves_are_as_accurate_as_substitution(m, seed, glo, ghi, cancelling):
     """Super-blocks beyond the growth bound: explicit inverse + two refinement steps against the factor (k_sfw_resid / k_sbw_resid)

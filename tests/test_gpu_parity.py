@@ -717,6 +717,12 @@ def test_one_launch_front_starved_by_another_process(refmex, busy):
     plan.close(); small.close()
 
 
+@pytest.mark.parametrize("m", [300, 530, 700])
+def test_inverse_by_one_launch_and_by_a_launch_per_stage(m):
+    """k_sprep against k_sinv128 + k_stile (items sorted longest first): the same solutions bit for bit."""
+    helpers.check_inverse_launch_paths(m)
+
+
 @pytest.mark.parametrize("m,thr", [(90, None), (300, None), (666, None), (700, 0.0), (700, 1e-3), (1100, None), (256, 0.0), (2500, None), (2500, 0.0)])
 def test_solve_widths(m, thr):
     """Every super-block width a one-front factor admits (256 ... one block, two blocks of 2048 beyond that): inverse path,

@@ -100,9 +100,9 @@ void solve_build(sdm_plan *P) {
     C.stage_ptr[st] = (int)items.size() / 8;
     // Longest items first.  The products are triangular (1 .. h/64 K steps per tile) and a launch of more tiles than fit the device
     // at once lasts as long as whatever is dispatched last: in the order the tiles are generated (long ones last in stage X) the two
-    // 496-tile stages of MAXCUT-4000 took 107 and 103 us, sorted 83 and 83 (profiles/r07e_timeline_maxcut4000.txt).  Measured and
-    // not kept: workgroups taking the tiles in pairs, longest with shortest (88 us: a workgroup alone on its CU needs 4.6 us per K
-    // step, two on a CU 6.4 us each), and operand blocks two K steps ahead in registers (3 us on all eight launches together, at the
+    // 496-tile stages of MAXCUT-4000 took 107 and 103 us, sorted 90 and 89 (profiles/r07_inverse_tile_variants.txt).  Measured and
+    // not kept: workgroups taking the tiles in pairs, longest with shortest (88 us, and the small stages slower: a workgroup alone on
+    // its CU needs 4.6 us per K step, two on a CU 6.4 us each), and operand blocks two K steps ahead in registers (a few us, at the
     // price of the second workgroup per CU) -- a K step is 64 KB of operands at the ~16 GB/s a CU gets when all CUs stream.
     const std::vector<int> &w = stage_w[st];
     std::vector<int> ord(w.size());

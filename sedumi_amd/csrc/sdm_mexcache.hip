@@ -308,11 +308,10 @@ double *g_pin = nullptr;                // pinned staging for the solves' right-
 sdm_int g_pin_n = 0;
 u64 *g_ck_host = nullptr;               // ... and where they land on the host: pinned, so that the copy is queued like the rest and the one
                                         // synchronisation of the gateway (its download) covers it (to pageable memory every copy blocked the host)
-// the eight sums of n device words -> acc8 (host), queued on the plan's stream: valid once the stream has been drained
-void device_checksum(sdm_plan *p, const double *v, sdm_int n, u64 *acc8) {
+// the eight sums of n device words -> g_ck_host, queued on the plan's stream: valid once the stream has been drained
+void device_checksum(sdm_plan *p, const double *v, sdm_int n) {
   if (!g_ck.p) g_ck.alloc(8);
   if (!g_ck_host) SDM_HIP_CHECK(hipHostMalloc((void **)&g_ck_host, 8 * sizeof(u64), 0));
-  (void)acc8;
   const sdm_int wg = std::min<sdm_int>(2048, std::max<sdm_int>(64, n / 8192));
   SDM_HIP_CHECK(hipMemsetAsync(g_ck.p, 0, 8 * sizeof(u64), p->stream));
   SDM_LAUNCH(k_words_checksum, dim3((unsigned)wg), dim3(256), 0, p->stream, (const unsigned long long *)v, (long long)n, g_ck.p);
@@ -321,8 +320,7 @@ void device_checksum(sdm_plan *p, const double *v, sdm_int n, u64 *acc8) {
 // ADA' values and absd of plan p -> the host arrays the shim returns, together with the checksum of the values summed on the device:
 // the array at pr is, from now on, known to hold what p->ada_val holds
 void download_returned(sdm_plan *p, double *pr, double *absd, sdm_int nnz) {
-  u64 acc[8];
-  device_checksum(p, p->ada_val.p, nnz, acc);
+  device_checksum(p, p->ada_val.p, nnz);
   gw_download(p, pr, absd);                                           // (drains the stream)
   g_last.plan = p; g_last.vals.take_with_full(pr, nnz, fold_sums(g_ck_host, nnz)); g_last.zero = false;
 }
@@ -609,9 +607,8 @@ int sdm_mexcache_blkchol(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, cons
   if (absd) SDM_HIP_CHECK(hipMemcpyAsync(p->absd.p, absd, (size_t)m * sizeof(double), hipMemcpyHostToDevice, p->stream));
   if (sdm_plan_blkchol_wait(p, pars, absd ? 1 : 0)) throw std::runtime_error(sdm_last_error());   // (waited for, repeated once on the launch-per-panel path after a time-out)
   // L.L values, L.d and the fingerprint of the factor (summed on the device: no pass over the host copy) in one drain of the stream
-  u64 acc[8];
   chol_extract(p, p->lpr.p);
-  device_checksum(p, p->lpr.p, nnzL, acc);
+  device_checksum(p, p->lpr.p, nnzL);
   SDM_HIP_CHECK(hipMemcpyAsync(Lpr, p->lpr.p, (size_t)nnzL * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   SDM_HIP_CHECK(hipMemcpyAsync(d, p->chol.d.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   if (sdm_plan_pivots(p, nskip, skip_idx, skip_val, nadd, add_idx, add_val)) throw std::runtime_error(sdm_last_error());   // (drains the stream)
@@ -630,6 +627,7 @@ int sdm_mexcache_solve(int fw, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir
   if (!hit) {
     g_stat[ST_SOLVE_STATELESS]++;
     if ((fw ? sdm_fwblkslv : sdm_bwblkslv)(m, Ljc, Lir, Lpr, perm, nsuper, xsuper, nrhs, b, y)) throw std::runtime_error(sdm_last_error());
+    drop_notes();
     return 0;
   }
   g_stat[ST_SOLVE_RESIDENT]++;

@@ -14,10 +14,14 @@ N>1 (launched with torch.distributed.run, one rank per GPU): ONE unit per step, 
 solves replicated -- they do not shard); the block-diagonal workload deals its independent subtrees to the ranks
 (all-gather of the solution only).  `--shard replicas` runs independent units per rank instead (weak scaling).
 
-Prints ONE JSON line (rank 0) with the fields the driver expects plus `roofline`, `cpu_baseline` (the unmodified
-reference MEX, naive BLAS-1) and `cpu_baseline_blas` (the same linked to the host's OpenBLAS), `pcie_inclusive` and
-`mex_inclusive` (the unit through the built mexFunction shims, host arrays in and out of every gateway: what an unmodified
-sedumi.m pays).
+Prints ONE compact JSON line (rank 0, < 4 KB, strict JSON: `compact_line`) with the fields the driver expects plus `roofline`
+and `cpu_baseline` (the unmodified reference MEX, naive BLAS-1, one host core) and a handful of scalar extras.  Everything
+else the run measures -- per-kernel times, the phases, `cpu_baseline_blas` (the reference linked to the host's OpenBLAS),
+`pcie_inclusive`, `mex_inclusive` (the unit through the built mexFunction shims: what an unmodified sedumi.m pays), the
+other configs with `--other-configs` -- goes to `profiles/bench_detail_<tag>.json`, whose path the line names.
+
+`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment) re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` on 127.0.0.1 and passes rank 0's line through.
 """
 import argparse
 import json
@@ -37,6 +41,111 @@ NSOLVE = 4
 CONFIG_NOTE = {"contro": "examples/control07.mat (BASELINE.json configs[1])", "nb": "examples/nb.mat (BASELINE.json configs[2]; no PSD blocks: the getada.m route)",
                "arch0": "examples/arch0.mat (BASELINE.json configs[0])", "nb_lik": "nb-shaped SOCP (BASELINE.json configs[2] shape)",
                "maxcut": "MAXCUT SDP, one dense PSD block (BASELINE.json configs[3])"}
+
+LINE_LIMIT = 4096                                                   # the driver parses ONE line; keep it far below any capture limit
+ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches_per_step", "algorithmic_work_per_launch")
+BASE_KEYS = ("value", "unit", "cores", "kind", "sample")
+TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+
+
+def _tidy(x, maxlen=240):
+    """Numbers to 6 significant digits, non-finite numbers to null (strict JSON), strings cut to maxlen."""
+    if isinstance(x, (bool, type(None), int)):
+        return x
+    if isinstance(x, (float, np.floating, np.integer)):
+        x = float(x)
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return int(x) if x == int(x) and abs(x) < 1e15 else float("%.6g" % x)
+    if isinstance(x, str):
+        return x if len(x) <= maxlen else x[:maxlen - 3] + "..."
+    if isinstance(x, dict):
+        return {str(k): _tidy(v, maxlen) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_tidy(v, maxlen) for v in x]
+    return _tidy(str(x), maxlen)
+
+
+def compact_line(full, extras=None, detail=None):
+    """THE line of the driver's contract from the full result dictionary: the contract's top-level fields, `config`
+    {workload, parallelism}, `roofline` (ROOF_KEYS), `cpu_baseline` (BASE_KEYS), at most five scalar extras and the path
+    of the detail file.  Strict JSON (no NaN / Infinity), shorter than LINE_LIMIT bytes whatever the strings hold."""
+    extras = dict(list((extras or {}).items())[:5])
+    for maxlen in (240, 160, 100, 60):
+        line = {k: full.get(k) for k in TOP_KEYS}
+        cfg = full.get("config") or {}
+        line["config"] = {k: cfg.get(k) for k in ("workload", "parallelism")}
+        roof, base = full.get("roofline"), full.get("cpu_baseline")
+        line["roofline"] = {k: roof.get(k) for k in ROOF_KEYS} if isinstance(roof, dict) else None
+        line["cpu_baseline"] = {k: base.get(k) for k in BASE_KEYS} if isinstance(base, dict) else None
+        for k, v in extras.items():
+            line[k] = v if isinstance(v, (int, float, bool, type(None), np.floating, np.integer)) else str(v)
+        line["detail"] = detail
+        text = json.dumps(_tidy(line, maxlen), allow_nan=False, separators=(", ", ": "))
+        if len(text.encode()) < LINE_LIMIT:
+            return text
+    raise AssertionError("bench line does not fit %d bytes" % LINE_LIMIT)
+
+
+def write_detail(full, tag):
+    """Everything the run measured, as profiles/bench_detail_<tag>.json (strict JSON); returns the path relative to the
+    repository (None when the directory cannot be written: the line is printed regardless)."""
+    import re
+    rel = os.path.join("profiles", "bench_detail_" + re.sub(r"[^A-Za-z0-9_.-]", "_", tag) + ".json")
+    try:
+        os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+        with open(os.path.join(ROOT, rel), "w") as f:
+            json.dump(_tidy(full, 2000), f, allow_nan=False, indent=1)
+            f.write("\n")
+        return rel
+    except Exception:
+        return None
+
+
+def emit(full, tag, extras=None):
+    print(compact_line(full, extras, write_detail(full, tag)), flush=True)
+
+
+def relaunch(args):
+    """`python bench.py --gpus N` with no launcher around it: the same command under torch.distributed.run, one rank per
+    GPU, rendezvous on 127.0.0.1; rank 0's line passes through on stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """--dry-run: the launcher / process-group / line plumbing only, on CPU (gloo): barrier, K empty steps, MAX over ranks.
+    NOTHING is measured and the line says so (value null); what tests/test_bench_line.py runs at world size 1 and 2."""
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        full = {"metric": "DRY RUN (plumbing only, nothing measured)", "value": None, "unit": "IPM iters/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                "data": "none", "config": {"workload": args.workload, "parallelism": f"{world} rank(s), gloo"}, "roofline": None, "cpu_baseline": None}
+        print(compact_line(full, {"dry_run": True}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def build_workload(name, seed):
@@ -146,7 +255,7 @@ def bench_lpdense(args, device):
         plan.timer_end(3)
         ph[[0, 1, 3]] += [plan.timer_ms(0), plan.timer_ms(1), plan.timer_ms(3)]
     ph /= nprof
-    print(json.dumps({
+    emit({
         "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": args.steps / el, "unit": "IPM iters/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
@@ -155,7 +264,7 @@ def bench_lpdense(args, device):
                                f"{NSOLVE}x(fwblkslv, fwdpr1, ./Ld, bwdpr1, bwblkslv)", "parallelism": "single GPU"},
         "roofline": None, "cpu_baseline": None,
         "phases_ms_per_step": {"ada_ms": ph[0], "factor_ms": ph[1], "deninfac_ms_host_timed": ph[2], "solves_ms": ph[3],
-                               "dpr1fact_on_host_fallback": bool(host[0])}}), flush=True)
+                               "dpr1fact_on_host_fallback": bool(host[0])}}, "lpdense_n1")
     plan.close()
 
 
@@ -627,14 +736,14 @@ def bench_subtrees(args, rank, local_rank, world, torch, dist, coll_dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": args.steps / elapsed, "unit": "IPM iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{P.name}: block-diagonal SDP (BASELINE.json configs[4]), m={P.m}, {nblk} independent subtrees; "
                                    f"unit = getada1+2+3, blkchol, {NSOLVE}x(fwblkslv,./d,bwblkslv)",
                        "parallelism": f"{world} rank(s): subtrees per rank {[int(c.size // mper) for c in solver.cols_of]}, all-gather of y only"},
-            "roofline": None, "cpu_baseline": None}), flush=True)
+            "roofline": None, "cpu_baseline": None}, f"blockdiag_n{world}")
     if dist is not None:
         dist.destroy_process_group()
 
@@ -680,7 +789,7 @@ def bench_separator(args, rank, local_rank, world, torch, dist, coll_dev):
         elapsed = float(t.item())
     if rank == 0:
         own = [int(np.sum((solver.owner == r) & ~solver.top)) for r in range(world)]
-        print(json.dumps({
+        emit({
             "metric": "IPM iters/sec (factor+solve of a matrix with separators)", "value": args.steps / elapsed, "unit": "IPM iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -688,7 +797,7 @@ def bench_separator(args, rank, local_rank, world, torch, dist, coll_dev):
                                    "right-hand side uploaded per solve",
                        "parallelism": f"{world} rank(s): {int(solver.top.sum())} separator supernodes on rank 0, subtree supernodes per rank {own}; "
                                       "reduce of the subtree roots' fronts, reduce of their update vectors, broadcast of the separators' solution"},
-            "roofline": None, "cpu_baseline": None}), flush=True)
+            "roofline": None, "cpu_baseline": None}, f"grid_n{world}")
     if dist is not None:
         dist.destroy_process_group()
 
@@ -708,13 +817,22 @@ def main():
                          "factor/solves replicated in both (one dense supernode does not shard); replicas = independent units per "
                          "rank (weak scaling, no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the brief measurements of configs[2..4]")
+    ap.add_argument("--other-configs", action="store_true",
+                    help="also measure the other BASELINE configs (both scalings of the reference examples, maxcut4000, blockdiag, the maxcut8000 solve "
+                         "leg), the OpenBLAS-linked CPU baseline and the lazy MEX tiers: minutes, all of it into the detail file only")
+    ap.add_argument("--no-other-configs", action="store_true", help="(accepted for older command lines; other configs are off unless --other-configs)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (one launch per step)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / process-group / line plumbing only, on CPU; nothing is measured")
+    ap.add_argument("--tag", default=None, help="suffix of profiles/bench_detail_<workload>_n<N>[_<tag>].json")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(relaunch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
@@ -800,49 +918,51 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    roof, phases = profile_unit(plan, P, ud, min(args.steps, 50))
+    roof, phases = profile_unit(plan, P, ud, min(max(args.steps, 20), 50))
 
     if rank == 0:
-        base = base_blas = pcie = mexleg = None
+        base = base_blas = pcie = mexleg = weighted = None
         others = []
+        headline = args.workload == "control07" and world == 1
         if world == 1:
             pcie = pcie_inclusive(plan, P, d, ud, rhs, min(args.steps, 20))
             plan.upload("rhs", rhs); plan.ldlsolve()
             mexleg = mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, min(args.steps, 30), plan.download("y"))
+            if headline:
+                # a WHOLE solve of control07.mat (41 factorisations, profiles/r04_control07_whole_solve_growth_by_iteration.txt): the explicit inverse of
+                # the solves' super-block stays within the growth bound for the first 35 iterations and is beyond it for the last 6 (inverse +
+                # refinement): `value` is the first regime; this is the iteration-weighted figure from the two units measured in this run
+                beyond = measure_config("control07", local_rank, 100, 5, 20, 0, growth_max=0.0)
+                others.append(beyond)
+                if "ms_per_step" in beyond:
+                    n_in, n_out = 35, 6
+                    ms_w = (n_in * 1e3 * elapsed / args.steps + n_out * beyond["ms_per_step"]) / (n_in + n_out)
+                    weighted = {"value": 1e3 / ms_w, "unit": "IPM iters/s", "ms_per_step": ms_w, "iterations_within_growth_bound": n_in, "iterations_beyond": n_out,
+                                "ms_per_step_within": 1e3 * elapsed / args.steps, "ms_per_step_beyond": beyond["ms_per_step"],
+                                "source": "regimes per iteration from profiles/r04_control07_whole_solve_growth_by_iteration.txt (tools/driver_log.py on the GPU box)"}
             if not args.no_cpu_baseline:
-                base = cpu_baseline(P, d, ud, rhs)
-                try:
-                    from oracle import refmex
-                    ob = refmex.find_openblas()
-                except Exception:
-                    ob = None
-                if ob:
-                    base_blas = cpu_baseline(P, d, ud, rhs, budget_s=8.0, blas=ob)
-            if not args.no_other_configs and args.workload == "control07":
+                base = cpu_baseline(P, d, ud, rhs, budget_s=10.0)
+            if args.other_configs:
+                if not args.no_cpu_baseline:
+                    try:
+                        from oracle import refmex
+                        ob = refmex.find_openblas()
+                    except Exception:
+                        ob = None
+                    if ob:
+                        base_blas = cpu_baseline(P, d, ud, rhs, budget_s=8.0, blas=ob)
                 # the second scaling of the headline config (identity scaling of iteration 1 next to an ill-conditioned one),
                 # the other reference examples at both scalings, then the synthetic configs[3], [4]
                 nocpu = args.no_cpu_baseline
                 for nm, st, wu, npf, mxu, cpu in (("control07_init", 100, 5, 20, 0, 0), ("arch0", 100, 5, 20, 5, 20), ("arch0_init", 100, 5, 20, 0, 0), ("nb", 100, 5, 20, 0, 20),
                                                   ("nb_init", 100, 5, 20, 0, 0), ("maxcut4000", 10, 2, 5, 2, 1), ("blockdiag", 20, 3, 10, 2, 3)):
-                    others.append(measure_config(nm, local_rank, st, wu, npf, mxu, cpu_units=0 if nocpu else cpu))
+                    if nm != args.workload:
+                        others.append(measure_config(nm, local_rank, st, wu, npf, mxu, cpu_units=0 if nocpu else cpu))
+                others.append(solve_leg("maxcut4000", local_rank))
                 others.append(solve_leg("maxcut8000", local_rank))
-                # the headline scaling sits just under the growth bound of the explicit inverses (max_growth 9.6e3 against 1e4): the same unit
-                # with every super-block on the substitution path
-                others.append(measure_config("control07", local_rank, 100, 5, 20, 0, growth_max=0.0))
-                others.append(measure_config("control07", local_rank, 30, 3, 10, 0, growth_max=0.0, refine=0))
+                if headline:
+                    others.append(measure_config("control07", local_rank, 30, 3, 10, 0, growth_max=0.0, refine=0))
         mult = 1 if (shard_cols or world == 1) else world
-        weighted = None
-        if args.workload == "control07" and world == 1:
-            # a WHOLE solve of control07.mat (41 factorisations, profiles/r04_control07_whole_solve_growth_by_iteration.txt): the explicit inverse of
-            # the solves' super-block stays within the growth bound for the first 35 and is beyond it for the last 6 (inverse + refinement):
-            # `value` is the first regime; this is the iteration-weighted figure from the two units measured in this run
-            beyond = next((o for o in others if isinstance(o, dict) and "growth_max = 0" in str(o.get("workload", "")) and "refinement steps" in str(o.get("workload", "")) and "ms_per_step" in o), None)
-            if beyond:
-                n_in, n_out = 35, 6
-                ms_w = (n_in * 1e3 * elapsed / args.steps + n_out * beyond["ms_per_step"]) / (n_in + n_out)
-                weighted = {"value": 1e3 / ms_w, "unit": "IPM iters/s", "ms_per_step": ms_w, "iterations_within_growth_bound": n_in, "iterations_beyond": n_out,
-                            "ms_per_step_within": 1e3 * elapsed / args.steps, "ms_per_step_beyond": beyond["ms_per_step"],
-                            "source": "regimes per iteration from profiles/r04_control07_whole_solve_growth_by_iteration.txt (tools/driver_log.py on the GPU box)"}
         out = {
             "metric": "IPM iters/sec (ADA' form+factor+solve)", "value": mult * args.steps / elapsed, "unit": "IPM iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -862,7 +982,12 @@ def main():
             out["speedup_vs_cpu_reference"] = out["value"] / mult / base["value"]
         if base_blas and base_blas.get("value"):
             out["speedup_vs_cpu_reference_blas"] = out["value"] / mult / base_blas["value"]
-        print(json.dumps(out), flush=True)
+        extras = {"speedup_vs_cpu_reference": out.get("speedup_vs_cpu_reference"),
+                  "mex_inclusive_value": mexleg.get("value") if isinstance(mexleg, dict) else None,
+                  "whole_solve_weighted_value": weighted and weighted["value"],
+                  "factor_frac_of_fp64_matrix_peak": phases["factor"]["frac_of_fp64_matrix_peak"],
+                  "solves_frac_of_hbm_peak": phases["solve"]["frac_of_hbm_peak"]}
+        emit(out, f"{args.workload}_n{world}" + (f"_{args.tag}" if args.tag else ""), extras)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -323,6 +323,7 @@ void download_returned(sdm_plan *p, double *pr, double *absd, sdm_int nnz) {
   device_checksum(p, p->ada_val.p, nnz);
   gw_download(p, pr, absd);                                           // (drains the stream)
   g_last.plan = p; g_last.vals.take_with_full(pr, nnz, fold_sums(g_ck_host, nnz)); g_last.zero = false;
+  g_tok.serial = 0;                                                   // real arrays went out: a token issued earlier is stale from here on (refused loudly)
 }
 // a gateway leaves its ADA' on the device and hands out a token for it (lazy mode)
 double returned_token(sdm_plan *p, u64 pat, sdm_int m, sdm_int nnz) {
@@ -659,6 +660,7 @@ sdm_plan *sdm_mexcache_plan(sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, c
   catch (const std::exception &e) { set_error(e.what()); return nullptr; }
 }
 void sdm_mexcache_remember_factor(const double *Lpr_host, sdm_int nnz) {
+  g_epoch++;                         // a (re)factorisation on this API too: no address stays trusted across it (file header)
   if (!g.plan || !Lpr_host || nnz != g.plan->chol.nnzL) { g.have_factor = false; return; }      // (NULL: invalidate -- a refactorisation is starting)
   g.have_factor = true;
   g.lpr.take(Lpr_host, nnz);

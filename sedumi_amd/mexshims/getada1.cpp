@@ -19,7 +19,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   cache_teardown_at_exit();
   // lazy intermediates (SEDUMI_HIP_LAZY >= 1): the result is a token, the values stay on the device; at level 2 the input is getada3's token
   const double tin = lazy_token_of(ADA);
-  const bool lazy = sdm_mexcache_lazy() >= 1;
+  const bool lazy = sdm_mexcache_lazy() >= 1 && m >= 2;           // (a 1 x 1 token would be indistinguishable from a genuine 1 x 1 ADA')
   IdxView jc, ir;
   if (tin == 0.0) { jc = jc_of(ADA); ir = ir_of(ADA); }
   double tout = 0.0;

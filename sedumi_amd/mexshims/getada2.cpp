@@ -20,7 +20,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   const double tin = lazy_token_of(ADA);                             // (lazy intermediates: token in -> token out)
   IdxView jc, ir;
   if (tin == 0.0) { jc = jc_of(ADA); ir = ir_of(ADA); }
-  const bool lazy = sdm_mexcache_lazy() >= 1;
+  const bool lazy = sdm_mexcache_lazy() >= 1 && m >= 2;           // (a 1 x 1 token would be indistinguishable from a genuine 1 x 1 ADA')
   double tout = 0.0;
   if (!lazy) plhs[0] = tin == 0.0 ? sparse_like(ADA) : sparse_of_token(tin, m);   // getada2.c:153 (the values come back from the device)
   sdm_check(sdm_mexcache_getada2(m, tin == 0.0 ? jc.data() : NULL, tin == 0.0 ? ir.data() : NULL, tin == 0.0 ? mxGetPr(ADA) : NULL, lazy ? NULL : mxGetPr(plhs[0]),

@@ -20,7 +20,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   cache_teardown_at_exit();
   // lazy intermediates: the input may be a token (level >= 1); at level 2 the result is one, too (absd is always real)
   const double tin = lazy_token_of(ADA);
-  const bool lazy_out = sdm_mexcache_lazy() >= 2;
+  const bool lazy_out = sdm_mexcache_lazy() >= 2 && m >= 2;       // (a 1 x 1 token would be indistinguishable from a genuine 1 x 1 ADA')
   IdxView jc, ir;
   if (tin == 0.0) { jc = jc_of(ADA); ir = ir_of(ADA); }
   double tout = 0.0;

@@ -389,6 +389,7 @@ k_sinv_follow(const double *F, const double *DT, double *S, double *STr, FrontTa
 // Fs = front, (k0, k0) = position of the block.  Sd = 64*TP doubles of LDS.
 constexpr int BSC = 32;          // columns per step of the substitution fallback (its LDS tile: BSC x (BSC + 1) doubles)
 constexpr int BSP = BSC + 1;
+#define SDM_DIAG_SMEM(W) ((size_t)((W) + BSC * BSP) * sizeof(double))   // (measured: the allocation costs the launch nothing, profiles/r08*)
 __device__ __noinline__ void block_solve_fw(const double *Fs, int ld, int k0, int nb, double *w, double *Sd) {
   const int tid = threadIdx.x, lane = tid & 63;
   for (int kk = 0; kk < nb; kk += BSC) {
@@ -595,6 +596,55 @@ __device__ __forceinline__ double row_dot(const double *__restrict__ M, const do
   for (int o = LPR / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
   return a;
 }
+// Round 6 (tools/ubench/ubench11, profiles/r08c_*): a launch of a sweep is a BURST, not a stream -- every workgroup of it is resident at once,
+// so what a launch takes is its boundary + the longest wavefront's chain of round trips; a wavefront that loops twice over 8 KB of a 16 KB row pays
+// two of them (triangle of 2048: 6.7 us against 5.5 with every wavefront exactly one trip, full rows 8.0 -> 7.5).  row_seg = the pairs
+// [plo, phi) of row_dot's sum, NL 16-byte loads per lane and trip; tri_task deals the rows of a triangular block so that a wavefront never loops:
+// a row of up to SEGN entries to one wavefront (four rows per workgroup), a longer one to TWO wavefronts of one workgroup (two rows per workgroup)
+// whose partial sums meet in LDS and are added in a fixed order.
+template <bool GATHER, int NL>
+__device__ __forceinline__ double row_seg(const double *__restrict__ M, const double *__restrict__ x, const int *__restrict__ px, int n, int jlo, int plo, int phi, int lane) {
+  double a0 = 0.0, a1 = 0.0;
+  const sdm_double2 *M2 = (const sdm_double2 *)M;
+  for (int p0 = plo; p0 < phi; p0 += 64 * NL) {
+    sdm_double2 v[NL];
+    double x0[NL], x1[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+      const int pi = p0 + lane + 64 * k, pc = min(pi, phi - 1);
+      v[k] = M2[pc];
+      const int j0 = 2 * pc, j1 = min(2 * pc + 1, n - 1);
+      x0[k] = GATHER ? x[px[j0]] : x[j0];
+      x1[k] = GATHER ? x[px[j1]] : x[j1];
+    }
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+      const int pi = p0 + lane + 64 * k;
+      const bool in0 = pi < phi && 2 * pi >= jlo, in1 = pi < phi && 2 * pi + 1 < n && 2 * pi + 1 >= jlo;
+      a0 += (in0 ? v[k].x : 0.0) * (in0 ? x0[k] : 0.0);
+      a1 += (in1 ? v[k].y : 0.0) * (in1 ? x1[k] : 0.0);
+    }
+  }
+  double a = a0 + a1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  return a;
+}
+constexpr int SEGN = 1024;                                           // entries of a row one wavefront takes in one trip (8 loads of 16 bytes per lane)
+// workgroup b, wavefront `wave` of a triangular block of nb rows -> t = the row's rank by length (its row has t + 1 entries; -1: none), seg of nseg
+__device__ __forceinline__ void tri_task(int nb, int b, int wave, int &t, int &seg, int &nseg) {
+  const int n1 = min(nb, SEGN), wg1 = (n1 + 3) >> 2;
+  if (b < wg1) { t = 4 * b + wave; seg = 0; nseg = 1; if (t >= n1) t = -1; }
+  else { t = n1 + 2 * (b - wg1) + (wave >> 1); seg = wave & 1; nseg = 2; if (t >= nb) t = -1; }
+}
+__host__ __device__ inline int tri_grid(int nb) { const int n1 = nb < SEGN ? nb : SEGN; return (n1 + 3) / 4 + (nb - n1 + 1) / 2; }
+// the two partial sums of a split row -> its first wavefront (every wavefront of the workgroup calls this)
+__device__ __forceinline__ double seg_combine(double *part, double a, int wave, int lane, int nseg) {
+  if (nseg == 1) return a;                                            // (uniform for the workgroup)
+  if (lane == 0) part[wave] = a;
+  __syncthreads();
+  return part[wave & ~1] + part[wave | 1];
+}
 // transposed copy of the rows of L below super-block Pb of a front (64x64 tiles through LDS): LT[r*W + c] = L((Pb+1) W + r, Pb W + c)
 __device__ __forceinline__ int64_t lt_boff(int ns, int W, int Pb) { return (int64_t)W * ((int64_t)Pb * ns - (int64_t)W * Pb * (Pb + 1) / 2); }
 __global__ void __launch_bounds__(ST)
@@ -647,6 +697,8 @@ __global__ void __launch_bounds__(ST)
 k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTab tab, const int *list, const double *wv, const double *src,
            const int *perm, double *y, const unsigned long long *sb_g, double thr, int Pb, int gather0, FwBatch bt,
            double *zdiv, const double *dscale, int W, int mode, double thr2, const double *resid, int *noted, int seq, int mark) {
+  const bool WIDE = W > 256;                                           // (uniform for the launch: the grid is sized accordingly)
+  const bool gather = gather0 && Pb == 0 && mode != 2;
   // mode 0: the sweep as planned for well-conditioned factors (blocks beyond the bound are substituted by workgroup 0);
   // mode 1: the first of the refinement launches: blocks of kind 1 are applied as their inverse like the good ones;
   // mode 2: blocks of kind 1 only:  y_P += inv(L_PP) r_P  with the residual r_P = t_P - L_PP y_P of k_sfw_resid (`resid`)
@@ -659,16 +711,41 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTa
   const int c0 = Pb * W;
   if (c0 >= ns) return;
   const int nb = min(W, ns - c0);
-  if ((W <= 256 ? 16 : 4) * (int)blockIdx.x >= nb) return;
+  if (!WIDE ? 16 * (int)blockIdx.x >= nb : (int)blockIdx.x >= tri_grid(nb)) return;
   wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; if (src) src += (int64_t)blockIdx.z * bt.src;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int sld = FT(sld);
   const double *a = wv + FT(woff) + c0;
-  const int cls = sb_class(sb_g, FT(sboff) + Pb, thr, thr2);
-  if (mode == 2 && cls != 1) return;
-  if (mode == 2) a = resid + first + c0;
-  const bool gather = gather0 && Pb == 0 && mode != 2;
+  int cls = -1;
+  if (mode == 2) {                                                     // (the refinement launches: blocks within the bound leave them at once)
+    cls = sb_class(sb_g, FT(sboff) + Pb, thr, thr2);
+    if (cls != 1) return;
+    a = resid + first + c0;
+  }
   const int *pp = perm + first + c0;
+  // the product of the planned path FIRST: its loads do not wait for the block's class (a scalar load and a branch in front of them was a
+  // round trip of its own); a block beyond the bound throws the sum away below
+  double sum = 0.0;
+  int r = -1, l16 = lane & 15;
+  __shared__ double part[ST / 64];
+  if (!WIDE) {                                                         // 16 rows per workgroup (the grid is sized accordingly)
+    r = 16 * blockIdx.x + 4 * wave + (lane >> 4);
+    const int rc = min(r, nb - 1);
+    const double *M = STr + FT(soff) + (int64_t)c0 * sld + (int64_t)rc * sld;
+    sum = gather ? row_dot<true, 16>(M, src, pp, rc + 1, 0, l16) : row_dot<false, 16>(M, a, nullptr, rc + 1, 0, l16);
+    if (l16 != 0 || r >= nb) r = -1;
+  } else {
+    int seg, nseg;
+    tri_task(nb, blockIdx.x, wave, r, seg, nseg);
+    if (r >= 0) {
+      const double *M = STr + FT(soff) + (int64_t)c0 * sld + (int64_t)r * sld;
+      const int npair = (r + 2) >> 1, plo = seg * (SEGN / 2), phi = nseg == 1 ? npair : min(npair, plo + SEGN / 2);
+      sum = gather ? row_seg<true, 8>(M, src, pp, r + 1, 0, plo, phi, lane) : row_seg<false, 8>(M, a, nullptr, r + 1, 0, plo, phi, lane);
+    }
+    sum = seg_combine(part, sum, wave, lane, nseg);
+    if (lane != 0 || seg != 0) r = -1;
+  }
+  if (cls < 0) cls = sb_class(sb_g, FT(sboff) + Pb, thr, thr2);
   // (a block of kind 1 met by a sweep: the host plans the refinement launches while such blocks keep turning up -- solve_refines)
   if (cls == 1 && mode != 2 && blockIdx.x == 0 && tid == 0 && noted) sdm_host_note(noted, seq);
   if (cls == 2 || (cls == 1 && mode == 0)) {
@@ -683,23 +760,7 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTa
     }
     return;
   }
-  if (W <= 256) {                                                      // (uniform for the launch: the grid is sized accordingly) 16 rows per workgroup
-    const int r = 16 * blockIdx.x + 4 * wave + (lane >> 4), l16 = lane & 15;
-    const int rc = min(r, nb - 1);
-    const double *M = STr + FT(soff) + (int64_t)c0 * sld + (int64_t)rc * sld;
-    const double sum = gather ? row_dot<true, 16>(M, src, pp, rc + 1, 0, l16) : row_dot<false, 16>(M, a, nullptr, rc + 1, 0, l16);
-    if (l16 == 0 && r < nb) {
-      const double yv = mode == 2 ? y[first + c0 + r] + sum : sum;
-      y[first + c0 + r] = yv;
-      if (zdiv) { const double dk = dscale[first + c0 + r]; zdiv[first + c0 + r] = yv / (dk > 0.0 ? dk : 1.0); }
-    }
-    return;
-  }
-  const int r = 4 * blockIdx.x + wave;
-  if (r >= nb) return;
-  const double *M = STr + FT(soff) + (int64_t)c0 * sld + (int64_t)r * sld;
-  const double sum = gather ? row_dot<true>(M, src, pp, r + 1, 0, lane) : row_dot<false>(M, a, nullptr, r + 1, 0, lane);
-  if (lane == 0) {
+  if (r >= 0) {
     const double yv = mode == 2 ? y[first + c0 + r] + sum : sum;
     y[first + c0 + r] = yv;
     if (zdiv) { const double dk = dscale[first + c0 + r]; zdiv[first + c0 + r] = yv / (dk > 0.0 ? dk : 1.0); }
@@ -751,19 +812,31 @@ k_sfw_resid(const double *__restrict__ F, FrontTab tab, const int *list, const d
 
 // step Pb, the front's OWN rows of later super-blocks:  - L(r, P) y_P  along the rows of the transposed copy LT
 // assign0 (Pb = 0 of a leaf level): the vector a has not been initialised: a = right-hand side - sum.
+#ifndef SDM_ROWS_NL
+#define SDM_ROWS_NL 4            // loads of 16 bytes per lane and trip in the full-row launches (ubench11: two wavefronts per 2048-entry row, 4 loads x 2 trips)
+#endif
 __global__ void __launch_bounds__(ST)
 k_sfw_rows(const double *__restrict__ LT, FrontTab tab, const int *list, double *wv, const double *src, const int *perm, const double *y,
            int Pb, int assign0, FwBatch bt, int W) {
+  // W > SEGN: two wavefronts per row (two rows per workgroup), else one (four rows per workgroup): uniform for the launch, the grid is sized accordingly
+  __shared__ double part[ST / 64];
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), first = FT(first);
   const int R0 = (Pb + 1) * W;
-  const int rl = 4 * blockIdx.x + (threadIdx.x >> 6);
-  if (R0 + rl >= ns) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nseg = W > SEGN ? 2 : 1, seg = nseg == 2 ? (wave & 1) : 0;
+  const int rl = nseg == 2 ? 2 * blockIdx.x + (wave >> 1) : 4 * blockIdx.x + wave;
+  if ((nseg == 2 ? 2 : 4) * (int)blockIdx.x + R0 >= ns) return;       // (the whole workgroup)
   wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; if (src) src += (int64_t)blockIdx.z * bt.src;
-  const int lane = threadIdx.x & 63;
-  const double *M = LT + FT(ltoff) + lt_boff(ns, W, Pb) + (int64_t)rl * W;
-  const double sum = row_dot<false>(M, y + first + Pb * W, nullptr, W, 0, lane);
-  if (lane == 0) {
+  const bool live = R0 + rl < ns;
+  double sum = 0.0;
+  if (live) {
+    const double *M = LT + FT(ltoff) + lt_boff(ns, W, Pb) + (int64_t)rl * W;
+    const int npair = W >> 1, per = npair / nseg;
+    sum = row_seg<false, SDM_ROWS_NL>(M, y + first + Pb * W, nullptr, W, 0, seg * per, (seg + 1) * per, lane);
+  }
+  sum = seg_combine(part, sum, wave, lane, nseg);
+  if (lane == 0 && seg == 0 && live) {
     double *a = wv + FT(woff);
     const int r = R0 + rl;
     a[r] = (assign0 ? src[perm[first + r]] : a[r]) - sum;
@@ -855,11 +928,39 @@ k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
   const int rb = Q * W;
   if (rb >= ns) return;
   const int nb = min(W, ns - rb);
-  if ((W <= 256 ? 16 : 4) * (int)blockIdx.x >= nb) return;
+  if (W <= 256 ? 16 * (int)blockIdx.x >= nb : (int)blockIdx.x >= tri_grid(nb)) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int cls = sb_class(sb_g, FT(sboff) + Q, thr, thr2);
-  if (mode == 2 && cls != 1) return;
+  int cls = -1;
+  if (mode == 2) {
+    cls = sb_class(sb_g, FT(sboff) + Q, thr, thr2);
+    if (cls != 1) return;
+  }
   const double *vp = mode == 2 ? wv + FT(woff) + rb : y + first + rb;
+  const int sld = FT(sld);
+  // (the planned path's product before the block's class is looked at: see k_sfw_diag)
+  double sum = 0.0;
+  int c = -1;
+  __shared__ double part[ST / 64];
+  if (W <= 256) {                                                     // 16 columns per workgroup (see k_sfw_diag)
+    c = 16 * blockIdx.x + 4 * wave + (lane >> 4);
+    const int l16 = lane & 15, cc = min(c, nb - 1), ce = cc & ~1;
+    const double *M = S + FT(soff) + (int64_t)rb * sld + (int64_t)cc * sld + ce;
+    sum = row_dot<false, 16>(M, vp + ce, nullptr, nb - ce, cc - ce, l16);
+    if (l16 != 0 || c >= nb) c = -1;
+  } else {
+    int t, seg, nseg;
+    tri_task(nb, blockIdx.x, wave, t, seg, nseg);                     // column nb - 1 - t has t + 1 entries from the diagonal down
+    if (t >= 0) {
+      c = nb - 1 - t;
+      const int ce = c & ~1;                                          // 16-byte aligned start (the entry above the diagonal is skipped: jlo)
+      const double *M = S + FT(soff) + (int64_t)rb * sld + (int64_t)c * sld + ce;
+      const int n = nb - ce, npair = (n + 1) >> 1, plo = seg * (SEGN / 2), phi = nseg == 1 ? npair : min(npair, plo + SEGN / 2);
+      sum = row_seg<false, 8>(M, vp + ce, nullptr, n, c - ce, plo, phi, lane);
+    }
+    sum = seg_combine(part, sum, wave, lane, nseg);
+    if (lane != 0 || seg != 0) c = -1;
+  }
+  if (cls < 0) cls = sb_class(sb_g, FT(sboff) + Q, thr, thr2);
   if (cls == 1 && mode != 2 && blockIdx.x == 0 && tid == 0 && noted) sdm_host_note(noted, seq);
   if (cls == 2 || (cls == 1 && mode == 0)) {
     if (blockIdx.x != 0) return;
@@ -869,21 +970,7 @@ k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
     for (int i = tid; i < nb; i += ST) { xfin[first + rb + i] = xs[i]; if (yout) yout[perm[first + rb + i]] = xs[i]; }
     return;
   }
-  const int sld = FT(sld);
-  if (W <= 256) {                                                      // 16 columns per workgroup (see k_sfw_diag)
-    const int c = 16 * blockIdx.x + 4 * wave + (lane >> 4), l16 = lane & 15;
-    const int cc = min(c, nb - 1), ce = cc & ~1;
-    const double *M = S + FT(soff) + (int64_t)rb * sld + (int64_t)cc * sld + ce;
-    const double sum = row_dot<false, 16>(M, vp + ce, nullptr, nb - ce, cc - ce, l16);
-    if (l16 == 0 && c < nb) { const double xv = mode == 2 ? xfin[first + rb + c] + sum : sum; xfin[first + rb + c] = xv; if (yout) yout[perm[first + rb + c]] = xv; }
-    return;
-  }
-  const int c = 4 * blockIdx.x + wave;
-  if (c >= nb) return;
-  const int ce = c & ~1;                                              // 16-byte aligned start (the entry above the diagonal is skipped: jlo)
-  const double *M = S + FT(soff) + (int64_t)rb * sld + (int64_t)c * sld + ce;
-  const double sum = row_dot<false>(M, vp + ce, nullptr, nb - ce, c - ce, lane);
-  if (lane == 0) { const double xv = mode == 2 ? xfin[first + rb + c] + sum : sum; xfin[first + rb + c] = xv; if (yout) yout[perm[first + rb + c]] = xv; }
+  if (c >= 0) { const double xv = mode == 2 ? xfin[first + rb + c] + sum : sum; xfin[first + rb + c] = xv; if (yout) yout[perm[first + rb + c]] = xv; }
 }
 
 // r_Q = v_Q - L_QQ' x_Q for the super-blocks of kind 1 (see k_sfw_resid): a column of L is contiguous, one wavefront per column;
@@ -910,15 +997,20 @@ k_sbw_resid(const double *__restrict__ F, FrontTab tab, const int *list, const d
 // of L is contiguous there), one wavefront per column
 __global__ void __launch_bounds__(ST)
 k_sbw_step(const double *__restrict__ F, FrontTab tab, const int *list, double *y, const double *xfin, int Q, int W) {
+  // (W > SEGN: two wavefronts per column, as in k_sfw_rows)
+  __shared__ double part[ST / 64];
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), first = FT(first), ld = FT(ld);
   const int rb = Q * W;
   if (rb >= ns) return;
   const int nbq = min(W, ns - rb);
-  const int c = 4 * blockIdx.x + (threadIdx.x >> 6);                // < rb by the grid
-  const int lane = threadIdx.x & 63;
-  const double sum = row_dot<false>(F + FT(foff) + (int64_t)c * ld + rb, xfin + first + rb, nullptr, nbq, 0, lane);
-  if (lane == 0) y[first + c] -= sum;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nseg = W > SEGN ? 2 : 1, seg = nseg == 2 ? (wave & 1) : 0;
+  const int c = nseg == 2 ? 2 * blockIdx.x + (wave >> 1) : 4 * blockIdx.x + wave;                // < rb by the grid
+  const int npair = (nbq + 1) >> 1, per = nseg == 2 ? ((npair + 1) >> 1) : npair;
+  double sum = row_seg<false, SDM_ROWS_NL>(F + FT(foff) + (int64_t)c * ld + rb, xfin + first + rb, nullptr, nbq, 0, seg * per, min(npair, (seg + 1) * per), lane);
+  sum = seg_combine(part, sum, wave, lane, nseg);
+  if (lane == 0 && seg == 0) y[first + c] -= sum;
 }
 #undef FT
 
@@ -1043,19 +1135,19 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
     if (!(what & 2)) continue;
     for (int Pb = 0; Pb < L.nsb; Pb++) {
       const int nbmax = std::min(W, L.maxns - Pb * W);
-      const dim3 gdiag(W <= 256 ? (nbmax + 15) / 16 : (nbmax + 3) / 4, L.nfronts, nrhs);
-      SDM_KLAUNCH(P, k_sfw_diag, gdiag, dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.ST.p, tab, list, wv, rhs,
+      const dim3 gdiag(W <= 256 ? (nbmax + 15) / 16 : tri_grid(nbmax), L.nfronts, nrhs);
+      SDM_KLAUNCH(P, k_sfw_diag, gdiag, dim3(ST), SDM_DIAG_SMEM(W), C.fronts.p, C.ST.p, tab, list, wv, rhs,
                   C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W, refine ? 1 : 0, C.refine_max, (const double *)nullptr, noted, seq, marked ? -1 : seq - 1);
       marked = true;
       for (int it = 0; refine && it < REFINE_STEPS; it++) {            // (blocks within the bound leave these launches at once)
         SDM_KLAUNCH(P, k_sfw_resid, dim3((nbmax + 63) / 64, L.nfronts), dim3(RT), 0, C.fronts.p, tab, list, wv, rhs, C.d_perm.p, y, C.xfin.p, C.sb_g.p, thr,
                     C.refine_max, Pb, gather, W);
-        SDM_KLAUNCH(P, k_sfw_diag, gdiag, dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.ST.p, tab, list, wv, rhs,
+        SDM_KLAUNCH(P, k_sfw_diag, gdiag, dim3(ST), SDM_DIAG_SMEM(W), C.fronts.p, C.ST.p, tab, list, wv, rhs,
                     C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W, 2, C.refine_max, (const double *)C.xfin.p, (int *)nullptr, seq, -1);
       }
       const int assign0 = (gather && Pb == 0) ? 1 : 0;
       if (L.maxns > (Pb + 1) * W)                                    // the fronts' own rows of later super-blocks
-        SDM_KLAUNCH(P, k_sfw_rows, dim3((L.maxns - (Pb + 1) * W + 3) / 4, L.nfronts, nrhs), dim3(ST), 0, C.LT.p, tab, list, wv, rhs, C.d_perm.p, y, Pb,
+        SDM_KLAUNCH(P, k_sfw_rows, dim3(W > SEGN ? (L.maxns - (Pb + 1) * W + 1) / 2 : (L.maxns - (Pb + 1) * W + 3) / 4, L.nfronts, nrhs), dim3(ST), 0, C.LT.p, tab, list, wv, rhs, C.d_perm.p, y, Pb,
                     assign0, bt, W);
       if (L.slabs_fw[Pb] > 0)                                        // the rows below the supernodes
         SDM_KLAUNCH(P, k_sfw_step, dim3(L.slabs_fw[Pb], L.nfronts, nrhs), dim3(ST), 0, C.fronts.p, tab, list, wv, y, Pb, assign0, bt, W);
@@ -1085,16 +1177,16 @@ static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double 
       SDM_KLAUNCH(P, k_sbw_init, dim3((L.maxns + SROWS - 1) / SROWS, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, dscale);
     for (int Q = L.nsb - 1; Q >= 0; Q--) {
       const int nbmax = std::min(W, L.maxns - Q * W);
-      const dim3 gdiag(W <= 256 ? (nbmax + 15) / 16 : (nbmax + 3) / 4, L.nfronts);
-      SDM_KLAUNCH(P, k_sbw_diag, gdiag, dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
+      const dim3 gdiag(W <= 256 ? (nbmax + 15) / 16 : tri_grid(nbmax), L.nfronts);
+      SDM_KLAUNCH(P, k_sbw_diag, gdiag, dim3(ST), SDM_DIAG_SMEM(W), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
                   C.d_perm.p, C.sb_g.p, thr, Q, W, refine ? 1 : 0, C.refine_max, (const double *)nullptr, noted, seq, marked ? -1 : seq - 1);
       marked = true;
       for (int it = 0; refine && it < REFINE_STEPS; it++) {
         SDM_KLAUNCH(P, k_sbw_resid, dim3((nbmax + 3) / 4, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, C.wvec.p, C.sb_g.p, thr, C.refine_max, Q, W);
-        SDM_KLAUNCH(P, k_sbw_diag, gdiag, dim3(ST), (size_t)(W + BSC * BSP) * sizeof(double), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
+        SDM_KLAUNCH(P, k_sbw_diag, gdiag, dim3(ST), SDM_DIAG_SMEM(W), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
                     C.d_perm.p, C.sb_g.p, thr, Q, W, 2, C.refine_max, (const double *)C.wvec.p, (int *)nullptr, seq, -1);
       }
-      if (Q > 0) SDM_KLAUNCH(P, k_sbw_step, dim3(Q * (W / 4), L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, Q, W);
+      if (Q > 0) SDM_KLAUNCH(P, k_sbw_step, dim3(W > SEGN ? Q * (W / 2) : Q * (W / 4), L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, Q, W);
     }
   }
 }

@@ -337,7 +337,8 @@ class Plan:
         for rec in buf.value.decode().split(";"):
             if rec:
                 name, calls, ms = rec.rsplit(":", 2)
-                out[name] = (int(calls), float(ms))
+                c0, m0 = out.get(name, (0, 0.0))
+                out[name] = (c0 + int(calls), m0 + float(ms))
         return out
 
     # --------------------------------------------------------------- timing

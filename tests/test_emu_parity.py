@@ -432,7 +432,7 @@ def test_one_launch_front_pivot_rule(refmex, m, maxu):
     helpers.check_one_launch_pivot_rule(refmex, m, maxu)
 
 
-@pytest.mark.parametrize("m,thr", [(90, None), (300, None), (666, None), (700, 0.0), (700, 1e-3), (256, 0.0), (530, None)])
+@pytest.mark.parametrize("m,thr", [(90, None), (300, None), (666, None), (700, 0.0), (700, 1e-3), (256, 0.0), (530, None), (1100, None)])   # (1100: rows split over two wavefronts)
 def test_solve_widths(m, thr):
     helpers.check_solve_widths(m, thr)
 

@@ -10,6 +10,9 @@ import numpy as np
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
+if os.environ.get("SDM_LIB"):                      # a measurement variant (python -m sedumi_amd.build --variant <tag> <flags>)
+    from sedumi_amd import capi
+    capi.use_library(os.path.join(ROOT, "sedumi_amd", "lib", os.environ["SDM_LIB"]))
 import bench  # noqa: E402
 
 for name in sys.argv[1:] or ["control07"]:

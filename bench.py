@@ -573,7 +573,7 @@ def measure_config(name, device, steps, warmup, nprof, mex_units=0, growth_max=N
             yres = plan.download("y")
             mexleg = mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, mex_units, yres)
             if name.startswith("maxcut") or name.startswith("blockdiag"):
-                mexlazy = {"level_%d" % lv: mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, mex_units, yres, lazy=lv) for lv in (1, 2)}
+                mexlazy = {"level_%d" % lv: mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, mex_units, yres, lazy=lv) for lv in (0, 1)}
         out = {"workload": name, "problem": P.name, "m": int(P.m), "nnzL": int(plan.nnzL), "nsuper": int(plan._xsuper.size - 1),
                "ms_per_step": 1e3 * el / steps, "iters_per_s": steps / el, "steps": steps,
                "dominant_kernel": roof and {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step")},
@@ -631,13 +631,14 @@ def pcie_inclusive(plan, P, d, ud, rhs, steps):
                     f"synchronous copies): {8 * (3 * nA + 2 * nL) / 1e6:.1f} MB per unit"}
 
 
-def mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, units, y_resident=None, mex_dir=None, lazy=0):
+def mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, units, y_resident=None, mex_dir=None, lazy=None):
     """The unit as an UNMODIFIED sedumi.m would run it: through the built mexFunction shims (sedumi_amd/lib/mex/<name>.so, the
     sources of sedumi_amd/mexshims compiled against the package's MEX host -- no MATLAB / Octave in this image), host mxArrays in
     and out of every one of the 4 + 2x4 gateway calls, outputs handed to the next gateway by reference as MATLAB does
     (sedumi_amd.mexhost.iteration_units).  Times only what happens inside mexFunction, like cpu_baseline does for the reference
     MEX.  The library's process-wide cache (sdm_mexcache.hip) keeps the analysis of At / K / the patterns and the value arrays that
-    travel between gateways on the device.  Never `value`."""
+    travel between gateways on the device.  lazy = None: the library's default (level 2 since round 6: getada1 / getada2 / getada3 hand a
+    token to the next gateway, ADA' stays on the device; SEDUMI_HIP_LAZY=0 turns it off); 0 / 1 / 2: that level.  Never `value`."""
     try:
         import ctypes
         import scipy.sparse as sp
@@ -662,12 +663,13 @@ def mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, units, y_resident=None, mex_dir
         lib = capi.lib()
         st = (ctypes.c_int64 * 16)()
         lib.sdm_mexcache_clear()
-        lib.sdm_mexcache_set_lazy(int(lazy))                          # (0: every gateway returns the reference's arrays, the default)
+        lib.sdm_mexcache_set_lazy(-1 if lazy is None else int(lazy))   # (-1: as SEDUMI_HIP_LAZY says, unset = level 2; 0: every gateway returns the reference's arrays)
+        level = int(lib.sdm_mexcache_lazy())
         host = mexhost.MexHost(mex_dir)
         try:
             times, y = mexhost.iteration_units(host, At, np.asarray(P.Ablkjc)[:, 2], Aord, K, dstruct, {"q": Qm}, ud, L, ADA, PARS, rhs, units + 1, NSOLVE)
         finally:
-            lib.sdm_mexcache_set_lazy(0)
+            lib.sdm_mexcache_set_lazy(-1)
         lib.sdm_mexcache_stats(st, ctypes.c_int64(16))
         lib.sdm_mexcache_clear()
         first, rest = times[0], times[1:]
@@ -682,10 +684,12 @@ def mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, units, y_resident=None, mex_dir
                                   "ms_per_unit": 1e-6 * float(st[13]) / len(times), "checksums_per_unit": float(st[14]) / len(times),
                                   "rule": "residency is decided by a checksum of every word of the host array (sdm_mexcache.hip): arrays up to 65536 words at every "
                                           "presentation, larger ones once per address and epoch (= between two blkchol calls)"},
-               **({"lazy_level": int(lazy), "lazy": "opt-in SEDUMI_HIP_LAZY=%d: getada1 / getada2%s return a token, ADA' stays on the device (sdm_mexcache.hip)" % (lazy, " / getada3" if lazy > 1 else "")} if lazy else {}),
+               "lazy_level": level,
+               "lazy": ("level %d%s: getada1 / getada2%s return a token, ADA' stays on the device (sdm_mexcache.hip)" % (level, " (the default)" if lazy is None else "", " / getada3" if level > 1 else "")
+                        if level else "level 0 (SEDUMI_HIP_LAZY=0): every gateway returns the reference's arrays"),
                "note": "mexFunction shims (sedumi_amd/lib/mex) on the MEX host of the package; host mxArrays cross PCIe at every gateway: scaling "
-                       "data and right-hand sides up, ADA' (3x), absd, L.L, L.d, pivot lists and solutions down; the first unit (analysis of At, "
-                       "the patterns and the symbolic factor, once per solve) is reported separately"}
+                       "data and right-hand sides up, absd, L.L, L.d, pivot lists and solutions down (level 0: ADA' three times as well); the first unit "
+                       "(analysis of At, the patterns and the symbolic factor, once per solve) is reported separately"}
         if y_resident is not None:
             out["rel_diff_vs_resident_tier"] = float(np.linalg.norm(y - y_resident) / max(np.linalg.norm(y_resident), 1e-300))
         return out
@@ -943,6 +947,8 @@ def main():
             if not args.no_cpu_baseline:
                 base = cpu_baseline(P, d, ud, rhs, budget_s=10.0)
             if args.other_configs:
+                others.append({"workload": args.workload + " (mex_inclusive at lazy level 0: every gateway returns the reference's arrays)",
+                               "mex_inclusive": mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, min(args.steps, 30), None, lazy=0)})
                 if not args.no_cpu_baseline:
                     try:
                         from oracle import refmex

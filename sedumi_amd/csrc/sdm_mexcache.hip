@@ -240,7 +240,7 @@ struct Finger {
 struct Pattern { sdm_int ncol = -1; Finger jc, ir; u64 id = 0, used = 0; std::vector<sdm_int> jcc, irc; };   // (jcc / irc: a host copy, lazy mode only)
 Pattern g_pat[12];
 u64 g_next_id = 1, g_clock = 0;
-// ---- lazy intermediates (opt-in: SEDUMI_HIP_LAZY = 1 | 2, or sdm_mexcache_set_lazy).  sedumi.m:450-458 hands ADA' from getada1 to getada2
+// ---- lazy intermediates (SEDUMI_HIP_LAZY = 0 | 1 | 2, or sdm_mexcache_set_lazy; default 2 since round 6).  sedumi.m:450-458 hands ADA' from getada1 to getada2
 // to getada3 to blkchol and never looks at it.  Level 1: getada1.mex / getada2.mex return, instead of ADA' (values + a copy of the pattern,
 // 2 x 128 MB for MAXCUT-4000, each read again by the next gateway's content check), a TOKEN: an m x m sparse matrix with the one nonzero
 // (1,1) = LAZY_BASE + a serial number that is never reused; the values stay on the device.  A gateway handed a token takes the
@@ -252,9 +252,18 @@ int g_lazy = -1;                                             // -1: not read fro
 u64 g_serial = 0;
 struct { u64 serial = 0, pat = 0; sdm_int m = 0, nnz = 0; } g_tok;      // the current token: which pattern the device's ADA' (g_last.plan) has
 int lazy_level() {
-  if (g_lazy < 0) { const char *e = getenv("SEDUMI_HIP_LAZY"); g_lazy = e ? std::max(0, std::min(2, atoi(e))) : 0; }
+  // default (round 6): level 2 -- every call site of the reference hands the array on untouched (sedumi.m:450-458, optstep.m:68-76; symbchol.m:62-73
+  // and sedumi.m:401 read the global before the first getada1): tests/test_mexshims.py runs whole solves through the shims at levels 0 and 2
+  // and compares the logs.  SEDUMI_HIP_LAZY=0 gives the reference's arrays back at every gateway.
+  if (g_lazy < 0) { const char *e = getenv("SEDUMI_HIP_LAZY"); g_lazy = e ? std::max(0, std::min(2, atoi(e))) : 2; }
   return g_lazy;
 }
+// the tokens handed out last (serial -> pattern): getada1.mex needs only the PATTERN of the ADA' it is given (it starts from zero, getada1.c:222-225),
+// so it also accepts a token that is no longer current -- sedumi.m's global still holds the token of ITS last getada3 when optstep.m has run the
+// three gateways on its own copy in between
+struct TokRec { u64 serial = 0, pat = 0; sdm_int m = 0, nnz = 0; };
+TokRec g_tok_hist[16];
+void remember_token(u64 serial, u64 pat, sdm_int m, sdm_int nnz) { TokRec &r = g_tok_hist[serial & 15]; r.serial = serial; r.pat = pat; r.m = m; r.nnz = nnz; }
 bool is_token(double t) { return t > LAZY_BASE && t < LAZY_BASE + 4294967296.0; }
 Pattern *pattern_by_id(u64 id) { for (auto &p : g_pat) if (p.id == id) return &p; return nullptr; }
 u64 intern(sdm_int ncol, const sdm_int *jc, const sdm_int *ir) {
@@ -330,6 +339,7 @@ double returned_token(sdm_plan *p, u64 pat, sdm_int m, sdm_int nnz) {
   SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
   g_last.plan = p; g_last.vals.forget(); g_last.zero = false;
   g_tok.serial = ++g_serial; g_tok.pat = pat; g_tok.m = m; g_tok.nnz = nnz;
+  remember_token(g_tok.serial, pat, m, nnz);
   return LAZY_BASE + (double)g_tok.serial;
 }
 // the pattern id of the ADA' a token stands for; throws unless it is the current token
@@ -337,6 +347,15 @@ u64 token_pattern(double tok, sdm_int m) {
   if (!g_last.plan || !is_token(tok) || tok != LAZY_BASE + (double)g_tok.serial || g_tok.m != m)
     throw std::runtime_error("lazy ADA token is not the current one (SEDUMI_HIP_LAZY: the array a getada gateway returned must be handed to the next gateway untouched)");
   return g_tok.pat;
+}
+// the pattern id behind ANY of the last sixteen tokens (getada1.mex: pattern only); throws when it is not remembered
+u64 token_pattern_any(double tok, sdm_int m) {
+  if (is_token(tok)) {
+    const u64 serial = (u64)(tok - LAZY_BASE);
+    const TokRec &r = g_tok_hist[serial & 15];
+    if (serial != 0 && r.serial == serial && r.m == m) return r.pat;
+  }
+  throw std::runtime_error("lazy ADA token is not one of the last sixteen handed out (SEDUMI_HIP_LAZY: getada1 needs the pattern behind the token it is given)");
 }
 void ada_input_token(sdm_plan *p, sdm_int nnz) {
   g_stat[ST_ADA_RESIDENT]++;
@@ -377,6 +396,7 @@ void drop_all() {
   if (g_ck_host) { (void)hipHostFree(g_ck_host); g_ck_host = nullptr; }
   if (g_pin) { (void)hipHostFree(g_pin); g_pin = nullptr; g_pin_n = 0; }
   for (auto &p : g_pat) p = Pattern();
+  for (auto &t : g_tok_hist) t = TokRec();
   g_fullsum_words = 0; g_hash_ns = 0; g_hash_calls = 0;
 }
 void at_exit_once() {
@@ -454,7 +474,7 @@ void sdm_mexcache_stats(sdm_int *out, sdm_int n) {
 }
 // arrays of up to `words` words are checksummed completely at every presentation (default 65 536); larger ones once per address and epoch
 void sdm_mexcache_set_full_below(sdm_int words) { full_below = words < 0 ? 0 : words; }
-// lazy intermediates (the block comment at LAZY_BASE): level 0 (default) | 1 | 2; -1: as the environment variable SEDUMI_HIP_LAZY says
+// lazy intermediates (the block comment at LAZY_BASE): level 0 | 1 | 2 (default); -1: as the environment variable SEDUMI_HIP_LAZY says (unset: 2)
 void sdm_mexcache_set_lazy(int level) { g_lazy = level < 0 ? -1 : std::min(level, 2); }
 int sdm_mexcache_lazy(void) { return lazy_level(); }
 // m x m of the ADA' a token stands for and its number of nonzeros; returns 1 (with sdm_last_error) unless `token` is the current token
@@ -482,7 +502,7 @@ int sdm_mexcache_getada1(sdm_int m, const sdm_int *ADAjc, const sdm_int *ADAir, 
   // token_out != NULL: the values stay on the device and *token_out stands for them (ADApr may be NULL)
   MC_TRY
   AdaSlot &S = g_s1;
-  const u64 pa = token_in != 0.0 ? token_pattern(token_in, m) : intern(m, ADAjc, ADAir), pA = intern(m, Ajc, Air);
+  const u64 pa = token_in != 0.0 ? token_pattern_any(token_in, m) : intern(m, ADAjc, ADAir), pA = intern(m, Ajc, Air);
   if (token_in != 0.0) { Pattern *pp = pattern_by_id(pa); if (!pp || pp->irc.empty()) throw std::runtime_error("lazy ADA token: its pattern is not cached any more"); ADAjc = pp->jcc.data(); ADAir = pp->irc.data(); }
   std::vector<sdm_int> ints = {m, N, lpN, lorN};
   ints.insert(ints.end(), qblkstart, qblkstart + lorN + 1);

@@ -6,6 +6,7 @@ the reference's own example problems, with the NORMAL-EQUATIONS HOT PATH pluggab
     hot = RefHot(glue)   the reference MEX (oracle/_ref):   getada1/2/3 | getada.m, blkchol, fwblkslv, bwblkslv, invcholfac
     hot = HipHot()       this repository's library through sedumi_amd.mex (HIP on a GPU box, the fiber emulator on CPU)
     hot = PlanHot()      the same library through its resident plan: problem, scaling, ADA', factor and solves stay in HBM
+    hot = ShimHot(host)  the same library through its built mexFunction shims on a MEX host (what an unmodified sedumi.m calls)
 
 Everything outside the hot path -- the cone algebra (qrK, psdframeit, psdinvjmul, urotorder, givensrot, sqrtinv, iswnbr,
 vecsym, ddot, qblkmul, quadadd: reference MEX through the oracle) and the MATLAB control flow (restated below, file and
@@ -190,6 +191,41 @@ class HipHot(MexShapedHot):
     def bw(self, L, r):
         from sedumi_amd import mex
         return mex.bwblkslv(L, col(r))
+
+
+class ShimHot(MexShapedHot):
+    """The drop-in tier as an unmodified sedumi.m drives it: the built mexFunction shims (sedumi_amd/mexshims) on a MEX host, the
+    global ADA_sedumi_ handed from iteration to iteration as sedumi.m:450-452 does (`ADA_sedumi_ = getada1(ADA_sedumi_, ...)`: with
+    lazy intermediates the array that comes back is a token, and it goes in again next time), L.L / L.d through blkchol.mex."""
+    name = "sedumi_amd.mexshims"
+
+    def __init__(self, host):
+        self.host, self.ADA = host, None                          # host.call(name, nlhs, *args): oracle.refmex.RefMex(mex_dir=<shims>) or sedumi_amd.mexhost.MexHost
+
+    def form(self, S, d, DAt):
+        K, h = S["K"], self.host
+        if self.ADA is None:
+            self.ADA = S["ADA"]                                    # sedumi.m:382 getsymbada
+        if np.sum(K["s"]) == 0:                                    # sedumi.m:446-448: getada.m's route, the global updated by the gateway
+            h.set_global("ADA_sedumi_", self.ADA)
+            absd = h.call("getada", 1, S["A"], K, {"l": col(d["l"]), "det": col(d["det"])}, DAt)
+            self.ADA = h.get_global("ADA_sedumi_")
+            return self.ADA, absd
+        dstruct = {"l": col(d["l"]), "det": col(d["det"])}
+        ADA = h.call("getada1", 1, self.ADA, S["A"], S["Ablkjc"][:, 2], S["Aord"]["lqperm"], dstruct, K["qblkstart"])
+        ADA = h.call("getada2", 1, ADA, DAt, S["Aord"], K)
+        ud = h.call("invcholfac", 1, col(d["u"]), K, col(d["perm"])) if np.size(d["perm"]) else h.call("invcholfac", 1, col(d["u"]), K)
+        self.ADA, absd = h.call("getada3", 2, ADA, S["A"], S["Ablkjc"][:, 2], S["Aord"], ud, K)
+        return self.ADA, absd
+
+    def blkchol(self, L, ADA, pars, absd):
+        return self.host.call("blkchol", 4, L, ADA, pars, absd)
+
+    def fw(self, L, r):
+        return self.host.call("fwblkslv", 1, L, col(r))
+
+    def bw(self, L, r):
+        return self.host.call("bwblkslv", 1, L, col(r))
 
 
 class PlanHot:

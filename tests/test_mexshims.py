@@ -36,6 +36,8 @@ def shimlib():
 
 @pytest.fixture(scope="module")
 def shimmex(refmex, shimlib):
+    import ctypes
+    ctypes.CDLL(shimlib).sdm_mexcache_set_lazy(0)      # these tests compare every gateway's arrays with the reference's (the library's default is level 2)
     return build_shims(shimlib, os.path.join(ROOT, "tests", "hipemu", "_mexshims"))
 
 
@@ -430,3 +432,99 @@ def test_units_on_a_problem_without_lp_or_lorentz_part(glue, refmex, shimmex, sh
     assert relerr(y, yr.ravel()) < TOL
     assert s1["ada_upload"] == s0["ada_upload"] and s1["ada_resident"] - s0["ada_resident"] == 3
     # (an ADA' with values handed to getada3.mex -- uploaded, symmetrised as before -- is test_shims_reproduce_an_iteration_unit's case)
+
+
+def test_lazy_level_2_is_the_default_and_the_environment_turns_it_off(shimlib):
+    """sdm_mexcache_set_lazy(-1) = "as SEDUMI_HIP_LAZY says"; unset means level 2 (every reference call site hands ADA' on untouched)."""
+    import subprocess
+    import sys
+    code = ("import ctypes,sys; lib = ctypes.CDLL(sys.argv[1]); lib.sdm_mexcache_set_lazy(-1); print(lib.sdm_mexcache_lazy())")
+    env = {k: v for k, v in os.environ.items() if k != "SEDUMI_HIP_LAZY"}
+    assert subprocess.check_output([sys.executable, "-c", code, shimlib], env=env).split()[-1] == b"2"
+    for val in ("0", "1"):
+        assert subprocess.check_output([sys.executable, "-c", code, shimlib], env=dict(env, SEDUMI_HIP_LAZY=val)).split()[-1] == val.encode()
+
+
+@pytest.mark.parametrize("name", ["quantum"])           # (tests/test_mexshims_gpu.py: + nb, arch0, control07)
+def test_whole_solves_through_the_shims_are_the_same_at_lazy_level_0_and_2(shimmex, shimlib, name):
+    check_whole_solve_at_lazy_levels(shimmex, shimlib, name)
+
+
+def check_whole_solve_at_lazy_levels(shimmex, shimlib, name):
+    """the default of the drop-in tier.  A whole interior-point solve (tests/driver, sedumi.m's loop) with its hot path through the
+    built mexFunction shims, ADA_sedumi_ handed from iteration to iteration the way sedumi.m:450-452 does -- once with every gateway returning the
+    reference's arrays (level 0), once with getada1 / getada2 / getada3 returning tokens (level 2): the same iteration log, bit for bit (the device
+    does the same arithmetic; only what crosses PCIe differs), and the optimal value of examples/test_sedumi.m."""
+    import ctypes
+    import test_driver as td
+    from driver import sedumi_loop as sl
+    lib = ctypes.CDLL(shimlib)
+    runs = {}
+    try:
+        for level in (0, 2):
+            lib.sdm_mexcache_clear()
+            lib.sdm_mexcache_set_lazy(level)
+            runs[level] = td.run(name, sl.ShimHot(shimmex))
+    finally:
+        lib.sdm_mexcache_set_lazy(0)
+        lib.sdm_mexcache_clear()
+    a, b = runs[0], runs[2]
+    assert a["hot"] == b["hot"] == "sedumi_amd.mexshims" and a["iter"] > 3
+    td.check_objectives(name, b)
+    assert a["iter"] == b["iter"] and len(a["rows"]) == len(b["rows"])
+    for ra, rb in zip(a["rows"], b["rows"]):
+        assert ra == rb, (ra, rb)
+    assert a["cx"] == b["cx"] and a["by"] == b["by"]
+    td.check_log(name, b, td.reference_run(name))
+
+
+def test_lazy_tokens_stale_consumed_and_one_by_one(glue, refmex, shimmex, shimlib):
+    """  A 1 x 1 problem never gets a token (it could not be told from a genuine ADA'); a token is consumed when real arrays come back
+    for it (re-presenting it is refused); getada1.mex -- which needs only the PATTERN of what it is given -- accepts a token that is no
+    longer the current one (sedumi.m's global after optstep.m:68-76 ran the gateways on its own copy)."""
+    import ctypes
+    from oracle.refmex import RefMexError
+    from sedumi_amd import problem
+    lib = ctypes.CDLL(shimlib)
+    lib.sdm_mexcache_token_base.restype = ctypes.c_double
+    P = problem.random_sdp(m=28, seed=21)
+    S = glue.setup(P.At, P.K)
+    d, ud = ref_scaling(P, 2)
+    it = glue.iteration_ref(S, d, ud)
+    dstruct = {"l": np.asarray(d["l"]).reshape(-1, 1), "det": np.asarray(d["det"]).reshape(-1, 1)}
+    a1 = (S["A"], S["Ablkjc"][:, 2], S["Aord"]["lqperm"], dstruct, P.K["qblkstart"])
+    a3 = (S["A"], S["Ablkjc"][:, 2], S["Aord"], ud.reshape(-1, 1), P.K)
+    try:
+        lib.sdm_mexcache_clear()
+        lib.sdm_mexcache_set_lazy(1)
+        t1 = shimmex.call("getada1", 1, S["ADA"], *a1)
+        t2 = shimmex.call("getada2", 1, t1, it["DAt"], S["Aord"], P.K)
+        ADA, absd = shimmex.call("getada3", 2, t2, *a3)                      # level 1: materialises
+        assert relerr(ADA, it["ADA"]) < TOL and relerr(absd, it["absd"]) < TOL
+        with pytest.raises(RefMexError, match="not the current one"):          # t2 was consumed: not added a second time
+            shimmex.call("getada3", 2, t2, *a3)
+        lib.sdm_mexcache_set_lazy(2)
+        t1 = shimmex.call("getada1", 1, S["ADA"], *a1)
+        t3, _ = shimmex.call("getada3", 2, shimmex.call("getada2", 1, t1, it["DAt"], S["Aord"], P.K), *a3)
+        t1b = shimmex.call("getada1", 1, t3, *a1)                              # the global of the iteration before: current token in
+        t3b, absd2 = shimmex.call("getada3", 2, shimmex.call("getada2", 1, t1b, it["DAt"], S["Aord"], P.K), *a3)
+        assert sp.csc_matrix(t3b).nnz == 1 and relerr(absd2, it["absd"]) < TOL
+        t1c = shimmex.call("getada1", 1, t3, *a1)                              # t3 is stale by now: still good for its pattern
+        _, absd3 = shimmex.call("getada3", 2, shimmex.call("getada2", 1, t1c, it["DAt"], S["Aord"], P.K), *a3)
+        assert relerr(absd3, it["absd"]) < TOL
+        with pytest.raises(RefMexError, match="not the current one"):          # ... but not for its values
+            shimmex.call("getada2", 1, t3, it["DAt"], S["Aord"], P.K)
+        # m = 1: real arrays at every level
+        P1 = problem.random_sdp(m=1, lp=3, q=(), s=(3,), seed=5)
+        S1 = glue.setup(P1.At, P1.K)
+        d1, ud1 = ref_scaling(P1, 2)
+        it1 = glue.iteration_ref(S1, d1, ud1)
+        ds1 = {"l": np.asarray(d1["l"]).reshape(-1, 1), "det": np.asarray(d1["det"]).reshape(-1, 1)}
+        A1 = shimmex.call("getada1", 1, S1["ADA"], S1["A"], S1["Ablkjc"][:, 2], S1["Aord"]["lqperm"], ds1, P1.K["qblkstart"])
+        assert float(sp.csc_matrix(A1)[0, 0]) < lib.sdm_mexcache_token_base()
+        A2 = shimmex.call("getada2", 1, A1, it1["DAt"], S1["Aord"], P1.K)
+        A3, ab = shimmex.call("getada3", 2, A2, S1["A"], S1["Ablkjc"][:, 2], S1["Aord"], ud1.reshape(-1, 1), P1.K)
+        assert relerr(A3, it1["ADA"]) < TOL and relerr(ab, it1["absd"]) < TOL
+    finally:
+        lib.sdm_mexcache_set_lazy(0)
+        lib.sdm_mexcache_clear()

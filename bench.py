@@ -268,9 +268,11 @@ def bench_lpdense(args, device):
     plan.close()
 
 
-def make_plan(device, P, L, ADA, Q, d, ud, rhs, qpr):
+def make_plan(device, P, L, ADA, Q, d, ud, rhs, qpr, one_launch_fronts=True):
     from sedumi_amd.plan import Plan
     plan = Plan(device)
+    if not one_launch_fronts:
+        plan.set_one_launch_fronts(False)                # the launch-per-panel path (--shard blockcyclic exchanges the panels between its launches)
     plan.set_chol(L, ADA)
     plan.set_ada(P.At, P.Ablkjc, P.K, Q)
     plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud); plan.upload("rhs", rhs)
@@ -815,11 +817,12 @@ def main():
                     help="control07 (default: examples/control07.mat, BASELINE configs[1]) | control07_like (synthetic, same shape) | "
                          "control07_init / arch0[_init] / nb[_init] (the reference examples at the golden scalings) | nb_like (configs[2] shape) | lpdense (configs[2] dense-column variant) | maxcut<n> (configs[3]) | blockdiag[:nblk:n:mper] (configs[4]) | "
                          "grid[:n] (factor + solves of a matrix with separators, subtrees sharded over the ranks)")
-    ap.add_argument("--shard", default="auto", choices=["auto", "replicas", "columns", "blocks"],
+    ap.add_argument("--shard", default="auto", choices=["auto", "replicas", "columns", "blocks", "blockcyclic"],
                     help="N>1, ONE unit per step: blocks = PSD blocks dealt to the ranks, partial ADA' + one RCCL all-reduce (auto when "
                          "the problem has at least N PSD blocks); columns = ADA' column panels per rank + RCCL all-gather (auto otherwise); "
                          "factor/solves replicated in both (one dense supernode does not shard); replicas = independent units per "
-                         "rank (weak scaling, no collective)")
+                         "rank (weak scaling, no collective); blockcyclic = columns for ADA' + ONE dense front factored block-column-cyclically "
+                         "(sedumi_amd.dist.BlockCyclicFactor: a broadcast per 64-column panel), solves replicated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--other-configs", action="store_true",
                     help="also measure the other BASELINE configs (both scalings of the reference examples, maxcut4000, blockdiag, the maxcut8000 solve "
@@ -865,8 +868,8 @@ def main():
     shard = "none" if world == 1 else args.shard
     if shard == "auto":                                 # the way the workload shards
         shard = "blocks" if nblk >= world else "columns"
-    shard_cols = shard in ("columns", "blocks")         # ONE unit per step, strong scaling
-    cs = bs = None
+    shard_cols = shard in ("columns", "blocks", "blockcyclic")         # ONE unit per step, strong scaling
+    cs = bs = bc = None
     if shard == "blocks":
         from sedumi_amd import dist as sd
         bs = sd.BlockShardedAda(P, L, ADA, device_index=local_rank, device=coll_dev)
@@ -874,11 +877,13 @@ def main():
         plan = bs.plan
         plan.upload("rhs", rhs)
     else:
-        plan = make_plan(local_rank, P, L, ADA, Q, d, ud, rhs, qpr)
+        plan = make_plan(local_rank, P, L, ADA, Q, d, ud, rhs, qpr, one_launch_fronts=shard != "blockcyclic")
     plan._xsuper = np.asarray(L["xsuper"]).ravel().astype(np.int64)
-    if shard == "columns":
+    if shard in ("columns", "blockcyclic"):
         from sedumi_amd import dist as sd
         cs = sd.ColumnShardedAda(plan, device=coll_dev)
+    if shard == "blockcyclic":
+        bc = sd.BlockCyclicFactor(L, ADA, device_index=local_rank, device=coll_dev, plan=plan)
 
     def step():
         if cs is not None:
@@ -887,7 +892,10 @@ def main():
             bs.getada()
         else:
             plan.getada()
-        plan.blkchol(PARS, True)
+        if bc is not None:
+            bc.factor_resident(PARS, True)
+        else:
+            plan.blkchol(PARS, True)
         for _ in range(NSOLVE):
             plan.ldlsolve()
 
@@ -922,7 +930,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    roof, phases = profile_unit(plan, P, ud, min(max(args.steps, 20), 50))
+    if bc is not None:                                   # (the per-kernel profile re-runs the unit on this plan alone: not with a front spread over ranks)
+        roof, phases = None, {"factor": {"frac_of_fp64_matrix_peak": None}, "solve": {"frac_of_hbm_peak": None}}
+    else:
+        roof, phases = profile_unit(plan, P, ud, min(max(args.steps, 20), 50))
 
     if rank == 0:
         base = base_blas = pcie = mexleg = weighted = None
@@ -978,6 +989,7 @@ def main():
                                    f"nnz(ADA')={plan.nnzADA}, nnz(L)={plan.nnzL}; unit = getada1+2+3, blkchol, {NSOLVE}x(fwblkslv,./d,bwblkslv)",
                        "parallelism": ({"columns": "ADA' column panels per rank + RCCL all-gather, factor/solves replicated (they do not shard: one dense supernode)",
                                          "blocks": "PSD blocks dealt to the ranks, partial ADA' + RCCL all-reduce, factor/solves replicated",
+                                         "blockcyclic": "ADA' column panels + all-gather; the ONE dense front factored block-column-cyclically (64-column panels, a broadcast per panel); solves replicated",
                                          "replicas": "replicas: independent units per rank, no collective"}[shard] if world > 1 else "single GPU")},
             "roofline": roof, "phases_ms_per_step": phases, "cpu_baseline": base, "cpu_baseline_blas": base_blas,
             "pcie_inclusive": pcie, "mex_inclusive": mexleg, "whole_solve_weighted": weighted, "other_configs": others,

@@ -398,13 +398,31 @@ int sdm_plan_solve_stats(sdm_plan *p, sdm_int *nblocks, sdm_int *nbad, double *m
  *   solve_levels(what, l0, l1) on the right-hand side in "rhs": what = 1 assembly of the fronts' right-hand sides (own entries +
  *     children's update vectors, in "wvec"), 2 the forward sweep of the levels without that assembly, 3 both, 4 the backward
  *     sweep of levels l1-1 .. l0 (reads the ancestors' solution from "xfin", writes "y").
- * The plan buffers "fronts", "wvec", "xfin", "ub" are reachable through sdm_plan_devptr / sdm_plan_copy. */
+ * The plan buffers "fronts", "wvec", "xfin", "ub", "panelrec" are reachable through sdm_plan_devptr / sdm_plan_copy. */
 int sdm_plan_set_active_supernodes(sdm_plan *p, const int *active, sdm_int nsuper);
 int sdm_plan_front_layout(sdm_plan *p, sdm_int *nlevels, sdm_int *level, sdm_int *foff, sdm_int *fsize, sdm_int *woff, sdm_int *ms, sdm_int *first, sdm_int *ns);
 int sdm_plan_blkchol_begin(sdm_plan *p, const sdm_cholpars *pars, int use_absd);
 int sdm_plan_blkchol_levels(sdm_plan *p, sdm_int l0, sdm_int l1, int extend_only);
 int sdm_plan_blkchol_end(sdm_plan *p);
 int sdm_plan_solve_levels(sdm_plan *p, int what, sdm_int l0, sdm_int l1);
+
+/* ---- One front across GPUs (SURVEY.md 8e row blkchol, "block-cyclic dense LDL' with panel broadcasts"; sedumi_amd.dist.BlockCyclicFactor).
+ * The ranks hold the same plan of ONE dense front (nsuper = 1, e.g. MAXCUT) on the launch-per-panel path (sdm_plan_set_one_launch_fronts(p, 0)
+ * before set_chol) and the same ADA' values.  Tile column c (64 columns) of the front belongs to rank (c / blk) % world:
+ *   set_column_owner(world, rank, blk)   before blkchol_begin; world = 1 gives the plan everything back;
+ *   blkchol_panels(l0, l1, pan0, pan1)   the panel launches pan0 .. pan1-1 of the levels: the owner of tile column q factors panel q
+ *                                        (cholonBlk, blkchol2.c:96-167, + the rows below it), every rank applies the trailing updates that
+ *                                        are due (precorrect, blkchol2.c:346-420) to ITS tile columns -- per tile the operations and their
+ *                                        order are those of the single plan: the same bits;
+ *   panel_record(panel, unpack, &off, &n) after launch `panel`: its owner packs d, lb, the pivot decisions, the front's progress counters and the
+ *                                        transposed diagonal block into the plan buffer "panelrec" (unpack = 0); the others store a received
+ *                                        record (unpack = 1); unpack < 0 only answers.  off / n = the slice of "fronts" that holds the panel's columns.  The caller
+ *                                        broadcasts both from the owner (what blkLDL's relinking, blkchol2.c:550-554, turns into when the
+ *                                        supernode is spread over ranks) before anybody launches panel + 1;
+ *   blkchol_end                           as above (every rank then holds the whole factor; the inverses for the solves are built by each). */
+int sdm_plan_set_column_owner(sdm_plan *p, int world, int rank, int blk);
+int sdm_plan_blkchol_panels(sdm_plan *p, sdm_int l0, sdm_int l1, sdm_int pan0, sdm_int pan1);
+int sdm_plan_panel_record(sdm_plan *p, sdm_int panel, int unpack, sdm_int *front_offset, sdm_int *front_nelem);
 
 /* ---- process-wide resident state behind the mexFunction shims (csrc/sdm_mexcache.hip).  Every .mex
  * binary is its own shared object, so the cache lives in this library.  The sdm_mexcache_<gateway> functions take the

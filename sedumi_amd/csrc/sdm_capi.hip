@@ -126,6 +126,7 @@ static DevBuf<double> *plan_buf(sdm_plan *p, const char *name) {
   if (s == "wvec") return &p->chol.wvec;
   if (s == "xfin") return &p->chol.xfin;
   if (s == "ub") return &p->chol.ub;
+  if (s == "panelrec") { if (p->chol.panelrec.n == 0) p->chol.panelrec.alloc((size_t)(4 * sdm::NB + 2 + sdm::NB * sdm::NB)); return &p->chol.panelrec; }
   throw std::runtime_error("unknown plan buffer: " + s);
 }
 void *sdm_plan_devptr(sdm_plan *p, const char *name, sdm_int *nelem) {
@@ -249,6 +250,33 @@ int sdm_plan_blkchol_begin(sdm_plan *p, const sdm_cholpars *pars, int use_absd) 
   if (q.abstol < 0.0) q.abstol = 0.0;
   p->dense.factored = false;
   chol_begin(p, q.canceltol, q.maxu, q.abstol, use_absd);
+  SDM_CATCH
+}
+// ---- one dense front factored block-column-cyclically by several ranks (include/sedumi_hip.h: "One front across GPUs")
+int sdm_plan_set_column_owner(sdm_plan *p, int world, int rank, int blk) {
+  SDM_TRY
+  if (world < 1 || world > 255 || rank < 0 || rank >= world || blk < 1 || blk > 255) throw std::runtime_error("sdm_plan_set_column_owner: need 1 <= world <= 255, 0 <= rank < world, 1 <= blk <= 255");
+  p->chol.own = world == 1 ? 0 : (world | rank << 8 | blk << 16);
+  SDM_CATCH
+}
+int sdm_plan_blkchol_panels(sdm_plan *p, sdm_int l0, sdm_int l1, sdm_int pan0, sdm_int pan1) {
+  SDM_TRY
+  if (!p->has_chol) throw std::runtime_error("sdm_plan_blkchol_panels: no symbolic factor set");
+  for (int l = (int)std::max<sdm_int>(l0, 0); l < (int)std::min<sdm_int>(l1, p->chol.nlevels); l++)
+    if (p->chol.lev_persist[l] && !p->chol.front_disabled)
+      throw std::runtime_error("sdm_plan_blkchol_panels: the level is planned as ONE launch; call sdm_plan_set_one_launch_fronts(plan, 0) before sdm_plan_set_chol");
+  chol_levels(p, (int)l0, (int)l1, false, (int)pan0, (int)std::min<sdm_int>(pan1, 1 << 30));
+  SDM_CATCH
+}
+int sdm_plan_panel_record(sdm_plan *p, sdm_int panel, int unpack, sdm_int *front_offset, sdm_int *front_nelem) {
+  SDM_TRY
+  if (!p->has_chol) throw std::runtime_error("sdm_plan_panel_record: no symbolic factor set");
+  if (unpack >= 0) chol_panel_record(p, (int)panel, unpack);            // (unpack < 0: only the slice of "fronts" is asked for)
+  const CholPlan &C = p->chol;
+  if (C.nsuper != 1 || panel < 0 || panel * NB >= C.sn_ns[0]) throw std::runtime_error("sdm_plan_panel_record: one dense front, 0 <= panel < its panels");
+  const sdm_int k0 = panel * NB, kb = std::min<sdm_int>(NB, C.sn_ns[0] - k0);
+  if (front_offset) *front_offset = C.sn_foff[0] + k0 * (sdm_int)C.sn_ld[0];
+  if (front_nelem) *front_nelem = kb * (sdm_int)C.sn_ld[0];
   SDM_CATCH
 }
 int sdm_plan_blkchol_levels(sdm_plan *p, sdm_int l0, sdm_int l1, int extend_only) {

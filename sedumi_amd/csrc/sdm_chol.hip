@@ -117,6 +117,18 @@ __host__ __device__ inline void tile_sched_item(const TileSched &sc, int q, int 
   for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (I + a < sc.nt && J + b < Jend && I + a >= J + b) act |= 1 << (2 * a + b);
 }
 
+// ============================================================ block-column-cyclic ownership (several ranks factor ONE dense front: sedumi_amd.dist.BlockCyclicFactor)
+// `own` = world | rank << 8 | blk << 16 (0: the plan owns everything).  Tile column c of the front belongs to rank (c / blk) % world.  The owner of
+// tile column q factors panel q (diagonal block + row solves of launch q); EVERY update of a tile is applied by the owner of the tile's column, in
+// the launch the single-plan schedule applies it in: per tile the same operations in the same order, i.e. the same bits (blkchol2.c:346-420 applied
+// column by column; the relink rule of blkchol2.c:550-554 becomes "panel q goes to everybody once it is final": the caller broadcasts it).
+__host__ __device__ inline bool owns_col(int own, int c) {
+  const int world = own & 255;
+  if (world <= 1) return true;
+  const int blk = own >> 16;
+  return (c / (blk > 0 ? blk : 1)) % world == ((own >> 8) & 255);
+}
+
 // ============================================================ host analysis
 void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, const sdm_int *perm,
                 sdm_int nsuper, const sdm_int *xsuper, const sdm_int *ADAjc, const sdm_int *ADAir) {
@@ -1220,7 +1232,7 @@ __device__ SDM_NI_ROWS SDM_NORETURN void panel_role_rows(char *smem, double *Fs,
 }
 // ---- tile workgroup w: two tiles of the previous panel's update side by side, 4 wavefronts each
 __device__ SDM_NI_TILES void panel_role_tiles(char *smem, double *Fs, const double *d, int ms, int ld, int first, int panel, int w, int nrw, int nt,
-                                              int *upd_cnt_s) {
+                                              int *upd_cnt_s, int own) {
   SDM_FP_STRICT;
   double (*As)[UTP] = (double (*)[UTP])smem;
   double (*Bs)[UTP] = As + NB;
@@ -1240,6 +1252,7 @@ __device__ SDM_NI_TILES void panel_role_tiles(char *smem, double *Fs, const doub
     active = u < ntl;
     tile_index(active ? u + 1 : 1, I, J);
   }
+  if (!owns_col(own, panel + J)) active = false;               // (another rank's tile column; the signal below is still given)
   __shared__ double dsh2[2][NB];
   update_tile<4, false, true>(Fs, ld, ms, first, kp, NB, I, J, d, As + half * 2 * NB, Bs + half * 2 * NB, dsh2[half],
                               nullptr, nullptr, 0, (int)threadIdx.x & 255, active);
@@ -1276,7 +1289,7 @@ __device__ SDM_NI_TILES void panel_role_tiles(char *smem, double *Fs, const doub
 // A tile's own values make one trip through the registers per macro tile and group.  Per tile: the same operands, the same instructions on
 // the same accumulators, the same order as the eager schedule -- the same bits.
 struct TileItem { int I, J, nch, kp0, ds0, act; };               // first tile of the macro tile (relative to tile column q); act: bit 2a+b = tile (I+a, J+b) is the item's
-__device__ SDM_NI_TILES void panel_role_tiles_stream(char *smem, double *Fs, const double *d, int ns, int ms, int ld, int first, int panel, int w, int ntw) {
+__device__ SDM_NI_TILES void panel_role_tiles_stream(char *smem, double *Fs, const double *d, int ns, int ms, int ld, int first, int panel, int w, int ntw, int own) {
   SDM_FP_STRICT;
   const int tid = threadIdx.x;
   double (*Ab)[UTP] = (double (*)[UTP])smem;                   // A(I) = Ab, A(I+1) = Ab + NB, B(J) = Ab + 2 NB, B(J+1) = Ab + 3 NB   (4 NB UTP doubles = PANEL_LDS_RIDE)
@@ -1299,6 +1312,7 @@ __device__ SDM_NI_TILES void panel_role_tiles_stream(char *smem, double *Fs, con
     int p0, np;
     tile_sched_item(sc, panel, u, t.I, t.J, t.act, p0, np);
     t.nch = np; t.kp0 = p0 * NB; t.ds0 = np == 1 ? 0 : 1;
+    if (own) for (int b = 0; b < 2; b++) if (!owns_col(own, panel + t.J + b)) t.act &= ~((1 << b) | (1 << (2 + b)));   // (another rank's tile column)
   };
   // A step covers HALF a chunk: 32 columns of the four operand blocks (64 KB: 8 sixteen-byte loads per work-item, two rows each).  The LDS
   // blocks hold a whole chunk; while the MFMAs read one half of them, the next step's operands go from the registers into the other
@@ -1557,7 +1571,7 @@ __device__ SDM_NOINLINE SDM_NORETURN void panel_role_diag(char *smem, SDM_GP(dou
 
 __global__ void __launch_bounds__(LDL_THREADS)
 k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, double *d, const PanelCtx *ctx,
-            int *upd_cnt, int *diag_cnt, int q0, int phase, int *tmo) {
+            int *upd_cnt, int *diag_cnt, int q0, int phase, int *tmo, int own) {
   SDM_FP_STRICT;   // no FMA contraction: the pivot decisions must see the reference's mul-then-subtract rounding
   SDM_DYN_SMEM(smem);
   // ONE launch per 64-column panel p.  grid = (workgroups, fronts); per front:
@@ -1595,14 +1609,15 @@ k_ldl_panel(double *F, double *DT, FrontTab tab, const int *list, int panel, dou
     if (bx > ntw) return;
     bx = bx < ntw ? 1 + bx : 0;
   }
+  if (bx <= nrw && !owns_col(own, panel)) return;                  // (block-cyclic ranks: the panel is factored by the owner of its tile column alone)
   if (bx > 0 && bx <= nrw) {
     panel_role_rows(smem, Fs, DT + tab.toff[s] + (int64_t)panel * NB * NB, d, ns, ms, ld, first, panel, bx - 1, upd_cnt + s, diag_cnt + s, phase, tmo);
     return;
   }
   if (bx > nrw) {
     if (phase == 2 || panel == 0) return;
-    if (nrw > 0) panel_role_tiles_stream(smem, Fs, d, ns, ms, ld, first, panel, bx - 1 - nrw, (int)gridDim.x - 1 - nrw);
-    else panel_role_tiles(smem, Fs, d, ms, ld, first, panel, bx - 1 - nrw, nrw, nt, upd_cnt + s);
+    if (nrw > 0) panel_role_tiles_stream(smem, Fs, d, ns, ms, ld, first, panel, bx - 1 - nrw, (int)gridDim.x - 1 - nrw, own);
+    else panel_role_tiles(smem, Fs, d, ms, ld, first, panel, bx - 1 - nrw, nrw, nt, upd_cnt + s, own);
     return;
   }
   // ---- workgroup 0
@@ -2061,7 +2076,9 @@ void chol_begin(sdm_plan *P, const double canceltol, const double maxu, const do
   SDM_HIP_CHECK(hipGetLastError());
 }
 // levels l0 .. l1-1: children's update matrices into the fronts of the level (extend-add), then -- unless extend_only -- its LDL'
-void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
+void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only, int pan0, int pan1) {
+  // pan0 .. pan1-1: of every level's panel launches only these (sdm_plan_blkchol_panels: ranks that factor one front block-cyclically
+  // exchange the finished panel between two launches); the extend-add of a level runs with its first launch
   CholPlan &C = P->chol;
   hipStream_t st = P->stream; (void)st;                              // (used by the emulator's launches of the follower only)
   FrontTab tab = front_tab(C);
@@ -2070,7 +2087,7 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
     const int *list = C.d_levlist.p + C.levptr[l];
     const int nfr = C.levptr[l + 1] - C.levptr[l];
     if (nfr == 0) continue;
-    if (l > 0) SDM_KLAUNCH(P, k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, C.fronts.p, tab, list);
+    if (l > 0 && pan0 <= 0) SDM_KLAUNCH(P, k_extend_add, dim3(C.lev_T[l], nfr), dim3(256), 0, C.fronts.p, tab, list);
     if (extend_only) continue;
     if (C.lev_persist[l] && !C.front_disabled) {                     // the whole level in one launch (k_ldl_front)
       PersistTurn turn(P);
@@ -2108,24 +2125,53 @@ void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only) {
     }
     for (int li = C.lev_first_launch[l]; li < C.lev_first_launch[l + 1]; li++) {
       const LevelLaunch &L = C.launches[li];
+      if (L.panel < pan0 || L.panel >= pan1) continue;
       // ONE launch per panel: diagonal block (+ tile 0 of the previous panel's update), the row solves and the rest of
       // the previous update (see k_ldl_panel).  The emulator runs it in two phases (workgroups are sequential there).
 #ifdef SDM_EMU
       if (emu_concurrent() && (1 + L.ride_wgs) * L.nactive <= 200)   // as on the device: one launch, the roles wait for each other (one process per workgroup)
         SDM_KLAUNCH_CONCURRENT(P, k_ldl_panel, dim3(1 + L.ride_wgs, L.nactive), dim3(LDL_THREADS), PANEL_LDS_RIDE, C.fronts.p, C.frontsT.p, tab, list,
-                               L.panel, C.d.p, C.panel_ctx.p, C.upd_cnt.p, C.diag_cnt.p, 1, 0, C.tmo.dev());
+                               L.panel, C.d.p, C.panel_ctx.p, C.upd_cnt.p, C.diag_cnt.p, 1, 0, C.tmo.dev(), C.own);
       else
       for (int phase = 1; phase <= 2; phase++)
 #else
       const int phase = 0;
 #endif
         SDM_KLAUNCH(P, k_ldl_panel, dim3(1 + L.ride_wgs, L.nactive), dim3(LDL_THREADS), PANEL_LDS_RIDE, C.fronts.p, C.frontsT.p, tab, list,
-                    L.panel, C.d.p, C.panel_ctx.p, C.upd_cnt.p, C.diag_cnt.p, 1, phase, C.tmo.dev());
+                    L.panel, C.d.p, C.panel_ctx.p, C.upd_cnt.p, C.diag_cnt.p, 1, phase, C.tmo.dev(), C.own);
       if (L.lasttiles > 0)                                           // supernodes that end with this panel and have rows beyond
         SDM_KLAUNCH(P, k_ldl_update, dim3(L.lasttiles, L.nactive), dim3(256), 0, C.fronts.p, tab, list, L.panel, C.d.p, 1);
     }
   }
   SDM_HIP_CHECK(hipGetLastError());
+}
+// ---- the record of a finished panel that travels between block-cyclic ranks beside the panel's columns of the front: d, lb, pivval, pivstat
+// (as doubles) of its 64 columns, the front's two progress counters, the transposed copy DT of its diagonal block  (3 NB + NB + 2 + NB NB doubles)
+__global__ void k_panel_record(double *rec, double *d, double *lb, double *pivval, int *pivstat, int *upd_cnt, int *diag_cnt, double *DT, int first, int k0, int kb,
+                               int s, int64_t toff, int unpack) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  for (int e = tid; e < 4 * NB + 2 + NB * NB; e += nth) {
+    double *slot = nullptr; int *islot = nullptr;
+    if (e < NB) { if (e < kb) slot = d + first + k0 + e; }
+    else if (e < 2 * NB) { if (e - NB < kb) slot = lb + first + k0 + e - NB; }
+    else if (e < 3 * NB) { if (e - 2 * NB < kb) slot = pivval + first + k0 + e - 2 * NB; }
+    else if (e < 4 * NB) { if (e - 3 * NB < kb) islot = pivstat + first + k0 + e - 3 * NB; }
+    else if (e == 4 * NB) islot = upd_cnt + s;
+    else if (e == 4 * NB + 1) islot = diag_cnt + s;
+    else slot = DT + toff + (int64_t)(k0 / NB) * NB * NB + (e - 4 * NB - 2);
+    if (slot) { if (unpack) *slot = rec[e]; else rec[e] = *slot; }
+    else if (islot) { if (unpack) *islot = (int)rec[e]; else rec[e] = (double)*islot; }
+    else if (!unpack) rec[e] = 0.0;
+  }
+}
+void chol_panel_record(sdm_plan *P, int panel, int unpack) {
+  CholPlan &C = P->chol;
+  if (C.nsuper != 1) throw std::runtime_error("panel records: block-cyclic factorisation is for ONE dense front");
+  if (C.panelrec.n < (size_t)(4 * NB + 2 + NB * NB)) C.panelrec.alloc((size_t)(4 * NB + 2 + NB * NB));
+  const int ns = C.sn_ns[0], k0 = panel * NB, kb = std::min(NB, ns - k0);
+  if (k0 >= ns) throw std::runtime_error("panel record: no such panel");
+  SDM_KLAUNCH(P, k_panel_record, dim3(8), dim3(256), 0, C.panelrec.p, C.d.p, C.lb.p, C.pivval.p, C.pivstat.p, C.upd_cnt.p, C.diag_cnt.p, C.frontsT.p, C.sn_first[0], k0, kb, 0,
+              C.sn_toff[0], unpack);
 }
 void chol_end(sdm_plan *P) {
   if (!P->chol.follow) solve_prepare(P, /*sb_g_is_zero=*/true);      // inverses of the diagonal super-blocks for the solves (else: built behind the levels)
@@ -2134,7 +2180,7 @@ void chol_end(sdm_plan *P) {
 }
 void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd) {
   chol_begin(P, canceltol, maxu, abstol, use_absd);
-  chol_levels(P, 0, P->chol.nlevels, false);
+  chol_levels(P, 0, P->chol.nlevels, false, 0, 1 << 30);
   chol_end(P);
 }
 

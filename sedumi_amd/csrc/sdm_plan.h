@@ -182,6 +182,8 @@ struct CholPlan {
   std::vector<int> lev_maxT;       // its grid: tile rows of the tallest front ...
   std::vector<int> lev_ntw;        // ... plus this many tile workgroups per front
   DevBuf<int> upd_cnt;     // per front: finished tile workgroups of the updates that rode along with k_ldl_panel
+  int own = 0;             // block-cyclic ranks (sdm_plan_set_column_owner): world | rank << 8 | blk << 16, 0 = this plan owns every tile column (sdm_chol.hip: owns_col)
+  DevBuf<double> panelrec; // the record of one finished panel between those ranks (chol_panel_record)
   DevBuf<PanelCtx> panel_ctx;   // what only workgroup 0 of k_ldl_panel needs, behind ONE kernel argument (uploaded when it changes)
   PanelCtx panel_ctx_host = {};
   HostFlag tmo;            // raised by a spin inside a panel launch of THIS plan that gave up (chol_wait_timeouts)
@@ -427,7 +429,8 @@ void chol_build(sdm_plan *P, sdm_int m, const sdm_int *Ljc, const sdm_int *Lir, 
 void chol_factor(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd);
 // the same in three steps (sdm_plan_blkchol_begin / _levels / _end: the multi-GPU layer reduces update matrices between levels)
 void chol_begin(sdm_plan *P, const double canceltol, const double maxu, const double abstol, int use_absd);
-void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only);
+void chol_levels(sdm_plan *P, int l0, int l1, bool extend_only, int pan0 = 0, int pan1 = 1 << 30);
+void chol_panel_record(sdm_plan *P, int panel, int unpack);
 void chol_end(sdm_plan *P);
 void chol_forget_plan(sdm_plan *P);    // the plan is being destroyed (turn-taking of k_ldl_front launches)
 int chol_wait_timeouts(sdm_plan *P);   // non-zero: a spin inside a panel launch of this plan gave up since the last call (call after a stream sync)

@@ -469,3 +469,79 @@ class SeparatorShardedSolver:
         self.xbuf.masked_fill_(~self.mask, 0.0)
         dist.all_reduce(self.xbuf, op=dist.ReduceOp.SUM, group=self.group)
         return self.xbuf
+
+
+# ----------------------------------------------------------------------------------------- one dense front over the ranks
+class BlockCyclicFactor:
+    """LDL' of ONE dense front (a single-supernode factor: MAXCUT, control07, every dense ADA') over the ranks, 1-D block-column-cyclic
+    (SURVEY.md 8e row blkchol: "block-cyclic dense LDL' with panel broadcasts").  Every rank holds the same plan on the
+    launch-per-panel path and the same ADA' values; tile column c (64 columns) belongs to rank (c // blk) % world:
+
+      for every panel q:   all ranks launch panel q -- its owner factors it (cholonBlk, blkchol2.c:96-167, and the rows below), every
+                           rank applies the trailing updates that are due to ITS tile columns (precorrect, blkchol2.c:346-420);
+                           ONE broadcast from the owner: the panel's columns of the front followed by its record (d, lb, pivot
+                           decisions, progress counters, the transposed diagonal block) -- what the relinking of a finished supernode
+                           to its parent (blkchol2.c:550-554) becomes when the supernode itself is spread over ranks.
+
+    Afterwards every rank holds the complete factor, d and the pivot lists (the solves are replicated: they do not shard),
+    bit for bit what the single plan computes: per tile the same operations in the same order (tests/test_distributed.py).
+    """
+
+    def __init__(self, L, ADApat, group=None, device_index=0, device=None, blk=1, plan=None):
+        """plan: an existing plan of this factor to take over (its set_chol must have followed set_one_launch_fronts(False): bench.py hands in
+        the plan that also forms ADA'); otherwise one is made."""
+        torch, dist = _torch()
+        self.group = group
+        if dist.is_available() and dist.is_initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        self.device = device if device is not None else torch.device("cpu")
+        xs = np.asarray(L["xsuper"]).ravel()
+        if xs.size != 2:
+            raise ValueError("BlockCyclicFactor: the symbolic factor must be ONE supernode (a dense front)")
+        self.m = int(sp.csc_matrix(ADApat).shape[0])
+        self.blk = int(blk)
+        if plan is None:
+            plan = Plan(device_index)
+            plan.set_one_launch_fronts(False)                        # the launch-per-panel path: the panels are exchanged between its launches
+            plan.set_chol(L, ADApat)
+        self.plan = plan
+        self.plan.set_column_owner(self.world, self.rank, self.blk)
+        self.npanel = (self.m + 63) // 64
+        self.nrec = 4 * 64 + 2 + 64 * 64
+        _, n0 = self.plan.panel_slice(0)
+        self.buf = torch.zeros(n0 + self.nrec, dtype=torch.float64, device=self.device)
+
+    def owner(self, panel):
+        return (panel // self.blk) % self.world
+
+    def factor(self, values, pars=None, absd=None):
+        """values: ADA' in the order of its pattern, the same on every rank (what the ADA' layers above leave there)."""
+        torch, dist = _torch()
+        self.plan.upload("ada", values)
+        if absd is not None:
+            self.plan.upload("absd", absd)
+        self.factor_resident(pars, absd is not None)
+
+    def factor_resident(self, pars=None, use_absd=True):
+        """The same on the ADA' / absd the plan already holds (complete and equal on every rank: e.g. after ColumnShardedAda.getada)."""
+        torch, dist = _torch()
+        pl = self.plan
+        pl.blkchol_begin(pars, use_absd)
+        for q in range(self.npanel):
+            pl.blkchol_panels(0, 1, q, q + 1)
+            if self.world == 1:
+                continue
+            src = self.owner(q)
+            off, n = pl.panel_slice(q)
+            if self.rank == src:
+                pl.panel_record(q, unpack=False)
+                pl.copy("fronts", self.buf, off, n, to_plan=False)
+                pl.copy("panelrec", self.buf[n:], 0, self.nrec, to_plan=False)
+            dist.broadcast(self.buf[:n + self.nrec], src=src, group=self.group)
+            if self.rank != src:
+                pl.copy("fronts", self.buf, off, n, to_plan=True)
+                pl.copy("panelrec", self.buf[n:], 0, self.nrec, to_plan=True)
+                pl.panel_record(q, unpack=True)
+        pl.blkchol_end()

@@ -283,6 +283,28 @@ class Plan:
     def blkchol_levels(self, l0, l1, extend_only=False):
         check(self._lib.sdm_plan_blkchol_levels(C.c_void_p(self._p), C.c_int64(int(l0)), C.c_int64(int(l1)), 1 if extend_only else 0))
 
+    # ---- one dense front block-column-cyclically over several ranks (sedumi_amd.dist.BlockCyclicFactor)
+    def set_column_owner(self, world, rank, blk=1):
+        """Tile column c (64 columns) of the front belongs to rank (c // blk) % world; before blkchol_begin."""
+        check(self._lib.sdm_plan_set_column_owner(C.c_void_p(self._p), C.c_int(int(world)), C.c_int(int(rank)), C.c_int(int(blk))))
+
+    def blkchol_panels(self, l0, l1, pan0, pan1):
+        """The panel launches pan0 .. pan1-1 of the levels l0 .. l1-1 (launch-per-panel path)."""
+        check(self._lib.sdm_plan_blkchol_panels(C.c_void_p(self._p), C.c_int64(int(l0)), C.c_int64(int(l1)), C.c_int64(int(pan0)), C.c_int64(int(pan1))))
+
+    def panel_slice(self, panel):
+        """(offset, nelem) of the slice of "fronts" that holds the columns of panel `panel` of the (one) front."""
+        off, n = C.c_int64(0), C.c_int64(0)
+        check(self._lib.sdm_plan_panel_record(C.c_void_p(self._p), C.c_int64(int(panel)), C.c_int(-1), C.byref(off), C.byref(n)))
+        return off.value, n.value
+
+    def panel_record(self, panel, unpack):
+        """Pack (owner) / unpack (receiver) the record of a finished panel in the plan buffer "panelrec"; returns the slice
+        (offset, nelem) of "fronts" that holds the panel's columns."""
+        off, n = C.c_int64(0), C.c_int64(0)
+        check(self._lib.sdm_plan_panel_record(C.c_void_p(self._p), C.c_int64(int(panel)), C.c_int(1 if unpack else 0), C.byref(off), C.byref(n)))
+        return off.value, n.value
+
     def blkchol_end(self):
         check(self._lib.sdm_plan_blkchol_end(C.c_void_p(self._p)))
 

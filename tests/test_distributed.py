@@ -2,6 +2,7 @@
 the GPU (one emulator library per process).  Checks that the sharded runs reproduce the single-process results:
   * ColumnShardedAda: ADA' / absd assembled from two column panels + one all-gather
   * SubtreeShardedSolver: independent etree subtrees dealt to the ranks, local factor + solve, all-gather of y
+  * BlockCyclicFactor: ONE dense front block-column-cyclically over 2 / 3 ranks, a broadcast per panel: L, d, pivot lists bit for bit
 """
 import os
 import socket
@@ -82,6 +83,32 @@ def _worker(rank, world, port, case, q):
             want = np.linalg.solve(X.toarray(), rhs)
             err = max(np.abs(xs[0] - x1).max() / np.abs(x1).max(), np.abs(xs[0] - want).max() / np.abs(want).max())
             q.put((rank, float(err), [int(solver.top.sum()), len(solver.roots)]))
+        elif case.startswith("blockcyclic"):
+            # ONE dense front, block-column-cyclic over the ranks (SURVEY.md 8e row blkchol): every panel factored by the owner of its tile
+            # column and broadcast, every tile updated by the owner of its column -- L, d and the pivot lists BIT FOR BIT those of one plan
+            _, mm, blk, deficient = case.split("_")
+            mm, blk = int(mm), int(blk)
+            rng = np.random.default_rng(mm)
+            B = rng.standard_normal((mm, mm - 9 if deficient == "rank" else mm + 5))
+            X = B @ B.T / mm + (0.0 if deficient == "rank" else 0.05) * np.eye(mm)       # ("rank": nine dependent columns -- the skip / add decisions)
+            absd = np.abs(X).sum(axis=1)
+            Lsym, pat = problem.dense_symbolic(mm), problem.dense_pattern(mm)
+            vals = X.ravel(order="F")
+            one = Plan(0); one.set_one_launch_fronts(False); one.set_chol(Lsym, pat); one.upload("ada", vals); one.upload("absd", absd)
+            one.blkchol(pars, True)
+            bc = sd.BlockCyclicFactor(Lsym, pat, blk=blk)
+            outs = []
+            for rep in range(2):                            # twice: the arenas and counters are reused
+                bc.factor(vals, pars, absd)
+                outs.append((bc.plan.download("lpr"), bc.plan.download("d"), bc.plan.pivots()))
+            l1, d1, (s1, a1) = one.download("lpr"), one.download("d"), one.pivots()
+            for lpr, dd, (sk, ad) in outs:
+                assert np.array_equal(lpr, l1) and np.array_equal(dd, d1), (float(np.abs(lpr - l1).max()), float(np.abs(dd - d1).max()))
+                assert all(np.array_equal(x, y) for x, y in zip(sk + ad, s1 + a1))
+            rhs = rng.standard_normal(mm)
+            bc.plan.upload("rhs", rhs); bc.plan.ldlsolve(); one.upload("rhs", rhs); one.ldlsolve()
+            assert np.array_equal(bc.plan.download("y"), one.download("y"))
+            q.put((rank, 0.0, [int(s1[0].size), int(a1[0].size), bc.npanel]))
         elif case in ("blocks", "blocks_confined"):
             # ADA' = sum of the PSD blocks' contributions: blocks dealt to the ranks, one all-reduce of [values | absd]
             from helpers import ref_scaling
@@ -155,7 +182,8 @@ def _worker(rank, world, port, case, q):
 
 
 @pytest.mark.parametrize("case,world", [("columns", 2), ("subtrees", 2), ("subtrees_lorentz", 2), ("blocks", 2), ("blocks_confined", 2),
-                                        ("separator_arrow", 2), ("separator_grid", 2), ("separator_bordered", 2), ("separator_grid", 4), ("separator_rand", 4)])
+                                        ("separator_arrow", 2), ("separator_grid", 2), ("separator_bordered", 2), ("separator_grid", 4), ("separator_rand", 4),
+                                        ("blockcyclic_700_1_full", 2), ("blockcyclic_450_2_rank", 2), ("blockcyclic_530_1_rank", 3)])
 def test_ranks_gloo(case, world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -172,6 +200,9 @@ def test_ranks_gloo(case, world):
         assert err < 1e-12, (rank, err)
         if case.startswith("separator"):
             assert info is not None and info[0] >= 1 and info[1] >= 2
+            continue
+        if case.startswith("blockcyclic"):
+            assert info is not None and info[2] >= 8 and (info[0] + info[1] > 0) == case.endswith("rank"), info
             continue
         if case in ("blocks", "blocks_confined"):
             assert info is not None and sum(info) == 4 and min(info) >= 1

@@ -138,7 +138,22 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
       cost[t] = nz * t_n[t] + (double)t_nslot[t] * t_n[t] * t_n[t];
     }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-    A.t_order.upload(order); }
+    A.t_order.upload(order);
+    // the generic kernel's dispatch order when there are many blocks (64 x 200): the hardware deals consecutive workgroups to the 8 XCDs
+    // in turn, and every task re-reads rows of its block's D_k through its XCD's L2 -- with the constraints in natural order every D_k
+    // was fetched by all eight L2s (246 MB of HBM traffic per launch against the 20 MB of the D_k).  So: block k's tasks go to XCD k % 8,
+    // workgroup 8 s + x takes the s-th task of XCD x's list (heaviest first inside a list); lists that run out leave their turns to the rest.
+    A.t_order_xcd.release();
+    if (sdpN >= 16 && !t_col.empty()) {
+      constexpr int NX = 8;
+      std::vector<std::vector<int>> lst(NX);
+      for (int t : order) lst[t_blk[t] % NX].push_back(t);
+      std::vector<int> ox; ox.reserve(order.size());
+      std::vector<size_t> pos(NX, 0);
+      while (ox.size() < order.size())
+        for (int x = 0; x < NX; x++) if (pos[x] < lst[x].size()) ox.push_back(lst[x][pos[x]++]);
+      A.t_order_xcd.upload(ox);
+    } }
   A.s1_maxnz = 0;
   for (size_t t = 0; t < t_col.size(); t++)
     A.s1_maxnz = std::max<int64_t>(A.s1_maxnz, (t + 1 < t_slotptr.size() ? s_nzptr[t_slotptr[t + 1]] : A.nnzA) - s_nzptr[t_slotptr[t]]);
@@ -493,10 +508,10 @@ struct Stage2Ride {
   const double *Apr;
 };
 __global__ void __launch_bounds__(512, 4)
-k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0, int nzcap, Stage2Ride R2) {
+k_psd_stage1(Stage1Tab T, const double *udsqr, double *zbuf, int ldsY, int task0, int nzcap, Stage2Ride R2, const int *order) {
   SDM_DYN_SMEM(smem);
   double *Y = (double *)smem;                       // Y[slot][row], chunk of CC slots (Hermitian: Re then Im plane)
-  const int task = blockIdx.x + task0;
+  const int task = order ? order[blockIdx.x] : blockIdx.x + task0;      // (order: the XCD-aware dispatch of a launch over all tasks)
   const int n = T.t_n[task], nslot = T.t_nslot[task], ulen = T.t_ulen[task];
   const int herm = T.t_herm[task];
   const int64_t slot0 = T.t_slotptr[task], tend = T.t_end[task];
@@ -1242,7 +1257,8 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
         R2.ada = ada; R2.absd = P->absd.p; R2.ADAjc = A.d_ADAjc.p; R2.Ajc = A.d_Ajc.p; R2.Ajc_psd = A.d_Ajc_psd.p; R2.ADAir = A.d_ADAir.p;
         R2.Ablk = A.d_Ablk.p; R2.Aupos = A.d_Aupos.p; R2.t_col = A.t_col.p; R2.invperm = d_invperm; R2.Apr = A.d_Apr.p;
       }
-      SDM_KLAUNCH(P, k_psd_stage1, dim3((unsigned)ntask), dim3(512), lds, T, A.udsqr.p, A.zbuf.p, (int)(ldsy / sizeof(double)), task0, nzcap, R2);
+      SDM_KLAUNCH(P, k_psd_stage1, dim3((unsigned)ntask), dim3(512), lds, T, A.udsqr.p, A.zbuf.p, (int)(ldsy / sizeof(double)), task0, nzcap, R2,
+                  (ntask == (int)A.ntask && A.t_order_xcd.n == (size_t)ntask) ? (const int *)A.t_order_xcd.p : (const int *)nullptr);
       if (ride) { SDM_HIP_CHECK(hipGetLastError()); return; }
     }
   }

@@ -260,7 +260,7 @@ struct AdaPlan {
   DevBuf<double> d_Apr;
   DevBuf<int> d_Ablk, d_Aupos;            // per PSD nonzero of At: block id, position in U_k
   // stage-1 tasks (constraint j, PSD block k)
-  DevBuf<int> t_col, t_blk, t_n, t_nslot, t_ulen, t_herm, t_order;
+  DevBuf<int> t_col, t_blk, t_n, t_nslot, t_ulen, t_herm, t_order, t_order_xcd;
   DevBuf<int64_t> t_slotptr, t_udoff, t_uoff, t_zoff;
   DevBuf<int> s_col;                      // per slot: column of X_jk
   DevBuf<int64_t> s_nzptr;                // per slot (+1): nonzero range in At

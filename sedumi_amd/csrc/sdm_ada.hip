@@ -874,6 +874,109 @@ k_psd_stage2(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, 
 // 128 MB each way, 715 MB of HBM traffic and two launches of 180 + 200 us).  One workgroup per column j, one pattern entry per work-item as
 // in k_psd_stage2; the symmetry of D_k puts the work-item's own index last in every D access (coalesced).  absd as in getada3.c:341-347.
 constexpr int S1_DIRECT_MAXNZ = 2;
+// ---- the same for FULL columns of ADA' (every row present: a dense ADA' pattern, MAXCUT), JB columns per workgroup.  Round 6: k_psd_direct re-reads
+// the description of constraint i (Ajc_psd[i], Ajc[i+1], Ablk / Air / Apr of its nonzeros: 36+ bytes) for every entry (i, j) -- on MAXCUT-4000
+// 16 M entries x 10 load instructions, ~1.2 GB through the L2s for 256 MB of D_k and ADA': 133 us, 1.9 TB/s.  Here a work-item owns ROW i of the
+// workgroup's JB columns: constraint i is looked up once, the entry's own index is i (no ADAir), and only the D_k terms and the store are per
+// column.  Per entry the same terms in the same order as k_psd_direct: the same bits.
+constexpr int DIRECT_JB = 8;
+__global__ void __launch_bounds__(256)
+k_psd_direct_cols(double *ada, double *absd, const int64_t *ADAjc, const int64_t *Ajc, const int64_t *Ajc_psd, const double *Apr,
+                  const int *Air, const int *Ablk, const int64_t *c_taskptr, const int *t_blk, const int *t_n, const int64_t *t_udoff,
+                  const int64_t *t_slotptr, const int64_t *s_nzptr, const int64_t *t_end, const int64_t *psd_start, const double *udsqr,
+                  int nblk, int jbase, int jend, int m, int base_zero) {
+  SDM_DYN_SMEM(smem);
+  // per column jj of the workgroup and block k: the tables of k_psd_direct
+  const int per_i = 2 * nblk + 2 * S1_DIRECT_MAXNZ * nblk + 2, per_ll = 2 * nblk, per_d = S1_DIRECT_MAXNZ * nblk;
+  int *bn_all = (int *)smem;                                                              // [JB][per_i]
+  long long *ll_all = (long long *)(bn_all + DIRECT_JB * (per_i + (per_i & 1)));          // [JB][per_ll]  (8-byte aligned)
+  double *bx_all = (double *)(ll_all + DIRECT_JB * per_ll);                               // [JB][per_d]
+  __shared__ int jhas_s[DIRECT_JB];
+  int *bnk = (int *)(bx_all + DIRECT_JB * per_d);                                         // [nblk] order of block k if one of the columns touches it, else 0
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int j0 = jbase + DIRECT_JB * blockIdx.x;
+  const int stride_i = per_i + (per_i & 1);
+  for (int jj = 0; jj < DIRECT_JB; jj++) {
+    int *bn = bn_all + jj * stride_i, *bnz = bn + nblk, *brc = bnz + nblk;
+    long long *bud = ll_all + jj * per_ll, *bst = bud + nblk;
+    double *bx = bx_all + jj * per_d;
+    for (int k = tid; k < nblk; k += bs) {
+      bn[k] = 0; bnz[k] = 0; bst[k] = psd_start[k]; bud[k] = 0;
+      for (int w = 0; w < S1_DIRECT_MAXNZ; w++) { brc[(k * S1_DIRECT_MAXNZ + w) * 2] = 0; brc[(k * S1_DIRECT_MAXNZ + w) * 2 + 1] = 0; bx[k * S1_DIRECT_MAXNZ + w] = 0.0; }
+    }
+  }
+  __syncthreads();
+  for (int jj = 0; jj < DIRECT_JB; jj++) {
+    const int j = j0 + jj;
+    if (j >= jend) { if (tid == 0) jhas_s[jj] = 0; continue; }
+    int *bn = bn_all + jj * stride_i, *bnz = bn + nblk, *brc = bnz + nblk;
+    long long *bud = ll_all + jj * per_ll;
+    double *bx = bx_all + jj * per_d;
+    const int64_t tb0 = c_taskptr[j], te0 = c_taskptr[j + 1];
+    if (tid == 0) jhas_s[jj] = te0 > tb0 ? 1 : 0;
+    for (int64_t t = tb0 + tid; t < te0; t += bs) {
+      const int k = t_blk[t], n = t_n[t];
+      const int64_t u0 = s_nzptr[t_slotptr[t]], u1 = t_end[t];
+      bn[k] = n; bud[k] = t_udoff[t]; bnz[k] = (int)(u1 - u0);
+      for (int64_t u = u0; u < u1 && u - u0 < S1_DIRECT_MAXNZ; u++) {
+        const int q = (int)(Air[u] - psd_start[k]);
+        brc[(k * S1_DIRECT_MAXNZ + (int)(u - u0)) * 2] = q % n; brc[(k * S1_DIRECT_MAXNZ + (int)(u - u0)) * 2 + 1] = q / n;
+        bx[k * S1_DIRECT_MAXNZ + (int)(u - u0)] = Apr[u];
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < nblk; k += bs) {
+    int nk = 0;
+    for (int jj = 0; jj < DIRECT_JB; jj++) nk = max(nk, (bn_all + jj * stride_i)[k]);
+    bnk[k] = nk;
+  }
+  __syncthreads();
+  const long long *bst0 = ll_all + nblk;                                                  // (the blocks' first rows: the same for every column)
+  // (the rows are split over gridDim.y workgroups: with all m rows in one workgroup the launch had 2 wavefronts per SIMD and ran at the
+  // latency of its dependent loads -- 175 us against the 133 of k_psd_direct)
+  const int rows_per = ((m + (int)gridDim.y - 1) / (int)gridDim.y + 1) & ~1;
+  const int i_end = min(m, ((int)blockIdx.y + 1) * rows_per);
+  for (int i = (int)blockIdx.y * rows_per + tid; i < i_end; i += bs) {
+    double acc[DIRECT_JB], aabs[DIRECT_JB];
+#pragma unroll
+    for (int jj = 0; jj < DIRECT_JB; jj++) { acc[jj] = 0.0; aabs[jj] = 0.0; }
+    for (int64_t p = Ajc_psd[i]; p < Ajc[i + 1]; p++) {
+      const int k = Ablk[p];
+      const int n = bnk[k];                                                               // (the block's order: one division per nonzero of a_i, not per column)
+      if (n == 0) continue;
+      const int q = (int)(Air[p] - bst0[k]);
+      const double xp = Apr[p];
+      const int c = q / n, r = q - c * n;
+#pragma unroll
+      for (int jj = 0; jj < DIRECT_JB; jj++) {
+        const int *bn = bn_all + jj * stride_i;
+        if (bn[k] == 0 || !jhas_s[jj]) continue;
+        const int *bnz = bn + nblk, *brc = bnz + nblk;
+        const double *D = udsqr + (ll_all + jj * per_ll)[k];
+        const double *bx = bx_all + jj * per_d;
+        double zv = 0.0;
+        for (int w = 0; w < bnz[k]; w++) {
+          const int s2 = brc[(k * S1_DIRECT_MAXNZ + w) * 2], t2 = brc[(k * S1_DIRECT_MAXNZ + w) * 2 + 1];
+          const double *Ds = D + (int64_t)s2 * n, *Dt = D + (int64_t)t2 * n;
+          zv += bx[k * S1_DIRECT_MAXNZ + w] * (Ds[r] * Dt[c] + Ds[c] * Dt[r]);
+        }
+        const double term = xp * (zv / 2);
+        acc[jj] += term; aabs[jj] += fabs(term);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < DIRECT_JB; jj++) {
+      const int j = j0 + jj;
+      if (j >= jend) continue;
+      const int64_t e = ADAjc[j] + i;                                                     // (full column: row i is its i-th entry)
+      const double base = base_zero ? 0.0 : ada[e];
+      ada[e] = base + acc[jj];
+      if (i == j) absd[j] = jhas_s[jj] ? base + aabs[jj] : 0.0;
+    }
+  }
+}
+
 constexpr size_t S1_DIRECT_LDS_MAX = 48 * 1024;   // its per-block tables (56 bytes per PSD block) must fit the default dynamic-LDS limit
 __global__ void __launch_bounds__(256)
 k_psd_direct(double *ada, double *absd, const int64_t *ADAjc, const int *ADAir, const int64_t *Ajc, const int64_t *Ajc_psd, const double *Apr,
@@ -1208,6 +1311,16 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
     }
     const int nb = (int)A.sdpN;
     const size_t lds = direct_lds;
+    // full columns (a dense ADA' pattern) and no skipped triangle: DIRECT_JB columns per workgroup, constraint i looked up once per row
+    const size_t lds_cols = (size_t)DIRECT_JB * (direct_lds + 16) + (size_t)A.sdpN * sizeof(int);
+    if (!d_invperm && (int64_t)(P->ada_jc[A.col1] - P->ada_jc[A.col0]) == (int64_t)ncols * m && lds_cols <= S1_DIRECT_LDS_MAX) {
+      const int ysplit = std::max(1, std::min(16, (int)((m + 511) / 512)));             // two rows per work-item
+      SDM_KLAUNCH(P, k_psd_direct_cols, dim3((ncols + DIRECT_JB - 1) / DIRECT_JB, ysplit), dim3(256), lds_cols, ada, P->absd.p, A.d_ADAjc.p, A.d_Ajc.p, A.d_Ajc_psd.p, A.d_Apr.p,
+                  A.d_Air.p, A.d_Ablk.p, A.c_taskptr.p, A.t_blk.p, A.t_n.p, A.t_udoff.p, A.t_slotptr.p, A.s_nzptr.p, A.t_end.p, A.d_psd_start.p, A.udsqr.p,
+                  nb, jbase, jbase + ncols, m, direct_zero ? 1 : 0);
+      SDM_HIP_CHECK(hipGetLastError());
+      return;
+    }
     SDM_KLAUNCH(P, k_psd_direct, dim3(ncols), dim3(256), lds, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, A.d_Ajc.p, A.d_Ajc_psd.p, A.d_Apr.p, A.d_Air.p,
                 A.d_Ablk.p, A.c_taskptr.p, A.t_blk.p, A.t_n.p, A.t_udoff.p, A.t_slotptr.p, A.s_nzptr.p, A.t_end.p, A.d_psd_start.p, A.udsqr.p,
                 d_invperm, nb, jbase, direct_zero ? 1 : 0);

@@ -543,3 +543,28 @@ def check_refinement_prediction(m=300):
     c = solves(4)
     assert c[0] >= c[1] >= c[2] >= c[3] and c[2:] == [lean, lean], c  # dropped after a few clean sweeps
     plan.close()
+
+
+def check_direct_columns_kernel(n):
+    """k_psd_direct_cols (full columns of a dense ADA' pattern, 8 columns per workgroup: the resident plan on MAXCUT-shaped problems) against
+    k_psd_direct (one column per workgroup: what the MEX route with its Aord permutations runs): the same bits, also for a column panel
+    (sdm_plan_getada_cols, the multi-GPU hook) whose width is not a multiple of 8."""
+    import scipy.sparse as sp
+    from sedumi_amd import mex, problem
+    from sedumi_amd.plan import Plan
+    P = problem.maxcut(n)
+    d, ud = problem.spd_scaling(P.K, seed=5)
+    L, ADA = problem.dense_symbolic(P.m), problem.dense_pattern(P.m)
+    plan = Plan(0)
+    plan.set_chol(L, ADA); plan.set_ada(P.At, P.Ablkjc, P.K, problem.lorentz_pattern(P))
+    plan.upload("dl", d["l"]); plan.upload("ddet", d["det"]); plan.upload("udsqr", ud)
+    plan.kprof(True); plan.getada(); prof = plan.kprof_summary(); plan.kprof(False)
+    assert "k_psd_direct_cols" in prof and "k_psd_direct" not in prof, sorted(prof)
+    a1, s1 = plan.download("ada"), plan.download("absd")
+    perm1 = np.arange(1, P.m + 1, dtype=np.float64)
+    A0 = mex.getada1(ADA, P.At, P.Ablkjc[:, 2], perm1, d, P.K["qblkstart"])
+    A3, absd = mex.getada3(A0, P.At, P.Ablkjc[:, 2], {"sperm": perm1}, ud, P.K)
+    assert np.array_equal(a1, sp.csc_matrix(A3).toarray().ravel(order="F")) and np.array_equal(s1, np.asarray(absd).ravel())
+    plan.upload("ada", np.full(plan.nnzADA, np.nan)); plan.getada_cols(5, n - 7)
+    a3 = plan.download("ada").reshape(n, n, order="F")
+    assert np.array_equal(a3[:, 5:n - 7], a1.reshape(n, n, order="F")[:, 5:n - 7]) and np.isnan(a3[:, :5]).all() and np.isnan(a3[:, n - 7:]).all()

@@ -101,6 +101,11 @@ def test_iteration_unit_many_tiny_blocks_keep_the_two_stage_path(glue):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("n", [90, 133])
+def test_direct_kernel_for_full_columns_matches_the_generic_one(n):
+    helpers.check_direct_columns_kernel(n)
+
+
 def test_iteration_unit_maxcut_small(glue):
     from sedumi_amd import problem
     errs, S, _ = check_iteration(glue, problem.maxcut(90), seed=5)

@@ -58,6 +58,13 @@ def test_blockdiag_multi_supernode_unit(glue):
     assert S["L"]["xsuper"].size - 1 >= 12
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [133, 1000])
+def test_direct_kernel_for_full_columns_matches_the_generic_one(n):
+    helpers.check_direct_columns_kernel(n)
+
+
+@pytest.mark.gpu
 def test_maxcut_unit(glue):
     from sedumi_amd import problem
     check_iteration(glue, problem.maxcut(600), seed=3)

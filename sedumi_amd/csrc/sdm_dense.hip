@@ -5,9 +5,9 @@
 // (deninfac.m:58-94).  What is here:
 //   * sdm_symbfwblk   symbolic pattern of L \ b(perm,:)           (symbfwblk.c:87-263)   host, integers
 //   * sdm_finsymbden  column order / first affecting pivot         (finsymbden.c:71-214)  host, integers
-//   * sdm_dpr1fact    the product-form factorisation itself        (dpr1fact.c:97-621)    host: a chain of scalar
-//                     recurrences with data-dependent pivot postponement and a sort; it does not shard and is
-//                     launched once per iteration on an m x nden problem (nden = a handful of columns)
+//   * sdm_dpr1fact    the product-form factorisation itself        (dpr1fact.c:97-621)    on the DEVICE since round 4 (sdm_dpr1.hip:
+//                     k_dpr1_deps, k_dpr1_general -- the whole of dodpr1fact incl. postponed pivots, findnewdep and the sort -- , k_dpr1_apply);
+//                     this file keeps the entry point, which uploads the gathered columns, runs those kernels and downloads
 //   * sdm_fwdpr1 / sdm_bwdpr1  apply prod_k L_k^{-1} / its transpose  (fwdpr1.c:70-90, bwdpr1.c:65-160,
 //                     auxfwdpr1.c:44-122): device kernels -- these run inside every normal-equation solve
 //                     (4+ times per iteration, wrapPcg.m:56-59).  Each factor is a first-order recurrence in a

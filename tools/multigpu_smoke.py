@@ -5,7 +5,7 @@ world_size 2 / 4 on gloo with the emulator).  One process per GPU:
 
 Every case builds its problem on all ranks, runs the sharded object (RCCL collectives on device buffers of the plans) and the
 single-plan reference on the rank's own GPU, and rank 0 prints one JSON line per case: {"case", "world", "max_rel_err", "ok"}.
-Expected: every line "ok": true with max_rel_err < 1e-12 (tools/multigpu_smoke.expected.txt)."""
+Expected: every line "ok": true with max_rel_err < 1e-12 (blockcyclic: 0, it is compared bit for bit) (tools/multigpu_smoke.expected.txt)."""
 import json
 import os
 import sys
@@ -86,6 +86,19 @@ def main():
     one.blkchol(pars, False); one.ldlsolve()
     x1 = one.download("y")
     report("separator_grid", float(np.abs(xs - x1).max() / np.abs(x1).max()))
+    # ---- ONE dense front, block-column-cyclic over the ranks (a broadcast per 64-column panel): bit for bit the single plan
+    mm = 900
+    rng = np.random.default_rng(mm)
+    B = rng.standard_normal((mm, mm - 9))                              # nine dependent columns: the skip / add decisions travel in the records
+    Xd = B @ B.T / mm
+    absd = np.abs(Xd).sum(axis=1)
+    Lsym, pat = problem.dense_symbolic(mm), problem.dense_pattern(mm)
+    vals = Xd.ravel(order="F")
+    one = Plan(lr); one.set_one_launch_fronts(False); one.set_chol(Lsym, pat); one.upload("ada", vals); one.upload("absd", absd); one.blkchol(pars, True)
+    bc = sd.BlockCyclicFactor(Lsym, pat, device_index=lr, device=dev)
+    bc.factor(vals, pars, absd)
+    same = np.array_equal(bc.plan.download("lpr"), one.download("lpr")) and np.array_equal(bc.plan.download("d"), one.download("d"))
+    report("blockcyclic", 0.0 if same else 1.0)
     dist.destroy_process_group()
 
 

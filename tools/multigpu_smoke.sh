@@ -10,3 +10,4 @@ $RUN --master-port 29535 bench.py --gpus $N --steps 5 --warmup 2 --workload maxc
 $RUN --master-port 29536 bench.py --gpus $N --steps 20 --warmup 3 --workload blockdiag
 $RUN --master-port 29537 bench.py --gpus $N --steps 20 --warmup 3 --workload grid:120
 $RUN --master-port 29538 bench.py --gpus $N --steps 20 --warmup 3 --workload control07 --shard replicas --no-cpu-baseline --no-other-configs
+$RUN --master-port 29539 bench.py --gpus $N --steps 5 --warmup 2 --workload maxcut2000 --shard blockcyclic --no-cpu-baseline

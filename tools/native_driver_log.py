@@ -17,7 +17,10 @@ for name in sys.argv[1:] or ["control07"]:
     t0 = time.time()
     r = lp.Sedumi(At, g["b"], g["c"], K, internal=True).solve()
     t1 = time.time()
-    ref = td.reference_run(name)
+    if name in ("trto3", "OH_2Pi"):                     # (six CPU minutes each with the reference MEX: their reference-hot-path run is a committed fixture)
+        ref = {"iter": int(g["iter"]), "cx": float(g["cx"]), "by": float(g["by"]), "STOP": None, "rows": []}
+    else:
+        ref = td.reference_run(name)
     t2 = time.time()
     print(json.dumps({"problem": name, "native_iter": r["iter"], "ref_iter": ref["iter"], "native_cx": r["cx"], "ref_cx": ref["cx"], "native_by": r["by"], "ref_by": ref["by"],
                       "opt": td.OPT.get(name), "native_STOP": r["STOP"], "ref_STOP": ref["STOP"], "native_feasratio": r["feasratio"], "native_s": t1 - t0, "reference_s": t2 - t1,

@@ -699,6 +699,38 @@ def mex_inclusive(P, L, ADA, Q, d, ud, rhs, qpr, units, y_resident=None, mex_dir
         return {"error": repr(e)}
 
 
+def whole_solve_leg(name="control07", with_reference=True):
+    """--other-configs: a WHOLE interior-point solve of one of the reference's examples by the product's MATLAB-free driver (sedumi_amd.driver:
+    sedumi.m's loop restated, the hot path on the resident plan, the cone algebra outside it on numpy / LAPACK) and -- the CPU baseline beside it --
+    the same loop with the compiled reference as every MEX (tests/driver + oracle/_ref: the checker, timed like cpu_baseline).  Seconds and iterations."""
+    try:
+        z = np.load(os.path.join(ROOT, "tests", "golden", f"driver_{name}.npz"))
+        import scipy.sparse as sp
+        from sedumi_amd import problem
+        from sedumi_amd.driver import loop as lp
+        g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+        At = sp.csc_matrix((g["At_data"], g["At_indices"], g["At_indptr"]), shape=tuple(g["At_shape"]))
+        K = problem.make_K(int(g["K_l"]), g["K_q"].ravel(), g["K_s"].ravel())
+        t0 = time.perf_counter()
+        r = lp.Sedumi(At, z["b"], z["c"], K, internal=True).solve()
+        out = {"workload": name + " (whole solve, sedumi_amd.driver)", "seconds": time.perf_counter() - t0, "iterations": int(r["iter"]), "cx": float(r["cx"]), "by": float(r["by"]),
+               "stop": int(r["STOP"])}
+        if with_reference:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from driver import sedumi_loop as sl
+                t0 = time.perf_counter()
+                rr = sl.Sedumi(At, z["b"], z["c"], K, internal=True).solve()
+                out["cpu_baseline"] = {"seconds": time.perf_counter() - t0, "iterations": int(rr["iter"]), "cx": float(rr["cx"]), "cores": 1, "kind": "reference",
+                                       "sample": "the same loop with the compiled reference as every MEX (oracle/_ref), one whole solve"}
+                out["speedup_vs_cpu_reference"] = out["cpu_baseline"]["seconds"] / out["seconds"]
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
+        return out
+    except Exception as e:  # never break the bench line
+        return {"workload": name + " (whole solve)", "error": repr(e)}
+
+
 def bench_subtrees(args, rank, local_rank, world, torch, dist, coll_dev):
     """BASELINE.json configs[4]: block-diagonal SDP (default 64 PSD blocks of order 200, 150 constraints each).  The
     64 independent elimination-tree subtrees are dealt to the ranks (sedumi_amd.dist.SubtreeShardedSolver): ADA',
@@ -975,6 +1007,7 @@ def main():
                                                   ("nb_init", 100, 5, 20, 0, 0), ("maxcut4000", 10, 2, 5, 2, 1), ("blockdiag", 20, 3, 10, 2, 3)):
                     if nm != args.workload:
                         others.append(measure_config(nm, local_rank, st, wu, npf, mxu, cpu_units=0 if nocpu else cpu))
+                others.append(whole_solve_leg("control07", with_reference=not nocpu))
                 others.append(solve_leg("maxcut4000", local_rank))
                 others.append(solve_leg("maxcut8000", local_rank))
                 if headline:

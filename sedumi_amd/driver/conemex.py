@@ -354,6 +354,14 @@ def sortnnz(At, Ajc1=None, Ajc2=None):
     return _col(np.argsort(hi - lo, kind="stable") + 1.0)
 
 
+def unwrap_raw(args):
+    """arguments for this package's own functions: RawSparse wrappers (sedumi_amd.mexhost: "hand this sparse matrix to a MEX as stored") taken off,
+    at the top level and inside structs"""
+    from sedumi_amd.mexhost import RawSparse
+    one = lambda a: a.X if isinstance(a, RawSparse) else ({k: (v.X if isinstance(v, RawSparse) else v) for k, v in a.items()} if isinstance(a, dict) else a)
+    return tuple(one(a) for a in args)
+
+
 # ------------------------------------------------------------------------------------------------ the host
 class NativeMex:
     """`.call(name, nlhs, *args)` like a MEX host: the cone algebra above, the hot path and the symbolic analysis through this package's library."""
@@ -366,6 +374,7 @@ class NativeMex:
                         "givensrot": givensrot, "partitA": partitA, "extractA": extractA, "findblks": findblks, "sortnnz": sortnnz}
 
     def call(self, name, nlhs, *args):
+        args = unwrap_raw(args)
         if name in self._native:
             return self._native[name](*args)
         if name == "qrK":

@@ -205,6 +205,19 @@ class Glue:
         L["split"] = ref.call("cholsplit", 1, L, cachsz)
         return L
 
+    @staticmethod
+    def raw(X):
+        """a sparse matrix to be handed to a MEX exactly as stored (incorder's dz: the row order inside its columns is data)"""
+        from sedumi_amd.mexhost import RawSparse
+        return RawSparse(X)
+
+    # symbcholden.m:43-55, dense LP columns only (LAD = [symbfwblk(L, dense.A(:, 1:dense.l))]; no Lorentz blocks / trace columns)
+    def symbcholden(self, L, dense):
+        ref = self.ref
+        LAD = ref.call("symbfwblk", 1, L, sp.csc_matrix(dense["A"]))
+        perm, dz = ref.call("incorder", 2, LAD)
+        return ref.call("finsymbden", 1, LAD, perm, self.raw(dz), float(int(dense["l"]) + 1))
+
     # sedumi.m:356-392
     def setup(self, A, K, denq=0.75, denf=10.0):
         ref = self.ref

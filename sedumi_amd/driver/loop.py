@@ -104,29 +104,56 @@ def default_pars():
 
 
 # ----------------------------------------------------------------------------------------------- hot paths
-class MexShapedHot:
-    """sedumi.m:442-463 for a hot path that is called MEX by MEX: ADA', blkchol, deninfac.m:87-94 (no dense columns)."""
+def _skipfix(Ld, skip, absd, perm, pars):
+    """deninfac.m:87-94: a skipped pivot whose (updated) d is still at most its threshold acts as 1"""
+    if skip.size:
+        perm0 = vec(perm).astype(int) - 1
+        dtol = np.maximum(pars["canceltol"] * vec(absd)[perm0[skip]], pars["abstol"])
+        Ld[skip[Ld[skip] <= dtol]] = 1.0
+    return Ld
 
-    def factor(self, S, d, DAt, L, pars):
+
+class MexShapedHot:
+    """sedumi.m:442-463 for a hot path that is called MEX by MEX: ADA', blkchol, deninfac.m:58-94 (dense LP columns: sparfwslv + dpr1fact)."""
+
+    def mexcall(self, name, nlhs, *args):                           # the MEX host of this hot path (subclasses)
+        raise NotImplementedError
+
+    def factor(self, S, d, DAt, L, pars, den=None):
         ADA, absd = self.form(S, d, DAt)                            # sedumi.m:446-452
         self.last_ADA = ADA
         LL, Ld, Lskip, Ladd = self.blkchol(L, ADA, pars, absd)      # sedumi.m:458
         L = dict(L)
         L["L"] = LL
         Ld = vec(Ld).copy()
+        L["den"] = None
+        if den is not None:                                         # deninfac.m:58-76 (dense LP columns)
+            sym = den["sym"]
+            LAD = self.mexcall("fwblkslv", 1, L, den["A"], sym["LAD"])                     # sparfwslv.m:55-57
+            Lden, Ld2 = self.mexcall("dpr1fact", 2, LAD, col(Ld), den["symstruct"], col(vec(d["l"])[den["rows"]]), float(pars["maxuden"]))
+            Lden = dict(Lden); Lden["dz"], Lden["first"], Lden["perm"] = den["symstruct"]["dz"], sym["first"], sym["perm"]
+            L["den"], Ld = Lden, vec(Ld2).copy()
         skip = sp.csc_matrix(Lskip).nonzero()[0]                    # deninfac.m:87-94
-        if skip.size:
-            perm0 = vec(L["perm"]).astype(int) - 1
-            dtol = np.maximum(pars["canceltol"] * vec(absd)[perm0[skip]], pars["abstol"])
-            Ld[skip[Ld[skip] <= dtol]] = 1.0
+        Ld = _skipfix(Ld, skip, absd, L["perm"], pars)
         L["d"], L["skip"], L["add"] = Ld, Lskip, Ladd
         L["nskip"], L["nadd"] = int(sp.csc_matrix(Lskip).nnz), int(sp.csc_matrix(Ladd).nnz)
         return L
+
+    def fwdpr1(self, L, b):                                         # wrapPcg.m:56
+        return b if L.get("den") is None else vec(self.mexcall("fwdpr1", 1, L["den"], col(b)))
+
+    def bwdpr1(self, L, b):                                         # wrapPcg.m:59
+        return b if L.get("den") is None else vec(self.mexcall("bwdpr1", 1, L["den"], col(b)))
 
 
 class HipHot(MexShapedHot):
     """This repository's library behind the same calls (sedumi_amd.mex mirrors the MEX signatures)."""
     name = "sedumi_amd"
+
+    def mexcall(self, name, nlhs, *args):
+        from sedumi_amd import mex
+        from .conemex import unwrap_raw
+        return getattr(mex, name)(*unwrap_raw(args))
 
     def form(self, S, d, DAt):
         from sedumi_amd import mex
@@ -161,12 +188,15 @@ class PlanHot:
         self.device, self.plan = device, None
         self._pcg, self._d, self._want_ops = False, None, device_ops
 
-    def factor(self, S, d, DAt, L, pars):
+    def factor(self, S, d, DAt, L, pars, den=None):
         from sedumi_amd.plan import Plan
         K = S["K"]
         if self.plan is None:
             self.plan = Plan(self.device)
             self.plan.set_chol(S["L"], S["ADA"])
+            if den is not None:                                     # dense LP columns: the resident dense-column unit (sdm_plan_set_dense / _deninfac)
+                self.plan.set_dense(den["symstruct_plain"])
+                self.plan.upload("ad", np.asarray(sp.csc_matrix(den["A"]).todense()).ravel(order="F"))
             self.plan.set_ada(S["A"], S["Ablkjc"], K, S["DAt"]["q"] if K["q"].size else None)
             self._N = int(S["A"].shape[0])
             ks = K["s"].ravel().astype(int); nr = int(K["rsdpN"])
@@ -187,11 +217,27 @@ class PlanHot:
         (si, _), (ai, _) = pl.pivots()
         pat = pl.ADA_pattern
         self.last_ADA = sp.csc_matrix((pl.download("ada"), pat.indices, pat.indptr), shape=pat.shape)
-        Ld = pl.download("d")
-        Ld[si] = np.where(Ld[si] <= 0.0, 1.0, Ld[si])               # deninfac.m:87-94 (skipped pivots carry d = 0)
         L = dict(L)
+        L["den"] = None
+        if den is not None:                                         # deninfac.m:58-76: LAD = L \ Ad and the product-form factors, on the device
+            pl.deninfac(vec(d["l"])[den["rows"]], float(pars["maxuden"]))
+            Lden, Ld = pl.lden()
+            Lden = dict(Lden); Lden["dz"], Lden["first"], Lden["perm"] = den["symstruct_plain"]["dz"], den["sym"]["first"], den["sym"]["perm"]
+            L["den"] = Lden
+            Ld = _skipfix(Ld, si, pl.download("absd"), L["perm"], pars)
+        else:
+            Ld = pl.download("d")
+            Ld[si] = np.where(Ld[si] <= 0.0, 1.0, Ld[si])           # deninfac.m:87-94 (skipped pivots carry d = 0)
         L["d"], L["nskip"], L["nadd"] = Ld, int(si.size), int(ai.size)
         return L
+
+    def fwdpr1(self, L, b):                                         # wrapPcg.m:56 (the library's product-form kernels)
+        from sedumi_amd import mex
+        return b if L.get("den") is None else vec(mex.fwdpr1(L["den"], col(b)))
+
+    def bwdpr1(self, L, b):                                         # wrapPcg.m:59
+        from sedumi_amd import mex
+        return b if L.get("den") is None else vec(mex.bwdpr1(L["den"], col(b)))
 
     def fw(self, L, r):
         self.plan.upload("rhs", vec(r)); self.plan.fwsolve()
@@ -205,6 +251,7 @@ class PlanHot:
     # (reference-held optimal values of examples/test_sedumi.m:22-28, the reference-hot-path log) pin them through every PCG step
     def has_ops(self, d=None):
         return self._want_ops and self.plan is not None and self._pcg and (d is None or d is self._d)
+        # (with dense columns the loop keeps Amul on the host: Sedumi._ops)
 
     def Amul(self, x, transp):
         pl = self.plan
@@ -444,30 +491,46 @@ class Sedumi:
             At, b, c, K = pretransfo(At, b, c, K)                       # sedumi.m:261
         self.A, self.b, self.c, self.K = sp.csc_matrix(At), vec(b), vec(c), K
         self.S = self.G.setup(self.A, K, self.pars["denq"], self.pars["denf"])     # sedumi.m:356-392
-        if len(self.S["dense"]["cols"]):
-            raise NotImplementedError("dense columns are outside this restatement")
+        self.den = None
+        dense = self.S["dense"]
+        if len(dense["cols"]):
+            # dense COLUMNS of A = dense variables (rows of At), sedumi.m:356-364: taken out of ADA' and brought back as a product of rank-1
+            # factors (symbcholden.m:43-55, deninfac.m:58-76, wrapPcg.m:56-59).  LP variables only; a dense Lorentz block (getdense.m:58-60,
+            # adendotd / adenscale) is not restated
+            if len(dense["q"]) or int(dense["l"]) != len(dense["cols"]):
+                raise NotImplementedError("dense Lorentz blocks are outside this restatement (dense LP columns are handled)")
+            sym = self.G.symbcholden(self.S["L"], dense)
+            self.den = {"rows": np.asarray(dense["cols"], dtype=np.int64) - 1, "A": sp.csc_matrix(dense["A"]), "sym": sym,
+                        "symstruct": {"dz": self.G.raw(sym["dz"]), "perm": sym["perm"], "first": sym["first"]},
+                        "symstruct_plain": {"LAD": sym["LAD"], "dz": sym["dz"], "perm": sym["perm"], "first": sym["first"]}}
         self.A = sp.csc_matrix(self.S["A"])
         self.cone = Cone(self.ref, K)
         self.hot = hot or PlanHot()
 
-    # Amul.m (no dense columns)
+    # Amul.m:43-56
     def _ops(self, d=None):
         """the hot path's own Amul / vecsym / psdscale (PlanHot: on the device), when it has them for this scaling"""
         h = self.hot
-        return h if getattr(h, "has_ops", None) and h.has_ops(d) else None
+        return h if self.den is None and getattr(h, "has_ops", None) and h.has_ops(d) else None
 
     def Amul(self, x, transp=0):
         h = self._ops()
         if h is not None:
             return vec(h.Amul(x, transp))
-        return vec(self.A.T @ x) if not transp else vec(self.A @ x)
+        if not transp:
+            y = vec(self.A.T @ x)
+            return y if self.den is None else y + vec(self.den["A"] @ vec(x)[self.den["rows"]])      # Amul.m:52
+        y = vec(self.A @ x)
+        if self.den is not None:
+            y[self.den["rows"]] = vec(self.den["A"].T @ x)                                           # Amul.m:54
+        return y
 
     def Amul1_vecsym(self, p):
         """vecsym(Amul(At,dense,p,1), K)   (wrapPcg.m:65)"""
         h = self._ops()
         if h is not None:
             return vec(h.Amul1_vecsym(p))
-        return self.cone.vecsym(vec(self.A @ p))
+        return self.cone.vecsym(self.Amul(p, 1))
 
     def psdscale(self, d, x, transp=False):
         """psdscale(d, x, K[, transp]); x full length or its PSD part only"""
@@ -522,11 +585,14 @@ class Sedumi:
         R["w"] = 2 * pars["w"] * np.array([R["maxRb"], R["maxRc"]]) / np.array([1 + R["maxb"], 1 + R["maxc"]])
         return d, v, vfrm, y, y0, R
 
-    # ---- wrapPcg.m:40-130 / loopPcg.m (no dense columns: fwdpr1 / bwdpr1 are the identity)
+    # ---- wrapPcg.m:40-130 / loopPcg.m
     def precond(self, L, r):
-        p = vec(self.hot.fw(L, r))
+        p = self.hot.fwdpr1(L, vec(self.hot.fw(L, r)))              # wrapPcg.m:56  p = fwdpr1(Lden, sparfwslv(L, r))
         yv = p / L["d"]
         return p, yv
+
+    def bwsolve(self, L, yv):
+        return vec(self.hot.bw(L, self.hot.bwdpr1(L, yv)))         # wrapPcg.m:59  sparbwslv(L, bwdpr1(Lden, y))
 
     def wrapPcg(self, L, d, DAt, rb, rv, cgpars, y0):
         cn = self.cone
@@ -537,7 +603,7 @@ class Sedumi:
             r = r + rb
         p, yv = self.precond(L, r)
         ssqrNew = p @ yv
-        p = vec(self.hot.bw(L, yv))
+        p = self.bwsolve(L, yv)
         x = self.Amul1_vecsym(p)
         dx = self.Dx(d, x, False)
         ssqrdx = dx @ dx
@@ -595,12 +661,12 @@ class Sedumi:
             Lr, tmp = self.precond(L, r)
             if p is None:
                 ssqrNew = Lr @ tmp
-                p = vec(self.hot.bw(L, tmp))
+                p = self.bwsolve(L, tmp)
             else:
                 ssqrOld = ssqrNew
                 ssqrNew = Lr @ tmp
                 p = (ssqrNew / ssqrOld) * p
-                p = p + vec(self.hot.bw(L, tmp))
+                p = p + self.bwsolve(L, tmp)
             Ap = self.Amul1_vecsym(p)
             DDAp, DApq, DAps, ssqrDAp = self.PopK(d, Ap)
             if ssqrDAp > 0.0:
@@ -981,7 +1047,7 @@ class Sedumi:
                 stepdif = 1
             self.pars["stepdif"] = stepdif
             DAt = self.G.getDAtm(S, d)                              # sedumi.m:442
-            L = hot.factor(S, d, DAt, L, pars["chol"])                 # sedumi.m:446-463
+            L = hot.factor(S, d, DAt, L, pars["chol"]) if self.den is None else hot.factor(S, d, DAt, L, pars["chol"], self.den)   # sedumi.m:446-463
             Lsd = self.sdfactor(L, d, DAt, v, y, R, y0)              # sedumi.m:466
             y0Old = y0
             xscl, yNxt, zscl, y0Nxt, w, relt, dxmdz, err, wr = self.wregion(L, Lsd, d, v, vfrm, DAt, R, y, y0, wr)

@@ -38,6 +38,9 @@ class RefHot(MexShapedHot):
     def __init__(self, G):
         self.G, self.ref = G, G.ref
 
+    def mexcall(self, name, nlhs, *args):
+        return self.ref.call(name, nlhs, *args)
+
     def form(self, S, d, DAt):
         K, ref = S["K"], self.ref
         if np.sum(K["s"]) == 0:                                    # getada.m:13-40
@@ -73,6 +76,9 @@ class ShimHot(MexShapedHot):
     global ADA_sedumi_ handed from iteration to iteration as sedumi.m:450-452 does (`ADA_sedumi_ = getada1(ADA_sedumi_, ...)`: with
     lazy intermediates the array that comes back is a token, and it goes in again next time), L.L / L.d through blkchol.mex."""
     name = "sedumi_amd.mexshims"
+
+    def mexcall(self, name, nlhs, *args):
+        return self.host.call(name, nlhs, *args)
 
     def __init__(self, host):
         self.host, self.ADA = host, None                          # host.call(name, nlhs, *args): oracle.refmex.RefMex(mex_dir=<shims>) or sedumi_amd.mexhost.MexHost
@@ -128,6 +134,12 @@ class ShadowHot:
                     "dcond": float(np.max(Lp["d"]) / max(np.min(Lp["d"]), 1e-300))}
         self.records.append(self.cur)
         return Lp
+
+    def fwdpr1(self, L, b):                                        # (no dense columns in the shadow runs: the identity)
+        return self.primary.fwdpr1(L, b)
+
+    def bwdpr1(self, L, b):
+        return self.primary.bwdpr1(L, b)
 
     def fw(self, L, r):
         a, b = self.primary.fw(L, r), self.shadow.fw(self.Ls, r)

@@ -210,6 +210,55 @@ def test_user_level_entry_point_on_a_small_sdp():
     assert abs(r["cx"] - r["by"]) <= 1e-6 * (1 + abs(r["cx"]))
 
 
+def _dense_lp(m, n, nd, seed):
+    """a feasible, bounded LP whose first nd variables appear in every constraint (dense columns of A: getdense.m:38-75 takes them out of ADA')"""
+    rng = np.random.default_rng(seed)
+    A = sp.random(m, n, density=0.03, random_state=seed, format="csr").toarray()
+    A[:, :nd] = rng.standard_normal((m, nd))
+    A[np.arange(m), nd + np.arange(m)] += 1.0                                   # full row rank
+    x0 = 1 + rng.random(n)
+    b = A @ x0
+    c = (1 + rng.random(n)) + A.T @ rng.standard_normal(m)
+    return A, b, c
+
+
+def test_dense_columns_through_the_product_form_on_the_emulated_library():
+    """sedumi.m:356-364, symbcholden.m:43-55, deninfac.m:58-76, wrapPcg.m:56-59 in the product driver: an LP with three dense columns is solved
+    through symbfwblk / incorder / finsymbden, the sparse forward solve of the dense columns, dpr1fact and fwdpr1 / bwdpr1 around every solve
+    (SURVEY.md 8a rows a18, a20 - a22 in a whole solve) -- against HiGHS, and against the same loop with the compiled reference everywhere."""
+    from scipy.optimize import linprog
+    from driver import sedumi_loop as sl
+    from sedumi_amd.driver import loop as lp
+    helpers.use_emu()
+    A, b, c = _dense_lp(70, 400, 3, 3)
+    want = linprog(c, A_eq=A, b_eq=b, bounds=(0, None), method="highs")
+    assert want.status == 0
+    At, K = sp.csc_matrix(A.T), {"l": A.shape[1]}
+    S = lp.Sedumi(At, b, c, K, hot=lp.HipHot())
+    assert S.den is not None and np.array_equal(S.den["rows"], [1, 2, 3])         # (row 0 of the internal At is x0, pretransfo.m)
+    r = S.solve()
+    assert abs(r["cx"] - want.fun) <= 1e-6 * abs(want.fun) and abs(r["by"] - want.fun) <= 1e-6 * abs(want.fun)
+    ref = sl.Sedumi(At, b, c, K).solve()                                          # oracle MEX host, reference hot path incl. its dpr1fact / fwdpr1 / bwdpr1
+    assert ref["hot"] == "reference" and abs(ref["cx"] - want.fun) <= 1e-6 * abs(want.fun)
+    assert abs(r["iter"] - ref["iter"]) <= 1
+
+
+@pytest.mark.gpu
+def test_dense_columns_on_the_resident_plan_on_the_gpu():
+    """The same with the product's default hot path: the resident dense-column unit (sdm_plan_set_dense / sdm_plan_deninfac: the forward solve of the dense columns and
+    dpr1fact on the device) and the product-form kernels around every solve."""
+    from scipy.optimize import linprog
+    from sedumi_amd.driver import loop as lp
+    helpers.use_hip()
+    A, b, c = _dense_lp(150, 900, 5, 7)
+    want = linprog(c, A_eq=A, b_eq=b, bounds=(0, None), method="highs")
+    assert want.status == 0
+    S = lp.Sedumi(sp.csc_matrix(A.T), b, c, {"l": A.shape[1]})
+    assert S.den is not None and S.den["rows"].size == 5 and type(S.hot).__name__ == "PlanHot"
+    r = S.solve()
+    assert abs(r["cx"] - want.fun) <= 1e-6 * abs(want.fun) and abs(r["by"] - want.fun) <= 1e-6 * abs(want.fun)
+
+
 def test_the_product_does_not_import_the_oracle():
     pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b|from\s+\.\.?oracle\b)", re.M)
     bad = []

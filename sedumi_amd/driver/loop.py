@@ -13,8 +13,8 @@ reference's own example problems, on top of
     r = solve(At, b, c, K)            # r["x"], r["y"], r["cx"], r["by"], r["iter"], r["feasratio"], r["rows"] (the iteration log)
 
 The tests run the same loop with the compiled reference as the MEX host and / or as the hot path (tests/driver/sedumi_loop.py:
-RefHot, ShimHot, ShadowHot) and compare the logs.  Restrictions: real data, no free variables / rotated cones (pretransfo_real), no dense
-columns (the shipped examples have none with default pars), pars = checkpars.m defaults.
+RefHot, ShimHot, ShadowHot) and compare the logs.  Restrictions: real or Hermitian data, no free variables / rotated cones (pretransfo_real), dense LP columns handled
+(sedumi.m:356-364, deninfac.m:58-76) but no dense Lorentz blocks, pars = checkpars.m defaults.
 """
 from __future__ import annotations
 

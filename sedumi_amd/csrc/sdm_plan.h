@@ -205,6 +205,7 @@ struct CholPlan {
   std::vector<int64_t> sn_ltoff; DevBuf<int64_t> d_ltoff;
   DevBuf<int> l_lt; int n_lt = 0;    // 64x64 tiles of that transposition (4 ints each: s, P, I, J)
   DevBuf<double> Tarena;             // scratch of the inversion, same layout as S: T = B inv(A) of every combine step
+  DevBuf<int> sweep_cnt;             // counters of the merged sweep launches (two sets of MC_N, a 128-byte line each: sdm_solve.hip, merged_count)
   DevBuf<unsigned long long> sb_g;   // per super-block: bit patterns of max|inverse| and max|L block| (growth check); behind them the counters of k_sprep
   DevBuf<int> l_i128, l_items;       // work lists of the inversion: 128-column leaves (4 ints each), combine tiles (8 ints each, sorted by stage)
   int n_i128 = 0, n_items = 0;

@@ -24,6 +24,7 @@ inline bool sdm_lane_pred(bool pred, int lane) { return emu_shfl(pred ? 1.0 : 0.
 // hence real atomics, volatile accesses and fences here (x86-64: aligned 8-byte accesses are single copies, stores stay in order)
 inline void sdm_signal_add(int *p, int n = 1) { __atomic_fetch_add(p, n, __ATOMIC_SEQ_CST); }
 inline int sdm_ticket_take(int *p) { return __atomic_fetch_add(p, 1, __ATOMIC_SEQ_CST); }
+inline void sdm_signal_reset(int *p) { __atomic_store_n(p, 0, __ATOMIC_SEQ_CST); }
 inline void sdm_store_wt(double *p, double v) { *(volatile double *)p = v; }
 inline double sdm_load_wt(const double *p) { return *(const volatile double *)p; }
 inline void sdm_store_wt2(double *p, double a, double b) { ((volatile double *)p)[0] = a; ((volatile double *)p)[1] = b; }
@@ -62,6 +63,8 @@ typedef double2 sdm_double2;
 __device__ __forceinline__ void sdm_signal_add(int *p, int n = 1) { __hip_atomic_fetch_add(p, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // a ticket: the value before the increment (device scope)
 __device__ __forceinline__ int sdm_ticket_take(int *p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a counter back to 0 for a LATER launch (device scope: the increments act at the coherence point, the zero must be there too)
+__device__ __forceinline__ void sdm_signal_reset(int *p) { __hip_atomic_store(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sdm_store_wt(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // 16 bytes write-through in one instruction (p 16-byte aligned): a row of published data as full-width fabric writes instead of
 // one 8-byte write per lane and word (MI355X_MICROARCH.md: scalar sc1 stores cost 2.7x the dwordx4 time per byte)

@@ -34,6 +34,7 @@
 namespace sdm {
 
 constexpr int SPREP_MAX_ITEMS = 256;                                  // k_sprep: one workgroup per item, all resident (one per CU)
+constexpr int MC_N = 32, MC_STRIDE = 32, MC_SET = MC_N * MC_STRIDE;   // counters of the merged sweep launches (merged_count below)
 constexpr int GRPW = 1024;       // columns (forward) / rows (backward) of a slab product in flight at a time: 32 16-byte loads per work-item
 
 // ---------------------------------------------------------------- host tables
@@ -143,6 +144,8 @@ void solve_build(sdm_plan *P) {
   const size_t gw = (size_t)std::max(sb, 1) * (2 + SPREP_NCNT / 2);
   C.sb_g.alloc(gw);
   SDM_HIP_CHECK(hipMemset(C.sb_g.p, 0, gw * sizeof(unsigned long long)));
+  C.sweep_cnt.alloc(2 * MC_SET);                                    // (the merged sweep launches' counters: merged_count)
+  SDM_HIP_CHECK(hipMemset(C.sweep_cnt.p, 0, 2 * MC_SET * sizeof(int)));
   // levels
   C.slev.assign(C.nlevels, SolveLevel());
   for (int l = 0; l < C.nlevels; l++) {
@@ -389,8 +392,13 @@ k_sinv_follow(const double *F, const double *DT, double *S, double *STr, FrontTa
 // Fs = front, (k0, k0) = position of the block.  Sd = 64*TP doubles of LDS.
 constexpr int BSC = 32;          // columns per step of the substitution fallback (its LDS tile: BSC x (BSC + 1) doubles)
 constexpr int BSP = BSC + 1;
+// (the merged launches: W = 2048 and the tile of 32 are 24.8 KB -- six workgroups per CU; with a tile of 16, 18.6 KB, all eight the streaming role lives on)
+constexpr int BSC_LEAN = 16;
+#define SDM_MERGED_SMEM(W) ((size_t)((W) + BSC_LEAN * (BSC_LEAN + 1)) * sizeof(double))
 #define SDM_DIAG_SMEM(W) ((size_t)((W) + BSC * BSP) * sizeof(double))   // (measured: the allocation costs the launch nothing, profiles/r08*)
-__device__ __noinline__ void block_solve_fw(const double *Fs, int ld, int k0, int nb, double *w, double *Sd) {
+template <int BSC>
+__device__ __forceinline__ void block_solve_fw_inl(const double *Fs, int ld, int k0, int nb, double *w, double *Sd) {
+  constexpr int BSP = BSC + 1;
   const int tid = threadIdx.x, lane = tid & 63;
   for (int kk = 0; kk < nb; kk += BSC) {
     const int kb = min(BSC, nb - kk);
@@ -413,7 +421,12 @@ __device__ __noinline__ void block_solve_fw(const double *Fs, int ld, int k0, in
     __syncthreads();
   }
 }
-__device__ __noinline__ void block_solve_bw(const double *Fs, int ld, int k0, int nb, double *w, double *Sd) {
+// (the merged sweep launches inline the substitutions -- no call: a kernel is allotted the registers of the fattest function it may call --,
+// the diagonal-block launches call them)
+__device__ __noinline__ void block_solve_fw(const double *Fs, int ld, int k0, int nb, double *w, double *Sd) { block_solve_fw_inl<BSC>(Fs, ld, k0, nb, w, Sd); }
+template <int BSC>
+__device__ __forceinline__ void block_solve_bw_inl(const double *Fs, int ld, int k0, int nb, double *w, double *Sd) {
+  constexpr int BSP = BSC + 1;
   const int tid = threadIdx.x, lane = tid & 63;
   for (int kk = ((nb - 1) / BSC) * BSC; kk >= 0; kk -= BSC) {
     const int kb = min(BSC, nb - kk);
@@ -436,6 +449,7 @@ __device__ __noinline__ void block_solve_bw(const double *Fs, int ld, int k0, in
     __syncthreads();
   }
 }
+__device__ __noinline__ void block_solve_bw(const double *Fs, int ld, int k0, int nb, double *w, double *Sd) { block_solve_bw_inl<BSC>(Fs, ld, k0, nb, w, Sd); }
 
 // ================================================================ slab products
 // Every kernel below issues its matrix loads FIRST (registers), then fetches the vector it multiplies with (written by the
@@ -621,8 +635,10 @@ __device__ __forceinline__ double row_seg(const double *__restrict__ M, const do
     for (int k = 0; k < NL; k++) {
       const int pi = p0 + lane + 64 * k;
       const bool in0 = pi < phi && 2 * pi >= jlo, in1 = pi < phi && 2 * pi + 1 < n && 2 * pi + 1 >= jlo;
-      a0 += (in0 ? v[k].x : 0.0) * (in0 ? x0[k] : 0.0);
-      a1 += (in1 ? v[k].y : 0.0) * (in1 ? x1[k] : 0.0);
+      // (fma spelled out: left to the compiler's contraction, two inlined copies of this loop -- the diagonal-block launch and the merged launch's
+      // diagonal role -- came out one fused, one not, and their results an ulp apart: profiles/r08s_probe.txt)
+      a0 = fma(in0 ? v[k].x : 0.0, in0 ? x0[k] : 0.0, a0);
+      a1 = fma(in1 ? v[k].y : 0.0, in1 ? x1[k] : 0.0, a1);
     }
   }
   double a = a0 + a1;
@@ -693,25 +709,26 @@ k_sfw_init(FrontTab tab, const int *list, double *wv, const double *src, const i
 // (wrapPcg.m:57; skipped pivots act as 1, deninfac.m:89-94) is written as well: y_P is final here.  One wavefront per row of
 // the TRANSPOSED inverse (row r of the inverse: r + 1 contiguous entries).  A block that failed the growth check is
 // substituted against the factor by workgroup 0.
-__global__ void __launch_bounds__(ST)
-k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTab tab, const int *list, const double *wv, const double *src,
-           const int *perm, double *y, const unsigned long long *sb_g, double thr, int Pb, int gather0, FwBatch bt,
-           double *zdiv, const double *dscale, int W, int mode, double thr2, const double *resid, int *noted, int seq, int mark) {
+__device__ __forceinline__ void sfw_diag_body(char *smem, double *part, int bx, const double *__restrict__ F, const double *__restrict__ STr, const FrontTab &tab, const int *list,
+           const double *wv, const double *src, const int *perm, double *y, const unsigned long long *sb_g, double thr, int Pb, int gather0, FwBatch bt,
+           double *zdiv, const double *dscale, int W, int mode, double thr2, const double *resid, int *noted, int seq, int mark, int *rearm) {
   const bool WIDE = W > 256;                                           // (uniform for the launch: the grid is sized accordingly)
   const bool gather = gather0 && Pb == 0 && mode != 2;
   // mode 0: the sweep as planned for well-conditioned factors (blocks beyond the bound are substituted by workgroup 0);
   // mode 1: the first of the refinement launches: blocks of kind 1 are applied as their inverse like the good ones;
   // mode 2: blocks of kind 1 only:  y_P += inv(L_PP) r_P  with the residual r_P = t_P - L_PP y_P of k_sfw_resid (`resid`)
-  SDM_DYN_SMEM(smem);                                                // (the rare substitution fallback only: W + BSC * BSP doubles -- as static
+  // (smem: the rare substitution fallback only: W + BSC * BSP doubles of dynamic LDS -- as static
   double *xs = (double *)smem, *Sd = xs + W;                          // arrays sized for the widest block they cost every launch 49 KB per workgroup)
   // (the first diagonal-block launch of a sweep tells the host that the sweep before it has run: CholPlan::noted)
-  if (mark >= 0 && noted && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) sdm_host_note(noted + 1, mark);
+  if (mark >= 0 && noted && bx == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) sdm_host_note(noted + 1, mark);
+  // (the level's first diagonal-block launch clears both counter sets of the merged launches that follow it: merged_count)
+  if (rearm && bx == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 2 * MC_N) sdm_signal_reset(rearm + (int)threadIdx.x * MC_STRIDE);
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), first = FT(first);
   const int c0 = Pb * W;
   if (c0 >= ns) return;
   const int nb = min(W, ns - c0);
-  if (!WIDE ? 16 * (int)blockIdx.x >= nb : (int)blockIdx.x >= tri_grid(nb)) return;
+  if (!WIDE ? 16 * bx >= nb : bx >= tri_grid(nb)) return;
   wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; if (src) src += (int64_t)blockIdx.z * bt.src;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int sld = FT(sld);
@@ -727,16 +744,15 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTa
   // round trip of its own); a block beyond the bound throws the sum away below
   double sum = 0.0;
   int r = -1, l16 = lane & 15;
-  __shared__ double part[ST / 64];
   if (!WIDE) {                                                         // 16 rows per workgroup (the grid is sized accordingly)
-    r = 16 * blockIdx.x + 4 * wave + (lane >> 4);
+    r = 16 * bx + 4 * wave + (lane >> 4);
     const int rc = min(r, nb - 1);
     const double *M = STr + FT(soff) + (int64_t)c0 * sld + (int64_t)rc * sld;
     sum = gather ? row_dot<true, 16>(M, src, pp, rc + 1, 0, l16) : row_dot<false, 16>(M, a, nullptr, rc + 1, 0, l16);
     if (l16 != 0 || r >= nb) r = -1;
   } else {
     int seg, nseg;
-    tri_task(nb, blockIdx.x, wave, r, seg, nseg);
+    tri_task(nb, bx, wave, r, seg, nseg);
     if (r >= 0) {
       const double *M = STr + FT(soff) + (int64_t)c0 * sld + (int64_t)r * sld;
       const int npair = (r + 2) >> 1, plo = seg * (SEGN / 2), phi = nseg == 1 ? npair : min(npair, plo + SEGN / 2);
@@ -747,9 +763,9 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTa
   }
   if (cls < 0) cls = sb_class(sb_g, FT(sboff) + Pb, thr, thr2);
   // (a block of kind 1 met by a sweep: the host plans the refinement launches while such blocks keep turning up -- solve_refines)
-  if (cls == 1 && mode != 2 && blockIdx.x == 0 && tid == 0 && noted) sdm_host_note(noted, seq);
+  if (cls == 1 && mode != 2 && bx == 0 && tid == 0 && noted) sdm_host_note(noted, seq);
   if (cls == 2 || (cls == 1 && mode == 0)) {
-    if (blockIdx.x != 0) return;
+    if (bx != 0) return;
     for (int c = tid; c < nb; c += ST) xs[c] = gather ? src[pp[c]] : a[c];
     __syncthreads();
     block_solve_fw(F + FT(foff), FT(ld), c0, nb, xs, Sd);
@@ -765,6 +781,14 @@ k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTa
     y[first + c0 + r] = yv;
     if (zdiv) { const double dk = dscale[first + c0 + r]; zdiv[first + c0 + r] = yv / (dk > 0.0 ? dk : 1.0); }
   }
+}
+__global__ void __launch_bounds__(ST)
+k_sfw_diag(const double *__restrict__ F, const double *__restrict__ STr, FrontTab tab, const int *list, const double *wv, const double *src,
+           const int *perm, double *y, const unsigned long long *sb_g, double thr, int Pb, int gather0, FwBatch bt,
+           double *zdiv, const double *dscale, int W, int mode, double thr2, const double *resid, int *noted, int seq, int mark, int *rearm) {
+  SDM_DYN_SMEM(smem);
+  __shared__ double part[ST / 64];
+  sfw_diag_body(smem, part, (int)blockIdx.x, F, STr, tab, list, wv, src, perm, y, sb_g, thr, Pb, gather0, bt, zdiv, dscale, W, mode, thr2, resid, noted, seq, mark, rearm);
 }
 
 // r_P = t_P - L_PP y_P for the super-blocks of kind 1 (iterative refinement of y_P = inv(L_PP) t_P against the factor itself: the
@@ -815,18 +839,18 @@ k_sfw_resid(const double *__restrict__ F, FrontTab tab, const int *list, const d
 #ifndef SDM_ROWS_NL
 #define SDM_ROWS_NL 4            // loads of 16 bytes per lane and trip in the full-row launches (ubench11: two wavefronts per 2048-entry row, 4 loads x 2 trips)
 #endif
-__global__ void __launch_bounds__(ST)
-k_sfw_rows(const double *__restrict__ LT, FrontTab tab, const int *list, double *wv, const double *src, const int *perm, const double *y,
-           int Pb, int assign0, FwBatch bt, int W) {
+// bx = the workgroup's index among the row workgroups; urgent_wt: rows of the NEXT super-block are stored write-through (the merged launch: its
+// diagonal role reads them in the same launch)
+__device__ __forceinline__ void sfw_rows_body(double *part, int bx, const double *__restrict__ LT, const FrontTab &tab, const int *list, double *wv, const double *src,
+                                              const int *perm, const double *y, int Pb, int assign0, FwBatch bt, int W, bool urgent_wt) {
   // W > SEGN: two wavefronts per row (two rows per workgroup), else one (four rows per workgroup): uniform for the launch, the grid is sized accordingly
-  __shared__ double part[ST / 64];
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), first = FT(first);
   const int R0 = (Pb + 1) * W;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nseg = W > SEGN ? 2 : 1, seg = nseg == 2 ? (wave & 1) : 0;
-  const int rl = nseg == 2 ? 2 * blockIdx.x + (wave >> 1) : 4 * blockIdx.x + wave;
-  if ((nseg == 2 ? 2 : 4) * (int)blockIdx.x + R0 >= ns) return;       // (the whole workgroup)
+  const int rl = nseg == 2 ? 2 * bx + (wave >> 1) : 4 * bx + wave;
+  if ((nseg == 2 ? 2 : 4) * bx + R0 >= ns) return;                    // (the whole workgroup)
   wv += (int64_t)blockIdx.z * bt.wv; y += (int64_t)blockIdx.z * bt.y; if (src) src += (int64_t)blockIdx.z * bt.src;
   const bool live = R0 + rl < ns;
   double sum = 0.0;
@@ -839,8 +863,130 @@ k_sfw_rows(const double *__restrict__ LT, FrontTab tab, const int *list, double 
   if (lane == 0 && seg == 0 && live) {
     double *a = wv + FT(woff);
     const int r = R0 + rl;
-    a[r] = (assign0 ? src[perm[first + r]] : a[r]) - sum;
+    const double v = (assign0 ? src[perm[first + r]] : a[r]) - sum;
+    if (urgent_wt && rl < W) sdm_store_wt(&a[r], v); else a[r] = v;
   }
+}
+__global__ void __launch_bounds__(ST)
+k_sfw_rows(const double *__restrict__ LT, FrontTab tab, const int *list, double *wv, const double *src, const int *perm, const double *y,
+           int Pb, int assign0, FwBatch bt, int W) {
+  __shared__ double part[ST / 64];
+  sfw_rows_body(part, (int)blockIdx.x, LT, tab, list, wv, src, perm, y, Pb, assign0, bt, W, false);
+}
+
+// ---- Round 6: a row launch and the NEXT diagonal-block launch as ONE (profiles/r08r_solve_trace_m16000.txt: the 16 diagonal-block launches of a
+// solve at m = 16000 are 26 % of its time for 13 % of its bytes -- 7.9 us each for 16.8 MB, a burst of loads behind a launch boundary).  Row r of
+// y_{P+1} = inv(L_{P+1,P+1}) t_{P+1} needs t_{P+1}[0 .. r]: the rows of the NEXT super-block (the URGENT rows of this launch) up to r, nothing of
+// the later rows of the front.  Grid order = dependency order: the urgent row workgroups in row order, up to PRE_WGS of the others, the diagonal
+// role's workgroups in row order (tri_task), the rest.  The urgent workgroups store their entries of t past the caches and count per CHUNK of 64
+// rows; a diagonal workgroup waits for the chunks its rows reach -- all handed out before it, none of which waits for anything --, copies that
+// much of t to LDS with L1-bypassing loads (once per workgroup: read that way per row, 2 M loads on the same 16 KB, the role took twice the
+// separate launch's time; an acquire fence and plain loads returned stale entries -- profiles/r08s_*) and runs its rows against the copy.  Its
+// loads ride in the stream of the launch, its first rows a few microseconds behind the first urgent ones.  One right-hand side, one front in the
+// level, W > 256, no refinement launches (solve_fw_batch).
+// The counters: 1024 increments of ONE address cost a launch 19 us (same-address atomics resolve one after the other at the device's coherence
+// point): one counter per chunk, each on a 128-byte line of its own (32 or 16 increments each).  Two sets: the launches of a level use them in
+// turn (set = super-block & 1), a launch clears the set the NEXT one counts on, and the level's first diagonal-block launch -- never merged --
+// clears both: no re-arming count that every diagonal workgroup would have to pass through, nothing carried from sweep to sweep (a replayed
+// graph finds what it was captured with).
+constexpr int PRE_WGS = 1024;
+#ifdef SDM_EMU
+#define SDM_EIGHT_WAVES
+#else
+#define SDM_EIGHT_WAVES __attribute__((amdgpu_waves_per_eu(8, 8)))      // <= 64 vector registers: eight workgroups of 256 per CU
+#endif
+// role of workgroup b of a merged launch: nurg urgent + nother other workgroups of the streaming role, ndiag of the diagonal role.  Returns true
+// for the diagonal role; bx = the index inside the role
+__device__ __forceinline__ bool merged_role(int b, int nurg, int nother, int ndiag, int &bx) {
+  const int pre = nurg + min(nother, PRE_WGS);
+  if (b < pre) { bx = b; return false; }
+  if (b < pre + ndiag) { bx = b - pre; return true; }
+  bx = b - ndiag;
+  return false;
+}
+// urgent workgroups per chunk of 64 rows (two rows per workgroup when W > SEGN, else four: sfw_rows_body)
+__device__ __forceinline__ int merged_per(int W) { return W > SEGN ? 32 : 16; }
+__device__ __forceinline__ void merged_count(int *cnt, int set, int bx, int W) { sdm_signal_add(cnt + set * MC_SET + (bx / merged_per(W)) * MC_STRIDE); }
+__device__ __forceinline__ void merged_clear(int *cnt, int set) { if (threadIdx.x < MC_N) sdm_signal_reset(cnt + set * MC_SET + (int)threadIdx.x * MC_STRIDE); }
+// until the first nch chunks of the urgent rows are out (work-item k polls chunk k's counter), then a barrier
+__device__ __forceinline__ void merged_wait(const int *cnt, int set, int nch, int nurg, int W, int *tmo) {
+  const int k = threadIdx.x, per = merged_per(W);
+  if (k < 64) {
+    // (the chunks come out roughly in order: ONE work-item polls the last one needed, then the others look at theirs -- with every one of them
+    // polling from the start, 12 000 pollers on 31 lines, an all-urgent launch took 22 us for 14 of separate launches)
+    for (int ph = 0; ph < 2; ph++)
+      if ((ph == 0 ? k == nch - 1 : k < nch - 1) && k * per < nurg) {
+        const int target = min(per, nurg - k * per);
+        const int *c = cnt + set * MC_SET + k * MC_STRIDE;
+        for (long it = 0; sdm_signal_load(c) < target; it++) { if (sdm_spin_giveup(it, tmo)) break; SDM_SPIN_PAUSE(); SDM_SPIN_PAUSE(); }
+      }
+  }
+  __syncthreads();
+}
+// the largest row rank among the tasks of workgroup b (tri_task)
+__device__ __forceinline__ int tri_tmax(int nb, int b) {
+  const int n1 = min(nb, SEGN), wg1 = (n1 + 3) >> 2;
+  return min(nb - 1, b < wg1 ? 4 * b + 3 : n1 + 2 * (b - wg1) + 1);
+}
+// the diagonal role of the merged launch: sfw_diag_body for W > 256, mode 0, no gather -- written out on its own, lean: the kernel must fit 64
+// vector registers, or its streaming role loses the eight workgroups per CU it lives on (sfw_diag_body with its W <= 256 and gather paths takes
+// 111; a second inlined copy of it also crashes the device compiler of ROCm 7.2, clang-22's CGSCC inliner)
+__device__ __forceinline__ void sfw_diag_lean(char *smem, double *part, int bx, const double *__restrict__ F, const double *__restrict__ STr, const FrontTab &tab,
+                                              const double *wv, double *y, const unsigned long long *sb_g, double thr, int Pb, double *zdiv, const double *dscale, int W,
+                                              double thr2, int *noted, int seq, const int *cnt, int set, int nurg, int *tmo) {
+  const int ns = tab.o_ns, first = tab.o_first, c0 = Pb * W, nb = min(W, ns - c0);   // (one-front levels only)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const double *a = wv + tab.o_woff + c0;
+  double *xs = (double *)smem, *Sd = xs + W;
+  // (the block's class first: its round trip passes while the counters are polled)
+  const int cls = sb_class(sb_g, tab.o_sboff + Pb, thr, thr2);
+  if (cls == 1 && bx == 0 && tid == 0 && noted) sdm_host_note(noted, seq);
+  if (cls != 0 && bx != 0) return;                                    // beyond the bound: substituted against the factor by workgroup 0 (as sfw_diag_body, mode 0)
+  const int need = cls != 0 ? nb : tri_tmax(nb, bx) + 1;
+  merged_wait(cnt, set, (need + 63) >> 6, nurg, W, tmo);
+  for (int c = tid; c < need; c += ST) xs[c] = sdm_load_wt(&a[c]);
+  __syncthreads();
+  if (cls != 0) {
+    block_solve_fw_inl<BSC_LEAN>(F + tab.o_foff, tab.o_ld, c0, nb, xs, Sd);
+    for (int i = tid; i < nb; i += ST) {
+      const double yv = xs[i];
+      y[first + c0 + i] = yv;
+      if (zdiv) { const double dk = dscale[first + c0 + i]; zdiv[first + c0 + i] = yv / (dk > 0.0 ? dk : 1.0); }
+    }
+    return;
+  }
+  int r, seg, nseg;
+  tri_task(nb, bx, wave, r, seg, nseg);
+  double sum = 0.0;
+  if (r >= 0) {
+    const double *M = STr + tab.o_soff + (int64_t)c0 * tab.o_sld + (int64_t)r * tab.o_sld;
+    const int npair = (r + 2) >> 1, plo = seg * (SEGN / 2), phi = nseg == 1 ? npair : min(npair, plo + SEGN / 2);
+    sum = row_seg<false, SDM_ROWS_NL>(M, xs, nullptr, r + 1, 0, plo, phi, lane);
+  }
+  sum = seg_combine(part, sum, wave, lane, nseg);
+  if (lane == 0 && seg == 0 && r >= 0) {
+    y[first + c0 + r] = sum;
+    if (zdiv) { const double dk = dscale[first + c0 + r]; zdiv[first + c0 + r] = sum / (dk > 0.0 ? dk : 1.0); }
+  }
+}
+__global__ void __launch_bounds__(ST) SDM_EIGHT_WAVES
+k_sfw_rows_diag(const double *__restrict__ LT, const double *__restrict__ F, const double *__restrict__ STr, FrontTab tab, const int *list, double *wv, const double *src,
+                const int *perm, double *y, const unsigned long long *sb_g, double thr, int Pb, int assign0, FwBatch bt, double *zdiv, const double *dscale, int W,
+                double thr2, int *noted, int seq, int *cnt, int nurg, int nother, int ndiag, int *tmo) {
+  SDM_DYN_SMEM(smem);
+  __shared__ double part[ST / 64];
+  int bx;
+  if (!merged_role((int)blockIdx.x, nurg, nother, ndiag, bx)) {
+    sfw_rows_body(part, bx, LT, tab, list, wv, src, perm, y, Pb, assign0, bt, W, true);
+    if (bx < nurg) {                                                   // an urgent workgroup: its rows of t_{P+1} are out (write-through), count it
+      SDM_STORES_DONE();
+      __syncthreads();
+      if (threadIdx.x == 0) merged_count(cnt, Pb & 1, bx, W);
+      if (bx == 0) merged_clear(cnt, (Pb + 1) & 1);
+    }
+    return;
+  }
+  sfw_diag_lean(smem, part, bx, F, STr, tab, wv, y, sb_g, thr, Pb + 1, zdiv, dscale, W, thr2, noted, seq, cnt, Pb & 1, nurg, tmo);
 }
 
 // step Pb, the rows BELOW the supernode (they belong to its ancestors; their sums are the update vector passed to the parent):
@@ -916,19 +1062,19 @@ k_sbw_init(const double *__restrict__ F, FrontTab tab, const int *list, double *
 // and the step launch read it) and, scattered through perm, to yout.  One wavefront per COLUMN of the inverse (column c: the
 // nb - c contiguous entries from the diagonal down).  A block that failed the growth check is substituted against the factor
 // by workgroup 0.
-__global__ void __launch_bounds__(ST)
-k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, const double *y, double *xfin, double *yout,
-           const int *perm, const unsigned long long *sb_g, double thr, int Q, int W, int mode, double thr2, const double *wv, int *noted, int seq, int mark) {
+__device__ __forceinline__ void sbw_diag_body(char *smem, double *part, int bx, const double *__restrict__ F, const double *__restrict__ S, const FrontTab &tab, const int *list,
+           const double *y, double *xfin, double *yout, const int *perm, const unsigned long long *sb_g, double thr, int Q, int W, int mode, double thr2, const double *wv,
+           int *noted, int seq, int mark, int *rearm) {
   // mode 0 / 1 / 2 as in k_sfw_diag; mode 2:  x_Q += inv(L_QQ)' r_Q  with the residual of k_sbw_resid (in the front's slice of wv)
-  SDM_DYN_SMEM(smem);
   double *xs = (double *)smem, *Sd = xs + W;
-  if (mark >= 0 && noted && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sdm_host_note(noted + 1, mark);
+  if (mark >= 0 && noted && bx == 0 && blockIdx.y == 0 && threadIdx.x == 0) sdm_host_note(noted + 1, mark);
+  if (rearm && bx == 0 && blockIdx.y == 0 && threadIdx.x < 2 * MC_N) sdm_signal_reset(rearm + (int)threadIdx.x * MC_STRIDE);
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), first = FT(first);
   const int rb = Q * W;
   if (rb >= ns) return;
   const int nb = min(W, ns - rb);
-  if (W <= 256 ? 16 * (int)blockIdx.x >= nb : (int)blockIdx.x >= tri_grid(nb)) return;
+  if (W <= 256 ? 16 * bx >= nb : bx >= tri_grid(nb)) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int cls = -1;
   if (mode == 2) {
@@ -940,16 +1086,15 @@ k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
   // (the planned path's product before the block's class is looked at: see k_sfw_diag)
   double sum = 0.0;
   int c = -1;
-  __shared__ double part[ST / 64];
   if (W <= 256) {                                                     // 16 columns per workgroup (see k_sfw_diag)
-    c = 16 * blockIdx.x + 4 * wave + (lane >> 4);
+    c = 16 * bx + 4 * wave + (lane >> 4);
     const int l16 = lane & 15, cc = min(c, nb - 1), ce = cc & ~1;
     const double *M = S + FT(soff) + (int64_t)rb * sld + (int64_t)cc * sld + ce;
     sum = row_dot<false, 16>(M, vp + ce, nullptr, nb - ce, cc - ce, l16);
     if (l16 != 0 || c >= nb) c = -1;
   } else {
     int t, seg, nseg;
-    tri_task(nb, blockIdx.x, wave, t, seg, nseg);                     // column nb - 1 - t has t + 1 entries from the diagonal down
+    tri_task(nb, bx, wave, t, seg, nseg);                     // column nb - 1 - t has t + 1 entries from the diagonal down
     if (t >= 0) {
       c = nb - 1 - t;
       const int ce = c & ~1;                                          // 16-byte aligned start (the entry above the diagonal is skipped: jlo)
@@ -961,9 +1106,9 @@ k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
     if (lane != 0 || seg != 0) c = -1;
   }
   if (cls < 0) cls = sb_class(sb_g, FT(sboff) + Q, thr, thr2);
-  if (cls == 1 && mode != 2 && blockIdx.x == 0 && tid == 0 && noted) sdm_host_note(noted, seq);
+  if (cls == 1 && mode != 2 && bx == 0 && tid == 0 && noted) sdm_host_note(noted, seq);
   if (cls == 2 || (cls == 1 && mode == 0)) {
-    if (blockIdx.x != 0) return;
+    if (bx != 0) return;
     for (int i = tid; i < nb; i += ST) xs[i] = vp[i];
     __syncthreads();
     block_solve_bw(F + FT(foff), FT(ld), rb, nb, xs, Sd);
@@ -971,6 +1116,48 @@ k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab 
     return;
   }
   if (c >= 0) { const double xv = mode == 2 ? xfin[first + rb + c] + sum : sum; xfin[first + rb + c] = xv; if (yout) yout[perm[first + rb + c]] = xv; }
+}
+__global__ void __launch_bounds__(ST)
+k_sbw_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, const double *y, double *xfin, double *yout,
+           const int *perm, const unsigned long long *sb_g, double thr, int Q, int W, int mode, double thr2, const double *wv, int *noted, int seq, int mark, int *rearm) {
+  SDM_DYN_SMEM(smem);
+  __shared__ double part[ST / 64];
+  sbw_diag_body(smem, part, (int)blockIdx.x, F, S, tab, list, y, xfin, yout, perm, sb_g, thr, Q, W, mode, thr2, wv, noted, seq, mark, rearm);
+}
+// the diagonal role of the merged launch k_sbw_step_diag (as sfw_diag_lean).  Super-block Q is a full one (only a front's last block is not);
+// the urgent workgroups take its columns from the last one down (sbw_step_body, rev): chunk k = columns W - 64 k - 64 .. W - 64 k - 1, and the
+// column of rank t (tri_task) needs the entries from its own -- W - 1 - t, an even start -- to the block's end: chunks 0 .. (t + 1) / 64
+__device__ __forceinline__ void sbw_diag_lean(char *smem, double *part, int bx, const double *__restrict__ F, const double *__restrict__ S, const FrontTab &tab,
+                                              const double *y, double *xfin, double *yout, const int *perm, const unsigned long long *sb_g, double thr, int Q, int W,
+                                              double thr2, int *noted, int seq, const int *cnt, int set, int nurg, int *tmo) {
+  const int first = tab.o_first, rb = Q * W, nb = W;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const double *vp = y + first + rb;
+  double *xs = (double *)smem, *Sd = xs + W;
+  const int cls = sb_class(sb_g, tab.o_sboff + Q, thr, thr2);
+  if (cls == 1 && bx == 0 && tid == 0 && noted) sdm_host_note(noted, seq);
+  if (cls != 0 && bx != 0) return;
+  const int lo = cls != 0 ? 0 : (nb - 1 - tri_tmax(nb, bx)) & ~1;
+  merged_wait(cnt, set, (nb - lo + 63) >> 6, nurg, W, tmo);
+  for (int i = lo + tid; i < nb; i += ST) xs[i] = sdm_load_wt(&vp[i]);
+  __syncthreads();
+  if (cls != 0) {
+    block_solve_bw_inl<BSC_LEAN>(F + tab.o_foff, tab.o_ld, rb, nb, xs, Sd);
+    for (int i = tid; i < nb; i += ST) { xfin[first + rb + i] = xs[i]; if (yout) yout[perm[first + rb + i]] = xs[i]; }
+    return;
+  }
+  int t, seg, nseg, c = -1;
+  tri_task(nb, bx, wave, t, seg, nseg);                               // column nb - 1 - t has t + 1 entries from the diagonal down
+  double sum = 0.0;
+  if (t >= 0) {
+    c = nb - 1 - t;
+    const int ce = c & ~1;
+    const double *M = S + tab.o_soff + (int64_t)rb * tab.o_sld + (int64_t)c * tab.o_sld + ce;
+    const int n = nb - ce, npair = (n + 1) >> 1, plo = seg * (SEGN / 2), phi = nseg == 1 ? npair : min(npair, plo + SEGN / 2);
+    sum = row_seg<false, SDM_ROWS_NL>(M, xs + ce, nullptr, n, c - ce, plo, phi, lane);
+  }
+  sum = seg_combine(part, sum, wave, lane, nseg);
+  if (lane == 0 && seg == 0 && c >= 0) { xfin[first + rb + c] = sum; if (yout) yout[perm[first + rb + c]] = sum; }
 }
 
 // r_Q = v_Q - L_QQ' x_Q for the super-blocks of kind 1 (see k_sfw_resid): a column of L is contiguous, one wavefront per column;
@@ -995,10 +1182,10 @@ k_sbw_resid(const double *__restrict__ F, FrontTab tab, const int *list, const d
 
 // step Q: x_Q is final; every column left of super-block Q receives  - L(Q rows, c)' x_Q , read from the factor (a column
 // of L is contiguous there), one wavefront per column
-__global__ void __launch_bounds__(ST)
-k_sbw_step(const double *__restrict__ F, FrontTab tab, const int *list, double *y, const double *xfin, int Q, int W) {
+// rev (the merged launch): workgroup bx takes the columns from rb - 1 DOWN -- those of super-block Q - 1 first, stored write-through
+__device__ __forceinline__ void sbw_step_body(double *part, int bx, const double *__restrict__ F, const FrontTab &tab, const int *list, double *y, const double *xfin, int Q, int W,
+                                              bool rev) {
   // (W > SEGN: two wavefronts per column, as in k_sfw_rows)
-  __shared__ double part[ST / 64];
   const int s = tab.one ? tab.o_s : list[blockIdx.y];
   const int ns = FT(ns), first = FT(first), ld = FT(ld);
   const int rb = Q * W;
@@ -1006,11 +1193,39 @@ k_sbw_step(const double *__restrict__ F, FrontTab tab, const int *list, double *
   const int nbq = min(W, ns - rb);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nseg = W > SEGN ? 2 : 1, seg = nseg == 2 ? (wave & 1) : 0;
-  const int c = nseg == 2 ? 2 * blockIdx.x + (wave >> 1) : 4 * blockIdx.x + wave;                // < rb by the grid
+  const int ci = nseg == 2 ? 2 * bx + (wave >> 1) : 4 * bx + wave;                                // < rb by the grid
+  const int c = rev ? rb - 1 - ci : ci;
   const int npair = (nbq + 1) >> 1, per = nseg == 2 ? ((npair + 1) >> 1) : npair;
   double sum = row_seg<false, SDM_ROWS_NL>(F + FT(foff) + (int64_t)c * ld + rb, xfin + first + rb, nullptr, nbq, 0, seg * per, min(npair, (seg + 1) * per), lane);
   sum = seg_combine(part, sum, wave, lane, nseg);
-  if (lane == 0 && seg == 0) y[first + c] -= sum;
+  if (lane == 0 && seg == 0) {
+    const double v = y[first + c] - sum;
+    if (rev && ci < W) sdm_store_wt(&y[first + c], v); else y[first + c] = v;
+  }
+}
+__global__ void __launch_bounds__(ST)
+k_sbw_step(const double *__restrict__ F, FrontTab tab, const int *list, double *y, const double *xfin, int Q, int W) {
+  __shared__ double part[ST / 64];
+  sbw_step_body(part, (int)blockIdx.x, F, tab, list, y, xfin, Q, W, false);
+}
+// step Q and the diagonal block Q - 1 as ONE launch (k_sfw_rows_diag's counterpart: the columns of super-block Q - 1 are the urgent ones)
+__global__ void __launch_bounds__(ST) SDM_EIGHT_WAVES
+k_sbw_step_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, double *y, double *xfin, double *yout, const int *perm,
+                const unsigned long long *sb_g, double thr, int Q, int W, double thr2, int *noted, int seq, int *cnt, int nurg, int nother, int ndiag, int *tmo) {
+  SDM_DYN_SMEM(smem);
+  __shared__ double part[ST / 64];
+  int bx;
+  if (!merged_role((int)blockIdx.x, nurg, nother, ndiag, bx)) {
+    sbw_step_body(part, bx, F, tab, list, y, xfin, Q, W, true);
+    if (bx < nurg) {
+      SDM_STORES_DONE();
+      __syncthreads();
+      if (threadIdx.x == 0) merged_count(cnt, Q & 1, bx, W);
+      if (bx == 0) merged_clear(cnt, (Q + 1) & 1);
+    }
+    return;
+  }
+  sbw_diag_lean(smem, part, bx, F, S, tab, y, xfin, yout, perm, sb_g, thr, Q - 1, W, thr2, noted, seq, cnt, Q & 1, nurg, tmo);
 }
 #undef FT
 
@@ -1098,6 +1313,11 @@ void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growt
 // do the sweeps run the refinement launches for blocks beyond the growth bound?  (CholPlan::refine_mode; the note is read as it is
 // now, without waiting for the device)
 constexpr int REFINE_STEPS = 2;
+// merged sweep launches (k_sfw_rows_diag): 0 never, 1 where rows beyond the next super-block exist, 2 every row launch of a one-front level
+static int sweep_merge_level() {
+  const char *e = getenv("SEDUMI_HIP_SWEEP_MERGE");               // (read per sweep: the tests switch it)
+  return e ? atoi(e) : 1;
+}
 static bool solve_refines(CholPlan &C) {
   if (C.refine_mode != 1) return C.refine_mode == 2;
   if (C.noted.host) {
@@ -1133,20 +1353,30 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
     const int gather = L.children ? 0 : 1;
     if (!gather && (what & 1)) SDM_KLAUNCH(P, k_sfw_init, dim3(L.nfronts, 1, nrhs), dim3(ST), 0, tab, list, wv, rhs, C.d_perm.p, y, bt);
     if (!(what & 2)) continue;
+    bool diag_done = false;                                          // (this super-block's diagonal role ran inside the row launch before it)
+    const int merge = sweep_merge_level();
+    const bool may_merge = merge && W > 256 && nrhs == 1 && !refine && tab.one && L.nsb >= 2;
     for (int Pb = 0; Pb < L.nsb; Pb++) {
       const int nbmax = std::min(W, L.maxns - Pb * W);
       const dim3 gdiag(W <= 256 ? (nbmax + 15) / 16 : tri_grid(nbmax), L.nfronts, nrhs);
-      SDM_KLAUNCH(P, k_sfw_diag, gdiag, dim3(ST), SDM_DIAG_SMEM(W), C.fronts.p, C.ST.p, tab, list, wv, rhs,
-                  C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W, refine ? 1 : 0, C.refine_max, (const double *)nullptr, noted, seq, marked ? -1 : seq - 1);
+      if (!diag_done) SDM_KLAUNCH(P, k_sfw_diag, gdiag, dim3(ST), SDM_DIAG_SMEM(W), C.fronts.p, C.ST.p, tab, list, wv, rhs,
+                  C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W, refine ? 1 : 0, C.refine_max, (const double *)nullptr, noted, seq, marked ? -1 : seq - 1, Pb == 0 && may_merge ? C.sweep_cnt.p : (int *)nullptr);
       marked = true;
       for (int it = 0; refine && it < REFINE_STEPS; it++) {            // (blocks within the bound leave these launches at once)
         SDM_KLAUNCH(P, k_sfw_resid, dim3((nbmax + 63) / 64, L.nfronts), dim3(RT), 0, C.fronts.p, tab, list, wv, rhs, C.d_perm.p, y, C.xfin.p, C.sb_g.p, thr,
                     C.refine_max, Pb, gather, W);
         SDM_KLAUNCH(P, k_sfw_diag, gdiag, dim3(ST), SDM_DIAG_SMEM(W), C.fronts.p, C.ST.p, tab, list, wv, rhs,
-                    C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W, 2, C.refine_max, (const double *)C.xfin.p, (int *)nullptr, seq, -1);
+                    C.d_perm.p, y, C.sb_g.p, thr, Pb, gather, bt, zdiv, dscale, W, 2, C.refine_max, (const double *)C.xfin.p, (int *)nullptr, seq, -1, (int *)nullptr);
       }
       const int assign0 = (gather && Pb == 0) ? 1 : 0;
-      if (L.maxns > (Pb + 1) * W)                                    // the fronts' own rows of later super-blocks
+      diag_done = false;
+      if (may_merge && L.maxns > (Pb + (merge >= 2 ? 1 : 2)) * W) {
+        const int nrw = W > SEGN ? (L.maxns - (Pb + 1) * W + 1) / 2 : (L.maxns - (Pb + 1) * W + 3) / 4;
+        const int nurg = std::min(nrw, W > SEGN ? W / 2 : W / 4), ndiag = tri_grid(std::min(W, L.maxns - (Pb + 1) * W));
+        SDM_KLAUNCH(P, k_sfw_rows_diag, dim3(nrw + ndiag), dim3(ST), SDM_MERGED_SMEM(W), C.LT.p, C.fronts.p, C.ST.p, tab, list, wv, rhs, C.d_perm.p, y, C.sb_g.p, thr, Pb,
+                    assign0, bt, zdiv, dscale, W, C.refine_max, noted, seq, C.sweep_cnt.p, nurg, nrw - nurg, ndiag, C.tmo.dev());
+        diag_done = true;
+      } else if (L.maxns > (Pb + 1) * W)                             // the fronts' own rows of later super-blocks
         SDM_KLAUNCH(P, k_sfw_rows, dim3(W > SEGN ? (L.maxns - (Pb + 1) * W + 1) / 2 : (L.maxns - (Pb + 1) * W + 3) / 4, L.nfronts, nrhs), dim3(ST), 0, C.LT.p, tab, list, wv, rhs, C.d_perm.p, y, Pb,
                     assign0, bt, W);
       if (L.slabs_fw[Pb] > 0)                                        // the rows below the supernodes
@@ -1175,18 +1405,29 @@ static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double 
     const FrontTab tab = level_tab(C, tab0, l);
     if (!(skip_plain_init && !L.below))
       SDM_KLAUNCH(P, k_sbw_init, dim3((L.maxns + SROWS - 1) / SROWS, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, dscale);
+    bool diag_done = false;
+    const int merge = sweep_merge_level();
+    const bool may_merge = merge && W > 256 && !refine && tab.one && L.nsb >= 2;
     for (int Q = L.nsb - 1; Q >= 0; Q--) {
       const int nbmax = std::min(W, L.maxns - Q * W);
       const dim3 gdiag(W <= 256 ? (nbmax + 15) / 16 : tri_grid(nbmax), L.nfronts);
-      SDM_KLAUNCH(P, k_sbw_diag, gdiag, dim3(ST), SDM_DIAG_SMEM(W), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
-                  C.d_perm.p, C.sb_g.p, thr, Q, W, refine ? 1 : 0, C.refine_max, (const double *)nullptr, noted, seq, marked ? -1 : seq - 1);
+      if (!diag_done) SDM_KLAUNCH(P, k_sbw_diag, gdiag, dim3(ST), SDM_DIAG_SMEM(W), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
+                  C.d_perm.p, C.sb_g.p, thr, Q, W, refine ? 1 : 0, C.refine_max, (const double *)nullptr, noted, seq, marked ? -1 : seq - 1,
+                  Q == L.nsb - 1 && may_merge ? C.sweep_cnt.p : (int *)nullptr);
       marked = true;
       for (int it = 0; refine && it < REFINE_STEPS; it++) {
         SDM_KLAUNCH(P, k_sbw_resid, dim3((nbmax + 3) / 4, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, C.wvec.p, C.sb_g.p, thr, C.refine_max, Q, W);
         SDM_KLAUNCH(P, k_sbw_diag, gdiag, dim3(ST), SDM_DIAG_SMEM(W), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout,
-                    C.d_perm.p, C.sb_g.p, thr, Q, W, 2, C.refine_max, (const double *)C.wvec.p, (int *)nullptr, seq, -1);
+                    C.d_perm.p, C.sb_g.p, thr, Q, W, 2, C.refine_max, (const double *)C.wvec.p, (int *)nullptr, seq, -1, (int *)nullptr);
       }
-      if (Q > 0) SDM_KLAUNCH(P, k_sbw_step, dim3(W > SEGN ? Q * (W / 2) : Q * (W / 4), L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, Q, W);
+      diag_done = false;
+      const int nst = W > SEGN ? Q * (W / 2) : Q * (W / 4);
+      if (may_merge && Q >= (merge >= 2 ? 1 : 2)) {
+        const int nurg = W > SEGN ? W / 2 : W / 4, ndiag = tri_grid(W);
+        SDM_KLAUNCH(P, k_sbw_step_diag, dim3(nst + ndiag), dim3(ST), SDM_MERGED_SMEM(W), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout, C.d_perm.p, C.sb_g.p, thr, Q, W,
+                    C.refine_max, noted, seq, C.sweep_cnt.p, nurg, nst - nurg, ndiag, C.tmo.dev());
+        diag_done = true;
+      } else if (Q > 0) SDM_KLAUNCH(P, k_sbw_step, dim3(nst, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, Q, W);
     }
   }
 }

@@ -411,8 +411,8 @@ def check_solve_widths(m, thr, seed=0):
     while wauto < m and wauto < 2048:
         wauto *= 2
     widths = [0] + [w for w in (256, 512, 1024) if w < wauto]
-    # (all three refinement modes at the automatic width, the default mode at the others)
-    for width, refine in [(w, r) for w in widths for r in ((1,) if thr is None or w != 0 else (0, 1, 2))]:
+    # (all three refinement modes at the automatic width, substitution and the default mode at the others)
+    for width, refine in [(w, r) for w in widths for r in ((1,) if thr is None else (0, 1, 2) if w == 0 else (0, 1))]:
         plan = Plan(0)
         plan.set_solve_width(width)
         plan.set_refinement(refine)
@@ -429,24 +429,41 @@ def check_solve_widths(m, thr, seed=0):
             assert bad == nsb
         elif thr is None:
             assert bad == 0
-        plan.kprof(True)
-        ys = []
-        for r in rhss:
-            plan.upload("rhs", r); plan.ldlsolve(); ys.append(plan.download("y"))
-        prof = plan.kprof_summary()
-        plan.kprof(False)
-        nl = sum(v[0] for k, v in prof.items() if k.startswith("k_sfw") or k.startswith("k_sbw"))
-        lean, robust = 2 * (2 * nsb - 1), 2 * (2 * nsb - 1) + 8 * nsb
-        if refine == 2:
-            assert nl == len(rhss) * robust, (width, refine, prof)
-        elif refine == 1 and thr is not None and bad > 0:
-            # the download after the first solve made the note visible (the emulator runs a launch to its end at once: there the
-            # first solve's backward sweep already sees the note its forward sweep left)
-            assert lean + (len(rhss) - 1) * robust <= nl <= len(rhss) * robust, (width, refine, prof)
-        else:
-            assert nl == len(rhss) * lean, (width, refine, prof)
-        for y, want in zip(ys, wants):
-            assert relerr(y, want) < 1e-9, (width, refine, relerr(y, want))
+        # the sweeps' launches: separate (SEDUMI_HIP_SWEEP_MERGE=0), a row / step launch merged with the NEXT diagonal block's where rows beyond that
+        # block stream on (1, the default: nsb - 2 merges per sweep) or wherever a next block exists (2: nsb - 1) -- one-front levels, W > 256, no
+        # refinement launches.  Same arithmetic per row: bit-identical results where every block is within the growth bound
+        levels = (1, 0, 2) if W > 256 and nsb >= 2 else (1,)
+        first = None
+        for level in levels:
+            os.environ["SEDUMI_HIP_SWEEP_MERGE"] = str(level)
+            try:
+                plan.kprof(True)
+                ys = []
+                for r in rhss:
+                    plan.upload("rhs", r); plan.ldlsolve(); ys.append(plan.download("y"))
+                prof = plan.kprof_summary()
+                plan.kprof(False)
+            finally:
+                del os.environ["SEDUMI_HIP_SWEEP_MERGE"]
+            nl = sum(v[0] for k, v in prof.items() if k.startswith("k_sfw") or k.startswith("k_sbw"))
+            nm = 0 if W <= 256 or level == 0 else 2 * max(0, nsb - (2 if level == 1 else 1))
+            lean, robust = 2 * (2 * nsb - 1), 2 * (2 * nsb - 1) + 8 * nsb
+            if refine == 2:
+                assert nl == len(rhss) * robust, (width, refine, level, prof)
+            elif refine == 1 and thr is not None and bad > 0:
+                # the download after the first solve made the note visible (the emulator runs a launch to its end at once: there the
+                # first solve's backward sweep already sees the note its forward sweep left)
+                assert lean - nm + (len(rhss) - 1) * robust <= nl <= len(rhss) * robust, (width, refine, level, prof)
+            else:
+                assert nl == len(rhss) * (lean - nm), (width, refine, level, prof)
+                if nm:
+                    assert any("rows_diag" in k for k in prof) and any("step_diag" in k for k in prof), prof
+            for y, want in zip(ys, wants):
+                assert relerr(y, want) < 1e-9, (width, refine, level, relerr(y, want))
+            if first is None:
+                first = ys
+            elif bad == 0:                                          # (a block beyond the bound: the merged launch substitutes in tiles of 16, not 32)
+                assert all(np.array_equal(u, v) for u, v in zip(first, ys)), (width, refine, level)
         plan.close()
 
 

@@ -12,9 +12,9 @@ void set_error(const std::string &msg) { g_err = msg; }
 using namespace sdm;
 
 // every read-back of a plan passes through here after its stream synchronise: a spin inside one of THIS plan's panel
-// launches that gave up makes the results unusable (the plan is marked not factored by chol_wait_timeouts)
+// launches (or merged sweep launches, sdm_solve.hip: merged_wait) that gave up makes the results unusable (the plan is marked not factored by chol_wait_timeouts)
 static void check_plan_health(sdm_plan *p) {
-  if (chol_wait_timeouts(p)) throw std::runtime_error("blkchol: a workgroup timed out waiting for another one inside a panel launch");
+  if (chol_wait_timeouts(p)) throw std::runtime_error("blkchol: a workgroup timed out waiting for another one inside a launch (factor panel or merged sweep)");
 }
 
 #define SDM_TRY try {
@@ -215,7 +215,7 @@ int sdm_plan_blkchol_wait(sdm_plan *p, const sdm_cholpars *pars, int use_absd) {
     if (sdm_plan_blkchol(p, pars, use_absd)) throw std::runtime_error(g_err);
     SDM_HIP_CHECK(hipStreamSynchronize(p->stream));
     if (!chol_wait_timeouts(p)) break;                               // (a time-out switches the plan to the launch-per-panel path)
-    if (attempt == 1) throw std::runtime_error("blkchol: a workgroup timed out waiting for another one inside a panel launch");
+    if (attempt == 1) throw std::runtime_error("blkchol: a workgroup timed out waiting for another one inside a launch (factor panel or merged sweep)");
   }
   SDM_CATCH
 }

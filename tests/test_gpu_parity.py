@@ -724,6 +724,43 @@ def test_one_launch_front_starved_by_another_process(refmex, busy):
     plan.close(); small.close()
 
 
+@pytest.mark.parametrize("m,width", [(4500, 1024), (6500, 0)])
+def test_merged_sweep_launches_eager_replayed_and_soaked(m, width):
+    """A front of five (width 1024) / four (2048) super-blocks: its sweeps merge a row / step launch with the next diagonal block's (k_sfw_rows_diag,
+    k_sbw_step_diag: workgroups of ONE launch hand the vector over through counters).  The same bits as the separate launches -- eagerly, 200 times in a
+    row (a hand-over that raced would show sooner or later), and replayed from a captured hipGraph (the counter sets carry nothing from sweep to sweep)."""
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    rng = np.random.default_rng(m)
+    X = rng.standard_normal((m, m)); X = 0.5 * (X + X.T) / np.sqrt(m); X[np.diag_indices(m)] = 4.0 + rng.random(m)
+    plan = Plan(0)
+    plan.set_solve_width(width)
+    plan.set_chol(problem.dense_symbolic(m), problem.dense_pattern(m))
+    plan.upload("ada", X.ravel(order="F"))
+    rhs = rng.standard_normal(m)
+    plan.upload("rhs", rhs)
+    plan.blkchol(None, False)
+    try:
+        os.environ["SEDUMI_HIP_SWEEP_MERGE"] = "0"
+        plan.ldlsolve(); want = plan.download("y")
+        assert relerr(X @ want, rhs) < 1e-10
+        os.environ["SEDUMI_HIP_SWEEP_MERGE"] = "1"
+        plan.kprof(True); plan.ldlsolve(); prof = plan.kprof_summary(); plan.kprof(False)
+        assert prof["k_sfw_rows_diag"][0] >= 2 and prof["k_sbw_step_diag"][0] >= 2, prof
+        for it in range(200):
+            plan.upload("y", np.zeros(m)); plan.ldlsolve()
+            assert np.array_equal(plan.download("y"), want), it
+        gid = plan.graph_capture(plan.ldlsolve)
+        for it in range(5):
+            plan.upload("y", np.zeros(m)); plan.graph_launch(gid); plan.sync()
+            assert np.array_equal(plan.download("y"), want), it
+        plan.ldlsolve()                                                # (and eagerly again behind the replays)
+        assert np.array_equal(plan.download("y"), want)
+    finally:
+        del os.environ["SEDUMI_HIP_SWEEP_MERGE"]
+    plan.close()
+
+
 @pytest.mark.parametrize("m", [300, 530, 700])
 def test_inverse_by_one_launch_and_by_a_launch_per_stage(m):
     """k_sprep against k_sinv128 + k_stile (items sorted longest first): the same solutions bit for bit."""

@@ -1174,8 +1174,12 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
 }
 
 // spmakesym (getada3.c:151-180): out(i,j) = in(i,j) + in(j,i) for i != j
+// (the transposed entries in[(j, i)] of a column are a stride of a column apart: a 128-byte line serves 16 neighbouring columns.  Workgroup b runs
+// on XCD b % 8: groups of 128 columns are dealt 16 neighbours to an XCD, so that the line is fetched into ONE L2 and used 16 times there --
+// MAXCUT-4000: 1.76 GB per launch for a 128 MB matrix with column j = b, profiles/r08u_maxcut4000_pmc_traffic.json)
 __global__ void k_symmetrize(double *out, const double *in, const int64_t *ADAjc, const int *ADAir, const int *adaT, int m) {
-  const int j = blockIdx.x;
+  int j = blockIdx.x;
+  if (j < (m / 128) * 128) { const int r = j & 127; j = (j & ~127) + (r & 7) * 16 + (r >> 3); }
   for (int64_t e = ADAjc[j] + threadIdx.x; e < ADAjc[j + 1]; e += blockDim.x) {
     const int i = ADAir[e];
     double v = in[e];

@@ -1026,6 +1026,11 @@ class Sedumi:
 
     # ---- sedumi.m:396-571 (main loop) and :590-612 (the solution)
     def solve(self, verbose=False):
+        """The interior-point loop (sedumi.m:300-640).  Runs under `blas_threads`: the cone algebra is many small LAPACK calls per iteration."""
+        with blas_threads(self.K):
+            return self._solve(verbose)
+
+    def _solve(self, verbose=False):
         cn, pars, hot, S, K = self.cone, dict(self.pars), self.hot, self.S, self.K
         b = self.b
         d, v, vfrm, y, y0, R = self.sdinit()
@@ -1119,6 +1124,22 @@ class Sedumi:
         by = float(b @ y)
         return {"iter": it, "STOP": STOP, "cx": cx / x0 if x0 > 0 else cx, "by": by / x0 if x0 > 0 else by, "x0": x0, "rows": rows,
                 "feasratio": feasratio, "hot": hot.name}
+
+
+def blas_threads(K):
+    """Context manager: the BLAS / LAPACK thread pools numpy and scipy use, sized for the cone's blocks.  With a pool as wide as the host (256
+    threads on the MI355X box) every small call -- a 70 x 70 triangular solve, eigh, qr, dozens per iteration -- pays the pool's wake-up:
+    control07 took 1.76 s in the default pool and 0.58 s with one thread (profiles/r08w_driver_profile_control07.txt).  One thread while no PSD /
+    Lorentz block exceeds order 256, up to 16 beyond (dense eigh / chol of a MAXCUT block).  Without threadpoolctl: nothing is changed."""
+    import contextlib
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:                                                 # pragma: no cover
+        return contextlib.nullcontext()
+    nmax = max([0] + [int(n) for key in ("s", "q") for n in np.atleast_1d(K.get(key, [])).ravel()])
+    ncpu = os.cpu_count() or 1
+    env = os.environ.get("SEDUMI_DRIVER_BLAS_THREADS")
+    return threadpool_limits(limits=int(env) if env else (1 if nmax <= 256 else min(16, ncpu)))
 
 
 def load_mat(path):

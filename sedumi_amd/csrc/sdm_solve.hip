@@ -889,16 +889,16 @@ k_sfw_rows(const double *__restrict__ LT, FrontTab tab, const int *list, double 
 // turn (set = super-block & 1), a launch clears the set the NEXT one counts on, and the level's first diagonal-block launch -- never merged --
 // clears both: no re-arming count that every diagonal workgroup would have to pass through, nothing carried from sweep to sweep (a replayed
 // graph finds what it was captured with).
-constexpr int PRE_WGS = 1024;
+constexpr int PRE_WGS = 1024;          // (SEDUMI_HIP_SWEEP_PRE overrides: 0 ... 512 lose 8 - 11 %, 1024 ... 4096 are level -- profiles/r08x_merge_pre_sweep.txt)
 #ifdef SDM_EMU
 #define SDM_EIGHT_WAVES
 #else
 #define SDM_EIGHT_WAVES __attribute__((amdgpu_waves_per_eu(8, 8)))      // <= 64 vector registers: eight workgroups of 256 per CU
 #endif
-// role of workgroup b of a merged launch: nurg urgent + nother other workgroups of the streaming role, ndiag of the diagonal role.  Returns true
+// role of workgroup b of a merged launch: nurg urgent workgroups, npre others of the streaming role ahead of the ndiag of the diagonal role, the rest behind.  Returns true
 // for the diagonal role; bx = the index inside the role
-__device__ __forceinline__ bool merged_role(int b, int nurg, int nother, int ndiag, int &bx) {
-  const int pre = nurg + min(nother, PRE_WGS);
+__device__ __forceinline__ bool merged_role(int b, int nurg, int npre, int ndiag, int &bx) {
+  const int pre = nurg + npre;
   if (b < pre) { bx = b; return false; }
   if (b < pre + ndiag) { bx = b - pre; return true; }
   bx = b - ndiag;
@@ -972,11 +972,11 @@ __device__ __forceinline__ void sfw_diag_lean(char *smem, double *part, int bx, 
 __global__ void __launch_bounds__(ST) SDM_EIGHT_WAVES
 k_sfw_rows_diag(const double *__restrict__ LT, const double *__restrict__ F, const double *__restrict__ STr, FrontTab tab, const int *list, double *wv, const double *src,
                 const int *perm, double *y, const unsigned long long *sb_g, double thr, int Pb, int assign0, FwBatch bt, double *zdiv, const double *dscale, int W,
-                double thr2, int *noted, int seq, int *cnt, int nurg, int nother, int ndiag, int *tmo) {
+                double thr2, int *noted, int seq, int *cnt, int nurg, int npre, int ndiag, int *tmo) {
   SDM_DYN_SMEM(smem);
   __shared__ double part[ST / 64];
   int bx;
-  if (!merged_role((int)blockIdx.x, nurg, nother, ndiag, bx)) {
+  if (!merged_role((int)blockIdx.x, nurg, npre, ndiag, bx)) {
     sfw_rows_body(part, bx, LT, tab, list, wv, src, perm, y, Pb, assign0, bt, W, true);
     if (bx < nurg) {                                                   // an urgent workgroup: its rows of t_{P+1} are out (write-through), count it
       SDM_STORES_DONE();
@@ -1211,11 +1211,11 @@ k_sbw_step(const double *__restrict__ F, FrontTab tab, const int *list, double *
 // step Q and the diagonal block Q - 1 as ONE launch (k_sfw_rows_diag's counterpart: the columns of super-block Q - 1 are the urgent ones)
 __global__ void __launch_bounds__(ST) SDM_EIGHT_WAVES
 k_sbw_step_diag(const double *__restrict__ F, const double *__restrict__ S, FrontTab tab, const int *list, double *y, double *xfin, double *yout, const int *perm,
-                const unsigned long long *sb_g, double thr, int Q, int W, double thr2, int *noted, int seq, int *cnt, int nurg, int nother, int ndiag, int *tmo) {
+                const unsigned long long *sb_g, double thr, int Q, int W, double thr2, int *noted, int seq, int *cnt, int nurg, int npre, int ndiag, int *tmo) {
   SDM_DYN_SMEM(smem);
   __shared__ double part[ST / 64];
   int bx;
-  if (!merged_role((int)blockIdx.x, nurg, nother, ndiag, bx)) {
+  if (!merged_role((int)blockIdx.x, nurg, npre, ndiag, bx)) {
     sbw_step_body(part, bx, F, tab, list, y, xfin, Q, W, true);
     if (bx < nurg) {
       SDM_STORES_DONE();
@@ -1314,6 +1314,7 @@ void solve_stats(sdm_plan *P, sdm_int *nblocks, sdm_int *nbad, double *max_growt
 // now, without waiting for the device)
 constexpr int REFINE_STEPS = 2;
 // merged sweep launches (k_sfw_rows_diag): 0 never, 1 where rows beyond the next super-block exist, 2 every row launch of a one-front level
+static int sweep_merge_pre() { const char *e = getenv("SEDUMI_HIP_SWEEP_PRE"); return e ? std::max(0, atoi(e)) : PRE_WGS; }
 static int sweep_merge_level() {
   const char *e = getenv("SEDUMI_HIP_SWEEP_MERGE");               // (read per sweep: the tests switch it)
   return e ? atoi(e) : 1;
@@ -1374,7 +1375,7 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
         const int nrw = W > SEGN ? (L.maxns - (Pb + 1) * W + 1) / 2 : (L.maxns - (Pb + 1) * W + 3) / 4;
         const int nurg = std::min(nrw, W > SEGN ? W / 2 : W / 4), ndiag = tri_grid(std::min(W, L.maxns - (Pb + 1) * W));
         SDM_KLAUNCH(P, k_sfw_rows_diag, dim3(nrw + ndiag), dim3(ST), SDM_MERGED_SMEM(W), C.LT.p, C.fronts.p, C.ST.p, tab, list, wv, rhs, C.d_perm.p, y, C.sb_g.p, thr, Pb,
-                    assign0, bt, zdiv, dscale, W, C.refine_max, noted, seq, C.sweep_cnt.p, nurg, nrw - nurg, ndiag, C.tmo.dev());
+                    assign0, bt, zdiv, dscale, W, C.refine_max, noted, seq, C.sweep_cnt.p, nurg, std::min(nrw - nurg, sweep_merge_pre()), ndiag, C.tmo.dev());
         diag_done = true;
       } else if (L.maxns > (Pb + 1) * W)                             // the fronts' own rows of later super-blocks
         SDM_KLAUNCH(P, k_sfw_rows, dim3(W > SEGN ? (L.maxns - (Pb + 1) * W + 1) / 2 : (L.maxns - (Pb + 1) * W + 3) / 4, L.nfronts, nrhs), dim3(ST), 0, C.LT.p, tab, list, wv, rhs, C.d_perm.p, y, Pb,
@@ -1425,7 +1426,7 @@ static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double 
       if (may_merge && Q >= (merge >= 2 ? 1 : 2)) {
         const int nurg = W > SEGN ? W / 2 : W / 4, ndiag = tri_grid(W);
         SDM_KLAUNCH(P, k_sbw_step_diag, dim3(nst + ndiag), dim3(ST), SDM_MERGED_SMEM(W), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout, C.d_perm.p, C.sb_g.p, thr, Q, W,
-                    C.refine_max, noted, seq, C.sweep_cnt.p, nurg, nst - nurg, ndiag, C.tmo.dev());
+                    C.refine_max, noted, seq, C.sweep_cnt.p, nurg, std::min(nst - nurg, sweep_merge_pre()), ndiag, C.tmo.dev());
         diag_done = true;
       } else if (Q > 0) SDM_KLAUNCH(P, k_sbw_step, dim3(nst, L.nfronts), dim3(ST), 0, C.fronts.p, tab, list, y, C.xfin.p, Q, W);
     }

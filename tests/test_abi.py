@@ -142,6 +142,22 @@ def test_no_kernel_spills_vector_registers(hiplib, tmp_path):
     assert all("k_ldl_front" in k or "k_ldl_panel" in k for k in scratch), scratch
 
 
+def test_merged_sweep_kernels_fit_eight_workgroups_per_cu(hiplib):
+    """k_sfw_rows_diag / k_sbw_step_diag carry a streaming role that lives on eight workgroups of 256 per CU: at most 64 vector registers, no
+    scratch, no spills (with the shared diagonal body called instead of a lean role the kernels were allotted 216 registers
+    and a merged launch took twice the time of the two it replaced)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("code_objects", os.path.join(ROOT, "tools", "code_objects.py"))
+    co = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(co)
+    if not os.path.exists(co.READELF):
+        pytest.skip("llvm-readelf not found")
+    ks = {k: v for k, v in co.kernels(hiplib).items() if "k_sfw_rows_diag" in k or "k_sbw_step_diag" in k}
+    assert len(ks) == 2, list(ks)
+    for k, v in ks.items():
+        assert v["vgpr_count"] <= 64 and v["agpr_count"] == 0 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
+
+
 def test_called_stages_of_the_factor_kernels_touch_scratch_only_at_entry(hiplib, tmp_path):
     """The stages of the two factor kernels are called functions (one register allocation each) that use most of the register
     file.  Under the default convention such a function saves and restores every callee-saved VGPR it touches through scratch

@@ -1,4 +1,4 @@
-"""tools/merge_probe.py <m> -- the merged sweep launches (SEDUMI_HIP_SWEEP_MERGE = 0 separate, 1 the default, 2 every row / step launch of a
+"""tools/merge_probe.py <m> [width] -- the merged sweep launches (SEDUMI_HIP_SWEEP_MERGE = 0 separate, 1 the default, 2 every row / step launch of a
 one-front level) on one dense front of order m: microseconds per solve by merge level and whether the results match the separate launches bit for
 bit over `reps` solves each."""
 import json
@@ -14,9 +14,11 @@ from sedumi_amd import problem  # noqa: E402
 from sedumi_amd.plan import Plan  # noqa: E402
 
 m = int(sys.argv[1])
+width = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(m)
 X = rng.standard_normal((m, m)); X = 0.5 * (X + X.T) / np.sqrt(m); X[np.diag_indices(m)] = 4.0 + rng.random(m)
 plan = Plan(0)
+plan.set_solve_width(width)
 plan.set_chol(problem.dense_symbolic(m), problem.dense_pattern(m))
 plan.upload("ada", X.ravel(order="F")); del X
 plan.upload("rhs", rng.standard_normal(m))
@@ -37,7 +39,7 @@ def run(level, reps=20):
 
 
 t0, ref = run(0)
-print(json.dumps({"m": m, "level": 0, "us": round(t0, 1)}), flush=True)
+print(json.dumps({"m": m, "width": width or "auto", "level": 0, "us": round(t0, 1)}), flush=True)
 for level in (1, 2):
     if True:
         t, ys = run(level)

@@ -357,6 +357,7 @@ struct sdm_plan {
   std::vector<sdm_int> ada_jc, ada_ir;   // host copy of the ADA pattern
   hipEvent_t ev_begin[16] = {}, ev_end[16] = {};
   bool capturing = false;
+  sdm::PinnedInts dl_stage;          // pinned staging of small read-backs (sdm_plan_download: DL_STAGE_BYTES)
   std::vector<hipGraphExec_t> graphs;   // captured launch sequences (sdm_plan_graph_*)
 };
 

@@ -881,7 +881,7 @@ k_sfw_rows(const double *__restrict__ LT, FrontTab tab, const int *list, double 
 // role's workgroups in row order (tri_task), the rest.  The urgent workgroups store their entries of t past the caches and count per CHUNK of 64
 // rows; a diagonal workgroup waits for the chunks its rows reach -- all handed out before it, none of which waits for anything --, copies that
 // much of t to LDS with L1-bypassing loads (once per workgroup: read that way per row, 2 M loads on the same 16 KB, the role took twice the
-// separate launch's time; an acquire fence and plain loads returned stale entries -- profiles/r08s_*) and runs its rows against the copy.  Its
+// separate launch's time -- profiles/r08s_*) and runs its rows against the copy.  Its
 // loads ride in the stream of the launch, its first rows a few microseconds behind the first urgent ones.  One right-hand side, one front in the
 // level, W > 256, no refinement launches (solve_fw_batch).
 // The counters: 1024 increments of ONE address cost a launch 19 us (same-address atomics resolve one after the other at the device's coherence
@@ -1374,6 +1374,12 @@ void solve_fw_batch(sdm_plan *P, const double *rhs, int64_t rhs_stride, double *
       if (may_merge && L.maxns > (Pb + (merge >= 2 ? 1 : 2)) * W) {
         const int nrw = W > SEGN ? (L.maxns - (Pb + 1) * W + 1) / 2 : (L.maxns - (Pb + 1) * W + 3) / 4;
         const int nurg = std::min(nrw, W > SEGN ? W / 2 : W / 4), ndiag = tri_grid(std::min(W, L.maxns - (Pb + 1) * W));
+#ifdef SDM_EMU
+        // (tests/test_emu_concurrent.py: one process per workgroup, the diagonal role really waits for the urgent rows)
+        if (emu_concurrent() && nrw + ndiag <= 256) SDM_KLAUNCH_CONCURRENT(P, k_sfw_rows_diag, dim3(nrw + ndiag), dim3(ST), SDM_MERGED_SMEM(W), C.LT.p, C.fronts.p, C.ST.p, tab, list, wv, rhs, C.d_perm.p, y, C.sb_g.p, thr, Pb,
+                    assign0, bt, zdiv, dscale, W, C.refine_max, noted, seq, C.sweep_cnt.p, nurg, std::min(nrw - nurg, sweep_merge_pre()), ndiag, C.tmo.dev());
+        else
+#endif
         SDM_KLAUNCH(P, k_sfw_rows_diag, dim3(nrw + ndiag), dim3(ST), SDM_MERGED_SMEM(W), C.LT.p, C.fronts.p, C.ST.p, tab, list, wv, rhs, C.d_perm.p, y, C.sb_g.p, thr, Pb,
                     assign0, bt, zdiv, dscale, W, C.refine_max, noted, seq, C.sweep_cnt.p, nurg, std::min(nrw - nurg, sweep_merge_pre()), ndiag, C.tmo.dev());
         diag_done = true;
@@ -1425,6 +1431,11 @@ static void solve_bw_inplace(sdm_plan *P, double *y, double *yout, const double 
       const int nst = W > SEGN ? Q * (W / 2) : Q * (W / 4);
       if (may_merge && Q >= (merge >= 2 ? 1 : 2)) {
         const int nurg = W > SEGN ? W / 2 : W / 4, ndiag = tri_grid(W);
+#ifdef SDM_EMU
+        if (emu_concurrent() && nst + ndiag <= 256) SDM_KLAUNCH_CONCURRENT(P, k_sbw_step_diag, dim3(nst + ndiag), dim3(ST), SDM_MERGED_SMEM(W), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout, C.d_perm.p, C.sb_g.p, thr, Q, W,
+                    C.refine_max, noted, seq, C.sweep_cnt.p, nurg, std::min(nst - nurg, sweep_merge_pre()), ndiag, C.tmo.dev());
+        else
+#endif
         SDM_KLAUNCH(P, k_sbw_step_diag, dim3(nst + ndiag), dim3(ST), SDM_MERGED_SMEM(W), C.fronts.p, C.S.p, tab, list, y, C.xfin.p, yout, C.d_perm.p, C.sb_g.p, thr, Q, W,
                     C.refine_max, noted, seq, C.sweep_cnt.p, nurg, std::min(nst - nurg, sweep_merge_pre()), ndiag, C.tmo.dev());
         diag_done = true;

@@ -139,6 +139,9 @@ void emu_shared_free(void *p) {
   munmap(m, *(size_t *)m);
 }
 void emu_set_concurrent(int on) { g_concurrent = on; }
+/* concurrent launches: fork the workgroups' processes from the LAST workgroup down (waiters before the workgroups they wait for) */
+static int g_reverse_blocks = 0;
+void emu_set_reverse_blocks(int on) { g_reverse_blocks = on; }
 static int g_injected_timeouts = 0;
 void emu_inject_timeouts(int n) { g_injected_timeouts = n; }
 int emu_take_injected_timeout() { if (g_injected_timeouts <= 0) return 0; g_injected_timeouts--; return 1; }
@@ -295,7 +298,8 @@ void emu_launch_concurrent(dim3 grid, dim3 block, size_t shmem, const std::funct
   std::vector<pid_t> kids;
   for (unsigned bz = 0; bz < grid.z; bz++)
     for (unsigned by = 0; by < grid.y; by++)
-      for (unsigned bx = 0; bx < grid.x; bx++) {
+      for (unsigned bi = 0; bi < grid.x; bi++) {
+        const unsigned bx = g_reverse_blocks ? grid.x - 1 - bi : bi;
         pid_t pid = fork();
         if (pid < 0) {
           kids.insert(kids.end(), g_group_kids.begin(), g_group_kids.end());

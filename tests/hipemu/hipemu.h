@@ -123,6 +123,7 @@ void emu_set_concurrent(int on);
 void emu_inject_timeouts(int n);
 int emu_take_injected_timeout();
 int emu_concurrent();
+void emu_set_reverse_blocks(int on);
 /* inside a spin loop on another workgroup's progress: yields the processor in a workgroup process, aborts in a sequential
    launch (there the other workgroup has either run already or never will) */
 void emu_spin_pause();

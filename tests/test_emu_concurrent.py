@@ -144,3 +144,45 @@ def test_multifront_solves_as_concurrent_workgroups(refmex, glue, concurrent_emu
 def test_iteration_units_as_concurrent_workgroups(glue, concurrent_emu):
     _tp.test_iteration_unit_block_diagonal_multi_supernode(glue)
     _tp.test_iteration_unit_maxcut_small(glue)
+
+
+@pytest.mark.parametrize("m,reverse", [(600, 0), (600, 1), (700, 0)])
+@pytest.mark.parametrize("last_first", [0, 1])
+def test_merged_sweep_launches_as_concurrent_workgroups(concurrent_emu, m, reverse, last_first):
+    """k_sfw_rows_diag / k_sbw_step_diag (a row / step launch and the next diagonal block's launch as one) with one process
+    per workgroup: the diagonal role's workgroups really wait for the urgent rows' chunk counters and read what those stored.  Two super-blocks of
+    512, every row launch merged (SEDUMI_HIP_SWEEP_MERGE=2): 44 processes forward, 256 backward.  The bits of the separate launches; reverse: the
+    work-items of every workgroup scheduled in descending order; last_first: the processes forked from the last workgroup down, so that the waiting
+    role is up before the role it waits for (with the wait removed from the kernel this case fails; forked in grid order it does not)."""
+    import os
+    from sedumi_amd import problem
+    from sedumi_amd.plan import Plan
+    X, rhs = _dense_front(m, m)
+    concurrent_emu._Z15emu_set_reversei(reverse)
+    concurrent_emu._Z22emu_set_reverse_blocksi(last_first)
+    try:
+        plan = Plan(0)
+        plan.set_solve_width(512)
+        plan.set_chol(problem.dense_symbolic(m), X)
+        plan.upload("ada", X.data); plan.upload("rhs", rhs)
+        concurrent_emu._Z18emu_set_concurrenti(0)
+        plan.blkchol(None, False)
+        os.environ["SEDUMI_HIP_SWEEP_MERGE"] = "0"
+        rhss = [rhs, np.cos(np.arange(m) * 0.37) + 2.0]               # (two right-hand sides in turn: what a solve leaves behind is NOT the next one's data)
+        wants = []
+        for r in rhss:
+            plan.upload("rhs", r); plan.ldlsolve(); wants.append(plan.download("y"))
+            assert relerr(X @ wants[-1], r) < 1e-10
+        os.environ["SEDUMI_HIP_SWEEP_MERGE"] = "2"
+        concurrent_emu._Z18emu_set_concurrenti(1)
+        plan.kprof(True)
+        for it in range(2):                                             # (the counter sets are re-armed between sweeps)
+            plan.upload("rhs", rhss[it]); plan.upload("y", np.zeros(m)); plan.ldlsolve()
+            assert np.array_equal(plan.download("y"), wants[it]), it
+        prof = plan.kprof_summary(); plan.kprof(False)
+        assert prof["k_sfw_rows_diag"][0] == 2 and prof["k_sbw_step_diag"][0] == 2, prof
+        plan.close()
+    finally:
+        os.environ.pop("SEDUMI_HIP_SWEEP_MERGE", None)
+        concurrent_emu._Z15emu_set_reversei(0)
+        concurrent_emu._Z22emu_set_reverse_blocksi(0)

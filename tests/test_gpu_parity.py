@@ -728,7 +728,7 @@ def test_one_launch_front_starved_by_another_process(refmex, busy):
 def test_merged_sweep_launches_eager_replayed_and_soaked(m, width):
     """A front of five (width 1024) / four (2048) super-blocks: its sweeps merge a row / step launch with the next diagonal block's (k_sfw_rows_diag,
     k_sbw_step_diag: workgroups of ONE launch hand the vector over through counters).  The same bits as the separate launches -- eagerly, 200 times in a
-    row (a hand-over that raced would show sooner or later), and replayed from a captured hipGraph (the counter sets carry nothing from sweep to sweep)."""
+    row with three right-hand sides in turn (a hand-over that raced would show sooner or later), and replayed from a captured hipGraph (the counter sets carry nothing from sweep to sweep)."""
     from sedumi_amd import problem
     from sedumi_amd.plan import Plan
     rng = np.random.default_rng(m)
@@ -742,20 +742,23 @@ def test_merged_sweep_launches_eager_replayed_and_soaked(m, width):
     plan.blkchol(None, False)
     try:
         os.environ["SEDUMI_HIP_SWEEP_MERGE"] = "0"
-        plan.ldlsolve(); want = plan.download("y")
-        assert relerr(X @ want, rhs) < 1e-10
+        rhss = [rhs, rng.standard_normal(m), rng.standard_normal(m)]   # (in turn: what a solve leaves in the work vectors is NOT the next one's data --
+        wants = []                                                      # with ONE right-hand side a hand-over that never waited would pass)
+        for r in rhss:
+            plan.upload("rhs", r); plan.ldlsolve(); wants.append(plan.download("y"))
+            assert relerr(X @ wants[-1], r) < 1e-10
         os.environ["SEDUMI_HIP_SWEEP_MERGE"] = "1"
         plan.kprof(True); plan.ldlsolve(); prof = plan.kprof_summary(); plan.kprof(False)
         assert prof["k_sfw_rows_diag"][0] >= 2 and prof["k_sbw_step_diag"][0] >= 2, prof
-        for it in range(200):
-            plan.upload("y", np.zeros(m)); plan.ldlsolve()
-            assert np.array_equal(plan.download("y"), want), it
+        for it in range(201):
+            plan.upload("rhs", rhss[it % 3]); plan.upload("y", np.zeros(m)); plan.ldlsolve()
+            assert np.array_equal(plan.download("y"), wants[it % 3]), it
         gid = plan.graph_capture(plan.ldlsolve)
-        for it in range(5):
-            plan.upload("y", np.zeros(m)); plan.graph_launch(gid); plan.sync()
-            assert np.array_equal(plan.download("y"), want), it
-        plan.ldlsolve()                                                # (and eagerly again behind the replays)
-        assert np.array_equal(plan.download("y"), want)
+        for it in range(6):
+            plan.upload("rhs", rhss[(it + 1) % 3]); plan.upload("y", np.zeros(m)); plan.graph_launch(gid); plan.sync()
+            assert np.array_equal(plan.download("y"), wants[(it + 1) % 3]), it
+        plan.upload("rhs", rhss[0]); plan.ldlsolve()                   # (and eagerly again behind the replays)
+        assert np.array_equal(plan.download("y"), wants[0])
     finally:
         del os.environ["SEDUMI_HIP_SWEEP_MERGE"]
     plan.close()

@@ -12,6 +12,18 @@ LIB = os.path.join(HERE, "libsedumi_hipemu.so")
 
 
 def build(force=False):
+    """(Serialised across processes: pytest-xdist workers that find the library stale at the same time would otherwise compile and link it on top of
+    each other -- `file too short` in the worker that loads it meanwhile.)"""
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build(force)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build(force=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
     deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "hipemu.*")) + \
         glob.glob(os.path.join(ROOT, "include", "*.h"))
@@ -28,7 +40,8 @@ def build(force=False):
                          "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-variable", "-c", s, "-o", o])
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(subprocess.check_call, jobs))
-    subprocess.check_call(["g++", "-shared", "-o", LIB] + objs)
+    subprocess.check_call(["g++", "-shared", "-o", LIB + ".tmp"] + objs)
+    os.replace(LIB + ".tmp", LIB)                      # (never a half-written library under the name the tests load)
     return LIB
 
 

@@ -460,6 +460,15 @@ def check_solve_widths(m, thr, seed=0):
                     assert any("rows_diag" in k for k in prof) and any("step_diag" in k for k in prof), prof
             for y, want in zip(ys, wants):
                 assert relerr(y, want) < 1e-9, (width, refine, level, relerr(y, want))
+            # the two sweeps on their own (fwblkslv / bwblkslv: no ./d folded into the forward sweep, the backward sweep from a fresh vector)
+            os.environ["SEDUMI_HIP_SWEEP_MERGE"] = str(level)
+            try:
+                plan.upload("rhs", rhss[0]); plan.fwsolve(); ys.append(plan.download("y"))
+                plan.upload("rhs", rhss[1]); plan.bwsolve(); ys.append(plan.download("y"))
+            finally:
+                del os.environ["SEDUMI_HIP_SWEEP_MERGE"]
+            if thr is None:
+                assert relerr(ys[-2], np.linalg.solve(Lv, rhss[0])) < 1e-9 and relerr(ys[-1], np.linalg.solve(Lv.T, rhss[1])) < 1e-9, (width, level)
             if first is None:
                 first = ys
             elif bad == 0:                                          # (a block beyond the bound: the merged launch substitutes in tiles of 16, not 32)

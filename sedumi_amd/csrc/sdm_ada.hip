@@ -219,6 +219,12 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
       A.ell_order.upload(order);
       A.ell_full = (ADAjc[m] == (sdm_int)m * m);                      // every column of the pattern full: (j, i) sits at ADAjc[i] + j
       A.d_uoff.upload(uoff);
+      { std::vector<int> zp((size_t)A.nnzA, 0);                       // position of a PSD nonzero's entry in the full-length z vector
+        for (sdm_int i = 0; i < m; i++) for (sdm_int t = Ajc_psd[i]; t < Ajc[i + 1]; t++) zp[(size_t)t] = (int)(uoff[Ablk[t]] + Aupos[t]);
+        A.d_Azpos.upload(zp);
+        std::vector<int> zd(t_blk.size());                            // and of a task's block
+        for (size_t t = 0; t < t_blk.size(); t++) zd[t] = (int)uoff[t_blk[t]];
+        A.t_zdst.upload(zd); }
       A.ell_ok = true;
     }
   }
@@ -1051,7 +1057,8 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
                  const int64_t *Ajc_psd, const double *Apr, const int *Ablk, const int *Aupos,
                  const int64_t *c_taskptr, const int *t_blk, const int *t_ulen, const int64_t *t_zoff, const double *zbuf,
                  const int64_t *uoff, const int *g_row, const int *g_len, const int64_t *g_off, const double *g_val,
-                 const int *g_pos, int ngroups, const int *invperm, int zmax, int m, int jbase, int jend, const int *ell_pos, const int *ell_order) {
+                 const int *g_pos, int ngroups, const int *invperm, int zmax, int m, int jbase, int jend, const int *ell_pos, const int *ell_order,
+                 const int *Azpos, const int *t_zdst, int base_zero) {
   // ell_order != null (full ADA' on a full pattern): the workgroup's columns are order[jbase + ...] -- neighbours in the ELL row
   // order -- and only the row groups from its columns' own group on are swept: an entry (i, j) with group(i) > group(j) is
   // computed once, at column j, and added to (j, i) as well (the PSD part is symmetric: <a_i, z_j> = <a_j, z_i>); pairs inside
@@ -1073,54 +1080,100 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
 #pragma unroll
     for (int q = 0; q < JB; q++) gq[q] = 0;
   }
+  // Round 6: the prologue was 44 % of a workgroup's time on control07 (in-kernel clocks, profiles/r08x_stage2_ell_phases.txt: z_j staged task by
+  // task, each behind three dependent look-ups and a copy loop of one load in flight per work-item: 15.7 us; absd 5.7 and the diagonal's base
+  // value 6.6 in ALL workgroups of a column set although one of them owns the diagonal entry).  Now: the (column, task) segments' descriptors in
+  // one round trip (positions precomputed at set-up: t_zdst, Azpos), every segment's entries in flight together, absd in the owner only.
+  constexpr int SEG_MAX = 16;
+  __shared__ long long sg_src[SEG_MAX];
+  __shared__ int sg_dst[SEG_MAX], sg_cum[SEG_MAX + 1];
+  __shared__ long long tb_s[JB], te_s[JB], ab_s[JB], ae_s[JB];
   for (int k = tid; k < zmax * JB; k += bs) zl[k] = 0.0;
+  if (tid < JB) {                                                    // (everything a column's index leads to, in the same round trip)
+    const int j = ELLCOL(j0 + tid);
+    const bool in = j0 + tid < jend;
+    tb_s[tid] = in ? c_taskptr[j] : 0; te_s[tid] = in ? c_taskptr[j + 1] : 0;
+    ab_s[tid] = in ? Ajc_psd[j] : 0; ae_s[tid] = in ? Ajc[j + 1] : 0;
+  }
   __syncthreads();
-  bool jhas[JB];
+  bool jhas[JB], own[JB], owns = false;
+  int nseg = 0;
 #pragma unroll
   for (int q = 0; q < JB; q++) {
-    const int j = ELLCOL(j0 + q);
-    jhas[q] = false;
-    if (j0 + q < jend) {
-      const int64_t tb = c_taskptr[j], te = c_taskptr[j + 1];
-      jhas[q] = te > tb;
+    jhas[q] = te_s[q] > tb_s[q]; nseg += (int)(te_s[q] - tb_s[q]);
+    // (the row groups are split over gridDim.y workgroups: the one that owns row j's group is the only writer of entry (j,j) and of absd(j))
+    const int grp = ell_order ? gq[q] : (ell_pos[min(j0 + q, jend - 1)] >> 6);    // (gq[]: already in registers)
+    own[q] = j0 + q < jend && (int)blockIdx.y == (grp - gstart) % (int)gridDim.y;
+    owns = owns || own[q];
+  }
+  if (nseg <= SEG_MAX) {
+    if (tid < nseg) {                                                // segment tid = task t of column q: zbuf[zoff ..] -> zl[q*zmax + position of the block ..]
+      int q = 0, r = tid;
+      while (r >= (int)(te_s[q] - tb_s[q])) { r -= (int)(te_s[q] - tb_s[q]); q++; }
+      const int64_t t = tb_s[q] + r;
+      sg_src[tid] = t_zoff[t]; sg_dst[tid] = q * zmax + t_zdst[t]; sg_cum[tid + 1] = t_ulen[t];
+    }
+    if (tid == 0) sg_cum[0] = 0;
+    __syncthreads();
+    if (tid == 0) for (int x = 0; x < nseg; x++) sg_cum[x + 1] += sg_cum[x];
+    __syncthreads();
+    const int ntot = sg_cum[nseg];
+    for (int base = 0; base < ntot; base += 12 * bs) {               // 12 entries per work-item in flight (two columns of control07: one trip)
+      double v[12]; int dd[12];
+#pragma unroll
+      for (int x = 0; x < 12; x++) {
+        const int idx = base + x * bs + tid;
+        dd[x] = -1; v[x] = 0.0;
+        if (idx < ntot) {
+          int sgi = 0;
+          while (idx >= sg_cum[sgi + 1]) sgi++;
+          v[x] = zbuf[sg_src[sgi] + (idx - sg_cum[sgi])]; dd[x] = sg_dst[sgi] + (idx - sg_cum[sgi]);
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < 12; x++) if (dd[x] >= 0) zl[dd[x]] = v[x];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < JB; q++) {
       double *zq = zl + (size_t)q * zmax;
-      for (int64_t t = tb; t < te; t++) {                        // the blocks touched by constraint j
+      for (int64_t t = tb_s[q]; t < te_s[q]; t++) {                  // the blocks touched by constraint j
         const double *src = zbuf + t_zoff[t];
-        double *dst = zq + uoff[t_blk[t]];
+        double *dst = zq + t_zdst[t];
         const int ul = t_ulen[t];
         for (int u = tid; u < ul; u += bs) dst[u] = src[u];
       }
     }
   }
   __syncthreads();
-  // absd(j) = ADA_jj (LP/Lorentz part so far) + sum |a_j[psd] .* z_j|   (getada3.c:341-347); 0 without PSD nonzeros
+  if (owns) {                                                        // (uniform for the workgroup)
+    // absd(j) = ADA_jj (LP/Lorentz part so far) + sum |a_j[psd] .* z_j|   (getada3.c:341-347); 0 without PSD nonzeros
 #pragma unroll
-  for (int q = 0; q < JB; q++) {
-    double aabs = 0.0;
-    const int j = ELLCOL(j0 + q);
-    if (jhas[q]) {
-      const double *zq = zl + (size_t)q * zmax;
-      for (int64_t t = Ajc_psd[j] + tid; t < Ajc[j + 1]; t += bs) aabs += fabs(Apr[t] * zq[uoff[Ablk[t]] + Aupos[t]]);
+    for (int q = 0; q < JB; q++) {
+      double aabs = 0.0;
+      if (own[q] && jhas[q]) {
+        const double *zq = zl + (size_t)q * zmax;
+        for (int64_t t = ab_s[q] + tid; t < ae_s[q]; t += bs) aabs += fabs(Apr[t] * zq[Azpos[t]]);
+      }
+      for (int off = 32; off > 0; off >>= 1) aabs += __shfl_down(aabs, off);
+      if (lane == 0) absred[q][wave] = aabs;
     }
-    for (int off = 32; off > 0; off >>= 1) aabs += __shfl_down(aabs, off);
-    if (lane == 0) absred[q][wave] = aabs;
+    __syncthreads();
+    // (the owner reads the entry's LP/Lorentz value here, before it adds to it)
+    if (tid < JB && own[tid]) {                                      // own[] / jhas[] are indexed by a per-lane value only in these JB lanes
+      const int j = ELLCOL(j0 + tid);
+      double basev = 0.0;
+      int64_t lo = ADAjc[j], hi = ADAjc[j + 1];
+      const int64_t ce = hi;
+      if (ce - lo == m) lo += j;                           // full column: no search
+      else while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ADAir[mid] < j) lo = mid + 1; else hi = mid; }
+      if (lo < ce && ADAir[lo] == j) basev = ada[lo];
+      double a = 0.0;
+      for (int w = 0; w < nw; w++) a += absred[tid][w];
+      absd[j] = jhas[tid] ? basev + a : 0.0;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  // (the row groups are split over gridDim.y workgroups: the one that owns row j's group is the only writer of
-  // entry (j,j) and reads its LP/Lorentz value here, before it adds to it)
-  if (tid < JB && j0 + tid < jend && (int)blockIdx.y == ((ell_pos[ELLCOL(j0 + tid)] >> 6) - gstart) % (int)gridDim.y) {
-    const int j = ELLCOL(j0 + tid);
-    double basev = 0.0;
-    int64_t lo = ADAjc[j], hi = ADAjc[j + 1];
-    const int64_t ce = hi;
-    if (ce - lo == m) lo += j;                           // full column: no search
-    else while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ADAir[mid] < j) lo = mid + 1; else hi = mid; }
-    if (lo < ce && ADAir[lo] == j) basev = ada[lo];
-    double a = 0.0;
-    for (int w = 0; w < nw; w++) a += absred[tid][w];
-    absd[j] = jhas[tid] ? basev + a : 0.0;            // jhas[] is indexed by a per-lane value only in these JB lanes
-  }
-  __syncthreads();
   // Every group of 64 rows is swept by ALL wavefronts: wave w takes the entries t = w, w+nw, ... of the 64 rows (one
   // row per lane), so the longest row costs len/nw dependent memory round trips instead of len; the nw partial
   // sums of a row meet in LDS and are added in wave order (deterministic).
@@ -1154,9 +1207,12 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
     if (wave < JB && i >= 0 && j0 + wave < jend && g >= gq[wave]) {      // wave q finishes column q of this group
       const int q = wave, j = ELLCOL(j0 + q);
       if (jhas[q] && !(invperm && invperm[i] > invperm[j])) {
-        int64_t lo = ADAjc[j], hi = ADAjc[j + 1], e = -1;
+        int64_t lo = 0, hi = 0, e = -1;
+        if (ell_order) e = (int64_t)j * m + i;            // (the full pattern: nothing to look up)
+        else { lo = ADAjc[j]; hi = ADAjc[j + 1]; }
         const int64_t ce = hi;
-        if (ce - lo == m) e = lo + i;                     // full column: no search
+        if (ell_order) {}
+        else if (ce - lo == m) e = lo + i;                // full column: no search
         else {
           while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ADAir[mid] < i) lo = mid + 1; else hi = mid; }
           if (lo < ce && ADAir[lo] == i) e = lo;
@@ -1164,8 +1220,12 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
         if (e >= 0) {
           double a = 0.0;
           for (int w2 = 0; w2 < nw; w2++) a += part[q][w2][lane];
-          ada[e] += a;
-          if (ell_order && g > gq[q]) ada[ADAjc[i] + j] += a;          // (j, i): not computed anywhere else (full columns)
+          // (base_zero: the LP / Lorentz part is the zero matrix the stage-1 launch has just written -- nothing to read; 0.0 + a: the bits of the sum)
+          if (base_zero) ada[e] = 0.0 + a; else ada[e] += a;
+          if (ell_order && g > gq[q]) {                                // (j, i): not computed anywhere else (full columns: it sits at i m + j)
+            const int64_t em = (int64_t)i * m + j;
+            if (base_zero) ada[em] = 0.0 + a; else ada[em] += a;
+          }
         }
       }
     }
@@ -1331,6 +1391,7 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
     SDM_HIP_CHECK(hipGetLastError());
     return;
   }
+  bool stage1_cleared_all = false;                                   // the LP / Lorentz part of the panel is zero and stage 1 has written those zeros
   if (ntask > 0) {
     Stage1Tab T;
     T.t_n = A.t_n.p; T.t_nslot = A.t_nslot.p; T.t_ulen = A.t_ulen.p; T.t_herm = A.t_herm.p; T.s_col = A.s_col.p;
@@ -1348,6 +1409,7 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
 #endif
       double *zp = A.zero_ptr; const long long zn = A.zero_n;         // (taken over from ada_lq: see ada_zero_flush)
       A.zero_ptr = nullptr; A.zero_n = 0;
+      stage1_cleared_all = zp == ada + P->ada_jc[A.col0] && zn == (long long)(P->ada_jc[A.col1] - P->ada_jc[A.col0]);
       SDM_KLAUNCH(P, k_psd_stage1_mfma, dim3((unsigned)ntask), dim3(64 * S1_WAVES), lds, T, A.udsqr.p, A.zbuf.p, task0,
                   (ntask == (int)A.ntask) ? (const int *)A.t_order.p : (const int *)nullptr, zp, zn);
     } else
@@ -1394,7 +1456,8 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
       SDM_KLAUNCH(P, k_psd_stage2_ell<JB>, dim3((ncols + JB - 1) / JB, gsplit), dim3(64 * ELL_WAVES), lds, ada, P->absd.p, A.d_ADAjc.p, A.d_ADAir.p, \
                   A.d_Ajc.p, A.d_Ajc_psd.p, A.d_Apr.p, A.d_Ablk.p, A.d_Aupos.p, A.c_taskptr.p, A.t_blk.p, A.t_ulen.p,    \
                   A.t_zoff.p, A.zbuf.p, A.d_uoff.p, A.g_row.p, A.g_len.p, A.g_off.p, A.g_val.p, A.g_bu.p, A.ell_ng, d_invperm, \
-                  (int)A.zmax, m, jbase, jbase + ncols, A.ell_pos.p, sym ? (const int *)A.ell_order.p : (const int *)nullptr);   \
+                  (int)A.zmax, m, jbase, jbase + ncols, A.ell_pos.p, sym ? (const int *)A.ell_order.p : (const int *)nullptr,     \
+                  A.d_Azpos.p, A.t_zdst.p, stage1_cleared_all && !sym_input ? 1 : 0);                                            \
     } while (0)
 #ifndef SDM_EMU
 #define SDM_STAGE2_ATTR(JB, lds) if ((lds) > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage2_ell<JB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)))

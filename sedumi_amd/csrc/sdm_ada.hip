@@ -254,6 +254,13 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
   { std::vector<int> v((size_t)ADAjc[m]); for (sdm_int t = 0; t < ADAjc[m]; t++) v[t] = (int)ADAir[t]; A.d_ADAir.upload(v); }
   A.d_ADAT.upload(adaT);
   A.u_pos.upload(upos_all);
+  { std::vector<int> urc(upos_all.size(), 0);                        // (r << 16) | c of a real block's target (k_psd_stage1_mfma: no division per target)
+    for (sdm_int k = 0; k < std::min(sdpN, rsdpN); k++) {
+      const int n = (int)A.psd_n[k];
+      if (n >= 65536) continue;
+      for (size_t u = 0; u < U[k].size(); u++) { const int q = U[k][u], c = q / n, r = q - c * n; urc[(size_t)uoff[k] + u] = (r << 16) | c; }
+    }
+    A.u_rc.upload(urc); }
   A.t_col.upload(t_col); A.t_blk.upload(t_blk); A.t_n.upload(t_n); A.t_nslot.upload(t_nslot); A.t_ulen.upload(t_ulen);
   A.t_herm.upload(t_herm);
   A.t_slotptr.upload(t_slotptr); A.t_udoff.upload(t_udoff); A.t_uoff.upload(t_uoff); A.t_zoff.upload(t_zoff);
@@ -500,7 +507,7 @@ __global__ void k_datq(double *qpr, const int64_t *Qjc, const int *Qir, const in
 
 // ---- stage 1: z_jk = (D_k sym(X_jk) D_k)[U_k]    (spscale.c:249-305)
 struct Stage1Tab {
-  const int *t_n, *t_nslot, *t_ulen, *t_herm, *s_col, *u_pos, *Air;
+  const int *t_n, *t_nslot, *t_ulen, *t_herm, *s_col, *u_pos, *u_rc, *Air;
   const int64_t *t_slotptr, *t_udoff, *t_uoff, *t_zoff, *t_end, *s_nzptr;
   const double *Apr;
   const int *t_blk;
@@ -706,7 +713,6 @@ k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0, con
                                                     // (LDS per task = max(2*16*np, np*np) doubles -> several tasks per CU)
   const int64_t slot0 = T.t_slotptr[task], tend = T.t_end[task];
   const double *D = udsqr + T.t_udoff[task];
-  const int *U = T.u_pos + T.t_uoff[task];
   double *z = zbuf + T.t_zoff[task];
   const int64_t rowbase = T.psd_start[T.t_blk[task]];
   const int tid = threadIdx.x, bs = blockDim.x;
@@ -789,10 +795,19 @@ k_psd_stage1_mfma(Stage1Tab T, const double *udsqr, double *zbuf, int task0, con
   }
   __syncthreads();
   SDM_PHASE(5);
-  for (int u = tid; u < ulen; u += bs) {
-    const int q = U[u];
-    const int c = q / n, r = q - c * n;
-    z[u] = (Zl[r * np + c] + Zl[c * np + r]) / 2;
+  // (the targets' (r, c) packed at set-up and eight of them in flight per work-item: one look-up per target behind the other and a division
+  // by the block's order each made this loop 7.6 us of a task's 25 -- in-kernel clocks, profiles/r08x_stage1_mfma_phases.txt)
+  const int *RC = T.u_rc + T.t_uoff[task];
+  for (int u0 = 0; u0 < ulen; u0 += 8 * bs) {
+    int rc[8];
+#pragma unroll
+    for (int x = 0; x < 8; x++) rc[x] = RC[min(u0 + x * bs + tid, ulen - 1)];
+#pragma unroll
+    for (int x = 0; x < 8; x++) {
+      const int u = u0 + x * bs + tid;
+      const int r = rc[x] >> 16, c = rc[x] & 0xffff;
+      if (u < ulen) z[u] = (Zl[r * np + c] + Zl[c * np + r]) / 2;
+    }
   }
   SDM_PHASE(6);
 #if defined(SDM_PHASES) && !defined(SDM_EMU)
@@ -1395,7 +1410,7 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
   if (ntask > 0) {
     Stage1Tab T;
     T.t_n = A.t_n.p; T.t_nslot = A.t_nslot.p; T.t_ulen = A.t_ulen.p; T.t_herm = A.t_herm.p; T.s_col = A.s_col.p;
-    T.u_pos = A.u_pos.p; T.Air = A.d_Air.p; T.t_slotptr = A.t_slotptr.p; T.t_udoff = A.t_udoff.p; T.t_uoff = A.t_uoff.p;
+    T.u_pos = A.u_pos.p; T.u_rc = A.u_rc.p; T.Air = A.d_Air.p; T.t_slotptr = A.t_slotptr.p; T.t_udoff = A.t_udoff.p; T.t_uoff = A.t_uoff.p;
     T.t_zoff = A.t_zoff.p; T.t_end = A.t_end.p; T.s_nzptr = A.s_nzptr.p; T.Apr = A.d_Apr.p; T.t_blk = A.t_blk.p;
     T.psd_start = A.d_psd_start.p;
 #ifndef SDM_EMU

@@ -269,6 +269,7 @@ struct AdaPlan {
   int64_t lq_maxcol = 0, q_maxcol = 0;    // longest column of the LP + Lorentz part of At / of DAt.q (k_ada_spdot: lanes per pattern entry)
   bool one_task_per_col = false;          // every constraint touches at most one PSD block (its z_j is one task's output: stage 2 can ride in that task)
   int s1_maxulen = 0;                     // targets of the largest union pattern
+  DevBuf<int> u_rc;                       // the same targets as (r << 16) | c (real blocks)
   DevBuf<int> u_pos;                      // concatenated target lists U_k (position r + c*n_k [+ n_k^2 for Im])
   DevBuf<int64_t> c_taskptr;              // per constraint: its tasks
   DevBuf<double> zbuf, dsqr, symtmp;

@@ -25,7 +25,9 @@ def _set_reverse(rev):
 @pytest.mark.parametrize("seed,kw", [(0, {}), (1, dict(m=20, lp=0, q=(), s=(6, 3))), (2, dict(m=35, lp=8, q=(4, 3, 5), s=())),
                                      (3, dict(m=40, block_local=True)), (4, dict(m=16, lp=3, q=(3,), s=(9,), dens=0.9)),
                                      (11, dict(m=24, lp=3, q=(3,), s=(4,), hs=(5, 3))),          # Hermitian PSD blocks (spcpxdxd)
-                                     (12, dict(m=30, lp=0, q=(), s=(), hs=(6,), dens=0.5))])
+                                     (12, dict(m=30, lp=0, q=(), s=(), hs=(6,), dens=0.5)),
+                                     # every constraint in 12 / 18 PSD blocks: k_psd_stage2_ell stages z_j from that many segments (one batch / the task-by-task path)
+                                     (13, dict(m=26, lp=2, q=(), s=(3,) * 12, dens=0.9)), (14, dict(m=26, lp=2, q=(), s=(3,) * 18, dens=0.9))])
 def test_iteration_unit_small_mixed_cones(glue, seed, kw):
     from sedumi_amd import problem
     P = problem.random_sdp(seed=seed, **kw)

@@ -38,7 +38,10 @@ def test_golden_reference_examples(name, tag):
                                      (5, dict(m=120, lp=30, q=(6, 9, 3, 4), s=(12, 20, 7), dens=0.15)),
                                      (6, dict(m=200, lp=10, q=(5,), s=(33, 10), dens=0.05, block_local=True)),
                                      (11, dict(m=24, lp=3, q=(3,), s=(4,), hs=(5, 3))),          # Hermitian PSD blocks (spcpxdxd)
-                                     (12, dict(m=150, lp=10, q=(5,), s=(12,), hs=(14, 9), dens=0.2))])
+                                     (12, dict(m=150, lp=10, q=(5,), s=(12,), hs=(14, 9), dens=0.2)),
+                                     # every constraint in 12 / 18 PSD blocks: k_psd_stage2_ell stages z_j from that many segments (one batch / the task-by-task path)
+                                     (13, dict(m=26, lp=2, q=(), s=(3,) * 12, dens=0.9)), (14, dict(m=26, lp=2, q=(), s=(3,) * 18, dens=0.9)),
+                                     (15, dict(m=600, lp=40, q=(), s=(12,) * 9, dens=0.5))])        # two columns per workgroup (m >= 512), 18 segments
 def test_iteration_unit_mixed_cones(glue, seed, kw):
     from sedumi_amd import problem
     P = problem.random_sdp(seed=seed, **kw)

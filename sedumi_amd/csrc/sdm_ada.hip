@@ -224,7 +224,24 @@ void ada_build(sdm_plan *P, sdm_int N, sdm_int m, const sdm_int *Ajc, const sdm_
         A.d_Azpos.upload(zp);
         std::vector<int> zd(t_blk.size());                            // and of a task's block
         for (size_t t = 0; t < t_blk.size(); t++) zd[t] = (int)uoff[t_blk[t]];
-        A.t_zdst.upload(zd); }
+        A.t_zdst.upload(zd);
+        // one record per column for the prologue of k_psd_stage2_ell, indexed by column (cdc*) and by ELL position (cdp*):
+        //   cd64[8 x + ..] = first task, first PSD nonzero, end of the column, source offset in zbuf of its first four tasks
+        //   cd32[16 x + ..] = the column, number of tasks, destination offset in z of the first four, their lengths
+        for (int byp = 0; byp < 2; byp++) {
+          std::vector<long long> c64((size_t)std::max<sdm_int>(m, 1) * 8, 0);
+          std::vector<int> c32((size_t)std::max<sdm_int>(m, 1) * 16, 0);
+          for (sdm_int x = 0; x < m; x++) {
+            const sdm_int j = byp ? order[(size_t)x] : x;
+            const int64_t tb = c_taskptr[j], te = c_taskptr[j + 1];
+            c64[8 * x] = tb; c64[8 * x + 1] = Ajc_psd[j]; c64[8 * x + 2] = Ajc[j + 1];
+            c32[16 * x] = (int)j; c32[16 * x + 1] = (int)(te - tb);
+            for (int sg = 0; sg < 4 && tb + sg < te; sg++) {
+              c64[8 * x + 3 + sg] = t_zoff[(size_t)(tb + sg)]; c32[16 * x + 2 + sg] = zd[(size_t)(tb + sg)]; c32[16 * x + 6 + sg] = t_ulen[(size_t)(tb + sg)];
+            }
+          }
+          if (byp) { A.cdp64.upload(c64); A.cdp32.upload(c32); } else { A.cdc64.upload(c64); A.cdc32.upload(c32); }
+        } }
       A.ell_ok = true;
     }
   }
@@ -1073,7 +1090,7 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
                  const int64_t *c_taskptr, const int *t_blk, const int *t_ulen, const int64_t *t_zoff, const double *zbuf,
                  const int64_t *uoff, const int *g_row, const int *g_len, const int64_t *g_off, const double *g_val,
                  const int *g_pos, int ngroups, const int *invperm, int zmax, int m, int jbase, int jend, const int *ell_pos, const int *ell_order,
-                 const int *Azpos, const int *t_zdst, int base_zero) {
+                 const int *Azpos, const int *t_zdst, int base_zero, const long long *cd64, const int *cd32) {
   // ell_order != null (full ADA' on a full pattern): the workgroup's columns are order[jbase + ...] -- neighbours in the ELL row
   // order -- and only the row groups from its columns' own group on are swept: an entry (i, j) with group(i) > group(j) is
   // computed once, at column j, and added to (j, i) as well (the PSD part is symmetric: <a_i, z_j> = <a_j, z_i>); pairs inside
@@ -1083,56 +1100,67 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
   __shared__ double absred[JB][ELL_WAVES];
   __shared__ double part[JB][ELL_WAVES][64];
   const int j0 = jbase + blockIdx.x * JB;
-#define ELLCOL(x) (ell_order ? ell_order[min((x), jend - 1)] : (x))
   const int tid = threadIdx.x, bs = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = bs >> 6;
   int gq[JB], gstart = 0;                                  // ELL group of each of the workgroup's columns
-  if (ell_order) {
+  if (ell_order) {                                         // (the column at ELL position x sits in group x / 64: nothing to look up)
     gstart = ngroups;
 #pragma unroll
-    for (int q = 0; q < JB; q++) { gq[q] = ell_pos[ELLCOL(j0 + q)] >> 6; gstart = min(gstart, gq[q]); }
+    for (int q = 0; q < JB; q++) { gq[q] = min(j0 + q, jend - 1) >> 6; gstart = min(gstart, gq[q]); }
   } else {
 #pragma unroll
     for (int q = 0; q < JB; q++) gq[q] = 0;
   }
-  // Round 6: the prologue was 44 % of a workgroup's time on control07 (in-kernel clocks, profiles/r08x_stage2_ell_phases.txt: z_j staged task by
-  // task, each behind three dependent look-ups and a copy loop of one load in flight per work-item: 15.7 us; absd 5.7 and the diagonal's base
-  // value 6.6 in ALL workgroups of a column set although one of them owns the diagonal entry).  Now: the (column, task) segments' descriptors in
-  // one round trip (positions precomputed at set-up: t_zdst, Azpos), every segment's entries in flight together, absd in the owner only.
-  constexpr int SEG_MAX = 16;
+  // Round 6 (in-kernel clocks, profiles/r08x_stage2_ell_phases.txt): the prologue was 44 % of a workgroup's 65 us on control07 -- z_j staged
+  // task by task, each behind three dependent look-ups and a copy loop with one load in flight per work-item (15.7 us), absd and the diagonal's
+  // base value in ALL workgroups of a column set although one owns the diagonal (12.3 us) -- and a round trip under this launch's load is 3 - 5
+  // us, so what counts is their NUMBER in front of the first product.  Now two: (1) ONE record per column (cd64 / cd32, built at set-up, indexed
+  // by ELL position on the symmetric path: column, task range, PSD range, up to four (source, destination, length) segments of z_j) and, beside
+  // it, the first row group's header; (2) every segment's entries in flight together.  (The sweep's first eight entries fetched ahead as well, beside
+  // the segments: 35.0 us against 31.5 without -- more registers held across the prologue, nothing hidden.)
+  constexpr int SEG_MAX = 4 * JB;
   __shared__ long long sg_src[SEG_MAX];
   __shared__ int sg_dst[SEG_MAX], sg_cum[SEG_MAX + 1];
   __shared__ long long tb_s[JB], te_s[JB], ab_s[JB], ae_s[JB];
+  __shared__ int jc_s[JB];
   for (int k = tid; k < zmax * JB; k += bs) zl[k] = 0.0;
-  if (tid < JB) {                                                    // (everything a column's index leads to, in the same round trip)
-    const int j = ELLCOL(j0 + tid);
-    const bool in = j0 + tid < jend;
-    tb_s[tid] = in ? c_taskptr[j] : 0; te_s[tid] = in ? c_taskptr[j + 1] : 0;
-    ab_s[tid] = in ? Ajc_psd[j] : 0; ae_s[tid] = in ? Ajc[j + 1] : 0;
+  if (tid < SEG_MAX) {
+    const int q = tid >> 2, sgi = tid & 3;
+    const int x = min(j0 + q, jend - 1);
+    const bool in = j0 + q < jend;
+    const int nt = cd32[16 * x + 1];
+    if (sgi == 0) {
+      jc_s[q] = cd32[16 * x];
+      const long long tb = cd64[8 * x];
+      tb_s[q] = in ? tb : 0; te_s[q] = in ? tb + nt : 0;
+      ab_s[q] = in ? cd64[8 * x + 1] : 0; ae_s[q] = in ? cd64[8 * x + 2] : 0;
+    }
+    const bool live = in && sgi < nt;
+    sg_src[tid] = cd64[8 * x + 3 + sgi]; sg_dst[tid] = q * zmax + cd32[16 * x + 2 + sgi]; sg_cum[tid + 1] = live ? cd32[16 * x + 6 + sgi] : 0;
   }
+  if (tid == 0) sg_cum[0] = 0;
+  // the first row group of this workgroup: its header now (it does not depend on z_j)
+  const int g0 = gstart + (int)blockIdx.y;
+  int i0 = -1, len0 = 0;
+  long long off0 = 0;
+  if (g0 < ngroups) { i0 = g_row[g0 * 64 + lane]; len0 = g_len[g0]; off0 = g_off[g0]; }
   __syncthreads();
+#define ELLCOL(x) (jc_s[(x) - j0 < JB ? (x) - j0 : JB - 1])           /* the workgroup's columns only: from the record */
   bool jhas[JB], own[JB], owns = false;
-  int nseg = 0;
+  bool inl = true;                                                   // every column's segments are in its record
 #pragma unroll
   for (int q = 0; q < JB; q++) {
-    jhas[q] = te_s[q] > tb_s[q]; nseg += (int)(te_s[q] - tb_s[q]);
+    jhas[q] = te_s[q] > tb_s[q];
+    inl = inl && te_s[q] - tb_s[q] <= 4;
     // (the row groups are split over gridDim.y workgroups: the one that owns row j's group is the only writer of entry (j,j) and of absd(j))
-    const int grp = ell_order ? gq[q] : (ell_pos[min(j0 + q, jend - 1)] >> 6);    // (gq[]: already in registers)
+    const int grp = ell_order ? gq[q] : (ell_pos[min(j0 + q, jend - 1)] >> 6);
     own[q] = j0 + q < jend && (int)blockIdx.y == (grp - gstart) % (int)gridDim.y;
     owns = owns || own[q];
   }
-  if (nseg <= SEG_MAX) {
-    if (tid < nseg) {                                                // segment tid = task t of column q: zbuf[zoff ..] -> zl[q*zmax + position of the block ..]
-      int q = 0, r = tid;
-      while (r >= (int)(te_s[q] - tb_s[q])) { r -= (int)(te_s[q] - tb_s[q]); q++; }
-      const int64_t t = tb_s[q] + r;
-      sg_src[tid] = t_zoff[t]; sg_dst[tid] = q * zmax + t_zdst[t]; sg_cum[tid + 1] = t_ulen[t];
-    }
-    if (tid == 0) sg_cum[0] = 0;
+  if (inl) {
+    if (tid == 0) for (int x = 0; x < SEG_MAX; x++) sg_cum[x + 1] += sg_cum[x];
     __syncthreads();
-    if (tid == 0) for (int x = 0; x < nseg; x++) sg_cum[x + 1] += sg_cum[x];
-    __syncthreads();
-    const int ntot = sg_cum[nseg];
+    const int ntot = sg_cum[SEG_MAX];
     for (int base = 0; base < ntot; base += 12 * bs) {               // 12 entries per work-item in flight (two columns of control07: one trip)
       double v[12]; int dd[12];
 #pragma unroll
@@ -1192,11 +1220,13 @@ k_psd_stage2_ell(double *ada, double *absd, const int64_t *ADAjc, const int *ADA
   // Every group of 64 rows is swept by ALL wavefronts: wave w takes the entries t = w, w+nw, ... of the 64 rows (one
   // row per lane), so the longest row costs len/nw dependent memory round trips instead of len; the nw partial
   // sums of a row meet in LDS and are added in wave order (deterministic).
-  for (int g = gstart + blockIdx.y; g < ngroups; g += gridDim.y) {
-    const int i = g_row[g * 64 + lane];
-    const int len = g_len[g];
-    const double *gv = g_val + g_off[g] * 64 + lane;
-    const int *gp = g_pos + g_off[g] * 64 + lane;
+  for (int g = g0; g < ngroups; g += gridDim.y) {
+    const bool first = g == g0;
+    const int i = first ? i0 : g_row[g * 64 + lane];
+    const int len = first ? len0 : g_len[g];
+    const int64_t goff = first ? off0 : g_off[g];
+    const double *gv = g_val + goff * 64 + lane;
+    const int *gp = g_pos + goff * 64 + lane;
     double acc[JB];
 #pragma unroll
     for (int q = 0; q < JB; q++) acc[q] = 0.0;
@@ -1472,7 +1502,8 @@ void ada_psd(sdm_plan *P, double *ada, const int *d_invperm, bool sym_input, boo
                   A.d_Ajc.p, A.d_Ajc_psd.p, A.d_Apr.p, A.d_Ablk.p, A.d_Aupos.p, A.c_taskptr.p, A.t_blk.p, A.t_ulen.p,    \
                   A.t_zoff.p, A.zbuf.p, A.d_uoff.p, A.g_row.p, A.g_len.p, A.g_off.p, A.g_val.p, A.g_bu.p, A.ell_ng, d_invperm, \
                   (int)A.zmax, m, jbase, jbase + ncols, A.ell_pos.p, sym ? (const int *)A.ell_order.p : (const int *)nullptr,     \
-                  A.d_Azpos.p, A.t_zdst.p, stage1_cleared_all && !sym_input ? 1 : 0);                                            \
+                  A.d_Azpos.p, A.t_zdst.p, stage1_cleared_all && !sym_input ? 1 : 0,                                             \
+                  sym ? (const long long *)A.cdp64.p : (const long long *)A.cdc64.p, sym ? (const int *)A.cdp32.p : (const int *)A.cdc32.p); \
     } while (0)
 #ifndef SDM_EMU
 #define SDM_STAGE2_ATTR(JB, lds) if ((lds) > 48 * 1024) SDM_HIP_CHECK(hipFuncSetAttribute((const void *)k_psd_stage2_ell<JB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)))

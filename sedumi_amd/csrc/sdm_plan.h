@@ -302,6 +302,8 @@ struct AdaPlan {
   int64_t zmax = 0, zmaxj = 0;
   DevBuf<int64_t> c_zlen;
   DevBuf<int> g_row, g_len, g_bu;
+  DevBuf<long long> cdc64, cdp64;          // k_psd_stage2_ell: one record per column, by column / by ELL position (sdm_ada.hip, set-up)
+  DevBuf<int> cdc32, cdp32;
   DevBuf<int> d_Azpos, t_zdst;             // k_psd_stage2_ell: position in the full-length z vector of every PSD nonzero / of every task's block
   DevBuf<int> ell_pos;                     // constraint -> position in the ELL row order (its group = pos / 64)
   DevBuf<int> ell_order;                   // position -> constraint
